@@ -1,0 +1,155 @@
+/*
+ * mgl_sw.h -- C ABI of libmgl_sw_hip.so, the MI355X (gfx950) implementation of
+ * mgl's Smith-Waterman affine-gap alignment core.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or framework
+ * types.  Every entry point names the reference interface it stands in for
+ * (paths relative to /root/reference/src/main/native/mgl_sw/).  Results are
+ * bit-exact with the reference CPU path (score, CIGAR, offset, traceback).
+ *
+ * Error convention (the reference has none -- it never checks anything,
+ * SURVEY.md 8b): every function returns an mgl_sw_status; 0 is success.
+ * There is NO CPU fallback inside this library: without a usable HIP device
+ * every compute entry point returns MGL_SW_ERR_DEVICE.
+ *
+ * Threading: like the reference's alignNative (stateless, re-entrant,
+ * ..._MicrosoftSmithWaterman.cpp:44-71) every function may be called from any
+ * thread.  An mgl_sw_ctx serialises the calls made on it; use one ctx per
+ * host thread (or per GPU) for concurrency.  mgl_sw_align() uses a
+ * thread-local ctx.
+ */
+#ifndef MGL_SW_H
+#define MGL_SW_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGL_SW_VERSION 100
+
+/* overhang strategies: sw_common.h:22-25 (= MicrosoftSmithWaterman.java:39-56) */
+#define MGL_SW_OS_SOFTCLIP 0x01
+#define MGL_SW_OS_INDEL 0x02
+#define MGL_SW_OS_LEAD_ID 0x04
+#define MGL_SW_OS_IGNORE 0x08
+
+#define MGL_SW_NEG_INF (-0x40000000) /* sw_common.h:33 */
+
+typedef enum mgl_sw_status {
+    MGL_SW_OK = 0,
+    MGL_SW_ERR_BAD_ARG = 1,        /* null pointer, length < 1, unknown strategy */
+    MGL_SW_ERR_CIGAR_OVERFLOW = 2, /* a CIGAR did not fit; *cigar_len holds the size needed */
+    MGL_SW_ERR_NOMEM = 3,          /* host or device allocation failed */
+    MGL_SW_ERR_DEVICE = 4,         /* no HIP device / HIP runtime error (see mgl_sw_last_error) */
+    MGL_SW_ERR_UNSUPPORTED = 5     /* geometry outside what the kernels cover (see mgl_sw_max_query_len) */
+} mgl_sw_status;
+
+/* ScoreMax, sw_common.h:36-40: best score of the last column (mqe, row mqe_t,
+ * ties -> larger row), best of last column U last row (max, max_t, max_q) and
+ * seg_length = ql - max_q when a last-row cell won. */
+typedef struct mgl_sw_score {
+    int32_t mqe, mqe_t;
+    int32_t max, max_t, max_q;
+    int32_t seg_length;
+} mgl_sw_score;
+
+/* What one kernel pass cost, for bench.py's roofline (HIP events recorded on
+ * the stream the kernels ran on, summed over the chunks of the last call). */
+typedef struct mgl_sw_timing {
+    float dp_ms;        /* sw_dp_kernel (matrix fill + traceback bits)     */
+    float tb_ms;        /* sw_traceback_kernel (path walk + CIGAR text)    */
+    int32_t dp_launches, tb_launches;
+    int64_t cells;      /* sum tl*ql of the last call                      */
+    int64_t tb_bytes;   /* traceback bytes written to HBM by the last call */
+} mgl_sw_timing;
+
+typedef struct mgl_sw_ctx mgl_sw_ctx; /* opaque: one GPU, its workspace and stream */
+
+int mgl_sw_version(void);
+const char *mgl_sw_strerror(int status);
+/* number of HIP devices visible (0 when there is none or no runtime) */
+int mgl_sw_device_count(void);
+/* longest query the kernels of this build accept (LDS-bounded) */
+int mgl_sw_max_query_len(void);
+
+int mgl_sw_ctx_create(int device, mgl_sw_ctx **out);
+void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx);
+/* text of the last HIP / argument error seen on this ctx ("" if none) */
+const char *mgl_sw_last_error(const mgl_sw_ctx *ctx);
+/* cap on the device traceback workspace (bytes); default 4 GiB.  Batches are
+ * processed in chunks that fit. */
+int mgl_sw_ctx_set_workspace(mgl_sw_ctx *ctx, int64_t bytes);
+/* enable per-kernel HIP-event timing (costs a stream sync per call) */
+int mgl_sw_ctx_set_profiling(mgl_sw_ctx *ctx, int enable);
+int mgl_sw_ctx_get_timing(const mgl_sw_ctx *ctx, mgl_sw_timing *out);
+
+/* Sign normalisation of the JNI boundary
+ * (..._MicrosoftSmithWaterman.cpp:51-55): match > 0, mismatch < 0, open > 0,
+ * ext > 0 whatever signs the caller used.  All align entry points apply it. */
+void mgl_sw_normalize_params(int *match, int *mismatch, int *gopen, int *gext);
+
+/*
+ * One pair.  Replaces align_avx (sw_avx.h:6) / align_scalar (sw_scalar.h:9)
+ * and the body of alignNative (..._MicrosoftSmithWaterman.cpp:44-71):
+ * cigar receives *cigar_len ASCII bytes, no terminator (like cigar.copy(),
+ * .cpp:65); *offset is the alignment offset they return; *ez (optional) the
+ * ScoreMax the reference keeps local (sw_avx.cpp:9).
+ */
+int mgl_sw_align(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen,
+                 int gext, int strategy, char *cigar, int cigar_cap, int *cigar_len, int *offset,
+                 mgl_sw_score *ez);
+
+/*
+ * Batch, host buffers.  Pair k is targets[t_off[k] .. t_off[k+1]) against
+ * queries[q_off[k] .. q_off[k+1]) (raw bytes, compared for equality exactly
+ * as sw.cpp:55).  One parameter set and strategy per batch.  cigar_out is
+ * n * cigar_stride bytes; each pair's slot is zero padded (the contract of
+ * the Java side's zero-filled direct buffer, MicrosoftSmithWaterman.java:71-85).
+ * score_out and cigar_len_out may be NULL.
+ */
+int mgl_sw_align_batch(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const int64_t *t_off,
+                       const uint8_t *queries, const int64_t *q_off, int match, int mismatch,
+                       int gopen, int gext, int strategy, int32_t *offset_out,
+                       mgl_sw_score *score_out, char *cigar_out, int cigar_stride,
+                       int32_t *cigar_len_out);
+
+/*
+ * Batch, device-resident: every pointer is a device pointer on ctx's GPU and
+ * the work is enqueued on `stream` (a hipStream_t; NULL = the null stream)
+ * without synchronising -- unless profiling is enabled.  max_tl / max_ql are
+ * upper bounds of the pair lengths (they size the workspace).  status_out
+ * (optional, int32[n]) receives a per-pair mgl_sw_status (0 or
+ * MGL_SW_ERR_CIGAR_OVERFLOW).
+ */
+int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_targets,
+                              const int64_t *d_t_off, const uint8_t *d_queries,
+                              const int64_t *d_q_off, int max_tl, int max_ql, int match,
+                              int mismatch, int gopen, int gext, int strategy,
+                              int32_t *d_offset_out, mgl_sw_score *d_score_out, char *d_cigar_out,
+                              int cigar_stride, int32_t *d_cigar_len_out, int32_t *d_status_out);
+
+/*
+ * Logical backtrack matrix of one pair, the reference's calculateMatrix
+ * (sw_scalar.h:7 / sw.cpp:5-146): btr is (tl+1)*(ql+1) int32 row-major with
+ * row 0 / column 0 zero, +k = k rows up (deletion run), -k = k columns left
+ * (insertion run), 0 = diagonal; *ez as the reference fills it.  Expanded on
+ * the GPU from the 4-bit-per-cell device traceback; a parity / debugging
+ * entry, not a fast path.
+ */
+int mgl_sw_backtrack_matrix(const char *t, int tl, const char *q, int ql, int match, int mismatch,
+                            int gopen, int gext, int strategy, int32_t *btr, mgl_sw_score *ez);
+
+/*
+ * Same expansion for pair `slot` of the LAST chunk a batch call processed on ctx
+ * (slot = pair index when the whole batch fitted one chunk).  The traceback
+ * workspace is only valid until the next call on ctx.  tl / ql must be that
+ * pair's lengths.  Parity / debugging entry.
+ */
+int mgl_sw_ctx_expand_slot(mgl_sw_ctx *ctx, int64_t slot, int tl, int ql, int32_t *btr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGL_SW_H */

@@ -1,0 +1,93 @@
+"""ctypes loader for libmgl_sw_hip.so (the C ABI declared in include/mgl_sw.h).
+
+There is no fallback: if the library is missing it is built in-tree with hipcc, and if that
+fails the import error is raised.  Compute entry points fail with MGL_SW_ERR_DEVICE when no
+GPU is visible.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmgl_sw_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+
+OK, ERR_BAD_ARG, ERR_CIGAR_OVERFLOW, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED = range(6)
+
+# every symbol include/mgl_sw.h declares (tests check that the library exports them all)
+SYMBOLS = (
+    "mgl_sw_version", "mgl_sw_strerror", "mgl_sw_device_count", "mgl_sw_max_query_len", "mgl_sw_ctx_create",
+    "mgl_sw_ctx_destroy", "mgl_sw_last_error", "mgl_sw_ctx_set_workspace", "mgl_sw_ctx_set_profiling",
+    "mgl_sw_ctx_get_timing", "mgl_sw_normalize_params", "mgl_sw_align", "mgl_sw_align_batch",
+    "mgl_sw_align_batch_device", "mgl_sw_backtrack_matrix", "mgl_sw_ctx_expand_slot",
+)
+
+
+class Score(C.Structure):
+    """mgl_sw_score == ScoreMax (sw_common.h:36-40)."""
+    _fields_ = [(n, C.c_int32) for n in ("mqe", "mqe_t", "max", "max_t", "max_q", "seg_length")]
+
+
+class Timing(C.Structure):
+    _fields_ = [("dp_ms", C.c_float), ("tb_ms", C.c_float), ("dp_launches", C.c_int32), ("tb_launches", C.c_int32),
+                ("cells", C.c_int64), ("tb_bytes", C.c_int64)]
+
+
+def _sources_newer():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))]
+    srcs.append(os.path.join(HERE, "..", "include", "mgl_sw.h"))
+    return any(os.path.getmtime(s) > t for s in srcs if os.path.exists(s))
+
+
+def build(force=False):
+    """Compile csrc/ for gfx950 into mgl_amd/libmgl_sw_hip.so (hipcc cross-compiles without a GPU)."""
+    if force or _sources_newer():
+        subprocess.check_call(["make", "-s", "-C", CSRC] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = C.CDLL(LIB_PATH)
+    vp, i32p, i64p, cp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_char_p
+    L.mgl_sw_version.restype = C.c_int
+    L.mgl_sw_strerror.restype = C.c_char_p
+    L.mgl_sw_strerror.argtypes = [C.c_int]
+    L.mgl_sw_device_count.restype = C.c_int
+    L.mgl_sw_max_query_len.restype = C.c_int
+    L.mgl_sw_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.mgl_sw_ctx_destroy.argtypes = [vp]
+    L.mgl_sw_ctx_destroy.restype = None
+    L.mgl_sw_last_error.argtypes = [vp]
+    L.mgl_sw_last_error.restype = C.c_char_p
+    L.mgl_sw_ctx_set_workspace.argtypes = [vp, C.c_int64]
+    L.mgl_sw_ctx_set_profiling.argtypes = [vp, C.c_int]
+    L.mgl_sw_ctx_get_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.mgl_sw_normalize_params.argtypes = [C.POINTER(C.c_int)] * 4
+    L.mgl_sw_normalize_params.restype = None
+    L.mgl_sw_align.argtypes = [cp, C.c_int, cp, C.c_int] + [C.c_int] * 5 + [
+        cp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(Score)]
+    L.mgl_sw_align_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp] + [C.c_int] * 5 + [vp, vp, vp, C.c_int, vp]
+    L.mgl_sw_align_batch_device.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, C.c_int, C.c_int] + [C.c_int] * 5 + [
+        vp, vp, vp, C.c_int, vp, vp]
+    L.mgl_sw_backtrack_matrix.argtypes = [cp, C.c_int, cp, C.c_int] + [C.c_int] * 5 + [i32p, C.POINTER(Score)]
+    L.mgl_sw_ctx_expand_slot.argtypes = [vp, C.c_int64, C.c_int, C.c_int, i32p]
+    _lib = L
+    return L
+
+
+class MglSwError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = lib().mgl_sw_strerror(status).decode()
+        super().__init__(f"mgl_sw status {status} ({msg})" + (f": {detail}" if detail else ""))

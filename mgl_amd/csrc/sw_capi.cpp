@@ -1,0 +1,458 @@
+// sw_capi.cpp -- the C ABI of include/mgl_sw.h over the gfx950 kernels of sw_kernels.hip.
+//
+// Host-side work only: argument checks, the parameter normalisation of the reference's JNI
+// boundary, workspace management, chunking of a batch so that its traceback fits the
+// workspace, and kernel launches.  No alignment arithmetic happens on the CPU and there is
+// no CPU fallback: without a HIP device every compute entry returns MGL_SW_ERR_DEVICE.
+#include "../../include/mgl_sw.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "sw_device.h"
+
+using namespace mgl_sw_dev;
+
+static_assert(sizeof(mgl_sw_score) == sizeof(Score), "mgl_sw_score layout");
+
+namespace {
+
+constexpr int kMaxLdsBytes = 160 * 1024;
+constexpr int64_t kDefaultWorkspace = 4ll << 30;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+} // namespace
+
+struct mgl_sw_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr; // used by the host-buffer entry points
+    int64_t ws_limit = kDefaultWorkspace;
+    DevBuf tb, rec;                                                   // kernel workspace
+    DevBuf d_t, d_toff, d_q, d_qoff, d_off, d_score, d_cig, d_len, d_status, d_btr; // host-API staging
+    int64_t last_stride_words = 0, last_chunk_count = 0; // geometry of the last chunk (for expand_slot)
+    bool profiling = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    mgl_sw_timing timing{};
+    std::string err;
+    std::mutex mu;
+};
+
+namespace {
+
+int fail(mgl_sw_ctx *ctx, int status, const std::string &what)
+{
+    if (ctx) ctx->err = what;
+    return status;
+}
+
+int hip_fail(mgl_sw_ctx *ctx, hipError_t e, const char *where)
+{
+    std::string msg = std::string(where) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return fail(ctx, e == hipErrorOutOfMemory ? MGL_SW_ERR_NOMEM : MGL_SW_ERR_DEVICE, msg);
+}
+
+#define HIP_TRY(ctx, call)                                     \
+    do {                                                       \
+        hipError_t e_ = (call);                                \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
+    } while (0)
+
+bool strategy_ok(int s)
+{
+    return s == MGL_SW_OS_SOFTCLIP || s == MGL_SW_OS_INDEL || s == MGL_SW_OS_LEAD_ID || s == MGL_SW_OS_IGNORE;
+}
+
+// largest waves-per-block whose LDS carve fits; 0 if even one wave does not
+int pick_waves_per_block(int sps_cap)
+{
+    for (int w = 4; w >= 1; w >>= 1)
+        if (dp_lds_bytes(sps_cap, w) <= 64 * 1024) return w;
+    return dp_lds_bytes(sps_cap, 1) <= kMaxLdsBytes ? 1 : 0;
+}
+
+int max_query_len()
+{
+    // largest ql whose one-wave carve fits the 160 KiB LDS
+    int lo = 1, hi = 1 << 20;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) / 2;
+        if (dp_lds_bytes(sps_for(mid), 1) <= kMaxLdsBytes)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
+}
+
+// Enqueue fill + traceback for a device-resident batch on `stream`.
+int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_targets, const int64_t *d_t_off,
+               const uint8_t *d_queries, const int64_t *d_q_off, int max_tl, int max_ql, int match, int mismatch,
+               int gopen, int gext, int strategy, int32_t *d_offset, Score *d_score, char *d_cigar, int cigar_stride,
+               int32_t *d_cigar_len, int32_t *d_status, int64_t cells_hint)
+{
+    if (n == 0) return MGL_SW_OK;
+    if (n < 0 || !d_targets || !d_t_off || !d_queries || !d_q_off || !d_offset || !d_cigar || cigar_stride < 1 ||
+        max_tl < 1 || max_ql < 1 || !strategy_ok(strategy))
+        return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch_device: bad argument");
+    mgl_sw_normalize_params(&match, &mismatch, &gopen, &gext);
+
+    const int sps_cap = sps_for(max_ql);
+    const int wpb = pick_waves_per_block(sps_cap);
+    if (wpb == 0) {
+        char msg[128];
+        snprintf(msg, sizeof msg, "query length %d exceeds the LDS-bounded maximum %d", max_ql, max_query_len());
+        return fail(ctx, MGL_SW_ERR_UNSUPPORTED, msg);
+    }
+    const int64_t stride_words = tb_words_for(max_tl, sps_cap);
+    const int64_t per_pair = stride_words * 4 + (int64_t)sizeof(DpRecord);
+    int64_t chunk = std::max<int64_t>(16, ctx->ws_limit / per_pair);
+    chunk = std::min<int64_t>(chunk, n);
+    chunk = (chunk + 15) / 16 * 16;
+
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, ctx->tb.reserve((size_t)chunk * stride_words * 4));
+    HIP_TRY(ctx, ctx->rec.reserve((size_t)chunk * sizeof(DpRecord)));
+
+    ctx->timing = mgl_sw_timing{};
+    ctx->timing.cells = cells_hint;
+
+    for (int64_t first = 0; first < n; first += chunk) {
+        const int64_t count = std::min(chunk, n - first);
+        DpArgs da;
+        da.targets = d_targets;
+        da.t_off = d_t_off;
+        da.queries = d_queries;
+        da.q_off = d_q_off;
+        da.first = first;
+        da.count = count;
+        da.match = match;
+        da.mismatch = mismatch;
+        da.gopen = gopen;
+        da.gext = gext;
+        da.strategy = strategy;
+        da.sps_cap = sps_cap;
+        da.tb = static_cast<uint32_t *>(ctx->tb.p);
+        da.tb_stride_words = stride_words;
+        da.rec = static_cast<DpRecord *>(ctx->rec.p);
+
+        TbArgs ta;
+        ta.t_off = d_t_off;
+        ta.q_off = d_q_off;
+        ta.first = first;
+        ta.count = count;
+        ta.strategy = strategy;
+        ta.tb = da.tb;
+        ta.tb_stride_words = stride_words;
+        ta.rec = da.rec;
+        ta.offset = d_offset;
+        ta.score = d_score;
+        ta.cigar = d_cigar;
+        ta.cigar_stride = cigar_stride;
+        ta.cigar_len = d_cigar_len;
+        ta.status = d_status;
+
+        if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
+        HIP_TRY(ctx, launch_dp(da, wpb, stream));
+        if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
+        HIP_TRY(ctx, launch_traceback(ta, stream));
+        if (ctx->profiling) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
+            HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2]));
+            float a = 0.f, b = 0.f;
+            HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+            HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
+            ctx->timing.dp_ms += a;
+            ctx->timing.tb_ms += b;
+        }
+        ctx->last_stride_words = stride_words;
+        ctx->last_chunk_count = count;
+        ctx->timing.dp_launches++;
+        ctx->timing.tb_launches++;
+        ctx->timing.tb_bytes += count * stride_words * 4;
+    }
+    return MGL_SW_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int mgl_sw_version(void) { return MGL_SW_VERSION; }
+
+const char *mgl_sw_strerror(int status)
+{
+    switch (status) {
+    case MGL_SW_OK: return "ok";
+    case MGL_SW_ERR_BAD_ARG: return "bad argument";
+    case MGL_SW_ERR_CIGAR_OVERFLOW: return "CIGAR does not fit the caller's buffer";
+    case MGL_SW_ERR_NOMEM: return "out of memory";
+    case MGL_SW_ERR_DEVICE: return "no usable HIP device / HIP runtime error";
+    case MGL_SW_ERR_UNSUPPORTED: return "geometry not supported by this build";
+    default: return "unknown status";
+    }
+}
+
+int mgl_sw_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int mgl_sw_max_query_len(void) { return max_query_len(); }
+
+void mgl_sw_normalize_params(int *match, int *mismatch, int *gopen, int *gext)
+{
+    // ..._MicrosoftSmithWaterman.cpp:51-55
+    if (*match < 0) *match = -*match;
+    if (*mismatch > 0) *mismatch = -*mismatch;
+    if (*gopen < 0) *gopen = -*gopen;
+    if (*gext < 0) *gext = -*gext;
+}
+
+int mgl_sw_ctx_create(int device, mgl_sw_ctx **out)
+{
+    if (!out) return MGL_SW_ERR_BAD_ARG;
+    *out = nullptr;
+    const int ndev = mgl_sw_device_count();
+    if (ndev <= 0 || device < 0 || device >= ndev) return MGL_SW_ERR_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return MGL_SW_ERR_DEVICE;
+    mgl_sw_ctx *ctx = new (std::nothrow) mgl_sw_ctx;
+    if (!ctx) return MGL_SW_ERR_NOMEM;
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return MGL_SW_ERR_DEVICE;
+    }
+    for (auto &e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            mgl_sw_ctx_destroy(ctx);
+            return MGL_SW_ERR_DEVICE;
+        }
+    *out = ctx;
+    return MGL_SW_OK;
+}
+
+void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf *b : {&ctx->tb, &ctx->rec, &ctx->d_t, &ctx->d_toff, &ctx->d_q, &ctx->d_qoff, &ctx->d_off, &ctx->d_score,
+                      &ctx->d_cig, &ctx->d_len, &ctx->d_status, &ctx->d_btr})
+        b->release();
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *mgl_sw_last_error(const mgl_sw_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int mgl_sw_ctx_set_workspace(mgl_sw_ctx *ctx, int64_t bytes)
+{
+    if (!ctx || bytes < (1 << 20)) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->ws_limit = bytes;
+    return MGL_SW_OK;
+}
+
+int mgl_sw_ctx_set_profiling(mgl_sw_ctx *ctx, int enable)
+{
+    if (!ctx) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->profiling = enable != 0;
+    return MGL_SW_OK;
+}
+
+int mgl_sw_ctx_get_timing(const mgl_sw_ctx *ctx, mgl_sw_timing *out)
+{
+    if (!ctx || !out) return MGL_SW_ERR_BAD_ARG;
+    *out = ctx->timing;
+    return MGL_SW_OK;
+}
+
+int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_targets,
+                              const int64_t *d_t_off, const uint8_t *d_queries, const int64_t *d_q_off, int max_tl,
+                              int max_ql, int match, int mismatch, int gopen, int gext, int strategy,
+                              int32_t *d_offset_out, mgl_sw_score *d_score_out, char *d_cigar_out, int cigar_stride,
+                              int32_t *d_cigar_len_out, int32_t *d_status_out)
+{
+    if (!ctx) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return run_device(ctx, static_cast<hipStream_t>(stream), n, d_targets, d_t_off, d_queries, d_q_off, max_tl, max_ql,
+                      match, mismatch, gopen, gext, strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out),
+                      d_cigar_out, cigar_stride, d_cigar_len_out, d_status_out, 0);
+}
+
+int mgl_sw_align_batch(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const int64_t *t_off,
+                       const uint8_t *queries, const int64_t *q_off, int match, int mismatch, int gopen, int gext,
+                       int strategy, int32_t *offset_out, mgl_sw_score *score_out, char *cigar_out, int cigar_stride,
+                       int32_t *cigar_len_out)
+{
+    if (!ctx) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (n == 0) return MGL_SW_OK;
+    if (n < 0 || !targets || !t_off || !queries || !q_off || !offset_out || !cigar_out || cigar_stride < 1 ||
+        !strategy_ok(strategy))
+        return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: bad argument");
+    int max_tl = 0, max_ql = 0;
+    int64_t cells = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t tl = t_off[k + 1] - t_off[k], ql = q_off[k + 1] - q_off[k];
+        // the reference reads out of bounds for empty sequences (sw.cpp:162-163,184): rejected here
+        if (tl < 1 || ql < 1 || tl > 0x3fffffff || ql > 0x3fffffff)
+            return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: sequence length < 1 or too large");
+        max_tl = std::max<int>(max_tl, (int)tl);
+        max_ql = std::max<int>(max_ql, (int)ql);
+        cells += tl * ql;
+    }
+    const size_t t_bytes = (size_t)(t_off[n] - t_off[0]), q_bytes = (size_t)(q_off[n] - q_off[0]);
+    if (t_off[0] != 0 || q_off[0] != 0)
+        return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: offsets must start at 0");
+
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, ctx->d_t.reserve(t_bytes));
+    HIP_TRY(ctx, ctx->d_q.reserve(q_bytes));
+    HIP_TRY(ctx, ctx->d_toff.reserve((size_t)(n + 1) * 8));
+    HIP_TRY(ctx, ctx->d_qoff.reserve((size_t)(n + 1) * 8));
+    HIP_TRY(ctx, ctx->d_off.reserve((size_t)n * 4));
+    HIP_TRY(ctx, ctx->d_score.reserve((size_t)n * sizeof(Score)));
+    HIP_TRY(ctx, ctx->d_cig.reserve((size_t)n * cigar_stride));
+    HIP_TRY(ctx, ctx->d_len.reserve((size_t)n * 4));
+    HIP_TRY(ctx, ctx->d_status.reserve((size_t)n * 4));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_t.p, targets, t_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q.p, queries, q_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_toff.p, t_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_qoff.p, q_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+
+    int rc = run_device(ctx, st, n, static_cast<const uint8_t *>(ctx->d_t.p), static_cast<const int64_t *>(ctx->d_toff.p),
+                        static_cast<const uint8_t *>(ctx->d_q.p), static_cast<const int64_t *>(ctx->d_qoff.p), max_tl,
+                        max_ql, match, mismatch, gopen, gext, strategy, static_cast<int32_t *>(ctx->d_off.p),
+                        static_cast<Score *>(ctx->d_score.p), static_cast<char *>(ctx->d_cig.p), cigar_stride,
+                        static_cast<int32_t *>(ctx->d_len.p), static_cast<int32_t *>(ctx->d_status.p), cells);
+    if (rc != MGL_SW_OK) return rc;
+
+    std::vector<int32_t> status((size_t)n);
+    HIP_TRY(ctx, hipMemcpyAsync(offset_out, ctx->d_off.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (score_out)
+        HIP_TRY(ctx, hipMemcpyAsync(score_out, ctx->d_score.p, (size_t)n * sizeof(Score), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(cigar_out, ctx->d_cig.p, (size_t)n * cigar_stride, hipMemcpyDeviceToHost, st));
+    if (cigar_len_out)
+        HIP_TRY(ctx, hipMemcpyAsync(cigar_len_out, ctx->d_len.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(status.data(), ctx->d_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int64_t k = 0; k < n; ++k)
+        if (status[(size_t)k] != 0) return fail(ctx, status[(size_t)k], "a CIGAR did not fit cigar_stride");
+    return MGL_SW_OK;
+}
+
+static mgl_sw_ctx *thread_ctx(int *rc)
+{
+    struct Holder {
+        mgl_sw_ctx *ctx = nullptr;
+        ~Holder() { mgl_sw_ctx_destroy(ctx); }
+    };
+    static thread_local Holder h;
+    if (!h.ctx) {
+        int dev = 0;
+        if (const char *e = getenv("MGL_SW_DEVICE")) dev = atoi(e);
+        *rc = mgl_sw_ctx_create(dev, &h.ctx);
+        if (*rc != MGL_SW_OK) return nullptr;
+        h.ctx->ws_limit = 256ll << 20;
+    }
+    *rc = MGL_SW_OK;
+    return h.ctx;
+}
+
+int mgl_sw_align(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen, int gext,
+                 int strategy, char *cigar, int cigar_cap, int *cigar_len, int *offset, mgl_sw_score *ez)
+{
+    if (!t || !q || tl < 1 || ql < 1 || !cigar || cigar_cap < 1 || !cigar_len || !offset || !strategy_ok(strategy))
+        return MGL_SW_ERR_BAD_ARG;
+    int rc;
+    mgl_sw_ctx *ctx = thread_ctx(&rc);
+    if (!ctx) return rc;
+    const int64_t t_off[2] = {0, tl}, q_off[2] = {0, ql};
+    int32_t off = 0, len = 0;
+    mgl_sw_score sc;
+    std::vector<char> buf((size_t)cigar_cap);
+    rc = mgl_sw_align_batch(ctx, 1, reinterpret_cast<const uint8_t *>(t), t_off, reinterpret_cast<const uint8_t *>(q),
+                            q_off, match, mismatch, gopen, gext, strategy, &off, &sc, buf.data(), cigar_cap, &len);
+    *cigar_len = len;
+    if (rc != MGL_SW_OK) return rc;
+    memcpy(cigar, buf.data(), (size_t)len); // exactly cigar.length() bytes, no terminator (.cpp:65)
+    *offset = off;
+    if (ez) *ez = sc;
+    return MGL_SW_OK;
+}
+
+int mgl_sw_ctx_expand_slot(mgl_sw_ctx *ctx, int64_t slot, int tl, int ql, int32_t *btr)
+{
+    if (!ctx || !btr || tl < 1 || ql < 1 || (int64_t)tl * ql > (1ll << 30)) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (slot < 0 || slot >= ctx->last_chunk_count)
+        return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_ctx_expand_slot: slot outside the last chunk");
+    const size_t cells = (size_t)(tl + 1) * (ql + 1);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, ctx->d_btr.reserve(cells * 4));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_btr.p, 0, cells * 4, ctx->stream));
+    HIP_TRY(ctx, launch_expand(static_cast<const uint32_t *>(ctx->tb.p) + slot * ctx->last_stride_words,
+                               static_cast<const DpRecord *>(ctx->rec.p) + slot, tl, ql,
+                               static_cast<int32_t *>(ctx->d_btr.p), ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(btr, ctx->d_btr.p, cells * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MGL_SW_OK;
+}
+
+int mgl_sw_backtrack_matrix(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen,
+                            int gext, int strategy, int32_t *btr, mgl_sw_score *ez)
+{
+    if (!t || !q || tl < 1 || ql < 1 || !btr || !strategy_ok(strategy) || (int64_t)tl * ql > (1ll << 30))
+        return MGL_SW_ERR_BAD_ARG;
+    int rc;
+    mgl_sw_ctx *ctx = thread_ctx(&rc);
+    if (!ctx) return rc;
+    // fill + traceback of the single pair leaves its 4-bit cells in slot 0 of the workspace
+    std::vector<char> cig((size_t)(tl + ql + 4) * 12);
+    int len = 0, off = 0;
+    mgl_sw_score sc;
+    rc = mgl_sw_align(t, tl, q, ql, match, mismatch, gopen, gext, strategy, cig.data(), (int)cig.size(), &len, &off, &sc);
+    if (rc != MGL_SW_OK) return rc;
+    rc = mgl_sw_ctx_expand_slot(ctx, 0, tl, ql, btr);
+    if (rc == MGL_SW_OK && ez) *ez = sc;
+    return rc;
+}
+
+} // extern "C"

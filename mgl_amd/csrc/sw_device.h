@@ -1,0 +1,70 @@
+// sw_device.h -- types shared by the kernels (sw_kernels.hip) and the C-ABI host layer (sw_capi.cpp).
+#ifndef MGL_SW_DEVICE_H
+#define MGL_SW_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mgl_sw_dev {
+
+constexpr int NEG_INF = -0x40000000; // sw_common.h:33
+constexpr int OS_SOFTCLIP = 1, OS_INDEL = 2, OS_LEAD_ID = 4, OS_IGNORE = 8; // sw_common.h:22-25
+constexpr int ERR_CIGAR_OVERFLOW = 2; // == MGL_SW_ERR_CIGAR_OVERFLOW
+
+// ScoreMax (sw_common.h:36-40); layout == mgl_sw_score
+struct Score {
+    int32_t mqe, mqe_t, max, max_t, max_q, seg_length;
+};
+
+// what the fill kernel hands to the traceback kernel, one per pair (workspace)
+struct DpRecord {
+    int32_t mqe, mqe_t, max, max_t, max_q, seg;
+    int32_t h_end; // H[tl][ql]
+    int32_t sps;   // anti-diagonal steps per stripe used by the wave that filled this pair
+};
+
+struct DpArgs {
+    const uint8_t *targets;
+    const int64_t *t_off;
+    const uint8_t *queries;
+    const int64_t *q_off;
+    int64_t first; // pairs [first, first + count) of the batch
+    int64_t count;
+    int match, mismatch, gopen, gext, strategy;
+    int sps_cap;             // upper bound of steps per stripe (sizes the LDS carve)
+    uint32_t *tb;            // traceback words, count * tb_stride_words
+    int64_t tb_stride_words; // per pair
+    DpRecord *rec;           // count records
+};
+
+struct TbArgs {
+    const int64_t *t_off;
+    const int64_t *q_off;
+    int64_t first, count;
+    int strategy;
+    const uint32_t *tb;
+    int64_t tb_stride_words;
+    const DpRecord *rec;
+    int32_t *offset; // indexed by batch pair index
+    Score *score;    // optional
+    char *cigar;
+    int cigar_stride;
+    int32_t *cigar_len; // optional
+    int32_t *status;    // optional
+};
+
+// geometry helpers (host and device agree on these)
+__host__ __device__ inline int sps_for(int ql) { return (ql + 16 + 3) & ~3; }
+__host__ __device__ inline int stripes_for(int tl) { return (tl + 15) >> 4; }
+__host__ __device__ inline int64_t tb_words_for(int tl, int sps)
+{
+    return (((int64_t)stripes_for(tl) * sps + 31) >> 5) * 64;
+}
+
+int dp_lds_bytes(int sps_cap, int waves_per_block);
+hipError_t launch_dp(const DpArgs &a, int waves_per_block, hipStream_t stream);
+hipError_t launch_traceback(const TbArgs &a, hipStream_t stream);
+hipError_t launch_expand(const uint32_t *tbw, const DpRecord *rec, int tl, int ql, int32_t *btr, hipStream_t stream);
+
+} // namespace mgl_sw_dev
+#endif

@@ -1,0 +1,529 @@
+// sw_kernels.hip -- gfx950 (MI355X / CDNA4) kernels for mgl's Smith-Waterman affine-gap core.
+//
+// Written for wave64 CDNA4 only; there is no other backend.
+//
+// What is computed (the function defined by the reference's sw.cpp:5-255, which its AVX2
+// path sw_avx.cpp:110-322 reproduces cell for cell; paths relative to
+// /root/reference/src/main/native/mgl_sw/):
+//
+//   diag = H[i-1][j-1] + (t[i-1]==q[j-1] ? match : mismatch)                 sw.cpp:55
+//   H[i][j] = diag if diag>=E && diag>=F, else F if F>=E, else E             sw.cpp:60-71
+//   E[i+1][j] = max(H-o, E-e)  (extension wins ties)                         sw.cpp:73-82
+//   F[i][j+1] = max(H-o, F-e)  (extension wins ties)                         sw.cpp:84-93
+//   no zero floor; maxima over last column / last row only                   sw.cpp:100-127
+//
+// Mapping onto the machine
+// ------------------------
+// * One pair per 16-lane DPP row ("group"), four pairs per wave64.  Lane L of a group owns
+//   one target row of a 16-row stripe; a step advances every lane one query column along an
+//   anti-diagonal (lane L is at column j = s - L), the AVX2 path's scheme (sw_avx.cpp:11,
+//   71-80) widened from 8 to 16 rows.  16 rather than 64 rows per stripe keeps the
+//   pipeline fill/drain at 15 steps per ql+16 (91 % lane use at ql = 150; 64 rows would
+//   give 70 %), and `row_shr:1` DPP moves H and E to the next row with no LDS traffic.
+// * The stripe carry (H and E of a stripe's last row, per column: the reference's
+//   score[]/step[] arrays, sw_avx.cpp:36-47) lives in an LDS ring per group; the lane that
+//   owns the stripe's last row (lane 15, or lane (tl-1)%16 in a partial final stripe -- the
+//   reference's actual_bw, sw_avx.cpp:74,196) writes column j when it gets there, lane 0 of
+//   the next stripe reads it at step j.  Rows past tl in the final stripe compute garbage
+//   that only ever flows to higher (also padding) lanes, as in sw_avx.cpp:154-156.
+// * The query is staged in LDS as four byte-shifted copies so that every lane fetches the
+//   four bases of a 4-step block with one aligned ds_read_b32.
+// * Traceback: 4 bits per cell {F>diag, E>max(diag,F), E opened, F opened} instead of the
+//   reference's int32 run lengths (equivalent: a run length is 1 + the number of
+//   consecutive "extended" decisions behind the cell, sw.cpp:73-93).  Each lane shifts the
+//   sign bits of four differences into four 32-step accumulators (v_alignbit) and stores
+//   16 bytes every 32 steps, so a group's stores are 256 contiguous bytes.
+// * A second kernel walks the path (one pair per lane) and writes offset, ScoreMax and the
+//   CIGAR text.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sw_device.h"
+
+namespace mgl_sw_dev {
+
+constexpr int DPP_ROW_SHR1 = 0x111;
+constexpr int RING_SLACK = 20, QCOPY_SLACK = 32;
+
+__device__ __forceinline__ int row_shr1(int lane0_value, int src)
+{
+    // lanes 1..15 of each 16-lane row take src from the lane below; lane 0 keeps lane0_value
+    return __builtin_amdgcn_update_dpp(lane0_value, src, DPP_ROW_SHR1, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ unsigned shift_in_sign(unsigned acc, int d)
+{
+    // (acc << 1) | (d < 0)
+    return __builtin_amdgcn_alignbit(acc, (unsigned)d, 31);
+}
+
+__device__ __forceinline__ int border(int k, int gopen, int gext, bool indel)
+{
+    // H on row 0 / column 0: sw.cpp:29-40,47-49
+    return (indel && k > 0) ? -gopen - (k - 1) * gext : 0;
+}
+
+struct LaneState {
+    int h_prev, e_prev; // this lane's H and E' of the previous step (shifted to lane+1 next step)
+    int hup;            // H[i-1][j] as of the previous step == H[i-1][j-1] for this step
+    int f;              // F entering this step
+    unsigned a0, a1, a2, a3; // traceback bit planes
+    int best, best_i;   // running last-column maximum of this lane's rows (ties: later row)
+};
+
+// One block of four anti-diagonal steps.
+//   PRO   : some lane may still be at column <= 0 (forced border values)
+//   EPI   : some lane may be at its last column (capture H[i][ql])
+// ringA / ringB hold the carry of columns s0, s0+1 / s0+2, s0+3; they are reloaded for the
+// next block as soon as their last use is behind (no register rotation at the loop edge).
+template <bool PRO, bool EPI>
+__device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, const int4 *ring_next,
+                                      const unsigned qw, const int tb, const int s0, const int L, const int hb,
+                                      const int qcap, const int row_i, const int match, const int mismatch,
+                                      const int gopen, const int gext, int2 *ring_wr, const bool writer)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int rh = u == 0 ? ringA.x : u == 1 ? ringA.z : u == 2 ? ringB.x : ringB.z;
+        const int re = u == 0 ? ringA.y : u == 1 ? ringA.w : u == 2 ? ringB.y : ringB.w;
+        if (u == 2) ringA = ring_next[0];
+        const int hup_new = row_shr1(rh, st.h_prev);
+        const int ein = row_shr1(re, st.e_prev);
+        const int qb = (int)((qw >> (8 * u)) & 0xffu);
+        const int diag = st.hup + (qb == tb ? match : mismatch);
+        const int d1 = diag - st.f; // < 0 <=> F > diag
+        const int sm = max(diag, st.f);
+        const int d2 = sm - ein; // < 0 <=> E > max(diag, F)
+        int h = max(sm, ein);
+        const int open_from = h - gopen;
+        const int ee = ein - gext;
+        const int d3 = ee - open_from; // < 0 <=> a new vertical gap beats extending
+        int eo = max(open_from, ee);
+        const int fe = st.f - gext;
+        const int d4 = fe - open_from; // < 0 <=> a new horizontal gap beats extending
+        int fo = max(open_from, fe);
+        if (PRO) {
+            const bool at_border = (s0 + u) <= L; // column j = s - L <= 0
+            h = at_border ? hb : h;
+            fo = at_border ? hb - gopen : fo;
+        }
+        st.a0 = shift_in_sign(st.a0, d1);
+        st.a1 = shift_in_sign(st.a1, d2);
+        st.a2 = shift_in_sign(st.a2, d3);
+        st.a3 = shift_in_sign(st.a3, d4);
+        if (EPI) {
+            const bool last_col = (s0 + u - L) == qcap;
+            const bool take = last_col && h >= st.best; // sw.cpp:100-104 (>=: later row wins)
+            st.best = take ? h : st.best;
+            st.best_i = take ? row_i : st.best_i;
+        }
+        if (writer) ring_wr[u] = make_int2(h, eo);
+        st.h_prev = h;
+        st.e_prev = eo;
+        st.hup = hup_new;
+        st.f = fo;
+    }
+    ringB = ring_next[1];
+}
+
+__global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int grp = lane >> 4;
+    const int L = lane & 15;
+    const int64_t slot = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 4 + grp;
+    // a wave with no pair at all leaves; in a partly filled wave the idle groups recompute the
+    // last pair (same wave => same geometry) but never store anything
+    if (slot - grp >= a.count) return;
+    const bool valid = slot < a.count;
+    const int64_t p = a.first + (valid ? slot : a.count - 1);
+
+    const int64_t t0 = a.t_off[p], q0 = a.q_off[p];
+    const int tl = (int)(a.t_off[p + 1] - t0);
+    const int ql = (int)(a.q_off[p + 1] - q0);
+    const uint8_t *tseq = a.targets + t0;
+    const uint8_t *qseq = a.queries + q0;
+
+    const int nstripes = stripes_for(tl);
+
+    // wave-uniform loop bounds over the four groups
+    int ql_max = ql, ql_min = ql, ns_max = nstripes;
+#pragma unroll
+    for (int m = 16; m < 64; m <<= 1) {
+        ql_max = max(ql_max, __shfl_xor(ql_max, m));
+        ql_min = min(ql_min, __shfl_xor(ql_min, m));
+        ns_max = max(ns_max, __shfl_xor(ns_max, m));
+    }
+    ql_max = __builtin_amdgcn_readfirstlane(ql_max);
+    ql_min = __builtin_amdgcn_readfirstlane(ql_min);
+    ns_max = __builtin_amdgcn_readfirstlane(ns_max);
+    const int sps = sps_for(ql_max);                             // steps per stripe
+    const int main_end = max(16, ql_min & ~3);                   // [16, main_end): no border, no last column
+
+    // LDS carve: per group  ring[sps_cap+20] int2 | 4 x qcopy[sps_cap+32] bytes
+    // (the slack covers columns -16..-1 and the one-block-ahead prefetches)
+    const int ring_entries = a.sps_cap + RING_SLACK;
+    const int qcopy_bytes = a.sps_cap + QCOPY_SLACK;
+    const int group_bytes = ring_entries * 8 + 4 * qcopy_bytes;
+    unsigned char *gbase = smem + (size_t)(wave * 4 + grp) * group_bytes;
+    int2 *ring = reinterpret_cast<int2 *>(gbase); // ring[j + 16] holds column j
+    unsigned char *qcopy = gbase + ring_entries * 8;
+
+    // match / mismatch feed a v_cndmask every step: pin them in VGPRs (two SGPR sources
+    // would be re-materialised into VGPRs each step)
+    int match = a.match, mismatch = a.mismatch;
+    asm volatile("" : "+v"(match), "+v"(mismatch));
+    const int gopen = a.gopen, gext = a.gext;
+    const bool indel = (a.strategy & (OS_INDEL | OS_LEAD_ID)) != 0;
+
+    // ---- stage the query: copy k holds q shifted right by 16 + k bytes, zero elsewhere
+    {
+        unsigned *qz = reinterpret_cast<unsigned *>(qcopy);
+        for (int w = L; w < qcopy_bytes; w += 16) qz[w] = 0u; // 4 * qcopy_bytes bytes == qcopy_bytes dwords
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int x = L; x < ql; x += 16) {
+            const unsigned char c = qseq[x];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) qcopy[k * qcopy_bytes + x + 16 + k] = c;
+        }
+        // ---- border row into the ring: H[0][j], E[1][j] = H[0][j] - o   (sw.cpp:14-18,31-35)
+        for (int j = L; j <= ql_max; j += 16) {
+            const int hb0 = border(j, gopen, gext, indel);
+            ring[j + 16] = make_int2(hb0, hb0 - gopen);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    LaneState st;
+    st.h_prev = st.e_prev = st.hup = st.f = 0;
+    st.a0 = st.a1 = st.a2 = st.a3 = 0u;
+    st.best = NEG_INF;
+    st.best_i = -1;
+
+    const int last_lane = (tl - 1) & 15; // owner of row tl in the final stripe
+    const int qk = (L + 1) & 3, qm = (L + 1) >> 2;
+    const unsigned *qrd0 = reinterpret_cast<const unsigned *>(qcopy + qk * qcopy_bytes) + (4 - qm);
+
+    uint32_t *tbp = a.tb + (size_t)(valid ? slot : a.count - 1) * a.tb_stride_words + L * 4;
+    int gsteps = 0; // wave-uniform global step counter (traceback bit position)
+
+    int row_next = 1 + L; // row of this lane in stripe 0
+    int tb_next = (row_next >= 1 && row_next <= tl) ? (int)tseq[row_next - 1] : 0;
+
+    for (int k = 0; k < ns_max; ++k) {
+        const int row_i = row_next;
+        const int tb = tb_next;
+        row_next += 16;
+        tb_next = (row_next >= 1 && row_next <= tl) ? (int)tseq[row_next - 1] : 0;
+
+        const int hb = border(row_i, gopen, gext, indel);
+        const int qcap = row_i <= tl ? ql : NEG_INF; // s - L >= -15 never equals NEG_INF
+        // the lane owning this stripe's last row publishes the carry (sw_avx.cpp:196-197)
+        const int wl = (k == nstripes - 1) ? last_lane : 15;
+        const bool writer = (L == wl);
+
+        const int4 *ring_rd = reinterpret_cast<const int4 *>(ring + 16);
+        int2 *ring_wr = ring + 16 - wl; // at step s the writer is at column s - wl
+        const unsigned *qrd = qrd0;
+        int4 rA = ring_rd[0], rB = ring_rd[1];
+        unsigned qw = qrd[0];
+
+        int s = 0;
+#define MGL_SW_BLOCK(PRO, EPI)                                                                             \
+    {                                                                                                      \
+        const unsigned nq = qrd[1];                                                                        \
+        step4<PRO, EPI>(st, rA, rB, ring_rd + 2, qw, tb, s, L, hb, qcap, row_i, match, mismatch, gopen,    \
+                        gext, ring_wr, writer);                                                            \
+        qw = nq;                                                                                           \
+        ring_rd += 2;                                                                                      \
+        ring_wr += 4;                                                                                      \
+        qrd += 1;                                                                                          \
+        s += 4;                                                                                            \
+        gsteps += 4;                                                                                       \
+        if ((gsteps & 31) == 0) {                                                                          \
+            if (valid) *reinterpret_cast<uint4 *>(tbp) = make_uint4(st.a0, st.a1, st.a2, st.a3);          \
+            tbp += 64;                                                                                     \
+        }                                                                                                  \
+    }
+        for (; s < 16;) MGL_SW_BLOCK(true, true)
+        for (; s < main_end;) MGL_SW_BLOCK(false, false)
+        for (; s < sps;) MGL_SW_BLOCK(false, true)
+#undef MGL_SW_BLOCK
+
+        if (k == nstripes - 1) {
+            // ---- this group's matrix is complete: last column max, last row scan (sw.cpp:100-127)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int mqe = st.best, mqe_t = st.best_i;
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                const int ob = __shfl_xor(mqe, m), oi = __shfl_xor(mqe_t, m);
+                const bool take = ob > mqe || (ob == mqe && oi > mqe_t);
+                mqe = take ? ob : mqe;
+                mqe_t = take ? oi : mqe_t;
+            }
+            // last row: best score, then closest to the diagonal, then smallest column
+            int rm = NEG_INF, rd = 0x7fffffff, rj = 0x7fffffff;
+            for (int j = L + 1; j <= ql; j += 16) {
+                const int sc = ring[j + 16].x;
+                const int d = abs(tl - j);
+                const bool take = sc > rm || (sc == rm && d < rd);
+                rm = take ? sc : rm;
+                rd = take ? d : rd;
+                rj = take ? j : rj;
+            }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                const int om = __shfl_xor(rm, m), od = __shfl_xor(rd, m), oj = __shfl_xor(rj, m);
+                const bool take = om > rm || (om == rm && (od < rd || (od == rd && oj < rj)));
+                rm = take ? om : rm;
+                rd = take ? od : rd;
+                rj = take ? oj : rj;
+            }
+            // sequential rule of sw.cpp:116-127 starting from (mqe, mqe_t, ql)
+            const bool row_wins = rm > mqe || (rm == mqe && rd < abs(mqe_t - ql));
+            if (L == 0 && valid) {
+                DpRecord r;
+                r.mqe = mqe;
+                r.mqe_t = mqe_t;
+                r.max = row_wins ? rm : mqe;
+                r.max_t = row_wins ? tl : mqe_t;
+                r.max_q = row_wins ? rj : ql;
+                r.seg = row_wins ? ql - rj : 0;
+                r.h_end = ring[ql + 16].x;
+                r.sps = sps;
+                a.rec[slot] = r;
+            }
+        }
+    }
+    // flush the partial traceback block, left-aligned like the full ones
+    const int rem = gsteps & 31;
+    if (rem && valid) {
+        const int sh = 32 - rem;
+        *reinterpret_cast<uint4 *>(tbp) = make_uint4(st.a0 << sh, st.a1 << sh, st.a2 << sh, st.a3 << sh);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// traceback bits accessor shared by the path walk and the matrix expansion
+struct TbView {
+    const uint32_t *base; // this pair's traceback words
+    int sps;
+    // nibble of cell (i, j), 1-based: bit0 F>diag, bit1 E>max(diag,F), bit2 E opened, bit3 F opened
+    __device__ __forceinline__ unsigned cell(int i, int j) const
+    {
+        const int r = i - 1;
+        const int lane = r & 15;
+        const int g = (r >> 4) * sps + j + lane;
+        const uint4 w = *reinterpret_cast<const uint4 *>(base + (size_t)(g >> 5) * 64 + lane * 4);
+        const int sh = 31 - (g & 31);
+        return ((w.x >> sh) & 1u) | (((w.y >> sh) & 1u) << 1) | (((w.z >> sh) & 1u) << 2) |
+               (((w.w >> sh) & 1u) << 3);
+    }
+    // run length of a vertical gap entered at (i, j): 1 + consecutive extensions above (sw.cpp:73-82)
+    __device__ __forceinline__ int vrun(int i, int j) const
+    {
+        int n = 1;
+        for (int r = i - 1; r >= 1 && !(cell(r, j) & 4u); --r) ++n;
+        return n;
+    }
+    // run length of a horizontal gap entered at (i, j) (sw.cpp:84-93)
+    __device__ __forceinline__ int hrun(int i, int j) const
+    {
+        int n = 1;
+        for (int c = j - 1; c >= 1 && !(cell(i, c) & 8u); --c) ++n;
+        return n;
+    }
+};
+
+struct CigarWriter {
+    char *slot;
+    int cap, pos, need;
+    // elements arrive last-first (the reference push_front()s, sw.cpp:172-248); text is built
+    // right-aligned and moved to the front at the end.  Zero lengths are skipped (sw.cpp:252).
+    __device__ __forceinline__ void push_front(char op, int len)
+    {
+        if (len <= 0) return;
+        int digits = 1;
+        for (int v = len; v >= 10; v /= 10) ++digits;
+        need += digits + 1;
+        if (pos - (digits + 1) < 0) {
+            pos = -1;
+            return;
+        }
+        slot[--pos] = op;
+        for (int v = len, d = 0; d < digits; ++d, v /= 10) slot[--pos] = (char)('0' + v % 10);
+    }
+};
+
+__global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
+{
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.count) return;
+    const int64_t p = a.first + slot;
+    const int tl = (int)(a.t_off[p + 1] - a.t_off[p]);
+    const int ql = (int)(a.q_off[p + 1] - a.q_off[p]);
+    const DpRecord r = a.rec[slot];
+
+    TbView tb;
+    tb.base = a.tb + (size_t)slot * a.tb_stride_words;
+    tb.sps = r.sps;
+
+    // start cell, sw.cpp:155-170
+    int I, J, seg = 0;
+    if (a.strategy == OS_INDEL) {
+        I = tl;
+        J = ql;
+    } else if (a.strategy != OS_LEAD_ID) {
+        I = r.max_t;
+        J = r.max_q;
+        seg = r.seg;
+    } else {
+        I = r.mqe_t;
+        J = ql;
+    }
+
+    CigarWriter cw;
+    cw.slot = a.cigar + (size_t)p * a.cigar_stride;
+    cw.cap = a.cigar_stride;
+    cw.pos = a.cigar_stride;
+    cw.need = 0;
+
+    if (seg > 0 && a.strategy == OS_SOFTCLIP) { // sw.cpp:173-176
+        cw.push_front('S', seg);
+        seg = 0;
+    }
+    char state = 'M';
+    do { // sw.cpp:182-214
+        const unsigned c = tb.cell(I, J);
+        char next;
+        int step = 1;
+        if (c & 2u) {
+            next = 'D';
+            step = tb.vrun(I, J);
+            I -= step;
+        } else if (c & 1u) {
+            next = 'I';
+            step = tb.hrun(I, J);
+            J -= step;
+        } else {
+            next = 'M';
+            --I;
+            --J;
+        }
+        if (next == state) {
+            seg += step;
+        } else {
+            cw.push_front(state, seg);
+            seg = step;
+            state = next;
+        }
+    } while (I > 0 && J > 0);
+
+    int off;
+    if (a.strategy == OS_SOFTCLIP) { // sw.cpp:225-229
+        cw.push_front(state, seg);
+        if (J > 0) cw.push_front('S', J);
+        off = I;
+    } else if (a.strategy == OS_IGNORE) { // sw.cpp:230-233
+        cw.push_front(state, seg + J);
+        off = I - J;
+    } else { // sw.cpp:234-248
+        cw.push_front(state, seg);
+        if (I > 0)
+            cw.push_front('D', I);
+        else if (J > 0)
+            cw.push_front('I', J);
+        off = 0;
+    }
+
+    int status = 0;
+    if (cw.pos < 0) {
+        status = ERR_CIGAR_OVERFLOW;
+        for (int k = 0; k < cw.cap; ++k) cw.slot[k] = 0;
+    } else {
+        const int len = cw.cap - cw.pos;
+        if (cw.pos > 0)
+            for (int k = 0; k < len; ++k) cw.slot[k] = cw.slot[cw.pos + k];
+        for (int k = len; k < cw.cap; ++k) cw.slot[k] = 0;
+    }
+    a.offset[p] = off;
+    if (a.cigar_len) a.cigar_len[p] = cw.need;
+    if (a.status) a.status[p] = status;
+    if (a.score) {
+        Score sc;
+        sc.mqe = r.mqe;
+        sc.mqe_t = r.mqe_t;
+        sc.max = r.max;
+        sc.max_t = r.max_t;
+        sc.max_q = r.max_q;
+        sc.seg_length = r.seg;
+        a.score[p] = sc;
+    }
+}
+
+// Logical backtrack matrix of ONE pair (slot 0 of the workspace): the int32 run lengths the
+// reference stores (sw.cpp:62,66,70), rebuilt from the 4-bit cells.
+__global__ __launch_bounds__(256) void sw_expand_kernel(const uint32_t *tbw, const DpRecord *rec, int tl, int ql,
+                                                        int32_t *btr)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= tl * ql) return;
+    const int i = idx / ql + 1, j = idx % ql + 1;
+    TbView tb;
+    tb.base = tbw;
+    tb.sps = rec[0].sps;
+    const unsigned c = tb.cell(i, j);
+    int v = 0;
+    if (c & 2u)
+        v = tb.vrun(i, j);
+    else if (c & 1u)
+        v = -tb.hrun(i, j);
+    btr[(size_t)i * (ql + 1) + j] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch wrappers (called from sw_capi.cpp)
+
+int dp_lds_bytes(int sps_cap, int waves_per_block)
+{
+    return waves_per_block * 4 * ((sps_cap + RING_SLACK) * 8 + 4 * (sps_cap + QCOPY_SLACK));
+}
+
+hipError_t launch_dp(const DpArgs &a, int waves_per_block, hipStream_t stream)
+{
+    const int per_block = waves_per_block * 4;
+    const int64_t blocks = (a.count + per_block - 1) / per_block;
+    const int lds = dp_lds_bytes(a.sps_cap, waves_per_block);
+    static int configured_lds = 0;
+    if (lds > 64 * 1024 && lds > configured_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_dp_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        configured_lds = lds;
+    }
+    hipLaunchKernelGGL(sw_dp_kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_traceback(const TbArgs &a, hipStream_t stream)
+{
+    const int64_t blocks = (a.count + 255) / 256;
+    hipLaunchKernelGGL(sw_traceback_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand(const uint32_t *tbw, const DpRecord *rec, int tl, int ql, int32_t *btr, hipStream_t stream)
+{
+    const int64_t n = (int64_t)tl * ql;
+    hipLaunchKernelGGL(sw_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tbw, rec, tl, ql,
+                       btr);
+    return hipGetLastError();
+}
+
+} // namespace mgl_sw_dev

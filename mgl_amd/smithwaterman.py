@@ -1,0 +1,192 @@
+"""Host-side mirror of the reference's Smith-Waterman operator interface, over the C ABI.
+
+The reference's entry point is ``MicrosoftSmithWaterman.align(ref, alt, parameters,
+overhangStrategy) -> SWNativeAlignerResult(cigar, alignment_offset)``
+(src/main/java/com/microsoft/mgl/smithwaterman/MicrosoftSmithWaterman.java:66-86) on top of
+``align_avx`` / ``align_scalar`` (src/main/native/mgl_sw/sw_avx.h:6, sw_scalar.h:9).  The
+names, argument meaning and the (cigar, offset) result are kept; a batch form is added because
+one pair per launch cannot feed a GPU.  All arithmetic happens in libmgl_sw_hip.so.
+"""
+import ctypes as C
+from collections import namedtuple
+from enum import IntEnum
+
+import numpy as np
+
+from . import _lib
+
+
+class SWOverhangStrategy(IntEnum):
+    """org.broadinstitute.gatk.nativebindings SWOverhangStrategy -> sw_common.h:22-25 codes
+    (the mapping of MicrosoftSmithWaterman.java:39-56)."""
+    SOFTCLIP = 0x01
+    INDEL = 0x02
+    LEADING_INDEL = 0x04
+    IGNORE = 0x08
+
+
+SWParameters = namedtuple("SWParameters", "match mismatch gap_open gap_extend")
+SWParameters.__doc__ = "swParameters (sw_common.h:42-47); any sign convention, normalised natively"
+
+# GATK's NEW_SW_PARAMETERS, the set the reference is exercised with
+GATK_PARAMETERS = SWParameters(200, -150, -260, -11)
+
+SWNativeAlignerResult = namedtuple("SWNativeAlignerResult", "cigar alignment_offset")
+ScoreMax = namedtuple("ScoreMax", "mqe mqe_t max max_t max_q seg_length")
+
+BatchResult = namedtuple("BatchResult", "offsets scores cigars cigar_len")
+
+
+def _check(rc, ctx=None):
+    if rc != _lib.OK:
+        detail = _lib.lib().mgl_sw_last_error(ctx).decode() if ctx else ""
+        raise _lib.MglSwError(rc, detail)
+
+
+def concat(seqs):
+    """list of bytes -> (uint8 array, int64 offsets[n+1])"""
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    if seqs:
+        np.cumsum([len(s) for s in seqs], out=off[1:])
+    data = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+    return data, off
+
+
+class MicrosoftSmithWaterman:
+    """Drop-in for the reference's SWAlignerNativeBinding implementation.
+
+    ``load()`` / ``align()`` / ``close()`` follow MicrosoftSmithWaterman.java:35,66,89.
+    One instance owns one GPU context; instances may be used from different threads.
+    """
+
+    def __init__(self, device=0):
+        self._device = device
+        self._ctx = None
+
+    # -- SWAlignerNativeBinding ------------------------------------------------------------
+    def load(self, temp_dir=None):
+        """True when the native library is present and a GPU context could be made
+        (the reference returns False when the library cannot be used, .java:27-37)."""
+        try:
+            self._ensure()
+            return True
+        except (OSError, _lib.MglSwError):
+            return False
+
+    def align(self, ref, alt, parameters=GATK_PARAMETERS, overhang_strategy=SWOverhangStrategy.SOFTCLIP):
+        ref, alt = bytes(ref), bytes(alt)
+        # the Java side allocates 2*max(refLength, altLength) CIGAR bytes (.java:71)
+        cap = max(16, 2 * max(len(ref), len(alt)))
+        res = self.align_batch([ref], [alt], parameters, overhang_strategy, cigar_stride=cap)
+        return SWNativeAlignerResult(res.cigars[0], int(res.offsets[0]))
+
+    def close(self):
+        if self._ctx is not None:
+            _lib.lib().mgl_sw_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    # -- batch form ------------------------------------------------------------------------
+    def align_batch(self, refs, alts, parameters=GATK_PARAMETERS, overhang_strategy=SWOverhangStrategy.SOFTCLIP,
+                    cigar_stride=None):
+        """Align refs[k] against alts[k] for every k; returns BatchResult with numpy arrays."""
+        td, toff = concat([bytes(x) for x in refs])
+        qd, qoff = concat([bytes(x) for x in alts])
+        return self.align_packed(td, toff, qd, qoff, parameters, overhang_strategy, cigar_stride)
+
+    def align_packed(self, targets, t_off, queries, q_off, parameters=GATK_PARAMETERS,
+                     overhang_strategy=SWOverhangStrategy.SOFTCLIP, cigar_stride=None):
+        """Concatenated-bytes form of align_batch (what mgl_sw_align_batch takes)."""
+        ctx = self._ensure()
+        n = len(t_off) - 1
+        assert len(q_off) - 1 == n
+        targets = np.ascontiguousarray(targets, dtype=np.uint8)
+        queries = np.ascontiguousarray(queries, dtype=np.uint8)
+        t_off = np.ascontiguousarray(t_off, dtype=np.int64)
+        q_off = np.ascontiguousarray(q_off, dtype=np.int64)
+        if cigar_stride is None:
+            longest = int(max(np.diff(t_off).max(initial=1), np.diff(q_off).max(initial=1)))
+            cigar_stride = max(16, 2 * longest)
+        off = np.zeros(n, np.int32)
+        sc = np.zeros((n, 6), np.int32)
+        cg = np.zeros(n * cigar_stride, np.uint8)
+        ln = np.zeros(n, np.int32)
+        p = SWParameters(*parameters)
+        rc = _lib.lib().mgl_sw_align_batch(ctx, n, targets.ctypes.data, t_off.ctypes.data, queries.ctypes.data,
+                                           q_off.ctypes.data, p.match, p.mismatch, p.gap_open, p.gap_extend,
+                                           int(overhang_strategy), off.ctypes.data, sc.ctypes.data, cg.ctypes.data,
+                                           cigar_stride, ln.ctypes.data)
+        _check(rc, ctx)
+        cg2 = cg.reshape(n, cigar_stride) if n else cg.reshape(0, cigar_stride)
+        cigars = [cg2[k, : ln[k]].tobytes().decode() for k in range(n)]
+        return BatchResult(off, sc, cigars, ln)
+
+    def expand_slot(self, slot, tl, ql):
+        """Logical backtrack matrix of pair ``slot`` of the last chunk of the last batch call."""
+        btr = np.zeros((tl + 1, ql + 1), dtype=np.int32)
+        _check(_lib.lib().mgl_sw_ctx_expand_slot(self._ensure(), slot, tl, ql,
+                                                 btr.ctypes.data_as(C.POINTER(C.c_int32))), self._ctx)
+        return btr
+
+    # -- extras the reference keeps internal -----------------------------------------------
+    def set_workspace(self, nbytes):
+        _check(_lib.lib().mgl_sw_ctx_set_workspace(self._ensure(), int(nbytes)))
+
+    def set_profiling(self, on=True):
+        _check(_lib.lib().mgl_sw_ctx_set_profiling(self._ensure(), int(bool(on))))
+
+    def timing(self):
+        t = _lib.Timing()
+        _check(_lib.lib().mgl_sw_ctx_get_timing(self._ensure(), C.byref(t)))
+        return t
+
+    @property
+    def ctx(self):
+        return self._ensure()
+
+    def _ensure(self):
+        if self._ctx is None:
+            h = C.c_void_p()
+            _check(_lib.lib().mgl_sw_ctx_create(self._device, C.byref(h)))
+            self._ctx = h
+        return self._ctx
+
+    def __enter__(self):
+        self._ensure()
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def align(ref, alt, parameters=GATK_PARAMETERS, overhang_strategy=SWOverhangStrategy.SOFTCLIP):
+    """One pair through mgl_sw_align (thread-local context), returning (cigar, offset, ScoreMax)."""
+    ref, alt = bytes(ref), bytes(alt)
+    L = _lib.lib()
+    cap = 12 * (len(ref) + len(alt) + 4)
+    buf = C.create_string_buffer(cap)
+    ln, off, ez = C.c_int(), C.c_int(), _lib.Score()
+    p = SWParameters(*parameters)
+    rc = L.mgl_sw_align(ref, len(ref), alt, len(alt), p.match, p.mismatch, p.gap_open, p.gap_extend,
+                        int(overhang_strategy), buf, cap, C.byref(ln), C.byref(off), C.byref(ez))
+    _check(rc)
+    return buf.raw[: ln.value].decode(), off.value, ScoreMax(ez.mqe, ez.mqe_t, ez.max, ez.max_t, ez.max_q,
+                                                            ez.seg_length)
+
+
+def backtrack_matrix(ref, alt, parameters=GATK_PARAMETERS, overhang_strategy=SWOverhangStrategy.SOFTCLIP):
+    """The reference's logical backtrack matrix (calculateMatrix, sw.cpp:5-146) rebuilt on the GPU."""
+    ref, alt = bytes(ref), bytes(alt)
+    btr = np.zeros((len(ref) + 1, len(alt) + 1), dtype=np.int32)
+    ez = _lib.Score()
+    p = SWParameters(*parameters)
+    rc = _lib.lib().mgl_sw_backtrack_matrix(ref, len(ref), alt, len(alt), p.match, p.mismatch, p.gap_open,
+                                            p.gap_extend, int(overhang_strategy),
+                                            btr.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ez))
+    _check(rc)
+    return btr, ScoreMax(ez.mqe, ez.mqe_t, ez.max, ez.max_t, ez.max_q, ez.seg_length)
