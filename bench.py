@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- GCUPS of the MI355X Smith-Waterman path on BASELINE.json's configs[1].
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (fill kernel + traceback kernel, every pair to offset,
+ScoreMax and CIGAR text) over one batch of synthetic input that is already resident in HBM:
+by default 10 M Illumina-style 150 bp reads, each against its own 256-base reference window
+(BASELINE.json configs[1], SURVEY.md 8d "Config 2"), GATK parameters, SOFTCLIP, full matrix.
+Every rank processes its own 10 M pairs (weak scaling, no data-path collective); with N > 1 the
+step ends with the RCCL gather of the int32 scores onto rank 0 (north_star).
+
+Rank 0 prints ONE JSON line.  `value` = whole-job GCUPS = sum(tl*ql) over all ranks and steps /
+max-over-ranks wall time.  `roofline` prices the dominant kernel (sw_dp_kernel) against HBM
+bandwidth with the algorithmic bytes of DESIGN.md; `cpu_baseline` is the reference's own AVX2
+path (oracle/_ref, built from /root/reference in the authoring container) timed on this host's
+cores on a bounded sample of the same batch and cross-checked against the GPU results.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mgl_amd import device_batch, dist  # noqa: E402
+from mgl_amd.smithwaterman import GATK_PARAMETERS, MicrosoftSmithWaterman, SWOverhangStrategy  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+
+def algorithmic_bytes_per_pair(tl, ql):
+    """DESIGN.md "algorithmic bytes": what sw_dp_kernel must move per pair whatever the schedule:
+    the two sequences as shipped (ASCII, like the reference's ByteBuffer), two int64 offsets each
+    (amortised 16 B), the 4-bit-per-cell traceback spilled to HBM, and the 32-byte fill record."""
+    return tl + ql + 16 + (tl * ql) // 2 + 32
+
+
+def host_cores():
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota
+    (the GPU box exposes 256 logical CPUs but grants a 16-CPU quota per GPU)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def pmc_traffic_per_pair(tl, ql):
+    """HBM bytes per pair of sw_dp_kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json: WRITE_SIZE + 2 x FETCH_SIZE, the gfx950 correction of
+    MI355X_MICROARCH.md), or None when no pass was taken for this geometry."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        for r in rec["sw_dp_kernel"]:
+            if (r["tl"], r["ql"]) == (tl, ql):
+                return r["hbm_bytes_per_pair"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
+def cpu_baseline(batch, target_seconds=15.0, max_pairs=4_000_000):
+    """Time the reference's CPU path on this host; returns the cpu_baseline JSON object."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+
+    cores = host_cores()
+    tl, ql = batch.max_tl, batch.max_ql
+    m, x, o, e = GATK_PARAMETERS
+    stride = batch.cigar_stride
+
+    def fetch(n):
+        t = batch.targets[: n * tl].cpu().numpy()
+        q = batch.queries[: n * ql].cpu().numpy()
+        toff = np.arange(n + 1, dtype=np.int64) * tl
+        qoff = np.arange(n + 1, dtype=np.int64) * ql
+        return t, toff, q, qoff
+
+    use_ref = ol.have_ref()
+    if use_ref:
+        lib = ol.ref()
+        kind = "reference"
+        label = "mgl align_avx (AVX2) via oracle/_ref" if lib.ref_has_avx2() else "mgl align_scalar via oracle/_ref"
+    else:
+        lib = ol.oracle()
+        kind = "port"
+        label = "oracle/sw_oracle.c scalar restatement"
+
+    def run(n):
+        t, toff, q, qoff = fetch(n)
+        off = np.zeros(n, np.int32)
+        cg = np.zeros(n * stride, np.uint8)
+        ln = np.zeros(n, np.int32)
+        t0 = time.perf_counter()
+        if use_ref:
+            rc = lib.ref_align_batch(n, t.ctypes.data, toff.ctypes.data, q.ctypes.data, qoff.ctypes.data, m, x, o, e,
+                                     int(SWOverhangStrategy.SOFTCLIP), 1, cores, off.ctypes.data, cg.ctypes.data,
+                                     stride, ln.ctypes.data)
+        else:
+            rc = lib.swo_align_batch(n, t.ctypes.data, toff.ctypes.data, q.ctypes.data, qoff.ctypes.data, m, x, o, e,
+                                     int(SWOverhangStrategy.SOFTCLIP), cores, off.ctypes.data, None, cg.ctypes.data,
+                                     stride, ln.ctypes.data)
+        dt = time.perf_counter() - t0
+        assert rc == 0, rc
+        return dt, off, cg.reshape(n, stride), ln
+
+    probe = min(batch.n, 20_000)
+    dt, *_ = run(probe)
+    n = int(min(batch.n, max_pairs, max(probe, probe * target_seconds / max(dt, 1e-6))))
+    dt, off, cg, ln = run(n)
+    # cross-check the CPU answers against what the GPU wrote for the same pairs
+    g_off = batch.offsets[:n].cpu().numpy()
+    g_cg = batch.cigars[:n].cpu().numpy()
+    mism = int((g_off != off).sum() + (g_cg != cg).any(axis=1).sum())
+    return {
+        "value": round(n * tl * ql / dt / 1e9, 3), "unit": "GCUPS", "cores": cores, "kind": kind,
+        "sample": f"first {n} pairs of the same batch ({tl}x{ql}), {label}, {cores} threads, {dt:.1f} s",
+        "reads_per_s": round(n / dt, 1), "mismatches_vs_gpu": mism,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=10_000_000, help="pairs per GPU per step")
+    ap.add_argument("--tl", type=int, default=256, help="reference window length")
+    ap.add_argument("--ql", type=int, default=150, help="read length")
+    ap.add_argument("--workspace-gib", type=float, default=8.0, help="traceback workspace per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline leg")
+    ap.add_argument("--seed", type=int, default=42)
+    args = ap.parse_args()
+
+    rank, local_rank, world = dist.init()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    aligner = MicrosoftSmithWaterman(local_rank)
+    aligner.set_workspace(int(args.workspace_gib * (1 << 30)))
+    batch = device_batch.window_batch(args.seed + rank, args.pairs, dev, window=args.tl, read_len=args.ql)
+    cells = args.pairs * args.tl * args.ql
+    n_total = args.pairs * world
+
+    def step():
+        batch.run(aligner, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP)
+        if world > 1:
+            # the only inter-GPU exchange: ScoreMax.max of every pair onto rank 0
+            return dist.gather_scores(batch.scores[:, 2].contiguous(), n_total, dst=0)
+        return batch.scores[:, 2]
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0, dev)
+
+    status_bad = int((batch.status != 0).sum().item())
+
+    # --- untimed pass with per-kernel HIP events (on the stream the kernels run on) for the roofline
+    aligner.set_profiling(True)
+    batch.run(aligner, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP)
+    torch.cuda.synchronize(dev)
+    tm = aligner.timing()
+    aligner.set_profiling(False)
+
+    if rank != 0:
+        return
+    total_cells = cells * world * args.steps
+    per_pair = algorithmic_bytes_per_pair(args.tl, args.ql)
+    dp_s = tm.dp_ms / 1e3
+    achieved = args.pairs * per_pair / dp_s / 1e9
+    pairs_per_launch = args.pairs / max(1, tm.dp_launches)
+    tpp = pmc_traffic_per_pair(args.tl, args.ql)
+    traffic = None if tpp is None else round(tpp * pairs_per_launch)  # HBM bytes per launch (PMC)
+    out = {
+        "metric": "GCUPS (+ aligned reads/s) for 150 bp short-read batch",
+        "value": round(total_cells / elapsed / 1e9, 2),
+        "unit": "GCUPS",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE.json configs[1]: {args.pairs} Illumina-style {args.ql} bp reads x {args.tl}-base "
+                        f"reference windows per GPU, affine-gap SW, full matrix, GATK params (200,-150,260,11), "
+                        f"SOFTCLIP, scores+offset+CIGAR for every pair",
+            "pairs_per_gpu": args.pairs, "target_len": args.tl, "query_len": args.ql,
+            "parallelism": f"pairs sharded over {world} GPU(s), score gather only" if world > 1 else "1 GPU",
+        },
+        "reads_per_s": round(args.pairs * world * args.steps / elapsed, 1),
+        "kernel_ms": {"sw_dp_kernel": round(tm.dp_ms, 3), "sw_traceback_kernel": round(tm.tb_ms, 3),
+                      "launches_each": tm.dp_launches},
+        "cigar_overflows": status_bad,
+        "roofline": {
+            "bound": "hbm", "kernel": "sw_dp_kernel",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": traffic,
+            "algorithmic_bytes_per_pair": per_pair,
+            "pairs_per_launch": round(pairs_per_launch, 1),
+            "avg_launch_ms": round(tm.dp_ms / max(1, tm.dp_launches), 4),
+            "kernel_gcups": round(cells / dp_s / 1e9, 2),
+            "note": "integer DP: the kernel is VALU-issue bound, the HBM fraction is small by construction",
+        },
+    }
+    if world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(batch)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

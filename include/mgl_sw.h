@@ -142,6 +142,14 @@ int mgl_sw_backtrack_matrix(const char *t, int tl, const char *q, int ql, int ma
                             int gopen, int gext, int strategy, int32_t *btr, mgl_sw_score *ez);
 
 /*
+ * Traceback + CIGAR text from a caller-supplied logical backtrack matrix and
+ * ScoreMax: the reference's calculateCigar (sw_scalar.h:8 / sw.cpp:149-255) with
+ * n = tl+1, m = ql+1.  The walk runs on the GPU (one lane).
+ */
+int mgl_sw_cigar_from_backtrack(const int32_t *btr, int tl, int ql, int strategy, const mgl_sw_score *ez,
+                                char *cigar, int cigar_cap, int *cigar_len, int *offset);
+
+/*
  * Same expansion for pair `slot` of the LAST chunk a batch call processed on ctx
  * (slot = pair index when the whole batch fitted one chunk).  The traceback
  * workspace is only valid until the next call on ctx.  tl / ql must be that

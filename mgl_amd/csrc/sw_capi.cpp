@@ -436,6 +436,44 @@ int mgl_sw_ctx_expand_slot(mgl_sw_ctx *ctx, int64_t slot, int tl, int ql, int32_
     return MGL_SW_OK;
 }
 
+int mgl_sw_cigar_from_backtrack(const int32_t *btr, int tl, int ql, int strategy, const mgl_sw_score *ez, char *cigar,
+                                int cigar_cap, int *cigar_len, int *offset)
+{
+    if (!btr || tl < 1 || ql < 1 || !ez || !cigar || cigar_cap < 1 || !cigar_len || !offset || !strategy_ok(strategy) ||
+        (int64_t)tl * ql > (1ll << 30))
+        return MGL_SW_ERR_BAD_ARG;
+    // the walk starts at a cell named by *ez: reject anything outside the matrix (the reference would read wild)
+    const bool from_ez = strategy == MGL_SW_OS_SOFTCLIP || strategy == MGL_SW_OS_IGNORE;
+    if (from_ez && (ez->max_t < 1 || ez->max_t > tl || ez->max_q < 1 || ez->max_q > ql || ez->seg_length < 0))
+        return MGL_SW_ERR_BAD_ARG;
+    if (strategy == MGL_SW_OS_LEAD_ID && (ez->mqe_t < 1 || ez->mqe_t > tl)) return MGL_SW_ERR_BAD_ARG;
+    int rc;
+    mgl_sw_ctx *ctx = thread_ctx(&rc);
+    if (!ctx) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const size_t cells = (size_t)(tl + 1) * (ql + 1);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, ctx->d_btr.reserve(cells * 4));
+    HIP_TRY(ctx, ctx->d_cig.reserve((size_t)cigar_cap));
+    HIP_TRY(ctx, ctx->d_status.reserve(16));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_btr.p, btr, cells * 4, hipMemcpyHostToDevice, ctx->stream));
+    Score sc;
+    memcpy(&sc, ez, sizeof sc);
+    HIP_TRY(ctx, launch_cigar_from_matrix(static_cast<const int32_t *>(ctx->d_btr.p), tl, ql, strategy, sc,
+                                          static_cast<char *>(ctx->d_cig.p), cigar_cap,
+                                          static_cast<int32_t *>(ctx->d_status.p), ctx->stream));
+    int32_t out3[3] = {0, 0, 0};
+    std::vector<char> buf((size_t)cigar_cap);
+    HIP_TRY(ctx, hipMemcpyAsync(out3, ctx->d_status.p, sizeof out3, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(buf.data(), ctx->d_cig.p, (size_t)cigar_cap, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *cigar_len = out3[1];
+    if (out3[2] != 0) return fail(ctx, out3[2], "CIGAR does not fit cigar_cap");
+    memcpy(cigar, buf.data(), (size_t)out3[1]);
+    *offset = out3[0];
+    return MGL_SW_OK;
+}
+
 int mgl_sw_backtrack_matrix(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen,
                             int gext, int strategy, int32_t *btr, mgl_sw_score *ez)
 {

@@ -64,6 +64,8 @@ __host__ __device__ inline int64_t tb_words_for(int tl, int sps)
 int dp_lds_bytes(int sps_cap, int waves_per_block);
 hipError_t launch_dp(const DpArgs &a, int waves_per_block, hipStream_t stream);
 hipError_t launch_traceback(const TbArgs &a, hipStream_t stream);
+hipError_t launch_cigar_from_matrix(const int32_t *btr, int tl, int ql, int strategy, const Score &ez, char *cigar,
+                                    int cap, int32_t *out3, hipStream_t stream);
 hipError_t launch_expand(const uint32_t *tbw, const DpRecord *rec, int tl, int ql, int32_t *btr, hipStream_t stream);
 
 } // namespace mgl_sw_dev

@@ -361,55 +361,59 @@ struct CigarWriter {
     }
 };
 
-__global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
-{
-    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= a.count) return;
-    const int64_t p = a.first + slot;
-    const int tl = (int)(a.t_off[p + 1] - a.t_off[p]);
-    const int ql = (int)(a.q_off[p + 1] - a.q_off[p]);
-    const DpRecord r = a.rec[slot];
-
+// Sources of one traceback move: the 4-bit device cells, or a reference-style int32 matrix.
+struct BitsMoves {
     TbView tb;
-    tb.base = a.tb + (size_t)slot * a.tb_stride_words;
-    tb.sps = r.sps;
+    // returns +k (k rows up), -k (k columns left) or 0 (diagonal): the value the reference stores
+    __device__ __forceinline__ int at(int i, int j) const
+    {
+        const unsigned c = tb.cell(i, j);
+        if (c & 2u) return tb.vrun(i, j);
+        if (c & 1u) return -tb.hrun(i, j);
+        return 0;
+    }
+};
+struct MatrixMoves {
+    const int32_t *btr;
+    int m; // ql + 1
+    __device__ __forceinline__ int at(int i, int j) const { return btr[(size_t)i * m + j]; }
+};
 
+// calculateCigar (sw.cpp:149-255): walk from the strategy's start cell, merge equal states,
+// post-process the overhangs, emit text.  Returns the alignment offset.
+template <typename Moves>
+__device__ __forceinline__ int walk_and_write(const Moves &mv, int tl, int ql, int strategy, int max_t, int max_q,
+                                              int mqe_t, int seg_length, CigarWriter &cw)
+{
     // start cell, sw.cpp:155-170
     int I, J, seg = 0;
-    if (a.strategy == OS_INDEL) {
+    if (strategy == OS_INDEL) {
         I = tl;
         J = ql;
-    } else if (a.strategy != OS_LEAD_ID) {
-        I = r.max_t;
-        J = r.max_q;
-        seg = r.seg;
+    } else if (strategy != OS_LEAD_ID) {
+        I = max_t;
+        J = max_q;
+        seg = seg_length;
     } else {
-        I = r.mqe_t;
+        I = mqe_t;
         J = ql;
     }
-
-    CigarWriter cw;
-    cw.slot = a.cigar + (size_t)p * a.cigar_stride;
-    cw.cap = a.cigar_stride;
-    cw.pos = a.cigar_stride;
-    cw.need = 0;
-
-    if (seg > 0 && a.strategy == OS_SOFTCLIP) { // sw.cpp:173-176
+    if (seg > 0 && strategy == OS_SOFTCLIP) { // sw.cpp:173-176
         cw.push_front('S', seg);
         seg = 0;
     }
     char state = 'M';
     do { // sw.cpp:182-214
-        const unsigned c = tb.cell(I, J);
+        const int b = mv.at(I, J);
         char next;
         int step = 1;
-        if (c & 2u) {
+        if (b > 0) {
             next = 'D';
-            step = tb.vrun(I, J);
+            step = b;
             I -= step;
-        } else if (c & 1u) {
+        } else if (b < 0) {
             next = 'I';
-            step = tb.hrun(I, J);
+            step = -b;
             J -= step;
         } else {
             next = 'M';
@@ -426,11 +430,11 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
     } while (I > 0 && J > 0);
 
     int off;
-    if (a.strategy == OS_SOFTCLIP) { // sw.cpp:225-229
+    if (strategy == OS_SOFTCLIP) { // sw.cpp:225-229
         cw.push_front(state, seg);
         if (J > 0) cw.push_front('S', J);
         off = I;
-    } else if (a.strategy == OS_IGNORE) { // sw.cpp:230-233
+    } else if (strategy == OS_IGNORE) { // sw.cpp:230-233
         cw.push_front(state, seg + J);
         off = I - J;
     } else { // sw.cpp:234-248
@@ -441,17 +445,45 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
             cw.push_front('I', J);
         off = 0;
     }
+    return off;
+}
 
-    int status = 0;
+// move the right-aligned text to the front of the slot and zero the rest; returns the status
+__device__ __forceinline__ int finish_cigar(CigarWriter &cw)
+{
     if (cw.pos < 0) {
-        status = ERR_CIGAR_OVERFLOW;
         for (int k = 0; k < cw.cap; ++k) cw.slot[k] = 0;
-    } else {
-        const int len = cw.cap - cw.pos;
-        if (cw.pos > 0)
-            for (int k = 0; k < len; ++k) cw.slot[k] = cw.slot[cw.pos + k];
-        for (int k = len; k < cw.cap; ++k) cw.slot[k] = 0;
+        return ERR_CIGAR_OVERFLOW;
     }
+    const int len = cw.cap - cw.pos;
+    if (cw.pos > 0)
+        for (int k = 0; k < len; ++k) cw.slot[k] = cw.slot[cw.pos + k];
+    for (int k = len; k < cw.cap; ++k) cw.slot[k] = 0;
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
+{
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.count) return;
+    const int64_t p = a.first + slot;
+    const int tl = (int)(a.t_off[p + 1] - a.t_off[p]);
+    const int ql = (int)(a.q_off[p + 1] - a.q_off[p]);
+    const DpRecord r = a.rec[slot];
+
+    BitsMoves mv;
+    mv.tb.base = a.tb + (size_t)slot * a.tb_stride_words;
+    mv.tb.sps = r.sps;
+
+    CigarWriter cw;
+    cw.slot = a.cigar + (size_t)p * a.cigar_stride;
+    cw.cap = a.cigar_stride;
+    cw.pos = a.cigar_stride;
+    cw.need = 0;
+
+    const int off = walk_and_write(mv, tl, ql, a.strategy, r.max_t, r.max_q, r.mqe_t, r.seg, cw);
+    const int status = finish_cigar(cw);
+
     a.offset[p] = off;
     if (a.cigar_len) a.cigar_len[p] = cw.need;
     if (a.status) a.status[p] = status;
@@ -465,6 +497,25 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
         sc.seg_length = r.seg;
         a.score[p] = sc;
     }
+}
+
+// calculateCigar on a caller-supplied int32 backtrack matrix (sw_scalar.h:8): one thread.
+// out[0] = offset, out[1] = text length needed, out[2] = status
+__global__ void sw_cigar_from_matrix_kernel(const int32_t *btr, int tl, int ql, int strategy, Score ez, char *cigar,
+                                            int cap, int32_t *out)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    MatrixMoves mv;
+    mv.btr = btr;
+    mv.m = ql + 1;
+    CigarWriter cw;
+    cw.slot = cigar;
+    cw.cap = cap;
+    cw.pos = cap;
+    cw.need = 0;
+    out[0] = walk_and_write(mv, tl, ql, strategy, ez.max_t, ez.max_q, ez.mqe_t, ez.seg_length, cw);
+    out[2] = finish_cigar(cw);
+    out[1] = cw.need;
 }
 
 // Logical backtrack matrix of ONE pair (slot 0 of the workspace): the int32 run lengths the
@@ -515,6 +566,14 @@ hipError_t launch_traceback(const TbArgs &a, hipStream_t stream)
 {
     const int64_t blocks = (a.count + 255) / 256;
     hipLaunchKernelGGL(sw_traceback_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_cigar_from_matrix(const int32_t *btr, int tl, int ql, int strategy, const Score &ez, char *cigar,
+                                    int cap, int32_t *out3, hipStream_t stream)
+{
+    hipLaunchKernelGGL(sw_cigar_from_matrix_kernel, dim3(1), dim3(64), 0, stream, btr, tl, ql, strategy, ez, cigar, cap,
+                       out3);
     return hipGetLastError();
 }
 

@@ -1,0 +1,120 @@
+"""Device-resident batches: torch is used only for HBM allocations, streams and (in dist.py)
+the RCCL gather; the alignment itself is mgl_sw_align_batch_device (include/mgl_sw.h)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .smithwaterman import GATK_PARAMETERS, SWOverhangStrategy, SWParameters, _check
+
+_BASES = b"ACGT"
+
+
+class DeviceBatch:
+    """Inputs and outputs of one batch, all resident in one GPU's HBM.
+
+    targets / queries: uint8 concatenated bases; t_off / q_off: int64 [n+1].
+    Outputs: offsets int32[n], scores int32[n,6] (ScoreMax), cigars uint8[n,stride] zero padded,
+    cigar_len int32[n], status int32[n].
+    """
+
+    def __init__(self, targets, t_off, queries, q_off, max_tl, max_ql, cigar_stride=64):
+        assert targets.is_cuda and targets.dtype == torch.uint8 and t_off.dtype == torch.int64
+        self.targets, self.t_off, self.queries, self.q_off = targets, t_off, queries, q_off
+        self.n = t_off.numel() - 1
+        self.max_tl, self.max_ql = int(max_tl), int(max_ql)
+        self.cigar_stride = int(cigar_stride)
+        dev = targets.device
+        self.offsets = torch.empty(self.n, dtype=torch.int32, device=dev)
+        self.scores = torch.empty((self.n, 6), dtype=torch.int32, device=dev)
+        self.cigars = torch.empty((self.n, self.cigar_stride), dtype=torch.uint8, device=dev)
+        self.cigar_len = torch.empty(self.n, dtype=torch.int32, device=dev)
+        self.status = torch.empty(self.n, dtype=torch.int32, device=dev)
+
+    @property
+    def cells(self):
+        tl = (self.t_off[1:] - self.t_off[:-1])
+        ql = (self.q_off[1:] - self.q_off[:-1])
+        return int((tl * ql).sum().item())
+
+    def run(self, aligner, parameters=GATK_PARAMETERS, overhang_strategy=SWOverhangStrategy.SOFTCLIP, stream=None):
+        """Enqueue fill + traceback on ``stream`` (default: torch's current stream); no sync."""
+        if stream is None:
+            stream = torch.cuda.current_stream(self.targets.device)
+        p = SWParameters(*parameters)
+        rc = _lib.lib().mgl_sw_align_batch_device(
+            aligner.ctx, C.c_void_p(stream.cuda_stream), self.n, self.targets.data_ptr(), self.t_off.data_ptr(),
+            self.queries.data_ptr(), self.q_off.data_ptr(), self.max_tl, self.max_ql, p.match, p.mismatch,
+            p.gap_open, p.gap_extend, int(overhang_strategy), self.offsets.data_ptr(), self.scores.data_ptr(),
+            self.cigars.data_ptr(), self.cigar_stride, self.cigar_len.data_ptr(), self.status.data_ptr())
+        _check(rc, aligner.ctx)
+
+    def cigar_strings(self, idx=None):
+        cg = self.cigars if idx is None else self.cigars[idx]
+        ln = self.cigar_len if idx is None else self.cigar_len[idx]
+        cg, ln = cg.cpu().numpy(), ln.cpu().numpy()
+        return [cg[k, : ln[k]].tobytes().decode() for k in range(len(ln))]
+
+    def host_pairs(self, idx):
+        """(targets, queries) as lists of bytes for the pairs ``idx`` (1-D LongTensor / list)."""
+        idx = torch.as_tensor(idx, device=self.targets.device, dtype=torch.int64)
+        t0, t1 = self.t_off[idx].cpu().numpy(), self.t_off[idx + 1].cpu().numpy()
+        q0, q1 = self.q_off[idx].cpu().numpy(), self.q_off[idx + 1].cpu().numpy()
+        lo_t, hi_t, lo_q, hi_q = int(t0.min()), int(t1.max()), int(q0.min()), int(q1.max())
+        T = self.targets[lo_t:hi_t].cpu().numpy()
+        Q = self.queries[lo_q:hi_q].cpu().numpy()
+        ts = [T[a - lo_t: b - lo_t].tobytes() for a, b in zip(t0, t1)]
+        qs = [Q[a - lo_q: b - lo_q].tobytes() for a, b in zip(q0, q1)]
+        return ts, qs
+
+
+def window_batch(seed, n_pairs, device, window=256, read_len=150, genome_len=1 << 24, sub=0.01, ins=0.001,
+                 dele=0.001, cigar_stride=64):
+    """BASELINE.json configs[1] generated on the GPU: per-pair ``window``-base target cut from a
+    seeded random genome, ``read_len``-bp read copied from inside the window with Illumina-style
+    errors (the model of synth.illumina_reads).  Deterministic in (seed, arguments, device type)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    bases = torch.tensor(list(_BASES), dtype=torch.uint8, device=device)
+    genome = torch.randint(0, 4, (genome_len,), generator=g, device=device, dtype=torch.uint8)
+    win = torch.randint(0, genome_len - window, (n_pairs,), generator=g, device=device, dtype=torch.int64)
+    inner = torch.randint(0, window - read_len - 8 + 1, (n_pairs,), generator=g, device=device, dtype=torch.int64)
+    ar_w = torch.arange(window, device=device, dtype=torch.int64)
+    targets = torch.empty((n_pairs, window), dtype=torch.uint8, device=device)
+    reads = torch.empty((n_pairs, read_len), dtype=torch.uint8, device=device)
+    step = 1 << 20  # bound the temporaries
+    for a in range(0, n_pairs, step):
+        b = min(n_pairs, a + step)
+        m = b - a
+        targets[a:b] = bases[genome[win[a:b, None] + ar_w].long()]
+        r = torch.rand((3, m, read_len), generator=g, device=device)
+        is_ins, is_del, is_sub = r[0] < ins, r[1] < dele, r[2] < sub
+        copied = ~is_ins
+        src = torch.cumsum(copied, 1) - copied.long() + torch.cumsum(is_del & copied, 1)
+        src = (src + (win[a:b] + inner[a:b])[:, None]).clamp_(0, genome_len - 1)
+        code = genome[src]
+        shift = torch.randint(1, 4, (m, read_len), generator=g, device=device, dtype=torch.uint8)
+        code = torch.where(is_sub, (code + shift) & 3, code)
+        rnd = torch.randint(0, 4, (m, read_len), generator=g, device=device, dtype=torch.uint8)
+        code = torch.where(is_ins, rnd, code)
+        reads[a:b] = bases[code.long()]
+        del r, is_ins, is_del, is_sub, copied, src, code, shift, rnd
+    t_off = torch.arange(n_pairs + 1, device=device, dtype=torch.int64) * window
+    q_off = torch.arange(n_pairs + 1, device=device, dtype=torch.int64) * read_len
+    return DeviceBatch(targets.reshape(-1), t_off, reads.reshape(-1), q_off, window, read_len, cigar_stride)
+
+
+def from_host(targets, t_off, queries, q_off, device, cigar_stride=None):
+    """Upload a host batch (numpy uint8 / int64 arrays as taken by mgl_sw_align_batch)."""
+    t_off = np.asarray(t_off, dtype=np.int64)
+    q_off = np.asarray(q_off, dtype=np.int64)
+    max_tl = int(np.diff(t_off).max())
+    max_ql = int(np.diff(q_off).max())
+    if cigar_stride is None:
+        cigar_stride = max(16, 2 * max(max_tl, max_ql))
+    dev = torch.device(device)
+    return DeviceBatch(torch.from_numpy(np.ascontiguousarray(targets, dtype=np.uint8)).to(dev),
+                       torch.from_numpy(t_off).to(dev),
+                       torch.from_numpy(np.ascontiguousarray(queries, dtype=np.uint8)).to(dev),
+                       torch.from_numpy(q_off).to(dev), max_tl, max_ql, cigar_stride)

@@ -1,0 +1,78 @@
+"""Multi-GPU plumbing: read pairs shard embarrassingly (each pair is a pure function of its two
+sequences, ..._MicrosoftSmithWaterman.cpp:44-71), so there is no data-path collective; the only
+exchange is one gather of the int32 alignment scores onto rank 0 at the end (RCCL over xGMI on
+GPUs, gloo in the CPU tests).  One process per GPU, launched by torch.distributed.run."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment (1 process: 0, 0, 1)."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init(backend=None):
+    """Initialise the default process group when launched with WORLD_SIZE > 1."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous shard [lo, hi) of n_total pairs for ``rank``; sizes differ by at most one."""
+    base, extra = divmod(int(n_total), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_counts(n_total, world):
+    return [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+
+
+def gather_scores(local_scores, n_total=None, dst=0):
+    """Gather each rank's int32 score vector onto ``dst`` in shard order.
+
+    Returns the concatenated [n_total] tensor on dst and None elsewhere.  Shards may differ in
+    length by one (shard_range): every rank pads to the longest shard so that the collective is
+    a plain equal-size gather.
+    """
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_scores
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if n_total is None:
+        n = torch.tensor([local_scores.numel()], device=local_scores.device, dtype=torch.int64)
+        dist.all_reduce(n)
+        n_total = int(n.item())
+        counts = None
+    counts = shard_counts(n_total, world)
+    assert local_scores.numel() == counts[rank], (local_scores.numel(), counts[rank])
+    width = max(counts)
+    send = local_scores
+    if send.numel() != width:
+        send = torch.zeros(width, dtype=local_scores.dtype, device=local_scores.device)
+        send[: local_scores.numel()] = local_scores
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send.contiguous(), recv, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([recv[r][: counts[r]] for r in range(world)])
+
+
+def max_over_ranks(value, device):
+    """MAX of a python float over all ranks (for timing)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

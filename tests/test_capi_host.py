@@ -1,0 +1,108 @@
+"""CPU-side checks of the C-ABI library and the host mirror: the library loads, exports every
+symbol include/mgl_sw.h declares, and fails loudly (never silently computes on the CPU) when no
+GPU is present.  No compute calls are made without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from mgl_amd import _lib, smithwaterman as sw, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "mgl_sw.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mgl_sw_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    declared = header_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/mgl_sw.h but not exported"
+    assert sorted(_lib.SYMBOLS) == declared
+    assert L.mgl_sw_version() == 100
+
+
+def test_header_constants_match_reference_codes():
+    text = open(os.path.join(ROOT, "include", "mgl_sw.h")).read()
+    # sw_common.h:22-25,33
+    for name, val in (("MGL_SW_OS_SOFTCLIP", "0x01"), ("MGL_SW_OS_INDEL", "0x02"), ("MGL_SW_OS_LEAD_ID", "0x04"),
+                      ("MGL_SW_OS_IGNORE", "0x08"), ("MGL_SW_NEG_INF", "(-0x40000000)")):
+        assert re.search(rf"#define {name} {re.escape(val)}", text), name
+    assert [int(s) for s in sw.SWOverhangStrategy] == [1, 2, 4, 8]
+    assert C.sizeof(_lib.Score) == 24
+
+
+def test_param_normalisation_matches_jni_boundary():
+    # ..._MicrosoftSmithWaterman.cpp:51-55
+    L = _lib.lib()
+    for given in ((200, -150, 260, 11), (-200, 150, -260, -11), (200, 150, 260, 11), (200, -150, -260, -11)):
+        v = [C.c_int(x) for x in given]
+        L.mgl_sw_normalize_params(*[C.byref(x) for x in v])
+        assert [x.value for x in v] == [200, -150, 260, 11]
+
+
+def test_strerror_and_limits():
+    L = _lib.lib()
+    assert L.mgl_sw_strerror(0) == b"ok"
+    assert b"HIP" in L.mgl_sw_strerror(_lib.ERR_DEVICE)
+    assert 1000 < L.mgl_sw_max_query_len() < 100000
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = _lib.lib()
+    assert L.mgl_sw_device_count() == 0
+    h = C.c_void_p()
+    assert L.mgl_sw_ctx_create(0, C.byref(h)) == _lib.ERR_DEVICE
+    assert not sw.MicrosoftSmithWaterman().load()
+    with pytest.raises(_lib.MglSwError) as e:
+        sw.align(b"ACGT", b"ACGT")
+    assert e.value.status == _lib.ERR_DEVICE
+    with pytest.raises(_lib.MglSwError):
+        sw.backtrack_matrix(b"ACGT", b"ACGT")
+
+
+def test_bad_arguments_rejected_before_any_device_work():
+    L = _lib.lib()
+    buf = C.create_string_buffer(16)
+    ln, off = C.c_int(), C.c_int()
+    assert L.mgl_sw_align(b"", 0, b"A", 1, 1, -1, 1, 1, 1, buf, 16, C.byref(ln), C.byref(off), None) == _lib.ERR_BAD_ARG
+    assert L.mgl_sw_align(b"A", 1, b"A", 1, 1, -1, 1, 1, 3, buf, 16, C.byref(ln), C.byref(off), None) == _lib.ERR_BAD_ARG
+    assert L.mgl_sw_ctx_set_workspace(None, 1 << 30) == _lib.ERR_BAD_ARG
+
+
+def test_product_never_imports_the_oracle():
+    """The shipped package and the native sources must not reference oracle/ in any way."""
+    pkg = os.path.join(ROOT, "mgl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_lib" not in text and "sw_oracle" not in text and "libmgl_ref" not in text, f
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        assert "oracle" not in open(os.path.join(ROOT, "include", f)).read().lower() or f.endswith(".md")
+
+
+def test_concat_layout():
+    d, off = sw.concat([b"ACG", b"T", b"GGTT"])
+    assert d.tobytes() == b"ACGTGGTT" and off.tolist() == [0, 3, 4, 8]
+
+
+def test_synthetic_workloads_are_deterministic():
+    ref1, reads1 = synth.config1()
+    ref2, reads2 = synth.config1()
+    assert (ref1 == ref2).all() and (reads1 == reads2).all() and reads1.shape == (1000, 150)
+    assert set(np.unique(reads1).tolist()) <= set(b"ACGT")
+    # error model sanity: ~1 % substitutions => most reads differ from their source in a few bases
+    g, ws, rd = synth.window_batch(3, 64, genome_len=1 << 14)
+    assert rd.shape == (64, 150) and (ws >= 0).all() and (ws + 256 <= len(g)).all()

@@ -149,3 +149,45 @@ def test_bad_arguments(aligner):
     with pytest.raises(_lib.MglSwError) as e:
         aligner.align_batch([b"ACGT"], [b"ACGT"], overhang_strategy=3)
     assert e.value.status == _lib.ERR_BAD_ARG
+
+
+def test_cpp_dropin_api():
+    """A C++ caller written against the reference's names (align_avx, align_scalar, calculateMatrix,
+    calculateCigar) built on include/mgl_sw.hpp reproduces the golden answers, including through the
+    two-step calculateMatrix -> calculateCigar form of sw.cpp:258-272."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "cpp")])
+    rows = [g for g in golden_io.load("known") + golden_io.load("shapes")[::9] + golden_io.load("random")[::40]
+            if b" " not in g.t]
+    inp = "".join(f"{g.t.decode()} {g.q.decode()} {g.params[0]} {g.params[1]} {g.params[2]} {g.params[3]} {g.strategy}\n"
+                  for g in rows)
+    out = subprocess.run([os.path.join(root, "tests", "cpp", "dropin_caller")], input=inp.encode(), capture_output=True,
+                         check=True).stdout.decode().splitlines()
+    assert len(out) == len(rows)
+    for g, line in zip(rows, out):
+        f = line.split()
+        assert (int(f[0]), f[1]) == (g.offset, g.cigar), (g, line)
+        assert (int(f[2]), f[3]) == (g.offset, g.cigar), (g, line)
+        assert tuple(int(x) for x in f[4:10]) == g.score
+        assert int(f[10]) == g.crc
+
+
+def test_batch_mode_backtrack_matrix(aligner):
+    """Traceback bits of pairs aligned inside a mixed-geometry batch (wave mates of different
+    tl/ql) expand to the reference's matrix as well."""
+    rows = golden_io.load("random")[:96:1]
+    by = defaultdict(list)
+    for g in rows:
+        by[(g.params, g.strategy)].append(g)
+    checked = 0
+    for (params, strategy), gs in by.items():
+        aligner.align_batch([g.t for g in gs], [g.q for g in gs], params, strategy)
+        for k, g in enumerate(gs):
+            btr = aligner.expand_slot(k, len(g.t), len(g.q))
+            crc = zlib.crc32(np.ascontiguousarray(btr[1:, 1:]).astype("<i4").tobytes()) & 0xFFFFFFFF
+            assert crc == g.crc, (k, g.params, g.strategy)
+            checked += 1
+    assert checked == len(rows)
