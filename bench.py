@@ -56,13 +56,13 @@ def host_cores():
     return n
 
 
-def pmc_traffic_per_pair(tl, ql):
+def pmc_traffic_per_pair(tl, ql, kernel="sw_dp_kernel"):
     """HBM bytes per pair of sw_dp_kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json: WRITE_SIZE + 2 x FETCH_SIZE, the gfx950 correction of
     MI355X_MICROARCH.md), or None when no pass was taken for this geometry."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        for r in rec["sw_dp_kernel"]:
+        for r in rec[kernel]:
             if (r["tl"], r["ql"]) == (tl, ql):
                 return r["hbm_bytes_per_pair"]
     except (OSError, KeyError, ValueError):
@@ -183,12 +183,13 @@ def main():
 
     if rank != 0:
         return
+    fill_kernel = "sw_dp16_kernel" if tm.packed16 else "sw_dp_kernel"
     total_cells = cells * world * args.steps
     per_pair = algorithmic_bytes_per_pair(args.tl, args.ql)
     dp_s = tm.dp_ms / 1e3
     achieved = args.pairs * per_pair / dp_s / 1e9
     pairs_per_launch = args.pairs / max(1, tm.dp_launches)
-    tpp = pmc_traffic_per_pair(args.tl, args.ql)
+    tpp = pmc_traffic_per_pair(args.tl, args.ql, fill_kernel)
     traffic = None if tpp is None else round(tpp * pairs_per_launch)  # HBM bytes per launch (PMC)
     out = {
         "metric": "GCUPS (+ aligned reads/s) for 150 bp short-read batch",
@@ -201,7 +202,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "int32",
+        "dtype": "int16" if tm.packed16 else "int32",
         "data": "synthetic",
         "config": {
             "workload": f"BASELINE.json configs[1]: {args.pairs} Illumina-style {args.ql} bp reads x {args.tl}-base "
@@ -211,11 +212,11 @@ def main():
             "parallelism": f"pairs sharded over {world} GPU(s), score gather only" if world > 1 else "1 GPU",
         },
         "reads_per_s": round(args.pairs * world * args.steps / elapsed, 1),
-        "kernel_ms": {"sw_dp_kernel": round(tm.dp_ms, 3), "sw_traceback_kernel": round(tm.tb_ms, 3),
+        "kernel_ms": {fill_kernel: round(tm.dp_ms, 3), "sw_traceback_kernel": round(tm.tb_ms, 3),
                       "launches_each": tm.dp_launches},
         "cigar_overflows": status_bad,
         "roofline": {
-            "bound": "hbm", "kernel": "sw_dp_kernel",
+            "bound": "hbm", "kernel": fill_kernel,
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic,

@@ -63,6 +63,8 @@ typedef struct mgl_sw_timing {
     int32_t dp_launches, tb_launches;
     int64_t cells;      /* sum tl*ql of the last call                      */
     int64_t tb_bytes;   /* traceback bytes written to HBM by the last call */
+    int32_t packed16;   /* 1 when the packed-int16 fill kernel (sw_dp16_kernel) ran */
+    int32_t reserved;
 } mgl_sw_timing;
 
 typedef struct mgl_sw_ctx mgl_sw_ctx; /* opaque: one GPU, its workspace and stream */
@@ -81,6 +83,10 @@ const char *mgl_sw_last_error(const mgl_sw_ctx *ctx);
 /* cap on the device traceback workspace (bytes); default 4 GiB.  Batches are
  * processed in chunks that fit. */
 int mgl_sw_ctx_set_workspace(mgl_sw_ctx *ctx, int64_t bytes);
+/* fill-kernel arithmetic: 0 (default) = per batch, the packed-int16 kernel when every pair has
+ * the same tl and ql and the score range fits 16 bits, else int32; 32 = always int32.  Results are
+ * bit-identical either way. */
+int mgl_sw_ctx_set_precision(mgl_sw_ctx *ctx, int bits);
 /* enable per-kernel HIP-event timing (costs a stream sync per call) */
 int mgl_sw_ctx_set_profiling(mgl_sw_ctx *ctx, int enable);
 int mgl_sw_ctx_get_timing(const mgl_sw_ctx *ctx, mgl_sw_timing *out);
@@ -121,14 +127,18 @@ int mgl_sw_align_batch(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const
  * without synchronising -- unless profiling is enabled.  max_tl / max_ql are
  * upper bounds of the pair lengths (they size the workspace).  status_out
  * (optional, int32[n]) receives a per-pair mgl_sw_status (0 or
- * MGL_SW_ERR_CIGAR_OVERFLOW).
+ * MGL_SW_ERR_CIGAR_OVERFLOW).  flags: MGL_SW_FLAG_UNIFORM_GEOMETRY promises that every
+ * pair has exactly tl == max_tl and ql == max_ql (enables the packed-int16 fill kernel; the
+ * host-buffer entry detects this by itself).
  */
+#define MGL_SW_FLAG_UNIFORM_GEOMETRY 0x1
 int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_targets,
                               const int64_t *d_t_off, const uint8_t *d_queries,
                               const int64_t *d_q_off, int max_tl, int max_ql, int match,
                               int mismatch, int gopen, int gext, int strategy,
                               int32_t *d_offset_out, mgl_sw_score *d_score_out, char *d_cigar_out,
-                              int cigar_stride, int32_t *d_cigar_len_out, int32_t *d_status_out);
+                              int cigar_stride, int32_t *d_cigar_len_out, int32_t *d_status_out,
+                              int flags);
 
 /*
  * Logical backtrack matrix of one pair, the reference's calculateMatrix

@@ -9,15 +9,17 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmgl_sw_hip.so")
+# MGL_SW_LIB points the loader at a diagnostic build (scripts/ablate.sh); never set in production
+LIB_PATH = os.environ.get("MGL_SW_LIB") or os.path.join(HERE, "libmgl_sw_hip.so")
 CSRC = os.path.join(HERE, "csrc")
 
+FLAG_UNIFORM_GEOMETRY = 1
 OK, ERR_BAD_ARG, ERR_CIGAR_OVERFLOW, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED = range(6)
 
 # every symbol include/mgl_sw.h declares (tests check that the library exports them all)
 SYMBOLS = (
     "mgl_sw_version", "mgl_sw_strerror", "mgl_sw_device_count", "mgl_sw_max_query_len", "mgl_sw_ctx_create",
-    "mgl_sw_ctx_destroy", "mgl_sw_last_error", "mgl_sw_ctx_set_workspace", "mgl_sw_ctx_set_profiling",
+    "mgl_sw_ctx_destroy", "mgl_sw_last_error", "mgl_sw_ctx_set_workspace", "mgl_sw_ctx_set_profiling", "mgl_sw_ctx_set_precision",
     "mgl_sw_ctx_get_timing", "mgl_sw_normalize_params", "mgl_sw_align", "mgl_sw_align_batch",
     "mgl_sw_align_batch_device", "mgl_sw_backtrack_matrix", "mgl_sw_ctx_expand_slot",
     "mgl_sw_cigar_from_backtrack",
@@ -31,7 +33,7 @@ class Score(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("dp_ms", C.c_float), ("tb_ms", C.c_float), ("dp_launches", C.c_int32), ("tb_launches", C.c_int32),
-                ("cells", C.c_int64), ("tb_bytes", C.c_int64)]
+                ("cells", C.c_int64), ("tb_bytes", C.c_int64), ("packed16", C.c_int32), ("reserved", C.c_int32)]
 
 
 def _sources_newer():
@@ -80,7 +82,8 @@ def lib():
         cp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(Score)]
     L.mgl_sw_align_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp] + [C.c_int] * 5 + [vp, vp, vp, C.c_int, vp]
     L.mgl_sw_align_batch_device.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, C.c_int, C.c_int] + [C.c_int] * 5 + [
-        vp, vp, vp, C.c_int, vp, vp]
+        vp, vp, vp, C.c_int, vp, vp, C.c_int]
+    L.mgl_sw_ctx_set_precision.argtypes = [vp, C.c_int]
     L.mgl_sw_backtrack_matrix.argtypes = [cp, C.c_int, cp, C.c_int] + [C.c_int] * 5 + [i32p, C.POINTER(Score)]
     L.mgl_sw_cigar_from_backtrack.argtypes = [i32p, C.c_int, C.c_int, C.c_int, C.POINTER(Score), cp, C.c_int,
                                               C.POINTER(C.c_int), C.POINTER(C.c_int)]

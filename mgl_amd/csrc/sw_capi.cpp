@@ -56,6 +56,8 @@ struct mgl_sw_ctx {
     DevBuf tb, rec;                                                   // kernel workspace
     DevBuf d_t, d_toff, d_q, d_qoff, d_off, d_score, d_cig, d_len, d_status, d_btr; // host-API staging
     int64_t last_stride_words = 0, last_chunk_count = 0; // geometry of the last chunk (for expand_slot)
+    int last_packed16 = 0;
+    int precision = 0; // 0 = choose per batch, 32 = always the int32 kernel
     bool profiling = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     mgl_sw_timing timing{};
@@ -115,7 +117,7 @@ int max_query_len()
 int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_targets, const int64_t *d_t_off,
                const uint8_t *d_queries, const int64_t *d_q_off, int max_tl, int max_ql, int match, int mismatch,
                int gopen, int gext, int strategy, int32_t *d_offset, Score *d_score, char *d_cigar, int cigar_stride,
-               int32_t *d_cigar_len, int32_t *d_status, int64_t cells_hint)
+               int32_t *d_cigar_len, int32_t *d_status, int64_t cells_hint, bool uniform)
 {
     if (n == 0) return MGL_SW_OK;
     if (n < 0 || !d_targets || !d_t_off || !d_queries || !d_q_off || !d_offset || !d_cigar || cigar_stride < 1 ||
@@ -124,20 +126,24 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
     mgl_sw_normalize_params(&match, &mismatch, &gopen, &gext);
 
     const int sps_cap = sps_for(max_ql);
-    const int wpb = pick_waves_per_block(sps_cap);
+    // packed-int16 kernel: one geometry for the whole batch and a score range that fits 16 bits
+    const bool use16 = uniform && ctx->precision != 32 && dp16_lds_bytes(sps_cap, 4) <= 64 * 1024 &&
+                       dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
+    const int wpb = use16 ? 4 : pick_waves_per_block(sps_cap);
     if (wpb == 0) {
         char msg[128];
         snprintf(msg, sizeof msg, "query length %d exceeds the LDS-bounded maximum %d", max_ql, max_query_len());
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, msg);
     }
-    const int64_t stride_words = tb_words_for(max_tl, sps_cap);
-    const int64_t per_pair = stride_words * 4 + (int64_t)sizeof(DpRecord);
+    // traceback words per pair (int32 layout) or per group of two pairs (packed16 layout)
+    const int64_t stride_words = use16 ? tb_words16_for(max_tl, sps_cap) : tb_words_for(max_tl, sps_cap);
+    const int64_t per_pair = stride_words * 4 / (use16 ? 2 : 1) + (int64_t)sizeof(DpRecord);
     int64_t chunk = std::max<int64_t>(16, ctx->ws_limit / per_pair);
     chunk = std::min<int64_t>(chunk, n);
     chunk = (chunk + 15) / 16 * 16;
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, ctx->tb.reserve((size_t)chunk * stride_words * 4));
+    HIP_TRY(ctx, ctx->tb.reserve((size_t)(use16 ? chunk / 2 : chunk) * stride_words * 4));
     HIP_TRY(ctx, ctx->rec.reserve((size_t)chunk * sizeof(DpRecord)));
 
     ctx->timing = mgl_sw_timing{};
@@ -158,6 +164,8 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
         da.gext = gext;
         da.strategy = strategy;
         da.sps_cap = sps_cap;
+        da.uni_tl = max_tl;
+        da.uni_ql = max_ql;
         da.tb = static_cast<uint32_t *>(ctx->tb.p);
         da.tb_stride_words = stride_words;
         da.rec = static_cast<DpRecord *>(ctx->rec.p);
@@ -170,6 +178,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
         ta.strategy = strategy;
         ta.tb = da.tb;
         ta.tb_stride_words = stride_words;
+        ta.packed16 = use16 ? 1 : 0;
         ta.rec = da.rec;
         ta.offset = d_offset;
         ta.score = d_score;
@@ -179,7 +188,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
         ta.status = d_status;
 
         if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
-        HIP_TRY(ctx, launch_dp(da, wpb, stream));
+        HIP_TRY(ctx, use16 ? launch_dp16(da, wpb, stream) : launch_dp(da, wpb, stream));
         if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
         HIP_TRY(ctx, launch_traceback(ta, stream));
         if (ctx->profiling) {
@@ -193,9 +202,11 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
         }
         ctx->last_stride_words = stride_words;
         ctx->last_chunk_count = count;
+        ctx->last_packed16 = use16 ? 1 : 0;
         ctx->timing.dp_launches++;
         ctx->timing.tb_launches++;
-        ctx->timing.tb_bytes += count * stride_words * 4;
+        ctx->timing.tb_bytes += (use16 ? (count + 1) / 2 : count) * stride_words * 4;
+        ctx->timing.packed16 = use16 ? 1 : 0;
     }
     return MGL_SW_OK;
 }
@@ -287,6 +298,14 @@ int mgl_sw_ctx_set_workspace(mgl_sw_ctx *ctx, int64_t bytes)
     return MGL_SW_OK;
 }
 
+int mgl_sw_ctx_set_precision(mgl_sw_ctx *ctx, int bits)
+{
+    if (!ctx || (bits != 0 && bits != 32)) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->precision = bits;
+    return MGL_SW_OK;
+}
+
 int mgl_sw_ctx_set_profiling(mgl_sw_ctx *ctx, int enable)
 {
     if (!ctx) return MGL_SW_ERR_BAD_ARG;
@@ -306,13 +325,14 @@ int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const ui
                               const int64_t *d_t_off, const uint8_t *d_queries, const int64_t *d_q_off, int max_tl,
                               int max_ql, int match, int mismatch, int gopen, int gext, int strategy,
                               int32_t *d_offset_out, mgl_sw_score *d_score_out, char *d_cigar_out, int cigar_stride,
-                              int32_t *d_cigar_len_out, int32_t *d_status_out)
+                              int32_t *d_cigar_len_out, int32_t *d_status_out, int flags)
 {
     if (!ctx) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     return run_device(ctx, static_cast<hipStream_t>(stream), n, d_targets, d_t_off, d_queries, d_q_off, max_tl, max_ql,
                       match, mismatch, gopen, gext, strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out),
-                      d_cigar_out, cigar_stride, d_cigar_len_out, d_status_out, 0);
+                      d_cigar_out, cigar_stride, d_cigar_len_out, d_status_out, 0,
+                      (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) != 0);
 }
 
 int mgl_sw_align_batch(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const int64_t *t_off,
@@ -328,8 +348,11 @@ int mgl_sw_align_batch(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: bad argument");
     int max_tl = 0, max_ql = 0;
     int64_t cells = 0;
+    bool uniform = true;
+    const int64_t tl0 = t_off[1] - t_off[0], ql0 = q_off[1] - q_off[0];
     for (int64_t k = 0; k < n; ++k) {
         const int64_t tl = t_off[k + 1] - t_off[k], ql = q_off[k + 1] - q_off[k];
+        uniform = uniform && tl == tl0 && ql == ql0;
         // the reference reads out of bounds for empty sequences (sw.cpp:162-163,184): rejected here
         if (tl < 1 || ql < 1 || tl > 0x3fffffff || ql > 0x3fffffff)
             return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: sequence length < 1 or too large");
@@ -361,7 +384,7 @@ int mgl_sw_align_batch(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const
                         static_cast<const uint8_t *>(ctx->d_q.p), static_cast<const int64_t *>(ctx->d_qoff.p), max_tl,
                         max_ql, match, mismatch, gopen, gext, strategy, static_cast<int32_t *>(ctx->d_off.p),
                         static_cast<Score *>(ctx->d_score.p), static_cast<char *>(ctx->d_cig.p), cigar_stride,
-                        static_cast<int32_t *>(ctx->d_len.p), static_cast<int32_t *>(ctx->d_status.p), cells);
+                        static_cast<int32_t *>(ctx->d_len.p), static_cast<int32_t *>(ctx->d_status.p), cells, uniform);
     if (rc != MGL_SW_OK) return rc;
 
     std::vector<int32_t> status((size_t)n);
@@ -428,9 +451,10 @@ int mgl_sw_ctx_expand_slot(mgl_sw_ctx *ctx, int64_t slot, int tl, int ql, int32_
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, ctx->d_btr.reserve(cells * 4));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_btr.p, 0, cells * 4, ctx->stream));
-    HIP_TRY(ctx, launch_expand(static_cast<const uint32_t *>(ctx->tb.p) + slot * ctx->last_stride_words,
-                               static_cast<const DpRecord *>(ctx->rec.p) + slot, tl, ql,
-                               static_cast<int32_t *>(ctx->d_btr.p), ctx->stream));
+    const int64_t region = ctx->last_packed16 ? slot >> 1 : slot;
+    HIP_TRY(ctx, launch_expand(static_cast<const uint32_t *>(ctx->tb.p) + region * ctx->last_stride_words,
+                               static_cast<const DpRecord *>(ctx->rec.p) + slot, tl, ql, ctx->last_packed16,
+                               (int)(slot & 1), static_cast<int32_t *>(ctx->d_btr.p), ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(btr, ctx->d_btr.p, cells * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MGL_SW_OK;

@@ -32,6 +32,7 @@ struct DpArgs {
     int64_t count;
     int match, mismatch, gopen, gext, strategy;
     int sps_cap;             // upper bound of steps per stripe (sizes the LDS carve)
+    int uni_tl, uni_ql;      // packed-int16 kernel only: the one geometry of the batch
     uint32_t *tb;            // traceback words, count * tb_stride_words
     int64_t tb_stride_words; // per pair
     DpRecord *rec;           // count records
@@ -43,7 +44,8 @@ struct TbArgs {
     int64_t first, count;
     int strategy;
     const uint32_t *tb;
-    int64_t tb_stride_words;
+    int64_t tb_stride_words; // per pair (int32 layout) or per group of two pairs (packed16 layout)
+    int packed16;            // traceback layout written by sw_dp16_kernel
     const DpRecord *rec;
     int32_t *offset; // indexed by batch pair index
     Score *score;    // optional
@@ -61,12 +63,19 @@ __host__ __device__ inline int64_t tb_words_for(int tl, int sps)
     return (((int64_t)stripes_for(tl) * sps + 31) >> 5) * 64;
 }
 
+// packed16 layout: one dword per lane per 4 steps, per group of two pairs
+__host__ __device__ inline int64_t tb_words16_for(int tl, int sps) { return (int64_t)stripes_for(tl) * sps * 4; }
+
 int dp_lds_bytes(int sps_cap, int waves_per_block);
+int dp16_lds_bytes(int sps, int waves_per_block);
+bool dp16_range_ok(int tl, int ql, int match, int mismatch, int gopen, int gext, int strategy);
+hipError_t launch_dp16(const DpArgs &a, int waves_per_block, hipStream_t stream);
 hipError_t launch_dp(const DpArgs &a, int waves_per_block, hipStream_t stream);
 hipError_t launch_traceback(const TbArgs &a, hipStream_t stream);
 hipError_t launch_cigar_from_matrix(const int32_t *btr, int tl, int ql, int strategy, const Score &ez, char *cigar,
                                     int cap, int32_t *out3, hipStream_t stream);
-hipError_t launch_expand(const uint32_t *tbw, const DpRecord *rec, int tl, int ql, int32_t *btr, hipStream_t stream);
+hipError_t launch_expand(const uint32_t *tbw, const DpRecord *rec, int tl, int ql, int packed16, int half, int32_t *btr,
+                         hipStream_t stream);
 
 } // namespace mgl_sw_dev
 #endif

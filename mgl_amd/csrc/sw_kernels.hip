@@ -76,6 +76,17 @@ struct LaneState {
 //   EPI   : some lane may be at its last column (capture H[i][ql])
 // ringA / ringB hold the carry of columns s0, s0+1 / s0+2, s0+3; they are reloaded for the
 // next block as soon as their last use is behind (no register rotation at the loop edge).
+#ifdef MGL_ABLATE_TBSTORE
+#define MGL_ABLATE_TBSTORE_V 1
+#else
+#define MGL_ABLATE_TBSTORE_V 0
+#endif
+#ifdef MGL_ABLATE_QREAD
+#define MGL_QREAD(p) (qw * 1664525u + 1013904223u)
+#else
+#define MGL_QREAD(p) ((p)[1])
+#endif
+
 template <bool PRO, bool EPI>
 __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, const int4 *ring_next,
                                       const unsigned qw, const int tb, const int s0, const int L, const int hb,
@@ -86,7 +97,9 @@ __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, c
     for (int u = 0; u < 4; ++u) {
         const int rh = u == 0 ? ringA.x : u == 1 ? ringA.z : u == 2 ? ringB.x : ringB.z;
         const int re = u == 0 ? ringA.y : u == 1 ? ringA.w : u == 2 ? ringB.y : ringB.w;
+#ifndef MGL_ABLATE_RINGREAD
         if (u == 2) ringA = ring_next[0];
+#endif
         const int hup_new = row_shr1(rh, st.h_prev);
         const int ein = row_shr1(re, st.e_prev);
         const int qb = (int)((qw >> (8 * u)) & 0xffu);
@@ -107,23 +120,29 @@ __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, c
             h = at_border ? hb : h;
             fo = at_border ? hb - gopen : fo;
         }
+#ifndef MGL_ABLATE_TB
         st.a0 = shift_in_sign(st.a0, d1);
         st.a1 = shift_in_sign(st.a1, d2);
         st.a2 = shift_in_sign(st.a2, d3);
         st.a3 = shift_in_sign(st.a3, d4);
+#endif
         if (EPI) {
             const bool last_col = (s0 + u - L) == qcap;
             const bool take = last_col && h >= st.best; // sw.cpp:100-104 (>=: later row wins)
             st.best = take ? h : st.best;
             st.best_i = take ? row_i : st.best_i;
         }
+#ifndef MGL_ABLATE_RINGWRITE
         if (writer) ring_wr[u] = make_int2(h, eo);
+#endif
         st.h_prev = h;
         st.e_prev = eo;
         st.hup = hup_new;
         st.f = fo;
     }
+#ifndef MGL_ABLATE_RINGREAD
     ringB = ring_next[1];
+#endif
 }
 
 __global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
@@ -236,7 +255,7 @@ __global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
         int s = 0;
 #define MGL_SW_BLOCK(PRO, EPI)                                                                             \
     {                                                                                                      \
-        const unsigned nq = qrd[1];                                                                        \
+        const unsigned nq = MGL_QREAD(qrd);                                                                \
         step4<PRO, EPI>(st, rA, rB, ring_rd + 2, qw, tb, s, L, hb, qcap, row_i, match, mismatch, gopen,    \
                         gext, ring_wr, writer);                                                            \
         qw = nq;                                                                                           \
@@ -246,7 +265,7 @@ __global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
         s += 4;                                                                                            \
         gsteps += 4;                                                                                       \
         if ((gsteps & 31) == 0) {                                                                          \
-            if (valid) *reinterpret_cast<uint4 *>(tbp) = make_uint4(st.a0, st.a1, st.a2, st.a3);          \
+            if (valid && !MGL_ABLATE_TBSTORE_V) *reinterpret_cast<uint4 *>(tbp) = make_uint4(st.a0, st.a1, st.a2, st.a3); \
             tbp += 64;                                                                                     \
         }                                                                                                  \
     }
@@ -312,14 +331,22 @@ __global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
 // ---------------------------------------------------------------------------------------------
 // traceback bits accessor shared by the path walk and the matrix expansion
 struct TbView {
-    const uint32_t *base; // this pair's traceback words
+    const uint32_t *base; // this pair's (int32 layout) or this group's (packed16 layout) traceback words
     int sps;
+    int packed16, half;
     // nibble of cell (i, j), 1-based: bit0 F>diag, bit1 E>max(diag,F), bit2 E opened, bit3 F opened
     __device__ __forceinline__ unsigned cell(int i, int j) const
     {
         const int r = i - 1;
         const int lane = r & 15;
         const int g = (r >> 4) * sps + j + lane;
+        if (packed16) {
+            // sw_dp16.hip: dword per lane per 4 steps; byte h = {E>S, F opened}, byte 2+h = {F>diag, E opened}
+            const uint32_t w = base[(size_t)(g >> 2) * 16 + lane];
+            const int t2 = (g & 3) * 2;
+            const unsigned be = (w >> (8 * half)) >> t2, bf = (w >> (16 + 8 * half)) >> t2;
+            return ((bf >> 1) & 1u) | (((be >> 1) & 1u) << 1) | ((bf & 1u) << 2) | ((be & 1u) << 3);
+        }
         const uint4 w = *reinterpret_cast<const uint4 *>(base + (size_t)(g >> 5) * 64 + lane * 4);
         const int sh = 31 - (g & 31);
         return ((w.x >> sh) & 1u) | (((w.y >> sh) & 1u) << 1) | (((w.z >> sh) & 1u) << 2) |
@@ -472,8 +499,10 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
     const DpRecord r = a.rec[slot];
 
     BitsMoves mv;
-    mv.tb.base = a.tb + (size_t)slot * a.tb_stride_words;
+    mv.tb.base = a.tb + (size_t)(a.packed16 ? slot >> 1 : slot) * a.tb_stride_words;
     mv.tb.sps = r.sps;
+    mv.tb.packed16 = a.packed16;
+    mv.tb.half = (int)(slot & 1);
 
     CigarWriter cw;
     cw.slot = a.cigar + (size_t)p * a.cigar_stride;
@@ -521,7 +550,7 @@ __global__ void sw_cigar_from_matrix_kernel(const int32_t *btr, int tl, int ql, 
 // Logical backtrack matrix of ONE pair (slot 0 of the workspace): the int32 run lengths the
 // reference stores (sw.cpp:62,66,70), rebuilt from the 4-bit cells.
 __global__ __launch_bounds__(256) void sw_expand_kernel(const uint32_t *tbw, const DpRecord *rec, int tl, int ql,
-                                                        int32_t *btr)
+                                                        int packed16, int half, int32_t *btr)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= tl * ql) return;
@@ -529,6 +558,8 @@ __global__ __launch_bounds__(256) void sw_expand_kernel(const uint32_t *tbw, con
     TbView tb;
     tb.base = tbw;
     tb.sps = rec[0].sps;
+    tb.packed16 = packed16;
+    tb.half = half;
     const unsigned c = tb.cell(i, j);
     int v = 0;
     if (c & 2u)
@@ -577,11 +608,12 @@ hipError_t launch_cigar_from_matrix(const int32_t *btr, int tl, int ql, int stra
     return hipGetLastError();
 }
 
-hipError_t launch_expand(const uint32_t *tbw, const DpRecord *rec, int tl, int ql, int32_t *btr, hipStream_t stream)
+hipError_t launch_expand(const uint32_t *tbw, const DpRecord *rec, int tl, int ql, int packed16, int half, int32_t *btr,
+                         hipStream_t stream)
 {
     const int64_t n = (int64_t)tl * ql;
     hipLaunchKernelGGL(sw_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tbw, rec, tl, ql,
-                       btr);
+                       packed16, half, btr);
     return hipGetLastError();
 }
 

@@ -19,12 +19,13 @@ class DeviceBatch:
     cigar_len int32[n], status int32[n].
     """
 
-    def __init__(self, targets, t_off, queries, q_off, max_tl, max_ql, cigar_stride=64):
+    def __init__(self, targets, t_off, queries, q_off, max_tl, max_ql, cigar_stride=64, uniform=False):
         assert targets.is_cuda and targets.dtype == torch.uint8 and t_off.dtype == torch.int64
         self.targets, self.t_off, self.queries, self.q_off = targets, t_off, queries, q_off
         self.n = t_off.numel() - 1
         self.max_tl, self.max_ql = int(max_tl), int(max_ql)
         self.cigar_stride = int(cigar_stride)
+        self.uniform = bool(uniform)  # every pair exactly max_tl x max_ql
         dev = targets.device
         self.offsets = torch.empty(self.n, dtype=torch.int32, device=dev)
         self.scores = torch.empty((self.n, 6), dtype=torch.int32, device=dev)
@@ -47,7 +48,8 @@ class DeviceBatch:
             aligner.ctx, C.c_void_p(stream.cuda_stream), self.n, self.targets.data_ptr(), self.t_off.data_ptr(),
             self.queries.data_ptr(), self.q_off.data_ptr(), self.max_tl, self.max_ql, p.match, p.mismatch,
             p.gap_open, p.gap_extend, int(overhang_strategy), self.offsets.data_ptr(), self.scores.data_ptr(),
-            self.cigars.data_ptr(), self.cigar_stride, self.cigar_len.data_ptr(), self.status.data_ptr())
+            self.cigars.data_ptr(), self.cigar_stride, self.cigar_len.data_ptr(), self.status.data_ptr(),
+            _lib.FLAG_UNIFORM_GEOMETRY if self.uniform else 0)
         _check(rc, aligner.ctx)
 
     def cigar_strings(self, idx=None):
@@ -102,19 +104,21 @@ def window_batch(seed, n_pairs, device, window=256, read_len=150, genome_len=1 <
         del r, is_ins, is_del, is_sub, copied, src, code, shift, rnd
     t_off = torch.arange(n_pairs + 1, device=device, dtype=torch.int64) * window
     q_off = torch.arange(n_pairs + 1, device=device, dtype=torch.int64) * read_len
-    return DeviceBatch(targets.reshape(-1), t_off, reads.reshape(-1), q_off, window, read_len, cigar_stride)
+    return DeviceBatch(targets.reshape(-1), t_off, reads.reshape(-1), q_off, window, read_len, cigar_stride,
+                       uniform=True)
 
 
 def from_host(targets, t_off, queries, q_off, device, cigar_stride=None):
     """Upload a host batch (numpy uint8 / int64 arrays as taken by mgl_sw_align_batch)."""
     t_off = np.asarray(t_off, dtype=np.int64)
     q_off = np.asarray(q_off, dtype=np.int64)
-    max_tl = int(np.diff(t_off).max())
-    max_ql = int(np.diff(q_off).max())
+    dt, dq = np.diff(t_off), np.diff(q_off)
+    max_tl, max_ql = int(dt.max()), int(dq.max())
+    uniform = bool((dt == max_tl).all() and (dq == max_ql).all())
     if cigar_stride is None:
         cigar_stride = max(16, 2 * max(max_tl, max_ql))
     dev = torch.device(device)
     return DeviceBatch(torch.from_numpy(np.ascontiguousarray(targets, dtype=np.uint8)).to(dev),
                        torch.from_numpy(t_off).to(dev),
                        torch.from_numpy(np.ascontiguousarray(queries, dtype=np.uint8)).to(dev),
-                       torch.from_numpy(q_off).to(dev), max_tl, max_ql, cigar_stride)
+                       torch.from_numpy(q_off).to(dev), max_tl, max_ql, cigar_stride, uniform=uniform)

@@ -131,6 +131,10 @@ class MicrosoftSmithWaterman:
     def set_workspace(self, nbytes):
         _check(_lib.lib().mgl_sw_ctx_set_workspace(self._ensure(), int(nbytes)))
 
+    def set_precision(self, bits):
+        """0 = per batch (packed int16 when possible), 32 = always the int32 fill kernel."""
+        _check(_lib.lib().mgl_sw_ctx_set_precision(self._ensure(), int(bits)))
+
     def set_profiling(self, on=True):
         _check(_lib.lib().mgl_sw_ctx_set_profiling(self._ensure(), int(bool(on))))
 

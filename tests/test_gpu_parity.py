@@ -191,3 +191,85 @@ def test_batch_mode_backtrack_matrix(aligner):
             assert crc == g.crc, (k, g.params, g.strategy)
             checked += 1
     assert checked == len(rows)
+
+
+# ---------------------------------------------------------------------------------------------
+# packed-int16 fill kernel (sw_dp16_kernel): taken for batches with one geometry whose score
+# range fits 16 bits.  It must be indistinguishable from the int32 kernel and from the oracle.
+
+def _uniform_batch(rng, n, tl, ql, alphabet=b"ACGT", related=True):
+    alpha = np.frombuffer(alphabet, np.uint8)
+    ts, qs = [], []
+    for k in range(n):
+        t = alpha[rng.integers(0, len(alpha), tl)]
+        if related and k % 4 != 3:
+            # read = noisy copy of a window of the target (substitutions + one indel), padded/cut to ql
+            a = int(rng.integers(0, max(1, tl - ql + 1))) if tl >= ql else 0
+            src = np.resize(t[a:], ql + 2).copy()
+            sub = rng.random(ql + 2) < 0.05
+            src[sub] = alpha[rng.integers(0, len(alpha), int(sub.sum()))]
+            if k % 4 == 1:
+                src = np.delete(src, int(rng.integers(0, ql)))
+            elif k % 4 == 2:
+                src = np.insert(src, int(rng.integers(0, ql)), alpha[0])
+            q = src[:ql]
+        else:
+            q = alpha[rng.integers(0, len(alpha), ql)]
+        ts.append(t.tobytes())
+        qs.append(q.tobytes())
+    return ts, qs
+
+
+@pytest.mark.parametrize("tl,ql", [(256, 150), (1000, 150), (16, 16), (17, 15), (1, 1), (5, 3), (33, 8), (64, 65),
+                                   (100, 151), (300, 7)])
+def test_packed16_uniform_batches(aligner, tl, ql):
+    rng = np.random.default_rng(tl * 1000 + ql)
+    n = 37  # odd: the last group has a lone pair
+    ts, qs = _uniform_batch(rng, n, tl, ql, b"ACGT" if ql % 2 else b"AC")
+    for params in [(200, -150, 260, 11), (25, -50, 110, 6), (3, -1, 4, 3), (1, -1, 1, 1), (5, -4, 10, 1)]:
+        for strategy in ol.STRATEGIES:
+            res = aligner.align_batch(ts, qs, params, strategy)
+            assert aligner.timing().packed16 == 1, "uniform small-range batch should take the packed kernel"
+            off, sc, cg = ol.oracle_align_batch(ts, qs, params, strategy, nthreads=4)
+            assert (res.offsets == off).all(), (params, strategy)
+            assert (res.scores == sc).all(), (params, strategy)
+            assert res.cigars == cg, (params, strategy)
+            # logical backtrack matrix of a pair in each half of a lane
+            for slot in (0, 1, n - 1):
+                btr = aligner.expand_slot(slot, tl, ql)
+                o = ol.oracle_align(ts[slot], qs[slot], params, strategy, want_btr=True)
+                assert (btr[1:, 1:] == o["btr"][1:, 1:]).all(), (params, strategy, slot)
+
+
+def test_packed16_equals_forced_int32(aligner):
+    rows = [g for g in golden_io.load("window") if g.strategy == ol.SOFTCLIP][:128]
+    ts, qs = [g.t for g in rows], [g.q for g in rows]
+    a = aligner.align_batch(ts, qs, rows[0].params, ol.SOFTCLIP)
+    assert aligner.timing().packed16 == 1
+    forced = sw.MicrosoftSmithWaterman(0)
+    forced.set_precision(32)
+    b = forced.align_batch(ts, qs, rows[0].params, ol.SOFTCLIP)
+    assert forced.timing().packed16 == 0
+    forced.close()
+    assert (a.offsets == b.offsets).all() and (a.scores == b.scores).all() and a.cigars == b.cigars
+    for k, g in enumerate(rows):
+        assert (int(a.offsets[k]), a.cigars[k], tuple(int(x) for x in a.scores[k])) == (g.offset, g.cigar, g.score)
+
+
+def test_packed16_range_guard(aligner):
+    """Scores that do not fit 16 bits must fall back to the int32 kernel -- and still be exact."""
+    rng = np.random.default_rng(99)
+    ts, qs = _uniform_batch(rng, 9, 200, 300)  # match * ql = 60000: with the gap terms beyond a 16-bit span
+    res = aligner.align_batch(ts, qs, (200, -150, 260, 11), ol.INDEL)
+    assert aligner.timing().packed16 == 0
+    off, sc, cg = ol.oracle_align_batch(ts, qs, (200, -150, 260, 11), ol.INDEL, nthreads=4)
+    assert (res.offsets == off).all() and (res.scores == sc).all() and res.cigars == cg
+    # just inside the guard: homopolymer pairs drive H to its extremes (all-match and all-mismatch)
+    for t, q in ((b"A" * 300, b"A" * 150), (b"A" * 300, b"C" * 150), (b"AC" * 150, b"CA" * 75)):
+        for strategy in ol.STRATEGIES:
+            r = aligner.align_batch([t] * 3, [q] * 3, (200, -150, 260, 11), strategy)
+            assert aligner.timing().packed16 == 1
+            o = ol.oracle_align(t, q, (200, -150, 260, 11), strategy)
+            for k in range(3):
+                assert (int(r.offsets[k]), r.cigars[k], tuple(int(x) for x in r.scores[k])) == (
+                    o["offset"], o["cigar"], o["score"])
