@@ -64,7 +64,7 @@ typedef struct mgl_sw_timing {
     int64_t cells;      /* sum tl*ql of the last call                      */
     int64_t tb_bytes;   /* traceback bytes written to HBM by the last call */
     int32_t packed16;   /* 1 when the packed-int16 fill kernel (sw_dp16_kernel) ran */
-    int32_t reserved;
+    int32_t clock_mhz;  /* profiling level 2: shader clock seen inside the fill kernel (s_memtime / s_memrealtime) */
 } mgl_sw_timing;
 
 typedef struct mgl_sw_ctx mgl_sw_ctx; /* opaque: one GPU, its workspace and stream */
@@ -87,7 +87,8 @@ int mgl_sw_ctx_set_workspace(mgl_sw_ctx *ctx, int64_t bytes);
  * the same tl and ql and the score range fits 16 bits, else int32; 32 = always int32.  Results are
  * bit-identical either way. */
 int mgl_sw_ctx_set_precision(mgl_sw_ctx *ctx, int bits);
-/* enable per-kernel HIP-event timing (costs a stream sync per call) */
+/* 1 = per-kernel HIP-event timing (costs a stream sync per chunk); 2 = additionally stamp the shader
+ * clock inside the fill kernel (diagnostic; a few extra instructions per workgroup); 0 = off */
 int mgl_sw_ctx_set_profiling(mgl_sw_ctx *ctx, int enable);
 int mgl_sw_ctx_get_timing(const mgl_sw_ctx *ctx, mgl_sw_timing *out);
 

@@ -33,7 +33,7 @@ class Score(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("dp_ms", C.c_float), ("tb_ms", C.c_float), ("dp_launches", C.c_int32), ("tb_launches", C.c_int32),
-                ("cells", C.c_int64), ("tb_bytes", C.c_int64), ("packed16", C.c_int32), ("reserved", C.c_int32)]
+                ("cells", C.c_int64), ("tb_bytes", C.c_int64), ("packed16", C.c_int32), ("clock_mhz", C.c_int32)]
 
 
 def _sources_newer():

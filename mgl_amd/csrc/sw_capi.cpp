@@ -53,12 +53,17 @@ struct mgl_sw_ctx {
     int device = 0;
     hipStream_t stream = nullptr; // used by the host-buffer entry points
     int64_t ws_limit = kDefaultWorkspace;
-    DevBuf tb, rec;                                                   // kernel workspace
+    // kernel workspace, two halves: the traceback of chunk k (aux stream) overlaps the fill of chunk k+1
+    DevBuf tb[2], rec[2], diag;
+    hipStream_t aux = nullptr;                       // traceback stream
+    hipEvent_t fill_done[2] = {nullptr, nullptr};    // fill of the chunk in half h finished (caller's stream)
+    hipEvent_t tb_done[2] = {nullptr, nullptr};      // traceback of the chunk in half h finished (aux stream)
+    int last_half = 0;
     DevBuf d_t, d_toff, d_q, d_qoff, d_off, d_score, d_cig, d_len, d_status, d_btr; // host-API staging
     int64_t last_stride_words = 0, last_chunk_count = 0; // geometry of the last chunk (for expand_slot)
     int last_packed16 = 0;
     int precision = 0; // 0 = choose per batch, 32 = always the int32 kernel
-    bool profiling = false;
+    int profiling = 0; // 0 off, 1 per-kernel HIP events, 2 also the in-kernel clock probe
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     mgl_sw_timing timing{};
     std::string err;
@@ -138,19 +143,28 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
     // traceback words per pair (int32 layout) or per group of two pairs (packed16 layout)
     const int64_t stride_words = use16 ? tb_words16_for(max_tl, sps_cap) : tb_words_for(max_tl, sps_cap);
     const int64_t per_pair = stride_words * 4 / (use16 ? 2 : 1) + (int64_t)sizeof(DpRecord);
-    int64_t chunk = std::max<int64_t>(16, ctx->ws_limit / per_pair);
+    // the workspace is split in two halves so that the traceback of one chunk can run (on ctx->aux)
+    // while the next chunk is being filled; a batch that fits one half is a single chunk
+    int64_t chunk = std::max<int64_t>(16, ctx->ws_limit / 2 / per_pair);
     chunk = std::min<int64_t>(chunk, n);
     chunk = (chunk + 15) / 16 * 16;
+    const bool overlap = ctx->profiling == 0 && n > chunk;
+    const int halves = n > chunk ? 2 : 1;
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, ctx->tb.reserve((size_t)(use16 ? chunk / 2 : chunk) * stride_words * 4));
-    HIP_TRY(ctx, ctx->rec.reserve((size_t)chunk * sizeof(DpRecord)));
+    for (int h = 0; h < halves; ++h) {
+        HIP_TRY(ctx, ctx->tb[h].reserve((size_t)(use16 ? chunk / 2 : chunk) * stride_words * 4));
+        HIP_TRY(ctx, ctx->rec[h].reserve((size_t)chunk * sizeof(DpRecord)));
+    }
 
     ctx->timing = mgl_sw_timing{};
     ctx->timing.cells = cells_hint;
 
-    for (int64_t first = 0; first < n; first += chunk) {
+    bool tb_pending[2] = {false, false};
+    int64_t k = 0;
+    for (int64_t first = 0; first < n; first += chunk, ++k) {
         const int64_t count = std::min(chunk, n - first);
+        const int h = (int)(k & (halves - 1));
         DpArgs da;
         da.targets = d_targets;
         da.t_off = d_t_off;
@@ -166,9 +180,16 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
         da.sps_cap = sps_cap;
         da.uni_tl = max_tl;
         da.uni_ql = max_ql;
-        da.tb = static_cast<uint32_t *>(ctx->tb.p);
+        da.tb = static_cast<uint32_t *>(ctx->tb[h].p);
         da.tb_stride_words = stride_words;
-        da.rec = static_cast<DpRecord *>(ctx->rec.p);
+        da.rec = static_cast<DpRecord *>(ctx->rec[h].p);
+        da.diag = nullptr;
+        const int per_block = use16 ? wpb * 8 : wpb * 4;
+        const int64_t n_blocks = (count + per_block - 1) / per_block;
+        if (ctx->profiling >= 2) {
+            HIP_TRY(ctx, ctx->diag.reserve((size_t)n_blocks * 16));
+            da.diag = static_cast<unsigned long long *>(ctx->diag.p);
+        }
 
         TbArgs ta;
         ta.t_off = d_t_off;
@@ -187,10 +208,21 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
         ta.cigar_len = d_cigar_len;
         ta.status = d_status;
 
-        if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
-        HIP_TRY(ctx, use16 ? launch_dp16(da, wpb, stream) : launch_dp(da, wpb, stream));
-        if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
-        HIP_TRY(ctx, launch_traceback(ta, stream));
+        if (overlap) {
+            // this half was last read by the traceback of chunk k-2
+            if (tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->tb_done[h], 0));
+            HIP_TRY(ctx, use16 ? launch_dp16(da, wpb, stream) : launch_dp(da, wpb, stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->fill_done[h], stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->fill_done[h], 0));
+            HIP_TRY(ctx, launch_traceback(ta, ctx->aux));
+            HIP_TRY(ctx, hipEventRecord(ctx->tb_done[h], ctx->aux));
+            tb_pending[h] = true;
+        } else {
+            if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
+            HIP_TRY(ctx, use16 ? launch_dp16(da, wpb, stream) : launch_dp(da, wpb, stream));
+            if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
+            HIP_TRY(ctx, launch_traceback(ta, stream));
+        }
         if (ctx->profiling) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
             HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2]));
@@ -199,15 +231,29 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
             HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
             ctx->timing.dp_ms += a;
             ctx->timing.tb_ms += b;
+            if (da.diag) {
+                std::vector<unsigned long long> h((size_t)n_blocks * 2);
+                HIP_TRY(ctx, hipMemcpy(h.data(), da.diag, h.size() * 8, hipMemcpyDeviceToHost));
+                double cyc = 0, real = 0;
+                for (int64_t i = 0; i < n_blocks; ++i) {
+                    cyc += (double)h[2 * i];
+                    real += (double)h[2 * i + 1];
+                }
+                if (real > 0) ctx->timing.clock_mhz = (int32_t)(cyc / real * 100.0); // s_memrealtime ticks at 100 MHz
+            }
         }
         ctx->last_stride_words = stride_words;
         ctx->last_chunk_count = count;
+        ctx->last_half = h;
         ctx->last_packed16 = use16 ? 1 : 0;
         ctx->timing.dp_launches++;
         ctx->timing.tb_launches++;
         ctx->timing.tb_bytes += (use16 ? (count + 1) / 2 : count) * stride_words * 4;
         ctx->timing.packed16 = use16 ? 1 : 0;
     }
+    // everything this call enqueued is ordered before whatever the caller enqueues next on `stream`
+    for (int h = 0; h < 2; ++h)
+        if (tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->tb_done[h], 0));
     return MGL_SW_OK;
 }
 
@@ -265,11 +311,14 @@ int mgl_sw_ctx_create(int device, mgl_sw_ctx **out)
         delete ctx;
         return MGL_SW_ERR_DEVICE;
     }
-    for (auto &e : ctx->ev)
-        if (hipEventCreate(&e) != hipSuccess) {
-            mgl_sw_ctx_destroy(ctx);
-            return MGL_SW_ERR_DEVICE;
-        }
+    bool ok = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) == hipSuccess;
+    for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    for (auto *set : {ctx->fill_done, ctx->tb_done})
+        for (int h = 0; h < 2; ++h) ok = ok && hipEventCreateWithFlags(&set[h], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        mgl_sw_ctx_destroy(ctx);
+        return MGL_SW_ERR_DEVICE;
+    }
     *out = ctx;
     return MGL_SW_OK;
 }
@@ -279,11 +328,16 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf *b : {&ctx->tb, &ctx->rec, &ctx->d_t, &ctx->d_toff, &ctx->d_q, &ctx->d_qoff, &ctx->d_off, &ctx->d_score,
+    if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
+    for (DevBuf *b : {&ctx->tb[0], &ctx->tb[1], &ctx->rec[0], &ctx->rec[1], &ctx->diag, &ctx->d_t, &ctx->d_toff, &ctx->d_q, &ctx->d_qoff, &ctx->d_off, &ctx->d_score,
                       &ctx->d_cig, &ctx->d_len, &ctx->d_status, &ctx->d_btr})
         b->release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto *set : {ctx->fill_done, ctx->tb_done})
+        for (int h = 0; h < 2; ++h)
+            if (set[h]) (void)hipEventDestroy(set[h]);
+    if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -310,7 +364,7 @@ int mgl_sw_ctx_set_profiling(mgl_sw_ctx *ctx, int enable)
 {
     if (!ctx) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->profiling = enable != 0;
+    ctx->profiling = enable < 0 ? 0 : enable;
     return MGL_SW_OK;
 }
 
@@ -452,8 +506,9 @@ int mgl_sw_ctx_expand_slot(mgl_sw_ctx *ctx, int64_t slot, int tl, int ql, int32_
     HIP_TRY(ctx, ctx->d_btr.reserve(cells * 4));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_btr.p, 0, cells * 4, ctx->stream));
     const int64_t region = ctx->last_packed16 ? slot >> 1 : slot;
-    HIP_TRY(ctx, launch_expand(static_cast<const uint32_t *>(ctx->tb.p) + region * ctx->last_stride_words,
-                               static_cast<const DpRecord *>(ctx->rec.p) + slot, tl, ql, ctx->last_packed16,
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
+    HIP_TRY(ctx, launch_expand(static_cast<const uint32_t *>(ctx->tb[ctx->last_half].p) + region * ctx->last_stride_words,
+                               static_cast<const DpRecord *>(ctx->rec[ctx->last_half].p) + slot, tl, ql, ctx->last_packed16,
                                (int)(slot & 1), static_cast<int32_t *>(ctx->d_btr.p), ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(btr, ctx->d_btr.p, cells * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

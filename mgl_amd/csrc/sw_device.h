@@ -36,6 +36,7 @@ struct DpArgs {
     uint32_t *tb;            // traceback words, count * tb_stride_words
     int64_t tb_stride_words; // per pair
     DpRecord *rec;           // count records
+    unsigned long long *diag; // profiling level 2 only: per block {shader-clock ticks, 100 MHz ticks}; else null
 };
 
 struct TbArgs {

@@ -27,6 +27,7 @@
 //   step t of the 4 in bits (2t+1, 2t).  A group stores 64 contiguous bytes every 4 steps.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "sw_device.h"
 
@@ -136,6 +137,11 @@ __device__ __forceinline__ void step4_16(Lane16 &st, uint4 &ringA, uint4 &ringB,
 __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long diag_t0 = 0, diag_w0 = 0;
+    if (a.diag) { // in-kernel clock probe (MI355X_MICROARCH.md, DVFS give-back item 6); off in normal runs
+        diag_t0 = __builtin_amdgcn_s_memtime();
+        diag_w0 = __builtin_amdgcn_s_memrealtime();
+    }
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -309,6 +315,10 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
             a.rec[half ? slotB : slotA] = r;
         }
     }
+    if (a.diag && threadIdx.x == 0) {
+        a.diag[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - diag_t0;
+        a.diag[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - diag_w0;
+    }
 }
 
 int dp16_lds_bytes(int sps, int waves_per_block)
@@ -333,7 +343,8 @@ hipError_t launch_dp16(const DpArgs &a, int waves_per_block, hipStream_t stream)
 {
     const int per_block = waves_per_block * 8; // pairs per block
     const int64_t blocks = (a.count + per_block - 1) / per_block;
-    const int lds = dp16_lds_bytes(sps_for(a.uni_ql), waves_per_block);
+    int lds = dp16_lds_bytes(sps_for(a.uni_ql), waves_per_block);
+    if (const char *e = getenv("MGL_SW_EXTRA_LDS")) lds += atoi(e); // occupancy experiments only
     static int configured_lds = 0;
     if (lds > 64 * 1024 && lds > configured_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_dp16_kernel),

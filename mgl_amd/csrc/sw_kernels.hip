@@ -148,6 +148,11 @@ __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, c
 __global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long diag_t0 = 0, diag_w0 = 0;
+    if (a.diag) { // in-kernel clock probe (MI355X_MICROARCH.md, DVFS give-back item 6); off in normal runs
+        diag_t0 = __builtin_amdgcn_s_memtime();
+        diag_w0 = __builtin_amdgcn_s_memrealtime();
+    }
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -325,6 +330,10 @@ __global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
     if (rem && valid) {
         const int sh = 32 - rem;
         *reinterpret_cast<uint4 *>(tbp) = make_uint4(st.a0 << sh, st.a1 << sh, st.a2 << sh, st.a3 << sh);
+    }
+    if (a.diag && threadIdx.x == 0) {
+        a.diag[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - diag_t0;
+        a.diag[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - diag_w0;
     }
 }
 

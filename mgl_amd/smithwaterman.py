@@ -136,7 +136,7 @@ class MicrosoftSmithWaterman:
         _check(_lib.lib().mgl_sw_ctx_set_precision(self._ensure(), int(bits)))
 
     def set_profiling(self, on=True):
-        _check(_lib.lib().mgl_sw_ctx_set_profiling(self._ensure(), int(bool(on))))
+        _check(_lib.lib().mgl_sw_ctx_set_profiling(self._ensure(), int(on)))
 
     def timing(self):
         t = _lib.Timing()

@@ -6,10 +6,11 @@
 #include <cstdio>
 #include <vector>
 #include <string>
+#include <cstring>
 
-#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+#define CHECK(x) do { hipError_t err_ = (x); if (err_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(err_), __LINE__); return 1; } } while (0)
 
-constexpr int ITERS = 2048;
+static int ITERS = 2048;
 constexpr int UNROLL = 32;
 
 // 8 independent registers r0..r7 and two sources a,b
@@ -17,7 +18,7 @@ constexpr int UNROLL = 32;
 #define REP32(I) REP8(I) REP8(I) REP8(I) REP8(I)
 
 #define KERNEL(NAME, ASM_INDEP, ASM_DEP)                                                              \
-    __global__ __launch_bounds__(256) void k_##NAME(unsigned *out, unsigned long long *clk, int dep)  \
+    __global__ __launch_bounds__(256) void k_##NAME(unsigned *out, unsigned long long *clk, int dep, int ITERS)  \
     {                                                                                                 \
         unsigned r0 = threadIdx.x, r1 = r0 * 3, r2 = r0 * 5, r3 = r0 * 7, r4 = r0 * 11, r5 = r0 * 13, \
                  r6 = r0 * 17, r7 = r0 * 19;                                                          \
@@ -133,11 +134,13 @@ KERNEL(mov, REP32(I_MOV), REP32(I_MOV))
 KERNEL(sad_u8, REP32(I_SADU8), REP32(I_SADU8))
 KERNEL(cndmask, REP32(I_CNDMASK), REP32(I_CNDMASK))
 
-struct Entry { const char *name; void (*fn)(unsigned *, unsigned long long *, int); int instr_per_rep; bool has_dep; };
+struct Entry { const char *name; void (*fn)(unsigned *, unsigned long long *, int, int); int instr_per_rep; bool has_dep; };
 
 int main(int argc, char **argv)
 {
     int blocks_per_cu = argc > 1 ? atoi(argv[1]) : 4; // x 4 waves = waves per CU
+    if (argc > 2) ITERS = atoi(argv[2]);
+    const char *only = argc > 3 ? argv[3] : nullptr;
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -165,16 +168,20 @@ int main(int argc, char **argv)
         {"v_add_co_u32", k_addco, 1, false}, {"v_subrev_u32", k_subrev, 1, false}, {"v_max_i16", k_maxi16, 1, false},
         {"v_add_u16", k_addu16, 1, false}, {"v_sad_u8", k_sad_u8, 1, false}, {"v_cndmask_b32", k_cndmask, 1, false},
     };
-    printf("CUs=%d waves/CU=%d (per SIMD %d)\n", cus, blocks_per_cu * 4, blocks_per_cu);
+    // one "round" of blocks: exactly blocks_per_cu resident per CU, enforced by the LDS each block claims
+    const int lds = (160 * 1024 / blocks_per_cu) & ~255;
+    printf("CUs=%d waves/CU=%d (per SIMD %d), LDS/block=%d\n", cus, blocks_per_cu * 4, blocks_per_cu, lds);
     printf("%-28s %10s %10s %12s %10s\n", "instruction", "indep cyc", "dep cyc", "clock GHz", "ms");
     for (auto &e : es) {
+        if (only && !strstr(e.name, only)) continue;
         double res[2] = {0, 0}, ghz = 0, ms_ = 0;
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(e.fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         for (int dep = 0; dep < (e.has_dep ? 2 : 1); ++dep) {
             hipEvent_t a, b;
             CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
-            hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), 0, 0, out, clk, dep); // warm
+            hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), lds, 0, out, clk, dep, ITERS); // warm
             CHECK(hipEventRecord(a));
-            hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), 0, 0, out, clk, dep);
+            hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), lds, 0, out, clk, dep, ITERS);
             CHECK(hipEventRecord(b));
             CHECK(hipEventSynchronize(b));
             float ms; CHECK(hipEventElapsedTime(&ms, a, b));
@@ -184,8 +191,9 @@ int main(int argc, char **argv)
             cyc /= blocks; real /= blocks;
             const double instr_per_wave = (double)ITERS * UNROLL * e.instr_per_rep;
             // waves per SIMD share the SIMD: cycles per wave-instruction on the SIMD = cyc / (instr_per_wave * waves_per_simd)
-            res[dep] = cyc / (instr_per_wave * blocks_per_cu);
             ghz = cyc / real * 0.1; ms_ = ms;
+            // wall-clock based: SIMD cycles per wave-instruction (kernel time x in-kernel clock / instr per SIMD)
+            res[dep] = (double)ms * 1e-3 * ghz * 1e9 / (instr_per_wave * blocks_per_cu);
         }
         printf("%-28s %10.3f %10.3f %12.3f %10.3f\n", e.name, res[0], res[1], ghz, ms_);
     }
