@@ -8,17 +8,19 @@
 // two cells.
 //
 // 16-bit representation.  A cell value is stored as
-//        v = X[i][j] - j*match + BIAS            (X = H, E or F;  BIAS = 32767)
-// i.e. every column is shifted down by j*match.  Consequences:
+//        v = X[i][j] + i*e - j*(match+e) + BASE      (X = H, E or F;  e = gap extend)
+// i.e. a per-cell offset that is linear in (i, j).  Consequences:
 //   * diag = H[i-1][j-1] + s(t,q)  becomes  v_diag = v_hup + (t==q ? 0 : mismatch-match): the constant of
 //     the match case vanishes, so the substitution score is  m*delta  with m = min(t^q, 1) -- one
 //     v_pk_mad_i16, no compare/select (there is no packed compare on CDNA4);
-//   * E moves within a column: constants o, e unchanged; F moves to the next column: o+match, e+match;
-//   * H <= match*min(i,j) <= match*j, so every stored value is <= BIAS and the range needed is
-//     match*ql + (gap terms), independent of tl (the host checks it, dp16_range_ok());
+//   * E moves one row down: E' = max(H - (o-e), E) -- extending a vertical gap costs NO instruction;
+//     F moves one column right: F' = max(H - (o+match+e), F - (match+2e));
+//   * H <= match*min(i,j), so v <= BASE + e*(i-j) <= BASE + e*tl, and v >= BASE - (match+2e)*ql - (gap
+//     terms): the span is about match*ql + e*(tl+2ql), checked by the host (dp16_range_ok()); BASE
+//     puts the top of that span at +32767;
 //   * comparisons between cells of the same (i,j) are unaffected, so all decisions -- hence the
 //     traceback -- are bit-identical to the int32 kernel; true scores are recovered where they are
-//     read (last column: + ql*match - BIAS; last row: + j*match - BIAS).
+//     read (last column, last row).
 // Flags are sign bits of saturating differences (v_pk_sub_i16 clamp keeps the sign right over the whole
 // 16-bit range).  Garbage lanes (columns > ql, rows > tl) may wrap; they never feed a valid cell.
 //
@@ -37,7 +39,6 @@ namespace {
 
 constexpr int DPP_ROW_SHR1 = 0x111;
 constexpr int RING_SLACK16 = 20, QQ_SLACK16 = 36;
-constexpr int BIAS16 = 32767;
 
 typedef short short2_t __attribute__((ext_vector_type(2)));
 typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
@@ -75,6 +76,8 @@ __device__ __forceinline__ int border(int k, int gopen, int gext, bool indel)
     return (indel && k > 0) ? -gopen - (k - 1) * gext : 0; // sw.cpp:29-40,47-49
 }
 
+__host__ __device__ inline int dp16_base(int tl, int gext) { return 32767 - gext * tl; }
+
 struct Lane16 {
     unsigned h_prev, e_prev, hup, f; // packed A|B, column-shifted + biased
     unsigned acc;                    // traceback flags of the current 4-step block
@@ -82,7 +85,7 @@ struct Lane16 {
 };
 
 struct Consts16 {
-    unsigned delta, one, o_e, e_e, o_f, e_f; // packed constants (both halves equal)
+    unsigned delta, one, o_e, o_f, e_f; // packed constants (both halves equal)
 };
 
 template <bool PRO, bool EPI>
@@ -106,9 +109,8 @@ __device__ __forceinline__ void step4_16(Lane16 &st, uint4 &ringA, uint4 &ringB,
         unsigned h = pk_max(sm, ein);
         const unsigned open_e = pk_sub(h, c.o_e);
         const unsigned open_f = pk_sub(h, c.o_f);
-        const unsigned ee = pk_sub(ein, c.e_e);
-        const unsigned d3 = pk_sub_sat(ee, open_e);         // < 0 <=> a new vertical gap wins
-        const unsigned eo = pk_max(open_e, ee);
+        const unsigned d3 = pk_sub_sat(ein, open_e);        // < 0 <=> a new vertical gap wins
+        const unsigned eo = pk_max(open_e, ein);            // extension is free in this representation
         const unsigned fe = pk_sub(st.f, c.e_f);
         const unsigned d4 = pk_sub_sat(fe, open_f);         // < 0 <=> a new horizontal gap wins
         unsigned fo = pk_max(open_f, fe);
@@ -179,11 +181,12 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
     Consts16 c;
     c.delta = pack2(a.mismatch - match, a.mismatch - match);
     c.one = pack2(1, 1);
-    c.o_e = pack2(gopen, gopen);
-    c.e_e = pack2(gext, gext);
-    c.o_f = pack2(gopen + match, gopen + match);
-    c.e_f = pack2(gext + match, gext + match);
-    asm volatile("" : "+v"(c.delta), "+v"(c.one), "+v"(c.o_e), "+v"(c.e_e), "+v"(c.o_f), "+v"(c.e_f));
+    const int colw = match + gext;          // column offset per j
+    const int base = dp16_base(tl, gext);    // BASE: the largest stored value is exactly 32767
+    c.o_e = pack2(gopen - gext, gopen - gext);
+    c.o_f = pack2(gopen + colw, gopen + colw);
+    c.e_f = pack2(gext + colw, gext + colw);
+    asm volatile("" : "+v"(c.delta), "+v"(c.one), "+v"(c.o_e), "+v"(c.o_f), "+v"(c.e_f));
 
     // ---- stage the two queries interleaved, and the border row (sw.cpp:14-18,31-35) in stored form
     for (int x = L; x < qq_entries; x += 16) {
@@ -193,8 +196,9 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
         qq[x] = v;
     }
     for (int j = L; j <= ql; j += 16) {
-        const int hb0 = border(j, gopen, gext, indel) - j * match + BIAS16;
-        ring[j + 16] = make_uint2(pack2(hb0, hb0), pack2(hb0 - gopen, hb0 - gopen));
+        const int hb0 = border(j, gopen, gext, indel) - j * colw + base;  // row 0
+        const int eb1 = hb0 - gopen + gext;                                // E[1][j] = H[0][j] - o, row 1 offset
+        ring[j + 16] = make_uint2(pack2(hb0, hb0), pack2(eb1, eb1));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
     Lane16 st;
     st.h_prev = st.e_prev = st.hup = st.f = 0;
     st.acc = 0;
-    int bestA = NEG_INF, bestA_i = -1, bestB = NEG_INF, bestB_i = -1; // stored-form last-column maxima
+    int bestA = NEG_INF, bestA_i = -1, bestB = NEG_INF, bestB_i = -1; // last-column maxima (scores)
 
     const int last_lane = (tl - 1) & 15;
     // traceback words: group region + lane; one dword per lane per 4 steps (16 dwords per group block)
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
         row_next += 16;
         tt_next = (row_next <= tl) ? ((unsigned)tA[row_next - 1] | ((unsigned)tB[row_next - 1] << 16)) : 0u;
 
-        const int hbv = border(row_i, gopen, gext, indel) + BIAS16; // column 0: no column shift
+        const int hbv = border(row_i, gopen, gext, indel) + row_i * gext + base; // column 0
         const unsigned hb = pack2(hbv, hbv);
         const int wl = (k == nstripes - 1) ? last_lane : 15;
         const bool writer = (L == wl);
@@ -249,13 +253,22 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
         tbp += 16;                                                                                        \
     }
         for (; s < 16;) MGL_SW_BLOCK16(true, true)
+#ifndef MGL_NO_UNROLL2
+        // two blocks per trip: the one-block-ahead prefetch registers alternate instead of being copied
+        for (; s + 8 <= main_end;) {
+            MGL_SW_BLOCK16(false, false)
+            MGL_SW_BLOCK16(false, false)
+        }
+#endif
         for (; s < main_end;) MGL_SW_BLOCK16(false, false)
         for (; s < sps;) MGL_SW_BLOCK16(false, true)
 #undef MGL_SW_BLOCK16
 
-        // last column of this stripe's rows (sw.cpp:100-104: >= so the later row wins)
+        // last column of this stripe's rows (sw.cpp:100-104: >= so the later row wins); rows carry
+        // different offsets, so compare scores, not stored values
         if (cap_valid) {
-            const int ca = lo16(st.cap), cb = hi16(st.cap);
+            const int unshift = ql * colw - row_i * gext - base;
+            const int ca = lo16(st.cap) + unshift, cb = hi16(st.cap) + unshift;
             if (ca >= bestA) {
                 bestA = ca;
                 bestA_i = row_i;
@@ -280,11 +293,10 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
             mqe = take ? ob : mqe;
             mqe_t = take ? oi : mqe_t;
         }
-        mqe += ql * match - BIAS16; // stored form -> score (all rows share the column shift of j = ql)
         int rm = NEG_INF, rd = 0x7fffffff, rj = 0x7fffffff;
         for (int j = L + 1; j <= ql; j += 16) {
             const unsigned x = ring[j + 16].x;
-            const int sc = (half ? hi16(x) : lo16(x)) + j * match - BIAS16;
+            const int sc = (half ? hi16(x) : lo16(x)) + j * colw - tl * gext - base;
             const int d = abs(tl - j);
             const bool take = sc > rm || (sc == rm && d < rd);
             rm = take ? sc : rm;
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
             r.max_q = row_wins ? rj : ql;
             r.seg = row_wins ? ql - rj : 0;
             const unsigned xe = ring[ql + 16].x;
-            r.h_end = (half ? hi16(xe) : lo16(xe)) + ql * match - BIAS16;
+            r.h_end = (half ? hi16(xe) : lo16(xe)) + ql * colw - tl * gext - base;
             r.sps = sps;
             a.rec[half ? slotB : slotA] = r;
         }
@@ -327,16 +339,20 @@ int dp16_lds_bytes(int sps, int waves_per_block)
 }
 
 // Can every stored value of a tl x ql problem with these (normalised) parameters be held in 16 bits?
+// stored = X + i*e - j*(match+e) + BASE with BASE = 32767 - e*tl (dp16_base): X <= match*min(i,j) gives
+// stored <= BASE + e*(i-j) <= 32767.
 bool dp16_range_ok(int tl, int ql, int match, int mismatch, int gopen, int gext, int strategy)
 {
     const bool indel = (strategy & (OS_INDEL | OS_LEAD_ID)) != 0;
-    // lowest H in stored form (before BIAS): -(match*ql) minus the cheapest gap path from a border
-    int64_t low = -(int64_t)match * ql - (gopen + (int64_t)(ql - 1) * gext);
+    const int64_t colw = (int64_t)match + gext;
+    // lowest H: the cheapest gap path from a border (sw.cpp:29-40), at i >= 0, j = ql
+    int64_t low = -(gopen + (int64_t)(ql - 1) * gext) - colw * ql;
     if (indel) low -= gopen + (int64_t)(tl - 1) * gext;
     // E / F / open / extend / diag intermediates below H
-    low -= 2 * (int64_t)(gopen + match) + (gext + match) + (match - mismatch);
-    return low + BIAS16 >= -32768 + 16 && match > 0 && (int64_t)match - mismatch <= 30000 && gopen + match <= 30000 &&
-           gext + match <= 30000;
+    low -= 2 * (gopen + colw) + (gext + colw) + ((int64_t)match - mismatch);
+    const int64_t base = 32767 - (int64_t)gext * tl;
+    return low + base >= -32768 + 16 && match > 0 && (int64_t)match - mismatch <= 30000 && gopen + colw <= 30000 &&
+           gext + colw <= 30000 && (int64_t)gext * tl <= 30000;
 }
 
 hipError_t launch_dp16(const DpArgs &a, int waves_per_block, hipStream_t stream)
