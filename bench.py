@@ -70,7 +70,7 @@ def pmc_traffic_per_pair(tl, ql, kernel="sw_dp_kernel"):
     return None
 
 
-def cpu_baseline(batch, target_seconds=15.0, max_pairs=4_000_000):
+def cpu_baseline(batch, target_seconds=15.0, max_pairs=10_000_000):
     """Time the reference's CPU path on this host; returns the cpu_baseline JSON object."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol

@@ -64,8 +64,11 @@ __host__ __device__ inline int64_t tb_words_for(int tl, int sps)
     return (((int64_t)stripes_for(tl) * sps + 31) >> 5) * 64;
 }
 
-// packed16 layout: one dword per lane per 4 steps, per group of two pairs
-__host__ __device__ inline int64_t tb_words16_for(int tl, int sps) { return (int64_t)stripes_for(tl) * sps * 4; }
+// packed16 layout: two dwords per lane per 8 steps, per group of two pairs
+__host__ __device__ inline int64_t tb_words16_for(int tl, int sps)
+{
+    return (((int64_t)stripes_for(tl) * sps + 7) >> 3) * 32;
+}
 
 int dp_lds_bytes(int sps_cap, int waves_per_block);
 int dp16_lds_bytes(int sps, int waves_per_block);

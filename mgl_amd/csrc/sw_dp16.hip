@@ -26,7 +26,9 @@
 //
 // Traceback layout ("packed16"): per group (= 2 pairs) one dword per lane per 4 steps,
 //   byte0 = pair A {E>S, F opened}, byte1 = pair B {same}, byte2 = pair A {F>diag, E opened}, byte3 = pair B,
-//   step t of the 4 in bits (2t+1, 2t).  A group stores 64 contiguous bytes every 4 steps.
+//   step t of the 4 in bits (2t+1, 2t).  Two such dwords are stored together (8 steps), so a group
+//   writes one full 128-byte line at a time (64-byte stores cost twice the HBM write traffic: PMC
+//   WRITE_SIZE of the first packed build, profiles/r01_b_packed16.txt).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -209,9 +211,10 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
     int bestA = NEG_INF, bestA_i = -1, bestB = NEG_INF, bestB_i = -1; // last-column maxima (scores)
 
     const int last_lane = (tl - 1) & 15;
-    // traceback words: group region + lane; one dword per lane per 4 steps (16 dwords per group block)
-    uint32_t *tbp = a.tb + (size_t)(gvalid ? gs : n_groups - 1) * a.tb_stride_words + L;
+    // traceback words: group region + lane; two dwords per lane per 8 steps (32 dwords per group block)
+    uint32_t *tbp = a.tb + (size_t)(gvalid ? gs : n_groups - 1) * a.tb_stride_words + L * 2;
     int gsteps = 0;
+    unsigned tb_hold = 0;
 
     int row_next = 1 + L;
     unsigned tt_next = (row_next <= tl) ? ((unsigned)tA[row_next - 1] | ((unsigned)tB[row_next - 1] << 16)) : 0u;
@@ -249,8 +252,12 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
         qrd += 4;                                                                                         \
         s += 4;                                                                                           \
         gsteps += 4;                                                                                      \
-        if (gvalid) *tbp = st.acc;                                                                        \
-        tbp += 16;                                                                                        \
+        if (gsteps & 4) {                                                                                 \
+            tb_hold = st.acc;                                                                             \
+        } else {                                                                                          \
+            if (gvalid) *reinterpret_cast<uint2 *>(tbp) = make_uint2(tb_hold, st.acc);                    \
+            tbp += 32;                                                                                    \
+        }                                                                                                 \
     }
         for (; s < 16;) MGL_SW_BLOCK16(true, true)
 #ifndef MGL_NO_UNROLL2
@@ -279,6 +286,8 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
             }
         }
     }
+
+    if ((gsteps & 4) && gvalid) *reinterpret_cast<uint2 *>(tbp) = make_uint2(tb_hold, 0u);
 
     // ---- both matrices are complete: last column max, last row scan (sw.cpp:100-127), per half
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

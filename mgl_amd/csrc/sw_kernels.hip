@@ -350,8 +350,9 @@ struct TbView {
         const int lane = r & 15;
         const int g = (r >> 4) * sps + j + lane;
         if (packed16) {
-            // sw_dp16.hip: dword per lane per 4 steps; byte h = {E>S, F opened}, byte 2+h = {F>diag, E opened}
-            const uint32_t w = base[(size_t)(g >> 2) * 16 + lane];
+            // sw_dp16.hip: dword per lane per 4 steps (two per 8-step block);
+            // byte h = {E>S, F opened}, byte 2+h = {F>diag, E opened}
+            const uint32_t w = base[(size_t)(g >> 3) * 32 + lane * 2 + ((g >> 2) & 1)];
             const int t2 = (g & 3) * 2;
             const unsigned be = (w >> (8 * half)) >> t2, bf = (w >> (16 + 8 * half)) >> t2;
             return ((bf >> 1) & 1u) | (((be >> 1) & 1u) << 1) | ((bf & 1u) << 2) | ((be & 1u) << 3);
