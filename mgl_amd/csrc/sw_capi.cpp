@@ -141,7 +141,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, msg);
     }
     // traceback words per pair (int32 layout) or per group of two pairs (packed16 layout)
-    const int64_t stride_words = use16 ? tb_words16_for(max_tl, sps_cap) : tb_words_for(max_tl, sps_cap);
+    const int64_t stride_words = use16 ? tb_words16_for(max_tl, max_ql) : tb_words_for(max_tl, sps_cap);
     const int64_t per_pair = stride_words * 4 / (use16 ? 2 : 1) + (int64_t)sizeof(DpRecord);
     // the workspace is split in two halves so that the traceback of one chunk can run (on ctx->aux)
     // while the next chunk is being filled; a batch that fits one half is a single chunk

@@ -19,8 +19,8 @@ struct Score {
 // what the fill kernel hands to the traceback kernel, one per pair (workspace)
 struct DpRecord {
     int32_t mqe, mqe_t, max, max_t, max_q, seg;
-    int32_t h_end; // H[tl][ql]
-    int32_t sps;   // anti-diagonal steps per stripe used by the wave that filled this pair
+    int32_t g_tail; // sw_dp16_kernel: global step at which the stand-alone tail stripes start (0: none chained)
+    int32_t sps;    // anti-diagonal steps per stripe (per chained stripe when g_tail > 0)
 };
 
 struct DpArgs {
@@ -64,11 +64,23 @@ __host__ __device__ inline int64_t tb_words_for(int tl, int sps)
     return (((int64_t)stripes_for(tl) * sps + 31) >> 5) * 64;
 }
 
-// packed16 layout: two dwords per lane per 8 steps, per group of two pairs
-__host__ __device__ inline int64_t tb_words16_for(int tl, int sps)
+// ---- schedule of sw_dp16_kernel (sw_dp16.hip): the first nc stripes run as one continuous pipeline with
+// period P steps per stripe (+ one 16-step drain window), the rest stand-alone with sps_for(ql) steps each
+__host__ __device__ inline int dp16_base(int tl, int gext) { return 32767 - gext * tl; }
+__host__ __device__ inline int dp16_period(int ql) { return (ql + 1 + 3) & ~3; }
+__host__ __device__ inline int dp16_chained_stripes(int tl, int ql)
 {
-    return (((int64_t)stripes_for(tl) * sps + 7) >> 3) * 32;
+    if (dp16_period(ql) < 32) return 0;          // the window needs P >= 32
+    const int n = stripes_for(tl);
+    return (tl & 15) == 0 ? n : n - 1;           // a partial last stripe runs stand-alone (other carry lane)
 }
+__host__ __device__ inline int64_t dp16_total_steps(int tl, int ql)
+{
+    const int n = stripes_for(tl), nc = dp16_chained_stripes(tl, ql);
+    return (nc ? (int64_t)nc * dp16_period(ql) + 16 : 0) + (int64_t)(n - nc) * sps_for(ql);
+}
+// packed16 layout: two dwords per lane per 8 steps, per group of two pairs
+__host__ __device__ inline int64_t tb_words16_for(int tl, int ql) { return ((dp16_total_steps(tl, ql) + 7) >> 3) * 32; }
 
 int dp_lds_bytes(int sps_cap, int waves_per_block);
 int dp16_lds_bytes(int sps, int waves_per_block);

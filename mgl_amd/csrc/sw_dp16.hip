@@ -40,7 +40,7 @@ namespace mgl_sw_dev {
 namespace {
 
 constexpr int DPP_ROW_SHR1 = 0x111;
-constexpr int RING_SLACK16 = 20, QQ_SLACK16 = 36;
+constexpr int RING_SLACK16 = 24, QQ_SLACK16 = 48;
 
 typedef short short2_t __attribute__((ext_vector_type(2)));
 typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
@@ -78,18 +78,65 @@ __device__ __forceinline__ int border(int k, int gopen, int gext, bool indel)
     return (indel && k > 0) ? -gopen - (k - 1) * gext : 0; // sw.cpp:29-40,47-49
 }
 
-__host__ __device__ inline int dp16_base(int tl, int gext) { return 32767 - gext * tl; }
-
 struct Lane16 {
-    unsigned h_prev, e_prev, hup, f; // packed A|B, column-shifted + biased
+    unsigned h_prev, e_prev, hup, f; // packed A|B, offset representation
     unsigned acc;                    // traceback flags of the current 4-step block
-    unsigned cap;                    // H of the last column (this stripe), packed
+    unsigned cap;                    // H of the last column (current stripe), packed
 };
 
 struct Consts16 {
     unsigned delta, one, o_e, o_f, e_f; // packed constants (both halves equal)
 };
 
+// mask bit set ? b : a   (mask is a wave-uniform 64-bit lane mask held in SGPRs: no VALU compare)
+__device__ __forceinline__ unsigned sel_mask(unsigned a, unsigned b, unsigned long long mask)
+{
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
+
+// The arithmetic of one anti-diagonal step for both packed pairs: returns H, E', F' of the cell and
+// shifts the four decision flags into st.acc.  rh / re: carry for lane 0 of each group.
+__device__ __forceinline__ void cell16(Lane16 &st, const unsigned rh, const unsigned re, const unsigned q,
+                                       const unsigned tt, const Consts16 &c, unsigned &h, unsigned &eo, unsigned &fo,
+                                       unsigned &hup_new)
+{
+    hup_new = row_shr1(rh, st.h_prev);
+    const unsigned ein = row_shr1(re, st.e_prev);
+    const unsigned m = pk_min_u(q ^ tt, c.one);         // 1 where the bases differ
+    const unsigned diag = pk_mad(m, c.delta, st.hup);   // + (mismatch - match) on a mismatch
+    const unsigned d1 = pk_sub_sat(diag, st.f);         // < 0 <=> F > diag
+    const unsigned sm = pk_max(diag, st.f);
+    const unsigned d2 = pk_sub_sat(sm, ein);            // < 0 <=> E > max(diag, F)
+    h = pk_max(sm, ein);
+    const unsigned open_e = pk_sub(h, c.o_e);
+    const unsigned open_f = pk_sub(h, c.o_f);
+    const unsigned d3 = pk_sub_sat(ein, open_e);        // < 0 <=> a new vertical gap wins
+    eo = pk_max(open_e, ein);                           // extension is free in this representation
+    const unsigned fe = pk_sub(st.f, c.e_f);
+    const unsigned d4 = pk_sub_sat(fe, open_f);         // < 0 <=> a new horizontal gap wins
+    fo = pk_max(open_f, fe);
+    // sign bytes: [d2.A, d2.B, d1.A, d1.B] and [d4.A, d4.B, d3.A, d3.B]
+    const unsigned p12 = __builtin_amdgcn_perm(d1, d2, 0x07050301u);
+    const unsigned p34 = __builtin_amdgcn_perm(d3, d4, 0x07050301u);
+    const unsigned y = (p12 & 0x80808080u) | ((p34 >> 1) & ~0x80808080u);      // v_bfi_b32
+    st.acc = (y & 0xC0C0C0C0u) | ((st.acc >> 2) & ~0xC0C0C0C0u);                // v_bfi_b32
+}
+
+__device__ __forceinline__ void commit16(Lane16 &st, unsigned h, unsigned eo, unsigned fo, unsigned hup_new)
+{
+    st.h_prev = h;
+    st.e_prev = eo;
+    st.hup = hup_new;
+    st.f = fo;
+}
+
+#define RING_U(u, A, B, x, z) ((u) == 0 ? (A).x : (u) == 1 ? (A).z : (u) == 2 ? (B).x : (B).z)
+
+// Stand-alone stripe (own pipeline fill and drain), four steps.
+//   PRO : some lane may still be at column <= 0 (forced border values)
+//   EPI : some lane may be at its last column (capture H[i][ql])
 template <bool PRO, bool EPI>
 __device__ __forceinline__ void step4_16(Lane16 &st, uint4 &ringA, uint4 &ringB, const uint4 *ring_next,
                                          const unsigned (&qq)[4], const unsigned tt, const int s0, const int L,
@@ -98,40 +145,79 @@ __device__ __forceinline__ void step4_16(Lane16 &st, uint4 &ringA, uint4 &ringB,
 {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const unsigned rh = u == 0 ? ringA.x : u == 1 ? ringA.z : u == 2 ? ringB.x : ringB.z;
-        const unsigned re = u == 0 ? ringA.y : u == 1 ? ringA.w : u == 2 ? ringB.y : ringB.w;
+        const unsigned rh = RING_U(u, ringA, ringB, x, z), re = RING_U(u, ringA, ringB, y, w);
         if (u == 2) ringA = ring_next[0];
-        const unsigned hup_new = row_shr1(rh, st.h_prev);
-        const unsigned ein = row_shr1(re, st.e_prev);
-        const unsigned m = pk_min_u(qq[u] ^ tt, c.one);     // 1 where the bases differ
-        const unsigned diag = pk_mad(m, c.delta, st.hup);   // + (mismatch - match) on a mismatch
-        const unsigned d1 = pk_sub_sat(diag, st.f);         // < 0 <=> F > diag
-        const unsigned sm = pk_max(diag, st.f);
-        const unsigned d2 = pk_sub_sat(sm, ein);            // < 0 <=> E > max(diag, F)
-        unsigned h = pk_max(sm, ein);
-        const unsigned open_e = pk_sub(h, c.o_e);
-        const unsigned open_f = pk_sub(h, c.o_f);
-        const unsigned d3 = pk_sub_sat(ein, open_e);        // < 0 <=> a new vertical gap wins
-        const unsigned eo = pk_max(open_e, ein);            // extension is free in this representation
-        const unsigned fe = pk_sub(st.f, c.e_f);
-        const unsigned d4 = pk_sub_sat(fe, open_f);         // < 0 <=> a new horizontal gap wins
-        unsigned fo = pk_max(open_f, fe);
+        unsigned h, eo, fo, hup_new;
+        cell16(st, rh, re, qq[u], tt, c, h, eo, fo, hup_new);
         if (PRO) {
             const bool at_border = (s0 + u) <= L; // column <= 0
             h = at_border ? hb : h;
             fo = at_border ? pk_sub(hb, c.o_f) : fo;
         }
-        // sign bytes: [d2.A, d2.B, d1.A, d1.B] and [d4.A, d4.B, d3.A, d3.B]
-        const unsigned p12 = __builtin_amdgcn_perm(d1, d2, 0x07050301u);
-        const unsigned p34 = __builtin_amdgcn_perm(d3, d4, 0x07050301u);
-        const unsigned y = (p12 & 0x80808080u) | ((p34 >> 1) & ~0x80808080u);      // v_bfi_b32
-        st.acc = (y & 0xC0C0C0C0u) | ((st.acc >> 2) & ~0xC0C0C0C0u);                // v_bfi_b32
         if (EPI) st.cap = ((s0 + u - L) == ql) ? h : st.cap;
         if (writer) ring_wr[u] = make_uint2(h, eo);
-        st.h_prev = h;
-        st.e_prev = eo;
-        st.hup = hup_new;
-        st.f = fo;
+        commit16(st, h, eo, fo, hup_new);
+    }
+    ringB = ring_next[1];
+}
+
+// Chained stripes, lean part of a period: no lane is at a border; with CAP the lanes that reach the
+// last column inside this block (lanes < P - ql, last block of the period) capture it.
+template <bool CAP>
+__device__ __forceinline__ void lean4_16(Lane16 &st, uint4 &ringA, uint4 &ringB, const uint4 *ring_next,
+                                         const unsigned (&qq)[4], const unsigned tt, const int col0, const int L,
+                                         const int ql, const Consts16 &c, uint2 *ring_wr, const bool writer)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const unsigned rh = RING_U(u, ringA, ringB, x, z), re = RING_U(u, ringA, ringB, y, w);
+        if (u == 2) ringA = ring_next[0];
+        unsigned h, eo, fo, hup_new;
+        cell16(st, rh, re, qq[u], tt, c, h, eo, fo, hup_new);
+        if (CAP) st.cap = ((col0 + u - L) == ql) ? h : st.cap;
+        if (writer) ring_wr[u] = make_uint2(h, eo);
+        commit16(st, h, eo, fo, hup_new);
+    }
+    ringB = ring_next[1];
+}
+
+// Chained stripes, the 16-step window that opens period k: at window step u lane u leaves stripe k-1
+// and starts stripe k at column 0 (forced border), lane u + (P - ql) is at the last column of stripe
+// k-1.  All lane selections use constant SGPR masks.  Block b covers window steps 4b .. 4b+3.
+//   FIRST : k == 0, nothing to finish or publish yet (lane 15 has not started)
+//   LAST  : k == number of chained stripes: lanes leave into nothing; lane 15 must not publish column 0
+template <int B, bool FIRST, bool LAST>
+__device__ __forceinline__ void window4_16(Lane16 &st, uint4 &ringA, uint4 &ringB, const uint4 *ring_next,
+                                           const unsigned (&qq)[4], unsigned &tt, const unsigned tt_nxt,
+                                           const unsigned hb_nxt, const unsigned hbf_nxt, const int cgap,
+                                           const Consts16 &c, uint2 *ring_wr_tail, uint2 *ring_col0, const bool lane15)
+{
+    constexpr unsigned long long ROWS = 0x0001000100010001ull; // lane 0 of every 16-lane row
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int u = 4 * B + t;
+        const unsigned rh = RING_U(t, ringA, ringB, x, z), re = RING_U(t, ringA, ringB, y, w);
+        if (t == 2) ringA = ring_next[0];
+        unsigned h, eo, fo, hup_new;
+        cell16(st, rh, re, qq[t], tt, c, h, eo, fo, hup_new);
+        const unsigned long long m_u = ROWS << u;
+        if (!FIRST) {
+            // lane u + cgap sits on column ql of the stripe it is finishing
+            const int cl = u + cgap;
+            const unsigned long long m_cap = cl < 16 ? ROWS << cl : 0ull;
+            st.cap = sel_mask(st.cap, h, m_cap);
+        }
+        // lane u: column 0 of its next row -- H[i][0] and F[i][1] are border values (sw.cpp:24,38,47-49)
+        h = sel_mask(h, hb_nxt, m_u);
+        fo = sel_mask(fo, hbf_nxt, m_u);
+        tt = sel_mask(tt, tt_nxt, m_u);
+        // lane 15 publishes the carry of the stripe it is finishing (columns P-15+u), then column 0 of the new one
+        if (!FIRST && u < 15) {
+            if (lane15) ring_wr_tail[u] = make_uint2(h, eo);
+        } else if (!LAST && u == 15) {
+            if (lane15) ring_col0[0] = make_uint2(h, eo);
+        }
+        commit16(st, h, eo, fo, hup_new);
     }
     ringB = ring_next[1];
 }
@@ -167,10 +253,12 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
     const uint8_t *qA = a.queries + a.q_off[pA], *qB = a.queries + a.q_off[pB];
 
     const int nstripes = stripes_for(tl);
-    const int sps = sps_for(ql);
+    const int sps = sps_for(ql);              // steps of a stand-alone stripe
+    const int P = dp16_period(ql);            // steps per chained stripe
+    const int nc = dp16_chained_stripes(tl, ql);
     const int main_end = max(16, ql & ~3);
 
-    // LDS carve per group: ring uint2[sps+20] (H, E' packed A|B per column) | qq uint32[sps+36]
+    // LDS carve per group: ring uint2[sps+20] (H, E' packed A|B per column) | qq uint32[sps+48]
     const int ring_entries = sps + RING_SLACK16;
     const int qq_entries = sps + QQ_SLACK16;
     const int group_bytes = ring_entries * 8 + qq_entries * 4;
@@ -190,9 +278,12 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
     c.e_f = pack2(gext + colw, gext + colw);
     asm volatile("" : "+v"(c.delta), "+v"(c.one), "+v"(c.o_e), "+v"(c.o_f), "+v"(c.e_f));
 
-    // ---- stage the two queries interleaved, and the border row (sw.cpp:14-18,31-35) in stored form
+    // ---- stage the two queries interleaved.  qq[x] is the base of column x - 15 (x - 16 as 0-based query
+    // index); beyond column P - 1 the array repeats with period P, so a chained lane keeps incrementing its
+    // read pointer across the end of a row.  Then the border row (sw.cpp:14-18,31-35) in stored form.
     for (int x = L; x < qq_entries; x += 16) {
-        const int cidx = x - 16;
+        int cidx = x - 16;
+        if (nc && cidx >= P - 1) cidx -= P;
         unsigned v = 0;
         if (cidx >= 0 && cidx < ql) v = (unsigned)qA[cidx] | ((unsigned)qB[cidx] << 16);
         qq[x] = v;
@@ -208,6 +299,7 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
     Lane16 st;
     st.h_prev = st.e_prev = st.hup = st.f = 0;
     st.acc = 0;
+    st.cap = 0;
     int bestA = NEG_INF, bestA_i = -1, bestB = NEG_INF, bestB_i = -1; // last-column maxima (scores)
 
     const int last_lane = (tl - 1) & 15;
@@ -216,10 +308,128 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
     int gsteps = 0;
     unsigned tb_hold = 0;
 
-    int row_next = 1 + L;
+#define MGL_TB_ADVANCE()                                                                                  \
+    {                                                                                                     \
+        gsteps += 4;                                                                                      \
+        if (gsteps & 4) {                                                                                 \
+            tb_hold = st.acc;                                                                             \
+        } else {                                                                                          \
+            if (gvalid) *reinterpret_cast<uint2 *>(tbp) = make_uint2(tb_hold, st.acc);                    \
+            tbp += 32;                                                                                    \
+        }                                                                                                 \
+    }
+// last column of a finished stripe row (sw.cpp:100-104: >= so the later row wins); rows carry different
+// offsets, so compare scores, not stored values
+#define MGL_TAKE_CAP(row)                                                                                 \
+    if ((row) >= 1 && (row) <= tl) {                                                                      \
+        const int unshift = ql * colw - (row) * gext - base;                                              \
+        const int ca = lo16(st.cap) + unshift, cb = hi16(st.cap) + unshift;                               \
+        if (ca >= bestA) {                                                                                \
+            bestA = ca;                                                                                   \
+            bestA_i = (row);                                                                              \
+        }                                                                                                 \
+        if (cb >= bestB) {                                                                                \
+            bestB = cb;                                                                                   \
+            bestB_i = (row);                                                                              \
+        }                                                                                                 \
+    }
+
+    int row_next = 1 + L; // row this lane takes in the next stripe
     unsigned tt_next = (row_next <= tl) ? ((unsigned)tA[row_next - 1] | ((unsigned)tB[row_next - 1] << 16)) : 0u;
 
-    for (int k = 0; k < nstripes; ++k) {
+    // ======================= chained stripes 0 .. nc-1: one continuous systolic pipeline =======================
+    if (nc > 0) {
+        const bool lane15 = (L == 15);
+        const int cgap = P - ql;                              // 1..4: columns between ql and the end of a period
+        const unsigned *qrd = qq + 15 - L;                    // window step u of lane L reads column u - L (+P before it wraps)
+        const uint4 *ring_c0 = reinterpret_cast<const uint4 *>(ring + 16);
+        uint4 rA = ring_c0[0], rB = ring_c0[1];
+        // a lane that has not wrapped yet is P columns further: qq is periodic, so read there
+        const unsigned *qcur = qrd + P;
+        unsigned qv[4] = {qcur[0], qcur[1], qcur[2], qcur[3]};
+        unsigned tt = 0;
+        for (int k = 0; k <= nc; ++k) {
+            // ---- what every lane adopts when it wraps inside this window
+            const int row_new = row_next;
+            const unsigned tt_new = tt_next;
+            const int hbv = border(row_new, gopen, gext, indel) + row_new * gext + base; // column 0 of the new row
+            const unsigned hb_new = pack2(hbv, hbv);
+            const unsigned hbf_new = pk_sub(hb_new, c.o_f);
+            if (k < nc) {
+                row_next += 16;
+                tt_next = (row_next <= tl) ? ((unsigned)tA[row_next - 1] | ((unsigned)tB[row_next - 1] << 16)) : 0u;
+            }
+            const uint4 *ring_rd = ring_c0;              // lane 0 is at column 0 when the window opens
+            uint2 *ring_tail = ring + 16 + (P - 15);     // lane 15: columns P-15 .. P-1 of the stripe it finishes
+#define MGL_WINDOW_BLOCK(B, FIRST, LAST)                                                                  \
+    {                                                                                                     \
+        const unsigned n0 = qcur[4], n1 = qcur[5], n2 = qcur[6], n3 = qcur[7];                            \
+        window4_16<B, FIRST, LAST>(st, rA, rB, ring_rd + 2, qv, tt, tt_new, hb_new, hbf_new, cgap, c,     \
+                                   ring_tail, ring + 16, lane15);                                         \
+        qv[0] = n0;                                                                                       \
+        qv[1] = n1;                                                                                       \
+        qv[2] = n2;                                                                                       \
+        qv[3] = n3;                                                                                       \
+        ring_rd += 2;                                                                                     \
+        qcur += 4;                                                                                        \
+        MGL_TB_ADVANCE()                                                                                  \
+    }
+            if (k == 0) {
+                MGL_WINDOW_BLOCK(0, true, false)
+                MGL_WINDOW_BLOCK(1, true, false)
+                MGL_WINDOW_BLOCK(2, true, false)
+                MGL_WINDOW_BLOCK(3, true, false)
+            } else if (k == nc) {
+                MGL_WINDOW_BLOCK(0, false, true)
+                MGL_WINDOW_BLOCK(1, false, true)
+                MGL_WINDOW_BLOCK(2, false, true)
+                MGL_WINDOW_BLOCK(3, false, true)
+            } else {
+                MGL_WINDOW_BLOCK(0, false, false)
+                MGL_WINDOW_BLOCK(1, false, false)
+                MGL_WINDOW_BLOCK(2, false, false)
+                MGL_WINDOW_BLOCK(3, false, false)
+            }
+#undef MGL_WINDOW_BLOCK
+            // every lane has now finished its row of stripe k-1 ...
+            if (k > 0) {
+                // lanes below cgap captured in the last lean block of the previous period, the others in this window
+                MGL_TAKE_CAP(row_new - 16)
+            }
+            if (k == nc) break;
+            // ... and is inside stripe k: all read pointers are one period too far, bring them back
+            qcur -= P;
+
+            // ---- lean part of the period: columns 16 .. P-1 for lane 0
+            uint2 *ring_wr = ring + 16 + 1;              // lane 15 is at column s - 15
+            int s = 16;
+#define MGL_LEAN_BLOCK(CAP, NEXT)                                                                         \
+    {                                                                                                     \
+        const unsigned n0 = qcur[4], n1 = qcur[5], n2 = qcur[6], n3 = qcur[7];                            \
+        lean4_16<CAP>(st, rA, rB, NEXT, qv, tt, s, L, ql, c, ring_wr, lane15);                            \
+        qv[0] = n0;                                                                                       \
+        qv[1] = n1;                                                                                       \
+        qv[2] = n2;                                                                                       \
+        qv[3] = n3;                                                                                       \
+        ring_rd += 2;                                                                                     \
+        ring_wr += 4;                                                                                     \
+        qcur += 4;                                                                                        \
+        s += 4;                                                                                           \
+        MGL_TB_ADVANCE()                                                                                  \
+    }
+            for (; s + 12 <= P;) {
+                MGL_LEAN_BLOCK(false, ring_rd + 2)
+                MGL_LEAN_BLOCK(false, ring_rd + 2)
+            }
+            for (; s + 8 <= P;) MGL_LEAN_BLOCK(false, ring_rd + 2)
+            // last block of the period: the next block is the window of period k+1 (lane 0 back at column 0)
+            MGL_LEAN_BLOCK(true, ring_c0)
+#undef MGL_LEAN_BLOCK
+        }
+    }
+
+    // ======================= remaining stripes stand-alone (partial last stripe, or short queries) =============
+    for (int k = nc; k < nstripes; ++k) {
         const int row_i = row_next;
         const unsigned tt = tt_next;
         row_next += 16;
@@ -229,7 +439,6 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
         const unsigned hb = pack2(hbv, hbv);
         const int wl = (k == nstripes - 1) ? last_lane : 15;
         const bool writer = (L == wl);
-        const bool cap_valid = row_i <= tl;
         st.cap = 0;
 
         const uint4 *ring_rd = reinterpret_cast<const uint4 *>(ring + 16);
@@ -251,43 +460,26 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
         ring_wr += 4;                                                                                     \
         qrd += 4;                                                                                         \
         s += 4;                                                                                           \
-        gsteps += 4;                                                                                      \
-        if (gsteps & 4) {                                                                                 \
-            tb_hold = st.acc;                                                                             \
-        } else {                                                                                          \
-            if (gvalid) *reinterpret_cast<uint2 *>(tbp) = make_uint2(tb_hold, st.acc);                    \
-            tbp += 32;                                                                                    \
-        }                                                                                                 \
+        MGL_TB_ADVANCE()                                                                                  \
     }
         for (; s < 16;) MGL_SW_BLOCK16(true, true)
-#ifndef MGL_NO_UNROLL2
         // two blocks per trip: the one-block-ahead prefetch registers alternate instead of being copied
         for (; s + 8 <= main_end;) {
             MGL_SW_BLOCK16(false, false)
             MGL_SW_BLOCK16(false, false)
         }
-#endif
         for (; s < main_end;) MGL_SW_BLOCK16(false, false)
         for (; s < sps;) MGL_SW_BLOCK16(false, true)
 #undef MGL_SW_BLOCK16
-
-        // last column of this stripe's rows (sw.cpp:100-104: >= so the later row wins); rows carry
-        // different offsets, so compare scores, not stored values
-        if (cap_valid) {
-            const int unshift = ql * colw - row_i * gext - base;
-            const int ca = lo16(st.cap) + unshift, cb = hi16(st.cap) + unshift;
-            if (ca >= bestA) {
-                bestA = ca;
-                bestA_i = row_i;
-            }
-            if (cb >= bestB) {
-                bestB = cb;
-                bestB_i = row_i;
-            }
-        }
+        MGL_TAKE_CAP(row_i)
     }
+#undef MGL_TB_ADVANCE
+#undef MGL_TAKE_CAP
 
     if ((gsteps & 4) && gvalid) *reinterpret_cast<uint2 *>(tbp) = make_uint2(tb_hold, 0u);
+
+    // global step at which the stand-alone stripes start (the traceback kernel needs it to find their cells)
+    const int g_tail = nc ? nc * P + 16 : 0;
 
     // ---- both matrices are complete: last column max, last row scan (sw.cpp:100-127), per half
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -330,9 +522,8 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
             r.max_t = row_wins ? tl : mqe_t;
             r.max_q = row_wins ? rj : ql;
             r.seg = row_wins ? ql - rj : 0;
-            const unsigned xe = ring[ql + 16].x;
-            r.h_end = (half ? hi16(xe) : lo16(xe)) + ql * colw - tl * gext - base;
-            r.sps = sps;
+            r.g_tail = g_tail;
+            r.sps = nc ? P : sps;
             a.rec[half ? slotB : slotA] = r;
         }
     }

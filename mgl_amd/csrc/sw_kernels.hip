@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
                 r.max_t = row_wins ? tl : mqe_t;
                 r.max_q = row_wins ? rj : ql;
                 r.seg = row_wins ? ql - rj : 0;
-                r.h_end = ring[ql + 16].x;
+                r.g_tail = 0;
                 r.sps = sps;
                 a.rec[slot] = r;
             }
@@ -343,12 +343,21 @@ struct TbView {
     const uint32_t *base; // this pair's (int32 layout) or this group's (packed16 layout) traceback words
     int sps;
     int packed16, half;
+    int g_tail, nc, sps_tail; // packed16 only: stripes >= nc are stand-alone, starting at global step g_tail
+    __device__ __forceinline__ void set_schedule(const DpRecord &r, int ql)
+    {
+        sps = r.sps;
+        g_tail = r.g_tail;
+        nc = r.g_tail > 0 ? (r.g_tail - 16) / r.sps : 0;
+        sps_tail = sps_for(ql);
+    }
     // nibble of cell (i, j), 1-based: bit0 F>diag, bit1 E>max(diag,F), bit2 E opened, bit3 F opened
     __device__ __forceinline__ unsigned cell(int i, int j) const
     {
         const int r = i - 1;
         const int lane = r & 15;
-        const int g = (r >> 4) * sps + j + lane;
+        const int k = r >> 4;
+        const int g = (g_tail > 0 && k >= nc ? g_tail + (k - nc) * sps_tail : k * sps) + j + lane;
         if (packed16) {
             // sw_dp16.hip: dword per lane per 4 steps (two per 8-step block);
             // byte h = {E>S, F opened}, byte 2+h = {F>diag, E opened}
@@ -510,7 +519,7 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
 
     BitsMoves mv;
     mv.tb.base = a.tb + (size_t)(a.packed16 ? slot >> 1 : slot) * a.tb_stride_words;
-    mv.tb.sps = r.sps;
+    mv.tb.set_schedule(r, ql);
     mv.tb.packed16 = a.packed16;
     mv.tb.half = (int)(slot & 1);
 
@@ -567,7 +576,7 @@ __global__ __launch_bounds__(256) void sw_expand_kernel(const uint32_t *tbw, con
     const int i = idx / ql + 1, j = idx % ql + 1;
     TbView tb;
     tb.base = tbw;
-    tb.sps = rec[0].sps;
+    tb.set_schedule(rec[0], ql);
     tb.packed16 = packed16;
     tb.half = half;
     const unsigned c = tb.cell(i, j);

@@ -221,7 +221,11 @@ def _uniform_batch(rng, n, tl, ql, alphabet=b"ACGT", related=True):
 
 
 @pytest.mark.parametrize("tl,ql", [(256, 150), (1000, 150), (16, 16), (17, 15), (1, 1), (5, 3), (33, 8), (64, 65),
-                                   (100, 151), (300, 7)])
+                                   (100, 151), (300, 7),
+                                   # chained-stripe schedule of sw_dp16_kernel: every gap P - ql in 1..4, whole and
+                                   # partial last stripes, the shortest period (32), one / two stripes
+                                   (256, 147), (256, 149), (256, 151), (256, 152), (250, 150), (32, 28), (48, 31),
+                                   (16, 150), (15, 150), (31, 40), (160, 27)])
 def test_packed16_uniform_batches(aligner, tl, ql):
     rng = np.random.default_rng(tl * 1000 + ql)
     n = 37  # odd: the last group has a lone pair
