@@ -1,0 +1,147 @@
+"""BASELINE.json configs[1] at FULL size (10 M pairs of 150 bp x 256 bases) on the GPU.
+
+The oracle cannot run 3.8e11 cells in a test, so the whole batch is checked through size-independent
+properties, and the oracle is used on a sample spread over the batch:
+  * every pair: status 0, CIGAR present, offset inside the window, score bounds;
+  * every pair: the result arrays are bit-identical between two runs, between a 2 GiB and an 8 GiB
+    traceback workspace (different chunking) and -- on a 1 M-pair slice -- between the packed-int16 and
+    the int32 fill kernels (a checksum of all result bytes);
+  * sampled pairs: the CIGAR consumes exactly the read (M+I+S = ql), stays inside the window
+    (offset + M + D <= tl), and re-scoring the alignment it spells out from the two sequences gives
+    exactly ScoreMax.max; 2 000 of them are compared field by field with the oracle.
+"""
+import re
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as ol
+from mgl_amd import device_batch, smithwaterman as sw
+
+pytestmark = pytest.mark.gpu
+
+N_FULL = 10_000_000
+TL, QL = 256, 150
+M, X, O, E = 200, -150, 260, 11
+
+
+def digest(b):
+    """CRC of every output byte of a batch (offsets, scores, CIGAR slots, lengths)."""
+    crc = 0
+    for t in (b.offsets, b.scores, b.cigar_len, b.status):
+        crc = zlib.crc32(t.cpu().numpy().tobytes(), crc)
+    # CIGAR slots are 640 MB: fold them on the GPU first (sum of 64-bit words, order independent per row)
+    words = b.cigars.view(torch.int64)
+    folded = (words * torch.arange(1, words.shape[1] + 1, device=words.device, dtype=torch.int64)).sum(1)
+    return zlib.crc32(folded.cpu().numpy().tobytes(), crc)
+
+
+def rescore(t, q, cigar, offset):
+    """Score of the alignment a SOFTCLIP CIGAR spells out: match/mismatch per M column, o+(k-1)e per gap."""
+    i, j, score = offset, 0, 0
+    for n, op in re.findall(r"(\d+)([MIDS])", cigar):
+        n = int(n)
+        if op == "S":
+            j += n
+        elif op == "M":
+            a = np.frombuffer(t[i:i + n], np.uint8)
+            b = np.frombuffer(q[j:j + n], np.uint8)
+            eq = int((a == b).sum())
+            score += eq * M + (n - eq) * X
+            i += n
+            j += n
+        elif op == "I":
+            score -= O + (n - 1) * E
+            j += n
+        else:
+            score -= O + (n - 1) * E
+            i += n
+    return score, i, j
+
+
+@pytest.fixture(scope="module")
+def full():
+    dev = torch.device("cuda", 0)
+    a = sw.MicrosoftSmithWaterman(0)
+    a.set_workspace(8 << 30)
+    b = device_batch.window_batch(42, N_FULL, dev, window=TL, read_len=QL)
+    b.run(a)
+    torch.cuda.synchronize()
+    yield a, b
+    a.close()
+
+
+def test_fullsize_global_invariants(full):
+    a, b = full
+    assert a.timing().packed16 == 1
+    assert int((b.status != 0).sum()) == 0
+    ln = b.cigar_len
+    assert int(ln.min()) >= 2 and int(ln.max()) <= b.cigar_stride
+    off = b.offsets
+    assert int(off.min()) >= 0 and int(off.max()) <= TL
+    sc = b.scores
+    assert int(sc[:, 2].max()) <= M * QL and int(sc[:, 2].min()) > -O - (TL + QL) * E
+    assert bool((sc[:, 2] >= sc[:, 0]).all())          # max >= mqe (sw.cpp:116)
+    assert bool(((sc[:, 1] >= 1) & (sc[:, 1] <= TL)).all())
+    assert bool(((sc[:, 4] >= 1) & (sc[:, 4] <= QL)).all())
+    assert bool((sc[:, 5] == QL - sc[:, 4]).logical_or(sc[:, 5] == 0).all())
+    # bytes after the reported length are zero (the Java side trims them, MicrosoftSmithWaterman.java:85)
+    col = torch.arange(b.cigar_stride, device=ln.device)[None, :]
+    assert int(((b.cigars != 0) & (col >= ln[:, None])).sum()) == 0
+
+
+def test_fullsize_reproducible_and_chunking_invariant(full):
+    a, b = full
+    d0 = digest(b)
+    b.run(a)
+    torch.cuda.synchronize()
+    assert digest(b) == d0, "two runs of the same batch differ"
+    small = sw.MicrosoftSmithWaterman(0)
+    small.set_workspace(2 << 30)
+    b.run(small)
+    torch.cuda.synchronize()
+    assert digest(b) == d0, "results depend on the workspace chunking"
+    small.close()
+
+
+def test_fullsize_int16_equals_int32_on_a_slice(full):
+    a, b = full
+    n = 1_000_000
+    sl = device_batch.DeviceBatch(b.targets[: n * TL], b.t_off[: n + 1], b.queries[: n * QL], b.q_off[: n + 1], TL, QL,
+                                  b.cigar_stride, uniform=True)
+    sl.run(a)
+    torch.cuda.synchronize()
+    assert a.timing().packed16 == 1
+    d16 = digest(sl)
+    forced = sw.MicrosoftSmithWaterman(0)
+    forced.set_precision(32)
+    sl.run(forced)
+    torch.cuda.synchronize()
+    assert forced.timing().packed16 == 0
+    assert digest(sl) == d16
+    forced.close()
+    # and the slice equals the corresponding part of the full run
+    b.run(a)
+    torch.cuda.synchronize()
+    assert torch.equal(sl.offsets, b.offsets[:n]) and torch.equal(sl.scores, b.scores[:n])
+    assert torch.equal(sl.cigars, b.cigars[:n])
+
+
+def test_fullsize_sample_rescoring_and_oracle(full):
+    a, b = full
+    rng = np.random.default_rng(5)
+    idx = np.sort(rng.choice(N_FULL, size=20_000, replace=False))
+    ts, qs = b.host_pairs(idx)
+    cig = b.cigar_strings(idx)
+    off = b.offsets[idx].cpu().numpy()
+    sc = b.scores[idx].cpu().numpy()
+    for k in range(len(idx)):
+        score, i_end, j_end = rescore(ts[k], qs[k], cig[k], int(off[k]))
+        assert j_end == QL, (idx[k], cig[k])
+        assert i_end <= TL and i_end == sc[k, 3], (idx[k], cig[k], off[k])
+        assert score == sc[k, 2], (idx[k], cig[k], score, sc[k])
+    sub = slice(0, 2000)
+    o_off, o_sc, o_cg = ol.oracle_align_batch(ts[sub], qs[sub], (M, X, O, E), ol.SOFTCLIP, nthreads=8)
+    assert (o_off == off[sub]).all() and (o_sc == sc[sub]).all() and o_cg == cig[sub]
