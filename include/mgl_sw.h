@@ -87,10 +87,11 @@ int mgl_sw_ctx_set_workspace(mgl_sw_ctx *ctx, int64_t bytes);
  * the same tl and ql and the score range fits 16 bits, else int32; 32 = always int32.  Results are
  * bit-identical either way. */
 int mgl_sw_ctx_set_precision(mgl_sw_ctx *ctx, int bits);
-/* 1 = per-kernel HIP-event timing (costs a stream sync per chunk); 2 = additionally stamp the shader
- * clock inside the fill kernel (diagnostic; a few extra instructions per workgroup); 0 = off */
+/* 1 = HIP events around every kernel launch of a call, on the streams the kernels run on, read back by
+ * mgl_sw_ctx_get_timing (the call itself stays asynchronous); 2 = additionally stamp the shader clock
+ * inside the fill kernel (diagnostic; a few extra instructions per workgroup); 0 = off */
 int mgl_sw_ctx_set_profiling(mgl_sw_ctx *ctx, int enable);
-int mgl_sw_ctx_get_timing(const mgl_sw_ctx *ctx, mgl_sw_timing *out);
+int mgl_sw_ctx_get_timing(mgl_sw_ctx *ctx, mgl_sw_timing *out); /* waits for the last call's kernels */
 
 /* Sign normalisation of the JNI boundary
  * (..._MicrosoftSmithWaterman.cpp:51-55): match > 0, mismatch < 0, open > 0,

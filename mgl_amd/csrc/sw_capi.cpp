@@ -59,6 +59,11 @@ struct mgl_sw_ctx {
     hipEvent_t fill_done[2] = {nullptr, nullptr};    // fill of the chunk in half h finished (caller's stream)
     hipEvent_t tb_done[2] = {nullptr, nullptr};      // traceback of the chunk in half h finished (aux stream)
     int last_half = 0;
+    // profiling: event pairs around every fill (caller's stream) and traceback (aux or caller's stream) launch of
+    // the last call; read back lazily by mgl_sw_ctx_get_timing so that the run itself is not serialised
+    std::vector<hipEvent_t> pool;
+    int pool_used = 0;
+    int64_t diag_blocks = 0;
     DevBuf d_t, d_toff, d_q, d_qoff, d_off, d_score, d_cig, d_len, d_status, d_btr; // host-API staging
     int64_t last_stride_words = 0, last_chunk_count = 0; // geometry of the last chunk (for expand_slot)
     int last_packed16 = 0;
@@ -148,7 +153,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
     int64_t chunk = std::max<int64_t>(16, ctx->ws_limit / 2 / per_pair);
     chunk = std::min<int64_t>(chunk, n);
     chunk = (chunk + 15) / 16 * 16;
-    const bool overlap = ctx->profiling == 0 && n > chunk;
+    const bool overlap = n > chunk;
     const int halves = n > chunk ? 2 : 1;
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -159,6 +164,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
 
     ctx->timing = mgl_sw_timing{};
     ctx->timing.cells = cells_hint;
+    ctx->pool_used = 0;
 
     bool tb_pending[2] = {false, false};
     int64_t k = 0;
@@ -208,39 +214,33 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
         ta.cigar_len = d_cigar_len;
         ta.status = d_status;
 
+        hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (ctx->profiling) {
+            while ((int)ctx->pool.size() < ctx->pool_used + 4) {
+                hipEvent_t e = nullptr;
+                HIP_TRY(ctx, hipEventCreate(&e));
+                ctx->pool.push_back(e);
+            }
+            for (int i = 0; i < 4; ++i) pe[i] = ctx->pool[(size_t)ctx->pool_used + i];
+            ctx->pool_used += 4;
+            ctx->diag_blocks = n_blocks;
+        }
+        hipStream_t tb_stream = overlap ? ctx->aux : stream;
+        // this half was last read by the traceback of chunk k-2
+        if (overlap && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->tb_done[h], 0));
+        if (pe[0]) HIP_TRY(ctx, hipEventRecord(pe[0], stream));
+        HIP_TRY(ctx, use16 ? launch_dp16(da, wpb, stream) : launch_dp(da, wpb, stream));
+        if (pe[1]) HIP_TRY(ctx, hipEventRecord(pe[1], stream));
         if (overlap) {
-            // this half was last read by the traceback of chunk k-2
-            if (tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->tb_done[h], 0));
-            HIP_TRY(ctx, use16 ? launch_dp16(da, wpb, stream) : launch_dp(da, wpb, stream));
             HIP_TRY(ctx, hipEventRecord(ctx->fill_done[h], stream));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->fill_done[h], 0));
-            HIP_TRY(ctx, launch_traceback(ta, ctx->aux));
+        }
+        if (pe[2]) HIP_TRY(ctx, hipEventRecord(pe[2], tb_stream));
+        HIP_TRY(ctx, launch_traceback(ta, tb_stream));
+        if (pe[3]) HIP_TRY(ctx, hipEventRecord(pe[3], tb_stream));
+        if (overlap) {
             HIP_TRY(ctx, hipEventRecord(ctx->tb_done[h], ctx->aux));
             tb_pending[h] = true;
-        } else {
-            if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
-            HIP_TRY(ctx, use16 ? launch_dp16(da, wpb, stream) : launch_dp(da, wpb, stream));
-            if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
-            HIP_TRY(ctx, launch_traceback(ta, stream));
-        }
-        if (ctx->profiling) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
-            HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2]));
-            float a = 0.f, b = 0.f;
-            HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
-            HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
-            ctx->timing.dp_ms += a;
-            ctx->timing.tb_ms += b;
-            if (da.diag) {
-                std::vector<unsigned long long> h((size_t)n_blocks * 2);
-                HIP_TRY(ctx, hipMemcpy(h.data(), da.diag, h.size() * 8, hipMemcpyDeviceToHost));
-                double cyc = 0, real = 0;
-                for (int64_t i = 0; i < n_blocks; ++i) {
-                    cyc += (double)h[2 * i];
-                    real += (double)h[2 * i + 1];
-                }
-                if (real > 0) ctx->timing.clock_mhz = (int32_t)(cyc / real * 100.0); // s_memrealtime ticks at 100 MHz
-            }
         }
         ctx->last_stride_words = stride_words;
         ctx->last_chunk_count = count;
@@ -334,6 +334,8 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
         b->release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->pool)
+        if (e) (void)hipEventDestroy(e);
     for (auto *set : {ctx->fill_done, ctx->tb_done})
         for (int h = 0; h < 2; ++h)
             if (set[h]) (void)hipEventDestroy(set[h]);
@@ -368,9 +370,36 @@ int mgl_sw_ctx_set_profiling(mgl_sw_ctx *ctx, int enable)
     return MGL_SW_OK;
 }
 
-int mgl_sw_ctx_get_timing(const mgl_sw_ctx *ctx, mgl_sw_timing *out)
+int mgl_sw_ctx_get_timing(mgl_sw_ctx *ctx, mgl_sw_timing *out)
 {
     if (!ctx || !out) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->pool_used > 0) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        float dp = 0.f, tb = 0.f;
+        for (int i = 0; i + 3 < ctx->pool_used; i += 4) {
+            float a = 0.f, b = 0.f;
+            HIP_TRY(ctx, hipEventSynchronize(ctx->pool[(size_t)i + 3]));
+            HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->pool[(size_t)i], ctx->pool[(size_t)i + 1]));
+            HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->pool[(size_t)i + 2], ctx->pool[(size_t)i + 3]));
+            dp += a;
+            tb += b;
+        }
+        ctx->timing.dp_ms = dp;
+        ctx->timing.tb_ms = tb;
+        if (ctx->profiling >= 2 && ctx->diag.p && ctx->diag_blocks > 0) {
+            // in-kernel clock of the last chunk's fill launch
+            std::vector<unsigned long long> h((size_t)ctx->diag_blocks * 2);
+            HIP_TRY(ctx, hipMemcpy(h.data(), ctx->diag.p, h.size() * 8, hipMemcpyDeviceToHost));
+            double cyc = 0, real = 0;
+            for (int64_t i = 0; i < ctx->diag_blocks; ++i) {
+                cyc += (double)h[2 * i];
+                real += (double)h[2 * i + 1];
+            }
+            if (real > 0) ctx->timing.clock_mhz = (int32_t)(cyc / real * 100.0); // s_memrealtime ticks at 100 MHz
+        }
+        ctx->pool_used = 0;
+    }
     *out = ctx->timing;
     return MGL_SW_OK;
 }
