@@ -110,6 +110,18 @@ int mgl_sw_align(const char *t, int tl, const char *q, int ql, int match, int mi
                  mgl_sw_score *ez);
 
 /*
+ * Coalescing of concurrent one-pair calls (the way GATK drives alignNative: many threads, one pair each,
+ * MicrosoftSmithWaterman.java:66-86).  With max_batch > 0 every mgl_sw_align call (hence the JNI export)
+ * is parked and merged with the calls of other threads that use the same parameters and strategy into one
+ * device batch, flushed when max_batch calls are waiting or the oldest has waited max_wait_us.  Results are
+ * exactly those of the direct call.  max_batch = 0 switches it off again.  Also enabled at load time by the
+ * environment variables MGL_SW_COALESCE_US (and MGL_SW_COALESCE_BATCH, default 4096).
+ */
+int mgl_sw_set_coalescing(int max_batch, int max_wait_us);
+/* device batches flushed / pairs served by the coalescer so far */
+int mgl_sw_coalescing_stats(int64_t *batches, int64_t *pairs);
+
+/*
  * Batch, host buffers.  Pair k is targets[t_off[k] .. t_off[k+1]) against
  * queries[q_off[k] .. q_off[k+1]) (raw bytes, compared for equality exactly
  * as sw.cpp:55).  One parameter set and strategy per batch.  cigar_out is

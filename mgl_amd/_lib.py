@@ -22,7 +22,7 @@ SYMBOLS = (
     "mgl_sw_ctx_destroy", "mgl_sw_last_error", "mgl_sw_ctx_set_workspace", "mgl_sw_ctx_set_profiling", "mgl_sw_ctx_set_precision",
     "mgl_sw_ctx_get_timing", "mgl_sw_normalize_params", "mgl_sw_align", "mgl_sw_align_batch",
     "mgl_sw_align_batch_device", "mgl_sw_backtrack_matrix", "mgl_sw_ctx_expand_slot",
-    "mgl_sw_cigar_from_backtrack",
+    "mgl_sw_cigar_from_backtrack", "mgl_sw_set_coalescing", "mgl_sw_coalescing_stats",
 )
 
 
@@ -61,7 +61,8 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         build()
-    L = C.CDLL(LIB_PATH)
+    # RTLD_NOW: an unresolved symbol in the library must fail here, not at the first call
+    L = C.CDLL(LIB_PATH, mode=os.RTLD_NOW)
     vp, i32p, i64p, cp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_char_p
     L.mgl_sw_version.restype = C.c_int
     L.mgl_sw_strerror.restype = C.c_char_p
@@ -87,6 +88,8 @@ def lib():
     L.mgl_sw_backtrack_matrix.argtypes = [cp, C.c_int, cp, C.c_int] + [C.c_int] * 5 + [i32p, C.POINTER(Score)]
     L.mgl_sw_cigar_from_backtrack.argtypes = [i32p, C.c_int, C.c_int, C.c_int, C.POINTER(Score), cp, C.c_int,
                                               C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mgl_sw_set_coalescing.argtypes = [C.c_int, C.c_int]
+    L.mgl_sw_coalescing_stats.argtypes = [i64p, i64p]
     L.mgl_sw_ctx_expand_slot.argtypes = [vp, C.c_int64, C.c_int, C.c_int, i32p]
     _lib = L
     return L

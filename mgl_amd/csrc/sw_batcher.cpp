@@ -1,0 +1,281 @@
+// sw_batcher.cpp -- coalescing front-end for one-pair-per-call callers.
+//
+// GATK reaches the aligner through alignNative, one pair per call, from many threads
+// (/root/reference/src/main/java/com/microsoft/mgl/smithwaterman/MicrosoftSmithWaterman.java:66-86,
+// ..._MicrosoftSmithWaterman.cpp:44-71).  One pair per launch cannot feed a GPU, so when coalescing is switched
+// on (mgl_sw_set_coalescing or the environment variable MGL_SW_COALESCE_US) mgl_sw_align -- and therefore the
+// JNI export built on it -- parks the calling thread, a dispatcher thread merges the requests that share one
+// parameter set and strategy into a device batch (mgl_sw_align_batch), and every caller gets exactly the answer
+// the direct call would have produced.  Host code only: queues, one std::thread, condition variables.
+#include "../../include/mgl_sw.h"
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+// sw_capi.cpp (library-internal, not part of include/mgl_sw.h)
+extern "C" int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const int64_t *t_off,
+                                         const uint8_t *queries, const int64_t *q_off, int match, int mismatch,
+                                         int gopen, int gext, int strategy, int32_t *offset_out,
+                                         mgl_sw_score *score_out, char *cigar_out, int cigar_stride,
+                                         int32_t *cigar_len_out, int32_t *status_out);
+
+namespace {
+
+struct Request {
+    const char *t, *q;
+    int tl, ql;
+    char *cigar;
+    int cigar_cap;
+    int *cigar_len, *offset;
+    mgl_sw_score *ez;
+    int rc = MGL_SW_OK;
+    bool done = false;
+};
+
+using Key = std::tuple<int, int, int, int, int>; // normalised match, mismatch, open, extend, strategy
+
+class Coalescer {
+  public:
+    static Coalescer &instance()
+    {
+        static Coalescer c;
+        return c;
+    }
+
+    void configure(int max_batch, int max_wait_us)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        max_batch_ = max_batch;
+        max_wait_us_ = max_wait_us;
+        enabled_.store(max_batch > 0 && max_wait_us >= 0);
+        if (enabled_ && !worker_.joinable()) worker_ = std::thread([this] { run(); });
+        cv_work_.notify_all();
+    }
+    bool enabled() const { return enabled_.load(std::memory_order_relaxed); }
+
+    int submit(Request &r, const Key &key)
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        auto &qd = queues_[key];
+        if (qd.empty()) oldest_[key] = std::chrono::steady_clock::now();
+        qd.push_back(&r);
+        ++pending_;
+        cv_work_.notify_one();
+        cv_done_.wait(lk, [&] { return r.done; });
+        return r.rc;
+    }
+
+    void stats(int64_t *batches, int64_t *pairs)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        *batches = n_batches_;
+        *pairs = n_pairs_;
+    }
+
+    ~Coalescer()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+            cv_work_.notify_all();
+        }
+        if (worker_.joinable()) worker_.join();
+        if (ctx_) mgl_sw_ctx_destroy(ctx_);
+    }
+
+  private:
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_work_.wait(lk, [&] { return stop_ || pending_ > 0; });
+            if (stop_) {
+                fail_all(MGL_SW_ERR_DEVICE);
+                return;
+            }
+            // pick the queue that is full, or whose oldest request has waited long enough; otherwise sleep until
+            // the earliest deadline (new arrivals wake us up too)
+            const auto now = std::chrono::steady_clock::now();
+            const Key *ready = nullptr;
+            auto earliest = now + std::chrono::hours(1);
+            for (auto &kv : queues_) {
+                if (kv.second.empty()) continue;
+                const auto deadline = oldest_[kv.first] + std::chrono::microseconds(max_wait_us_);
+                if ((int)kv.second.size() >= max_batch_ || deadline <= now) {
+                    ready = &kv.first;
+                    break;
+                }
+                earliest = std::min(earliest, deadline);
+            }
+            if (!ready) {
+                cv_work_.wait_until(lk, earliest);
+                continue;
+            }
+            const Key key = *ready;
+            auto &qd = queues_[key];
+            std::vector<Request *> batch;
+            while (!qd.empty() && (int)batch.size() < max_batch_) {
+                batch.push_back(qd.front());
+                qd.pop_front();
+            }
+            if (!qd.empty()) oldest_[key] = now; // the rest starts a new waiting period
+            pending_ -= (int)batch.size();
+            lk.unlock();
+            process(key, batch);
+            lk.lock();
+            for (Request *r : batch) r->done = true;
+            ++n_batches_;
+            n_pairs_ += (int64_t)batch.size();
+            cv_done_.notify_all();
+        }
+    }
+
+    void fail_all(int rc)
+    {
+        for (auto &kv : queues_)
+            for (Request *r : kv.second) {
+                r->rc = rc;
+                r->done = true;
+            }
+        queues_.clear();
+        pending_ = 0;
+        cv_done_.notify_all();
+    }
+
+    void process(const Key &key, std::vector<Request *> &batch)
+    {
+        const int n = (int)batch.size();
+        if (!ctx_) {
+            int dev = 0;
+            if (const char *e = getenv("MGL_SW_DEVICE")) dev = atoi(e);
+            const int rc = mgl_sw_ctx_create(dev, &ctx_);
+            if (rc != MGL_SW_OK) {
+                for (Request *r : batch) r->rc = rc;
+                return;
+            }
+            mgl_sw_ctx_set_workspace(ctx_, 1ll << 30);
+        }
+        toff_.assign((size_t)n + 1, 0);
+        qoff_.assign((size_t)n + 1, 0);
+        int stride = 16;
+        for (int k = 0; k < n; ++k) {
+            toff_[(size_t)k + 1] = toff_[(size_t)k] + batch[(size_t)k]->tl;
+            qoff_[(size_t)k + 1] = qoff_[(size_t)k] + batch[(size_t)k]->ql;
+            stride = std::max(stride, batch[(size_t)k]->cigar_cap);
+        }
+        stride = std::min(stride, 1 << 16); // a slot larger than any caller's buffer is pointless
+        tbuf_.resize((size_t)toff_[(size_t)n]);
+        qbuf_.resize((size_t)qoff_[(size_t)n]);
+        for (int k = 0; k < n; ++k) {
+            memcpy(tbuf_.data() + toff_[(size_t)k], batch[(size_t)k]->t, (size_t)batch[(size_t)k]->tl);
+            memcpy(qbuf_.data() + qoff_[(size_t)k], batch[(size_t)k]->q, (size_t)batch[(size_t)k]->ql);
+        }
+        off_.resize((size_t)n);
+        len_.resize((size_t)n);
+        status_.resize((size_t)n);
+        score_.resize((size_t)n);
+        cig_.resize((size_t)n * stride);
+        const int rc = mgl_sw_align_batch_status(ctx_, n, tbuf_.data(), toff_.data(), qbuf_.data(), qoff_.data(),
+                                                 std::get<0>(key), std::get<1>(key), std::get<2>(key), std::get<3>(key),
+                                                 std::get<4>(key), off_.data(), score_.data(), cig_.data(), stride,
+                                                 len_.data(), status_.data());
+        for (int k = 0; k < n; ++k) {
+            Request *r = batch[(size_t)k];
+            if (rc != MGL_SW_OK) {
+                r->rc = rc;
+                continue;
+            }
+            *r->cigar_len = len_[(size_t)k];
+            if (status_[(size_t)k] != 0 || len_[(size_t)k] > r->cigar_cap) {
+                r->rc = MGL_SW_ERR_CIGAR_OVERFLOW;
+                continue;
+            }
+            memcpy(r->cigar, cig_.data() + (size_t)k * stride, (size_t)len_[(size_t)k]);
+            *r->offset = off_[(size_t)k];
+            if (r->ez) *r->ez = score_[(size_t)k];
+            r->rc = MGL_SW_OK;
+        }
+    }
+
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_done_;
+    std::map<Key, std::deque<Request *>> queues_;
+    std::map<Key, std::chrono::steady_clock::time_point> oldest_;
+    int pending_ = 0;
+    int max_batch_ = 0, max_wait_us_ = 0;
+    std::atomic<bool> enabled_{false};
+    bool stop_ = false;
+    std::thread worker_;
+    mgl_sw_ctx *ctx_ = nullptr;
+    int64_t n_batches_ = 0, n_pairs_ = 0;
+    std::vector<uint8_t> tbuf_, qbuf_;
+    std::vector<int64_t> toff_, qoff_;
+    std::vector<int32_t> off_, len_, status_;
+    std::vector<mgl_sw_score> score_;
+    std::vector<char> cig_;
+};
+
+struct EnvInit {
+    EnvInit()
+    {
+        if (const char *e = getenv("MGL_SW_COALESCE_US")) {
+            const int us = atoi(e);
+            int mb = 4096;
+            if (const char *b = getenv("MGL_SW_COALESCE_BATCH")) mb = atoi(b);
+            if (us >= 0 && mb > 0) Coalescer::instance().configure(mb, us);
+        }
+    }
+};
+
+} // namespace
+
+// library-internal entry points used by mgl_sw_align (sw_capi.cpp); C linkage, not in include/mgl_sw.h
+extern "C" bool mgl_sw_coalescing_enabled()
+{
+    static EnvInit once;
+    return Coalescer::instance().enabled();
+}
+
+extern "C" int mgl_sw_coalesced_align(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen, int gext,
+                           int strategy, char *cigar, int cigar_cap, int *cigar_len, int *offset, mgl_sw_score *ez)
+{
+    mgl_sw_normalize_params(&match, &mismatch, &gopen, &gext);
+    Request r;
+    r.t = t;
+    r.q = q;
+    r.tl = tl;
+    r.ql = ql;
+    r.cigar = cigar;
+    r.cigar_cap = cigar_cap;
+    r.cigar_len = cigar_len;
+    r.offset = offset;
+    r.ez = ez;
+    return Coalescer::instance().submit(r, Key(match, mismatch, gopen, gext, strategy));
+}
+
+extern "C" {
+
+int mgl_sw_set_coalescing(int max_batch, int max_wait_us)
+{
+    if (max_batch < 0 || max_wait_us < 0 || max_batch > (1 << 20)) return MGL_SW_ERR_BAD_ARG;
+    Coalescer::instance().configure(max_batch, max_batch == 0 ? -1 : max_wait_us);
+    return MGL_SW_OK;
+}
+
+int mgl_sw_coalescing_stats(int64_t *batches, int64_t *pairs)
+{
+    if (!batches || !pairs) return MGL_SW_ERR_BAD_ARG;
+    Coalescer::instance().stats(batches, pairs);
+    return MGL_SW_OK;
+}
+
+} // extern "C"

@@ -418,10 +418,26 @@ int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const ui
                       (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) != 0);
 }
 
+// mgl_sw_align_batch with an optional per-pair status array: with it, a CIGAR overflow of one pair does not
+// fail the call (used by the coalescing front-end, where every caller has its own buffer size)
+int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const int64_t *t_off,
+                              const uint8_t *queries, const int64_t *q_off, int match, int mismatch, int gopen,
+                              int gext, int strategy, int32_t *offset_out, mgl_sw_score *score_out, char *cigar_out,
+                              int cigar_stride, int32_t *cigar_len_out, int32_t *status_out);
+
 int mgl_sw_align_batch(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const int64_t *t_off,
                        const uint8_t *queries, const int64_t *q_off, int match, int mismatch, int gopen, int gext,
                        int strategy, int32_t *offset_out, mgl_sw_score *score_out, char *cigar_out, int cigar_stride,
                        int32_t *cigar_len_out)
+{
+    return mgl_sw_align_batch_status(ctx, n, targets, t_off, queries, q_off, match, mismatch, gopen, gext, strategy,
+                                     offset_out, score_out, cigar_out, cigar_stride, cigar_len_out, nullptr);
+}
+
+int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const int64_t *t_off,
+                              const uint8_t *queries, const int64_t *q_off, int match, int mismatch, int gopen,
+                              int gext, int strategy, int32_t *offset_out, mgl_sw_score *score_out, char *cigar_out,
+                              int cigar_stride, int32_t *cigar_len_out, int32_t *status_out)
 {
     if (!ctx) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -479,10 +495,19 @@ int mgl_sw_align_batch(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const
         HIP_TRY(ctx, hipMemcpyAsync(cigar_len_out, ctx->d_len.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(status.data(), ctx->d_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (status_out) {
+        memcpy(status_out, status.data(), (size_t)n * 4);
+        return MGL_SW_OK;
+    }
     for (int64_t k = 0; k < n; ++k)
         if (status[(size_t)k] != 0) return fail(ctx, status[(size_t)k], "a CIGAR did not fit cigar_stride");
     return MGL_SW_OK;
 }
+
+// sw_batcher.cpp
+bool mgl_sw_coalescing_enabled();
+int mgl_sw_coalesced_align(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen, int gext,
+                           int strategy, char *cigar, int cigar_cap, int *cigar_len, int *offset, mgl_sw_score *ez);
 
 static mgl_sw_ctx *thread_ctx(int *rc)
 {
@@ -507,6 +532,9 @@ int mgl_sw_align(const char *t, int tl, const char *q, int ql, int match, int mi
 {
     if (!t || !q || tl < 1 || ql < 1 || !cigar || cigar_cap < 1 || !cigar_len || !offset || !strategy_ok(strategy))
         return MGL_SW_ERR_BAD_ARG;
+    if (mgl_sw_coalescing_enabled())
+        return mgl_sw_coalesced_align(t, tl, q, ql, match, mismatch, gopen, gext, strategy, cigar, cigar_cap, cigar_len,
+                                      offset, ez);
     int rc;
     mgl_sw_ctx *ctx = thread_ctx(&rc);
     if (!ctx) return rc;

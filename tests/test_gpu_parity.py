@@ -277,3 +277,52 @@ def test_packed16_range_guard(aligner):
             for k in range(3):
                 assert (int(r.offsets[k]), r.cigars[k], tuple(int(x) for x in r.scores[k])) == (
                     o["offset"], o["cigar"], o["score"])
+
+
+def test_coalescing_front_end():
+    """Many threads calling the one-pair entry (the way GATK drives alignNative) are merged into device
+    batches by the coalescer and each gets exactly the answer of the direct call."""
+    import ctypes as C
+    import threading
+
+    from mgl_amd import _lib
+
+    L = _lib.lib()
+    rows = (golden_io.load("window")[:256] + golden_io.load("random")[:256] + golden_io.load("known"))
+    results = [None] * len(rows)
+
+    def call(k):
+        g = rows[k]
+        cap = 12 * (len(g.t) + len(g.q) + 4)
+        buf = C.create_string_buffer(cap)
+        ln, off, ez = C.c_int(), C.c_int(), _lib.Score()
+        rc = L.mgl_sw_align(g.t, len(g.t), g.q, len(g.q), *g.params, g.strategy, buf, cap, C.byref(ln), C.byref(off),
+                            C.byref(ez))
+        results[k] = (rc, off.value, buf.raw[: ln.value].decode(),
+                      (ez.mqe, ez.mqe_t, ez.max, ez.max_t, ez.max_q, ez.seg_length))
+
+    b0, p0 = C.c_int64(), C.c_int64()
+    L.mgl_sw_coalescing_stats(C.byref(b0), C.byref(p0))
+    assert L.mgl_sw_set_coalescing(256, 2000) == 0
+    try:
+        threads = [threading.Thread(target=lambda lo=lo: [call(k) for k in range(lo, len(rows), 32)]) for lo in range(32)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        # a caller whose buffer is too small gets the overflow status and the length it needs, others are unaffected
+        g = golden_io.load("known")[1]
+        small = C.create_string_buffer(4)
+        ln, off = C.c_int(), C.c_int()
+        rc = L.mgl_sw_align(g.t, len(g.t), g.q, len(g.q), *g.params, g.strategy, small, 4, C.byref(ln), C.byref(off), None)
+        assert rc == _lib.ERR_CIGAR_OVERFLOW and ln.value == len(g.cigar)
+    finally:
+        assert L.mgl_sw_set_coalescing(0, 0) == 0
+    b1, p1 = C.c_int64(), C.c_int64()
+    L.mgl_sw_coalescing_stats(C.byref(b1), C.byref(p1))
+    assert p1.value - p0.value == len(rows) + 1
+    assert b1.value - b0.value < len(rows) // 2, "calls were not merged into batches"
+    for k, g in enumerate(rows):
+        assert results[k] == (0, g.offset, g.cigar, g.score), (k, results[k], g)
+    # and the direct path still works after switching it off
+    assert sw.align(rows[0].t, rows[0].q, rows[0].params, rows[0].strategy)[:2] == (rows[0].cigar, rows[0].offset)
