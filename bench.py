@@ -144,6 +144,7 @@ def main():
     args = ap.parse_args()
 
     rank, local_rank, world = dist.init()
+    distributed = torch.distributed.is_initialized()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -156,8 +157,8 @@ def main():
 
     def step():
         batch.run(aligner, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP)
-        if world > 1:
-            # the only inter-GPU exchange: ScoreMax.max of every pair onto rank 0
+        if distributed:
+            # the only inter-GPU exchange: ScoreMax.max of every pair onto rank 0 (RCCL gather)
             return dist.gather_scores(batch.scores[:, 2].contiguous(), n_total, dst=0)
         return batch.scores[:, 2]
 
@@ -181,6 +182,8 @@ def main():
     aligner.set_profiling(0)
 
     if rank != 0:
+        if distributed:
+            torch.distributed.destroy_process_group()
         return
     fill_kernel = "sw_dp16_kernel" if tm.packed16 else "sw_dp_kernel"
     total_cells = cells * world * args.steps
@@ -229,6 +232,8 @@ def main():
     if world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(batch)
     print(json.dumps(out), flush=True)
+    if distributed:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

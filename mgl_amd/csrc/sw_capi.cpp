@@ -311,7 +311,11 @@ int mgl_sw_ctx_create(int device, mgl_sw_ctx **out)
         delete ctx;
         return MGL_SW_ERR_DEVICE;
     }
-    bool ok = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) == hipSuccess;
+    // the traceback stream gets the lowest priority: its waves should only take what the fill kernel leaves
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (const char *e = getenv("MGL_SW_AUX_PRIO")) prio_lo = atoi(e);
+    bool ok = hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, prio_lo) == hipSuccess;
     for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     for (auto *set : {ctx->fill_done, ctx->tb_done})
         for (int h = 0; h < 2; ++h) ok = ok && hipEventCreateWithFlags(&set[h], hipEventDisableTiming) == hipSuccess;

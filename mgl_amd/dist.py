@@ -14,13 +14,19 @@ def env_world():
 
 
 def init(backend=None):
-    """Initialise the default process group when launched with WORLD_SIZE > 1."""
+    """Initialise the default process group when launched by torch.distributed.run (RANK in the
+    environment) -- also for a single rank, so that a 1-GPU torchrun exercises the RCCL path."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if "RANK" in os.environ and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank)  # binds the communicator to this rank's GPU
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
 
@@ -42,7 +48,7 @@ def gather_scores(local_scores, n_total=None, dst=0):
     length by one (shard_range): every rank pads to the longest shard so that the collective is
     a plain equal-size gather.
     """
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return local_scores
     world, rank = dist.get_world_size(), dist.get_rank()
     if n_total is None:
@@ -57,8 +63,15 @@ def gather_scores(local_scores, n_total=None, dst=0):
     if send.numel() != width:
         send = torch.zeros(width, dtype=local_scores.dtype, device=local_scores.device)
         send[: local_scores.numel()] = local_scores
+    send = send.contiguous()
     recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send.contiguous(), recv, dst=dst)
+    try:
+        dist.gather(send, recv, dst=dst)
+    except RuntimeError:
+        # a backend without a gather primitive: every rank receives everything instead
+        full = torch.empty(world * width, dtype=send.dtype, device=send.device)
+        dist.all_gather_into_tensor(full, send)
+        recv = list(full.view(world, width).unbind(0))
     if rank != dst:
         return None
     return torch.cat([recv[r][: counts[r]] for r in range(world)])
@@ -66,7 +79,7 @@ def gather_scores(local_scores, n_total=None, dst=0):
 
 def max_over_ranks(value, device):
     """MAX of a python float over all ranks (for timing)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return float(value)
     t = torch.tensor([float(value)], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -74,5 +87,8 @@ def max_over_ranks(value, device):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+    if dist.is_initialized():
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()

@@ -64,3 +64,21 @@ def test_single_process_is_identity():
     x = torch.arange(5, dtype=torch.int32)
     assert dist.gather_scores(x) is x
     assert dist.max_over_ranks(1.5, torch.device("cpu")) == 1.5
+
+
+def _solo_worker(rank, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, lr, w = dist.init(backend="gloo")
+    got = dist.gather_scores(torch.arange(7, dtype=torch.int32), 7, dst=0)
+    dist.barrier()
+    torch.save(got, out_path)
+    torch.distributed.destroy_process_group()
+
+
+def test_world_size_one_under_torchrun_env(tmp_path):
+    """torchrun with one rank still builds the process group and runs the gather (what a 1-GPU
+    `python -m torch.distributed.run --nproc-per-node 1 bench.py` does)."""
+    out = str(tmp_path / "solo.pt")
+    mp.spawn(_solo_worker, args=(_free_port(), out), nprocs=1, join=True)
+    assert torch.load(out).tolist() == list(range(7))
