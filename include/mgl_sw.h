@@ -73,8 +73,10 @@ int mgl_sw_version(void);
 const char *mgl_sw_strerror(int status);
 /* number of HIP devices visible (0 when there is none or no runtime) */
 int mgl_sw_device_count(void);
-/* longest query the kernels of this build accept (LDS-bounded) */
+/* longest query accepted (2^24; the matrix must also stay below 2^34 cells) */
 int mgl_sw_max_query_len(void);
+/* longest query whose stripe carry fits LDS; longer ones keep it in an HBM scratch area (slower fill) */
+int mgl_sw_max_lds_query_len(void);
 
 int mgl_sw_ctx_create(int device, mgl_sw_ctx **out);
 void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx);
@@ -87,6 +89,9 @@ int mgl_sw_ctx_set_workspace(mgl_sw_ctx *ctx, int64_t bytes);
  * the same tl and ql and the score range fits 16 bits, else int32; 32 = always int32.  Results are
  * bit-identical either way. */
 int mgl_sw_ctx_set_precision(mgl_sw_ctx *ctx, int bits);
+/* where the int32 fill kernel keeps its stripe carry: 0 (default) = LDS whenever the query fits, 1 = always the
+ * HBM scratch used for long queries (for tests; results are identical) */
+int mgl_sw_ctx_set_carry_memory(mgl_sw_ctx *ctx, int mode);
 /* 1 = HIP events around every kernel launch of a call, on the streams the kernels run on, read back by
  * mgl_sw_ctx_get_timing (the call itself stays asynchronous); 2 = additionally stamp the shader clock
  * inside the fill kernel (diagnostic; a few extra instructions per workgroup); 0 = off */

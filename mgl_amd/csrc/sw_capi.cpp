@@ -54,7 +54,8 @@ struct mgl_sw_ctx {
     hipStream_t stream = nullptr; // used by the host-buffer entry points
     int64_t ws_limit = kDefaultWorkspace;
     // kernel workspace, two halves: the traceback of chunk k (aux stream) overlaps the fill of chunk k+1
-    DevBuf tb[2], rec[2], diag;
+    DevBuf tb[2], rec[2], diag, scratch;
+    int carry_memory = 0; // 0 = LDS when it fits, 1 = always the HBM scratch (tests)
     hipStream_t aux = nullptr;                       // traceback stream
     hipEvent_t fill_done[2] = {nullptr, nullptr};    // fill of the chunk in half h finished (caller's stream)
     hipEvent_t tb_done[2] = {nullptr, nullptr};      // traceback of the chunk in half h finished (aux stream)
@@ -109,9 +110,9 @@ int pick_waves_per_block(int sps_cap)
     return dp_lds_bytes(sps_cap, 1) <= kMaxLdsBytes ? 1 : 0;
 }
 
-int max_query_len()
+int max_lds_query_len()
 {
-    // largest ql whose one-wave carve fits the 160 KiB LDS
+    // largest ql whose one-wave carve fits the 160 KiB LDS (longer queries use the HBM scratch)
     int lo = 1, hi = 1 << 20;
     while (lo < hi) {
         int mid = (lo + hi + 1) / 2;
@@ -139,17 +140,23 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
     // packed-int16 kernel: one geometry for the whole batch and a score range that fits 16 bits
     const bool use16 = uniform && ctx->precision != 32 && dp16_lds_bytes(sps_cap, 4) <= 64 * 1024 &&
                        dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
-    const int wpb = use16 ? 4 : pick_waves_per_block(sps_cap);
-    if (wpb == 0) {
-        char msg[128];
-        snprintf(msg, sizeof msg, "query length %d exceeds the LDS-bounded maximum %d", max_ql, max_query_len());
-        return fail(ctx, MGL_SW_ERR_UNSUPPORTED, msg);
-    }
+    int wpb = use16 ? 4 : pick_waves_per_block(sps_cap);
+    // queries too long for the LDS carve: carry ring and query copies in an HBM scratch area instead
+    const bool use_scratch = !use16 && (wpb == 0 || ctx->carry_memory == 1);
+    if (use_scratch) wpb = 4;
+    if ((int64_t)max_tl * max_ql > (1ll << 34) || max_ql > (1 << 24) || max_tl > (1 << 24))
+        return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "matrix larger than 2^34 cells");
     // traceback words per pair (int32 layout) or per group of two pairs (packed16 layout)
     const int64_t stride_words = use16 ? tb_words16_for(max_tl, max_ql) : tb_words_for(max_tl, sps_cap);
     const int64_t per_pair = stride_words * 4 / (use16 ? 2 : 1) + (int64_t)sizeof(DpRecord);
     // the workspace is split in two halves so that the traceback of one chunk can run (on ctx->aux)
     // while the next chunk is being filled; a batch that fits one half is a single chunk
+    if (per_pair * 16 > ctx->ws_limit / 2) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "traceback of 16 pairs (%lld bytes) does not fit half the workspace: raise it with "
+                                  "mgl_sw_ctx_set_workspace", (long long)(per_pair * 16));
+        return fail(ctx, MGL_SW_ERR_NOMEM, msg);
+    }
     int64_t chunk = std::max<int64_t>(16, ctx->ws_limit / 2 / per_pair);
     chunk = std::min<int64_t>(chunk, n);
     chunk = (chunk + 15) / 16 * 16;
@@ -160,6 +167,11 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
     for (int h = 0; h < halves; ++h) {
         HIP_TRY(ctx, ctx->tb[h].reserve((size_t)(use16 ? chunk / 2 : chunk) * stride_words * 4));
         HIP_TRY(ctx, ctx->rec[h].reserve((size_t)chunk * sizeof(DpRecord)));
+    }
+
+    if (use_scratch) {
+        const int64_t groups = (chunk + 15) / 16 * 16; // every group of every launched wave has its own area
+        HIP_TRY(ctx, ctx->scratch.reserve((size_t)(groups * dp_group_bytes(sps_cap))));
     }
 
     ctx->timing = mgl_sw_timing{};
@@ -189,6 +201,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
         da.tb = static_cast<uint32_t *>(ctx->tb[h].p);
         da.tb_stride_words = stride_words;
         da.rec = static_cast<DpRecord *>(ctx->rec[h].p);
+        da.scratch = use_scratch ? static_cast<unsigned char *>(ctx->scratch.p) : nullptr;
         da.diag = nullptr;
         const int per_block = use16 ? wpb * 8 : wpb * 4;
         const int64_t n_blocks = (count + per_block - 1) / per_block;
@@ -286,7 +299,8 @@ int mgl_sw_device_count(void)
     return n;
 }
 
-int mgl_sw_max_query_len(void) { return max_query_len(); }
+int mgl_sw_max_query_len(void) { return 1 << 24; }
+int mgl_sw_max_lds_query_len(void) { return max_lds_query_len(); }
 
 void mgl_sw_normalize_params(int *match, int *mismatch, int *gopen, int *gext)
 {
@@ -333,7 +347,7 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
-    for (DevBuf *b : {&ctx->tb[0], &ctx->tb[1], &ctx->rec[0], &ctx->rec[1], &ctx->diag, &ctx->d_t, &ctx->d_toff, &ctx->d_q, &ctx->d_qoff, &ctx->d_off, &ctx->d_score,
+    for (DevBuf *b : {&ctx->tb[0], &ctx->tb[1], &ctx->rec[0], &ctx->rec[1], &ctx->diag, &ctx->scratch, &ctx->d_t, &ctx->d_toff, &ctx->d_q, &ctx->d_qoff, &ctx->d_off, &ctx->d_score,
                       &ctx->d_cig, &ctx->d_len, &ctx->d_status, &ctx->d_btr})
         b->release();
     for (auto &e : ctx->ev)
@@ -363,6 +377,14 @@ int mgl_sw_ctx_set_precision(mgl_sw_ctx *ctx, int bits)
     if (!ctx || (bits != 0 && bits != 32)) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->precision = bits;
+    return MGL_SW_OK;
+}
+
+int mgl_sw_ctx_set_carry_memory(mgl_sw_ctx *ctx, int mode)
+{
+    if (!ctx || (mode != 0 && mode != 1)) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->carry_memory = mode;
     return MGL_SW_OK;
 }
 

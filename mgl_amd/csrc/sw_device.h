@@ -36,6 +36,7 @@ struct DpArgs {
     uint32_t *tb;            // traceback words, count * tb_stride_words
     int64_t tb_stride_words; // per pair
     DpRecord *rec;           // count records
+    unsigned char *scratch;   // long queries (sw_dp_scratch_kernel): per-group carry ring + query copies in HBM, else null
     unsigned long long *diag; // profiling level 2 only: per block {shader-clock ticks, 100 MHz ticks}; else null
 };
 
@@ -82,6 +83,7 @@ __host__ __device__ inline int64_t dp16_total_steps(int tl, int ql)
 // packed16 layout: two dwords per lane per 8 steps, per group of two pairs
 __host__ __device__ inline int64_t tb_words16_for(int tl, int ql) { return ((dp16_total_steps(tl, ql) + 7) >> 3) * 32; }
 
+int64_t dp_group_bytes(int sps_cap); // carry ring + query copies of one pair (LDS, or HBM scratch for long queries)
 int dp_lds_bytes(int sps_cap, int waves_per_block);
 int dp16_lds_bytes(int sps, int waves_per_block);
 bool dp16_range_ok(int tl, int ql, int match, int mismatch, int gopen, int gext, int strategy);

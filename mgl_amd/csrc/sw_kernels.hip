@@ -84,10 +84,47 @@ struct LaneState {
 #ifdef MGL_ABLATE_QREAD
 #define MGL_QREAD(p) (qw * 1664525u + 1013904223u)
 #else
-#define MGL_QREAD(p) ((p)[1])
+#define MGL_QREAD(p) (Carry<SCRATCH>::loadq((p) + 1))
 #endif
 
-template <bool PRO, bool EPI>
+// Where the per-group carry ring and query copies live: LDS (normal), or -- when a query is too long for the
+// LDS carve -- a scratch area in HBM that the same wave writes and reads back.  The scratch accesses are
+// agent-scope relaxed atomics (global_load/store ... sc1): they are served by L2, so a ring entry written by
+// lane 15 is what lane 0 reads a stripe later whatever the CU's L1 still holds.
+template <bool SCRATCH>
+struct Carry {
+    static __device__ __forceinline__ int4 load2cols(const int4 *p)
+    {
+        if (!SCRATCH) return *p;
+        const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+        const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_int4((int)a, (int)(a >> 32), (int)b, (int)(b >> 32));
+    }
+    static __device__ __forceinline__ int2 load1col(const int2 *p)
+    {
+        if (!SCRATCH) return *p;
+        const unsigned long long a =
+            __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_int2((int)a, (int)(a >> 32));
+    }
+    static __device__ __forceinline__ void store1col(int2 *p, int h, int e)
+    {
+        if (!SCRATCH) {
+            *p = make_int2(h, e);
+            return;
+        }
+        const unsigned long long v = (unsigned long long)(unsigned)h | ((unsigned long long)(unsigned)e << 32);
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static __device__ __forceinline__ unsigned loadq(const unsigned *p)
+    {
+        if (!SCRATCH) return *p;
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
+template <bool PRO, bool EPI, bool SCRATCH>
 __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, const int4 *ring_next,
                                       const unsigned qw, const int tb, const int s0, const int L, const int hb,
                                       const int qcap, const int row_i, const int match, const int mismatch,
@@ -98,7 +135,7 @@ __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, c
         const int rh = u == 0 ? ringA.x : u == 1 ? ringA.z : u == 2 ? ringB.x : ringB.z;
         const int re = u == 0 ? ringA.y : u == 1 ? ringA.w : u == 2 ? ringB.y : ringB.w;
 #ifndef MGL_ABLATE_RINGREAD
-        if (u == 2) ringA = ring_next[0];
+        if (u == 2) ringA = Carry<SCRATCH>::load2cols(ring_next);
 #endif
         const int hup_new = row_shr1(rh, st.h_prev);
         const int ein = row_shr1(re, st.e_prev);
@@ -133,7 +170,7 @@ __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, c
             st.best_i = take ? row_i : st.best_i;
         }
 #ifndef MGL_ABLATE_RINGWRITE
-        if (writer) ring_wr[u] = make_int2(h, eo);
+        if (writer) Carry<SCRATCH>::store1col(ring_wr + u, h, eo);
 #endif
         st.h_prev = h;
         st.e_prev = eo;
@@ -141,13 +178,13 @@ __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, c
         st.f = fo;
     }
 #ifndef MGL_ABLATE_RINGREAD
-    ringB = ring_next[1];
+    ringB = Carry<SCRATCH>::load2cols(ring_next + 1);
 #endif
 }
 
-__global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
+template <bool SCRATCH>
+__device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long diag_t0 = 0, diag_w0 = 0;
     if (a.diag) { // in-kernel clock probe (MI355X_MICROARCH.md, DVFS give-back item 6); off in normal runs
         diag_t0 = __builtin_amdgcn_s_memtime();
@@ -192,7 +229,9 @@ __global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
     const int ring_entries = a.sps_cap + RING_SLACK;
     const int qcopy_bytes = a.sps_cap + QCOPY_SLACK;
     const int group_bytes = ring_entries * 8 + 4 * qcopy_bytes;
-    unsigned char *gbase = smem + (size_t)(wave * 4 + grp) * group_bytes;
+    unsigned char *gbase =
+        SCRATCH ? a.scratch + ((size_t)blockIdx.x * (blockDim.x >> 6) * 4 + (size_t)(wave * 4 + grp)) * group_bytes
+                : smem + (size_t)(wave * 4 + grp) * group_bytes;
     int2 *ring = reinterpret_cast<int2 *>(gbase); // ring[j + 16] holds column j
     unsigned char *qcopy = gbase + ring_entries * 8;
 
@@ -217,9 +256,12 @@ __global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
         // ---- border row into the ring: H[0][j], E[1][j] = H[0][j] - o   (sw.cpp:14-18,31-35)
         for (int j = L; j <= ql_max; j += 16) {
             const int hb0 = border(j, gopen, gext, indel);
-            ring[j + 16] = make_int2(hb0, hb0 - gopen);
+            Carry<SCRATCH>::store1col(ring + j + 16, hb0, hb0 - gopen);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (SCRATCH)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the plain byte stores above reach L2 before any read
+        else
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
 
@@ -254,15 +296,15 @@ __global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
         const int4 *ring_rd = reinterpret_cast<const int4 *>(ring + 16);
         int2 *ring_wr = ring + 16 - wl; // at step s the writer is at column s - wl
         const unsigned *qrd = qrd0;
-        int4 rA = ring_rd[0], rB = ring_rd[1];
-        unsigned qw = qrd[0];
+        int4 rA = Carry<SCRATCH>::load2cols(ring_rd), rB = Carry<SCRATCH>::load2cols(ring_rd + 1);
+        unsigned qw = Carry<SCRATCH>::loadq(qrd);
 
         int s = 0;
 #define MGL_SW_BLOCK(PRO, EPI)                                                                             \
     {                                                                                                      \
         const unsigned nq = MGL_QREAD(qrd);                                                                \
-        step4<PRO, EPI>(st, rA, rB, ring_rd + 2, qw, tb, s, L, hb, qcap, row_i, match, mismatch, gopen,    \
-                        gext, ring_wr, writer);                                                            \
+        step4<PRO, EPI, SCRATCH>(st, rA, rB, ring_rd + 2, qw, tb, s, L, hb, qcap, row_i, match, mismatch,  \
+                                 gopen, gext, ring_wr, writer);                                            \
         qw = nq;                                                                                           \
         ring_rd += 2;                                                                                      \
         ring_wr += 4;                                                                                      \
@@ -281,7 +323,7 @@ __global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
 
         if (k == nstripes - 1) {
             // ---- this group's matrix is complete: last column max, last row scan (sw.cpp:100-127)
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (!SCRATCH) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             int mqe = st.best, mqe_t = st.best_i;
 #pragma unroll
@@ -294,7 +336,7 @@ __global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
             // last row: best score, then closest to the diagonal, then smallest column
             int rm = NEG_INF, rd = 0x7fffffff, rj = 0x7fffffff;
             for (int j = L + 1; j <= ql; j += 16) {
-                const int sc = ring[j + 16].x;
+                const int sc = Carry<SCRATCH>::load1col(ring + j + 16).x;
                 const int d = abs(tl - j);
                 const bool take = sc > rm || (sc == rm && d < rd);
                 rm = take ? sc : rm;
@@ -336,6 +378,15 @@ __global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
         a.diag[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - diag_w0;
     }
 }
+
+__global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    sw_dp_body<false>(a, smem);
+}
+
+// long queries: the carry ring and the query copies do not fit LDS and live in an HBM scratch area
+__global__ __launch_bounds__(256) void sw_dp_scratch_kernel(const DpArgs a) { sw_dp_body<true>(a, nullptr); }
 
 // ---------------------------------------------------------------------------------------------
 // traceback bits accessor shared by the path walk and the matrix expansion
@@ -591,15 +642,22 @@ __global__ __launch_bounds__(256) void sw_expand_kernel(const uint32_t *tbw, con
 // ---------------------------------------------------------------------------------------------
 // launch wrappers (called from sw_capi.cpp)
 
+int64_t dp_group_bytes(int sps_cap) { return (int64_t)(sps_cap + RING_SLACK) * 8 + 4ll * (sps_cap + QCOPY_SLACK); }
+
 int dp_lds_bytes(int sps_cap, int waves_per_block)
 {
-    return waves_per_block * 4 * ((sps_cap + RING_SLACK) * 8 + 4 * (sps_cap + QCOPY_SLACK));
+    const int64_t b = waves_per_block * 4 * dp_group_bytes(sps_cap);
+    return b > (1 << 30) ? (1 << 30) : (int)b;
 }
 
 hipError_t launch_dp(const DpArgs &a, int waves_per_block, hipStream_t stream)
 {
     const int per_block = waves_per_block * 4;
     const int64_t blocks = (a.count + per_block - 1) / per_block;
+    if (a.scratch) {
+        hipLaunchKernelGGL(sw_dp_scratch_kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), 0, stream, a);
+        return hipGetLastError();
+    }
     const int lds = dp_lds_bytes(a.sps_cap, waves_per_block);
     static int configured_lds = 0;
     if (lds > 64 * 1024 && lds > configured_lds) {

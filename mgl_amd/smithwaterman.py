@@ -135,6 +135,10 @@ class MicrosoftSmithWaterman:
         """0 = per batch (packed int16 when possible), 32 = always the int32 fill kernel."""
         _check(_lib.lib().mgl_sw_ctx_set_precision(self._ensure(), int(bits)))
 
+    def set_carry_memory(self, mode):
+        """0 = stripe carry in LDS when the query fits, 1 = always in the HBM scratch (long-query path)."""
+        _check(_lib.lib().mgl_sw_ctx_set_carry_memory(self._ensure(), int(mode)))
+
     def set_profiling(self, on=True):
         _check(_lib.lib().mgl_sw_ctx_set_profiling(self._ensure(), int(on)))
 

@@ -52,7 +52,8 @@ def test_strerror_and_limits():
     L = _lib.lib()
     assert L.mgl_sw_strerror(0) == b"ok"
     assert b"HIP" in L.mgl_sw_strerror(_lib.ERR_DEVICE)
-    assert 1000 < L.mgl_sw_max_query_len() < 100000
+    assert 1000 < L.mgl_sw_max_lds_query_len() < 100000
+    assert L.mgl_sw_max_query_len() == 1 << 24
 
 
 def test_no_gpu_means_loud_failure():

@@ -50,17 +50,30 @@ def test_golden_suite(aligner, suite):
 
 
 def test_golden_long(aligner):
-    # 2 kb ONT-style pairs (full CIGAR); the 10 kb x 10 kb record exceeds this build's
-    # LDS-bounded query length and must be refused loudly, not mis-computed
-    rows = golden_io.load("long")
-    short = [g for g in rows if len(g.q) <= 3000]
-    assert run_groups(aligner, short) == len(short) == 8
-    big = [g for g in rows if len(g.q) > 3000]
+    """2 kb ONT-style pairs (full CIGAR) and the 10 kb x 10 kb pair (CIGAR hash): the latter is beyond the LDS
+    carve, so its stripe carry lives in the HBM scratch (sw_dp_scratch_kernel)."""
     from mgl_amd import _lib
-    for g in big:
-        with pytest.raises(_lib.MglSwError) as e:
-            aligner.align_batch([g.t], [g.q], g.params, g.strategy)
-        assert e.value.status == _lib.ERR_UNSUPPORTED
+
+    rows = golden_io.load("long")
+    assert max(len(g.q) for g in rows) > _lib.lib().mgl_sw_max_lds_query_len()
+    assert run_groups(aligner, rows) == len(rows) == 9
+
+
+def test_scratch_carry_equals_lds():
+    """The long-query path (carry ring + query copies in HBM, agent-scope accesses) forced onto ordinary
+    batches must reproduce the goldens exactly."""
+    forced = sw.MicrosoftSmithWaterman(0)
+    forced.set_carry_memory(1)
+    forced.set_precision(32)
+    rows = golden_io.load("known") + golden_io.load("shapes") + golden_io.load("random")[:600] + golden_io.load("ties")[::7]
+    assert run_groups(forced, rows) == len(rows)
+    # mixed geometry inside one batch + backtrack matrices
+    gs = [g for g in golden_io.load("random") if g.params == (200, -150, 260, 11) and g.strategy == ol.SOFTCLIP][:24]
+    forced.align_batch([g.t for g in gs], [g.q for g in gs], gs[0].params, ol.SOFTCLIP)
+    for k, g in enumerate(gs):
+        btr = forced.expand_slot(k, len(g.t), len(g.q))
+        assert zlib.crc32(np.ascontiguousarray(btr[1:, 1:]).astype("<i4").tobytes()) & 0xFFFFFFFF == g.crc
+    forced.close()
 
 
 def test_backtrack_matrix_bit_exact():
