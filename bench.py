@@ -36,11 +36,12 @@ from mgl_amd.smithwaterman import GATK_PARAMETERS, MicrosoftSmithWaterman, SWOve
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 
 
-def algorithmic_bytes_per_pair(tl, ql):
-    """DESIGN.md "algorithmic bytes": what sw_dp_kernel must move per pair whatever the schedule:
-    the two sequences as shipped (ASCII, like the reference's ByteBuffer), two int64 offsets each
-    (amortised 16 B), the 4-bit-per-cell traceback spilled to HBM, and the 32-byte fill record."""
-    return tl + ql + 16 + (tl * ql) // 2 + 32
+def algorithmic_bytes_per_pair(tl, ql, packed2=False):
+    """DESIGN.md "algorithmic bytes": what the fill kernel must move per pair whatever the schedule:
+    the two sequences as shipped (ASCII like the reference's ByteBuffer, or 2-bit packed), two int64
+    offsets each (amortised 16 B), the 4-bit-per-cell traceback spilled to HBM, and the 32-byte fill record."""
+    seq = (tl + 3) // 4 + (ql + 3) // 4 if packed2 else tl + ql
+    return seq + 16 + (tl * ql) // 2 + 32
 
 
 def host_cores():
@@ -141,6 +142,9 @@ def main():
     ap.add_argument("--workspace-gib", type=float, default=8.0, help="traceback workspace per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline leg")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--input", choices=("ascii", "2bit"), default="ascii",
+                    help="ascii: concatenated bytes (the reference's ByteBuffer contract); 2bit: one 2-bit packed "
+                         "genome with target windows addressed by base offset + packed reads (SURVEY 8d config 2)")
     args = ap.parse_args()
 
     rank, local_rank, world = dist.init()
@@ -151,7 +155,15 @@ def main():
 
     aligner = MicrosoftSmithWaterman(local_rank)
     aligner.set_workspace(int(args.workspace_gib * (1 << 30)))
-    batch = device_batch.window_batch(args.seed + rank, args.pairs, dev, window=args.tl, read_len=args.ql)
+    if args.input == "2bit":
+        batch, ascii_twin = device_batch.window_batch_2bit(args.seed + rank, args.pairs, dev, window=args.tl,
+                                                           read_len=args.ql)
+        if args.no_cpu or world > 1:
+            del ascii_twin  # only the CPU-baseline leg needs the unpacked bases
+            ascii_twin = None
+    else:
+        batch = device_batch.window_batch(args.seed + rank, args.pairs, dev, window=args.tl, read_len=args.ql)
+        ascii_twin = batch
     cells = args.pairs * args.tl * args.ql
     n_total = args.pairs * world
 
@@ -187,7 +199,7 @@ def main():
         return
     fill_kernel = "sw_dp16_kernel" if tm.packed16 else "sw_dp_kernel"
     total_cells = cells * world * args.steps
-    per_pair = algorithmic_bytes_per_pair(args.tl, args.ql)
+    per_pair = algorithmic_bytes_per_pair(args.tl, args.ql, args.input == "2bit")
     dp_s = tm.dp_ms / 1e3
     achieved = args.pairs * per_pair / dp_s / 1e9
     pairs_per_launch = args.pairs / max(1, tm.dp_launches)
@@ -210,7 +222,7 @@ def main():
             "workload": f"BASELINE.json configs[1]: {args.pairs} Illumina-style {args.ql} bp reads x {args.tl}-base "
                         f"reference windows per GPU, affine-gap SW, full matrix, GATK params (200,-150,260,11), "
                         f"SOFTCLIP, scores+offset+CIGAR for every pair",
-            "pairs_per_gpu": args.pairs, "target_len": args.tl, "query_len": args.ql,
+            "pairs_per_gpu": args.pairs, "target_len": args.tl, "query_len": args.ql, "input": args.input,
             "parallelism": f"pairs sharded over {world} GPU(s), score gather only" if world > 1 else "1 GPU",
         },
         "reads_per_s": round(args.pairs * world * args.steps / elapsed, 1),
@@ -230,7 +242,9 @@ def main():
         },
     }
     if world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(batch)
+        if ascii_twin is not batch:  # the CPU leg reads ASCII bases and compares with the GPU's result arrays
+            ascii_twin.offsets, ascii_twin.cigars = batch.offsets, batch.cigars
+        out["cpu_baseline"] = cpu_baseline(ascii_twin)
     print(json.dumps(out), flush=True)
     if distributed:
         torch.distributed.destroy_process_group()

@@ -160,6 +160,24 @@ int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const ui
                               int flags);
 
 /*
+ * Batch, device-resident, 2-bit packed bases -- the wire format for ACGT data instead of the
+ * ASCII-in-ByteBuffer of MicrosoftSmithWaterman.java:73-75.  d_target_bases / d_query_bases hold four bases per
+ * byte, base k of an array in bits 2*(k%4) of byte k/4 (A=0 C=1 G=2 T=3 by convention; the kernels only test
+ * equality, exactly like sw.cpp:55 does on bytes).  Pair p is the d_t_len[p] bases starting at BASE index
+ * d_t_start[p] against the d_q_len[p] bases starting at d_q_start[p] -- target windows may overlap, e.g. windows
+ * into one packed genome.  With MGL_SW_FLAG_UNIFORM_GEOMETRY the length arrays may be NULL (every pair max_tl x
+ * max_ql).  Everything else as mgl_sw_align_batch_device; results equal those of the ASCII entries on the
+ * unpacked sequences.
+ */
+int mgl_sw_align_batch_device_2bit(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_target_bases,
+                                   const int64_t *d_t_start, const int32_t *d_t_len,
+                                   const uint8_t *d_query_bases, const int64_t *d_q_start,
+                                   const int32_t *d_q_len, int max_tl, int max_ql, int match, int mismatch,
+                                   int gopen, int gext, int strategy, int32_t *d_offset_out,
+                                   mgl_sw_score *d_score_out, char *d_cigar_out, int cigar_stride,
+                                   int32_t *d_cigar_len_out, int32_t *d_status_out, int flags);
+
+/*
  * Logical backtrack matrix of one pair, the reference's calculateMatrix
  * (sw_scalar.h:7 / sw.cpp:5-146): btr is (tl+1)*(ql+1) int32 row-major with
  * row 0 / column 0 zero, +k = k rows up (deletion run), -k = k columns left

@@ -125,13 +125,12 @@ int max_lds_query_len()
 }
 
 // Enqueue fill + traceback for a device-resident batch on `stream`.
-int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_targets, const int64_t *d_t_off,
-               const uint8_t *d_queries, const int64_t *d_q_off, int max_tl, int max_ql, int match, int mismatch,
-               int gopen, int gext, int strategy, int32_t *d_offset, Score *d_score, char *d_cigar, int cigar_stride,
-               int32_t *d_cigar_len, int32_t *d_status, int64_t cells_hint, bool uniform)
+int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tset, const SeqSet &qset, int max_tl,
+               int max_ql, int match, int mismatch, int gopen, int gext, int strategy, int32_t *d_offset, Score *d_score,
+               char *d_cigar, int cigar_stride, int32_t *d_cigar_len, int32_t *d_status, int64_t cells_hint, bool uniform)
 {
     if (n == 0) return MGL_SW_OK;
-    if (n < 0 || !d_targets || !d_t_off || !d_queries || !d_q_off || !d_offset || !d_cigar || cigar_stride < 1 ||
+    if (n < 0 || !tset.data || !tset.off || !qset.data || !qset.off || !d_offset || !d_cigar || cigar_stride < 1 ||
         max_tl < 1 || max_ql < 1 || !strategy_ok(strategy))
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch_device: bad argument");
     mgl_sw_normalize_params(&match, &mismatch, &gopen, &gext);
@@ -184,10 +183,8 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
         const int64_t count = std::min(chunk, n - first);
         const int h = (int)(k & (halves - 1));
         DpArgs da;
-        da.targets = d_targets;
-        da.t_off = d_t_off;
-        da.queries = d_queries;
-        da.q_off = d_q_off;
+        da.t = tset;
+        da.q = qset;
         da.first = first;
         da.count = count;
         da.match = match;
@@ -211,8 +208,8 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const uint8_t *d_
         }
 
         TbArgs ta;
-        ta.t_off = d_t_off;
-        ta.q_off = d_q_off;
+        ta.t = tset;
+        ta.q = qset;
         ta.first = first;
         ta.count = count;
         ta.strategy = strategy;
@@ -438,10 +435,30 @@ int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const ui
 {
     if (!ctx) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    return run_device(ctx, static_cast<hipStream_t>(stream), n, d_targets, d_t_off, d_queries, d_q_off, max_tl, max_ql,
-                      match, mismatch, gopen, gext, strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out),
-                      d_cigar_out, cigar_stride, d_cigar_len_out, d_status_out, 0,
-                      (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) != 0);
+    const SeqSet ts{d_targets, d_t_off, nullptr, max_tl, 0}, qs{d_queries, d_q_off, nullptr, max_ql, 0};
+    return run_device(ctx, static_cast<hipStream_t>(stream), n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext,
+                      strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride,
+                      d_cigar_len_out, d_status_out, 0, (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) != 0);
+}
+
+int mgl_sw_align_batch_device_2bit(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_target_bases,
+                                   const int64_t *d_t_start, const int32_t *d_t_len, const uint8_t *d_query_bases,
+                                   const int64_t *d_q_start, const int32_t *d_q_len, int max_tl, int max_ql, int match,
+                                   int mismatch, int gopen, int gext, int strategy, int32_t *d_offset_out,
+                                   mgl_sw_score *d_score_out, char *d_cigar_out, int cigar_stride,
+                                   int32_t *d_cigar_len_out, int32_t *d_status_out, int flags)
+{
+    if (!ctx) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const bool uniform = (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) != 0;
+    // without per-pair length arrays every pair has exactly max_tl / max_ql bases
+    if ((!d_t_len || !d_q_len) && !uniform)
+        return fail(ctx, MGL_SW_ERR_BAD_ARG, "2-bit batch: length arrays are required unless the geometry is uniform");
+    const SeqSet ts{d_target_bases, d_t_start, uniform ? nullptr : d_t_len, max_tl, 1},
+        qs{d_query_bases, d_q_start, uniform ? nullptr : d_q_len, max_ql, 1};
+    return run_device(ctx, static_cast<hipStream_t>(stream), n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext,
+                      strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride,
+                      d_cigar_len_out, d_status_out, 0, uniform);
 }
 
 // mgl_sw_align_batch with an optional per-pair status array: with it, a CIGAR overflow of one pair does not
@@ -505,8 +522,9 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_toff.p, t_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_qoff.p, q_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
 
-    int rc = run_device(ctx, st, n, static_cast<const uint8_t *>(ctx->d_t.p), static_cast<const int64_t *>(ctx->d_toff.p),
-                        static_cast<const uint8_t *>(ctx->d_q.p), static_cast<const int64_t *>(ctx->d_qoff.p), max_tl,
+    const SeqSet ts{static_cast<const uint8_t *>(ctx->d_t.p), static_cast<const int64_t *>(ctx->d_toff.p), nullptr, max_tl, 0},
+        qs{static_cast<const uint8_t *>(ctx->d_q.p), static_cast<const int64_t *>(ctx->d_qoff.p), nullptr, max_ql, 0};
+    int rc = run_device(ctx, st, n, ts, qs, max_tl,
                         max_ql, match, mismatch, gopen, gext, strategy, static_cast<int32_t *>(ctx->d_off.p),
                         static_cast<Score *>(ctx->d_score.p), static_cast<char *>(ctx->d_cig.p), cigar_stride,
                         static_cast<int32_t *>(ctx->d_len.p), static_cast<int32_t *>(ctx->d_status.p), cells, uniform);

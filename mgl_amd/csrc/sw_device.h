@@ -23,11 +23,31 @@ struct DpRecord {
     int32_t sps;    // anti-diagonal steps per stripe (per chained stripe when g_tail > 0)
 };
 
+// How the sequences of a batch are addressed.  ASCII: pair p is data[off[p] .. off[p+1]) (one byte per base,
+// compared raw, sw.cpp:55).  2-bit packed (packed2 = 1): four bases per byte, base k of the array in bits
+// 2*(k&3) of byte k>>2 (A=0 C=1 G=2 T=3 by convention -- only equality matters); pair p starts at BASE index
+// off[p] and has len[p] bases (uni_len when len is null), so windows into one packed genome may overlap.
+struct SeqSet {
+    const uint8_t *data;
+    const int64_t *off;
+    const int32_t *len; // optional
+    int uni_len;        // length of every sequence when len == nullptr and packed2
+    int packed2;
+    __host__ __device__ inline int length(int64_t p) const
+    {
+        if (len) return len[p];
+        return packed2 ? uni_len : (int)(off[p + 1] - off[p]);
+    }
+    __device__ inline int at(int64_t start, int k) const
+    {
+        const int64_t pos = start + k;
+        if (packed2) return (data[pos >> 2] >> (2 * (int)(pos & 3))) & 3;
+        return data[pos];
+    }
+};
+
 struct DpArgs {
-    const uint8_t *targets;
-    const int64_t *t_off;
-    const uint8_t *queries;
-    const int64_t *q_off;
+    SeqSet t, q;
     int64_t first; // pairs [first, first + count) of the batch
     int64_t count;
     int match, mismatch, gopen, gext, strategy;
@@ -41,8 +61,7 @@ struct DpArgs {
 };
 
 struct TbArgs {
-    const int64_t *t_off;
-    const int64_t *q_off;
+    SeqSet t, q;
     int64_t first, count;
     int strategy;
     const uint32_t *tb;

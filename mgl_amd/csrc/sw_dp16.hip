@@ -249,8 +249,7 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
     const int64_t pA = a.first + slotA, pB = a.first + slotB;
 
     const int tl = a.uni_tl, ql = a.uni_ql; // one geometry for the whole batch
-    const uint8_t *tA = a.targets + a.t_off[pA], *tB = a.targets + a.t_off[pB];
-    const uint8_t *qA = a.queries + a.q_off[pA], *qB = a.queries + a.q_off[pB];
+    const int64_t tA = a.t.off[pA], tB = a.t.off[pB], qA = a.q.off[pA], qB = a.q.off[pB];
 
     const int nstripes = stripes_for(tl);
     const int sps = sps_for(ql);              // steps of a stand-alone stripe
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
         int cidx = x - 16;
         if (nc && cidx >= P - 1) cidx -= P;
         unsigned v = 0;
-        if (cidx >= 0 && cidx < ql) v = (unsigned)qA[cidx] | ((unsigned)qB[cidx] << 16);
+        if (cidx >= 0 && cidx < ql) v = (unsigned)a.q.at(qA, cidx) | ((unsigned)a.q.at(qB, cidx) << 16);
         qq[x] = v;
     }
     for (int j = L; j <= ql; j += 16) {
@@ -335,7 +334,7 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
     }
 
     int row_next = 1 + L; // row this lane takes in the next stripe
-    unsigned tt_next = (row_next <= tl) ? ((unsigned)tA[row_next - 1] | ((unsigned)tB[row_next - 1] << 16)) : 0u;
+    unsigned tt_next = (row_next <= tl) ? ((unsigned)a.t.at(tA, row_next - 1) | ((unsigned)a.t.at(tB, row_next - 1) << 16)) : 0u;
 
     // ======================= chained stripes 0 .. nc-1: one continuous systolic pipeline =======================
     if (nc > 0) {
@@ -357,7 +356,7 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
             const unsigned hbf_new = pk_sub(hb_new, c.o_f);
             if (k < nc) {
                 row_next += 16;
-                tt_next = (row_next <= tl) ? ((unsigned)tA[row_next - 1] | ((unsigned)tB[row_next - 1] << 16)) : 0u;
+                tt_next = (row_next <= tl) ? ((unsigned)a.t.at(tA, row_next - 1) | ((unsigned)a.t.at(tB, row_next - 1) << 16)) : 0u;
             }
             const uint4 *ring_rd = ring_c0;              // lane 0 is at column 0 when the window opens
             uint2 *ring_tail = ring + 16 + (P - 15);     // lane 15: columns P-15 .. P-1 of the stripe it finishes
@@ -433,7 +432,7 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
         const int row_i = row_next;
         const unsigned tt = tt_next;
         row_next += 16;
-        tt_next = (row_next <= tl) ? ((unsigned)tA[row_next - 1] | ((unsigned)tB[row_next - 1] << 16)) : 0u;
+        tt_next = (row_next <= tl) ? ((unsigned)a.t.at(tA, row_next - 1) | ((unsigned)a.t.at(tB, row_next - 1) << 16)) : 0u;
 
         const int hbv = border(row_i, gopen, gext, indel) + row_i * gext + base; // column 0
         const unsigned hb = pack2(hbv, hbv);

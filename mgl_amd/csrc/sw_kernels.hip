@@ -202,11 +202,9 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
     const bool valid = slot < a.count;
     const int64_t p = a.first + (valid ? slot : a.count - 1);
 
-    const int64_t t0 = a.t_off[p], q0 = a.q_off[p];
-    const int tl = (int)(a.t_off[p + 1] - t0);
-    const int ql = (int)(a.q_off[p + 1] - q0);
-    const uint8_t *tseq = a.targets + t0;
-    const uint8_t *qseq = a.queries + q0;
+    const int64_t t0 = a.t.off[p], q0 = a.q.off[p];
+    const int tl = a.t.length(p);
+    const int ql = a.q.length(p);
 
     const int nstripes = stripes_for(tl);
 
@@ -249,7 +247,7 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (int x = L; x < ql; x += 16) {
-            const unsigned char c = qseq[x];
+            const unsigned char c = (unsigned char)a.q.at(q0, x);
 #pragma unroll
             for (int k = 0; k < 4; ++k) qcopy[k * qcopy_bytes + x + 16 + k] = c;
         }
@@ -279,13 +277,13 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
     int gsteps = 0; // wave-uniform global step counter (traceback bit position)
 
     int row_next = 1 + L; // row of this lane in stripe 0
-    int tb_next = (row_next >= 1 && row_next <= tl) ? (int)tseq[row_next - 1] : 0;
+    int tb_next = (row_next >= 1 && row_next <= tl) ? a.t.at(t0, row_next - 1) : 0;
 
     for (int k = 0; k < ns_max; ++k) {
         const int row_i = row_next;
         const int tb = tb_next;
         row_next += 16;
-        tb_next = (row_next >= 1 && row_next <= tl) ? (int)tseq[row_next - 1] : 0;
+        tb_next = (row_next >= 1 && row_next <= tl) ? a.t.at(t0, row_next - 1) : 0;
 
         const int hb = border(row_i, gopen, gext, indel);
         const int qcap = row_i <= tl ? ql : NEG_INF; // s - L >= -15 never equals NEG_INF
@@ -564,8 +562,8 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
     const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= a.count) return;
     const int64_t p = a.first + slot;
-    const int tl = (int)(a.t_off[p + 1] - a.t_off[p]);
-    const int ql = (int)(a.q_off[p + 1] - a.q_off[p]);
+    const int tl = a.t.length(p);
+    const int ql = a.q.length(p);
     const DpRecord r = a.rec[slot];
 
     BitsMoves mv;

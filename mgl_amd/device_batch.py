@@ -122,3 +122,83 @@ def from_host(targets, t_off, queries, q_off, device, cigar_stride=None):
                        torch.from_numpy(t_off).to(dev),
                        torch.from_numpy(np.ascontiguousarray(queries, dtype=np.uint8)).to(dev),
                        torch.from_numpy(q_off).to(dev), max_tl, max_ql, cigar_stride, uniform=uniform)
+
+
+# ---------------------------------------------------------------------------------------------
+# 2-bit packed inputs (mgl_sw_align_batch_device_2bit)
+
+_CODE = np.full(256, 255, dtype=np.uint8)
+for _k, _c in enumerate(b"ACGT"):
+    _CODE[_c] = _k
+
+
+def pack2bit(seq_bytes, lead=0):
+    """ACGT bytes (numpy uint8 / bytes) -> 2-bit packed uint8 array, four bases per byte, base k in bits
+    2*(k%4) of byte k//4.  ``lead`` unused base slots (zeros) are put in front, so the first real base gets
+    base index ``lead``."""
+    a = np.frombuffer(bytes(seq_bytes), dtype=np.uint8) if not isinstance(seq_bytes, np.ndarray) else seq_bytes
+    code = _CODE[a]
+    if (code == 255).any():
+        raise ValueError("2-bit packing needs ACGT only")
+    code = np.concatenate([np.zeros(lead, np.uint8), code])
+    pad = (-len(code)) % 4
+    code = np.concatenate([code, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+    return (code[:, 0] | (code[:, 1] << 2) | (code[:, 2] << 4) | (code[:, 3] << 6)).astype(np.uint8)
+
+
+class PackedBatch(DeviceBatch):
+    """A batch whose sequences are 2-bit packed: pair k = t_len[k] bases from base index t_start[k] of
+    ``target_bases`` against q_len[k] bases from q_start[k] of ``query_bases`` (t_len / q_len None: uniform)."""
+
+    def __init__(self, target_bases, t_start, t_len, query_bases, q_start, q_len, max_tl, max_ql, cigar_stride=64):
+        self.target_bases, self.query_bases = target_bases, query_bases
+        self.t_start, self.q_start, self.t_len, self.q_len = t_start, q_start, t_len, q_len
+        self.n = t_start.numel()
+        self.max_tl, self.max_ql = int(max_tl), int(max_ql)
+        self.cigar_stride = int(cigar_stride)
+        self.uniform = t_len is None and q_len is None
+        dev = target_bases.device
+        self.offsets = torch.empty(self.n, dtype=torch.int32, device=dev)
+        self.scores = torch.empty((self.n, 6), dtype=torch.int32, device=dev)
+        self.cigars = torch.empty((self.n, self.cigar_stride), dtype=torch.uint8, device=dev)
+        self.cigar_len = torch.empty(self.n, dtype=torch.int32, device=dev)
+        self.status = torch.empty(self.n, dtype=torch.int32, device=dev)
+
+    def run(self, aligner, parameters=GATK_PARAMETERS, overhang_strategy=SWOverhangStrategy.SOFTCLIP, stream=None):
+        if stream is None:
+            stream = torch.cuda.current_stream(self.target_bases.device)
+        p = SWParameters(*parameters)
+        rc = _lib.lib().mgl_sw_align_batch_device_2bit(
+            aligner.ctx, C.c_void_p(stream.cuda_stream), self.n, self.target_bases.data_ptr(), self.t_start.data_ptr(),
+            None if self.t_len is None else self.t_len.data_ptr(), self.query_bases.data_ptr(), self.q_start.data_ptr(),
+            None if self.q_len is None else self.q_len.data_ptr(), self.max_tl, self.max_ql, p.match, p.mismatch,
+            p.gap_open, p.gap_extend, int(overhang_strategy), self.offsets.data_ptr(), self.scores.data_ptr(),
+            self.cigars.data_ptr(), self.cigar_stride, self.cigar_len.data_ptr(), self.status.data_ptr(),
+            _lib.FLAG_UNIFORM_GEOMETRY if self.uniform else 0)
+        _check(rc, aligner.ctx)
+
+
+def _pack2bit_torch(code):
+    """uint8 codes 0..3 (length multiple of 4) -> packed bytes, on the tensor's device."""
+    c = code.view(-1, 4)
+    return c[:, 0] | (c[:, 1] << 2) | (c[:, 2] << 4) | (c[:, 3] << 6)
+
+
+def window_batch_2bit(seed, n_pairs, device, window=256, read_len=150, genome_len=1 << 24, cigar_stride=64, **kw):
+    """The window_batch workload in its packed form (SURVEY.md 8d "Config 2"): ONE 2-bit packed genome, target
+    windows addressed by base offset into it, reads packed back to back.  Same bases as window_batch(seed, ...)."""
+    b = window_batch(seed, n_pairs, device, window, read_len, genome_len, cigar_stride=cigar_stride, **kw)
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    genome = torch.randint(0, 4, (genome_len,), generator=g, device=device, dtype=torch.uint8)
+    win = torch.randint(0, genome_len - window, (n_pairs,), generator=g, device=device, dtype=torch.int64)
+    lut = torch.zeros(256, dtype=torch.uint8, device=device)
+    for k, ch in enumerate(_BASES):
+        lut[ch] = k
+    reads_code = lut[b.queries.long()]
+    pad = (-reads_code.numel()) % 4
+    if pad:
+        reads_code = torch.cat([reads_code, torch.zeros(pad, dtype=torch.uint8, device=device)])
+    q_start = torch.arange(n_pairs, device=device, dtype=torch.int64) * read_len
+    return PackedBatch(_pack2bit_torch(genome), win, None, _pack2bit_torch(reads_code), q_start, None, window, read_len,
+                       cigar_stride), b

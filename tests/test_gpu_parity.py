@@ -339,3 +339,72 @@ def test_coalescing_front_end():
         assert results[k] == (0, g.offset, g.cigar, g.score), (k, results[k], g)
     # and the direct path still works after switching it off
     assert sw.align(rows[0].t, rows[0].q, rows[0].params, rows[0].strategy)[:2] == (rows[0].cigar, rows[0].offset)
+
+
+# ---------------------------------------------------------------------------------------------
+# 2-bit packed inputs (mgl_sw_align_batch_device_2bit)
+
+def _packed_from_rows(rows, dev):
+    """Pack golden (ACGT-only) pairs into one target array and one query array at unaligned base offsets."""
+    import torch
+    from mgl_amd import device_batch as db
+
+    tparts, qparts, ts, qs, tlens, qlens = [], [], [], [], [], []
+    tpos = qpos = 0
+    for k, g in enumerate(rows):
+        lead_t, lead_q = (k * 7) % 5, (k * 3) % 4  # gaps so that starts are not multiples of 4
+        tparts.append(b"A" * lead_t + g.t)
+        qparts.append(b"C" * lead_q + g.q)
+        ts.append(tpos + lead_t)
+        qs.append(qpos + lead_q)
+        tpos += lead_t + len(g.t)
+        qpos += lead_q + len(g.q)
+        tlens.append(len(g.t))
+        qlens.append(len(g.q))
+    T = torch.from_numpy(db.pack2bit(b"".join(tparts))).to(dev)
+    Q = torch.from_numpy(db.pack2bit(b"".join(qparts))).to(dev)
+    i64 = lambda v: torch.tensor(v, dtype=torch.int64, device=dev)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+    return db.PackedBatch(T, i64(ts), i32(tlens), Q, i64(qs), i32(qlens), max(tlens), max(qlens),
+                          cigar_stride=2 * max(max(tlens), max(qlens)) + 16)
+
+
+def test_2bit_inputs_match_goldens(aligner):
+    import torch
+
+    dev = torch.device("cuda", 0)
+    acgt = set(b"ACGT")
+    rows = [g for g in golden_io.load("random") + golden_io.load("shapes") + golden_io.load("window")
+            if set(g.t) <= acgt and set(g.q) <= acgt]
+    groups = defaultdict(list)
+    for g in rows:
+        groups[(g.params, g.strategy)].append(g)
+    n = 0
+    for (params, strategy), gs in groups.items():
+        b = _packed_from_rows(gs, dev)
+        b.run(aligner, params, strategy)
+        torch.cuda.synchronize()
+        assert int((b.status != 0).sum()) == 0
+        off, sc, cg = b.offsets.cpu().numpy(), b.scores.cpu().numpy(), b.cigar_strings()
+        for k, g in enumerate(gs):
+            assert (int(off[k]), cg[k], tuple(int(x) for x in sc[k])) == (g.offset, g.cigar, g.score), (params, strategy, k)
+            n += 1
+    assert n == len(rows) and n > 1500
+
+
+def test_2bit_window_batch_equals_ascii(aligner):
+    """Windows into ONE packed genome + packed reads (the SURVEY config-2 layout) give byte-identical outputs to
+    the ASCII batch of the same bases; the uniform batch takes the packed-int16 kernel in both forms."""
+    import torch
+    from mgl_amd import device_batch as db
+
+    dev = torch.device("cuda", 0)
+    pb, ab = db.window_batch_2bit(77, 20000, dev, genome_len=1 << 20)
+    ab.run(aligner)
+    torch.cuda.synchronize()
+    assert aligner.timing().packed16 == 1
+    pb.run(aligner)
+    torch.cuda.synchronize()
+    assert aligner.timing().packed16 == 1
+    assert torch.equal(pb.offsets, ab.offsets) and torch.equal(pb.scores, ab.scores)
+    assert torch.equal(pb.cigars, ab.cigars) and torch.equal(pb.cigar_len, ab.cigar_len)
