@@ -151,6 +151,10 @@ int mgl_sw_align_batch(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const
  * host-buffer entry detects this by itself).
  */
 #define MGL_SW_FLAG_UNIFORM_GEOMETRY 0x1
+/* MGL_SW_FLAG_BINARY_CIGAR: the CIGAR slot receives BAM-style little-endian uint32 elements
+ * (length << 4 | op, op M=0 I=1 D=2 S=4) instead of the text of sw.cpp:251-252; cigar_len is then in bytes
+ * (4 per element) and cigar_stride should be a multiple of 4.  Same elements, same order. */
+#define MGL_SW_FLAG_BINARY_CIGAR 0x2
 int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_targets,
                               const int64_t *d_t_off, const uint8_t *d_queries,
                               const int64_t *d_q_off, int max_tl, int max_ql, int match,

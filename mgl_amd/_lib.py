@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("MGL_SW_LIB") or os.path.join(HERE, "libmgl_sw_hip.so"
 CSRC = os.path.join(HERE, "csrc")
 
 FLAG_UNIFORM_GEOMETRY = 1
+FLAG_BINARY_CIGAR = 2
 OK, ERR_BAD_ARG, ERR_CIGAR_OVERFLOW, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED = range(6)
 
 # every symbol include/mgl_sw.h declares (tests check that the library exports them all)

@@ -127,7 +127,8 @@ int max_lds_query_len()
 // Enqueue fill + traceback for a device-resident batch on `stream`.
 int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tset, const SeqSet &qset, int max_tl,
                int max_ql, int match, int mismatch, int gopen, int gext, int strategy, int32_t *d_offset, Score *d_score,
-               char *d_cigar, int cigar_stride, int32_t *d_cigar_len, int32_t *d_status, int64_t cells_hint, bool uniform)
+               char *d_cigar, int cigar_stride, int32_t *d_cigar_len, int32_t *d_status, int64_t cells_hint, bool uniform,
+               bool binary_cigar = false)
 {
     if (n == 0) return MGL_SW_OK;
     if (n < 0 || !tset.data || !tset.off || !qset.data || !qset.off || !d_offset || !d_cigar || cigar_stride < 1 ||
@@ -221,6 +222,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         ta.score = d_score;
         ta.cigar = d_cigar;
         ta.cigar_stride = cigar_stride;
+        ta.binary_cigar = binary_cigar ? 1 : 0;
         ta.cigar_len = d_cigar_len;
         ta.status = d_status;
 
@@ -438,7 +440,8 @@ int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const ui
     const SeqSet ts{d_targets, d_t_off, nullptr, max_tl, 0}, qs{d_queries, d_q_off, nullptr, max_ql, 0};
     return run_device(ctx, static_cast<hipStream_t>(stream), n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext,
                       strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride,
-                      d_cigar_len_out, d_status_out, 0, (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) != 0);
+                      d_cigar_len_out, d_status_out, 0, (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) != 0,
+                      (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0);
 }
 
 int mgl_sw_align_batch_device_2bit(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_target_bases,
@@ -458,7 +461,7 @@ int mgl_sw_align_batch_device_2bit(mgl_sw_ctx *ctx, void *stream, int64_t n, con
         qs{d_query_bases, d_q_start, uniform ? nullptr : d_q_len, max_ql, 1};
     return run_device(ctx, static_cast<hipStream_t>(stream), n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext,
                       strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride,
-                      d_cigar_len_out, d_status_out, 0, uniform);
+                      d_cigar_len_out, d_status_out, 0, uniform, (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0);
 }
 
 // mgl_sw_align_batch with an optional per-pair status array: with it, a CIGAR overflow of one pair does not

@@ -72,6 +72,7 @@ struct TbArgs {
     Score *score;    // optional
     char *cigar;
     int cigar_stride;
+    int binary_cigar; // BAM-style uint32 elements instead of text
     int32_t *cigar_len; // optional
     int32_t *status;    // optional
 };

@@ -439,11 +439,27 @@ struct TbView {
 struct CigarWriter {
     char *slot;
     int cap, pos, need;
+    int binary; // 1: BAM-style uint32 elements (len << 4 | op, op M=0 I=1 D=2 S=4) instead of text
     // elements arrive last-first (the reference push_front()s, sw.cpp:172-248); text is built
     // right-aligned and moved to the front at the end.  Zero lengths are skipped (sw.cpp:252).
     __device__ __forceinline__ void push_front(char op, int len)
     {
         if (len <= 0) return;
+        if (binary) {
+            need += 4;
+            if (pos - 4 < 0) {
+                pos = -1;
+                return;
+            }
+            const unsigned code = op == 'M' ? 0u : op == 'I' ? 1u : op == 'D' ? 2u : 4u;
+            const unsigned v = ((unsigned)len << 4) | code;
+            pos -= 4;
+            slot[pos] = (char)(v & 0xff);
+            slot[pos + 1] = (char)((v >> 8) & 0xff);
+            slot[pos + 2] = (char)((v >> 16) & 0xff);
+            slot[pos + 3] = (char)(v >> 24);
+            return;
+        }
         int digits = 1;
         for (int v = len; v >= 10; v /= 10) ++digits;
         need += digits + 1;
@@ -574,12 +590,14 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
 
     CigarWriter cw;
     cw.slot = a.cigar + (size_t)p * a.cigar_stride;
-    cw.cap = a.cigar_stride;
-    cw.pos = a.cigar_stride;
+    cw.binary = a.binary_cigar;
+    cw.cap = a.binary_cigar ? (a.cigar_stride & ~3) : a.cigar_stride;
+    cw.pos = cw.cap;
     cw.need = 0;
 
     const int off = walk_and_write(mv, tl, ql, a.strategy, r.max_t, r.max_q, r.mqe_t, r.seg, cw);
     const int status = finish_cigar(cw);
+    for (int k = cw.cap; k < a.cigar_stride; ++k) cw.slot[k] = 0;
 
     a.offset[p] = off;
     if (a.cigar_len) a.cigar_len[p] = cw.need;
@@ -607,6 +625,7 @@ __global__ void sw_cigar_from_matrix_kernel(const int32_t *btr, int tl, int ql, 
     mv.m = ql + 1;
     CigarWriter cw;
     cw.slot = cigar;
+    cw.binary = 0;
     cw.cap = cap;
     cw.pos = cap;
     cw.need = 0;

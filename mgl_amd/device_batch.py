@@ -39,18 +39,30 @@ class DeviceBatch:
         ql = (self.q_off[1:] - self.q_off[:-1])
         return int((tl * ql).sum().item())
 
-    def run(self, aligner, parameters=GATK_PARAMETERS, overhang_strategy=SWOverhangStrategy.SOFTCLIP, stream=None):
+    def run(self, aligner, parameters=GATK_PARAMETERS, overhang_strategy=SWOverhangStrategy.SOFTCLIP, stream=None,
+            binary_cigar=False):
         """Enqueue fill + traceback on ``stream`` (default: torch's current stream); no sync."""
         if stream is None:
             stream = torch.cuda.current_stream(self.targets.device)
         p = SWParameters(*parameters)
+        flags = (_lib.FLAG_UNIFORM_GEOMETRY if self.uniform else 0) | (_lib.FLAG_BINARY_CIGAR if binary_cigar else 0)
         rc = _lib.lib().mgl_sw_align_batch_device(
             aligner.ctx, C.c_void_p(stream.cuda_stream), self.n, self.targets.data_ptr(), self.t_off.data_ptr(),
             self.queries.data_ptr(), self.q_off.data_ptr(), self.max_tl, self.max_ql, p.match, p.mismatch,
             p.gap_open, p.gap_extend, int(overhang_strategy), self.offsets.data_ptr(), self.scores.data_ptr(),
-            self.cigars.data_ptr(), self.cigar_stride, self.cigar_len.data_ptr(), self.status.data_ptr(),
-            _lib.FLAG_UNIFORM_GEOMETRY if self.uniform else 0)
+            self.cigars.data_ptr(), self.cigar_stride, self.cigar_len.data_ptr(), self.status.data_ptr(), flags)
         _check(rc, aligner.ctx)
+
+    def cigar_elements(self, idx=None):
+        """Decode BAM-style binary CIGARs (run(..., binary_cigar=True)) into text."""
+        cg = self.cigars if idx is None else self.cigars[idx]
+        ln = self.cigar_len if idx is None else self.cigar_len[idx]
+        cg, ln = cg.cpu().numpy(), ln.cpu().numpy()
+        out = []
+        for k in range(len(ln)):
+            el = np.frombuffer(cg[k, : ln[k]].tobytes(), dtype="<u4")
+            out.append("".join(f"{int(v) >> 4}{'MIDNS'[int(v) & 15]}" for v in el))
+        return out
 
     def cigar_strings(self, idx=None):
         cg = self.cigars if idx is None else self.cigars[idx]

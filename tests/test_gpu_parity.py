@@ -408,3 +408,22 @@ def test_2bit_window_batch_equals_ascii(aligner):
     assert aligner.timing().packed16 == 1
     assert torch.equal(pb.offsets, ab.offsets) and torch.equal(pb.scores, ab.scores)
     assert torch.equal(pb.cigars, ab.cigars) and torch.equal(pb.cigar_len, ab.cigar_len)
+
+
+def test_binary_cigar_output(aligner):
+    """MGL_SW_FLAG_BINARY_CIGAR: BAM-style uint32 elements carry the same elements in the same order as the text."""
+    import torch
+    from mgl_amd import device_batch as db
+
+    rows = [g for g in golden_io.load("window") if g.strategy == ol.SOFTCLIP][:300] + \
+           [g for g in golden_io.load("random") if g.params == (200, -150, 260, 11) and g.strategy == ol.SOFTCLIP]
+    td, toff = sw.concat([g.t for g in rows])
+    qd, qoff = sw.concat([g.q for g in rows])
+    b = db.from_host(td, toff, qd, qoff, "cuda:0", cigar_stride=4 * 700)
+    b.run(aligner, rows[0].params, ol.SOFTCLIP, binary_cigar=True)
+    torch.cuda.synchronize()
+    assert int((b.status != 0).sum()) == 0
+    got = b.cigar_elements()
+    for k, g in enumerate(rows):
+        assert got[k] == g.cigar, (k, got[k], g.cigar)
+    assert (b.offsets.cpu().numpy() == np.array([g.offset for g in rows])).all()
