@@ -427,3 +427,63 @@ def test_binary_cigar_output(aligner):
     for k, g in enumerate(rows):
         assert got[k] == g.cigar, (k, got[k], g.cigar)
     assert (b.offsets.cpu().numpy() == np.array([g.offset for g in rows])).all()
+
+
+def test_parameter_and_alphabet_fuzz(aligner):
+    """Unusual scoring parameters (zero gap costs, zero mismatch, huge match) and arbitrary byte alphabets
+    (0..255, compared raw like sw.cpp:55) through both fill kernels: uniform batches take the packed-int16
+    kernel when the score range allows it, ragged ones the int32 kernel."""
+    rng = np.random.default_rng(314159)
+    psets = [(200, -150, 260, 11), (1, 0, 0, 0), (5, -3, 0, 1), (5, -3, 7, 0), (1000, -1000, 3000, 100), (2, -7, 1, 1),
+             (127, -128, 255, 1), (9, -9, 9, 9), (1, -1, 50, 50)]
+    for it, params in enumerate(psets):
+        for uniform in (True, False):
+            ts, qs = [], []
+            tl0, ql0 = int(rng.integers(20, 90)), int(rng.integers(20, 90))
+            for k in range(41):
+                tl = tl0 if uniform else int(rng.integers(1, 90))
+                ql = ql0 if uniform else int(rng.integers(1, 90))
+                hi = 256 if it % 2 else 3  # full byte range or a tiny alphabet (many ties)
+                t = rng.integers(0, hi, tl, dtype=np.uint8)
+                q = t[: ql].copy() if (k % 2 and tl >= ql) else rng.integers(0, hi, ql, dtype=np.uint8)
+                if k % 4 == 1 and len(q) > 4:
+                    q[len(q) // 2] ^= 1
+                ts.append(t.tobytes())
+                qs.append(np.resize(q, ql).tobytes())
+            for strategy in ol.STRATEGIES:
+                res = aligner.align_batch(ts, qs, params, strategy)
+                off, sc, cg = ol.oracle_align_batch(ts, qs, params, strategy, nthreads=4)
+                ctx = (params, strategy, uniform, bool(aligner.timing().packed16))
+                assert (res.offsets == off).all(), ctx
+                assert (res.scores == sc).all(), ctx
+                assert res.cigars == cg, ctx
+
+
+def test_contexts_on_many_threads():
+    """One mgl_sw_ctx per host thread, all on the same GPU, running batches concurrently (the reference's
+    alignNative is re-entrant, ..._MicrosoftSmithWaterman.cpp:44-71)."""
+    import threading
+
+    rows = [g for g in golden_io.load("window") if g.strategy == ol.SOFTCLIP]
+    ts, qs = [g.t for g in rows], [g.q for g in rows]
+    errors = []
+
+    def worker(seed):
+        try:
+            a = sw.MicrosoftSmithWaterman(0)
+            for rep in range(3):
+                res = a.align_batch(ts, qs, rows[0].params, ol.SOFTCLIP)
+                for k, g in enumerate(rows):
+                    if (int(res.offsets[k]), res.cigars[k], tuple(int(x) for x in res.scores[k])) != (g.offset, g.cigar, g.score):
+                        errors.append((seed, rep, k))
+                        return
+            a.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((seed, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
