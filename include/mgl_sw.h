@@ -92,6 +92,9 @@ int mgl_sw_ctx_set_precision(mgl_sw_ctx *ctx, int bits);
 /* where the int32 fill kernel keeps its stripe carry: 0 (default) = LDS whenever the query fits, 1 = always the
  * HBM scratch used for long queries (for tests; results are identical) */
 int mgl_sw_ctx_set_carry_memory(mgl_sw_ctx *ctx, int mode);
+/* target rows per stripe (= lanes per pair) of the int32 fill kernel: 0 (default) = 16 (four pairs per wave) for
+ * queries below 1024 bases, 64 (one pair per wave) from there on; 16 / 64 force one (tests; identical results) */
+int mgl_sw_ctx_set_stripe_rows(mgl_sw_ctx *ctx, int rows);
 /* 1 = HIP events around every kernel launch of a call, on the streams the kernels run on, read back by
  * mgl_sw_ctx_get_timing (the call itself stays asynchronous); 2 = additionally stamp the shader clock
  * inside the fill kernel (diagnostic; a few extra instructions per workgroup); 0 = off */

@@ -56,6 +56,8 @@ struct mgl_sw_ctx {
     // kernel workspace, two halves: the traceback of chunk k (aux stream) overlaps the fill of chunk k+1
     DevBuf tb[2], rec[2], diag, scratch;
     int carry_memory = 0; // 0 = LDS when it fits, 1 = always the HBM scratch (tests)
+    int stripe_rows = 0;  // 0 = choose per batch, 16 / 64 = force (tests)
+    int last_rows = 16;
     hipStream_t aux = nullptr;                       // traceback stream
     hipEvent_t fill_done[2] = {nullptr, nullptr};    // fill of the chunk in half h finished (caller's stream)
     hipEvent_t tb_done[2] = {nullptr, nullptr};      // traceback of the chunk in half h finished (aux stream)
@@ -103,12 +105,19 @@ bool strategy_ok(int s)
 }
 
 // largest waves-per-block whose LDS carve fits; 0 if even one wave does not
-int pick_waves_per_block(int sps_cap)
+int pick_waves_per_block(int sps_cap, int rows)
 {
+    // a wave whose carve exceeds 40 KiB would leave fewer than four waves per CU: such queries keep their
+    // carry in the HBM scratch instead (return 0)
+    if (dp_lds_bytes(sps_cap, 1, rows) > 40 * 1024) return 0;
     for (int w = 4; w >= 1; w >>= 1)
-        if (dp_lds_bytes(sps_cap, w) <= 64 * 1024) return w;
-    return dp_lds_bytes(sps_cap, 1) <= kMaxLdsBytes ? 1 : 0;
+        if (dp_lds_bytes(sps_cap, w, rows) <= 64 * 1024) return w;
+    return 1;
 }
+
+// queries from this length on run one pair per wave (64-row stripes): the pipeline fill/drain is then
+// 63/(ql+64) <= 6 %, and a batch needs four times fewer pairs to occupy the machine
+constexpr int kRows64MinQuery = 1024;
 
 int max_lds_query_len()
 {
@@ -116,7 +125,7 @@ int max_lds_query_len()
     int lo = 1, hi = 1 << 20;
     while (lo < hi) {
         int mid = (lo + hi + 1) / 2;
-        if (dp_lds_bytes(sps_for(mid), 1) <= kMaxLdsBytes)
+        if (dp_lds_bytes(sps_for_rows(mid, 64), 1, 64) <= 40 * 1024)
             lo = mid;
         else
             hi = mid - 1;
@@ -136,18 +145,20 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch_device: bad argument");
     mgl_sw_normalize_params(&match, &mismatch, &gopen, &gext);
 
-    const int sps_cap = sps_for(max_ql);
     // packed-int16 kernel: one geometry for the whole batch and a score range that fits 16 bits
-    const bool use16 = uniform && ctx->precision != 32 && dp16_lds_bytes(sps_cap, 4) <= 64 * 1024 &&
+    const bool use16 = uniform && ctx->precision != 32 && dp16_lds_bytes(sps_for(max_ql), 4) <= 64 * 1024 &&
                        dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
-    int wpb = use16 ? 4 : pick_waves_per_block(sps_cap);
+    // int32 kernel: 16 target rows per stripe (four pairs per wave) or 64 (one pair per wave, long reads)
+    const int rows = use16 ? 16 : ctx->stripe_rows ? ctx->stripe_rows : (max_ql >= kRows64MinQuery ? 64 : 16);
+    const int sps_cap = sps_for_rows(max_ql, rows);
+    int wpb = use16 ? 4 : pick_waves_per_block(sps_cap, rows);
     // queries too long for the LDS carve: carry ring and query copies in an HBM scratch area instead
     const bool use_scratch = !use16 && (wpb == 0 || ctx->carry_memory == 1);
     if (use_scratch) wpb = 4;
     if ((int64_t)max_tl * max_ql > (1ll << 34) || max_ql > (1 << 24) || max_tl > (1 << 24))
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "matrix larger than 2^34 cells");
     // traceback words per pair (int32 layout) or per group of two pairs (packed16 layout)
-    const int64_t stride_words = use16 ? tb_words16_for(max_tl, max_ql) : tb_words_for(max_tl, sps_cap);
+    const int64_t stride_words = use16 ? tb_words16_for(max_tl, max_ql) : tb_words_for(max_tl, sps_cap, rows);
     const int64_t per_pair = stride_words * 4 / (use16 ? 2 : 1) + (int64_t)sizeof(DpRecord);
     // the workspace is split in two halves so that the traceback of one chunk can run (on ctx->aux)
     // while the next chunk is being filled; a batch that fits one half is a single chunk
@@ -171,7 +182,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
 
     if (use_scratch) {
         const int64_t groups = (chunk + 15) / 16 * 16; // every group of every launched wave has its own area
-        HIP_TRY(ctx, ctx->scratch.reserve((size_t)(groups * dp_group_bytes(sps_cap))));
+        HIP_TRY(ctx, ctx->scratch.reserve((size_t)(groups * dp_group_bytes(sps_cap, rows))));
     }
 
     ctx->timing = mgl_sw_timing{};
@@ -201,7 +212,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         da.rec = static_cast<DpRecord *>(ctx->rec[h].p);
         da.scratch = use_scratch ? static_cast<unsigned char *>(ctx->scratch.p) : nullptr;
         da.diag = nullptr;
-        const int per_block = use16 ? wpb * 8 : wpb * 4;
+        const int per_block = use16 ? wpb * 8 : wpb * (64 / rows);
         const int64_t n_blocks = (count + per_block - 1) / per_block;
         if (ctx->profiling >= 2) {
             HIP_TRY(ctx, ctx->diag.reserve((size_t)n_blocks * 16));
@@ -217,6 +228,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         ta.tb = da.tb;
         ta.tb_stride_words = stride_words;
         ta.packed16 = use16 ? 1 : 0;
+        ta.rows_per_stripe = rows;
         ta.rec = da.rec;
         ta.offset = d_offset;
         ta.score = d_score;
@@ -241,7 +253,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         // this half was last read by the traceback of chunk k-2
         if (overlap && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->tb_done[h], 0));
         if (pe[0]) HIP_TRY(ctx, hipEventRecord(pe[0], stream));
-        HIP_TRY(ctx, use16 ? launch_dp16(da, wpb, stream) : launch_dp(da, wpb, stream));
+        HIP_TRY(ctx, use16 ? launch_dp16(da, wpb, stream) : launch_dp(da, wpb, rows, stream));
         if (pe[1]) HIP_TRY(ctx, hipEventRecord(pe[1], stream));
         if (overlap) {
             HIP_TRY(ctx, hipEventRecord(ctx->fill_done[h], stream));
@@ -257,6 +269,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         ctx->last_stride_words = stride_words;
         ctx->last_chunk_count = count;
         ctx->last_half = h;
+        ctx->last_rows = rows;
         ctx->last_packed16 = use16 ? 1 : 0;
         ctx->timing.dp_launches++;
         ctx->timing.tb_launches++;
@@ -384,6 +397,14 @@ int mgl_sw_ctx_set_carry_memory(mgl_sw_ctx *ctx, int mode)
     if (!ctx || (mode != 0 && mode != 1)) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->carry_memory = mode;
+    return MGL_SW_OK;
+}
+
+int mgl_sw_ctx_set_stripe_rows(mgl_sw_ctx *ctx, int rows)
+{
+    if (!ctx || (rows != 0 && rows != 16 && rows != 64)) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->stripe_rows = rows;
     return MGL_SW_OK;
 }
 
@@ -613,7 +634,7 @@ int mgl_sw_ctx_expand_slot(mgl_sw_ctx *ctx, int64_t slot, int tl, int ql, int32_
     HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
     HIP_TRY(ctx, launch_expand(static_cast<const uint32_t *>(ctx->tb[ctx->last_half].p) + region * ctx->last_stride_words,
                                static_cast<const DpRecord *>(ctx->rec[ctx->last_half].p) + slot, tl, ql, ctx->last_packed16,
-                               (int)(slot & 1), static_cast<int32_t *>(ctx->d_btr.p), ctx->stream));
+                               (int)(slot & 1), ctx->last_rows, static_cast<int32_t *>(ctx->d_btr.p), ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(btr, ctx->d_btr.p, cells * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MGL_SW_OK;

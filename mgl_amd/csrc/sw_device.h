@@ -67,6 +67,7 @@ struct TbArgs {
     const uint32_t *tb;
     int64_t tb_stride_words; // per pair (int32 layout) or per group of two pairs (packed16 layout)
     int packed16;            // traceback layout written by sw_dp16_kernel
+    int rows_per_stripe;     // 16 or 64 (int32 layout)
     const DpRecord *rec;
     int32_t *offset; // indexed by batch pair index
     Score *score;    // optional
@@ -77,12 +78,16 @@ struct TbArgs {
     int32_t *status;    // optional
 };
 
-// geometry helpers (host and device agree on these)
-__host__ __device__ inline int sps_for(int ql) { return (ql + 16 + 3) & ~3; }
+// geometry helpers (host and device agree on these); rows = target rows per stripe = lanes per pair (16 or 64)
+__host__ __device__ inline int sps_for_rows(int ql, int rows) { return (ql + rows + 3) & ~3; }
+__host__ __device__ inline int sps_for(int ql) { return sps_for_rows(ql, 16); }
 __host__ __device__ inline int stripes_for(int tl) { return (tl + 15) >> 4; }
-__host__ __device__ inline int64_t tb_words_for(int tl, int sps)
+__host__ __device__ inline int dp_ring_entries(int sps_cap, int rows) { return sps_cap + rows + 4; }
+__host__ __device__ inline int dp_qcopy_bytes(int sps_cap, int rows) { return sps_cap + rows + 16; }
+// int32 layout: per 32 steps, `rows` lanes x four 32-bit planes
+__host__ __device__ inline int64_t tb_words_for(int tl, int sps, int rows)
 {
-    return (((int64_t)stripes_for(tl) * sps + 31) >> 5) * 64;
+    return ((((int64_t)(tl + rows - 1) / rows) * sps + 31) >> 5) * rows * 4;
 }
 
 // ---- schedule of sw_dp16_kernel (sw_dp16.hip): the first nc stripes run as one continuous pipeline with
@@ -103,17 +108,17 @@ __host__ __device__ inline int64_t dp16_total_steps(int tl, int ql)
 // packed16 layout: two dwords per lane per 8 steps, per group of two pairs
 __host__ __device__ inline int64_t tb_words16_for(int tl, int ql) { return ((dp16_total_steps(tl, ql) + 7) >> 3) * 32; }
 
-int64_t dp_group_bytes(int sps_cap); // carry ring + query copies of one pair (LDS, or HBM scratch for long queries)
-int dp_lds_bytes(int sps_cap, int waves_per_block);
+int64_t dp_group_bytes(int sps_cap, int rows); // carry ring + query copies of one pair (LDS, or HBM scratch)
+int dp_lds_bytes(int sps_cap, int waves_per_block, int rows);
 int dp16_lds_bytes(int sps, int waves_per_block);
 bool dp16_range_ok(int tl, int ql, int match, int mismatch, int gopen, int gext, int strategy);
 hipError_t launch_dp16(const DpArgs &a, int waves_per_block, hipStream_t stream);
-hipError_t launch_dp(const DpArgs &a, int waves_per_block, hipStream_t stream);
+hipError_t launch_dp(const DpArgs &a, int waves_per_block, int rows, hipStream_t stream);
 hipError_t launch_traceback(const TbArgs &a, hipStream_t stream);
 hipError_t launch_cigar_from_matrix(const int32_t *btr, int tl, int ql, int strategy, const Score &ez, char *cigar,
                                     int cap, int32_t *out3, hipStream_t stream);
-hipError_t launch_expand(const uint32_t *tbw, const DpRecord *rec, int tl, int ql, int packed16, int half, int32_t *btr,
-                         hipStream_t stream);
+hipError_t launch_expand(const uint32_t *tbw, const DpRecord *rec, int tl, int ql, int packed16, int half, int rows,
+                         int32_t *btr, hipStream_t stream);
 
 } // namespace mgl_sw_dev
 #endif

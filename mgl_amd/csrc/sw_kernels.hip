@@ -43,12 +43,15 @@
 namespace mgl_sw_dev {
 
 constexpr int DPP_ROW_SHR1 = 0x111;
-constexpr int RING_SLACK = 20, QCOPY_SLACK = 32;
 
-__device__ __forceinline__ int row_shr1(int lane0_value, int src)
+constexpr int DPP_WAVE_SHR1 = 0x138;
+
+// every lane takes src from the lane below it inside its group of G lanes (G = 16: one DPP row, row_shr:1;
+// G = 64: the whole wave, wave_shr:1); lane 0 of the group keeps lane0_value (the stripe carry)
+template <int G>
+__device__ __forceinline__ int lane_shr1(int lane0_value, int src)
 {
-    // lanes 1..15 of each 16-lane row take src from the lane below; lane 0 keeps lane0_value
-    return __builtin_amdgcn_update_dpp(lane0_value, src, DPP_ROW_SHR1, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(lane0_value, src, G == 16 ? DPP_ROW_SHR1 : DPP_WAVE_SHR1, 0xf, 0xf, false);
 }
 
 __device__ __forceinline__ unsigned shift_in_sign(unsigned acc, int d)
@@ -124,7 +127,7 @@ struct Carry {
     }
 };
 
-template <bool PRO, bool EPI, bool SCRATCH>
+template <bool PRO, bool EPI, bool SCRATCH, int G>
 __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, const int4 *ring_next,
                                       const unsigned qw, const int tb, const int s0, const int L, const int hb,
                                       const int qcap, const int row_i, const int match, const int mismatch,
@@ -137,8 +140,8 @@ __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, c
 #ifndef MGL_ABLATE_RINGREAD
         if (u == 2) ringA = Carry<SCRATCH>::load2cols(ring_next);
 #endif
-        const int hup_new = row_shr1(rh, st.h_prev);
-        const int ein = row_shr1(re, st.e_prev);
+        const int hup_new = lane_shr1<G>(rh, st.h_prev);
+        const int ein = lane_shr1<G>(re, st.e_prev);
         const int qb = (int)((qw >> (8 * u)) & 0xffu);
         const int diag = st.hup + (qb == tb ? match : mismatch);
         const int d1 = diag - st.f; // < 0 <=> F > diag
@@ -182,9 +185,13 @@ __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, c
 #endif
 }
 
-template <bool SCRATCH>
+// G = target rows per stripe = lanes per pair: 16 (four pairs per wave; short reads: little fill/drain per
+// stripe) or 64 (one pair per wave, the classic 64-row wavefront; long reads: 4x the waves for the same
+// traceback memory, fill/drain 63/(ql+64)).
+template <int G, bool SCRATCH>
 __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
 {
+    constexpr int PW = 64 / G; // pairs per wave
     unsigned long long diag_t0 = 0, diag_w0 = 0;
     if (a.diag) { // in-kernel clock probe (MI355X_MICROARCH.md, DVFS give-back item 6); off in normal runs
         diag_t0 = __builtin_amdgcn_s_memtime();
@@ -193,9 +200,9 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int grp = lane >> 4;
-    const int L = lane & 15;
-    const int64_t slot = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 4 + grp;
+    const int grp = lane / G;
+    const int L = lane % G;
+    const int64_t slot = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * PW + grp;
     // a wave with no pair at all leaves; in a partly filled wave the idle groups recompute the
     // last pair (same wave => same geometry) but never store anything
     if (slot - grp >= a.count) return;
@@ -206,12 +213,12 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
     const int tl = a.t.length(p);
     const int ql = a.q.length(p);
 
-    const int nstripes = stripes_for(tl);
+    const int nstripes = (tl + G - 1) / G;
 
-    // wave-uniform loop bounds over the four groups
+    // wave-uniform loop bounds over the groups of the wave
     int ql_max = ql, ql_min = ql, ns_max = nstripes;
 #pragma unroll
-    for (int m = 16; m < 64; m <<= 1) {
+    for (int m = G; m < 64; m <<= 1) {
         ql_max = max(ql_max, __shfl_xor(ql_max, m));
         ql_min = min(ql_min, __shfl_xor(ql_min, m));
         ns_max = max(ns_max, __shfl_xor(ns_max, m));
@@ -219,18 +226,18 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
     ql_max = __builtin_amdgcn_readfirstlane(ql_max);
     ql_min = __builtin_amdgcn_readfirstlane(ql_min);
     ns_max = __builtin_amdgcn_readfirstlane(ns_max);
-    const int sps = sps_for(ql_max);                             // steps per stripe
-    const int main_end = max(16, ql_min & ~3);                   // [16, main_end): no border, no last column
+    const int sps = sps_for_rows(ql_max, G);                     // steps per stripe
+    const int main_end = max(G, ql_min & ~3);                    // [G, main_end): no border, no last column
 
-    // LDS carve: per group  ring[sps_cap+20] int2 | 4 x qcopy[sps_cap+32] bytes
-    // (the slack covers columns -16..-1 and the one-block-ahead prefetches)
-    const int ring_entries = a.sps_cap + RING_SLACK;
-    const int qcopy_bytes = a.sps_cap + QCOPY_SLACK;
+    // carve per group: ring[sps_cap + G + 4] int2 | 4 x qcopy[sps_cap + G + 16] bytes
+    // (the slack covers columns -G..-1 and the one-block-ahead prefetches)
+    const int ring_entries = dp_ring_entries(a.sps_cap, G);
+    const int qcopy_bytes = dp_qcopy_bytes(a.sps_cap, G);
     const int group_bytes = ring_entries * 8 + 4 * qcopy_bytes;
     unsigned char *gbase =
-        SCRATCH ? a.scratch + ((size_t)blockIdx.x * (blockDim.x >> 6) * 4 + (size_t)(wave * 4 + grp)) * group_bytes
-                : smem + (size_t)(wave * 4 + grp) * group_bytes;
-    int2 *ring = reinterpret_cast<int2 *>(gbase); // ring[j + 16] holds column j
+        SCRATCH ? a.scratch + ((size_t)blockIdx.x * (blockDim.x >> 6) * PW + (size_t)(wave * PW + grp)) * group_bytes
+                : smem + (size_t)(wave * PW + grp) * group_bytes;
+    int2 *ring = reinterpret_cast<int2 *>(gbase); // ring[j + G] holds column j
     unsigned char *qcopy = gbase + ring_entries * 8;
 
     // match / mismatch feed a v_cndmask every step: pin them in VGPRs (two SGPR sources
@@ -240,21 +247,21 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
     const int gopen = a.gopen, gext = a.gext;
     const bool indel = (a.strategy & (OS_INDEL | OS_LEAD_ID)) != 0;
 
-    // ---- stage the query: copy k holds q shifted right by 16 + k bytes, zero elsewhere
+    // ---- stage the query: copy k holds q shifted right by G + k bytes, zero elsewhere
     {
         unsigned *qz = reinterpret_cast<unsigned *>(qcopy);
-        for (int w = L; w < qcopy_bytes; w += 16) qz[w] = 0u; // 4 * qcopy_bytes bytes == qcopy_bytes dwords
+        for (int w = L; w < qcopy_bytes; w += G) qz[w] = 0u; // 4 * qcopy_bytes bytes == qcopy_bytes dwords
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int x = L; x < ql; x += 16) {
+        for (int x = L; x < ql; x += G) {
             const unsigned char c = (unsigned char)a.q.at(q0, x);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) qcopy[k * qcopy_bytes + x + 16 + k] = c;
+            for (int k = 0; k < 4; ++k) qcopy[k * qcopy_bytes + x + G + k] = c;
         }
         // ---- border row into the ring: H[0][j], E[1][j] = H[0][j] - o   (sw.cpp:14-18,31-35)
-        for (int j = L; j <= ql_max; j += 16) {
+        for (int j = L; j <= ql_max; j += G) {
             const int hb0 = border(j, gopen, gext, indel);
-            Carry<SCRATCH>::store1col(ring + j + 16, hb0, hb0 - gopen);
+            Carry<SCRATCH>::store1col(ring + j + G, hb0, hb0 - gopen);
         }
         if (SCRATCH)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the plain byte stores above reach L2 before any read
@@ -269,9 +276,9 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
     st.best = NEG_INF;
     st.best_i = -1;
 
-    const int last_lane = (tl - 1) & 15; // owner of row tl in the final stripe
+    const int last_lane = (tl - 1) % G; // owner of row tl in the final stripe
     const int qk = (L + 1) & 3, qm = (L + 1) >> 2;
-    const unsigned *qrd0 = reinterpret_cast<const unsigned *>(qcopy + qk * qcopy_bytes) + (4 - qm);
+    const unsigned *qrd0 = reinterpret_cast<const unsigned *>(qcopy + qk * qcopy_bytes) + (G / 4 - qm);
 
     uint32_t *tbp = a.tb + (size_t)(valid ? slot : a.count - 1) * a.tb_stride_words + L * 4;
     int gsteps = 0; // wave-uniform global step counter (traceback bit position)
@@ -282,17 +289,17 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
     for (int k = 0; k < ns_max; ++k) {
         const int row_i = row_next;
         const int tb = tb_next;
-        row_next += 16;
+        row_next += G;
         tb_next = (row_next >= 1 && row_next <= tl) ? a.t.at(t0, row_next - 1) : 0;
 
         const int hb = border(row_i, gopen, gext, indel);
-        const int qcap = row_i <= tl ? ql : NEG_INF; // s - L >= -15 never equals NEG_INF
+        const int qcap = row_i <= tl ? ql : NEG_INF; // s - L > -G never equals NEG_INF
         // the lane owning this stripe's last row publishes the carry (sw_avx.cpp:196-197)
-        const int wl = (k == nstripes - 1) ? last_lane : 15;
+        const int wl = (k == nstripes - 1) ? last_lane : G - 1;
         const bool writer = (L == wl);
 
-        const int4 *ring_rd = reinterpret_cast<const int4 *>(ring + 16);
-        int2 *ring_wr = ring + 16 - wl; // at step s the writer is at column s - wl
+        const int4 *ring_rd = reinterpret_cast<const int4 *>(ring + G);
+        int2 *ring_wr = ring + G - wl; // at step s the writer is at column s - wl
         const unsigned *qrd = qrd0;
         int4 rA = Carry<SCRATCH>::load2cols(ring_rd), rB = Carry<SCRATCH>::load2cols(ring_rd + 1);
         unsigned qw = Carry<SCRATCH>::loadq(qrd);
@@ -301,8 +308,8 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
 #define MGL_SW_BLOCK(PRO, EPI)                                                                             \
     {                                                                                                      \
         const unsigned nq = MGL_QREAD(qrd);                                                                \
-        step4<PRO, EPI, SCRATCH>(st, rA, rB, ring_rd + 2, qw, tb, s, L, hb, qcap, row_i, match, mismatch,  \
-                                 gopen, gext, ring_wr, writer);                                            \
+        step4<PRO, EPI, SCRATCH, G>(st, rA, rB, ring_rd + 2, qw, tb, s, L, hb, qcap, row_i, match,         \
+                                    mismatch, gopen, gext, ring_wr, writer);                               \
         qw = nq;                                                                                           \
         ring_rd += 2;                                                                                      \
         ring_wr += 4;                                                                                      \
@@ -311,10 +318,10 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
         gsteps += 4;                                                                                       \
         if ((gsteps & 31) == 0) {                                                                          \
             if (valid && !MGL_ABLATE_TBSTORE_V) *reinterpret_cast<uint4 *>(tbp) = make_uint4(st.a0, st.a1, st.a2, st.a3); \
-            tbp += 64;                                                                                     \
+            tbp += G * 4;                                                                                  \
         }                                                                                                  \
     }
-        for (; s < 16;) MGL_SW_BLOCK(true, true)
+        for (; s < G;) MGL_SW_BLOCK(true, true)
         for (; s < main_end;) MGL_SW_BLOCK(false, false)
         for (; s < sps;) MGL_SW_BLOCK(false, true)
 #undef MGL_SW_BLOCK
@@ -325,7 +332,7 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
             __builtin_amdgcn_wave_barrier();
             int mqe = st.best, mqe_t = st.best_i;
 #pragma unroll
-            for (int m = 1; m < 16; m <<= 1) {
+            for (int m = 1; m < G; m <<= 1) {
                 const int ob = __shfl_xor(mqe, m), oi = __shfl_xor(mqe_t, m);
                 const bool take = ob > mqe || (ob == mqe && oi > mqe_t);
                 mqe = take ? ob : mqe;
@@ -333,8 +340,8 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
             }
             // last row: best score, then closest to the diagonal, then smallest column
             int rm = NEG_INF, rd = 0x7fffffff, rj = 0x7fffffff;
-            for (int j = L + 1; j <= ql; j += 16) {
-                const int sc = Carry<SCRATCH>::load1col(ring + j + 16).x;
+            for (int j = L + 1; j <= ql; j += G) {
+                const int sc = Carry<SCRATCH>::load1col(ring + j + G).x;
                 const int d = abs(tl - j);
                 const bool take = sc > rm || (sc == rm && d < rd);
                 rm = take ? sc : rm;
@@ -342,7 +349,7 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
                 rj = take ? j : rj;
             }
 #pragma unroll
-            for (int m = 1; m < 16; m <<= 1) {
+            for (int m = 1; m < G; m <<= 1) {
                 const int om = __shfl_xor(rm, m), od = __shfl_xor(rd, m), oj = __shfl_xor(rj, m);
                 const bool take = om > rm || (om == rm && (od < rd || (od == rd && oj < rj)));
                 rm = take ? om : rm;
@@ -380,32 +387,42 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
 __global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    sw_dp_body<false>(a, smem);
+    sw_dp_body<16, false>(a, smem);
 }
 
 // long queries: the carry ring and the query copies do not fit LDS and live in an HBM scratch area
-__global__ __launch_bounds__(256) void sw_dp_scratch_kernel(const DpArgs a) { sw_dp_body<true>(a, nullptr); }
+__global__ __launch_bounds__(256) void sw_dp_scratch_kernel(const DpArgs a) { sw_dp_body<16, true>(a, nullptr); }
+
+// one pair per wave (64-row stripes): long reads
+__global__ __launch_bounds__(256) void sw_dp64_kernel(const DpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    sw_dp_body<64, false>(a, smem);
+}
+__global__ __launch_bounds__(256) void sw_dp64_scratch_kernel(const DpArgs a) { sw_dp_body<64, true>(a, nullptr); }
 
 // ---------------------------------------------------------------------------------------------
 // traceback bits accessor shared by the path walk and the matrix expansion
 struct TbView {
     const uint32_t *base; // this pair's (int32 layout) or this group's (packed16 layout) traceback words
     int sps;
+    int rows;                 // target rows per stripe (= lanes per pair) of the fill kernel: 16 or 64
     int packed16, half;
     int g_tail, nc, sps_tail; // packed16 only: stripes >= nc are stand-alone, starting at global step g_tail
-    __device__ __forceinline__ void set_schedule(const DpRecord &r, int ql)
+    __device__ __forceinline__ void set_schedule(const DpRecord &r, int ql, int rows_per_stripe)
     {
+        rows = rows_per_stripe;
         sps = r.sps;
         g_tail = r.g_tail;
         nc = r.g_tail > 0 ? (r.g_tail - 16) / r.sps : 0;
-        sps_tail = sps_for(ql);
+        sps_tail = sps_for_rows(ql, 16);
     }
     // nibble of cell (i, j), 1-based: bit0 F>diag, bit1 E>max(diag,F), bit2 E opened, bit3 F opened
     __device__ __forceinline__ unsigned cell(int i, int j) const
     {
         const int r = i - 1;
-        const int lane = r & 15;
-        const int k = r >> 4;
+        const int lane = r % rows;
+        const int k = r / rows;
         const int g = (g_tail > 0 && k >= nc ? g_tail + (k - nc) * sps_tail : k * sps) + j + lane;
         if (packed16) {
             // sw_dp16.hip: dword per lane per 4 steps (two per 8-step block);
@@ -415,7 +432,7 @@ struct TbView {
             const unsigned be = (w >> (8 * half)) >> t2, bf = (w >> (16 + 8 * half)) >> t2;
             return ((bf >> 1) & 1u) | (((be >> 1) & 1u) << 1) | ((bf & 1u) << 2) | ((be & 1u) << 3);
         }
-        const uint4 w = *reinterpret_cast<const uint4 *>(base + (size_t)(g >> 5) * 64 + lane * 4);
+        const uint4 w = *reinterpret_cast<const uint4 *>(base + ((size_t)(g >> 5) * rows + lane) * 4);
         const int sh = 31 - (g & 31);
         return ((w.x >> sh) & 1u) | (((w.y >> sh) & 1u) << 1) | (((w.z >> sh) & 1u) << 2) |
                (((w.w >> sh) & 1u) << 3);
@@ -584,7 +601,7 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
 
     BitsMoves mv;
     mv.tb.base = a.tb + (size_t)(a.packed16 ? slot >> 1 : slot) * a.tb_stride_words;
-    mv.tb.set_schedule(r, ql);
+    mv.tb.set_schedule(r, ql, a.rows_per_stripe);
     mv.tb.packed16 = a.packed16;
     mv.tb.half = (int)(slot & 1);
 
@@ -637,14 +654,14 @@ __global__ void sw_cigar_from_matrix_kernel(const int32_t *btr, int tl, int ql, 
 // Logical backtrack matrix of ONE pair (slot 0 of the workspace): the int32 run lengths the
 // reference stores (sw.cpp:62,66,70), rebuilt from the 4-bit cells.
 __global__ __launch_bounds__(256) void sw_expand_kernel(const uint32_t *tbw, const DpRecord *rec, int tl, int ql,
-                                                        int packed16, int half, int32_t *btr)
+                                                        int packed16, int half, int rows, int32_t *btr)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= tl * ql) return;
     const int i = idx / ql + 1, j = idx % ql + 1;
     TbView tb;
     tb.base = tbw;
-    tb.set_schedule(rec[0], ql);
+    tb.set_schedule(rec[0], ql, rows);
     tb.packed16 = packed16;
     tb.half = half;
     const unsigned c = tb.cell(i, j);
@@ -659,31 +676,43 @@ __global__ __launch_bounds__(256) void sw_expand_kernel(const uint32_t *tbw, con
 // ---------------------------------------------------------------------------------------------
 // launch wrappers (called from sw_capi.cpp)
 
-int64_t dp_group_bytes(int sps_cap) { return (int64_t)(sps_cap + RING_SLACK) * 8 + 4ll * (sps_cap + QCOPY_SLACK); }
-
-int dp_lds_bytes(int sps_cap, int waves_per_block)
+int64_t dp_group_bytes(int sps_cap, int rows)
 {
-    const int64_t b = waves_per_block * 4 * dp_group_bytes(sps_cap);
+    return (int64_t)dp_ring_entries(sps_cap, rows) * 8 + 4ll * dp_qcopy_bytes(sps_cap, rows);
+}
+
+int dp_lds_bytes(int sps_cap, int waves_per_block, int rows)
+{
+    const int64_t b = waves_per_block * (64 / rows) * dp_group_bytes(sps_cap, rows);
     return b > (1 << 30) ? (1 << 30) : (int)b;
 }
 
-hipError_t launch_dp(const DpArgs &a, int waves_per_block, hipStream_t stream)
+hipError_t launch_dp(const DpArgs &a, int waves_per_block, int rows, hipStream_t stream)
 {
-    const int per_block = waves_per_block * 4;
+    const int per_block = waves_per_block * (64 / rows);
     const int64_t blocks = (a.count + per_block - 1) / per_block;
+    const dim3 grid((unsigned)blocks), block(64 * waves_per_block);
     if (a.scratch) {
-        hipLaunchKernelGGL(sw_dp_scratch_kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), 0, stream, a);
+        if (rows == 64)
+            hipLaunchKernelGGL(sw_dp64_scratch_kernel, grid, block, 0, stream, a);
+        else
+            hipLaunchKernelGGL(sw_dp_scratch_kernel, grid, block, 0, stream, a);
         return hipGetLastError();
     }
-    const int lds = dp_lds_bytes(a.sps_cap, waves_per_block);
-    static int configured_lds = 0;
-    if (lds > 64 * 1024 && lds > configured_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_dp_kernel),
+    const int lds = dp_lds_bytes(a.sps_cap, waves_per_block, rows);
+    static int configured_lds[2] = {0, 0};
+    int &conf = configured_lds[rows == 64];
+    if (lds > 64 * 1024 && lds > conf) {
+        hipError_t e = hipFuncSetAttribute(rows == 64 ? reinterpret_cast<const void *>(sw_dp64_kernel)
+                                                      : reinterpret_cast<const void *>(sw_dp_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        configured_lds = lds;
+        conf = lds;
     }
-    hipLaunchKernelGGL(sw_dp_kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), lds, stream, a);
+    if (rows == 64)
+        hipLaunchKernelGGL(sw_dp64_kernel, grid, block, lds, stream, a);
+    else
+        hipLaunchKernelGGL(sw_dp_kernel, grid, block, lds, stream, a);
     return hipGetLastError();
 }
 
@@ -702,12 +731,12 @@ hipError_t launch_cigar_from_matrix(const int32_t *btr, int tl, int ql, int stra
     return hipGetLastError();
 }
 
-hipError_t launch_expand(const uint32_t *tbw, const DpRecord *rec, int tl, int ql, int packed16, int half, int32_t *btr,
-                         hipStream_t stream)
+hipError_t launch_expand(const uint32_t *tbw, const DpRecord *rec, int tl, int ql, int packed16, int half, int rows,
+                         int32_t *btr, hipStream_t stream)
 {
     const int64_t n = (int64_t)tl * ql;
     hipLaunchKernelGGL(sw_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tbw, rec, tl, ql,
-                       packed16, half, btr);
+                       packed16, half, rows, btr);
     return hipGetLastError();
 }
 

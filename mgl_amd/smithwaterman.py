@@ -139,6 +139,10 @@ class MicrosoftSmithWaterman:
         """0 = stripe carry in LDS when the query fits, 1 = always in the HBM scratch (long-query path)."""
         _check(_lib.lib().mgl_sw_ctx_set_carry_memory(self._ensure(), int(mode)))
 
+    def set_stripe_rows(self, rows):
+        """Lanes per pair of the int32 fill kernel: 0 = by query length, 16 or 64 = forced."""
+        _check(_lib.lib().mgl_sw_ctx_set_stripe_rows(self._ensure(), int(rows)))
+
     def set_profiling(self, on=True):
         _check(_lib.lib().mgl_sw_ctx_set_profiling(self._ensure(), int(on)))
 

@@ -59,6 +59,26 @@ def test_golden_long(aligner):
     assert run_groups(aligner, rows) == len(rows) == 9
 
 
+@pytest.mark.parametrize("rows,carry", [(64, 0), (64, 1), (16, 1)])
+def test_stripe_rows_and_carry_variants(rows, carry):
+    """The int32 fill kernel with 64-row stripes (one pair per wave, wave_shr DPP) and / or the carry in the HBM
+    scratch, forced onto ordinary mixed batches: identical to the goldens, traceback included."""
+    forced = sw.MicrosoftSmithWaterman(0)
+    forced.set_precision(32)
+    forced.set_stripe_rows(rows)
+    forced.set_carry_memory(carry)
+    rows_ = golden_io.load("known") + golden_io.load("shapes") + golden_io.load("random")[:500] + golden_io.load("ties")[::9]
+    assert run_groups(forced, rows_) == len(rows_)
+    gs = [g for g in golden_io.load("random") if g.params == (200, -150, 260, 11) and g.strategy == ol.SOFTCLIP][:24]
+    forced.align_batch([g.t for g in gs], [g.q for g in gs], gs[0].params, ol.SOFTCLIP)
+    for k, g in enumerate(gs):
+        btr = forced.expand_slot(k, len(g.t), len(g.q))
+        assert zlib.crc32(np.ascontiguousarray(btr[1:, 1:]).astype("<i4").tobytes()) & 0xFFFFFFFF == g.crc
+    # long pairs (2 kb, and the 10 kb x 10 kb one) through the same variant
+    assert run_groups(forced, golden_io.load("long")) == 9
+    forced.close()
+
+
 def test_scratch_carry_equals_lds():
     """The long-query path (carry ring + query copies in HBM, agent-scope accesses) forced onto ordinary
     batches must reproduce the goldens exactly."""
