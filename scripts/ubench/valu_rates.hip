@@ -92,6 +92,30 @@ constexpr int UNROLL = 32;
 #define I_SUBREV(n) "v_subrev_u32 %" #n ", %8, %" #n "\n"
 #define I_MAXI16(n) "v_max_i16 %" #n ", %" #n ", %8\n"
 #define I_ADDU16(n) "v_add_u16 %" #n ", %" #n ", %8\n"
+#define I_MAXF(n) "v_max_f32 %" #n ", %" #n ", %8\n"
+#define I_ADDF(n) "v_add_f32 %" #n ", %" #n ", %8\n"
+#define I_SUBF(n) "v_sub_f32 %" #n ", %" #n ", %8\n"
+#define I_MAXF16(n) "v_max_f16 %" #n ", %" #n ", %8\n"
+#define I_PKMAXF16(n) "v_pk_max_f16 %" #n ", %" #n ", %8\n"
+#define I_PKADDF16(n) "v_pk_add_f16 %" #n ", %" #n ", %8\n"
+#define I_MINI16(n) "v_min_i16 %" #n ", %" #n ", %8\n"
+#define I_SUBU16(n) "v_sub_u16 %" #n ", %" #n ", %8\n"
+#define I_ASHR(n) "v_ashrrev_i32 %" #n ", 1, %" #n "\n"
+#define I_MULU24(n) "v_mul_u32_u24 %" #n ", %" #n ", %8\n"
+#define I_FMA(n) "v_fma_f32 %" #n ", %" #n ", %8, %9\n"
+#define I_FMAC(n) "v_fmac_f32 %" #n ", %8, %9\n"
+KERNEL(maxf, REP32(I_MAXF), REP32(I_MAXF))
+KERNEL(addf, REP32(I_ADDF), REP32(I_ADDF))
+KERNEL(subf, REP32(I_SUBF), REP32(I_SUBF))
+KERNEL(maxf16, REP32(I_MAXF16), REP32(I_MAXF16))
+KERNEL(pkmaxf16, REP32(I_PKMAXF16), REP32(I_PKMAXF16))
+KERNEL(pkaddf16, REP32(I_PKADDF16), REP32(I_PKADDF16))
+KERNEL(mini16, REP32(I_MINI16), REP32(I_MINI16))
+KERNEL(subu16, REP32(I_SUBU16), REP32(I_SUBU16))
+KERNEL(ashr, REP32(I_ASHR), REP32(I_ASHR))
+KERNEL(mulu24, REP32(I_MULU24), REP32(I_MULU24))
+KERNEL(fma, REP32(I_FMA), REP32(I_FMA))
+KERNEL(fmac, REP32(I_FMAC), REP32(I_FMAC))
 KERNEL(and_, REP32(I_AND), REP32(I_AND))
 KERNEL(or_, REP32(I_OR), REP32(I_OR))
 KERNEL(min_, REP32(I_MIN), REP32(I_MIN))
@@ -161,6 +185,10 @@ int main(int argc, char **argv)
         {"v_pk_ashrrev_i16", k_pk_ashr_i16, 1, false}, {"v_pk_add_i16 clamp", k_pk_add_clamp, 1, false},
         {"v_perm_b32", k_perm, 1, false}, {"v_bfi_b32", k_bfi, 1, false}, {"v_and_or_b32", k_and_or, 1, false},
         {"v_lshl_or_b32", k_lshl_or, 1, false}, {"v_xor_b32", k_xor_, 1, false}, {"v_lshrrev_b32", k_lshr, 1, false},
+        {"v_max_f32", k_maxf, 1, false}, {"v_add_f32", k_addf, 1, false}, {"v_sub_f32", k_subf, 1, false},
+        {"v_max_f16", k_maxf16, 1, false}, {"v_pk_max_f16", k_pkmaxf16, 1, false}, {"v_pk_add_f16", k_pkaddf16, 1, false},
+        {"v_min_i16", k_mini16, 1, false}, {"v_sub_u16", k_subu16, 1, false}, {"v_ashrrev_i32", k_ashr, 1, false},
+        {"v_mul_u32_u24", k_mulu24, 1, false}, {"v_fma_f32", k_fma, 1, false}, {"v_fmac_f32", k_fmac, 1, false},
         {"v_mov_b32", k_mov, 1, false}, {"v_and_b32", k_and_, 1, false}, {"v_or_b32", k_or_, 1, false},
         {"v_min_i32", k_min_, 1, false}, {"v_max_u32", k_maxu, 1, false}, {"v_pk_mul_lo_u16", k_pkmul, 1, false},
         {"v_mad_i32_i24", k_mad24, 1, false}, {"v_bfe_u32", k_bfe, 1, false}, {"v_pk_lshrrev_b16", k_pklshr, 1, false},
