@@ -9,7 +9,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -59,6 +62,9 @@ struct mgl_sw_ctx {
     int stripe_rows = 0;  // 0 = choose per batch, 16 / 64 = force (tests)
     int last_rows = 16;
     hipStream_t aux = nullptr;                       // traceback stream
+    hipStream_t h2d = nullptr;                       // host-buffer entry: input copies of the next chunk
+    hipEvent_t in_done = nullptr;
+    hipEvent_t out_ready[2] = {nullptr, nullptr};    // host-buffer entry: traceback of chunk k done (k & 1)
     hipEvent_t fill_done[2] = {nullptr, nullptr};    // fill of the chunk in half h finished (caller's stream)
     hipEvent_t tb_done[2] = {nullptr, nullptr};      // traceback of the chunk in half h finished (aux stream)
     int last_half = 0;
@@ -67,7 +73,7 @@ struct mgl_sw_ctx {
     std::vector<hipEvent_t> pool;
     int pool_used = 0;
     int64_t diag_blocks = 0;
-    DevBuf d_t, d_toff, d_q, d_qoff, d_off, d_score, d_cig, d_len, d_status, d_btr; // host-API staging
+    DevBuf d_t, d_toff, d_q, d_qoff, d_off, d_score, d_cig, d_len, d_status, d_btr, d_any; // host-API staging
     int64_t last_stride_words = 0, last_chunk_count = 0; // geometry of the last chunk (for expand_slot)
     int last_packed16 = 0;
     int precision = 0; // 0 = choose per batch, 32 = always the int32 kernel
@@ -133,11 +139,20 @@ int max_lds_query_len()
     return lo;
 }
 
+// Host-buffer entry only: per-chunk hooks that move a chunk's inputs in before its fill is launched and its
+// results out after the NEXT chunk has been launched (pageable copies block the calling thread, so this order
+// is what lets the copies of one chunk overlap the kernels of its neighbours).
+struct ChunkHooks {
+    std::function<int(int64_t first, int64_t count, hipStream_t fill_stream)> before_fill;
+    std::function<int(int64_t first, int64_t count, hipEvent_t results_ready)> after_traceback;
+    int32_t *d_status_any = nullptr;   // device word receiving the largest per-pair status
+};
+
 // Enqueue fill + traceback for a device-resident batch on `stream`.
 int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tset, const SeqSet &qset, int max_tl,
                int max_ql, int match, int mismatch, int gopen, int gext, int strategy, int32_t *d_offset, Score *d_score,
                char *d_cigar, int cigar_stride, int32_t *d_cigar_len, int32_t *d_status, int64_t cells_hint, bool uniform,
-               bool binary_cigar = false)
+               bool binary_cigar = false, const ChunkHooks *hooks = nullptr)
 {
     if (n == 0) return MGL_SW_OK;
     if (n < 0 || !tset.data || !tset.off || !qset.data || !qset.off || !d_offset || !d_cigar || cigar_stride < 1 ||
@@ -191,9 +206,17 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
 
     bool tb_pending[2] = {false, false};
     int64_t k = 0;
+    // result copies trail the launches by two chunks: the traceback of chunk k-2 is what the fill of chunk k waits
+    // for anyway, so the (blocking) copy of its results never stalls behind the low-priority traceback stream
+    struct Pending { int64_t first, count; hipEvent_t ready; } pending[2];
+    int n_pending = 0;
     for (int64_t first = 0; first < n; first += chunk, ++k) {
         const int64_t count = std::min(chunk, n - first);
         const int h = (int)(k & (halves - 1));
+        if (hooks) {
+            const int hrc = hooks->before_fill(first, count, stream);
+            if (hrc != MGL_SW_OK) return hrc;
+        }
         DpArgs da;
         da.t = tset;
         da.q = qset;
@@ -237,6 +260,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         ta.binary_cigar = binary_cigar ? 1 : 0;
         ta.cigar_len = d_cigar_len;
         ta.status = d_status;
+        ta.status_any = hooks ? hooks->d_status_any : nullptr;
 
         hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
         if (ctx->profiling) {
@@ -266,6 +290,17 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             HIP_TRY(ctx, hipEventRecord(ctx->tb_done[h], ctx->aux));
             tb_pending[h] = true;
         }
+        if (hooks) {
+            if (n_pending == 2) {
+                const int hrc = hooks->after_traceback(pending[0].first, pending[0].count, pending[0].ready);
+                if (hrc != MGL_SW_OK) return hrc;
+                pending[0] = pending[1];
+                n_pending = 1;
+            }
+            // (chunk k-2, just copied out, was the last user of this event)
+            HIP_TRY(ctx, hipEventRecord(ctx->out_ready[k & 1], tb_stream));
+            pending[n_pending++] = Pending{first, count, ctx->out_ready[k & 1]};
+        }
         ctx->last_stride_words = stride_words;
         ctx->last_chunk_count = count;
         ctx->last_half = h;
@@ -275,6 +310,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         ctx->timing.tb_launches++;
         ctx->timing.tb_bytes += (use16 ? (count + 1) / 2 : count) * stride_words * 4;
         ctx->timing.packed16 = use16 ? 1 : 0;
+    }
+    for (int i = 0; hooks && i < n_pending; ++i) {
+        const int hrc = hooks->after_traceback(pending[i].first, pending[i].count, pending[i].ready);
+        if (hrc != MGL_SW_OK) return hrc;
     }
     // everything this call enqueued is ordered before whatever the caller enqueues next on `stream`
     for (int h = 0; h < 2; ++h)
@@ -342,6 +381,9 @@ int mgl_sw_ctx_create(int device, mgl_sw_ctx **out)
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (const char *e = getenv("MGL_SW_AUX_PRIO")) prio_lo = atoi(e);
     bool ok = hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, prio_lo) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&ctx->h2d, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->in_done, hipEventDisableTiming) == hipSuccess;
+    for (auto &e : ctx->out_ready) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     for (auto *set : {ctx->fill_done, ctx->tb_done})
         for (int h = 0; h < 2; ++h) ok = ok && hipEventCreateWithFlags(&set[h], hipEventDisableTiming) == hipSuccess;
@@ -360,7 +402,7 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     for (DevBuf *b : {&ctx->tb[0], &ctx->tb[1], &ctx->rec[0], &ctx->rec[1], &ctx->diag, &ctx->scratch, &ctx->d_t, &ctx->d_toff, &ctx->d_q, &ctx->d_qoff, &ctx->d_off, &ctx->d_score,
-                      &ctx->d_cig, &ctx->d_len, &ctx->d_status, &ctx->d_btr})
+                      &ctx->d_cig, &ctx->d_len, &ctx->d_status, &ctx->d_btr, &ctx->d_any})
         b->release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
@@ -369,6 +411,10 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     for (auto *set : {ctx->fill_done, ctx->tb_done})
         for (int h = 0; h < 2; ++h)
             if (set[h]) (void)hipEventDestroy(set[h]);
+    if (ctx->in_done) (void)hipEventDestroy(ctx->in_done);
+    for (auto &e : ctx->out_ready)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->h2d) (void)hipStreamDestroy(ctx->h2d);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -512,20 +558,20 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     if (n < 0 || !targets || !t_off || !queries || !q_off || !offset_out || !cigar_out || cigar_stride < 1 ||
         !strategy_ok(strategy))
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: bad argument");
-    int max_tl = 0, max_ql = 0;
-    int64_t cells = 0;
-    bool uniform = true;
-    const int64_t tl0 = t_off[1] - t_off[0], ql0 = q_off[1] - q_off[0];
-    for (int64_t k = 0; k < n; ++k) {
+    int64_t lo_t = INT64_MAX, hi_t = 0, lo_q = INT64_MAX, hi_q = 0, cells = 0;
+    for (int64_t k = 0; k < n; ++k) {   // branch-free so that it vectorises: 16 bytes of offsets per pair
         const int64_t tl = t_off[k + 1] - t_off[k], ql = q_off[k + 1] - q_off[k];
-        uniform = uniform && tl == tl0 && ql == ql0;
-        // the reference reads out of bounds for empty sequences (sw.cpp:162-163,184): rejected here
-        if (tl < 1 || ql < 1 || tl > 0x3fffffff || ql > 0x3fffffff)
-            return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: sequence length < 1 or too large");
-        max_tl = std::max<int>(max_tl, (int)tl);
-        max_ql = std::max<int>(max_ql, (int)ql);
+        lo_t = std::min(lo_t, tl);
+        hi_t = std::max(hi_t, tl);
+        lo_q = std::min(lo_q, ql);
+        hi_q = std::max(hi_q, ql);
         cells += tl * ql;
     }
+    // the reference reads out of bounds for empty sequences (sw.cpp:162-163,184): rejected here
+    if (lo_t < 1 || lo_q < 1 || hi_t > 0x3fffffff || hi_q > 0x3fffffff)
+        return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: sequence length < 1 or too large");
+    const int max_tl = (int)hi_t, max_ql = (int)hi_q;
+    const bool uniform = lo_t == hi_t && lo_q == hi_q;
     const size_t t_bytes = (size_t)(t_off[n] - t_off[0]), q_bytes = (size_t)(q_off[n] - q_off[0]);
     if (t_off[0] != 0 || q_off[0] != 0)
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: offsets must start at 0");
@@ -540,35 +586,76 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     HIP_TRY(ctx, ctx->d_cig.reserve((size_t)n * cigar_stride));
     HIP_TRY(ctx, ctx->d_len.reserve((size_t)n * 4));
     HIP_TRY(ctx, ctx->d_status.reserve((size_t)n * 4));
+    HIP_TRY(ctx, ctx->d_any.reserve(16));
     hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_t.p, targets, t_bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q.p, queries, q_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_any.p, 0, 4, st));
+    // offsets first (16 bytes per pair); the bases follow chunk by chunk, overlapped with the kernels
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_toff.p, t_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_qoff.p, q_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
 
+    ChunkHooks hooks;
+    hooks.d_status_any = static_cast<int32_t *>(ctx->d_any.p);
+    static const bool host_timing = getenv("MGL_SW_HOST_TIMING") != nullptr;   // diagnostic: where the calling thread waits
+    double t_in = 0, t_out = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    hooks.before_fill = [&](int64_t first, int64_t count, hipStream_t fill_stream) -> int {
+        const double t0 = now();
+        const int64_t ta = t_off[first], tb = t_off[first + count], qa = q_off[first], qb = q_off[first + count];
+        HIP_TRY(ctx, hipMemcpyAsync(static_cast<uint8_t *>(ctx->d_t.p) + ta, targets + ta, (size_t)(tb - ta),
+                                    hipMemcpyHostToDevice, ctx->h2d));
+        HIP_TRY(ctx, hipMemcpyAsync(static_cast<uint8_t *>(ctx->d_q.p) + qa, queries + qa, (size_t)(qb - qa),
+                                    hipMemcpyHostToDevice, ctx->h2d));
+        HIP_TRY(ctx, hipEventRecord(ctx->in_done, ctx->h2d));
+        HIP_TRY(ctx, hipStreamWaitEvent(fill_stream, ctx->in_done, 0));
+        t_in += now() - t0;
+        return MGL_SW_OK;
+    };
+    hooks.after_traceback = [&](int64_t first, int64_t count, hipEvent_t results_ready) -> int {
+        const double t0 = now();
+        hipStream_t tb_stream = ctx->h2d;   // the copy stream: never queued behind a later chunk's kernels
+        HIP_TRY(ctx, hipStreamWaitEvent(tb_stream, results_ready, 0));
+        const size_t f = (size_t)first, c = (size_t)count;
+        HIP_TRY(ctx, hipMemcpyAsync(offset_out + f, static_cast<int32_t *>(ctx->d_off.p) + f, c * 4, hipMemcpyDeviceToHost,
+                                    tb_stream));
+        if (score_out)
+            HIP_TRY(ctx, hipMemcpyAsync(score_out + f, static_cast<Score *>(ctx->d_score.p) + f, c * sizeof(Score),
+                                        hipMemcpyDeviceToHost, tb_stream));
+        HIP_TRY(ctx, hipMemcpyAsync(cigar_out + f * cigar_stride, static_cast<char *>(ctx->d_cig.p) + f * cigar_stride,
+                                    c * cigar_stride, hipMemcpyDeviceToHost, tb_stream));
+        if (cigar_len_out)
+            HIP_TRY(ctx, hipMemcpyAsync(cigar_len_out + f, static_cast<int32_t *>(ctx->d_len.p) + f, c * 4,
+                                        hipMemcpyDeviceToHost, tb_stream));
+        if (status_out)
+            HIP_TRY(ctx, hipMemcpyAsync(status_out + f, static_cast<int32_t *>(ctx->d_status.p) + f, c * 4,
+                                        hipMemcpyDeviceToHost, tb_stream));
+        t_out += now() - t0;
+        return MGL_SW_OK;
+    };
+
     const SeqSet ts{static_cast<const uint8_t *>(ctx->d_t.p), static_cast<const int64_t *>(ctx->d_toff.p), nullptr, max_tl, 0},
         qs{static_cast<const uint8_t *>(ctx->d_q.p), static_cast<const int64_t *>(ctx->d_qoff.p), nullptr, max_ql, 0};
-    int rc = run_device(ctx, st, n, ts, qs, max_tl,
-                        max_ql, match, mismatch, gopen, gext, strategy, static_cast<int32_t *>(ctx->d_off.p),
-                        static_cast<Score *>(ctx->d_score.p), static_cast<char *>(ctx->d_cig.p), cigar_stride,
-                        static_cast<int32_t *>(ctx->d_len.p), static_cast<int32_t *>(ctx->d_status.p), cells, uniform);
-    if (rc != MGL_SW_OK) return rc;
-
-    std::vector<int32_t> status((size_t)n);
-    HIP_TRY(ctx, hipMemcpyAsync(offset_out, ctx->d_off.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    if (score_out)
-        HIP_TRY(ctx, hipMemcpyAsync(score_out, ctx->d_score.p, (size_t)n * sizeof(Score), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(cigar_out, ctx->d_cig.p, (size_t)n * cigar_stride, hipMemcpyDeviceToHost, st));
-    if (cigar_len_out)
-        HIP_TRY(ctx, hipMemcpyAsync(cigar_len_out, ctx->d_len.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(status.data(), ctx->d_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (status_out) {
-        memcpy(status_out, status.data(), (size_t)n * 4);
-        return MGL_SW_OK;
+    int rc = run_device(ctx, st, n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext, strategy,
+                        static_cast<int32_t *>(ctx->d_off.p), static_cast<Score *>(ctx->d_score.p),
+                        static_cast<char *>(ctx->d_cig.p), cigar_stride, static_cast<int32_t *>(ctx->d_len.p),
+                        static_cast<int32_t *>(ctx->d_status.p), cells, uniform, false, &hooks);
+    if (rc != MGL_SW_OK) {
+        (void)hipStreamSynchronize(ctx->h2d);
+        (void)hipStreamSynchronize(ctx->aux);
+        (void)hipStreamSynchronize(st);
+        return rc;
     }
-    for (int64_t k = 0; k < n; ++k)
-        if (status[(size_t)k] != 0) return fail(ctx, status[(size_t)k], "a CIGAR did not fit cigar_stride");
+    const double t_enq = now();
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->h2d));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (host_timing)
+        fprintf(stderr, "[mgl_sw] host entry: %.1f ms enqueue (%.1f ms in input copies, %.1f ms in result copies), %.1f ms drain\n",
+                (t_enq - t_begin) * 1e3, t_in * 1e3, t_out * 1e3, (now() - t_enq) * 1e3);
+    if (status_out) return MGL_SW_OK;
+    int32_t any = 0;
+    HIP_TRY(ctx, hipMemcpy(&any, ctx->d_any.p, 4, hipMemcpyDeviceToHost));
+    if (any != 0) return fail(ctx, any, "a CIGAR did not fit cigar_stride");
     return MGL_SW_OK;
 }
 

@@ -76,6 +76,7 @@ struct TbArgs {
     int binary_cigar; // BAM-style uint32 elements instead of text
     int32_t *cigar_len; // optional
     int32_t *status;    // optional
+    int32_t *status_any; // optional: max of all non-zero statuses of the call
 };
 
 // geometry helpers (host and device agree on these); rows = target rows per stripe = lanes per pair (16 or 64)

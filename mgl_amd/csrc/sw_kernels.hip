@@ -619,6 +619,7 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
     a.offset[p] = off;
     if (a.cigar_len) a.cigar_len[p] = cw.need;
     if (a.status) a.status[p] = status;
+    if (a.status_any && status != 0) atomicMax(a.status_any, status);
     if (a.score) {
         Score sc;
         sc.mqe = r.mqe;
