@@ -95,6 +95,11 @@ int mgl_sw_ctx_set_carry_memory(mgl_sw_ctx *ctx, int mode);
 /* target rows per stripe (= lanes per pair) of the int32 fill kernel: 0 (default) = 16 (four pairs per wave) for
  * queries below 1024 bases, 64 (one pair per wave) from there on; 16 / 64 force one (tests; identical results) */
 int mgl_sw_ctx_set_stripe_rows(mgl_sw_ctx *ctx, int rows);
+/* long reads: one pair per workgroup, its waves pipelined over the pair's 64-row stripes (sw_dp_coop.hip).
+ * 0 (default) = taken when the query is too long for the one-wave-per-pair LDS carve (see
+ * mgl_sw_max_lds_query_len); 1 = never; 2..16 = always, with that many waves per pair (tests; identical
+ * results) */
+int mgl_sw_ctx_set_cooperative(mgl_sw_ctx *ctx, int mode);
 /* 1 = HIP events around every kernel launch of a call, on the streams the kernels run on, read back by
  * mgl_sw_ctx_get_timing (the call itself stays asynchronous); 2 = additionally stamp the shader clock
  * inside the fill kernel (diagnostic; a few extra instructions per workgroup); 0 = off */

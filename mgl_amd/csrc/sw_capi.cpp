@@ -60,6 +60,7 @@ struct mgl_sw_ctx {
     DevBuf tb[2], rec[2], diag, scratch;
     int carry_memory = 0; // 0 = LDS when it fits, 1 = always the HBM scratch (tests)
     int stripe_rows = 0;  // 0 = choose per batch, 16 / 64 = force (tests)
+    int cooperative = 0;  // 0 = choose per batch, 1 = never, 2..16 = always, that many waves per pair (tests)
     int last_rows = 16;
     hipStream_t aux = nullptr;                       // traceback stream
     hipStream_t h2d = nullptr;                       // host-buffer entry: input copies of the next chunk
@@ -164,11 +165,23 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const bool use16 = uniform && ctx->precision != 32 && dp16_lds_bytes(sps_for(max_ql), 4) <= 64 * 1024 &&
                        dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
     // int32 kernel: 16 target rows per stripe (four pairs per wave) or 64 (one pair per wave, long reads)
-    const int rows = use16 ? 16 : ctx->stripe_rows ? ctx->stripe_rows : (max_ql >= kRows64MinQuery ? 64 : 16);
-    const int sps_cap = sps_for_rows(max_ql, rows);
+    int rows = use16 ? 16 : ctx->stripe_rows ? ctx->stripe_rows : (max_ql >= kRows64MinQuery ? 64 : 16);
+    int sps_cap = sps_for_rows(max_ql, rows);
     int wpb = use16 ? 4 : pick_waves_per_block(sps_cap, rows);
+    // long reads: one pair per WORKGROUP (sw_dp_coop_kernel), its waves pipelined over the 64-row stripes.  Taken
+    // when the one-wave-per-pair carve does not fit LDS, or when forced; needs at least two stripes to share.
+    int coop_waves = 0;
+    if (!use16 && ctx->cooperative != 1 && ctx->carry_memory == 0 && gopen < 65536 && (ctx->stripe_rows == 0 || ctx->cooperative >= 2) &&
+        ((rows == 64 && wpb == 0) || ctx->cooperative >= 2) && coop_lds_bytes(coop_sps_for(max_ql), 2) <= 160 * 1024) {
+        const int stripes = (max_tl + 63) / 64;
+        coop_waves = ctx->cooperative >= 2 ? ctx->cooperative : 16;
+        while (coop_waves > 2 && (coop_waves > stripes || coop_lds_bytes(coop_sps_for(max_ql), coop_waves) > 160 * 1024)) --coop_waves;
+        rows = 64;
+        sps_cap = coop_sps_for(max_ql);
+        wpb = coop_waves;
+    }
     // queries too long for the LDS carve: carry ring and query copies in an HBM scratch area instead
-    const bool use_scratch = !use16 && (wpb == 0 || ctx->carry_memory == 1);
+    const bool use_scratch = !use16 && !coop_waves && (wpb == 0 || ctx->carry_memory == 1);
     if (use_scratch) wpb = 4;
     if ((int64_t)max_tl * max_ql > (1ll << 34) || max_ql > (1 << 24) || max_tl > (1 << 24))
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "matrix larger than 2^34 cells");
@@ -199,6 +212,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         const int64_t groups = (chunk + 15) / 16 * 16; // every group of every launched wave has its own area
         HIP_TRY(ctx, ctx->scratch.reserve((size_t)(groups * dp_group_bytes(sps_cap, rows))));
     }
+    if (coop_waves) HIP_TRY(ctx, ctx->scratch.reserve((size_t)chunk * coop_wrap_cols(sps_cap) * 8)); // one carry row per pair
 
     ctx->timing = mgl_sw_timing{};
     ctx->timing.cells = cells_hint;
@@ -233,7 +247,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         da.tb = static_cast<uint32_t *>(ctx->tb[h].p);
         da.tb_stride_words = stride_words;
         da.rec = static_cast<DpRecord *>(ctx->rec[h].p);
-        da.scratch = use_scratch ? static_cast<unsigned char *>(ctx->scratch.p) : nullptr;
+        da.scratch = (use_scratch || coop_waves) ? static_cast<unsigned char *>(ctx->scratch.p) : nullptr;
         da.diag = nullptr;
         const int per_block = use16 ? wpb * 8 : wpb * (64 / rows);
         const int64_t n_blocks = (count + per_block - 1) / per_block;
@@ -277,7 +291,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         // this half was last read by the traceback of chunk k-2
         if (overlap && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->tb_done[h], 0));
         if (pe[0]) HIP_TRY(ctx, hipEventRecord(pe[0], stream));
-        HIP_TRY(ctx, use16 ? launch_dp16(da, wpb, stream) : launch_dp(da, wpb, rows, stream));
+        HIP_TRY(ctx, use16 ? launch_dp16(da, wpb, stream) : coop_waves ? launch_dp_coop(da, coop_waves, stream) : launch_dp(da, wpb, rows, stream));
         if (pe[1]) HIP_TRY(ctx, hipEventRecord(pe[1], stream));
         if (overlap) {
             HIP_TRY(ctx, hipEventRecord(ctx->fill_done[h], stream));
@@ -451,6 +465,14 @@ int mgl_sw_ctx_set_stripe_rows(mgl_sw_ctx *ctx, int rows)
     if (!ctx || (rows != 0 && rows != 16 && rows != 64)) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->stripe_rows = rows;
+    return MGL_SW_OK;
+}
+
+int mgl_sw_ctx_set_cooperative(mgl_sw_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 16) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->cooperative = mode;
     return MGL_SW_OK;
 }
 

@@ -10,6 +10,7 @@ namespace mgl_sw_dev {
 constexpr int NEG_INF = -0x40000000; // sw_common.h:33
 constexpr int OS_SOFTCLIP = 1, OS_INDEL = 2, OS_LEAD_ID = 4, OS_IGNORE = 8; // sw_common.h:22-25
 constexpr int ERR_CIGAR_OVERFLOW = 2; // == MGL_SW_ERR_CIGAR_OVERFLOW
+constexpr int ERR_DEVICE = 4;         // == MGL_SW_ERR_DEVICE
 
 // ScoreMax (sw_common.h:36-40); layout == mgl_sw_score
 struct Score {
@@ -109,12 +110,20 @@ __host__ __device__ inline int64_t dp16_total_steps(int tl, int ql)
 // packed16 layout: two dwords per lane per 8 steps, per group of two pairs
 __host__ __device__ inline int64_t tb_words16_for(int tl, int ql) { return ((dp16_total_steps(tl, ql) + 7) >> 3) * 32; }
 
+// ---- sw_dp_coop_kernel (sw_dp_coop.hip): one pair per workgroup, 64-row stripes, steps per stripe rounded to
+// the 32-step traceback block so that every stripe (= every wave) owns whole blocks
+__host__ __device__ inline int coop_sps_for(int ql) { return (ql + 64 + 31) & ~31; }
+__host__ __device__ inline int coop_query_bytes(int sps_cap) { return (sps_cap + 192 + 15) & ~15; } // 64 + ql + slack
+__host__ __device__ inline int coop_wrap_cols(int sps_cap) { return sps_cap + 192; }                // 8 bytes each, per pair
+
 int64_t dp_group_bytes(int sps_cap, int rows); // carry ring + query copies of one pair (LDS, or HBM scratch)
 int dp_lds_bytes(int sps_cap, int waves_per_block, int rows);
 int dp16_lds_bytes(int sps, int waves_per_block);
 bool dp16_range_ok(int tl, int ql, int match, int mismatch, int gopen, int gext, int strategy);
 hipError_t launch_dp16(const DpArgs &a, int waves_per_block, hipStream_t stream);
 hipError_t launch_dp(const DpArgs &a, int waves_per_block, int rows, hipStream_t stream);
+int coop_lds_bytes(int sps_cap, int waves_per_block);
+hipError_t launch_dp_coop(const DpArgs &a, int waves_per_block, hipStream_t stream);
 hipError_t launch_traceback(const TbArgs &a, hipStream_t stream);
 hipError_t launch_cigar_from_matrix(const int32_t *btr, int tl, int ql, int strategy, const Score &ez, char *cigar,
                                     int cap, int32_t *out3, hipStream_t stream);

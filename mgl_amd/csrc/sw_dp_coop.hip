@@ -1,0 +1,421 @@
+// sw_dp_coop.hip -- long-read fill kernel for gfx950: ONE pair per WORKGROUP, the waves of the workgroup
+// running consecutive 64-row stripes of that pair as a systolic pipeline.  Same function as sw_dp_kernel
+// (sw_kernels.hip; the reference's sw.cpp:5-146), same int32 arithmetic, same traceback layout
+// (rows = 64), so the traceback kernel does not know which fill kernel ran.
+//
+// Why: with one pair per wave (sw_dp64_kernel) a 10 kb x 10 kb batch needs one 50 MB traceback area per
+// resident wave, so the workspace -- not the chip -- bounds occupancy, and queries whose carry ring does not
+// fit LDS (> ~3.3 kb) paid an L2 round trip per 4-step block for the ring in HBM scratch (282 ms for 256 pairs;
+// profiles/r01_e_long_reads.txt).  Here W waves share one pair:
+//   * wave w runs stripes w, w + W, w + 2W, ...; stripe k+1 trails stripe k by ~100 columns;
+//   * the stripe carry (H and E of a stripe's last row: the reference's score[]/step[], sw_avx.cpp:36-47,
+//     196-197) goes from the wave of stripe k to the wave of stripe k+1 through a small circular LDS ring
+//     (RING_COLS columns) with a produced / consumed counter pair per ring -- whatever the query length, LDS
+//     holds the query once plus W * 2 KB;
+//   * sequence numbers: column c of the stripe consumed as stripe k has number (k / W) * S + c on ring
+//     (k-1) mod W (S = a multiple of RING_COLS >= steps per stripe + slack), so `produced >= n` / `consumed >= n`
+//     are single integer comparisons and ring slot = c mod RING_COLS in every round;
+//   * the LAST wave's carry cannot go through a small ring: wave 0 only comes back for stripe W after it has
+//     finished stripe 0, so that hop must hold a whole row or the back-pressure closes a cycle (deadlock).  It
+//     goes through a per-pair row in HBM instead, with NO back-pressure and no fence: every column is one
+//     64-bit agent-scope atomic {H : 32, H - E' : 16, tag : 16} (0 < H - E' <= gap open for every valid cell,
+//     sw.cpp:73-82; tag = round number, never 0, the row is zeroed when the kernel starts).  Wave 0 loads its
+//     columns two 32-step groups ahead, checks the tags when it needs them (re-loading a column that is not
+//     there yet) and drops them into its private LDS ring, from where the step code reads them like any other
+//     carry;
+//   * row 0 (the border row, sw.cpp:14-18,31-35) is written into that private ring by the wave of stripe 0
+//     itself, 32 columns ahead of where it reads;
+//   * the last stripe has no consumer: instead of publishing its last row it keeps the running best of
+//     sw.cpp:116-127 in registers (the lane that owns row tl sees H[tl][j] for every j in order).
+// Every spin is bounded (SPIN_LIMIT) so the grid drains even if a counter were wrong; the pair is then
+// marked failed (DpRecord.sps = -1, reported as MGL_SW_ERR_DEVICE by the traceback kernel's status).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sw_device.h"
+
+namespace mgl_sw_dev {
+
+namespace {
+
+constexpr int DPP_WAVE_SHR1 = 0x138;
+constexpr int RING_COLS = 256;     // columns per ring (8 bytes each)
+constexpr int RING_MASK = RING_COLS - 1;
+constexpr int AHEAD = 40;          // a 32-step group loads carry columns up to s + 39 (one block of prefetch)
+constexpr int SPIN_LIMIT = 1 << 24;
+
+__device__ __forceinline__ int wave_shr1(int lane0_value, int src)
+{
+    return __builtin_amdgcn_update_dpp(lane0_value, src, DPP_WAVE_SHR1, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned shift_in_sign(unsigned acc, int d)
+{
+    return __builtin_amdgcn_alignbit(acc, (unsigned)d, 31); // (acc << 1) | (d < 0)
+}
+__device__ __forceinline__ int border(int k, int gopen, int gext, bool indel)
+{
+    return (indel && k > 0) ? -gopen - (k - 1) * gext : 0; // sw.cpp:29-40,47-49
+}
+
+struct CoopLane {
+    int h_prev, e_prev, hup, f;
+    unsigned a0, a1, a2, a3; // traceback bit planes of the current 32-step block
+    int best, best_i;        // last-column maximum over this lane's rows (ties: later row)
+    int rm, rd, rj;          // last stripe only: running best of the last row (score, |tl-j|, j)
+};
+
+struct CoopConsts {
+    int match, mismatch, gopen, gext, tl, ql;
+};
+
+__device__ __forceinline__ bool wait_at_least(const int *ctr, int need)
+{
+    for (int spin = 0; spin < SPIN_LIMIT; ++spin) {
+        const int v = __hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__builtin_amdgcn_readfirstlane(v) >= need) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false; // (uniform: every lane saw the same counter values)
+}
+
+__device__ __forceinline__ unsigned long long wrap_load(const unsigned long long *row, int col, int cols)
+{
+    return __hip_atomic_load(row + min(col, cols - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Wave 0, stripes W, 2W, ...: put columns col_base + (0..31) of the row above (written by the last wave one
+// round earlier, into the pair's HBM row) into the private LDS ring.  v was loaded two groups ago; a column
+// whose tag is not this round's has not been written yet and is loaded again.
+__device__ __forceinline__ bool stage_wrap(unsigned long long v, const int col, const bool active, const int ql,
+                                           const unsigned tag, const unsigned long long *row, const int cols, int2 *ring)
+{
+    bool ok = true;
+    for (int spin = 0;; ++spin) {
+        const bool missing = active && col <= ql && (unsigned)(v >> 48) != tag;
+        if (!__builtin_amdgcn_ballot_w64(missing)) break;
+        if (spin >= SPIN_LIMIT) {
+            ok = false;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        if (missing) v = wrap_load(row, col, cols);
+    }
+    if (active) {
+        const int h = (int)(unsigned)v;
+        ring[col & RING_MASK] = make_int2(h, h - (int)((unsigned)(v >> 32) & 0xffffu));
+    }
+    return ok;
+}
+
+enum { OUT_RING = 0, OUT_WRAP = 1, OUT_LAST = 2 };
+
+// 32 anti-diagonal steps of one 64-row stripe.
+//   EDGE : some lane may be at a column <= 0 (forced border) or at its last column (capture H[i][ql])
+//   OUT  : where the carry of this stripe's last row goes: the LDS ring of the next wave, the pair's HBM row
+//          (last wave of the workgroup), or nowhere (the stripe that holds row tl: running last-row best instead)
+template <bool EDGE, int OUT>
+__device__ __forceinline__ void coop_group32(CoopLane &st, int4 &rA, int4 &rB, const int2 *ring_in, int2 *ring_out,
+                                             unsigned long long *wrap_out, const unsigned tag_out, const unsigned *qrd,
+                                             unsigned &q_lo, const int q_shift, const int tb, const int s_begin,
+                                             const int L, const int hb, const int qcap, const int row_i,
+                                             const CoopConsts &c, const bool writer)
+{
+#pragma unroll 1
+    for (int b = 0; b < 8; ++b) {
+        const int s0 = s_begin + 4 * b;
+        // bases of the four columns of this block: bytes (s0 - L + 63) .. +3 of the padded query
+        const unsigned q_hi = qrd[(s0 >> 2) + 1];
+        const unsigned qw = __builtin_amdgcn_alignbyte(q_hi, q_lo, (unsigned)q_shift);
+        q_lo = q_hi;
+        // carry of the NEXT block (all lanes read the same two addresses), reloaded as soon as the registers are free
+        const int4 *nxt = reinterpret_cast<const int4 *>(ring_in + ((s0 + 4) & RING_MASK));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rh = u == 0 ? rA.x : u == 1 ? rA.z : u == 2 ? rB.x : rB.z;
+            const int re = u == 0 ? rA.y : u == 1 ? rA.w : u == 2 ? rB.y : rB.w;
+            if (u == 2) rA = nxt[0];
+            const int hup_new = wave_shr1(rh, st.h_prev);
+            const int ein = wave_shr1(re, st.e_prev);
+            const int qb = (int)((qw >> (8 * u)) & 0xffu);
+            const int diag = st.hup + (qb == tb ? c.match : c.mismatch);
+            const int d1 = diag - st.f; // < 0 <=> F > diag
+            const int sm = max(diag, st.f);
+            const int d2 = sm - ein; // < 0 <=> E > max(diag, F)
+            int h = max(sm, ein);
+            const int open_from = h - c.gopen;
+            const int ee = ein - c.gext;
+            const int d3 = ee - open_from; // < 0 <=> a new vertical gap beats extending
+            const int eo = max(open_from, ee);
+            const int fe = st.f - c.gext;
+            const int d4 = fe - open_from; // < 0 <=> a new horizontal gap beats extending
+            int fo = max(open_from, fe);
+            const int j = s0 + u - L; // this lane's column
+            if (EDGE) {
+                const bool at_border = j <= 0;
+                h = at_border ? hb : h;
+                fo = at_border ? hb - c.gopen : fo;
+                const bool take = j == qcap && h >= st.best; // sw.cpp:100-104 (>=: later row wins)
+                st.best = take ? h : st.best;
+                st.best_i = take ? row_i : st.best_i;
+            }
+            st.a0 = shift_in_sign(st.a0, d1);
+            st.a1 = shift_in_sign(st.a1, d2);
+            st.a2 = shift_in_sign(st.a2, d3);
+            st.a3 = shift_in_sign(st.a3, d4);
+            if (OUT == OUT_LAST) {
+                // sw.cpp:116-127 in column order: better score, or same score closer to the diagonal
+                const int d = abs(c.tl - j);
+                const bool take = j >= 1 && j <= c.ql && (h > st.rm || (h == st.rm && d < st.rd));
+                st.rm = take ? h : st.rm;
+                st.rd = take ? d : st.rd;
+                st.rj = take ? j : st.rj;
+            } else if (!EDGE || s0 + u >= 63) {
+                // lane 63 finishes column s - 63 of this stripe's last row
+                const int col = s0 + u - 63;
+                if (OUT == OUT_RING) {
+                    if (writer) ring_out[col & RING_MASK] = make_int2(h, eo);
+                } else {
+                    // {H, H - E' (16 bits), tag}: in the lean part lane 63 is on a valid cell, 0 < H - E' <= gap open
+                    const unsigned hi = EDGE ? (((unsigned)(h - eo) & 0xffffu) | tag_out) : (unsigned)(h - eo) + tag_out;
+                    if (writer)
+                        __hip_atomic_store(wrap_out + col, (unsigned long long)(unsigned)h | ((unsigned long long)hi << 32),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            st.h_prev = h;
+            st.e_prev = eo;
+            st.hup = hup_new;
+            st.f = fo;
+        }
+        rB = nxt[1];
+    }
+}
+
+__device__ __forceinline__ unsigned wrap_tag(int consumer_stripe, int W) { return (unsigned)((consumer_stripe / W) & 0x7fff) + 1u; }
+
+} // namespace
+
+// grid = pairs of the chunk, block = 64 * W threads
+__global__ __launch_bounds__(1024) void sw_dp_coop_kernel(const DpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform, and the compiler knows it
+    const int W = blockDim.x >> 6;
+    const int L = lane;
+    const int64_t slot = blockIdx.x;
+    const int64_t p = a.first + slot;
+
+    const int64_t t0 = a.t.off[p], q0 = a.q.off[p];
+    const int tl = a.t.length(p);
+    const int ql = a.q.length(p);
+    const int nstripes = (tl + 63) >> 6;
+    const int sps = coop_sps_for(ql);                  // steps per stripe, a multiple of 32
+    const int S = (sps + 64 + RING_MASK) & ~RING_MASK; // sequence numbers per stripe
+    const int main_lo = 64, main_hi = ql & ~31;        // groups inside [main_lo, main_hi) touch no edge
+
+    // LDS: query bytes (64 zero bytes, q, zeros) | W rings | produced[W] | consumed[W] | per-wave results
+    const int qbytes = coop_query_bytes(a.sps_cap);
+    unsigned char *qbuf = smem;
+    int2 *rings = reinterpret_cast<int2 *>(smem + qbytes);
+    int *produced = reinterpret_cast<int *>(rings + (size_t)W * RING_COLS);
+    int *consumed = produced + W;
+    int *wres = consumed + W; // [W][2] last-column best, then [4] last row {rm, rd, rj, failed}
+
+    // the pair's row in HBM for the hop last wave -> wave 0
+    const int wrap_cols = coop_wrap_cols(a.sps_cap);
+    unsigned long long *wrap = reinterpret_cast<unsigned long long *>(a.scratch) + (size_t)slot * wrap_cols;
+
+    {
+        unsigned *qz = reinterpret_cast<unsigned *>(qbuf);
+        for (int w = threadIdx.x; w < (qbytes >> 2); w += blockDim.x) qz[w] = 0u;
+        if ((int)threadIdx.x < 2 * W) produced[threadIdx.x] = 0; // produced[] and consumed[] are contiguous
+        if (threadIdx.x < 4) wres[2 * W + threadIdx.x] = threadIdx.x == 0 ? NEG_INF : threadIdx.x == 3 ? 0 : 0x7fffffff;
+        if (nstripes > W)
+            for (int x = threadIdx.x; x < wrap_cols; x += blockDim.x) wrap[x] = 0ull; // tag 0 = not written
+        __threadfence();
+        __syncthreads();
+        for (int x = threadIdx.x; x < ql; x += blockDim.x) qbuf[64 + x] = (unsigned char)a.q.at(q0, x);
+        __syncthreads();
+    }
+
+    CoopConsts c;
+    c.match = a.match;
+    c.mismatch = a.mismatch;
+    asm volatile("" : "+v"(c.match), "+v"(c.mismatch)); // both feed a v_cndmask every step
+    c.gopen = a.gopen;
+    c.gext = a.gext;
+    c.tl = tl;
+    c.ql = ql;
+    const bool indel = (a.strategy & (OS_INDEL | OS_LEAD_ID)) != 0;
+
+    CoopLane st;
+    st.h_prev = st.e_prev = st.hup = st.f = 0;
+    st.a0 = st.a1 = st.a2 = st.a3 = 0u;
+    st.best = NEG_INF;
+    st.best_i = -1;
+    st.rm = NEG_INF;
+    st.rd = 0x7fffffff;
+    st.rj = 0x7fffffff;
+    int failed = 0; // wave-uniform
+
+    const int q_shift = (63 - L) & 3;
+    const unsigned *qrd = reinterpret_cast<const unsigned *>(qbuf) + ((63 - L) >> 2);
+    const bool writer = (L == 63);
+    const int last_lane = (tl - 1) & 63;
+    // wave 0 feeds itself (border row or HBM row) through ring W-1; the others read the ring of the wave before
+    const int b_in = (wave + W - 1) % W, b_out = wave;
+    int2 *ring_in = rings + (size_t)b_in * RING_COLS;
+    int2 *ring_out = rings + (size_t)b_out * RING_COLS;
+
+    for (int k = wave; k < nstripes; k += W) {
+        const bool first = (k == 0), last = (k == nstripes - 1);
+        const int out = last ? OUT_LAST : (wave == W - 1 ? OUT_WRAP : OUT_RING);
+        const int row_i = k * 64 + 1 + L;
+        const int tb = row_i <= tl ? a.t.at(t0, row_i - 1) : 0;
+        const int hb = border(row_i, c.gopen, c.gext, indel);
+        const int qcap = row_i <= tl ? ql : NEG_INF;
+        const int base_in = (k / W) * S, base_out = ((k + 1) / W) * S;
+        const unsigned tag_in = wrap_tag(k, W), tag_out = wrap_tag(k + 1, W) << 16;
+        uint32_t *tbp = a.tb + (size_t)slot * a.tb_stride_words + ((size_t)k * (sps >> 5) * 64 + L) * 4;
+
+        int4 rA = make_int4(0, 0, 0, 0), rB = rA;
+        unsigned q_lo = qrd[0];
+        unsigned long long pend_a = 0, pend_b = 0; // wave 0: HBM-row columns of the next two groups
+        for (int s = 0; s < sps; s += 32) {
+            // ---- carry in: columns < s + AHEAD of the row above this stripe
+            if (wave == 0) {
+                if (first) {
+                    // row 0: H[0][j], E[1][j] = H[0][j] - o
+                    for (int col = (s == 0 ? 0 : s + AHEAD - 32) + L; col < s + AHEAD; col += 64) {
+                        const int hb0 = border(col, c.gopen, c.gext, indel);
+                        ring_in[col & RING_MASK] = make_int2(hb0, hb0 - c.gopen);
+                    }
+                } else if (s == 0) {
+                    const unsigned long long v = wrap_load(wrap, L, wrap_cols);
+                    pend_a = wrap_load(wrap, AHEAD + L, wrap_cols);
+                    pend_b = wrap_load(wrap, AHEAD + 32 + L, wrap_cols);
+                    if (!failed) failed = !stage_wrap(v, L, true, ql, tag_in, wrap, wrap_cols, ring_in);
+                } else {
+                    const int col = s + AHEAD - 32 + L;
+                    if (!failed) failed = !stage_wrap(pend_a, col, L < 32, ql, tag_in, wrap, wrap_cols, ring_in);
+                    pend_a = pend_b;
+                    pend_b = wrap_load(wrap, col + 64, wrap_cols);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else if (!failed) {
+                failed = !wait_at_least(produced + b_in, base_in + s + AHEAD);
+            }
+            // ---- carry out through a ring: the slots of columns (s - 63) .. (s - 32) must have been read one lap ago
+            if (out == OUT_RING && !failed && s + 31 - 63 >= 0) {
+                const int need = base_out + s + 31 - 63 - RING_MASK;
+                if (need > 0) failed = !wait_at_least(consumed + b_out, need);
+            }
+            if (s == 0) {
+                const int4 *r0 = reinterpret_cast<const int4 *>(ring_in);
+                rA = r0[0];
+                rB = r0[1];
+            }
+            const bool lean = s >= main_lo && s + 32 <= main_hi;
+#define MGL_COOP_GROUP(EDGE, OUT)                                                                                      \
+    coop_group32<EDGE, OUT>(st, rA, rB, ring_in, ring_out, wrap, tag_out, qrd, q_lo, q_shift, tb, s, L, hb, qcap, row_i, c, \
+                            writer)
+            if (out == OUT_RING) {
+                if (lean)
+                    MGL_COOP_GROUP(false, OUT_RING);
+                else
+                    MGL_COOP_GROUP(true, OUT_RING);
+            } else if (out == OUT_WRAP) {
+                if (lean)
+                    MGL_COOP_GROUP(false, OUT_WRAP);
+                else
+                    MGL_COOP_GROUP(true, OUT_WRAP);
+            } else {
+                if (lean)
+                    MGL_COOP_GROUP(false, OUT_LAST);
+                else
+                    MGL_COOP_GROUP(true, OUT_LAST);
+            }
+#undef MGL_COOP_GROUP
+            *reinterpret_cast<uint4 *>(tbp) = make_uint4(st.a0, st.a1, st.a2, st.a3);
+            tbp += 256;
+            // ---- publish progress (the release orders lane 63's ring stores before the counter)
+            if (L == 0) {
+                if (out == OUT_RING && s + 32 - 63 > 0)
+                    __hip_atomic_store(produced + b_out, base_out + s + 32 - 63, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (wave != 0)
+                    __hip_atomic_store(consumed + b_in, base_in + s + 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (L == 0) {
+            if (out == OUT_RING)
+                __hip_atomic_store(produced + b_out, base_out + S, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (wave != 0) __hip_atomic_store(consumed + b_in, base_in + S, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // the lane that owns row tl holds the last-row best
+        if (last && L == last_lane) {
+            wres[2 * W + 0] = st.rm;
+            wres[2 * W + 1] = st.rd;
+            wres[2 * W + 2] = st.rj;
+        }
+    }
+
+    // ---- last column: reduce over the lanes of this wave, then over the waves (ties: larger row)
+    int mqe = st.best, mqe_t = st.best_i;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int ob = __shfl_xor(mqe, m), oi = __shfl_xor(mqe_t, m);
+        const bool take = ob > mqe || (ob == mqe && oi > mqe_t);
+        mqe = take ? ob : mqe;
+        mqe_t = take ? oi : mqe_t;
+    }
+    if (L == 0) {
+        wres[2 * wave] = mqe;
+        wres[2 * wave + 1] = mqe_t;
+        if (failed) wres[2 * W + 3] = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < W; ++w) {
+            const int ob = wres[2 * w], oi = wres[2 * w + 1];
+            const bool take = ob > mqe || (ob == mqe && oi > mqe_t);
+            mqe = take ? ob : mqe;
+            mqe_t = take ? oi : mqe_t;
+        }
+        const int rm = wres[2 * W], rd = wres[2 * W + 1], rj = wres[2 * W + 2];
+        // sequential rule of sw.cpp:116-127 starting from (mqe, mqe_t, ql)
+        const bool row_wins = rm > mqe || (rm == mqe && rd < abs(mqe_t - ql));
+        DpRecord r;
+        r.mqe = mqe;
+        r.mqe_t = mqe_t;
+        r.max = row_wins ? rm : mqe;
+        r.max_t = row_wins ? tl : mqe_t;
+        r.max_q = row_wins ? rj : ql;
+        r.seg = row_wins ? ql - rj : 0;
+        r.g_tail = 0;
+        r.sps = wres[2 * W + 3] ? -1 : sps;
+        a.rec[slot] = r;
+    }
+}
+
+int coop_lds_bytes(int sps_cap, int waves_per_block)
+{
+    return coop_query_bytes(sps_cap) + waves_per_block * (RING_COLS * 8 + 8 + 8) + 16;
+}
+
+hipError_t launch_dp_coop(const DpArgs &a, int waves_per_block, hipStream_t stream)
+{
+    const int lds = coop_lds_bytes(a.sps_cap, waves_per_block);
+    static int configured_lds = 0;
+    if (lds > 64 * 1024 && lds > configured_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_dp_coop_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        configured_lds = lds;
+    }
+    hipLaunchKernelGGL(sw_dp_coop_kernel, dim3((unsigned)a.count), dim3(64 * waves_per_block), lds, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace mgl_sw_dev

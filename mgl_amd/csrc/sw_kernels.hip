@@ -598,6 +598,15 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
     const int tl = a.t.length(p);
     const int ql = a.q.length(p);
     const DpRecord r = a.rec[slot];
+    if (r.sps < 0) {
+        // the fill kernel gave up on this pair (sw_dp_coop_kernel: a bounded wait ran out)
+        a.offset[p] = 0;
+        if (a.cigar_len) a.cigar_len[p] = 0;
+        if (a.status) a.status[p] = ERR_DEVICE;
+        if (a.status_any) atomicMax(a.status_any, ERR_DEVICE);
+        for (int k = 0; k < a.cigar_stride; ++k) a.cigar[(size_t)p * a.cigar_stride + k] = 0;
+        return;
+    }
 
     BitsMoves mv;
     mv.tb.base = a.tb + (size_t)(a.packed16 ? slot >> 1 : slot) * a.tb_stride_words;

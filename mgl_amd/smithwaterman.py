@@ -37,6 +37,36 @@ ScoreMax = namedtuple("ScoreMax", "mqe mqe_t max max_t max_q seg_length")
 BatchResult = namedtuple("BatchResult", "offsets scores cigars cigar_len")
 
 
+class CigarColumn:
+    """The CIGAR texts of a batch, decoded on access (a 10 M-pair batch would otherwise spend ten times the
+    alignment time building Python strings).  Behaves like a read-only list of str."""
+
+    def __init__(self, slots, lengths):
+        self.slots, self.lengths = slots, lengths      # uint8 [n, stride], int32 [n]
+
+    def __len__(self):
+        return len(self.lengths)
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        if k < 0:
+            k += len(self)
+        return self.slots[k, : self.lengths[k]].tobytes().decode()
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+    def __eq__(self, other):
+        try:
+            return len(self) == len(other) and all(a == b for a, b in zip(self, other))
+        except TypeError:
+            return NotImplemented
+
+    def __repr__(self):
+        return "CigarColumn(%r)" % (self[:8] + (["..."] if len(self) > 8 else []),)
+
+
 def _check(rc, ctx=None):
     if rc != _lib.OK:
         detail = _lib.lib().mgl_sw_last_error(ctx).decode() if ctx else ""
@@ -106,19 +136,17 @@ class MicrosoftSmithWaterman:
         if cigar_stride is None:
             longest = int(max(np.diff(t_off).max(initial=1), np.diff(q_off).max(initial=1)))
             cigar_stride = max(16, 2 * longest)
-        off = np.zeros(n, np.int32)
-        sc = np.zeros((n, 6), np.int32)
-        cg = np.zeros(n * cigar_stride, np.uint8)
-        ln = np.zeros(n, np.int32)
+        off = np.empty(n, np.int32)
+        sc = np.empty((n, 6), np.int32)
+        cg = np.empty(n * cigar_stride, np.uint8)
+        ln = np.empty(n, np.int32)
         p = SWParameters(*parameters)
         rc = _lib.lib().mgl_sw_align_batch(ctx, n, targets.ctypes.data, t_off.ctypes.data, queries.ctypes.data,
                                            q_off.ctypes.data, p.match, p.mismatch, p.gap_open, p.gap_extend,
                                            int(overhang_strategy), off.ctypes.data, sc.ctypes.data, cg.ctypes.data,
                                            cigar_stride, ln.ctypes.data)
         _check(rc, ctx)
-        cg2 = cg.reshape(n, cigar_stride) if n else cg.reshape(0, cigar_stride)
-        cigars = [cg2[k, : ln[k]].tobytes().decode() for k in range(n)]
-        return BatchResult(off, sc, cigars, ln)
+        return BatchResult(off, sc, CigarColumn(cg.reshape(n, cigar_stride), ln), ln)
 
     def expand_slot(self, slot, tl, ql):
         """Logical backtrack matrix of pair ``slot`` of the last chunk of the last batch call."""
@@ -142,6 +170,11 @@ class MicrosoftSmithWaterman:
     def set_stripe_rows(self, rows):
         """Lanes per pair of the int32 fill kernel: 0 = by query length, 16 or 64 = forced."""
         _check(_lib.lib().mgl_sw_ctx_set_stripe_rows(self._ensure(), int(rows)))
+
+    def set_cooperative(self, mode):
+        """Long-read fill kernel (one pair per workgroup): 0 = when the query does not fit the one-wave LDS carve,
+        1 = never, 2..16 = always with that many waves per pair."""
+        _check(_lib.lib().mgl_sw_ctx_set_cooperative(self._ensure(), int(mode)))
 
     def set_profiling(self, on=True):
         _check(_lib.lib().mgl_sw_ctx_set_profiling(self._ensure(), int(on)))

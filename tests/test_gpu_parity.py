@@ -79,6 +79,24 @@ def test_stripe_rows_and_carry_variants(rows, carry):
     forced.close()
 
 
+@pytest.mark.parametrize("waves", [2, 3, 8, 16])
+def test_cooperative_long_read_kernel(waves):
+    """sw_dp_coop_kernel (one pair per workgroup, `waves` waves pipelined over the 64-row stripes, LDS rings between
+    them and the HBM row from the last wave back to wave 0) forced onto ordinary mixed batches and the long goldens:
+    identical results, traceback included."""
+    forced = sw.MicrosoftSmithWaterman(0)
+    forced.set_cooperative(waves)
+    rows_ = golden_io.load("known") + golden_io.load("shapes") + golden_io.load("random")[:500] + golden_io.load("ties")[::9]
+    assert run_groups(forced, rows_) == len(rows_)
+    gs = [g for g in golden_io.load("random") if g.params == (200, -150, 260, 11) and g.strategy == ol.SOFTCLIP][:24]
+    forced.align_batch([g.t for g in gs], [g.q for g in gs], gs[0].params, ol.SOFTCLIP)
+    for k, g in enumerate(gs):
+        btr = forced.expand_slot(k, len(g.t), len(g.q))
+        assert zlib.crc32(np.ascontiguousarray(btr[1:, 1:]).astype("<i4").tobytes()) & 0xFFFFFFFF == g.crc
+    assert run_groups(forced, golden_io.load("long")) == 9
+    forced.close()
+
+
 def test_scratch_carry_equals_lds():
     """The long-query path (carry ring + query copies in HBM, agent-scope accesses) forced onto ordinary
     batches must reproduce the goldens exactly."""
