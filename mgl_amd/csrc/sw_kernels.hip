@@ -457,6 +457,7 @@ struct CigarWriter {
     char *slot;
     int cap, pos, need;
     int binary; // 1: BAM-style uint32 elements (len << 4 | op, op M=0 I=1 D=2 S=4) instead of text
+    bool store = true; // wave-per-pair walk: every lane tracks pos / need, one lane stores
     // elements arrive last-first (the reference push_front()s, sw.cpp:172-248); text is built
     // right-aligned and moved to the front at the end.  Zero lengths are skipped (sw.cpp:252).
     __device__ __forceinline__ void push_front(char op, int len)
@@ -471,10 +472,12 @@ struct CigarWriter {
             const unsigned code = op == 'M' ? 0u : op == 'I' ? 1u : op == 'D' ? 2u : 4u;
             const unsigned v = ((unsigned)len << 4) | code;
             pos -= 4;
-            slot[pos] = (char)(v & 0xff);
-            slot[pos + 1] = (char)((v >> 8) & 0xff);
-            slot[pos + 2] = (char)((v >> 16) & 0xff);
-            slot[pos + 3] = (char)(v >> 24);
+            if (store) {
+                slot[pos] = (char)(v & 0xff);
+                slot[pos + 1] = (char)((v >> 8) & 0xff);
+                slot[pos + 2] = (char)((v >> 16) & 0xff);
+                slot[pos + 3] = (char)(v >> 24);
+            }
             return;
         }
         int digits = 1;
@@ -484,8 +487,12 @@ struct CigarWriter {
             pos = -1;
             return;
         }
-        slot[--pos] = op;
-        for (int v = len, d = 0; d < digits; ++d, v /= 10) slot[--pos] = (char)('0' + v % 10);
+        --pos;
+        if (store) slot[pos] = op;
+        for (int v = len, d = 0; d < digits; ++d, v /= 10) {
+            --pos;
+            if (store) slot[pos] = (char)('0' + v % 10);
+        }
     }
 };
 
@@ -510,7 +517,7 @@ struct MatrixMoves {
 // calculateCigar (sw.cpp:149-255): walk from the strategy's start cell, merge equal states,
 // post-process the overhangs, emit text.  Returns the alignment offset.
 template <typename Moves>
-__device__ __forceinline__ int walk_and_write(const Moves &mv, int tl, int ql, int strategy, int max_t, int max_q,
+__device__ __forceinline__ int walk_and_write(Moves &mv, int tl, int ql, int strategy, int max_t, int max_q,
                                               int mqe_t, int seg_length, CigarWriter &cw)
 {
     // start cell, sw.cpp:155-170
@@ -641,6 +648,135 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Long reads: ONE WAVE per pair.  With one lane per pair every path step of a 10 kb x 10 kb pair is a
+// dependent 16-byte load from a 50 MB area (~1 us each, 20 ms per batch whatever its size).  Here all 64
+// lanes run the same walk (wave-uniform state, scalar branches); a lane keeps ITS 16 bytes of the current
+// 32-step traceback block in registers (one coalesced 1 KB load per block), the cell of lane l is fetched
+// with v_readlane, and the block below (where an up-left path goes next inside a stripe) is already on its
+// way.  int32 layout only (rows = 16 or 64).
+struct WaveMoves {
+    const uint4 *base; // this pair's traceback, as [block][rows] x 16 bytes
+    int sps, rows, L;
+    int cur_blk, nxt_blk;
+    uint4 cur, nxt;
+    __device__ __forceinline__ uint4 load(int blk) const
+    {
+        return L < rows ? base[(size_t)blk * rows + L] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    __device__ __forceinline__ void init(const uint32_t *words, int sps_, int rows_, int lane)
+    {
+        base = reinterpret_cast<const uint4 *>(words);
+        sps = sps_;
+        rows = rows_;
+        L = lane;
+        cur_blk = nxt_blk = -1;
+        cur = nxt = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __device__ __forceinline__ unsigned cell(int i, int j)
+    {
+        const int r = i - 1;
+        const int lane = r % rows;
+        const int g = (r / rows) * sps + j + lane;
+        const int blk = g >> 5;
+        if (blk != cur_blk) {
+            cur = blk == nxt_blk ? nxt : load(blk);
+            cur_blk = blk;
+            nxt_blk = blk - 1;
+            if (nxt_blk >= 0) nxt = load(nxt_blk);
+        }
+        const int sh = 31 - (g & 31);
+        const unsigned x = (unsigned)__builtin_amdgcn_readlane((int)cur.x, lane), y = (unsigned)__builtin_amdgcn_readlane((int)cur.y, lane),
+                       z = (unsigned)__builtin_amdgcn_readlane((int)cur.z, lane), w = (unsigned)__builtin_amdgcn_readlane((int)cur.w, lane);
+        return ((x >> sh) & 1u) | (((y >> sh) & 1u) << 1) | (((z >> sh) & 1u) << 2) | (((w >> sh) & 1u) << 3);
+    }
+    __device__ __forceinline__ int at(int i, int j)
+    {
+        const unsigned c = cell(i, j);
+        if (c & 2u) { // vertical gap: 1 + consecutive extensions above (sw.cpp:73-82)
+            int n = 1;
+            for (int r = i - 1; r >= 1 && !(cell(r, j) & 4u); --r) ++n;
+            return n;
+        }
+        if (c & 1u) { // horizontal gap (sw.cpp:84-93)
+            int n = 1;
+            for (int q = j - 1; q >= 1 && !(cell(i, q) & 8u); --q) ++n;
+            return -n;
+        }
+        return 0;
+    }
+};
+
+__global__ __launch_bounds__(256) void sw_traceback_wave_kernel(const TbArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t slot = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (slot >= a.count) return;
+    const int64_t p = a.first + slot;
+    const int tl = a.t.length(p);
+    const int ql = a.q.length(p);
+    const DpRecord r = a.rec[slot];
+    char *const slot_out = a.cigar + (size_t)p * a.cigar_stride;
+    if (r.sps < 0) {
+        // the fill kernel gave up on this pair (sw_dp_coop_kernel: a bounded wait ran out)
+        for (int k = lane; k < a.cigar_stride; k += 64) slot_out[k] = 0;
+        if (lane == 0) {
+            a.offset[p] = 0;
+            if (a.cigar_len) a.cigar_len[p] = 0;
+            if (a.status) a.status[p] = ERR_DEVICE;
+            if (a.status_any) atomicMax(a.status_any, ERR_DEVICE);
+        }
+        return;
+    }
+
+    WaveMoves mv;
+    mv.init(a.tb + (size_t)slot * a.tb_stride_words, r.sps, a.rows_per_stripe, lane);
+
+    CigarWriter cw;
+    cw.slot = slot_out;
+    cw.binary = a.binary_cigar;
+    cw.cap = a.binary_cigar ? (a.cigar_stride & ~3) : a.cigar_stride;
+    cw.pos = cw.cap;
+    cw.need = 0;
+    cw.store = (lane == 0);
+
+    const int off = walk_and_write(mv, tl, ql, a.strategy, r.max_t, r.max_q, r.mqe_t, r.seg, cw);
+
+    // the text was built right-aligned by lane 0: move it to the front and zero the rest, 64 bytes at a time
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    int status = 0;
+    if (cw.pos < 0) {
+        for (int k = lane; k < a.cigar_stride; k += 64) slot_out[k] = 0;
+        status = ERR_CIGAR_OVERFLOW;
+    } else {
+        const int len = cw.cap - cw.pos;
+        if (cw.pos > 0)
+            for (int k0 = 0; k0 < len; k0 += 64) {
+                const int k = k0 + lane;
+                const char ch = k < len ? __builtin_nontemporal_load(slot_out + cw.pos + k) : 0;
+                if (k < len) slot_out[k] = ch;
+            }
+        for (int k = len + lane; k < a.cigar_stride; k += 64) slot_out[k] = 0;
+    }
+    if (lane == 0) {
+        a.offset[p] = off;
+        if (a.cigar_len) a.cigar_len[p] = cw.need;
+        if (a.status) a.status[p] = status;
+        if (a.status_any && status != 0) atomicMax(a.status_any, status);
+        if (a.score) {
+            Score sc;
+            sc.mqe = r.mqe;
+            sc.mqe_t = r.mqe_t;
+            sc.max = r.max;
+            sc.max_t = r.max_t;
+            sc.max_q = r.max_q;
+            sc.seg_length = r.seg;
+            a.score[p] = sc;
+        }
+    }
+}
+
 // calculateCigar on a caller-supplied int32 backtrack matrix (sw_scalar.h:8): one thread.
 // out[0] = offset, out[1] = text length needed, out[2] = status
 __global__ void sw_cigar_from_matrix_kernel(const int32_t *btr, int tl, int ql, int strategy, Score ez, char *cigar,
@@ -728,6 +864,11 @@ hipError_t launch_dp(const DpArgs &a, int waves_per_block, int rows, hipStream_t
 
 hipError_t launch_traceback(const TbArgs &a, hipStream_t stream)
 {
+    if (!a.packed16 && a.rows_per_stripe == 64) {
+        // long reads: one wave per pair (the path walk is the latency, not the lane count)
+        hipLaunchKernelGGL(sw_traceback_wave_kernel, dim3((unsigned)a.count), dim3(64), 0, stream, a);
+        return hipGetLastError();
+    }
     const int64_t blocks = (a.count + 255) / 256;
     hipLaunchKernelGGL(sw_traceback_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
