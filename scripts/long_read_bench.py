@@ -1,43 +1,79 @@
-"""BASELINE.json configs[3] shape: ONT-style 10 kb x 10 kb pairs (5 % sub / 5 % ins / 5 % del), int32 scores,
-full matrix, on-device traceback and full CIGAR.  The traceback needs tl*ql/2 bytes per pair (50 MB), so the
-number of pairs in flight -- hence GPU occupancy -- is set by the workspace."""
-import os, sys, time
+"""BASELINE.json configs[3] shape: ONT-style ~10 kb x ~10 kb pairs (5 % sub /
+5 % ins / 5 % del), int32 scores, full matrix, on-device traceback and full CIGAR.  The traceback needs tl*ql/2
+bytes per pair (50 MB), so the number of pairs in flight is set by the workspace; the cooperative fill kernel
+(sw_dp_coop.hip) fills the chip with 256 of them.
+
+  python scripts/long_read_bench.py --pairs 2048 --workspace-gib 220 --seconds 30 --cpu-pairs 64
+"""
+import argparse, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
 import torch
 from mgl_amd import device_batch, synth
-from mgl_amd.smithwaterman import MicrosoftSmithWaterman, GATK_PARAMETERS, SWOverhangStrategy
+from mgl_amd.smithwaterman import MicrosoftSmithWaterman, GATK_PARAMETERS, SWOverhangStrategy, concat
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-ws_gib = float(sys.argv[2]) if len(sys.argv) > 2 else 32
-length = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
-check = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+ap = argparse.ArgumentParser()
+ap.add_argument("pairs", nargs="?", type=int, default=256)
+ap.add_argument("workspace_gib", nargs="?", type=float, default=32)
+ap.add_argument("length", nargs="?", type=int, default=10000)
+ap.add_argument("check", nargs="?", type=int, default=2, help="pairs compared with the scalar oracle")
+ap.add_argument("--seconds", type=float, default=0, help="repeat the batch until this much GPU time has been spent")
+ap.add_argument("--cpu-pairs", type=int, default=0, help="time the reference's CPU path (oracle/_ref) on this many pairs")
+ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic pairs (the batch cycles through them)")
+args = ap.parse_args()
+PARAMS = (200, -150, 260, 11)  # GATK_PARAMETERS after the sign normalisation of the JNI boundary
+n, length = args.pairs, args.length
+
 rng = synth.rng_for(11)
-base = [synth.ont_pair(rng, length) for _ in range(min(n, 32))]
+base = [synth.ont_pair(rng, length) for _ in range(min(n, args.distinct))]
 ts = [base[k % len(base)][0].tobytes() for k in range(n)]
 qs = [base[k % len(base)][1].tobytes() for k in range(n)]
-from mgl_amd.smithwaterman import concat
 td, toff = concat(ts); qd, qoff = concat(qs)
-b = device_batch.from_host(td, toff, qd, qoff, "cuda:0", cigar_stride=2 * (length + 2000))
+stride = 2 * (length + 2000)
+b = device_batch.from_host(td, toff, qd, qoff, "cuda:0", cigar_stride=stride)
 a = MicrosoftSmithWaterman(0)
-a.set_workspace(int(ws_gib * (1 << 30)))
+a.set_workspace(int(args.workspace_gib * (1 << 30)))
+if os.environ.get("MGL_COOP_W"):
+    a.set_cooperative(int(os.environ["MGL_COOP_W"]))
 cells = b.cells
 b.run(a); torch.cuda.synchronize()
 a.set_profiling(1)
-t0 = time.perf_counter()
-b.run(a); torch.cuda.synchronize()
-dt = time.perf_counter() - t0
+reps, t0 = 0, time.perf_counter()
+while True:
+    b.run(a); torch.cuda.synchronize()
+    reps += 1
+    dt = time.perf_counter() - t0
+    if dt >= args.seconds:
+        break
 tm = a.timing()
-print(f"{n} pairs of ~{length} x {length}: {dt*1e3:.1f} ms = {cells/dt/1e9:.1f} GCUPS "
-      f"(fill {tm.dp_ms:.1f} ms in {tm.dp_launches} launches, traceback {tm.tb_ms:.1f} ms, "
-      f"traceback workspace {tm.tb_bytes/2**30:.1f} GiB per pass)", flush=True)
+print(f"{n} pairs of ~{length} x {length}, {reps} pass(es): {dt*1e3/reps:.1f} ms per pass = {cells*reps/dt/1e9:.1f} GCUPS over "
+      f"{dt:.1f} s (last pass: fill {tm.dp_ms:.1f} ms in {tm.dp_launches} launches, traceback {tm.tb_ms:.1f} ms, "
+      f"traceback workspace {tm.tb_bytes/2**30:.1f} GiB)", flush=True)
 assert int((b.status != 0).sum()) == 0
-if check:
-    import oracle_lib as ol
-    idx = list(range(min(check, len(base))))
+import oracle_lib as ol
+if args.check:
+    idx = list(range(min(args.check, len(base))))
     cg = b.cigar_strings(idx)
     for k in idx:
-        o = ol.oracle_align(ts[k], qs[k], (200, -150, 260, 11), ol.SOFTCLIP)
+        o = ol.oracle_align(ts[k], qs[k], PARAMS, ol.SOFTCLIP)
         assert (int(b.offsets[k]), cg[k], tuple(int(x) for x in b.scores[k])) == (o["offset"], o["cigar"], o["score"]), k
     print(f"checked {len(idx)} pairs against the oracle: identical", flush=True)
+if args.cpu_pairs and ol.have_ref():
+    sys.path.insert(0, R)
+    from bench import host_cores
+    m = min(args.cpu_pairs, n)
+    cores = host_cores()
+    lib = ol.ref()
+    off = np.zeros(m, np.int32); cgb = np.zeros(m * stride, np.uint8); ln = np.zeros(m, np.int32)
+    mt, mx, mo, me = PARAMS
+    t0 = time.perf_counter()
+    rc = lib.ref_align_batch(m, td.ctypes.data, toff.ctypes.data, qd.ctypes.data, qoff.ctypes.data, mt, mx, mo, me,
+                             int(SWOverhangStrategy.SOFTCLIP), 1, cores, off.ctypes.data, cgb.ctypes.data, stride, ln.ctypes.data)
+    dtc = time.perf_counter() - t0
+    assert rc == 0
+    ccells = int(sum(len(ts[k]) * len(qs[k]) for k in range(m)))
+    g_off = b.offsets[:m].cpu().numpy(); g_cg = b.cigars[:m].cpu().numpy()
+    mism = int((g_off != off).sum() + (g_cg != cgb.reshape(m, stride)).any(axis=1).sum())
+    print(f"CPU baseline: mgl align_avx via oracle/_ref, {m} pairs on {cores} threads: {dtc:.2f} s = {ccells/dtc/1e9:.2f} GCUPS; "
+          f"mismatches vs GPU: {mism}", flush=True)
