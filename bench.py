@@ -131,6 +131,36 @@ def cpu_baseline(batch, target_seconds=15.0, max_pairs=10_000_000):
     }
 
 
+def file_batch(args, dev):
+    """--dataset bam / fastx: pairs read from files (mgl_amd/formats.py), tiled to --pairs on the device."""
+    from mgl_amd import formats
+
+    if args.dataset == "bam":
+        path = os.path.join(ROOT, "tests", "golden", "HiSeq.1mb.1RG.2k_lines.bam")
+        ts, qs, _ = formats.bam_pairs(path, window=args.tl)
+        label = f"real Illumina reads (tests/golden/{os.path.basename(path)}, {len(ts)} distinct pairs, tiled)"
+    else:
+        assert args.fasta and args.fastq, "--dataset fastx needs --fasta and --fastq"
+        _, _, genome = next(iter(formats.read_fasta(args.fasta)))
+        ts, qs = [], []
+        for _name, desc, seq, _qual in formats.read_fastq(args.fastq):
+            pos = int(dict(kv.split("=") for kv in desc.split() if "=" in kv)["pos"])
+            ts.append(genome[pos:pos + args.tl])
+            qs.append(seq)
+        label = f"{os.path.basename(args.fasta)} + {os.path.basename(args.fastq)} ({len(ts)} distinct pairs, tiled)"
+    ql = len(qs[0])
+    assert all(len(t) == args.tl for t in ts) and all(len(q) == ql for q in qs), "one geometry per bench batch"
+    T = torch.from_numpy(np.frombuffer(b"".join(ts), dtype=np.uint8).reshape(len(ts), args.tl).copy()).to(dev)
+    Q = torch.from_numpy(np.frombuffer(b"".join(qs), dtype=np.uint8).reshape(len(qs), ql).copy()).to(dev)
+    idx = torch.arange(args.pairs, device=dev) % len(ts)
+    t_off = torch.arange(args.pairs + 1, device=dev, dtype=torch.int64) * args.tl
+    q_off = torch.arange(args.pairs + 1, device=dev, dtype=torch.int64) * ql
+    # real reads can need long CIGARs: the Java side's buffer size, 2 * max(tl, ql) (MicrosoftSmithWaterman.java:71)
+    b = device_batch.DeviceBatch(T[idx].reshape(-1), t_off, Q[idx].reshape(-1), q_off, args.tl, ql, 2 * max(args.tl, ql),
+                                 uniform=True)
+    return b, label
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,6 +175,13 @@ def main():
     ap.add_argument("--input", choices=("ascii", "2bit"), default="ascii",
                     help="ascii: concatenated bytes (the reference's ByteBuffer contract); 2bit: one 2-bit packed "
                          "genome with target windows addressed by base offset + packed reads (SURVEY 8d config 2)")
+    ap.add_argument("--dataset", choices=("synthetic", "bam", "fastx"), default="synthetic",
+                    help="synthetic: BASELINE configs[1] (default, what `value` is quoted on); bam: the real Illumina "
+                         "reads of tests/golden/HiSeq.1mb.1RG.2k_lines.bam against --tl-base windows (reference bases "
+                         "rebuilt from CIGAR + MD, random flanks), tiled to --pairs; fastx: --fasta genome + --fastq "
+                         "reads whose description carries pos=<window start> (scripts/make_synth_fastx.py), tiled")
+    ap.add_argument("--fasta", help="--dataset fastx: reference FASTA (first record is used)")
+    ap.add_argument("--fastq", help="--dataset fastx: reads, description 'pos=<0-based window start>'")
     args = ap.parse_args()
 
     rank, local_rank, world = dist.init()
@@ -155,7 +192,13 @@ def main():
 
     aligner = MicrosoftSmithWaterman(local_rank)
     aligner.set_workspace(int(args.workspace_gib * (1 << 30)))
-    if args.input == "2bit":
+    data_label = "synthetic"
+    if args.dataset != "synthetic":
+        assert args.input == "ascii", "--dataset bam/fastx use the ASCII wire format"
+        batch, data_label = file_batch(args, dev)
+        args.ql = batch.max_ql
+        ascii_twin = batch
+    elif args.input == "2bit":
         batch, ascii_twin = device_batch.window_batch_2bit(args.seed + rank, args.pairs, dev, window=args.tl,
                                                            read_len=args.ql)
         if args.no_cpu or world > 1:
@@ -217,11 +260,13 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "int16" if tm.packed16 else "int32",
-        "data": "synthetic",
+        "data": data_label,
         "config": {
-            "workload": f"BASELINE.json configs[1]: {args.pairs} Illumina-style {args.ql} bp reads x {args.tl}-base "
-                        f"reference windows per GPU, affine-gap SW, full matrix, GATK params (200,-150,260,11), "
-                        f"SOFTCLIP, scores+offset+CIGAR for every pair",
+            "workload": (f"BASELINE.json configs[1]: {args.pairs} Illumina-style {args.ql} bp reads x {args.tl}-base "
+                         f"reference windows per GPU" if args.dataset == "synthetic" else
+                         f"{args.pairs} pairs per GPU ({data_label}), {args.ql} bp reads x {args.tl}-base windows") +
+                        ", affine-gap SW, full matrix, GATK params (200,-150,260,11), SOFTCLIP, scores+offset+CIGAR "
+                        "for every pair",
             "pairs_per_gpu": args.pairs, "target_len": args.tl, "query_len": args.ql, "input": args.input,
             "parallelism": f"pairs sharded over {world} GPU(s), score gather only" if world > 1 else "1 GPU",
         },

@@ -195,16 +195,31 @@ def suite_long():
     return rows
 
 
+def suite_bam():
+    # real Illumina reads: the reference repo's own test resource (src/test/resources/HiSeq.1mb.1RG.2k_lines.bam,
+    # kept here as a data fixture); target = the reference bases under the read rebuilt from CIGAR + MD
+    # ("bam"), and the same padded to a 256-base window with seeded random flanks ("bamwin", one geometry)
+    from mgl_amd import formats
+    path = os.path.join(HERE, "HiSeq.1mb.1RG.2k_lines.bam")
+    rows = []
+    ts, qs, _ = formats.bam_pairs(path)
+    for k, (t, q) in enumerate(zip(ts, qs)):
+        rows.append(record("bam", t, q, GATK, ol.STRATEGIES[k % 4] if k % 5 == 4 else ol.SOFTCLIP))
+    ts, qs, _ = formats.bam_pairs(path, window=256)
+    for k, (t, q) in enumerate(zip(ts, qs)):
+        rows.append(record("bamwin", t, q, GATK, ol.SOFTCLIP))
+    return rows
+
+
+SUITE_FUNCS = {"known": suite_known, "tiny": suite_tiny, "random": suite_random, "ties": suite_ties,
+               "shapes": suite_shapes, "config1": suite_config1, "window": suite_window, "long": suite_long,
+               "bam": suite_bam}
+
+
 def main():
     assert ol.have_ref(), "build oracle/_ref first: make -C oracle ref"
-    write("known", suite_known())
-    write("tiny", suite_tiny())
-    write("random", suite_random())
-    write("ties", suite_ties())
-    write("shapes", suite_shapes())
-    write("config1", suite_config1())
-    write("window", suite_window())
-    write("long", suite_long())
+    for name in (sys.argv[1:] or list(SUITE_FUNCS)):
+        write(name, SUITE_FUNCS[name]())
     print("AVX2 path asserted equal to scalar on", n_avx_checked, "records")
 
 

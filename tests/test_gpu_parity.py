@@ -43,10 +43,49 @@ def run_groups(aligner, rows):
     return n
 
 
-@pytest.mark.parametrize("suite", ["known", "tiny", "random", "ties", "shapes", "config1", "window"])
+@pytest.mark.parametrize("suite", ["known", "tiny", "random", "ties", "shapes", "config1", "window", "bam"])
 def test_golden_suite(aligner, suite):
     rows = golden_io.load(suite)
     assert run_groups(aligner, rows) == len(rows)
+
+
+def test_bam_pairs_device_formats(aligner):
+    """Real Illumina reads (tests/golden/HiSeq.1mb.1RG.2k_lines.bam) against 256-base windows, through the
+    device-resident entry in both wire formats (ASCII, 2-bit packed) and with BAM-style binary CIGAR output:
+    identical to the goldens (one geometry, so this is the packed-int16 kernel)."""
+    import torch
+    from mgl_amd import device_batch, formats
+
+    rows = [g for g in golden_io.load("bam") if g.suite == "bamwin"]
+    keep = [g for g in rows if set(g.t) <= set(b"ACGT") and set(g.q) <= set(b"ACGT")]  # 2-bit has no N
+    assert len(keep) > 1000
+    td, toff = sw.concat([g.t for g in keep])
+    qd, qoff = sw.concat([g.q for g in keep])
+    b = device_batch.from_host(td, toff, qd, qoff, "cuda:0", cigar_stride=512)  # the Java side's 2*max(tl,ql)
+    assert b.uniform
+    b.run(aligner)
+    cg = b.cigar_strings()
+    for k, g in enumerate(keep):
+        assert (int(b.offsets[k]), cg[k], tuple(int(x) for x in b.scores[k])) == (g.offset, g.cigar, g.score)
+    assert aligner.timing().packed16 == 1
+    # binary CIGAR == BAM encoding of the same text
+    b.run(aligner, binary_cigar=True)
+    raw, ln = b.cigars.cpu().numpy(), b.cigar_len.cpu().numpy()
+    for k, g in enumerate(keep):
+        words = np.frombuffer(raw[k, : ln[k]].tobytes(), dtype="<u4")
+        assert (words == formats.cigar_elements_to_binary(formats.cigar_text_to_elements(g.cigar))).all()
+        assert formats.cigar_binary_to_text(words) == g.cigar
+    # 2-bit packed inputs
+    tp = device_batch.pack2bit(td)
+    qp = device_batch.pack2bit(qd)
+    pb = device_batch.PackedBatch(torch.from_numpy(tp).cuda(), torch.from_numpy(toff[:-1].copy()).cuda(),
+                                  torch.from_numpy(np.diff(toff).astype(np.int32)).cuda(), torch.from_numpy(qp).cuda(),
+                                  torch.from_numpy(qoff[:-1].copy()).cuda(), torch.from_numpy(np.diff(qoff).astype(np.int32)).cuda(),
+                                  256, 101, cigar_stride=512)
+    pb.run(aligner)
+    torch.cuda.synchronize()
+    assert torch.equal(pb.offsets, b.offsets) and torch.equal(pb.scores, b.scores)
+    assert pb.cigar_strings() == cg
 
 
 def test_golden_long(aligner):
