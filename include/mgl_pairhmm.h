@@ -47,6 +47,11 @@ void mgl_pairhmm_ctx_destroy(mgl_pairhmm_ctx *ctx);
 /* replaces initNative(use_double, max_threads), …PairHmm.cc:47-70 (max_threads is ignored there too) */
 int mgl_pairhmm_initialize(mgl_pairhmm_ctx *ctx, int use_double, int max_threads);
 
+/* read rows per stripe = lanes per pair of the kernels: 0 (default) = per batch (16 rows x four pairs per wave
+ * while the four LDS carry rings leave the CU occupied, else 64 rows x one pair per wave); 16 / 64 force one
+ * (tests; every cell and the column-order final sum are computed the same way, so the results are identical) */
+int mgl_pairhmm_set_stripe_rows(mgl_pairhmm_ctx *ctx, int rows);
+
 /* replaces computeLikelihoodsNative(lengthBuffer, readsBuffer, haplotypesBuffer, likelihoodBuffer),
  * …PairHmm.cc:77-222, with the very same buffer contents (MicrosoftPairHmm.java:62-112):
  *   lengths   = { n_reads, len(read 0), ..., n_haps, len(hap 0), ... }              int32

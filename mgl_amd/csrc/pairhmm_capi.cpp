@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -84,6 +85,7 @@ struct mgl_pairhmm_ctx {
     std::string err;
     int use_double = 0;
     int profiling = 0;
+    int stripe_rows = 0; // 0 = per batch, 16 / 64 = forced (mgl_pairhmm_set_stripe_rows; MGL_PAIRHMM_ROWS for the bench scripts)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false, ran_float = false;
     mgl_pairhmm_timing timing{};
@@ -114,7 +116,7 @@ int max_hap_len_for(int elem_bytes)
     int lo = 1, hi = 1 << 20;
     while (lo < hi) {
         const int mid = (lo + hi + 1) / 2;
-        if (ph_lds_bytes(mid, 1, elem_bytes) <= 160 * 1024)
+        if (ph_lds_bytes(mid, 64, elem_bytes) <= 160 * 1024)
             lo = mid;
         else
             hi = mid - 1;
@@ -157,16 +159,25 @@ int run_device(mgl_pairhmm_ctx *ctx, hipStream_t stream, int64_t n_pairs, const 
     a.out = d_out;
     a.need_double = d_need;
     a.rescue_only = ctx->use_double ? 0 : 1;
+    // lanes per pair: 16 rows x four pairs per wave wastes the fewest lanes, but its four carry rings (16 bytes per
+    // haplotype base each) can leave a CU with one or two waves; 64 rows x one pair keeps the CU full
+    int rows = ctx->stripe_rows;
+    if (!rows) {
+        if (const char *e = getenv("MGL_PAIRHMM_ROWS")) rows = atoi(e);
+        if (rows != 16 && rows != 64)
+            rows = (max_read_len >= 48 && ph_lds_bytes(max_hap_len, 16, 4) > 12 * 1024) ? 64 : 16;
+    }
+    const int rows_d = ph_lds_bytes(max_hap_len, 16, 8) <= 160 * 1024 && rows == 16 ? 16 : 64;
     const bool prof = ctx->profiling != 0;
     ctx->ev_valid = false;
     ctx->ran_float = !ctx->use_double;
     if (!ctx->use_double) {
         if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
-        HIP_TRY(ctx, launch_pairhmm_float(a, stream));
+        HIP_TRY(ctx, launch_pairhmm_float(a, rows, stream));
         if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
     }
     if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
-    HIP_TRY(ctx, launch_pairhmm_double(a, stream));
+    HIP_TRY(ctx, launch_pairhmm_double(a, rows_d, stream));
     if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
     ctx->ev_valid = prof;
     return MGL_PAIRHMM_OK;
@@ -257,6 +268,14 @@ int mgl_pairhmm_initialize(mgl_pairhmm_ctx *ctx, int use_double, int max_threads
     if (!ctx) return MGL_PAIRHMM_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->use_double = use_double ? 1 : 0;
+    return MGL_PAIRHMM_OK;
+}
+
+int mgl_pairhmm_set_stripe_rows(mgl_pairhmm_ctx *ctx, int rows)
+{
+    if (!ctx || (rows != 0 && rows != 16 && rows != 64)) return MGL_PAIRHMM_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->stripe_rows = rows;
     return MGL_PAIRHMM_OK;
 }
 

@@ -10,7 +10,6 @@ namespace mgl_ph_dev {
 
 constexpr int MAX_QUAL = 254;                                       // Context.h:7
 constexpr int M2M_SIZE = ((MAX_QUAL + 1) * (MAX_QUAL + 2)) >> 1;    // Context.h:24
-constexpr int ROWS_PER_STRIPE = 16;                                 // read rows per stripe = lanes per pair
 
 struct PhArgs {
     int64_t n_pairs;
@@ -28,9 +27,10 @@ struct PhArgs {
     int rescue_only;                // double pass: 1 = only the pairs flagged by the float pass, 0 = every pair
 };
 
-int ph_lds_bytes(int hap_cap, int waves_per_block, int elem_bytes);
-hipError_t launch_pairhmm_float(const PhArgs &a, hipStream_t stream);
-hipError_t launch_pairhmm_double(const PhArgs &a, hipStream_t stream);
+// rows = read rows per stripe = lanes per pair: 16 (four pairs per wave) or 64 (one pair per wave)
+int ph_lds_bytes(int hap_cap, int rows, int elem_bytes);
+hipError_t launch_pairhmm_float(const PhArgs &a, int rows, hipStream_t stream);
+hipError_t launch_pairhmm_double(const PhArgs &a, int rows, hipStream_t stream);
 
 } // namespace mgl_ph_dev
 #endif

@@ -28,23 +28,26 @@ namespace mgl_ph_dev {
 
 namespace {
 
-constexpr int DPP_ROW_SHR1 = 0x111;
-constexpr int G = ROWS_PER_STRIPE;
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_WAVE_SHR1 = 0x138;
 constexpr double MIN_ACCEPTED = (double)1e-28f; // pairhmm_common.h:32, compared as double (…PairHmm.cc:149,185)
 
+template <int G>
 __device__ __forceinline__ int dpp_shr1(int lane0_value, int src)
 {
-    return __builtin_amdgcn_update_dpp(lane0_value, src, DPP_ROW_SHR1, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(lane0_value, src, G == 16 ? DPP_ROW_SHR1 : DPP_WAVE_SHR1, 0xf, 0xf, false);
 }
-// every lane takes src from the lane below it inside its 16-lane group; lane 0 of the group takes lane0_value
+// every lane takes src from the lane below it inside its group of G lanes (16: one DPP row; 64: the wave);
+// lane 0 of the group takes lane0_value
+template <int G>
 __device__ __forceinline__ float shift_in(float lane0_value, float src)
 {
-    return __int_as_float(dpp_shr1(__float_as_int(lane0_value), __float_as_int(src)));
+    return __int_as_float(dpp_shr1<G>(__float_as_int(lane0_value), __float_as_int(src)));
 }
+template <int G>
 __device__ __forceinline__ double shift_in(double lane0_value, double src)
 {
-    const int lo = dpp_shr1(__double2loint(lane0_value), __double2loint(src));
-    const int hi = dpp_shr1(__double2hiint(lane0_value), __double2hiint(src));
+    const int lo = dpp_shr1<G>(__double2loint(lane0_value), __double2loint(src));
+    const int hi = dpp_shr1<G>(__double2hiint(lane0_value), __double2hiint(src));
     return __hiloint2double(hi, lo);
 }
 
@@ -84,20 +87,28 @@ struct RowConst {
 };
 
 // Four anti-diagonal steps.  PRO: some lane may still be at a column <= 0 (forced zeros, :150-152);
-// EPI: some lane may be past its last column (stop accumulating).
-template <typename T, bool PRO, bool EPI>
-__device__ __forceinline__ void ph_step4(Lane<T> &st, const Carry<T> *ring_rd, Carry<T> *ring_wr, const unsigned hw,
-                                         const RowConst<T> &rc, const int s0, const int L, const int hap_len,
-                                         const bool writer)
+// EPI: some lane may be past its last column (stop accumulating); HAP_N: some haplotype of this wave holds an 'N';
+// ACC: accumulate M + X along the row (the stripe that holds a pair's last row).
+// cin holds the carry of the four columns lane 0 visits in this block (only lane 0 of a group needs it: it is the
+// DPP's lane-0 operand); nxt receives the next block's, loaded here by lane 0 alone -- one masked region, a sixteenth
+// (or a sixty-fourth) of the LDS traffic of a whole-wave read -- so no step waits for LDS.
+template <typename T, int G, bool PRO, bool EPI, bool HAP_N, bool ACC>
+__device__ __forceinline__ void ph_step4(Lane<T> &st, const Carry<T> (&cin)[4], Carry<T> (&nxt)[4], const Carry<T> *ring_next,
+                                         Carry<T> *ring_wr, const unsigned hw, const RowConst<T> &rc, const int s0, const int L,
+                                         const int hap_len, const bool writer)
 {
+    if (L == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nxt[u] = ring_next[u]; // columns s0 + 4 .. s0 + 7
+    }
+    Carry<T> o[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const Carry<T> cin = ring_rd[u]; // row above this stripe at lane 0's column (all lanes of a group read one address)
-        const T um = shift_in(cin.m, st.m);     // M[r-1][c]
-        const T ux = shift_in(cin.x, st.x);     // X[r-1][c]
-        const T uxy = shift_in(cin.xy, st.xy);  // (X + Y)[r-1][c]
+        const T um = shift_in<G>(cin[u].m, st.m);     // M[r-1][c]
+        const T ux = shift_in<G>(cin[u].x, st.x);     // X[r-1][c]
+        const T uxy = shift_in<G>(cin[u].xy, st.xy);  // (X + Y)[r-1][c]
         const int hb = (int)((hw >> (8 * u)) & 0xffu);
-        const bool match = (hb == rc.rs) | (hb == 'N'); // rs == 'N' is folded into prior_mismatch
+        const bool match = HAP_N ? ((hb == rc.rs) | (hb == 'N')) : (hb == rc.rs); // rs == 'N' is folded into prior_mismatch
         const T prior = match ? rc.prior_match : rc.prior_mismatch;
         T mn = prior * (st.dm * rc.pMM + st.dxy * rc.pGapM);
         T yn = st.m * rc.pMY + st.y * rc.pZZ;
@@ -110,18 +121,16 @@ __device__ __forceinline__ void ph_step4(Lane<T> &st, const Carry<T> *ring_rd, C
             xn = border ? (T)0 : xn;
         }
         const T xyn = xn + yn;
-        if (EPI)
-            st.acc = c <= hap_len ? st.acc + (mn + xn) : st.acc;
-        else
-            st.acc = st.acc + (mn + xn);
-        if (writer) {
-            Carry<T> o;
-            o.m = mn;
-            o.x = xn;
-            o.xy = xyn;
-            o.pad = (T)0;
-            ring_wr[u] = o;
+        if (ACC) { // only the stripe that holds row R needs the sum
+            if (EPI)
+                st.acc = c <= hap_len ? st.acc + (mn + xn) : st.acc;
+            else
+                st.acc = st.acc + (mn + xn);
         }
+        o[u].m = mn;
+        o[u].x = xn;
+        o[u].xy = xyn;
+        o[u].pad = (T)0;
         st.m = mn;
         st.x = xn;
         st.y = yn;
@@ -129,16 +138,22 @@ __device__ __forceinline__ void ph_step4(Lane<T> &st, const Carry<T> *ring_rd, C
         st.dm = um;
         st.dxy = uxy;
     }
+    // the lane that owns the stripe's last row publishes its four columns (one masked region per block)
+    if (writer) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ring_wr[u] = o[u];
+    }
 }
 
-template <typename T, bool RESCUE>
+template <typename T, int G, bool RESCUE>
 __device__ __forceinline__ void pairhmm_body(const PhArgs &a, unsigned char *smem)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int grp = lane >> 4;
-    const int L = lane & 15;
-    const int64_t slot = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 4 + grp;
+    constexpr int PW = 64 / G; // pairs per wave
+    const int grp = lane / G;
+    const int L = lane % G;
+    const int64_t slot = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * PW + grp;
     if (slot - grp >= a.n_pairs) return;
     const bool valid = slot < a.n_pairs;
     const int64_t p = valid ? slot : a.n_pairs - 1;
@@ -163,24 +178,29 @@ __device__ __forceinline__ void pairhmm_body(const PhArgs &a, unsigned char *sme
     h_max = __builtin_amdgcn_readfirstlane(h_max);
     h_min = __builtin_amdgcn_readfirstlane(h_min);
     ns_max = __builtin_amdgcn_readfirstlane(ns_max);
-    const int sps = (h_max + G + 3) & ~3;      // steps per stripe: lane 15 reaches column h_max at step h_max + 15
-    const int lean_end = max(G, h_min & ~3);   // [G, lean_end): no border, nobody past the last column
+    const int sps8 = (h_max + G + 7) & ~7;     // steps per stripe: the last lane reaches column h_max at step h_max + G - 1
+    const int lean_end8 = max(G, h_min & ~7);  // [G, lean_end8): no border, nobody past the last column
 
-    // LDS carve per group: ring[hap_cap + G + 8] carries (ring[j + G] = column j) | hap bytes (G zeros, hap, zeros)
-    const int ring_entries = a.hap_cap + G + 8;
-    const int hap_bytes = (a.hap_cap + G + 24 + 3) & ~3;
+    // LDS carve per group: ring[hap_cap + 2G + 16] carries (ring[j + G] = column j) | hap bytes (G zeros, hap, zeros)
+    const int ring_entries = a.hap_cap + 2 * G + 16;
+    const int hap_bytes = (a.hap_cap + 2 * G + 28 + 3) & ~3;
     const int group_bytes = ring_entries * (int)sizeof(Carry<T>) + hap_bytes;
-    unsigned char *gbase = smem + (size_t)(wave * 4 + grp) * group_bytes;
+    unsigned char *gbase = smem + (size_t)(wave * PW + grp) * group_bytes;
     Carry<T> *ring = reinterpret_cast<Carry<T> *>(gbase);
     unsigned char *hbuf = gbase + ring_entries * sizeof(Carry<T>);
 
     const T y_initial = Num<T>::initial() / (T)H; // :101
+    bool hap_has_n = false;
     {
         unsigned *hz = reinterpret_cast<unsigned *>(hbuf);
         for (int w = L; w < (hap_bytes >> 2); w += G) hz[w] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int x = L; x < H; x += G) hbuf[G + x] = a.haps[h0 + x];
+        for (int x = L; x < H; x += G) {
+            const uint8_t ch = a.haps[h0 + x];
+            hap_has_n |= ch == 'N';
+            hbuf[G + x] = ch;
+        }
         // row 0: M = X = 0, Y = INITIAL_CONSTANT / haplen (:126-136)
         for (int j = L; j < ring_entries - G; j += G) {
             Carry<T> o;
@@ -194,6 +214,7 @@ __device__ __forceinline__ void pairhmm_body(const PhArgs &a, unsigned char *sme
         __builtin_amdgcn_wave_barrier();
     }
 
+    const bool any_n = __builtin_amdgcn_ballot_w64(hap_has_n) != 0; // wave-uniform: which block variant runs
     const T *ph2pr = Num<T>::ph2pr(a);
     const T *m2m = Num<T>::m2m(a);
     const T three_over = (T)1.0 / (T)3.0; // :18
@@ -230,23 +251,39 @@ __device__ __forceinline__ void pairhmm_body(const PhArgs &a, unsigned char *sme
         const bool writer = (L == wl);
         const Carry<T> *ring_rd = ring + G;  // lane 0 is at column s
         Carry<T> *ring_wr = ring + G - wl;   // the writer is at column s - wl
+        Carry<T> ca[4] = {ring_rd[0], ring_rd[1], ring_rd[2], ring_rd[3]}, cb[4] = {ca[0], ca[1], ca[2], ca[3]};
         const unsigned *hrd = hrd0;
-        unsigned h_lo = hrd[0];
+        unsigned h_lo = hrd[0], h_hi = hrd[1]; // the haplotype dwords are fetched one block ahead as well
         int s = 0;
-#define MGL_PH_BLOCK(PRO, EPI)                                                                        \
+#define MGL_PH_BLOCK(PRO, EPI, HAP_N, ACC, CUR, NXT)                                                  \
     {                                                                                                 \
-        const unsigned h_hi = hrd[1];                                                                 \
         const unsigned hw = __builtin_amdgcn_alignbyte(h_hi, h_lo, (unsigned)q_shift);                \
         h_lo = h_hi;                                                                                  \
-        ph_step4<T, PRO, EPI>(st, ring_rd, ring_wr, hw, rc, s, L, H, writer);                         \
+        h_hi = hrd[2];                                                                                \
+        ph_step4<T, G, PRO, EPI, HAP_N, ACC>(st, CUR, NXT, ring_rd + 4, ring_wr, hw, rc, s, L, H, writer); \
         ring_rd += 4;                                                                                 \
         ring_wr += 4;                                                                                 \
         hrd += 1;                                                                                     \
         s += 4;                                                                                       \
     }
-        for (; s < G;) MGL_PH_BLOCK(true, true)
-        for (; s < lean_end;) MGL_PH_BLOCK(false, false)
-        for (; s < sps;) MGL_PH_BLOCK(false, true)
+// two blocks per trip: the two carry register sets alternate instead of being copied (every phase boundary is
+// a multiple of 8 steps: G, lean_end8, sps8)
+#define MGL_PH_PAIR(PRO, EPI, HAP_N, ACC) { MGL_PH_BLOCK(PRO, EPI, HAP_N, ACC, ca, cb) MGL_PH_BLOCK(PRO, EPI, HAP_N, ACC, cb, ca) }
+#define MGL_PH_STRIPE(HAP_N, ACC)                                                                     \
+    {                                                                                                 \
+        for (; s < G;) MGL_PH_PAIR(true, true, HAP_N, ACC)                                            \
+        for (; s < lean_end8;) MGL_PH_PAIR(false, false, HAP_N, ACC)                                  \
+        for (; s < sps8;) MGL_PH_PAIR(false, true, HAP_N, ACC)                                        \
+    }
+        // with four pairs per wave some pair may end in any stripe; with one pair per wave only the last stripe sums
+        const bool acc_here = G == 16 || k == __builtin_amdgcn_readfirstlane(nstripes) - 1; // wave-uniform
+        if (any_n) {
+            if (acc_here) MGL_PH_STRIPE(true, true) else MGL_PH_STRIPE(true, false)
+        } else {
+            if (acc_here) MGL_PH_STRIPE(false, true) else MGL_PH_STRIPE(false, false)
+        }
+#undef MGL_PH_STRIPE
+#undef MGL_PH_PAIR
 #undef MGL_PH_BLOCK
         if (k == nstripes - 1) result = st.acc; // meaningful on the lane that owns row R
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -271,47 +308,59 @@ __device__ __forceinline__ void pairhmm_body(const PhArgs &a, unsigned char *sme
 __global__ __launch_bounds__(64) void pairhmm_float_kernel(const PhArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    pairhmm_body<float, false>(a, smem);
+    pairhmm_body<float, 16, false>(a, smem);
 }
-
+__global__ __launch_bounds__(64) void pairhmm_float64_kernel(const PhArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    pairhmm_body<float, 64, false>(a, smem);
+}
 __global__ __launch_bounds__(64) void pairhmm_double_kernel(const PhArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    pairhmm_body<double, true>(a, smem);
+    pairhmm_body<double, 16, true>(a, smem);
+}
+__global__ __launch_bounds__(64) void pairhmm_double64_kernel(const PhArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    pairhmm_body<double, 64, true>(a, smem);
 }
 
-int ph_lds_bytes(int hap_cap, int waves_per_block, int elem_bytes)
+int ph_lds_bytes(int hap_cap, int rows, int elem_bytes)
 {
-    const int ring_entries = hap_cap + G + 8;
-    const int hap_bytes = (hap_cap + G + 24 + 3) & ~3;
-    const int64_t b = (int64_t)waves_per_block * 4 * ((int64_t)ring_entries * 4 * elem_bytes + hap_bytes);
+    const int ring_entries = hap_cap + 2 * rows + 16;
+    const int hap_bytes = (hap_cap + 2 * rows + 28 + 3) & ~3;
+    const int64_t b = (int64_t)(64 / rows) * ((int64_t)ring_entries * 4 * elem_bytes + hap_bytes);
     return b > (1 << 30) ? (1 << 30) : (int)b;
 }
 
 template <typename K>
-static hipError_t launch(K kernel, const PhArgs &a, int elem_bytes, hipStream_t stream, int &configured)
+static hipError_t launch(K kernel, const PhArgs &a, int rows, int elem_bytes, hipStream_t stream, int &configured)
 {
-    const int lds = ph_lds_bytes(a.hap_cap, 1, elem_bytes);
+    const int lds = ph_lds_bytes(a.hap_cap, rows, elem_bytes);
     if (lds > 64 * 1024 && lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    const int64_t blocks = (a.n_pairs + 3) / 4; // one wave (four pairs) per block: the LDS carve, not the wave count, limits a CU
+    const int per_wave = 64 / rows;
+    const int64_t blocks = (a.n_pairs + per_wave - 1) / per_wave; // one wave per block: the LDS carve, not the wave count, limits a CU
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_pairhmm_float(const PhArgs &a, hipStream_t stream)
+hipError_t launch_pairhmm_float(const PhArgs &a, int rows, hipStream_t stream)
 {
-    static int configured = 0;
-    return launch(pairhmm_float_kernel, a, 4, stream, configured);
+    static int configured[2] = {0, 0};
+    return rows == 64 ? launch(pairhmm_float64_kernel, a, 64, 4, stream, configured[1])
+                      : launch(pairhmm_float_kernel, a, 16, 4, stream, configured[0]);
 }
 
-hipError_t launch_pairhmm_double(const PhArgs &a, hipStream_t stream)
+hipError_t launch_pairhmm_double(const PhArgs &a, int rows, hipStream_t stream)
 {
-    static int configured = 0;
-    return launch(pairhmm_double_kernel, a, 8, stream, configured);
+    static int configured[2] = {0, 0};
+    return rows == 64 ? launch(pairhmm_double64_kernel, a, 64, 8, stream, configured[1])
+                      : launch(pairhmm_double_kernel, a, 16, 8, stream, configured[0]);
 }
 
 } // namespace mgl_ph_dev

@@ -24,7 +24,7 @@ SYMBOLS = (
     "mgl_pairhmm_version", "mgl_pairhmm_strerror", "mgl_pairhmm_last_error", "mgl_pairhmm_device_count",
     "mgl_pairhmm_max_haplotype_len", "mgl_pairhmm_ctx_create", "mgl_pairhmm_ctx_destroy", "mgl_pairhmm_initialize",
     "mgl_pairhmm_compute_likelihoods", "mgl_pairhmm_compute_pairs", "mgl_pairhmm_compute_pairs_device",
-    "mgl_pairhmm_set_profiling", "mgl_pairhmm_get_timing",
+    "mgl_pairhmm_set_profiling", "mgl_pairhmm_get_timing", "mgl_pairhmm_set_stripe_rows",
 )
 
 
@@ -63,6 +63,7 @@ def lib():
     L.mgl_pairhmm_compute_pairs.argtypes = [vp, C.c_int64, C.c_int64, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
     L.mgl_pairhmm_compute_pairs_device.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
     L.mgl_pairhmm_set_profiling.argtypes = [vp, C.c_int]
+    L.mgl_pairhmm_set_stripe_rows.argtypes = [vp, C.c_int]
     L.mgl_pairhmm_get_timing.argtypes = [vp, C.POINTER(Timing)]
     _lib = L
     return L
@@ -184,6 +185,10 @@ class MicrosoftPairHmm:
             haps.data_ptr(), hap_off.data_ptr(), pair_read.data_ptr(), pair_hap.data_ptr(), int(max_read_len), int(max_hap_len),
             out.data_ptr(), None if used_double is None else used_double.data_ptr()), self._ctx)
         return out
+
+    def set_stripe_rows(self, rows):
+        """Lanes per pair of the kernels: 0 = per batch, 16 (four pairs per wave) or 64 (one pair per wave)."""
+        _check(lib().mgl_pairhmm_set_stripe_rows(self._ensure(), int(rows)))
 
     def set_profiling(self, on=True):
         _check(lib().mgl_pairhmm_set_profiling(self._ensure(), int(on)))

@@ -71,12 +71,15 @@ def _region(rng, n_reads, n_haps, alphabet=b"ACGT", with_n=False, max_read=260, 
     return reads, haps
 
 
+@pytest.mark.parametrize("rows", [0, 16, 64])
 @pytest.mark.parametrize("use_double", [False, True])
-def test_regions_against_restatement(hmm, use_double):
+def test_regions_against_restatement(hmm, use_double, rows):
     """Whole regions through the JNI-layout entry: every read against every haplotype, ragged lengths from 1 up,
-    N bases, reads that need the double rescue."""
+    N bases, reads that need the double rescue; with four pairs per wave (16 rows), one pair per wave (64 rows) and
+    the per-batch choice."""
     rng = np.random.default_rng(11)
     hmm.initialize(pairhmm.PairHMMNativeArguments(use_double, 1))
+    hmm.set_stripe_rows(rows)
     for trial in range(6):
         reads, haps = _region(rng, int(rng.integers(1, 40)), int(rng.integers(1, 9)), with_n=(trial % 2 == 1))
         got = np.zeros(len(reads) * len(haps))
@@ -87,13 +90,16 @@ def test_regions_against_restatement(hmm, use_double):
         ph = np.tile(np.arange(len(haps), dtype=np.int32), len(reads))
         want, used = pol.compute_pairs(rd, roff, hd, hoff, pr, ph, use_double, nthreads=4)
         assert np.isfinite(got).all()
-        tol = 1e-9 if use_double else 2e-5 / np.log(10)  # log10 difference for a 2e-5 relative difference
         err = np.abs(got - want)
-        assert (err[used != 0] < 1e-9 * np.maximum(1.0, np.abs(want[used != 0]))).all(), "double path"
-        assert (err < max(tol, 1e-9) * np.maximum(1.0, np.abs(want) * (use_double))).all() or (err < 1e-5).all(), err.max()
+        # pairs computed in double (all of them in double mode, the rescued ones in float mode): 1e-9 on the log10;
+        # pairs computed in float: 1e-5, the reference's own tolerance (fma contraction differs from the scalar code)
+        dbl = (used != 0) | use_double
+        assert (err[dbl] < 1e-9 * np.maximum(1.0, np.abs(want[dbl]))).all(), err[dbl].max()
+        assert (err[~dbl] < 1e-5).all(), err[~dbl].max()
         if not use_double:
             assert used.sum() > 0 or len(reads) < 4
             assert hmm.timing().rescued == int(used.sum())
+    hmm.set_stripe_rows(0)
 
 
 def test_pair_list_and_errors(hmm):
