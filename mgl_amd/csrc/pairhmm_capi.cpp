@@ -167,6 +167,7 @@ int run_device(mgl_pairhmm_ctx *ctx, hipStream_t stream, int64_t n_pairs, const 
         if (rows != 16 && rows != 64)
             rows = (max_read_len >= 48 && ph_lds_bytes(max_hap_len, 16, 4) > 12 * 1024) ? 64 : 16;
     }
+    if (ph_lds_bytes(max_hap_len, rows, 4) > 160 * 1024) rows = 64; // four rings would not fit LDS at all
     const int rows_d = ph_lds_bytes(max_hap_len, 16, 8) <= 160 * 1024 && rows == 16 ? 16 : 64;
     const bool prof = ctx->profiling != 0;
     ctx->ev_valid = false;

@@ -15,8 +15,9 @@ csv.field_size_limit(1 << 30)
 
 
 def short(name):
-    if "mgl_sw_dev::" in name:
-        return name.split("mgl_sw_dev::")[1].split("(")[0]
+    for ns in ("mgl_sw_dev::", "mgl_ph_dev::"):
+        if ns in name:
+            return name.split(ns)[1].split("(")[0]
     return "other"
 
 
