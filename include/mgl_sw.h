@@ -190,6 +190,24 @@ int mgl_sw_align_batch_device_2bit(mgl_sw_ctx *ctx, void *stream, int64_t n, con
                                    int32_t *d_cigar_len_out, int32_t *d_status_out, int flags);
 
 /*
+ * Substitution-matrix scoring ("protein" mode).  NOT in the reference, which scores
+ * by byte equality only (sw.cpp:55): the same recurrence, overhang strategies and traceback with
+ *     diag = H[i-1][j-1] + matrix[code[t[i-1]] * 32 + code[q[j-1]]]
+ * code: 256 bytes -> 0..31, matrix: 32 x 32 int8 (both HOST pointers, copied per call); gopen / gext as in the
+ * other entries.  d_t_len / d_q_len (optional, int32 per pair): with them d_t_off[k] / d_q_off[k] are per-pair START
+ * positions, so one database sequence can serve many pairs; NULL = pair k is [off[k], off[k+1]).  int32 kernel only; queries up to about 800 residues (MGL_SW_ERR_UNSUPPORTED beyond), targets any
+ * length.  No parity claim exists for this mode: it is validated against the CPU restatement's own extension and
+ * an independent textbook DP (tests/test_gpu_matrix.py).
+ */
+int mgl_sw_align_batch_device_matrix(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_targets,
+                                     const int64_t *d_t_off, const int32_t *d_t_len, const uint8_t *d_queries,
+                                     const int64_t *d_q_off, const int32_t *d_q_len, int max_tl, int max_ql,
+                                     const int8_t *matrix, const uint8_t *code, int gopen,
+                                     int gext, int strategy, int32_t *d_offset_out, mgl_sw_score *d_score_out,
+                                     char *d_cigar_out, int cigar_stride, int32_t *d_cigar_len_out,
+                                     int32_t *d_status_out, int flags);
+
+/*
  * Logical backtrack matrix of one pair, the reference's calculateMatrix
  * (sw_scalar.h:7 / sw.cpp:5-146): btr is (tl+1)*(ql+1) int32 row-major with
  * row 0 / column 0 zero, +k = k rows up (deletion run), -k = k columns left

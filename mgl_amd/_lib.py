@@ -22,7 +22,7 @@ SYMBOLS = (
     "mgl_sw_version", "mgl_sw_strerror", "mgl_sw_device_count", "mgl_sw_max_query_len", "mgl_sw_max_lds_query_len", "mgl_sw_ctx_set_carry_memory", "mgl_sw_ctx_set_stripe_rows", "mgl_sw_ctx_set_cooperative", "mgl_sw_ctx_create",
     "mgl_sw_ctx_destroy", "mgl_sw_last_error", "mgl_sw_ctx_set_workspace", "mgl_sw_ctx_set_profiling", "mgl_sw_ctx_set_precision",
     "mgl_sw_ctx_get_timing", "mgl_sw_normalize_params", "mgl_sw_align", "mgl_sw_align_batch",
-    "mgl_sw_align_batch_device", "mgl_sw_align_batch_device_2bit", "mgl_sw_backtrack_matrix", "mgl_sw_ctx_expand_slot",
+    "mgl_sw_align_batch_device", "mgl_sw_align_batch_device_2bit", "mgl_sw_align_batch_device_matrix", "mgl_sw_backtrack_matrix", "mgl_sw_ctx_expand_slot",
     "mgl_sw_cigar_from_backtrack", "mgl_sw_set_coalescing", "mgl_sw_coalescing_stats",
 )
 
@@ -92,6 +92,8 @@ def lib():
     L.mgl_sw_ctx_set_precision.argtypes = [vp, C.c_int]
     L.mgl_sw_align_batch_device_2bit.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int] + [
         C.c_int] * 5 + [vp, vp, vp, C.c_int, vp, vp, C.c_int]
+    L.mgl_sw_align_batch_device_matrix.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int,
+                                                   C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int]
     L.mgl_sw_backtrack_matrix.argtypes = [cp, C.c_int, cp, C.c_int] + [C.c_int] * 5 + [i32p, C.POINTER(Score)]
     L.mgl_sw_cigar_from_backtrack.argtypes = [i32p, C.c_int, C.c_int, C.c_int, C.POINTER(Score), cp, C.c_int,
                                               C.POINTER(C.c_int), C.POINTER(C.c_int)]

@@ -74,7 +74,7 @@ struct mgl_sw_ctx {
     std::vector<hipEvent_t> pool;
     int pool_used = 0;
     int64_t diag_blocks = 0;
-    DevBuf d_t, d_toff, d_q, d_qoff, d_off, d_score, d_cig, d_len, d_status, d_btr, d_any; // host-API staging
+    DevBuf d_t, d_toff, d_q, d_qoff, d_off, d_score, d_cig, d_len, d_status, d_btr, d_any, d_matrix; // host-API staging
     int64_t last_stride_words = 0, last_chunk_count = 0; // geometry of the last chunk (for expand_slot)
     int last_packed16 = 0;
     int precision = 0; // 0 = choose per batch, 32 = always the int32 kernel
@@ -153,25 +153,31 @@ struct ChunkHooks {
 int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tset, const SeqSet &qset, int max_tl,
                int max_ql, int match, int mismatch, int gopen, int gext, int strategy, int32_t *d_offset, Score *d_score,
                char *d_cigar, int cigar_stride, int32_t *d_cigar_len, int32_t *d_status, int64_t cells_hint, bool uniform,
-               bool binary_cigar = false, const ChunkHooks *hooks = nullptr)
+               bool binary_cigar = false, const ChunkHooks *hooks = nullptr, const int8_t *d_matrix = nullptr,
+               const uint8_t *d_code = nullptr)
 {
     if (n == 0) return MGL_SW_OK;
     if (n < 0 || !tset.data || !tset.off || !qset.data || !qset.off || !d_offset || !d_cigar || cigar_stride < 1 ||
         max_tl < 1 || max_ql < 1 || !strategy_ok(strategy))
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch_device: bad argument");
+    if (d_matrix) {
+        // substitution-matrix scoring: match / mismatch are unused, the gap penalties keep the sign convention
+        match = 1;
+        mismatch = -1;
+    }
     mgl_sw_normalize_params(&match, &mismatch, &gopen, &gext);
 
     // packed-int16 kernel: one geometry for the whole batch and a score range that fits 16 bits
-    const bool use16 = uniform && ctx->precision != 32 && dp16_lds_bytes(sps_for(max_ql), 4) <= 64 * 1024 &&
+    const bool use16 = !d_matrix && uniform && ctx->precision != 32 && dp16_lds_bytes(sps_for(max_ql), 4) <= 64 * 1024 &&
                        dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
     // int32 kernel: 16 target rows per stripe (four pairs per wave) or 64 (one pair per wave, long reads)
-    int rows = use16 ? 16 : ctx->stripe_rows ? ctx->stripe_rows : (max_ql >= kRows64MinQuery ? 64 : 16);
+    int rows = use16 || d_matrix ? 16 : ctx->stripe_rows ? ctx->stripe_rows : (max_ql >= kRows64MinQuery ? 64 : 16);
     int sps_cap = sps_for_rows(max_ql, rows);
     int wpb = use16 ? 4 : pick_waves_per_block(sps_cap, rows);
     // long reads: one pair per WORKGROUP (sw_dp_coop_kernel), its waves pipelined over the 64-row stripes.  Taken
     // when the one-wave-per-pair carve does not fit LDS, or when forced; needs at least two stripes to share.
     int coop_waves = 0;
-    if (!use16 && ctx->cooperative != 1 && ctx->carry_memory == 0 && gopen < 65536 && (ctx->stripe_rows == 0 || ctx->cooperative >= 2) &&
+    if (!use16 && !d_matrix && ctx->cooperative != 1 && ctx->carry_memory == 0 && gopen < 65536 && (ctx->stripe_rows == 0 || ctx->cooperative >= 2) &&
         ((rows == 64 && wpb == 0) || ctx->cooperative >= 2) && coop_lds_bytes(coop_sps_for(max_ql), 2) <= 160 * 1024) {
         const int stripes = (max_tl + 63) / 64;
         coop_waves = ctx->cooperative >= 2 ? ctx->cooperative : 16;
@@ -181,7 +187,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         wpb = coop_waves;
     }
     // queries too long for the LDS carve: carry ring and query copies in an HBM scratch area instead
-    const bool use_scratch = !use16 && !coop_waves && (wpb == 0 || ctx->carry_memory == 1);
+    while (d_matrix && wpb > 1 && dp_lds_bytes(sps_cap, wpb, 16) + 1024 > 64 * 1024) wpb >>= 1; // room for the matrix
+    if (d_matrix && (wpb == 0 || dp_lds_bytes(sps_cap, wpb, 16) + 1024 > 64 * 1024))
+        return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "substitution-matrix scoring: query too long for the LDS carve (about 800 residues)");
+    const bool use_scratch = !use16 && !coop_waves && !d_matrix && (wpb == 0 || ctx->carry_memory == 1);
     if (use_scratch) wpb = 4;
     if ((int64_t)max_tl * max_ql > (1ll << 34) || max_ql > (1 << 24) || max_tl > (1 << 24))
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "matrix larger than 2^34 cells");
@@ -249,6 +258,9 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         da.rec = static_cast<DpRecord *>(ctx->rec[h].p);
         da.scratch = (use_scratch || coop_waves) ? static_cast<unsigned char *>(ctx->scratch.p) : nullptr;
         da.diag = nullptr;
+        da.matrix = d_matrix;
+        da.code = d_code;
+        da.matrix_lds_offset = 0;
         const int per_block = use16 ? wpb * 8 : wpb * (64 / rows);
         const int64_t n_blocks = (count + per_block - 1) / per_block;
         if (ctx->profiling >= 2) {
@@ -416,7 +428,7 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     for (DevBuf *b : {&ctx->tb[0], &ctx->tb[1], &ctx->rec[0], &ctx->rec[1], &ctx->diag, &ctx->scratch, &ctx->d_t, &ctx->d_toff, &ctx->d_q, &ctx->d_qoff, &ctx->d_off, &ctx->d_score,
-                      &ctx->d_cig, &ctx->d_len, &ctx->d_status, &ctx->d_btr, &ctx->d_any})
+                      &ctx->d_cig, &ctx->d_len, &ctx->d_status, &ctx->d_btr, &ctx->d_any, &ctx->d_matrix})
         b->release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
@@ -531,6 +543,33 @@ int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const ui
                       strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride,
                       d_cigar_len_out, d_status_out, 0, (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) != 0,
                       (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0);
+}
+
+int mgl_sw_align_batch_device_matrix(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_targets,
+                                     const int64_t *d_t_off, const int32_t *d_t_len, const uint8_t *d_queries,
+                                     const int64_t *d_q_off, const int32_t *d_q_len, int max_tl, int max_ql,
+                                     const int8_t *matrix, const uint8_t *code, int gopen, int gext,
+                                     int strategy, int32_t *d_offset_out, mgl_sw_score *d_score_out, char *d_cigar_out,
+                                     int cigar_stride, int32_t *d_cigar_len_out, int32_t *d_status_out, int flags)
+{
+    if (!ctx) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!matrix || !code) return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch_device_matrix: null matrix or code table");
+    for (int k = 0; k < 256; ++k)
+        if (code[k] >= MATRIX_DIM) return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch_device_matrix: code >= 32");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, ctx->d_matrix.reserve(MATRIX_DIM * MATRIX_DIM + 256));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int8_t *dm = static_cast<int8_t *>(ctx->d_matrix.p);
+    uint8_t *dc = reinterpret_cast<uint8_t *>(dm) + MATRIX_DIM * MATRIX_DIM;
+    // (pageable host memory: these two small copies complete before the call returns)
+    HIP_TRY(ctx, hipMemcpyAsync(dm, matrix, MATRIX_DIM * MATRIX_DIM, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dc, code, 256, hipMemcpyHostToDevice, st));
+    // with length arrays the offsets are per-pair START positions (a database sequence may serve many pairs)
+    const SeqSet ts{d_targets, d_t_off, d_t_len, max_tl, 0}, qs{d_queries, d_q_off, d_q_len, max_ql, 0};
+    return run_device(ctx, st, n, ts, qs, max_tl, max_ql, 1, -1, gopen, gext, strategy, d_offset_out,
+                      reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride, d_cigar_len_out, d_status_out, 0,
+                      false, (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, nullptr, dm, dc);
 }
 
 int mgl_sw_align_batch_device_2bit(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_target_bases,

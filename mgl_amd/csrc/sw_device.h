@@ -11,6 +11,7 @@ constexpr int NEG_INF = -0x40000000; // sw_common.h:33
 constexpr int OS_SOFTCLIP = 1, OS_INDEL = 2, OS_LEAD_ID = 4, OS_IGNORE = 8; // sw_common.h:22-25
 constexpr int ERR_CIGAR_OVERFLOW = 2; // == MGL_SW_ERR_CIGAR_OVERFLOW
 constexpr int ERR_DEVICE = 4;         // == MGL_SW_ERR_DEVICE
+constexpr int MATRIX_DIM = 32;        // substitution-matrix mode: codes 0..31
 
 // ScoreMax (sw_common.h:36-40); layout == mgl_sw_score
 struct Score {
@@ -59,6 +60,10 @@ struct DpArgs {
     DpRecord *rec;           // count records
     unsigned char *scratch;   // long queries (sw_dp_scratch_kernel): per-group carry ring + query copies in HBM, else null
     unsigned long long *diag; // profiling level 2 only: per block {shader-clock ticks, 100 MHz ticks}; else null
+    // substitution-matrix scoring (sw_dp_matrix_kernel; null = the reference's match / mismatch)
+    const int8_t *matrix;     // MATRIX_DIM x MATRIX_DIM scores, row = target code, column = query code
+    const uint8_t *code;      // byte -> 0 .. MATRIX_DIM-1
+    int matrix_lds_offset;    // set by the launcher
 };
 
 struct TbArgs {

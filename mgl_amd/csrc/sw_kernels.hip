@@ -127,11 +127,12 @@ struct Carry {
     }
 };
 
-template <bool PRO, bool EPI, bool SCRATCH, int G>
+template <bool PRO, bool EPI, bool SCRATCH, int G, bool MATRIX = false>
 __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, const int4 *ring_next,
                                       const unsigned qw, const int tb, const int s0, const int L, const int hb,
                                       const int qcap, const int row_i, const int match, const int mismatch,
-                                      const int gopen, const int gext, int2 *ring_wr, const bool writer)
+                                      const int gopen, const int gext, int2 *ring_wr, const bool writer,
+                                      const int (&sub)[4] = {0, 0, 0, 0})
 {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -143,7 +144,8 @@ __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, c
         const int hup_new = lane_shr1<G>(rh, st.h_prev);
         const int ein = lane_shr1<G>(re, st.e_prev);
         const int qb = (int)((qw >> (8 * u)) & 0xffu);
-        const int diag = st.hup + (qb == tb ? match : mismatch);
+        // substitution-matrix mode (protein extension): the score was looked up one block ahead
+        const int diag = st.hup + (MATRIX ? sub[u] : (qb == tb ? match : mismatch));
         const int d1 = diag - st.f; // < 0 <=> F > diag
         const int sm = max(diag, st.f);
         const int d2 = sm - ein; // < 0 <=> E > max(diag, F)
@@ -188,8 +190,8 @@ __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, c
 // G = target rows per stripe = lanes per pair: 16 (four pairs per wave; short reads: little fill/drain per
 // stripe) or 64 (one pair per wave, the classic 64-row wavefront; long reads: 4x the waves for the same
 // traceback memory, fill/drain 63/(ql+64)).
-template <int G, bool SCRATCH>
-__device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
+template <int G, bool SCRATCH, bool MATRIX = false>
+__device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem, const signed char *mat_lds = nullptr)
 {
     constexpr int PW = 64 / G; // pairs per wave
     unsigned long long diag_t0 = 0, diag_w0 = 0;
@@ -254,7 +256,8 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (int x = L; x < ql; x += G) {
-            const unsigned char c = (unsigned char)a.q.at(q0, x);
+            unsigned char c = (unsigned char)a.q.at(q0, x);
+            if (MATRIX) c = a.code[c]; // the copies hold matrix column codes
 #pragma unroll
             for (int k = 0; k < 4; ++k) qcopy[k * qcopy_bytes + x + G + k] = c;
         }
@@ -284,13 +287,16 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
     int gsteps = 0; // wave-uniform global step counter (traceback bit position)
 
     int row_next = 1 + L; // row of this lane in stripe 0
+    // matrix mode: tb is the byte offset of the target base's matrix row
     int tb_next = (row_next >= 1 && row_next <= tl) ? a.t.at(t0, row_next - 1) : 0;
+    if (MATRIX) tb_next = a.code[tb_next & 0xff] * MATRIX_DIM;
 
     for (int k = 0; k < ns_max; ++k) {
         const int row_i = row_next;
         const int tb = tb_next;
         row_next += G;
         tb_next = (row_next >= 1 && row_next <= tl) ? a.t.at(t0, row_next - 1) : 0;
+        if (MATRIX) tb_next = a.code[tb_next & 0xff] * MATRIX_DIM;
 
         const int hb = border(row_i, gopen, gext, indel);
         const int qcap = row_i <= tl ? ql : NEG_INF; // s - L > -G never equals NEG_INF
@@ -303,13 +309,25 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem)
         const unsigned *qrd = qrd0;
         int4 rA = Carry<SCRATCH>::load2cols(ring_rd), rB = Carry<SCRATCH>::load2cols(ring_rd + 1);
         unsigned qw = Carry<SCRATCH>::loadq(qrd);
+        int sub[4] = {0, 0, 0, 0}; // matrix mode: scores of this block's four columns, looked up one block ahead
+        if (MATRIX) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sub[u] = mat_lds[tb + (int)((qw >> (8 * u)) & 0xffu)];
+        }
 
         int s = 0;
 #define MGL_SW_BLOCK(PRO, EPI)                                                                             \
     {                                                                                                      \
         const unsigned nq = MGL_QREAD(qrd);                                                                \
-        step4<PRO, EPI, SCRATCH, G>(st, rA, rB, ring_rd + 2, qw, tb, s, L, hb, qcap, row_i, match,         \
-                                    mismatch, gopen, gext, ring_wr, writer);                               \
+        int nsub[4] = {0, 0, 0, 0};                                                                        \
+        if (MATRIX) {                                                                                      \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) nsub[u] = mat_lds[tb + (int)((nq >> (8 * u)) & 0xffu)]; \
+        }                                                                                                  \
+        step4<PRO, EPI, SCRATCH, G, MATRIX>(st, rA, rB, ring_rd + 2, qw, tb, s, L, hb, qcap, row_i, match, \
+                                            mismatch, gopen, gext, ring_wr, writer, sub);                  \
+        if (MATRIX) {                                                                                      \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) sub[u] = nsub[u];                               \
+        }                                                                                                  \
         qw = nq;                                                                                           \
         ring_rd += 2;                                                                                      \
         ring_wr += 4;                                                                                      \
@@ -388,6 +406,17 @@ __global__ __launch_bounds__(256) void sw_dp_kernel(const DpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     sw_dp_body<16, false>(a, smem);
+}
+
+// substitution-matrix scoring (protein extension, SURVEY.md 8f rank 4 -- no reference path): the 32 x 32 int8 matrix
+// sits in LDS behind the per-group carves; a lane looks its four scores of a block up one block ahead
+__global__ __launch_bounds__(256) void sw_dp_matrix_kernel(const DpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    signed char *mat = reinterpret_cast<signed char *>(smem) + a.matrix_lds_offset;
+    for (int x = threadIdx.x; x < MATRIX_DIM * MATRIX_DIM; x += blockDim.x) mat[x] = a.matrix[x];
+    __syncthreads();
+    sw_dp_body<16, false, true>(a, smem, mat);
 }
 
 // long queries: the carry ring and the query copies do not fit LDS and live in an HBM scratch area
@@ -838,6 +867,13 @@ hipError_t launch_dp(const DpArgs &a, int waves_per_block, int rows, hipStream_t
     const int per_block = waves_per_block * (64 / rows);
     const int64_t blocks = (a.count + per_block - 1) / per_block;
     const dim3 grid((unsigned)blocks), block(64 * waves_per_block);
+    if (a.matrix) {
+        // (the host layer only takes this path with rows == 16 and an LDS carve below 64 KB)
+        DpArgs b = a;
+        b.matrix_lds_offset = dp_lds_bytes(a.sps_cap, waves_per_block, 16);
+        hipLaunchKernelGGL(sw_dp_matrix_kernel, grid, block, b.matrix_lds_offset + MATRIX_DIM * MATRIX_DIM, stream, b);
+        return hipGetLastError();
+    }
     if (a.scratch) {
         if (rows == 64)
             hipLaunchKernelGGL(sw_dp64_scratch_kernel, grid, block, 0, stream, a);

@@ -1,0 +1,110 @@
+"""Substitution-matrix ("protein") scoring on top of the Smith-Waterman core (SURVEY.md section 8f rank 4,
+BASELINE.json configs[4]).  The reference has no such path (it scores by byte equality, sw.cpp:55): this is an
+extension -- the same recurrence, overhang strategies and traceback with a 32 x 32 int8 matrix in LDS -- and no
+parity with the reference is claimed for it.
+
+BLOSUM62 below is the standard NCBI table (Henikoff & Henikoff 1992), order ARNDCQEGHILKMFPSTWYVBZX*.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+AMINO = "ARNDCQEGHILKMFPSTWYVBZX*"
+_BLOSUM62_ROWS = """
+ 4 -1 -2 -2  0 -1 -1  0 -2 -1 -1 -1 -1 -2 -1  1  0 -3 -2  0 -2 -1  0 -4
+-1  5  0 -2 -3  1  0 -2  0 -3 -2  2 -1 -3 -2 -1 -1 -3 -2 -3 -1  0 -1 -4
+-2  0  6  1 -3  0  0  0  1 -3 -3  0 -2 -3 -2  1  0 -4 -2 -3  3  0 -1 -4
+-2 -2  1  6 -3  0  2 -1 -1 -3 -4 -1 -3 -3 -1  0 -1 -4 -3 -3  4  1 -1 -4
+ 0 -3 -3 -3  9 -3 -4 -3 -3 -1 -1 -3 -1 -2 -3 -1 -1 -2 -2 -1 -3 -3 -2 -4
+-1  1  0  0 -3  5  2 -2  0 -3 -2  1  0 -3 -1  0 -1 -2 -1 -2  0  3 -1 -4
+-1  0  0  2 -4  2  5 -2  0 -3 -3  1 -2 -3 -1  0 -1 -3 -2 -2  1  4 -1 -4
+ 0 -2  0 -1 -3 -2 -2  6 -2 -4 -4 -2 -3 -3 -2  0 -2 -2 -3 -3 -1 -2 -1 -4
+-2  0  1 -1 -3  0  0 -2  8 -3 -3 -1 -2 -1 -2 -1 -2 -2  2 -3  0  0 -1 -4
+-1 -3 -3 -3 -1 -3 -3 -4 -3  4  2 -3  1  0 -3 -2 -1 -3 -1  3 -3 -3 -1 -4
+-1 -2 -3 -4 -1 -2 -3 -4 -3  2  4 -2  2  0 -3 -2 -1 -2 -1  1 -4 -3 -1 -4
+-1  2  0 -1 -3  1  1 -2 -1 -3 -2  5 -1 -3 -1  0 -1 -3 -2 -2  0  1 -1 -4
+-1 -1 -2 -3 -1  0 -2 -3 -2  1  2 -1  5  0 -2 -1 -1 -1 -1  1 -3 -1 -1 -4
+-2 -3 -3 -3 -2 -3 -3 -3 -1  0  0 -3  0  6 -4 -2 -2  1  3 -1 -3 -3 -1 -4
+-1 -2 -2 -1 -3 -1 -1 -2 -2 -3 -3 -1 -2 -4  7 -1 -1 -4 -3 -2 -2 -1 -2 -4
+ 1 -1  1  0 -1  0  0  0 -1 -2 -2  0 -1 -2 -1  4  1 -3 -2 -2  0  0  0 -4
+ 0 -1  0 -1 -1 -1 -1 -2 -2 -1 -1 -1 -1 -2 -1  1  5 -2 -2  0 -1 -1  0 -4
+-3 -3 -4 -4 -2 -2 -3 -2 -2 -3 -2 -3 -1  1 -4 -3 -2 11  2 -3 -4 -3 -2 -4
+-2 -2 -2 -3 -2 -1 -2 -3  2 -1 -1 -2 -1  3 -3 -2 -2  2  7 -1 -3 -2 -1 -4
+ 0 -3 -3 -3 -1 -2 -2 -3 -3  3  1 -2  1 -1 -2 -2  0 -3 -1  4 -3 -2 -1 -4
+-2 -1  3  4 -3  0  1 -1  0 -3 -4  0 -3 -3 -2  0 -1 -4 -3 -3  4  1 -1 -4
+-1  0  0  1 -3  3  4 -2  0 -3 -3  1 -1 -3 -1  0 -1 -3 -2 -2  1  4 -1 -4
+ 0 -1 -1 -1 -2 -1 -1 -1 -1 -1 -1 -1 -1 -1 -2  0  0 -2 -1 -1 -1 -1 -1 -4
+-4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4  1
+"""
+
+
+def blosum62():
+    """(code uint8[256], matrix int8[32, 32]): residues in AMINO order get codes 0..23 (lower case too), every other
+    byte the code of 'X'; unused matrix rows / columns score like 'X'."""
+    rows = np.array([[int(x) for x in line.split()] for line in _BLOSUM62_ROWS.strip().splitlines()], dtype=np.int8)
+    assert rows.shape == (24, 24) and (rows == rows.T).all()
+    x = AMINO.index("X")
+    mat = np.empty((32, 32), dtype=np.int8)
+    mat[:] = rows[x, x]
+    mat[:24, :24] = rows
+    mat[24:, :24] = rows[x]
+    mat[:24, 24:] = rows[:, x:x + 1]
+    code = np.full(256, x, dtype=np.uint8)
+    for k, ch in enumerate(AMINO):
+        code[ord(ch)] = k
+        code[ord(ch.lower())] = k
+    return code, mat
+
+
+# Robinson & Robinson (1991) background frequencies of the 20 standard residues, for synthetic proteins
+_FREQ = dict(A=7.8, R=5.1, N=4.5, D=5.4, C=1.9, Q=4.3, E=6.3, G=7.4, H=2.2, I=5.1, L=9.1, K=5.7, M=2.2, F=3.9, P=5.2,
+             S=7.1, T=5.8, W=1.3, Y=3.2, V=6.4)
+
+
+def random_proteins(rng, n, length):
+    """n random sequences of ``length`` residues (uint8 [n, length]) with natural background frequencies."""
+    letters = np.frombuffer("".join(_FREQ).encode(), dtype=np.uint8)
+    p = np.array(list(_FREQ.values()))
+    return letters[rng.choice(len(letters), size=(n, length), p=p / p.sum())]
+
+
+class IndexedBatch:
+    """Pairs addressed by (start, length) into shared sequence arrays -- a database search: pair k = targets[t_off[k] :
+    t_off[k] + t_len[k]] against queries[q_off[k] : q_off[k] + q_len[k]] (torch CUDA tensors)."""
+
+    def __init__(self, targets, t_off, t_len, queries, q_off, q_len, max_tl, max_ql, cigar_stride):
+        import torch
+
+        self.targets, self.t_off, self.t_len = targets, t_off, t_len
+        self.queries, self.q_off, self.q_len = queries, q_off, q_len
+        self.n, self.max_tl, self.max_ql, self.cigar_stride = t_off.numel(), int(max_tl), int(max_ql), int(cigar_stride)
+        dev = targets.device
+        self.offsets = torch.empty(self.n, dtype=torch.int32, device=dev)
+        self.scores = torch.empty((self.n, 6), dtype=torch.int32, device=dev)
+        self.cigars = torch.empty((self.n, self.cigar_stride), dtype=torch.uint8, device=dev)
+        self.cigar_len = torch.empty(self.n, dtype=torch.int32, device=dev)
+        self.status = torch.empty(self.n, dtype=torch.int32, device=dev)
+
+
+def run_matrix(batch, aligner, code, matrix, gap_open=11, gap_extend=1, overhang_strategy=1, stream=None, binary_cigar=False):
+    """mgl_sw_align_batch_device_matrix on a device_batch.DeviceBatch (ASCII wire format); no sync."""
+    import torch
+
+    if stream is None:
+        stream = torch.cuda.current_stream(batch.targets.device)
+    code = np.ascontiguousarray(code, dtype=np.uint8)
+    matrix = np.ascontiguousarray(matrix, dtype=np.int8)
+    assert code.shape == (256,) and matrix.shape == (32, 32)
+    L = _lib.lib()
+    rc = L.mgl_sw_align_batch_device_matrix(
+        aligner.ctx, C.c_void_p(stream.cuda_stream), batch.n, batch.targets.data_ptr(), batch.t_off.data_ptr(),
+        None if getattr(batch, "t_len", None) is None else batch.t_len.data_ptr(), batch.queries.data_ptr(),
+        batch.q_off.data_ptr(), None if getattr(batch, "q_len", None) is None else batch.q_len.data_ptr(), batch.max_tl,
+        batch.max_ql, matrix.ctypes.data, code.ctypes.data,
+        int(gap_open), int(gap_extend), int(overhang_strategy), batch.offsets.data_ptr(), batch.scores.data_ptr(),
+        batch.cigars.data_ptr(), batch.cigar_stride, batch.cigar_len.data_ptr(), batch.status.data_ptr(),
+        _lib.FLAG_BINARY_CIGAR if binary_cigar else 0)
+    if rc != _lib.OK:
+        raise _lib.MglSwError(rc, L.mgl_sw_last_error(aligner.ctx).decode())

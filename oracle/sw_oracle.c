@@ -36,9 +36,10 @@ static inline int border(int k, int gopen, int gext, int indel)
     return (indel && k > 0) ? -gopen - (k - 1) * gext : 0;
 }
 
-int swo_fill(const uint8_t *t, int tl, const uint8_t *q, int ql, int match,
-             int mismatch, int gopen, int gext, int strategy, int32_t *btr,
-             swo_score *ez, int32_t *h_end)
+/* code / mat: substitution-matrix scoring (swo_fill_matrix below), NULL for the reference's match / mismatch */
+static int fill_core(const uint8_t *t, int tl, const uint8_t *q, int ql, int match,
+                     int mismatch, const uint8_t *code, const int8_t *mat, int gopen, int gext, int strategy,
+                     int32_t *btr, swo_score *ez, int32_t *h_end)
 {
     if (!t || !q || !btr || !ez || tl < 1 || ql < 1) return SWO_BAD_ARG;
     const int m = ql + 1;
@@ -70,8 +71,9 @@ int swo_fill(const uint8_t *t, int tl, const uint8_t *q, int ql, int match,
         const uint8_t a = t[i - 1];
         int h = 0;
         for (int j = 1; j <= ql; j++) {
-            /* sw.cpp:55 raw byte comparison */
-            const int diag = hdiag + (a == q[j - 1] ? match : mismatch);
+            /* sw.cpp:55 raw byte comparison (or the substitution matrix of the protein extension) */
+            const int diag = hdiag + (mat ? (int)mat[code[a] * SWO_MATRIX_DIM + code[q[j - 1]]]
+                                          : (a == q[j - 1] ? match : mismatch));
             const int down = ecol[j], right = f;
             int32_t mark;
             /* sw.cpp:60-71 */
@@ -129,6 +131,20 @@ int swo_fill(const uint8_t *t, int tl, const uint8_t *q, int ql, int match,
     if (h_end) *h_end = hrow[ql];
     free(hrow);
     return SWO_OK;
+}
+
+int swo_fill(const uint8_t *t, int tl, const uint8_t *q, int ql, int match,
+             int mismatch, int gopen, int gext, int strategy, int32_t *btr,
+             swo_score *ez, int32_t *h_end)
+{
+    return fill_core(t, tl, q, ql, match, mismatch, NULL, NULL, gopen, gext, strategy, btr, ez, h_end);
+}
+
+int swo_fill_matrix(const uint8_t *t, int tl, const uint8_t *q, int ql, const uint8_t *code, const int8_t *mat,
+                    int gopen, int gext, int strategy, int32_t *btr, swo_score *ez, int32_t *h_end)
+{
+    if (!code || !mat) return SWO_BAD_ARG;
+    return fill_core(t, tl, q, ql, 0, 0, code, mat, gopen, gext, strategy, btr, ez, h_end);
 }
 
 typedef struct {
@@ -258,6 +274,20 @@ int swo_align(const uint8_t *t, int tl, const uint8_t *q, int ql, int match,
     return rc;
 }
 
+int swo_align_matrix(const uint8_t *t, int tl, const uint8_t *q, int ql, const uint8_t *code, const int8_t *mat,
+                     int gopen, int gext, int strategy, char *cigar, int cap, int *len, int *offset, swo_score *ez)
+{
+    if (tl < 1 || ql < 1) return SWO_BAD_ARG;
+    swo_score local;
+    if (!ez) ez = &local;
+    int32_t *btr = (int32_t *)calloc((size_t)(tl + 1) * (size_t)(ql + 1), sizeof(int32_t));
+    if (!btr) return SWO_NOMEM;
+    int rc = swo_fill_matrix(t, tl, q, ql, code, mat, gopen, gext, strategy, btr, ez, NULL);
+    if (rc == SWO_OK) rc = swo_cigar(btr, tl, ql, strategy, ez, cigar, cap, len, offset);
+    free(btr);
+    return rc;
+}
+
 uint32_t swo_btr_crc32(const int32_t *btr, int tl, int ql)
 {
     static uint32_t table[256];
@@ -293,6 +323,8 @@ typedef struct {
     char *cigar_out;
     int cigar_stride;
     int rc;
+    const uint8_t *code; /* matrix mode (swo_align_batch_matrix), else NULL */
+    const int8_t *mat;
 } batch_job;
 
 static void *batch_worker(void *arg)
@@ -305,7 +337,10 @@ static void *batch_worker(void *arg)
         swo_score ez;
         char *cg = jb->cigar_out + (size_t)k * jb->cigar_stride;
         memset(cg, 0, (size_t)jb->cigar_stride);
-        int rc = swo_align(jb->targets + jb->t_off[k], tl,
+        int rc = jb->mat ? swo_align_matrix(jb->targets + jb->t_off[k], tl, jb->queries + jb->q_off[k], ql, jb->code,
+                                            jb->mat, jb->gopen, jb->gext, jb->strategy, cg, jb->cigar_stride, &len,
+                                            &off, &ez)
+                         : swo_align(jb->targets + jb->t_off[k], tl,
                            jb->queries + jb->q_off[k], ql, jb->match,
                            jb->mismatch, jb->gopen, jb->gext, jb->strategy, cg,
                            jb->cigar_stride, &len, &off, &ez, NULL);
@@ -317,25 +352,25 @@ static void *batch_worker(void *arg)
     return NULL;
 }
 
-int swo_align_batch(int n, const uint8_t *targets, const int64_t *t_off,
+static int align_batch_core(int n, const uint8_t *targets, const int64_t *t_off,
                     const uint8_t *queries, const int64_t *q_off, int match,
                     int mismatch, int gopen, int gext, int strategy,
                     int nthreads, int32_t *offset_out, swo_score *score_out,
-                    char *cigar_out, int cigar_stride, int32_t *cigar_len)
+                    char *cigar_out, int cigar_stride, int32_t *cigar_len, const uint8_t *code, const int8_t *mat)
 {
     if (n < 0 || !targets || !queries || !t_off || !q_off || !offset_out ||
         !cigar_out || cigar_stride < 1)
         return SWO_BAD_ARG;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
-    swo_normalize_params(&match, &mismatch, &gopen, &gext);
+    if (!mat) swo_normalize_params(&match, &mismatch, &gopen, &gext);
     pthread_t th[256];
     batch_job jobs[256];
     for (int w = 0; w < nthreads; w++) {
         batch_job jb = {n,        w,        nthreads, targets,    queries,
                         t_off,    q_off,    match,    mismatch,   gopen,
                         gext,     strategy, offset_out, cigar_len, score_out,
-                        cigar_out, cigar_stride, SWO_OK};
+                        cigar_out, cigar_stride, SWO_OK, code, mat};
         jobs[w] = jb;
     }
     for (int w = 1; w < nthreads; w++)
@@ -347,4 +382,24 @@ int swo_align_batch(int n, const uint8_t *targets, const int64_t *t_off,
         if (rc == SWO_OK) rc = jobs[w].rc;
     }
     return rc;
+}
+
+int swo_align_batch(int n, const uint8_t *targets, const int64_t *t_off,
+                    const uint8_t *queries, const int64_t *q_off, int match,
+                    int mismatch, int gopen, int gext, int strategy,
+                    int nthreads, int32_t *offset_out, swo_score *score_out,
+                    char *cigar_out, int cigar_stride, int32_t *cigar_len)
+{
+    return align_batch_core(n, targets, t_off, queries, q_off, match, mismatch, gopen, gext, strategy, nthreads,
+                            offset_out, score_out, cigar_out, cigar_stride, cigar_len, NULL, NULL);
+}
+
+int swo_align_batch_matrix(int n, const uint8_t *targets, const int64_t *t_off, const uint8_t *queries,
+                           const int64_t *q_off, const uint8_t *code, const int8_t *mat, int gopen, int gext,
+                           int strategy, int nthreads, int32_t *offset_out, swo_score *score_out, char *cigar_out,
+                           int cigar_stride, int32_t *cigar_len)
+{
+    if (!code || !mat) return SWO_BAD_ARG;
+    return align_batch_core(n, targets, t_off, queries, q_off, 0, 0, gopen, gext, strategy, nthreads, offset_out,
+                            score_out, cigar_out, cigar_stride, cigar_len, code, mat);
 }

@@ -67,6 +67,20 @@ int swo_align(const uint8_t *t, int tl, const uint8_t *q, int ql, int match,
  * i=1..tl, j=1..ql, row-major, little-endian int32 -- the fixture checksum. */
 uint32_t swo_btr_crc32(const int32_t *btr, int tl, int ql);
 
+/* ---- substitution-matrix scoring ("protein"): NOT in the reference, which scores by
+ * byte equality only (sw.cpp:55) -- PARITY UNPINNED for this mode, never claimed.  The same recurrence with
+ * diag = H[i-1][j-1] + mat[code[t] * 32 + code[q]] (code: byte -> 0..31, mat: 32 x 32 int8); gap open / extend
+ * are taken as given (positive). */
+#define SWO_MATRIX_DIM 32
+int swo_fill_matrix(const uint8_t *t, int tl, const uint8_t *q, int ql, const uint8_t *code, const int8_t *mat,
+                    int gopen, int gext, int strategy, int32_t *btr, swo_score *ez, int32_t *h_end);
+int swo_align_matrix(const uint8_t *t, int tl, const uint8_t *q, int ql, const uint8_t *code, const int8_t *mat,
+                     int gopen, int gext, int strategy, char *cigar, int cap, int *len, int *offset, swo_score *ez);
+int swo_align_batch_matrix(int n, const uint8_t *targets, const int64_t *t_off, const uint8_t *queries,
+                           const int64_t *q_off, const uint8_t *code, const int8_t *mat, int gopen, int gext,
+                           int strategy, int nthreads, int32_t *offset_out, swo_score *score_out, char *cigar_out,
+                           int cigar_stride, int32_t *cigar_len);
+
 /* Batch driver over nthreads POSIX threads (one pair per task) -- used for
  * bench.py's cpu_baseline "port" leg.  Sequences are concatenated; pair k is
  * targets[t_off[k]..t_off[k+1]) vs queries[q_off[k]..q_off[k+1]).  cigar_out

@@ -1,0 +1,82 @@
+"""BASELINE.json configs[4] shape: protein Smith-Waterman with BLOSUM62 (gap open 11, extend 1), 300-residue
+queries against a 5 000-sequence database, every query against every database sequence (a subset of the 1 M
+queries: queries x 5 000 pairs per pass).  The reference has no such path: this
+measures the substitution-matrix extension of the int32 kernel; results are checked against the CPU restatement's
+extension on a sample.
+
+  python scripts/protein_bench.py [--queries 400] [--db 5000]
+"""
+import argparse, os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np
+import torch
+from mgl_amd import protein, smithwaterman as sw
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--queries", type=int, default=400)
+ap.add_argument("--db", type=int, default=5000)
+ap.add_argument("--query-len", type=int, default=300)
+ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--stride", type=int, default=256, help="CIGAR bytes kept per pair (longer ones are flagged, not written)")
+ap.add_argument("--workspace-gib", type=float, default=16)
+ap.add_argument("--check", type=int, default=200)
+args = ap.parse_args()
+rng = np.random.default_rng(42)
+code, mat = protein.blosum62()
+# database: log-normal lengths (median ~300, clipped to [40, 2000]), sorted by length so that the four pairs of a wave
+# have like geometry; a fifth of the queries are diverged fragments of database sequences, the rest unrelated
+lens = np.clip(np.exp(rng.normal(5.7, 0.55, size=args.db)).astype(np.int64), 40, 2000)
+lens.sort()
+db_off = np.zeros(args.db + 1, np.int64); np.cumsum(lens, out=db_off[1:])
+db = protein.random_proteins(rng, 1, int(db_off[-1]))[0]
+Q, QL = args.queries, args.query_len
+queries = protein.random_proteins(rng, Q, QL)
+for k in range(0, Q, 5):
+    d = int(rng.integers(0, args.db))
+    if lens[d] >= QL:
+        s = int(rng.integers(0, lens[d] - QL + 1)); frag = db[db_off[d] + s: db_off[d] + s + QL].copy()
+        mut = rng.random(QL) < 0.4
+        frag[mut] = protein.random_proteins(rng, 1, int(mut.sum()))[0]
+        queries[k] = frag
+n = Q * args.db
+dev = torch.device("cuda", 0)
+t_start = torch.from_numpy(np.repeat(db_off[:-1], Q)).to(dev)                 # pair index = d * Q + q
+t_len = torch.from_numpy(np.repeat(lens, Q).astype(np.int32)).to(dev)
+q_start = torch.from_numpy(np.tile(np.arange(Q, dtype=np.int64) * QL, args.db)).to(dev)
+q_len = torch.full((n,), QL, dtype=torch.int32, device=dev)
+b = protein.IndexedBatch(torch.from_numpy(db).to(dev), t_start, t_len, torch.from_numpy(queries.reshape(-1)).to(dev), q_start, q_len,
+                         int(lens.max()), QL, args.stride)
+cells = int(lens.sum()) * Q * QL
+a = sw.MicrosoftSmithWaterman(0)
+a.set_workspace(int(args.workspace_gib * (1 << 30)))
+protein.run_matrix(b, a, code, mat, 11, 1); torch.cuda.synchronize()
+a.set_profiling(1)
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    protein.run_matrix(b, a, code, mat, 11, 1)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / args.steps
+tm = a.timing()
+over = int((b.status != 0).sum())
+print(f"protein SW (BLOSUM62, 11/1, SOFTCLIP): {Q} queries of {QL} aa x {args.db} database sequences (mean {lens.mean():.0f} aa) = "
+      f"{n} pairs, {dt*1e3:.1f} ms per pass = {cells/dt/1e9:.1f} GCUPS, {n/dt/1e6:.2f} M alignments/s (fill {tm.dp_ms:.1f} ms in "
+      f"{tm.dp_launches} launches, traceback {tm.tb_ms:.1f} ms; {over} CIGARs longer than {args.stride} bytes flagged)", flush=True)
+if args.check:
+    import ctypes as C
+    import oracle_lib as ol
+    idx = rng.choice(n, size=args.check, replace=False)
+    L = ol.oracle()
+    L.swo_align_matrix.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
+    offs = b.offsets.cpu().numpy(); scs = b.scores.cpu().numpy(); st = b.status.cpu().numpy()
+    cgs = b.cigars[torch.from_numpy(idx).to(dev)].cpu().numpy(); lns = b.cigar_len.cpu().numpy()
+    for j, k in enumerate(idx):
+        d, q = divmod(int(k), Q)
+        t = db[db_off[d]:db_off[d + 1]].tobytes(); qq = queries[q].tobytes()
+        buf = C.create_string_buffer(8192); ln, off = C.c_int(), C.c_int(); ez = (C.c_int32 * 6)()
+        assert L.swo_align_matrix(t, len(t), qq, len(qq), code.ctypes.data, mat.ctypes.data, 11, 1, 1, buf, 8192, C.byref(ln), C.byref(off), ez) == 0
+        assert tuple(scs[k]) == tuple(ez), k
+        if st[k] == 0:
+            assert offs[k] == off.value and cgs[j, :lns[k]].tobytes() == buf.raw[:ln.value], k
+    print(f"checked {len(idx)} random pairs against the CPU restatement's extension: identical", flush=True)
