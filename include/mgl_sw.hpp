@@ -15,9 +15,9 @@
 //   int calculateCigar(...)             (sw_scalar.h:8)      -> mgl_sw_cigar_from_backtrack
 //   (new) int align_gpu(..., ScoreMax* ez = nullptr)         -> mgl_sw_align, also returns the score
 //
-// Not provided: calculateMatrix_avx / calculateCigar_avx / bcktrMatrix_index (sw_avx.h:7-8,33-40)
-// expose the AVX2 register layout of the reference's backtrack buffer, which has no meaning here;
-// the logical matrix of calculateMatrix is the portable form.
+// Also: bcktrMatrix_index and calculateCigar_avx (sw_avx.h:8,33-40) on the AVX2 path's band layout, and
+// calculateMatrix_banded producing that layout.  Not provided: the per-band step calculateMatrix_avx (sw_avx.h:7),
+// an internal stage of the reference's AVX2 driver (one band per call, with its score / step / gap carry arrays).
 //
 // Error behaviour: the reference's functions cannot fail.  These throw std::runtime_error
 // carrying the mgl_sw_status text when the library reports an error (no GPU, bad length, ...).
@@ -165,6 +165,43 @@ inline int calculateCigar(int *bcktrack, int n, int m, int overhangStrategy, Sco
         cigar->append(buf.data(), (size_t)len);
         return off;
     }
+}
+
+// sw_avx.h:33-40 -- position of cell (i, j) (0-based) in the AVX2 path's anti-diagonal band layout: bands of bw
+// target rows, inside a band bw consecutive ints per anti-diagonal.
+inline int bcktrMatrix_index(int i, int j, int n_col, int bw)
+{
+    const int band = i / bw, J = i % bw, I = j + J;
+    return band * bw * n_col + I * bw + J;
+}
+
+// The band-layout backtrack matrix of sw_avx.cpp:33-34,173 for callers that hold their traceback in that form:
+// (query_length + bw - 1) * ceil(target_length / bw) * bw ints, cells outside the matrix zero (the reference leaves
+// garbage there).  Filled from the logical matrix of calculateMatrix().
+inline std::vector<int> calculateMatrix_banded(const char *target, int target_length, const char *query, int query_length,
+                                               swParameters parameters, int overhangStrategy, ScoreMax *ez, int bw = 8)
+{
+    std::vector<int> logical((size_t)(target_length + 1) * (size_t)(query_length + 1));
+    calculateMatrix(target, target_length, query, query_length, logical.data(), parameters, overhangStrategy, ez);
+    const int rows = (target_length + bw - 1) / bw * bw, n_col = query_length + bw - 1;
+    std::vector<int> banded((size_t)rows * (size_t)n_col, 0);
+    for (int i = 1; i <= target_length; ++i)
+        for (int j = 1; j <= query_length; ++j)
+            banded[(size_t)bcktrMatrix_index(i - 1, j - 1, n_col, bw)] = logical[(size_t)i * (query_length + 1) + j];
+    return banded;
+}
+
+// sw_avx.h:8 -- traceback on a band-layout matrix (n = target_length + 1, m = query_length + 1, bw = the band
+// width it was written with, 8 in the reference); appends to *cigar, returns the offset.  The per-band fill
+// calculateMatrix_avx (sw_avx.h:7) is an internal step of the reference's AVX2 driver -- one band per call with its
+// score / step / gap carry arrays -- and has no counterpart here: calculateMatrix[_banded] give the whole matrix.
+inline int calculateCigar_avx(int *bcktrack, int n, int m, int bw, int overhangStrategy, ScoreMax *ez, std::string *cigar)
+{
+    const int tl = n - 1, ql = m - 1, n_col = ql + bw - 1;
+    std::vector<int> logical((size_t)n * (size_t)m, 0);
+    for (int i = 1; i <= tl; ++i)
+        for (int j = 1; j <= ql; ++j) logical[(size_t)i * m + j] = bcktrack[bcktrMatrix_index(i - 1, j - 1, n_col, bw)];
+    return calculateCigar(logical.data(), n, m, overhangStrategy, ez, cigar);
 }
 
 #endif /* MGL_SW_HPP */

@@ -51,6 +51,15 @@ int main()
         ScoreMax ez;
         calculateMatrix(t.data(), tl, q.data(), ql, btr.data(), p, strategy, &ez);
         const int off_m = calculateCigar(btr.data(), tl + 1, ql + 1, strategy, &ez, &cigar_m);
+        // the AVX2 driver's form (sw_avx.cpp:97): traceback on the band-layout matrix, band width 8
+        ScoreMax ez_b;
+        std::vector<int> banded = calculateMatrix_banded(t.data(), tl, q.data(), ql, p, strategy, &ez_b);
+        std::string cigar_b;
+        const int off_b = calculateCigar_avx(banded.data(), tl + 1, ql + 1, 8, strategy, &ez_b, &cigar_b);
+        if (off_b != off_m || cigar_b != cigar_m || banded[(size_t)bcktrMatrix_index(tl - 1, ql - 1, ql + 7, 8)] != btr[(size_t)tl * (ql + 1) + ql]) {
+            std::fprintf(stderr, "calculateCigar_avx != calculateCigar\n");
+            return 3;
+        }
         std::printf("%d %s %d %s %d %d %d %d %d %d %u\n", off_a, cigar_a.c_str(), off_m, cigar_m.c_str(), ez.mqe, ez.mqe_t,
                     ez.max, ez.max_t, ez.max_q, ez.seg_length, crc32_le(btr.data(), tl, ql));
     }
