@@ -22,13 +22,20 @@
 #include <vector>
 
 // sw_capi.cpp (library-internal, not part of include/mgl_sw.h)
-extern "C" int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const int64_t *t_off,
-                                         const uint8_t *queries, const int64_t *q_off, int match, int mismatch,
-                                         int gopen, int gext, int strategy, int32_t *offset_out,
-                                         mgl_sw_score *score_out, char *cigar_out, int cigar_stride,
-                                         int32_t *cigar_len_out, int32_t *status_out);
+extern "C" int mgl_sw_stage_buffers(mgl_sw_ctx *ctx, size_t in_bytes, size_t out_bytes, void **in, void **out);
+extern "C" int mgl_sw_align_batch_staged(mgl_sw_ctx *ctx, int n, size_t in_bytes, size_t t_bytes_padded, int max_tl, int max_ql,
+                                         int match, int mismatch, int gopen, int gext, int strategy, int cigar_stride,
+                                         size_t out_bytes);
 
 namespace {
+
+// Callers sleep on one of a few condition variables chosen by thread, each with its own mutex: a finished batch then
+// wakes its callers shard by shard instead of stampeding every parked thread through the submission lock.
+constexpr int kShards = 32;
+struct Shard {
+    std::mutex mu;
+    std::condition_variable cv;
+};
 
 struct Request {
     const char *t, *q;
@@ -38,7 +45,8 @@ struct Request {
     int *cigar_len, *offset;
     mgl_sw_score *ez;
     int rc = MGL_SW_OK;
-    bool done = false;
+    bool done = false; // guarded by the shard's mutex
+    int shard = 0;
 };
 
 using Key = std::tuple<int, int, int, int, int>; // normalised match, mismatch, open, extend, strategy
@@ -64,13 +72,19 @@ class Coalescer {
 
     int submit(Request &r, const Key &key)
     {
-        std::unique_lock<std::mutex> lk(mu_);
-        auto &qd = queues_[key];
-        if (qd.empty()) oldest_[key] = std::chrono::steady_clock::now();
-        qd.push_back(&r);
-        ++pending_;
-        cv_work_.notify_one();
-        cv_done_.wait(lk, [&] { return r.done; });
+        static std::atomic<unsigned> next_shard{0};
+        thread_local const int my_shard = (int)(next_shard.fetch_add(1) % kShards);
+        r.shard = my_shard;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            auto &qd = queues_[key];
+            if (qd.empty()) oldest_[key] = std::chrono::steady_clock::now();
+            qd.push_back(&r);
+            if (++pending_ == 1 || (int)qd.size() >= max_batch_) cv_work_.notify_one(); // the dispatcher is idle, or a batch is full
+        }
+        Shard &sh = shards_[my_shard];
+        std::unique_lock<std::mutex> lk(sh.mu);
+        sh.cv.wait(lk, [&] { return r.done; });
         return r.rc;
     }
 
@@ -131,24 +145,41 @@ class Coalescer {
             pending_ -= (int)batch.size();
             lk.unlock();
             process(key, batch);
+            release(batch);
             lk.lock();
-            for (Request *r : batch) r->done = true;
             ++n_batches_;
             n_pairs_ += (int64_t)batch.size();
-            cv_done_.notify_all();
+        }
+    }
+
+    // hand the results back: per shard, mark its requests done under the shard's mutex, then wake that shard
+    // (a request lives on its caller's stack and is gone the moment that caller sees done: sort the batch by shard
+    // first, then touch every request exactly once, under its shard's mutex)
+    void release(const std::vector<Request *> &batch)
+    {
+        std::vector<Request *> by_shard[kShards];
+        for (Request *r : batch) by_shard[r->shard].push_back(r);
+        for (int s = 0; s < kShards; ++s) {
+            if (by_shard[s].empty()) continue;
+            {
+                std::lock_guard<std::mutex> lk(shards_[s].mu);
+                for (Request *r : by_shard[s]) r->done = true;
+            }
+            shards_[s].cv.notify_all();
         }
     }
 
     void fail_all(int rc)
     {
+        std::vector<Request *> all;
         for (auto &kv : queues_)
             for (Request *r : kv.second) {
                 r->rc = rc;
-                r->done = true;
+                all.push_back(r);
             }
         queues_.clear();
         pending_ = 0;
-        cv_done_.notify_all();
+        release(all);
     }
 
     void process(const Key &key, std::vector<Request *> &batch)
@@ -163,31 +194,43 @@ class Coalescer {
                 return;
             }
             mgl_sw_ctx_set_workspace(ctx_, 1ll << 30);
+            // small batches are latency bound: one workgroup of four waves per pair (sw_dp_coop.hip) finishes a
+            // 256 x 150 pair in a quarter of the time of one wave walking its 16 stripes (tests/cpp/coalesce_bench)
+            mgl_sw_ctx_set_cooperative(ctx_, 4);
         }
-        toff_.assign((size_t)n + 1, 0);
-        qoff_.assign((size_t)n + 1, 0);
-        int stride = 16;
-        for (int k = 0; k < n; ++k) {
-            toff_[(size_t)k + 1] = toff_[(size_t)k] + batch[(size_t)k]->tl;
-            qoff_[(size_t)k + 1] = qoff_[(size_t)k] + batch[(size_t)k]->ql;
-            stride = std::max(stride, batch[(size_t)k]->cigar_cap);
+        // lay the batch out in the context's pinned staging buffer (see mgl_sw_align_batch_staged)
+        int stride = 16, max_tl = 1, max_ql = 1;
+        size_t t_bytes = 0, q_bytes = 0;
+        for (Request *r : batch) {
+            t_bytes += (size_t)r->tl;
+            q_bytes += (size_t)r->ql;
+            stride = std::max(stride, r->cigar_cap);
+            max_tl = std::max(max_tl, r->tl);
+            max_ql = std::max(max_ql, r->ql);
         }
-        stride = std::min(stride, 1 << 16); // a slot larger than any caller's buffer is pointless
-        tbuf_.resize((size_t)toff_[(size_t)n]);
-        qbuf_.resize((size_t)qoff_[(size_t)n]);
-        for (int k = 0; k < n; ++k) {
-            memcpy(tbuf_.data() + toff_[(size_t)k], batch[(size_t)k]->t, (size_t)batch[(size_t)k]->tl);
-            memcpy(qbuf_.data() + qoff_[(size_t)k], batch[(size_t)k]->q, (size_t)batch[(size_t)k]->ql);
+        stride = std::min((stride + 3) & ~3, 1 << 16); // a slot larger than any caller's buffer is pointless
+        const size_t offs = (size_t)(n + 1) * 8, t_pad = (t_bytes + 7) & ~(size_t)7, q_pad = (q_bytes + 7) & ~(size_t)7;
+        const size_t in_bytes = 2 * offs + t_pad + q_pad;
+        const size_t out_bytes = (size_t)n * (12 + sizeof(mgl_sw_score)) + (size_t)n * stride;
+        void *in = nullptr, *out = nullptr;
+        int rc = mgl_sw_stage_buffers(ctx_, in_bytes, out_bytes, &in, &out);
+        if (rc == MGL_SW_OK) {
+            int64_t *toff = static_cast<int64_t *>(in), *qoff = toff + (n + 1);
+            uint8_t *tb = static_cast<uint8_t *>(in) + 2 * offs, *qb = tb + t_pad;
+            toff[0] = qoff[0] = 0;
+            for (int k = 0; k < n; ++k) {
+                const Request *r = batch[(size_t)k];
+                memcpy(tb + toff[k], r->t, (size_t)r->tl);
+                memcpy(qb + qoff[k], r->q, (size_t)r->ql);
+                toff[k + 1] = toff[k] + r->tl;
+                qoff[k + 1] = qoff[k] + r->ql;
+            }
+            rc = mgl_sw_align_batch_staged(ctx_, n, in_bytes, t_pad, max_tl, max_ql, std::get<0>(key), std::get<1>(key),
+                                           std::get<2>(key), std::get<3>(key), std::get<4>(key), stride, out_bytes);
         }
-        off_.resize((size_t)n);
-        len_.resize((size_t)n);
-        status_.resize((size_t)n);
-        score_.resize((size_t)n);
-        cig_.resize((size_t)n * stride);
-        const int rc = mgl_sw_align_batch_status(ctx_, n, tbuf_.data(), toff_.data(), qbuf_.data(), qoff_.data(),
-                                                 std::get<0>(key), std::get<1>(key), std::get<2>(key), std::get<3>(key),
-                                                 std::get<4>(key), off_.data(), score_.data(), cig_.data(), stride,
-                                                 len_.data(), status_.data());
+        const int32_t *off_ = static_cast<const int32_t *>(out), *len_ = off_ + n, *status_ = len_ + n;
+        const mgl_sw_score *score_ = reinterpret_cast<const mgl_sw_score *>(status_ + n);
+        const char *cig_ = reinterpret_cast<const char *>(score_ + n);
         for (int k = 0; k < n; ++k) {
             Request *r = batch[(size_t)k];
             if (rc != MGL_SW_OK) {
@@ -199,7 +242,7 @@ class Coalescer {
                 r->rc = MGL_SW_ERR_CIGAR_OVERFLOW;
                 continue;
             }
-            memcpy(r->cigar, cig_.data() + (size_t)k * stride, (size_t)len_[(size_t)k]);
+            memcpy(r->cigar, cig_ + (size_t)k * stride, (size_t)len_[(size_t)k]);
             *r->offset = off_[(size_t)k];
             if (r->ez) *r->ez = score_[(size_t)k];
             r->rc = MGL_SW_OK;
@@ -207,7 +250,8 @@ class Coalescer {
     }
 
     std::mutex mu_;
-    std::condition_variable cv_work_, cv_done_;
+    std::condition_variable cv_work_;
+    Shard shards_[kShards];
     std::map<Key, std::deque<Request *>> queues_;
     std::map<Key, std::chrono::steady_clock::time_point> oldest_;
     int pending_ = 0;
@@ -217,11 +261,6 @@ class Coalescer {
     std::thread worker_;
     mgl_sw_ctx *ctx_ = nullptr;
     int64_t n_batches_ = 0, n_pairs_ = 0;
-    std::vector<uint8_t> tbuf_, qbuf_;
-    std::vector<int64_t> toff_, qoff_;
-    std::vector<int32_t> off_, len_, status_;
-    std::vector<mgl_sw_score> score_;
-    std::vector<char> cig_;
 };
 
 struct EnvInit {

@@ -26,7 +26,6 @@ static_assert(sizeof(mgl_sw_score) == sizeof(Score), "mgl_sw_score layout");
 
 namespace {
 
-constexpr int kMaxLdsBytes = 160 * 1024;
 constexpr int64_t kDefaultWorkspace = 4ll << 30;
 
 struct DevBuf {
@@ -58,6 +57,10 @@ struct mgl_sw_ctx {
     int64_t ws_limit = kDefaultWorkspace;
     // kernel workspace, two halves: the traceback of chunk k (aux stream) overlaps the fill of chunk k+1
     DevBuf tb[2], rec[2], diag, scratch;
+    // small-batch entry of the coalescing front-end: one pinned host buffer each way, mirrored on the device
+    void *pin_in = nullptr, *pin_out = nullptr;
+    size_t pin_in_cap = 0, pin_out_cap = 0;
+    DevBuf stage_in, stage_out;
     int carry_memory = 0; // 0 = LDS when it fits, 1 = always the HBM scratch (tests)
     int stripe_rows = 0;  // 0 = choose per batch, 16 / 64 = force (tests)
     int cooperative = 0;  // 0 = choose per batch, 1 = never, 2..16 = always, that many waves per pair (tests)
@@ -437,6 +440,10 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     for (auto *set : {ctx->fill_done, ctx->tb_done})
         for (int h = 0; h < 2; ++h)
             if (set[h]) (void)hipEventDestroy(set[h]);
+    if (ctx->pin_in) (void)hipHostFree(ctx->pin_in);
+    if (ctx->pin_out) (void)hipHostFree(ctx->pin_out);
+    ctx->stage_in.release();
+    ctx->stage_out.release();
     if (ctx->in_done) (void)hipEventDestroy(ctx->in_done);
     for (auto &e : ctx->out_ready)
         if (e) (void)hipEventDestroy(e);
@@ -720,6 +727,63 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     return MGL_SW_OK;
 }
 
+// ---- small-batch entry for the coalescing front-end (sw_batcher.cpp; library-internal, not in include/mgl_sw.h).
+// One pinned host buffer in, one out, each mirrored on the device: a batch costs one copy each way, two launches
+// and one synchronisation instead of the eleven copies of the general host entry.
+//   in : int64 t_off[n+1] | int64 q_off[n+1] | target bytes | query bytes      (sections 8-byte aligned)
+//   out: int32 offset[n] | int32 cigar_len[n] | int32 status[n] | mgl_sw_score[n] | char cigar[n][stride]
+int mgl_sw_stage_buffers(mgl_sw_ctx *ctx, size_t in_bytes, size_t out_bytes, void **in, void **out)
+{
+    if (!ctx || !in || !out) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    auto grow = [&](void *&p, size_t &cap, size_t want) -> hipError_t {
+        if (want <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t bytes = want + want / 2 + 4096;
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    };
+    HIP_TRY(ctx, grow(ctx->pin_in, ctx->pin_in_cap, in_bytes));
+    HIP_TRY(ctx, grow(ctx->pin_out, ctx->pin_out_cap, out_bytes));
+    HIP_TRY(ctx, ctx->stage_in.reserve(ctx->pin_in_cap));
+    HIP_TRY(ctx, ctx->stage_out.reserve(ctx->pin_out_cap));
+    *in = ctx->pin_in;
+    *out = ctx->pin_out;
+    return MGL_SW_OK;
+}
+
+int mgl_sw_align_batch_staged(mgl_sw_ctx *ctx, int n, size_t in_bytes, size_t t_bytes_padded, int max_tl, int max_ql, int match,
+                              int mismatch, int gopen, int gext, int strategy, int cigar_stride, size_t out_bytes)
+{
+    if (!ctx || n < 1) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (in_bytes > ctx->pin_in_cap || out_bytes > ctx->pin_out_cap) return fail(ctx, MGL_SW_ERR_BAD_ARG, "staged batch larger than its buffers");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_in.p, ctx->pin_in, in_bytes, hipMemcpyHostToDevice, st));
+    const uint8_t *din = static_cast<const uint8_t *>(ctx->stage_in.p);
+    const size_t offs_bytes = (size_t)(n + 1) * 8;
+    const SeqSet ts{din + 2 * offs_bytes, reinterpret_cast<const int64_t *>(din), nullptr, max_tl, 0},
+        qs{din + 2 * offs_bytes + t_bytes_padded, reinterpret_cast<const int64_t *>(din + offs_bytes), nullptr, max_ql, 0};
+    uint8_t *dout = static_cast<uint8_t *>(ctx->stage_out.p);
+    int32_t *d_off = reinterpret_cast<int32_t *>(dout), *d_len = d_off + n, *d_status = d_len + n;
+    Score *d_score = reinterpret_cast<Score *>(d_status + n);
+    char *d_cig = reinterpret_cast<char *>(d_score + n);
+    const int rc = run_device(ctx, st, n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext, strategy, d_off, d_score, d_cig,
+                              cigar_stride, d_len, d_status, 0, false);
+    if (rc != MGL_SW_OK) {
+        (void)hipStreamSynchronize(st);
+        return rc;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_out, ctx->stage_out.p, out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return MGL_SW_OK;
+}
+
 // sw_batcher.cpp
 bool mgl_sw_coalescing_enabled();
 int mgl_sw_coalesced_align(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen, int gext,
@@ -738,6 +802,7 @@ static mgl_sw_ctx *thread_ctx(int *rc)
         *rc = mgl_sw_ctx_create(dev, &h.ctx);
         if (*rc != MGL_SW_OK) return nullptr;
         h.ctx->ws_limit = 256ll << 20;
+        h.ctx->cooperative = 4; // one pair per call: latency, not occupancy (see sw_batcher.cpp)
     }
     *rc = MGL_SW_OK;
     return h.ctx;

@@ -265,6 +265,19 @@ def test_cpp_dropin_api():
         assert int(f[10]) == g.crc
 
 
+def test_native_threads_through_the_coalescer():
+    """GATK's calling pattern from native threads (tests/cpp/coalesce_bench.cpp): 48 threads, one pair per
+    mgl_sw_align call, merged into device batches by the dispatcher; every answer equals the direct call's."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "cpp")])
+    for args in (["48", "60", "50"], ["7", "40", "0", "97", "33"]):
+        r = subprocess.run([os.path.join(root, "tests", "cpp", "coalesce_bench")] + args, capture_output=True, text=True)
+        assert r.returncode == 0 and "wrong results 0" in r.stdout, (r.stdout, r.stderr)
+
+
 def test_batch_mode_backtrack_matrix(aligner):
     """Traceback bits of pairs aligned inside a mixed-geometry batch (wave mates of different
     tl/ql) expand to the reference's matrix as well."""
