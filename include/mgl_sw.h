@@ -163,6 +163,11 @@ int mgl_sw_align_batch(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const
  * (length << 4 | op, op M=0 I=1 D=2 S=4) instead of the text of sw.cpp:251-252; cigar_len is then in bytes
  * (4 per element) and cigar_stride should be a multiple of 4.  Same elements, same order. */
 #define MGL_SW_FLAG_BINARY_CIGAR 0x2
+/* MGL_SW_FLAG_GROUPED_GEOMETRY: a promise that every aligned block of eight consecutive pairs (pairs 8k .. 8k+7;
+ * the last block may be shorter) has one (tl, ql) -- e.g. a batch of variable-length reads sorted by length and
+ * padded per length to a multiple of eight.  Such a batch is eligible for the packed-int16 kernel like a uniform
+ * one (each wave of that kernel works on one block).  Results are undefined if the promise is broken. */
+#define MGL_SW_FLAG_GROUPED_GEOMETRY 0x4
 int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_targets,
                               const int64_t *d_t_off, const uint8_t *d_queries,
                               const int64_t *d_q_off, int max_tl, int max_ql, int match,
@@ -188,6 +193,19 @@ int mgl_sw_align_batch_device_2bit(mgl_sw_ctx *ctx, void *stream, int64_t n, con
                                    int gopen, int gext, int strategy, int32_t *d_offset_out,
                                    mgl_sw_score *d_score_out, char *d_cigar_out, int cigar_stride,
                                    int32_t *d_cigar_len_out, int32_t *d_status_out, int flags);
+
+/*
+ * ASCII bases addressed by (start, length) per pair instead of consecutive offsets: pair k =
+ * d_targets[d_t_start[k] .. + d_t_len[k]) against d_queries[d_q_start[k] .. + d_q_len[k]).  Sequences may be shared
+ * or reordered without moving bytes (e.g. to satisfy MGL_SW_FLAG_GROUPED_GEOMETRY by sorting index arrays).
+ * Everything else as mgl_sw_align_batch_device; outputs are indexed by k.
+ */
+int mgl_sw_align_batch_device_indexed(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_targets,
+                                      const int64_t *d_t_start, const int32_t *d_t_len, const uint8_t *d_queries,
+                                      const int64_t *d_q_start, const int32_t *d_q_len, int max_tl, int max_ql,
+                                      int match, int mismatch, int gopen, int gext, int strategy,
+                                      int32_t *d_offset_out, mgl_sw_score *d_score_out, char *d_cigar_out,
+                                      int cigar_stride, int32_t *d_cigar_len_out, int32_t *d_status_out, int flags);
 
 /*
  * Substitution-matrix scoring ("protein" mode).  NOT in the reference, which scores

@@ -548,7 +548,24 @@ int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const ui
     const SeqSet ts{d_targets, d_t_off, nullptr, max_tl, 0}, qs{d_queries, d_q_off, nullptr, max_ql, 0};
     return run_device(ctx, static_cast<hipStream_t>(stream), n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext,
                       strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride,
-                      d_cigar_len_out, d_status_out, 0, (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) != 0,
+                      d_cigar_len_out, d_status_out, 0, (flags & (MGL_SW_FLAG_UNIFORM_GEOMETRY | MGL_SW_FLAG_GROUPED_GEOMETRY)) != 0,
+                      (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0);
+}
+
+int mgl_sw_align_batch_device_indexed(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_targets,
+                                      const int64_t *d_t_start, const int32_t *d_t_len, const uint8_t *d_queries,
+                                      const int64_t *d_q_start, const int32_t *d_q_len, int max_tl, int max_ql, int match,
+                                      int mismatch, int gopen, int gext, int strategy, int32_t *d_offset_out,
+                                      mgl_sw_score *d_score_out, char *d_cigar_out, int cigar_stride,
+                                      int32_t *d_cigar_len_out, int32_t *d_status_out, int flags)
+{
+    if (!ctx) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!d_t_len || !d_q_len) return fail(ctx, MGL_SW_ERR_BAD_ARG, "indexed batch: length arrays are required");
+    const SeqSet ts{d_targets, d_t_start, d_t_len, max_tl, 0}, qs{d_queries, d_q_start, d_q_len, max_ql, 0};
+    return run_device(ctx, static_cast<hipStream_t>(stream), n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext,
+                      strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride,
+                      d_cigar_len_out, d_status_out, 0, (flags & (MGL_SW_FLAG_UNIFORM_GEOMETRY | MGL_SW_FLAG_GROUPED_GEOMETRY)) != 0,
                       (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0);
 }
 
@@ -589,6 +606,7 @@ int mgl_sw_align_batch_device_2bit(mgl_sw_ctx *ctx, void *stream, int64_t n, con
     if (!ctx) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     const bool uniform = (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) != 0;
+    const bool grouped = (flags & MGL_SW_FLAG_GROUPED_GEOMETRY) != 0;
     // without per-pair length arrays every pair has exactly max_tl / max_ql bases
     if ((!d_t_len || !d_q_len) && !uniform)
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "2-bit batch: length arrays are required unless the geometry is uniform");
@@ -596,7 +614,7 @@ int mgl_sw_align_batch_device_2bit(mgl_sw_ctx *ctx, void *stream, int64_t n, con
         qs{d_query_bases, d_q_start, uniform ? nullptr : d_q_len, max_ql, 1};
     return run_device(ctx, static_cast<hipStream_t>(stream), n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext,
                       strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride,
-                      d_cigar_len_out, d_status_out, 0, uniform, (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0);
+                      d_cigar_len_out, d_status_out, 0, uniform || grouped, (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0);
 }
 
 // mgl_sw_align_batch with an optional per-pair status array: with it, a CIGAR overflow of one pair does not

@@ -248,7 +248,10 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
     const int64_t slotB = validB ? 2 * gs + 1 : slotA;
     const int64_t pA = a.first + slotA, pB = a.first + slotB;
 
-    const int tl = a.uni_tl, ql = a.uni_ql; // one geometry for the whole batch
+    // one geometry per WAVE: every pair of the batch has it (MGL_SW_FLAG_UNIFORM_GEOMETRY), or at least every aligned
+    // block of eight consecutive pairs (MGL_SW_FLAG_GROUPED_GEOMETRY, batches sorted by read length); a.uni_tl /
+    // a.uni_ql are then the maxima that size the LDS carve and the traceback stride
+    const int tl = __builtin_amdgcn_readfirstlane(a.t.length(pA)), ql = __builtin_amdgcn_readfirstlane(a.q.length(pA));
     const int64_t tA = a.t.off[pA], tB = a.t.off[pB], qA = a.q.off[pA], qB = a.q.off[pB];
 
     const int nstripes = stripes_for(tl);
@@ -257,9 +260,11 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
     const int nc = dp16_chained_stripes(tl, ql);
     const int main_end = max(16, ql & ~3);
 
-    // LDS carve per group: ring uint2[sps+20] (H, E' packed A|B per column) | qq uint32[sps+48]
-    const int ring_entries = sps + RING_SLACK16;
-    const int qq_entries = sps + QQ_SLACK16;
+    // LDS carve per group: ring uint2[sps+20] (H, E' packed A|B per column) | qq uint32[sps+48], sized for the longest
+    // query of the batch so that every wave of a block carves the same way
+    const int sps_carve = sps_for(a.uni_ql);
+    const int ring_entries = sps_carve + RING_SLACK16;
+    const int qq_entries = sps_carve + QQ_SLACK16;
     const int group_bytes = ring_entries * 8 + qq_entries * 4;
     unsigned char *gbase = smem + (size_t)(wave * 4 + grp) * group_bytes;
     uint2 *ring = reinterpret_cast<uint2 *>(gbase);                          // ring[j + 16] = column j

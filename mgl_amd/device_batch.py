@@ -137,6 +137,62 @@ def from_host(targets, t_off, queries, q_off, device, cigar_stride=None):
 
 
 # ---------------------------------------------------------------------------------------------
+# variable-length batches at packed-kernel speed: sort by geometry, pad every geometry to a multiple of eight
+class GroupedBatch(DeviceBatch):
+    """ASCII pairs addressed by (start, length) (mgl_sw_align_batch_device_indexed), reordered so that every aligned
+    block of eight pairs has one (tl, ql) (MGL_SW_FLAG_GROUPED_GEOMETRY).  ``order[k]`` is the original pair index of
+    slot k (a geometry whose count is not a multiple of eight repeats its last pair to fill the block);
+    ``first_slot[i]`` is a slot holding original pair i: results of pair i are ``offsets[first_slot[i]]`` etc."""
+
+    def __init__(self, targets, t_start, t_len, queries, q_start, q_len, cigar_stride=64):
+        dev = targets.device
+        tl, ql = t_len.to(torch.int64), q_len.to(torch.int64)
+        key = tl * (1 << 32) + ql
+        order = torch.argsort(key, stable=True)
+        skey = key[order]
+        uniq, counts = torch.unique_consecutive(skey, return_counts=True)
+        padded = (counts + 7) // 8 * 8
+        ends = torch.cumsum(counts, 0)
+        # slot -> index into `order`: the bucket's own pairs, then its last pair repeated
+        bucket = torch.repeat_interleave(torch.arange(len(uniq), device=dev), padded)
+        pos = torch.arange(int(padded.sum()), device=dev) - torch.repeat_interleave(torch.cumsum(padded, 0) - padded, padded)
+        src = (ends - counts)[bucket] + torch.minimum(pos, counts[bucket] - 1)
+        self.order = order[src]
+        self.first_slot = torch.full_like(order, len(self.order)).scatter_reduce_(
+            0, self.order, torch.arange(len(self.order), device=dev), "amin")
+        self.targets, self.queries = targets, queries
+        self.t_off, self.q_off = t_start[self.order].contiguous(), q_start[self.order].contiguous()
+        self.t_len, self.q_len = t_len[self.order].to(torch.int32).contiguous(), q_len[self.order].to(torch.int32).contiguous()
+        self.n = len(self.order)
+        self.max_tl, self.max_ql = int(tl.max()), int(ql.max())
+        self.cigar_stride = int(cigar_stride)
+        self.uniform = False
+        self.offsets = torch.empty(self.n, dtype=torch.int32, device=dev)
+        self.scores = torch.empty((self.n, 6), dtype=torch.int32, device=dev)
+        self.cigars = torch.empty((self.n, self.cigar_stride), dtype=torch.uint8, device=dev)
+        self.cigar_len = torch.empty(self.n, dtype=torch.int32, device=dev)
+        self.status = torch.empty(self.n, dtype=torch.int32, device=dev)
+
+    @property
+    def cells(self):
+        return int((self.t_len.to(torch.int64) * self.q_len.to(torch.int64)).sum())
+
+    def run(self, aligner, parameters=GATK_PARAMETERS, overhang_strategy=SWOverhangStrategy.SOFTCLIP, stream=None,
+            binary_cigar=False):
+        if stream is None:
+            stream = torch.cuda.current_stream(self.targets.device)
+        p = SWParameters(*parameters)
+        flags = _lib.FLAG_GROUPED_GEOMETRY | (_lib.FLAG_BINARY_CIGAR if binary_cigar else 0)
+        rc = _lib.lib().mgl_sw_align_batch_device_indexed(
+            aligner.ctx, C.c_void_p(stream.cuda_stream), self.n, self.targets.data_ptr(), self.t_off.data_ptr(),
+            self.t_len.data_ptr(), self.queries.data_ptr(), self.q_off.data_ptr(), self.q_len.data_ptr(), self.max_tl,
+            self.max_ql, p.match, p.mismatch, p.gap_open, p.gap_extend, int(overhang_strategy), self.offsets.data_ptr(),
+            self.scores.data_ptr(), self.cigars.data_ptr(), self.cigar_stride, self.cigar_len.data_ptr(),
+            self.status.data_ptr(), flags)
+        _check(rc, aligner.ctx)
+
+
+# ---------------------------------------------------------------------------------------------
 # 2-bit packed inputs (mgl_sw_align_batch_device_2bit)
 
 _CODE = np.full(256, 255, dtype=np.uint8)

@@ -265,6 +265,46 @@ def test_cpp_dropin_api():
         assert int(f[10]) == g.crc
 
 
+def test_grouped_geometry_variable_length_reads(aligner):
+    """Reads of varying length (trimmed reads) against windows of two sizes, addressed by (start, length), sorted by
+    geometry and padded to blocks of eight (MGL_SW_FLAG_GROUPED_GEOMETRY): the packed-int16 kernel runs one geometry
+    per wave; results equal the oracle's and the int32 kernel's on the same pairs."""
+    import torch
+    from mgl_amd import device_batch, synth
+
+    rng = synth.rng_for(77)
+    n = 3000
+    genome = synth.random_genome(rng, 1 << 16)
+    tl = rng.choice([200, 256], size=n)
+    ql = rng.integers(118, 151, size=n)
+    ql[::97] = 9          # a few odd ones: too short for the chained schedule / a bucket of its own
+    ts = rng.integers(0, len(genome) - 300, size=n)
+    reads = synth.illumina_reads(rng, genome, ts + rng.integers(0, 40, size=n), 150)
+    q_start = np.arange(n, dtype=np.int64) * 150
+    dev = torch.device("cuda", 0)
+    gb = device_batch.GroupedBatch(torch.from_numpy(genome).to(dev), torch.from_numpy(ts).to(dev), torch.from_numpy(tl).to(dev),
+                                   torch.from_numpy(reads.reshape(-1)).to(dev), torch.from_numpy(q_start).to(dev),
+                                   torch.from_numpy(ql).to(dev), cigar_stride=128)
+    assert gb.n % 8 == 0 and gb.n >= n
+    # the promise itself: every aligned block of eight slots has one geometry
+    assert (gb.t_len.view(-1, 8) == gb.t_len.view(-1, 8)[:, :1]).all() and (gb.q_len.view(-1, 8) == gb.q_len.view(-1, 8)[:, :1]).all()
+    gb.run(aligner)
+    torch.cuda.synchronize()
+    assert aligner.timing().packed16 == 1
+    assert int((gb.status != 0).sum()) == 0
+    slot = gb.first_slot.cpu().numpy()
+    assert (gb.order.cpu().numpy()[slot] == np.arange(n)).all()
+    off, sc = gb.offsets.cpu().numpy()[slot], gb.scores.cpu().numpy()[slot]
+    cg = gb.cigar_strings(slot.tolist())
+    tseqs = [genome[ts[k]:ts[k] + tl[k]].tobytes() for k in range(n)]
+    qseqs = [reads[k, :ql[k]].tobytes() for k in range(n)]
+    woff, wsc, wcg = ol.oracle_align_batch(tseqs, qseqs, (200, -150, 260, 11), ol.SOFTCLIP, nthreads=8)
+    assert (off == woff).all() and (sc == wsc).all() and cg == wcg
+    # duplicates (padding slots) carry the same answers as the pair they repeat
+    o = gb.order.cpu().numpy()
+    assert (gb.offsets.cpu().numpy() == off[o]).all() and (gb.scores.cpu().numpy() == sc[o]).all()
+
+
 def test_native_threads_through_the_coalescer():
     """GATK's calling pattern from native threads (tests/cpp/coalesce_bench.cpp): 48 threads, one pair per
     mgl_sw_align call, merged into device batches by the dispatcher; every answer equals the direct call's."""
