@@ -644,7 +644,7 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     if (n < 0 || !targets || !t_off || !queries || !q_off || !offset_out || !cigar_out || cigar_stride < 1 ||
         !strategy_ok(strategy))
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: bad argument");
-    int64_t lo_t = INT64_MAX, hi_t = 0, lo_q = INT64_MAX, hi_q = 0, cells = 0;
+    int64_t lo_t = INT64_MAX, hi_t = 0, lo_q = INT64_MAX, hi_q = 0, cells = 0, ungrouped = 0;
     for (int64_t k = 0; k < n; ++k) {   // branch-free so that it vectorises: 16 bytes of offsets per pair
         const int64_t tl = t_off[k + 1] - t_off[k], ql = q_off[k + 1] - q_off[k];
         lo_t = std::min(lo_t, tl);
@@ -652,12 +652,16 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
         lo_q = std::min(lo_q, ql);
         hi_q = std::max(hi_q, ql);
         cells += tl * ql;
+        // does every aligned block of eight pairs have one geometry (a batch sorted by read length)?
+        const int64_t kp = k > 0 ? k - 1 : 0;
+        const int64_t d = ((t_off[kp + 1] - t_off[kp]) ^ tl) | ((q_off[kp + 1] - q_off[kp]) ^ ql);
+        ungrouped |= (k & 7) != 0 ? d : 0;
     }
     // the reference reads out of bounds for empty sequences (sw.cpp:162-163,184): rejected here
     if (lo_t < 1 || lo_q < 1 || hi_t > 0x3fffffff || hi_q > 0x3fffffff)
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: sequence length < 1 or too large");
     const int max_tl = (int)hi_t, max_ql = (int)hi_q;
-    const bool uniform = lo_t == hi_t && lo_q == hi_q;
+    const bool uniform = (lo_t == hi_t && lo_q == hi_q) || ungrouped == 0; // one geometry per batch, or per block of eight
     const size_t t_bytes = (size_t)(t_off[n] - t_off[0]), q_bytes = (size_t)(q_off[n] - q_off[0]);
     if (t_off[0] != 0 || q_off[0] != 0)
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: offsets must start at 0");

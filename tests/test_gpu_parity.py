@@ -300,6 +300,11 @@ def test_grouped_geometry_variable_length_reads(aligner):
     qseqs = [reads[k, :ql[k]].tobytes() for k in range(n)]
     woff, wsc, wcg = ol.oracle_align_batch(tseqs, qseqs, (200, -150, 260, 11), ol.SOFTCLIP, nthreads=8)
     assert (off == woff).all() and (sc == wsc).all() and cg == wcg
+    # the host-buffer entry notices a batch that is sorted this way by itself
+    o_np = gb.order.cpu().numpy()
+    res = aligner.align_batch([tseqs[i] for i in o_np], [qseqs[i] for i in o_np], (200, -150, 260, 11), ol.SOFTCLIP, cigar_stride=128)
+    assert aligner.timing().packed16 == 1
+    assert (res.offsets == woff[o_np]).all() and (res.scores == wsc[o_np]).all() and list(res.cigars) == [wcg[i] for i in o_np]
     # duplicates (padding slots) carry the same answers as the pair they repeat
     o = gb.order.cpu().numpy()
     assert (gb.offsets.cpu().numpy() == off[o]).all() and (gb.scores.cpu().numpy() == sc[o]).all()
