@@ -70,7 +70,7 @@ struct Num<double> {
 
 template <typename T>
 struct Carry { // one column of a stripe's last row
-    T m, x, xy, pad;
+    T m, x, xy;
 };
 
 template <typename T>
@@ -130,7 +130,6 @@ __device__ __forceinline__ void ph_step4(Lane<T> &st, const Carry<T> (&cin)[4], 
         o[u].m = mn;
         o[u].x = xn;
         o[u].xy = xyn;
-        o[u].pad = (T)0;
         st.m = mn;
         st.x = xn;
         st.y = yn;
@@ -181,7 +180,7 @@ __device__ __forceinline__ void pairhmm_body(const PhArgs &a, unsigned char *sme
     const int sps8 = (h_max + G + 7) & ~7;     // steps per stripe: the last lane reaches column h_max at step h_max + G - 1
     const int lean_end8 = max(G, h_min & ~7);  // [G, lean_end8): no border, nobody past the last column
 
-    // LDS carve per group: ring[hap_cap + 2G + 16] carries (ring[j + G] = column j) | hap bytes (G zeros, hap, zeros)
+    // LDS carve per group: ring[hap_cap + 2G + 16] carries of 12 (float) / 24 (double) bytes (ring[j + G] = column j) | hap bytes (G zeros, hap, zeros)
     const int ring_entries = a.hap_cap + 2 * G + 16;
     const int hap_bytes = (a.hap_cap + 2 * G + 28 + 3) & ~3;
     const int group_bytes = ring_entries * (int)sizeof(Carry<T>) + hap_bytes;
@@ -207,7 +206,6 @@ __device__ __forceinline__ void pairhmm_body(const PhArgs &a, unsigned char *sme
             o.m = (T)0;
             o.x = (T)0;
             o.xy = y_initial;
-            o.pad = (T)0;
             ring[j + G] = o;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -330,7 +328,7 @@ int ph_lds_bytes(int hap_cap, int rows, int elem_bytes)
 {
     const int ring_entries = hap_cap + 2 * rows + 16;
     const int hap_bytes = (hap_cap + 2 * rows + 28 + 3) & ~3;
-    const int64_t b = (int64_t)(64 / rows) * ((int64_t)ring_entries * 4 * elem_bytes + hap_bytes);
+    const int64_t b = (int64_t)(64 / rows) * ((int64_t)ring_entries * 3 * elem_bytes + hap_bytes);
     return b > (1 << 30) ? (1 << 30) : (int)b;
 }
 
