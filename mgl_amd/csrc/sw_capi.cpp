@@ -174,7 +174,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const bool use16 = !d_matrix && uniform && ctx->precision != 32 && dp16_lds_bytes(sps_for(max_ql), 4) <= 64 * 1024 &&
                        dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
     // int32 kernel: 16 target rows per stripe (four pairs per wave) or 64 (one pair per wave, long reads)
-    int rows = use16 || d_matrix ? 16 : ctx->stripe_rows ? ctx->stripe_rows : (max_ql >= kRows64MinQuery ? 64 : 16);
+    int rows = use16 ? 16 : ctx->stripe_rows ? ctx->stripe_rows : (max_ql >= kRows64MinQuery ? 64 : 16);
+    // substitution-matrix mode: 16 rows x four pairs per wave while that carve fits LDS (queries up to ~800 residues;
+    // measured faster than one pair per wave at 300 residues: 1 006 vs 960 GCUPS), else 64 rows x one pair (to ~3 300)
+    if (d_matrix && !ctx->stripe_rows) rows = pick_waves_per_block(sps_for_rows(max_ql, 16), 16) == 0 ? 64 : 16;
     int sps_cap = sps_for_rows(max_ql, rows);
     int wpb = use16 ? 4 : pick_waves_per_block(sps_cap, rows);
     // long reads: one pair per WORKGROUP (sw_dp_coop_kernel), its waves pipelined over the 64-row stripes.  Taken
@@ -190,9 +193,9 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         wpb = coop_waves;
     }
     // queries too long for the LDS carve: carry ring and query copies in an HBM scratch area instead
-    while (d_matrix && wpb > 1 && dp_lds_bytes(sps_cap, wpb, 16) + 1024 > 64 * 1024) wpb >>= 1; // room for the matrix
-    if (d_matrix && (wpb == 0 || dp_lds_bytes(sps_cap, wpb, 16) + 1024 > 64 * 1024))
-        return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "substitution-matrix scoring: query too long for the LDS carve (about 800 residues)");
+    while (d_matrix && wpb > 1 && dp_lds_bytes(sps_cap, wpb, rows) + 1024 > 64 * 1024) wpb >>= 1; // room for the matrix
+    if (d_matrix && (wpb == 0 || dp_lds_bytes(sps_cap, wpb, rows) + 1024 > 64 * 1024))
+        return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "substitution-matrix scoring: query too long for the LDS carve (about 3 300 residues)");
     const bool use_scratch = !use16 && !coop_waves && !d_matrix && (wpb == 0 || ctx->carry_memory == 1);
     if (use_scratch) wpb = 4;
     if ((int64_t)max_tl * max_ql > (1ll << 34) || max_ql > (1 << 24) || max_tl > (1 << 24))

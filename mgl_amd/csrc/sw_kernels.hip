@@ -419,6 +419,15 @@ __global__ __launch_bounds__(256) void sw_dp_matrix_kernel(const DpArgs a)
     sw_dp_body<16, false, true>(a, smem, mat);
 }
 
+__global__ __launch_bounds__(256) void sw_dp64_matrix_kernel(const DpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    signed char *mat = reinterpret_cast<signed char *>(smem) + a.matrix_lds_offset;
+    for (int x = threadIdx.x; x < MATRIX_DIM * MATRIX_DIM; x += blockDim.x) mat[x] = a.matrix[x];
+    __syncthreads();
+    sw_dp_body<64, false, true>(a, smem, mat);
+}
+
 // long queries: the carry ring and the query copies do not fit LDS and live in an HBM scratch area
 __global__ __launch_bounds__(256) void sw_dp_scratch_kernel(const DpArgs a) { sw_dp_body<16, true>(a, nullptr); }
 
@@ -868,10 +877,13 @@ hipError_t launch_dp(const DpArgs &a, int waves_per_block, int rows, hipStream_t
     const int64_t blocks = (a.count + per_block - 1) / per_block;
     const dim3 grid((unsigned)blocks), block(64 * waves_per_block);
     if (a.matrix) {
-        // (the host layer only takes this path with rows == 16 and an LDS carve below 64 KB)
+        // (the host layer only takes this path with an LDS carve below 64 KB)
         DpArgs b = a;
-        b.matrix_lds_offset = dp_lds_bytes(a.sps_cap, waves_per_block, 16);
-        hipLaunchKernelGGL(sw_dp_matrix_kernel, grid, block, b.matrix_lds_offset + MATRIX_DIM * MATRIX_DIM, stream, b);
+        b.matrix_lds_offset = dp_lds_bytes(a.sps_cap, waves_per_block, rows);
+        if (rows == 64)
+            hipLaunchKernelGGL(sw_dp64_matrix_kernel, grid, block, b.matrix_lds_offset + MATRIX_DIM * MATRIX_DIM, stream, b);
+        else
+            hipLaunchKernelGGL(sw_dp_matrix_kernel, grid, block, b.matrix_lds_offset + MATRIX_DIM * MATRIX_DIM, stream, b);
         return hipGetLastError();
     }
     if (a.scratch) {

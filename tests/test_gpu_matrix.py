@@ -110,6 +110,14 @@ def test_blosum62_batches_bit_exact():
     ref = a.align_batch(ts, qs, (100, -75, 130, 6), ol.SOFTCLIP, cigar_stride=512)
     assert (b.offsets.cpu().numpy() == ref.offsets).all() and (b.scores.cpu().numpy() == ref.scores).all()
     assert b.cigar_strings() == list(ref.cigars)
+    # a 2 000-residue query takes the one-pair-per-wave variant of the matrix kernel
+    long_t = protein.random_proteins(rng, 1, 2500)[0]
+    long_q = np.concatenate([long_t[300:1500], protein.random_proteins(rng, 1, 800)[0]])
+    b = device_batch.from_host(*sw.concat([long_t.tobytes()] * 3), *sw.concat([long_q.tobytes()] * 3), "cuda:0", cigar_stride=8192)
+    protein.run_matrix(b, a, code, mat, 11, 1, ol.SOFTCLIP)
+    torch.cuda.synchronize()
+    off, sc, cg = oracle_matrix_batch([long_t.tobytes()] * 3, [long_q.tobytes()] * 3, code, mat, 11, 1, ol.SOFTCLIP, 8192)
+    assert (b.offsets.cpu().numpy() == off).all() and (b.scores.cpu().numpy() == sc).all() and b.cigar_strings() == cg
     # too long a query for the matrix kernel's LDS carve
     long_q = protein.random_proteins(rng, 1, 5000)[0].tobytes()
     b = device_batch.from_host(*sw.concat([long_q]), *sw.concat([long_q]), "cuda:0")
