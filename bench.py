@@ -161,6 +161,38 @@ def file_batch(args, dev):
     return b, label
 
 
+def secondary_workloads():
+    """The other workloads of BASELINE.json / SURVEY.md 8f, each run once as its own short script after the timed
+    region (never part of `value`); failures are reported, not raised."""
+    import re
+    import subprocess
+
+    out = {}
+    runs = {
+        "long_reads_10kb (configs[3] shape, 256 pairs)": ["scripts/long_read_bench.py", "256", "32", "10000", "1"],
+        "pairhmm_150x300 (SURVEY 8f rank 3, 1.6 M pairs)": ["scripts/pairhmm_bench.py", "--steps", "3", "--cpu-seconds", "3"],
+        "protein_blosum62 (configs[4] shape, 2 M alignments, no reference path)": ["scripts/protein_bench.py", "--steps", "2", "--check", "50"],
+    }
+    for name, cmd in runs.items():
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, cmd[0])] + cmd[1:], capture_output=True, text=True, timeout=240)
+            m = re.search(r"= ([0-9.]+) GCUPS", r.stdout)
+            if r.returncode == 0 and m:
+                out[name] = {"gcups": float(m.group(1)), "checked": ("identical" in r.stdout) or None}
+                d = re.search(r"max \|log10 difference\| vs GPU: ([0-9.e+-]+)", r.stdout)
+                c = re.search(r"CPU baseline[^:]*: .* = ([0-9.]+) GCUPS", r.stdout)
+                if d:
+                    out[name]["max_abs_log10_diff_vs_cpu"] = float(d.group(1))
+                    out[name]["checked"] = float(d.group(1)) < 1e-5
+                if c:
+                    out[name]["cpu_gcups"] = float(c.group(1))
+            else:
+                out[name] = {"error": (r.stderr or r.stdout)[-200:]}
+        except Exception as e:  # noqa: BLE001 -- a secondary line must never take the headline down
+            out[name] = {"error": repr(e)[:200]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +203,7 @@ def main():
     ap.add_argument("--ql", type=int, default=150, help="read length")
     ap.add_argument("--workspace-gib", type=float, default=8.0, help="traceback workspace per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline leg")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (long reads, PairHMM, protein)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--input", choices=("ascii", "2bit"), default="ascii",
                     help="ascii: concatenated bytes (the reference's ByteBuffer contract); 2bit: one 2-bit packed "
@@ -290,6 +323,11 @@ def main():
         if ascii_twin is not batch:  # the CPU leg reads ASCII bases and compares with the GPU's result arrays
             ascii_twin.offsets, ascii_twin.cigars = batch.offsets, batch.cigars
         out["cpu_baseline"] = cpu_baseline(ascii_twin)
+    if world == 1 and not args.no_cpu and not args.no_secondary and args.dataset == "synthetic":
+        del batch, ascii_twin
+        aligner.close()
+        torch.cuda.empty_cache()
+        out["secondary"] = secondary_workloads()
     print(json.dumps(out), flush=True)
     if distributed:
         torch.distributed.destroy_process_group()
