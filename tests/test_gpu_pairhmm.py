@@ -102,6 +102,28 @@ def test_regions_against_restatement(hmm, use_double, rows):
     hmm.set_stripe_rows(0)
 
 
+def test_quality_bytes_are_masked_like_the_reference(hmm):
+    """compute_prob_scalar.cc:68-86 masks every quality byte with 127: bytes with the top bit set, and qualities of 0,
+    behave accordingly (raw bytes 0..255 in all four tracks)."""
+    rng = np.random.default_rng(21)
+    hmm.initialize(None)
+    hap = bytes(rng.choice(list(b"ACGT"), size=90).astype(np.uint8))
+    reads = []
+    for _ in range(40):
+        n = int(rng.integers(1, 80))
+        s = int(rng.integers(0, 90 - n + 1))
+        q, i, d, c = (rng.integers(0, 256, size=n).astype(np.uint8).tobytes() for _ in range(4))
+        reads.append(pairhmm.ReadDataHolder(hap[s:s + n], q, i, d, c))
+    got = np.zeros(len(reads))
+    hmm.computeLikelihoods(reads, [pairhmm.HaplotypeDataHolder(hap)], got)
+    for k, r in enumerate(reads):
+        want, used = pol.log10_likelihood(hap, r.readBases, r.readQuals, r.insertionGOP, r.deletionGOP, r.overallGCP)
+        masked, _ = pol.log10_likelihood(hap, r.readBases, *(bytes(b & 127 for b in t) for t in
+                                                             (r.readQuals, r.insertionGOP, r.deletionGOP, r.overallGCP)))
+        assert want == masked
+        assert abs(got[k] - want) < (1e-9 * max(1.0, abs(want)) if used else 1e-5), (k, got[k], want)
+
+
 def test_pair_list_and_errors(hmm):
     hmm.initialize(None)
     rng = np.random.default_rng(3)
