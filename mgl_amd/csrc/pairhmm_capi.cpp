@@ -169,16 +169,17 @@ int run_device(mgl_pairhmm_ctx *ctx, hipStream_t stream, int64_t n_pairs, const 
     }
     if (ph_lds_bytes(max_hap_len, rows, 4) > 160 * 1024) rows = 64; // four rings would not fit LDS at all
     const int rows_d = ph_lds_bytes(max_hap_len, 16, 8) <= 160 * 1024 && rows == 16 ? 16 : 64;
+    const int rows_per_lane = std::min(4, (max_read_len + 63) / 64);
     const bool prof = ctx->profiling != 0;
     ctx->ev_valid = false;
     ctx->ran_float = !ctx->use_double;
     if (!ctx->use_double) {
         if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
-        HIP_TRY(ctx, launch_pairhmm_float(a, rows, stream));
+        HIP_TRY(ctx, launch_pairhmm_float(a, rows, rows_per_lane, stream));
         if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
     }
     if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
-    HIP_TRY(ctx, launch_pairhmm_double(a, rows_d, stream));
+    HIP_TRY(ctx, launch_pairhmm_double(a, rows_d, rows_per_lane, stream));
     if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
     ctx->ev_valid = prof;
     return MGL_PAIRHMM_OK;

@@ -29,8 +29,8 @@ struct PhArgs {
 
 // rows = read rows per stripe = lanes per pair: 16 (four pairs per wave) or 64 (one pair per wave)
 int ph_lds_bytes(int hap_cap, int rows, int elem_bytes);
-hipError_t launch_pairhmm_float(const PhArgs &a, int rows, hipStream_t stream);
-hipError_t launch_pairhmm_double(const PhArgs &a, int rows, hipStream_t stream);
+hipError_t launch_pairhmm_float(const PhArgs &a, int rows, int rows_per_lane, hipStream_t stream);
+hipError_t launch_pairhmm_double(const PhArgs &a, int rows, int rows_per_lane, hipStream_t stream);
 
 } // namespace mgl_ph_dev
 #endif

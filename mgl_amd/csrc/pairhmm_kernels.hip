@@ -301,6 +301,247 @@ __device__ __forceinline__ void pairhmm_body(const PhArgs &a, unsigned char *sme
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One pair per wave, K consecutive read rows per lane (K = ceil(rows / 64), up to 4).  A lane computes its K cells of
+// the current column one after the other -- row j+1 takes "up" from the value row j has just produced and "diagonal"
+// from the value row j held before this step -- so only the lane's LAST row is shifted to the next lane: three DPP
+// moves per K cells instead of per cell, a K times shorter carry ring, and a read of up to 256 bases in a single
+// stripe.  The rows are numbered so that the pair's last row is always the last row of its lane: p = (K - R mod K) mod K
+// virtual rows are put in front, set up to reproduce row 0 (M = X = 0, Y = INITIAL / haplen, prior 0).
+template <typename T, int K>
+struct LaneK {
+    T m[K], x[K], y[K], xy[K]; // this lane's cells of the previous step: (row j, c-1)
+    T dm, dxy;                 // (row above the lane's first row, c-1)
+    T acc;
+};
+
+template <typename T, int K>
+struct RowConstK {
+    T pMM[K], pGapM[K], pMX[K], pMY[K], pZZ[K], prior_match[K], prior_mismatch[K], border_y[K];
+    int rs[K];
+};
+
+template <typename T, int K, bool PRO, bool EPI, bool HAP_N, bool ACC>
+__device__ __forceinline__ void phk_step4(LaneK<T, K> &st, const Carry<T> (&cin)[4], Carry<T> (&nxt)[4], const Carry<T> *ring_next,
+                                          Carry<T> *ring_wr, const unsigned hw, const RowConstK<T, K> &rc, const int s0, const int L,
+                                          const int hap_len, const bool writer)
+{
+    if (L == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nxt[u] = ring_next[u];
+    }
+    Carry<T> o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const T um = shift_in<64>(cin[u].m, st.m[K - 1]);
+        const T ux = shift_in<64>(cin[u].x, st.x[K - 1]);
+        const T uxy = shift_in<64>(cin[u].xy, st.xy[K - 1]);
+        const int hb = (int)((hw >> (8 * u)) & 0xffu);
+        const int c = s0 + u - L; // this lane's column
+        const bool border = PRO && c <= 0;
+        T up_m = um, up_x = ux, dg_m = st.dm, dg_xy = st.dxy;
+        T nm[K], nx[K], ny[K], nxy[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const bool match = HAP_N ? ((hb == rc.rs[j]) | (hb == 'N')) : (hb == rc.rs[j]);
+            const T prior = match ? rc.prior_match[j] : rc.prior_mismatch[j];
+            T mn = prior * (dg_m * rc.pMM[j] + dg_xy * rc.pGapM[j]);
+            T yn = st.m[j] * rc.pMY[j] + st.y[j] * rc.pZZ[j];
+            T xn = up_m * rc.pMX[j] + up_x * rc.pZZ[j];
+            if (PRO) {
+                mn = border ? (T)0 : mn;
+                yn = border ? rc.border_y[j] : yn; // 0, or row 0's Y for the virtual rows in front
+                xn = border ? (T)0 : xn;
+            }
+            dg_m = st.m[j]; // what row j held before this step is the diagonal of row j + 1
+            dg_xy = st.xy[j];
+            up_m = mn;
+            up_x = xn;
+            nm[j] = mn;
+            nx[j] = xn;
+            ny[j] = yn;
+            nxy[j] = xn + yn;
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            st.m[j] = nm[j];
+            st.x[j] = nx[j];
+            st.y[j] = ny[j];
+            st.xy[j] = nxy[j];
+        }
+        st.dm = um;
+        st.dxy = uxy;
+        if (ACC) {
+            if (EPI)
+                st.acc = c <= hap_len ? st.acc + (nm[K - 1] + nx[K - 1]) : st.acc;
+            else
+                st.acc = st.acc + (nm[K - 1] + nx[K - 1]);
+        }
+        o[u].m = nm[K - 1];
+        o[u].x = nx[K - 1];
+        o[u].xy = nxy[K - 1];
+    }
+    if (writer) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ring_wr[u] = o[u];
+    }
+}
+
+template <typename T, int K, bool RESCUE>
+__device__ __forceinline__ void pairhmm_body_k(const PhArgs &a, unsigned char *smem, const int64_t p, const int R, const int H,
+                                               const uint8_t *rbase, const int64_t h0)
+{
+    constexpr int G = 64;
+    const int L = threadIdx.x & 63;
+    const int pad = (K - R % K) % K;         // virtual rows in front
+    const int rows_v = R + pad;              // a multiple of K
+    const int nstripes = (rows_v + G * K - 1) / (G * K);
+    const int sps8 = (H + G + 7) & ~7;
+    const int lean_end8 = max(G, H & ~7);
+
+    const int ring_entries = a.hap_cap + 2 * G + 16;
+    const int hap_bytes = (a.hap_cap + 2 * G + 28 + 3) & ~3;
+    Carry<T> *ring = reinterpret_cast<Carry<T> *>(smem);
+    unsigned char *hbuf = smem + ring_entries * sizeof(Carry<T>);
+
+    const T y_initial = Num<T>::initial() / (T)H; // :101
+    bool hap_has_n = false;
+    {
+        unsigned *hz = reinterpret_cast<unsigned *>(hbuf);
+        for (int w = L; w < (hap_bytes >> 2); w += G) hz[w] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int x = L; x < H; x += G) {
+            const uint8_t ch = a.haps[h0 + x];
+            hap_has_n |= ch == 'N';
+            hbuf[G + x] = ch;
+        }
+        for (int j = L; j < ring_entries - G; j += G) { // row 0 (:126-136)
+            Carry<T> o;
+            o.m = (T)0;
+            o.x = (T)0;
+            o.xy = y_initial;
+            ring[j + G] = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const bool any_n = __builtin_amdgcn_ballot_w64(hap_has_n) != 0;
+    const T *ph2pr = Num<T>::ph2pr(a);
+    const T *m2m = Num<T>::m2m(a);
+    const T three_over = (T)1.0 / (T)3.0; // :18
+    const int last_lane = ((rows_v / K) - 1) % G; // the lane whose last row is read row R (in the last stripe)
+    const int q_shift = (G - 1 - L) & 3;
+    const unsigned *hrd0 = reinterpret_cast<const unsigned *>(hbuf) + ((G - 1 - L) >> 2);
+
+    LaneK<T, K> st;
+    T result = (T)0;
+    for (int k = 0; k < nstripes; ++k) {
+        RowConstK<T, K> rc;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int row = (k * G + L) * K + j + 1 - pad; // read row, 1-based; <= 0: virtual row in front
+            if (row >= 1 && row <= R) {
+                const int q = rbase[row - 1 + R] & 127, qi = rbase[row - 1 + 2 * R] & 127, qd = rbase[row - 1 + 3 * R] & 127,
+                          qc = rbase[row - 1 + 4 * R] & 127;
+                const int mx = max(qi, qd), mn = min(qi, qd);
+                rc.pMM[j] = m2m[((mx * (mx + 1)) >> 1) + mn];
+                rc.pGapM[j] = (T)1.0 - ph2pr[qc];
+                rc.pMX[j] = ph2pr[qi];
+                rc.pMY[j] = ph2pr[qd];
+                rc.pZZ[j] = ph2pr[qc];
+                const T distm = ph2pr[q];
+                rc.rs[j] = rbase[row - 1];
+                rc.prior_match[j] = (T)1.0 - distm;
+                rc.prior_mismatch[j] = rc.rs[j] == 'N' ? rc.prior_match[j] : distm * three_over;
+                rc.border_y[j] = (T)0;
+            } else {
+                // rows past R compute nothing that is used; virtual rows in front repeat row 0: M = X = 0, Y constant
+                rc.pMM[j] = rc.pGapM[j] = rc.pMX[j] = rc.pMY[j] = rc.prior_match[j] = rc.prior_mismatch[j] = (T)0;
+                rc.pZZ[j] = row <= 0 ? (T)1 : (T)0;
+                rc.border_y[j] = row <= 0 ? y_initial : (T)0;
+                rc.rs[j] = 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) st.m[j] = st.x[j] = st.y[j] = st.xy[j] = (T)0;
+        st.dm = st.dxy = (T)0;
+        st.acc = (T)0;
+        const bool last = (k == nstripes - 1);
+        const int wl = last ? last_lane : G - 1;
+        const bool writer = (L == wl);
+        const Carry<T> *ring_rd = ring + G;
+        Carry<T> *ring_wr = ring + G - wl;
+        Carry<T> ca[4] = {ring_rd[0], ring_rd[1], ring_rd[2], ring_rd[3]}, cb[4] = {ca[0], ca[1], ca[2], ca[3]};
+        const unsigned *hrd = hrd0;
+        unsigned h_lo = hrd[0], h_hi = hrd[1];
+        int s = 0;
+#define MGL_PHK_BLOCK(PRO, EPI, HAP_N, ACC, CUR, NXT)                                                    \
+    {                                                                                                    \
+        const unsigned hw = __builtin_amdgcn_alignbyte(h_hi, h_lo, (unsigned)q_shift);                   \
+        h_lo = h_hi;                                                                                     \
+        h_hi = hrd[2];                                                                                   \
+        phk_step4<T, K, PRO, EPI, HAP_N, ACC>(st, CUR, NXT, ring_rd + 4, ring_wr, hw, rc, s, L, H, writer); \
+        ring_rd += 4;                                                                                    \
+        ring_wr += 4;                                                                                    \
+        hrd += 1;                                                                                        \
+        s += 4;                                                                                          \
+    }
+#define MGL_PHK_PAIR(PRO, EPI, HAP_N, ACC) { MGL_PHK_BLOCK(PRO, EPI, HAP_N, ACC, ca, cb) MGL_PHK_BLOCK(PRO, EPI, HAP_N, ACC, cb, ca) }
+#define MGL_PHK_STRIPE(HAP_N, ACC)                                                                       \
+    {                                                                                                    \
+        for (; s < G;) MGL_PHK_PAIR(true, true, HAP_N, ACC)                                              \
+        for (; s < lean_end8;) MGL_PHK_PAIR(false, false, HAP_N, ACC)                                    \
+        for (; s < sps8;) MGL_PHK_PAIR(false, true, HAP_N, ACC)                                          \
+    }
+        if (any_n) {
+            if (last) MGL_PHK_STRIPE(true, true) else MGL_PHK_STRIPE(true, false)
+        } else {
+            if (last) MGL_PHK_STRIPE(false, true) else MGL_PHK_STRIPE(false, false)
+        }
+#undef MGL_PHK_STRIPE
+#undef MGL_PHK_PAIR
+#undef MGL_PHK_BLOCK
+        if (last) result = st.acc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (L == last_lane) {
+        const double rd = (double)result;
+        if (!RESCUE) {
+            const bool small = rd < MIN_ACCEPTED; // …PairHmm.cc:179-195
+            a.need_double[p] = small ? 1 : 0;
+            if (!small) a.out[p] = log10(rd) - Num<T>::log10_initial(a);
+        } else if (!a.rescue_only || a.need_double[p] != 0) {
+            a.out[p] = log10(rd) - Num<T>::log10_initial(a); // :203-209
+        }
+    }
+}
+
+// one pair per wave: picks the rows-per-lane variant for this pair's read length
+template <typename T, bool RESCUE, int KMAX>
+__device__ __forceinline__ void pairhmm_wave(const PhArgs &a, unsigned char *smem)
+{
+    const int64_t slot = (int64_t)blockIdx.x;
+    if (slot >= a.n_pairs) return;
+    if (RESCUE && a.rescue_only && a.need_double[slot] == 0) return;
+    const int32_t ri = a.pair_read[slot], hi = a.pair_hap[slot];
+    const int64_t r0 = a.read_off[ri], h0 = a.hap_off[hi];
+    const int R = __builtin_amdgcn_readfirstlane((int)(a.read_off[ri + 1] - r0));
+    const int H = __builtin_amdgcn_readfirstlane((int)(a.hap_off[hi + 1] - h0));
+    const uint8_t *rbase = a.reads + 5 * r0;
+    // (the kernel is compiled per KMAX so that batches of short reads do not pay the registers of the 4-row variant)
+    const int k = min(KMAX, (R + 63) >> 6);
+    if (KMAX == 1 || k <= 1)
+        pairhmm_body_k<T, 1, RESCUE>(a, smem, slot, R, H, rbase, h0);
+    else if (KMAX == 2 || k == 2)
+        pairhmm_body_k<T, 2, RESCUE>(a, smem, slot, R, H, rbase, h0);
+    else if (KMAX == 3 || k == 3)
+        pairhmm_body_k<T, 3, RESCUE>(a, smem, slot, R, H, rbase, h0);
+    else
+        pairhmm_body_k<T, 4, RESCUE>(a, smem, slot, R, H, rbase, h0);
+}
+
 } // namespace
 
 __global__ __launch_bounds__(64) void pairhmm_float_kernel(const PhArgs a)
@@ -308,20 +549,22 @@ __global__ __launch_bounds__(64) void pairhmm_float_kernel(const PhArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     pairhmm_body<float, 16, false>(a, smem);
 }
+template <int KMAX>
 __global__ __launch_bounds__(64) void pairhmm_float64_kernel(const PhArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    pairhmm_body<float, 64, false>(a, smem);
+    pairhmm_wave<float, false, KMAX>(a, smem);
 }
 __global__ __launch_bounds__(64) void pairhmm_double_kernel(const PhArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     pairhmm_body<double, 16, true>(a, smem);
 }
+template <int KMAX>
 __global__ __launch_bounds__(64) void pairhmm_double64_kernel(const PhArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    pairhmm_body<double, 64, true>(a, smem);
+    pairhmm_wave<double, true, KMAX>(a, smem);
 }
 
 int ph_lds_bytes(int hap_cap, int rows, int elem_bytes)
@@ -347,18 +590,29 @@ static hipError_t launch(K kernel, const PhArgs &a, int rows, int elem_bytes, hi
     return hipGetLastError();
 }
 
-hipError_t launch_pairhmm_float(const PhArgs &a, int rows, hipStream_t stream)
+// rows_per_lane: read rows per lane of the one-pair-per-wave kernels = min(4, ceil(longest read / 64))
+hipError_t launch_pairhmm_float(const PhArgs &a, int rows, int rows_per_lane, hipStream_t stream)
 {
-    static int configured[2] = {0, 0};
-    return rows == 64 ? launch(pairhmm_float64_kernel, a, 64, 4, stream, configured[1])
-                      : launch(pairhmm_float_kernel, a, 16, 4, stream, configured[0]);
+    static int configured[5] = {0, 0, 0, 0, 0};
+    if (rows != 64) return launch(pairhmm_float_kernel, a, 16, 4, stream, configured[0]);
+    switch (rows_per_lane) {
+    case 1: return launch(pairhmm_float64_kernel<1>, a, 64, 4, stream, configured[1]);
+    case 2: return launch(pairhmm_float64_kernel<2>, a, 64, 4, stream, configured[2]);
+    case 3: return launch(pairhmm_float64_kernel<3>, a, 64, 4, stream, configured[3]);
+    default: return launch(pairhmm_float64_kernel<4>, a, 64, 4, stream, configured[4]);
+    }
 }
 
-hipError_t launch_pairhmm_double(const PhArgs &a, int rows, hipStream_t stream)
+hipError_t launch_pairhmm_double(const PhArgs &a, int rows, int rows_per_lane, hipStream_t stream)
 {
-    static int configured[2] = {0, 0};
-    return rows == 64 ? launch(pairhmm_double64_kernel, a, 64, 8, stream, configured[1])
-                      : launch(pairhmm_double_kernel, a, 16, 8, stream, configured[0]);
+    static int configured[5] = {0, 0, 0, 0, 0};
+    if (rows != 64) return launch(pairhmm_double_kernel, a, 16, 8, stream, configured[0]);
+    switch (rows_per_lane) {
+    case 1: return launch(pairhmm_double64_kernel<1>, a, 64, 8, stream, configured[1]);
+    case 2: return launch(pairhmm_double64_kernel<2>, a, 64, 8, stream, configured[2]);
+    case 3: return launch(pairhmm_double64_kernel<3>, a, 64, 8, stream, configured[3]);
+    default: return launch(pairhmm_double64_kernel<4>, a, 64, 8, stream, configured[4]);
+    }
 }
 
 } // namespace mgl_ph_dev
