@@ -576,13 +576,12 @@ int ph_lds_bytes(int hap_cap, int rows, int elem_bytes)
 }
 
 template <typename K>
-static hipError_t launch(K kernel, const PhArgs &a, int rows, int elem_bytes, hipStream_t stream, int &configured)
+static hipError_t launch(K kernel, const PhArgs &a, int rows, int elem_bytes, hipStream_t stream)
 {
     const int lds = ph_lds_bytes(a.hap_cap, rows, elem_bytes);
-    if (lds > 64 * 1024 && lds > configured) {
+    if (lds > 64 * 1024) { // per device and rare (haplotypes beyond ~1 300 bases): set every time, no cache to go stale
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        configured = lds;
     }
     const int per_wave = 64 / rows;
     const int64_t blocks = (a.n_pairs + per_wave - 1) / per_wave; // one wave per block: the LDS carve, not the wave count, limits a CU
@@ -593,25 +592,23 @@ static hipError_t launch(K kernel, const PhArgs &a, int rows, int elem_bytes, hi
 // rows_per_lane: read rows per lane of the one-pair-per-wave kernels = min(4, ceil(longest read / 64))
 hipError_t launch_pairhmm_float(const PhArgs &a, int rows, int rows_per_lane, hipStream_t stream)
 {
-    static int configured[5] = {0, 0, 0, 0, 0};
-    if (rows != 64) return launch(pairhmm_float_kernel, a, 16, 4, stream, configured[0]);
+    if (rows != 64) return launch(pairhmm_float_kernel, a, 16, 4, stream);
     switch (rows_per_lane) {
-    case 1: return launch(pairhmm_float64_kernel<1>, a, 64, 4, stream, configured[1]);
-    case 2: return launch(pairhmm_float64_kernel<2>, a, 64, 4, stream, configured[2]);
-    case 3: return launch(pairhmm_float64_kernel<3>, a, 64, 4, stream, configured[3]);
-    default: return launch(pairhmm_float64_kernel<4>, a, 64, 4, stream, configured[4]);
+    case 1: return launch(pairhmm_float64_kernel<1>, a, 64, 4, stream);
+    case 2: return launch(pairhmm_float64_kernel<2>, a, 64, 4, stream);
+    case 3: return launch(pairhmm_float64_kernel<3>, a, 64, 4, stream);
+    default: return launch(pairhmm_float64_kernel<4>, a, 64, 4, stream);
     }
 }
 
 hipError_t launch_pairhmm_double(const PhArgs &a, int rows, int rows_per_lane, hipStream_t stream)
 {
-    static int configured[5] = {0, 0, 0, 0, 0};
-    if (rows != 64) return launch(pairhmm_double_kernel, a, 16, 8, stream, configured[0]);
+    if (rows != 64) return launch(pairhmm_double_kernel, a, 16, 8, stream);
     switch (rows_per_lane) {
-    case 1: return launch(pairhmm_double64_kernel<1>, a, 64, 8, stream, configured[1]);
-    case 2: return launch(pairhmm_double64_kernel<2>, a, 64, 8, stream, configured[2]);
-    case 3: return launch(pairhmm_double64_kernel<3>, a, 64, 8, stream, configured[3]);
-    default: return launch(pairhmm_double64_kernel<4>, a, 64, 8, stream, configured[4]);
+    case 1: return launch(pairhmm_double64_kernel<1>, a, 64, 8, stream);
+    case 2: return launch(pairhmm_double64_kernel<2>, a, 64, 8, stream);
+    case 3: return launch(pairhmm_double64_kernel<3>, a, 64, 8, stream);
+    default: return launch(pairhmm_double64_kernel<4>, a, 64, 8, stream);
     }
 }
 

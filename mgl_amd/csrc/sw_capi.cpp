@@ -61,6 +61,9 @@ struct mgl_sw_ctx {
     void *pin_in = nullptr, *pin_out = nullptr;
     size_t pin_in_cap = 0, pin_out_cap = 0;
     DevBuf stage_in, stage_out;
+    // substitution matrix + code table: copied here first, so the caller's buffers may go away when the call returns
+    void *pin_matrix = nullptr;
+    hipEvent_t matrix_copied = nullptr;
     int carry_memory = 0; // 0 = LDS when it fits, 1 = always the HBM scratch (tests)
     int stripe_rows = 0;  // 0 = choose per batch, 16 / 64 = force (tests)
     int cooperative = 0;  // 0 = choose per batch, 1 = never, 2..16 = always, that many waves per pair (tests)
@@ -443,6 +446,8 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     for (auto *set : {ctx->fill_done, ctx->tb_done})
         for (int h = 0; h < 2; ++h)
             if (set[h]) (void)hipEventDestroy(set[h]);
+    if (ctx->pin_matrix) (void)hipHostFree(ctx->pin_matrix);
+    if (ctx->matrix_copied) (void)hipEventDestroy(ctx->matrix_copied);
     if (ctx->pin_in) (void)hipHostFree(ctx->pin_in);
     if (ctx->pin_out) (void)hipHostFree(ctx->pin_out);
     ctx->stage_in.release();
@@ -589,9 +594,16 @@ int mgl_sw_align_batch_device_matrix(mgl_sw_ctx *ctx, void *stream, int64_t n, c
     hipStream_t st = static_cast<hipStream_t>(stream);
     int8_t *dm = static_cast<int8_t *>(ctx->d_matrix.p);
     uint8_t *dc = reinterpret_cast<uint8_t *>(dm) + MATRIX_DIM * MATRIX_DIM;
-    // (pageable host memory: these two small copies complete before the call returns)
-    HIP_TRY(ctx, hipMemcpyAsync(dm, matrix, MATRIX_DIM * MATRIX_DIM, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(dc, code, 256, hipMemcpyHostToDevice, st));
+    if (!ctx->pin_matrix) {
+        HIP_TRY(ctx, hipHostMalloc(&ctx->pin_matrix, MATRIX_DIM * MATRIX_DIM + 256, hipHostMallocDefault));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->matrix_copied, hipEventDisableTiming));
+    } else {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->matrix_copied)); // the previous call's copy has left the staging buffer
+    }
+    memcpy(ctx->pin_matrix, matrix, MATRIX_DIM * MATRIX_DIM);
+    memcpy(static_cast<char *>(ctx->pin_matrix) + MATRIX_DIM * MATRIX_DIM, code, 256);
+    HIP_TRY(ctx, hipMemcpyAsync(dm, ctx->pin_matrix, MATRIX_DIM * MATRIX_DIM + 256, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipEventRecord(ctx->matrix_copied, st));
     // with length arrays the offsets are per-pair START positions (a database sequence may serve many pairs)
     const SeqSet ts{d_targets, d_t_off, d_t_len, max_tl, 0}, qs{d_queries, d_q_off, d_q_len, max_ql, 0};
     return run_device(ctx, st, n, ts, qs, max_tl, max_ql, 1, -1, gopen, gext, strategy, d_offset_out,

@@ -565,12 +565,10 @@ hipError_t launch_dp16(const DpArgs &a, int waves_per_block, hipStream_t stream)
     const int64_t blocks = (a.count + per_block - 1) / per_block;
     int lds = dp16_lds_bytes(sps_for(a.uni_ql), waves_per_block);
     if (const char *e = getenv("MGL_SW_EXTRA_LDS")) lds += atoi(e); // occupancy experiments only
-    static int configured_lds = 0;
-    if (lds > 64 * 1024 && lds > configured_lds) {
+    if (lds > 64 * 1024) { // per device and rare (long queries): set every time rather than cache across devices / threads
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_dp16_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        configured_lds = lds;
     }
     hipLaunchKernelGGL(sw_dp16_kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), lds, stream, a);
     return hipGetLastError();

@@ -407,12 +407,10 @@ int coop_lds_bytes(int sps_cap, int waves_per_block)
 hipError_t launch_dp_coop(const DpArgs &a, int waves_per_block, hipStream_t stream)
 {
     const int lds = coop_lds_bytes(a.sps_cap, waves_per_block);
-    static int configured_lds = 0;
-    if (lds > 64 * 1024 && lds > configured_lds) {
+    if (lds > 64 * 1024) { // per device and rare: set every time rather than cache across devices / threads
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_dp_coop_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        configured_lds = lds;
     }
     hipLaunchKernelGGL(sw_dp_coop_kernel, dim3((unsigned)a.count), dim3(64 * waves_per_block), lds, stream, a);
     return hipGetLastError();

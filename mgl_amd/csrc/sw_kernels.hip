@@ -894,14 +894,11 @@ hipError_t launch_dp(const DpArgs &a, int waves_per_block, int rows, hipStream_t
         return hipGetLastError();
     }
     const int lds = dp_lds_bytes(a.sps_cap, waves_per_block, rows);
-    static int configured_lds[2] = {0, 0};
-    int &conf = configured_lds[rows == 64];
-    if (lds > 64 * 1024 && lds > conf) {
+    if (lds > 64 * 1024) { // per device and rare: set every time rather than cache across devices / threads
         hipError_t e = hipFuncSetAttribute(rows == 64 ? reinterpret_cast<const void *>(sw_dp64_kernel)
                                                       : reinterpret_cast<const void *>(sw_dp_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        conf = lds;
     }
     if (rows == 64)
         hipLaunchKernelGGL(sw_dp64_kernel, grid, block, lds, stream, a);
