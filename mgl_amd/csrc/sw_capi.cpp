@@ -167,22 +167,27 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         max_tl < 1 || max_ql < 1 || !strategy_ok(strategy))
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch_device: bad argument");
     if (d_matrix) {
-        // substitution-matrix scoring: match / mismatch are unused, the gap penalties keep the sign convention
-        match = 1;
-        mismatch = -1;
+        // substitution-matrix scoring: `match` / `mismatch` carry the largest / smallest matrix entry (range check and
+        // offset representation of the packed kernel); only the gap penalties go through the sign normalisation
+        int m1 = 1, m2 = -1;
+        mgl_sw_normalize_params(&m1, &m2, &gopen, &gext);
+    } else {
+        mgl_sw_normalize_params(&match, &mismatch, &gopen, &gext);
     }
-    mgl_sw_normalize_params(&match, &mismatch, &gopen, &gext);
 
-    // packed-int16 kernel: one geometry for the whole batch and a score range that fits 16 bits
-    const bool use16 = !d_matrix && uniform && ctx->precision != 32 && dp16_lds_bytes(sps_for(max_ql), 4) <= 64 * 1024 &&
-                       dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
-    // int32 kernel: 16 target rows per stripe (four pairs per wave) or 64 (one pair per wave, long reads)
+    // packed-int16 kernel: one geometry per batch (or per block of eight pairs) and a score range that fits 16 bits;
+    // four waves per block while their LDS carve fits, else two or one
+    const int lds_extra = d_matrix ? MATRIX_DIM * MATRIX_DIM * 2 : 0;
+    int wpb16 = 4;
+    while (wpb16 > 1 && dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra > 64 * 1024) wpb16 >>= 1;
+    const bool use16 = uniform && ctx->precision != 32 && dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra <= 64 * 1024 &&
+                       match > 0 && dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
     int rows = use16 ? 16 : ctx->stripe_rows ? ctx->stripe_rows : (max_ql >= kRows64MinQuery ? 64 : 16);
     // substitution-matrix mode: 16 rows x four pairs per wave while that carve fits LDS (queries up to ~800 residues;
     // measured faster than one pair per wave at 300 residues: 1 006 vs 960 GCUPS), else 64 rows x one pair (to ~3 300)
-    if (d_matrix && !ctx->stripe_rows) rows = pick_waves_per_block(sps_for_rows(max_ql, 16), 16) == 0 ? 64 : 16;
+    if (d_matrix && !use16 && !ctx->stripe_rows) rows = pick_waves_per_block(sps_for_rows(max_ql, 16), 16) == 0 ? 64 : 16;
     int sps_cap = sps_for_rows(max_ql, rows);
-    int wpb = use16 ? 4 : pick_waves_per_block(sps_cap, rows);
+    int wpb = use16 ? wpb16 : pick_waves_per_block(sps_cap, rows);
     // long reads: one pair per WORKGROUP (sw_dp_coop_kernel), its waves pipelined over the 64-row stripes.  Taken
     // when the one-wave-per-pair carve does not fit LDS, or when forced; needs at least two stripes to share.
     int coop_waves = 0;
@@ -196,8 +201,8 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         wpb = coop_waves;
     }
     // queries too long for the LDS carve: carry ring and query copies in an HBM scratch area instead
-    while (d_matrix && wpb > 1 && dp_lds_bytes(sps_cap, wpb, rows) + 1024 > 64 * 1024) wpb >>= 1; // room for the matrix
-    if (d_matrix && (wpb == 0 || dp_lds_bytes(sps_cap, wpb, rows) + 1024 > 64 * 1024))
+    while (d_matrix && !use16 && wpb > 1 && dp_lds_bytes(sps_cap, wpb, rows) + 1024 > 64 * 1024) wpb >>= 1; // room for the matrix
+    if (d_matrix && !use16 && (wpb == 0 || dp_lds_bytes(sps_cap, wpb, rows) + 1024 > 64 * 1024))
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "substitution-matrix scoring: query too long for the LDS carve (about 3 300 residues)");
     const bool use_scratch = !use16 && !coop_waves && !d_matrix && (wpb == 0 || ctx->carry_memory == 1);
     if (use_scratch) wpb = 4;
@@ -606,9 +611,15 @@ int mgl_sw_align_batch_device_matrix(mgl_sw_ctx *ctx, void *stream, int64_t n, c
     HIP_TRY(ctx, hipEventRecord(ctx->matrix_copied, st));
     // with length arrays the offsets are per-pair START positions (a database sequence may serve many pairs)
     const SeqSet ts{d_targets, d_t_off, d_t_len, max_tl, 0}, qs{d_queries, d_q_off, d_q_len, max_ql, 0};
-    return run_device(ctx, st, n, ts, qs, max_tl, max_ql, 1, -1, gopen, gext, strategy, d_offset_out,
+    int cmax = matrix[0], cmin = matrix[0];
+    for (int k = 0; k < MATRIX_DIM * MATRIX_DIM; ++k) {
+        cmax = std::max<int>(cmax, matrix[k]);
+        cmin = std::min<int>(cmin, matrix[k]);
+    }
+    return run_device(ctx, st, n, ts, qs, max_tl, max_ql, cmax, cmin, gopen, gext, strategy, d_offset_out,
                       reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride, d_cigar_len_out, d_status_out, 0,
-                      false, (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, nullptr, dm, dc);
+                      (flags & (MGL_SW_FLAG_UNIFORM_GEOMETRY | MGL_SW_FLAG_GROUPED_GEOMETRY)) != 0,
+                      (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, nullptr, dm, dc);
 }
 
 int mgl_sw_align_batch_device_2bit(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_target_bases,

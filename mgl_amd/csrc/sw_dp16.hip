@@ -98,14 +98,22 @@ __device__ __forceinline__ unsigned sel_mask(unsigned a, unsigned b, unsigned lo
 
 // The arithmetic of one anti-diagonal step for both packed pairs: returns H, E', F' of the cell and
 // shifts the four decision flags into st.acc.  rh / re: carry for lane 0 of each group.
+// MATRIX (substitution-matrix scoring, sw_dp16_matrix_kernel): sub = {S[tA][qA] - max S, S[tB][qB] - max S}, looked up one
+// block ahead; the representation then uses max S where the DNA kernel uses `match`.
+template <bool MATRIX>
 __device__ __forceinline__ void cell16(Lane16 &st, const unsigned rh, const unsigned re, const unsigned q,
                                        const unsigned tt, const Consts16 &c, unsigned &h, unsigned &eo, unsigned &fo,
-                                       unsigned &hup_new)
+                                       unsigned &hup_new, const unsigned sub)
 {
     hup_new = row_shr1(rh, st.h_prev);
     const unsigned ein = row_shr1(re, st.e_prev);
-    const unsigned m = pk_min_u(q ^ tt, c.one);         // 1 where the bases differ
-    const unsigned diag = pk_mad(m, c.delta, st.hup);   // + (mismatch - match) on a mismatch
+    unsigned diag;
+    if (MATRIX) {
+        diag = as_u(as_s2(st.hup) + as_s2(sub));
+    } else {
+        const unsigned m = pk_min_u(q ^ tt, c.one);     // 1 where the bases differ
+        diag = pk_mad(m, c.delta, st.hup);              // + (mismatch - match) on a mismatch
+    }
     const unsigned d1 = pk_sub_sat(diag, st.f);         // < 0 <=> F > diag
     const unsigned sm = pk_max(diag, st.f);
     const unsigned d2 = pk_sub_sat(sm, ein);            // < 0 <=> E > max(diag, F)
@@ -137,18 +145,18 @@ __device__ __forceinline__ void commit16(Lane16 &st, unsigned h, unsigned eo, un
 // Stand-alone stripe (own pipeline fill and drain), four steps.
 //   PRO : some lane may still be at column <= 0 (forced border values)
 //   EPI : some lane may be at its last column (capture H[i][ql])
-template <bool PRO, bool EPI>
+template <bool PRO, bool EPI, bool MATRIX>
 __device__ __forceinline__ void step4_16(Lane16 &st, uint4 &ringA, uint4 &ringB, const uint4 *ring_next,
                                          const unsigned (&qq)[4], const unsigned tt, const int s0, const int L,
                                          const unsigned hb, const int ql, const Consts16 &c, uint2 *ring_wr,
-                                         const bool writer)
+                                         const bool writer, const unsigned (&sub)[4])
 {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const unsigned rh = RING_U(u, ringA, ringB, x, z), re = RING_U(u, ringA, ringB, y, w);
         if (u == 2) ringA = ring_next[0];
         unsigned h, eo, fo, hup_new;
-        cell16(st, rh, re, qq[u], tt, c, h, eo, fo, hup_new);
+        cell16<MATRIX>(st, rh, re, qq[u], tt, c, h, eo, fo, hup_new, sub[u]);
         if (PRO) {
             const bool at_border = (s0 + u) <= L; // column <= 0
             h = at_border ? hb : h;
@@ -163,17 +171,18 @@ __device__ __forceinline__ void step4_16(Lane16 &st, uint4 &ringA, uint4 &ringB,
 
 // Chained stripes, lean part of a period: no lane is at a border; with CAP the lanes that reach the
 // last column inside this block (lanes < P - ql, last block of the period) capture it.
-template <bool CAP>
+template <bool CAP, bool MATRIX>
 __device__ __forceinline__ void lean4_16(Lane16 &st, uint4 &ringA, uint4 &ringB, const uint4 *ring_next,
                                          const unsigned (&qq)[4], const unsigned tt, const int col0, const int L,
-                                         const int ql, const Consts16 &c, uint2 *ring_wr, const bool writer)
+                                         const int ql, const Consts16 &c, uint2 *ring_wr, const bool writer,
+                                         const unsigned (&sub)[4])
 {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const unsigned rh = RING_U(u, ringA, ringB, x, z), re = RING_U(u, ringA, ringB, y, w);
         if (u == 2) ringA = ring_next[0];
         unsigned h, eo, fo, hup_new;
-        cell16(st, rh, re, qq[u], tt, c, h, eo, fo, hup_new);
+        cell16<MATRIX>(st, rh, re, qq[u], tt, c, h, eo, fo, hup_new, sub[u]);
         if (CAP) st.cap = ((col0 + u - L) == ql) ? h : st.cap;
         if (writer) ring_wr[u] = make_uint2(h, eo);
         commit16(st, h, eo, fo, hup_new);
@@ -186,11 +195,12 @@ __device__ __forceinline__ void lean4_16(Lane16 &st, uint4 &ringA, uint4 &ringB,
 // k-1.  All lane selections use constant SGPR masks.  Block b covers window steps 4b .. 4b+3.
 //   FIRST : k == 0, nothing to finish or publish yet (lane 15 has not started)
 //   LAST  : k == number of chained stripes: lanes leave into nothing; lane 15 must not publish column 0
-template <int B, bool FIRST, bool LAST>
+template <int B, bool FIRST, bool LAST, bool MATRIX>
 __device__ __forceinline__ void window4_16(Lane16 &st, uint4 &ringA, uint4 &ringB, const uint4 *ring_next,
                                            const unsigned (&qq)[4], unsigned &tt, const unsigned tt_nxt,
                                            const unsigned hb_nxt, const unsigned hbf_nxt, const int cgap,
-                                           const Consts16 &c, uint2 *ring_wr_tail, uint2 *ring_col0, const bool lane15)
+                                           const Consts16 &c, uint2 *ring_wr_tail, uint2 *ring_col0, const bool lane15,
+                                           const unsigned (&sub)[4])
 {
     constexpr unsigned long long ROWS = 0x0001000100010001ull; // lane 0 of every 16-lane row
 #pragma unroll
@@ -199,7 +209,7 @@ __device__ __forceinline__ void window4_16(Lane16 &st, uint4 &ringA, uint4 &ring
         const unsigned rh = RING_U(t, ringA, ringB, x, z), re = RING_U(t, ringA, ringB, y, w);
         if (t == 2) ringA = ring_next[0];
         unsigned h, eo, fo, hup_new;
-        cell16(st, rh, re, qq[t], tt, c, h, eo, fo, hup_new);
+        cell16<MATRIX>(st, rh, re, qq[t], tt, c, h, eo, fo, hup_new, sub[t]);
         const unsigned long long m_u = ROWS << u;
         if (!FIRST) {
             // lane u + cgap sits on column ql of the stripe it is finishing
@@ -222,11 +232,29 @@ __device__ __forceinline__ void window4_16(Lane16 &st, uint4 &ringA, uint4 &ring
     ringB = ring_next[1];
 }
 
-} // namespace
-
-__global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
+// ---- substitution-matrix mode: the table in LDS holds int16 S[t][q] - max S, 32 x 32; tt = row byte offsets (code * 64)
+// of the two pairs packed, q = column byte offsets (code * 2) packed, so one add gives both table offsets
+__device__ __forceinline__ unsigned lut2(const short *lut, const unsigned tt, const unsigned q)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned s = tt + q;
+    const char *base = reinterpret_cast<const char *>(lut);
+    const unsigned short lo = *reinterpret_cast<const unsigned short *>(base + (s & 0xffffu));
+    const unsigned short hi = *reinterpret_cast<const unsigned short *>(base + (s >> 16));
+    return (unsigned)lo | ((unsigned)hi << 16);
+}
+// the target residue lane L uses at window step W: it adopts its next row's at step L
+template <int W>
+__device__ __forceinline__ unsigned tt_at(const unsigned tt, const unsigned tt_new)
+{
+    if (W < 0) return tt;
+    if (W >= 15) return tt_new;
+    constexpr unsigned long long LE = ((1ull << ((W < 0 ? 0 : W > 14 ? 14 : W) + 1)) - 1ull) * 0x0001000100010001ull; // lanes L <= W of every row
+    return sel_mask(tt, tt_new, LE);
+}
+
+template <bool MATRIX>
+__device__ __forceinline__ void sw_dp16_body(const DpArgs &a, unsigned char *smem, const short *lut)
+{
     unsigned long long diag_t0 = 0, diag_w0 = 0;
     if (a.diag) { // in-kernel clock probe (MI355X_MICROARCH.md, DVFS give-back item 6); off in normal runs
         diag_t0 = __builtin_amdgcn_s_memtime();
@@ -289,7 +317,12 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
         int cidx = x - 16;
         if (nc && cidx >= P - 1) cidx -= P;
         unsigned v = 0;
-        if (cidx >= 0 && cidx < ql) v = (unsigned)a.q.at(qA, cidx) | ((unsigned)a.q.at(qB, cidx) << 16);
+        if (cidx >= 0 && cidx < ql) {
+            if (MATRIX)
+                v = (unsigned)a.code[a.q.at(qA, cidx) & 0xff] * 2u | ((unsigned)a.code[a.q.at(qB, cidx) & 0xff] * 2u << 16);
+            else
+                v = (unsigned)a.q.at(qA, cidx) | ((unsigned)a.q.at(qB, cidx) << 16);
+        }
         qq[x] = v;
     }
     for (int j = L; j <= ql; j += 16) {
@@ -338,8 +371,11 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
         }                                                                                                 \
     }
 
+#define MGL_TT_PACK(row)                                                                                  \
+    (MATRIX ? ((unsigned)a.code[a.t.at(tA, (row)-1) & 0xff] * 64u | ((unsigned)a.code[a.t.at(tB, (row)-1) & 0xff] * 64u << 16)) \
+            : ((unsigned)a.t.at(tA, (row)-1) | ((unsigned)a.t.at(tB, (row)-1) << 16)))
     int row_next = 1 + L; // row this lane takes in the next stripe
-    unsigned tt_next = (row_next <= tl) ? ((unsigned)a.t.at(tA, row_next - 1) | ((unsigned)a.t.at(tB, row_next - 1) << 16)) : 0u;
+    unsigned tt_next = (row_next <= tl) ? MGL_TT_PACK(row_next) : 0u;
 
     // ======================= chained stripes 0 .. nc-1: one continuous systolic pipeline =======================
     if (nc > 0) {
@@ -352,6 +388,13 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
         const unsigned *qcur = qrd + P;
         unsigned qv[4] = {qcur[0], qcur[1], qcur[2], qcur[3]};
         unsigned tt = 0;
+        unsigned sub[4] = {0u, 0u, 0u, 0u}; // MATRIX: scores of the current block's four steps
+        if (MATRIX) { // window block 0 of stripe 0: lane L starts at step L
+            sub[0] = lut2(lut, tt_at<0>(tt, tt_next), qv[0]);
+            sub[1] = lut2(lut, tt_at<1>(tt, tt_next), qv[1]);
+            sub[2] = lut2(lut, tt_at<2>(tt, tt_next), qv[2]);
+            sub[3] = lut2(lut, tt_at<3>(tt, tt_next), qv[3]);
+        }
         for (int k = 0; k <= nc; ++k) {
             // ---- what every lane adopts when it wraps inside this window
             const int row_new = row_next;
@@ -361,15 +404,26 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
             const unsigned hbf_new = pk_sub(hb_new, c.o_f);
             if (k < nc) {
                 row_next += 16;
-                tt_next = (row_next <= tl) ? ((unsigned)a.t.at(tA, row_next - 1) | ((unsigned)a.t.at(tB, row_next - 1) << 16)) : 0u;
+                tt_next = (row_next <= tl) ? MGL_TT_PACK(row_next) : 0u;
             }
             const uint4 *ring_rd = ring_c0;              // lane 0 is at column 0 when the window opens
             uint2 *ring_tail = ring + 16 + (P - 15);     // lane 15: columns P-15 .. P-1 of the stripe it finishes
 #define MGL_WINDOW_BLOCK(B, FIRST, LAST)                                                                  \
     {                                                                                                     \
         const unsigned n0 = qcur[4], n1 = qcur[5], n2 = qcur[6], n3 = qcur[7];                            \
-        window4_16<B, FIRST, LAST>(st, rA, rB, ring_rd + 2, qv, tt, tt_new, hb_new, hbf_new, cgap, c,     \
-                                   ring_tail, ring + 16, lane15);                                         \
+        unsigned ns0 = 0, ns1 = 0, ns2 = 0, ns3 = 0;                                                      \
+        if (MATRIX) { /* the next block's steps 4(B+1) .. 4(B+1)+3 */                                      \
+            ns0 = lut2(lut, tt_at<4 * (B) + 4>(tt, tt_new), n0);                                          \
+            ns1 = lut2(lut, tt_at<4 * (B) + 5>(tt, tt_new), n1);                                          \
+            ns2 = lut2(lut, tt_at<4 * (B) + 6>(tt, tt_new), n2);                                          \
+            ns3 = lut2(lut, tt_at<4 * (B) + 7>(tt, tt_new), n3);                                          \
+        }                                                                                                 \
+        window4_16<B, FIRST, LAST, MATRIX>(st, rA, rB, ring_rd + 2, qv, tt, tt_new, hb_new, hbf_new, cgap, c, \
+                                           ring_tail, ring + 16, lane15, sub);                            \
+        sub[0] = ns0;                                                                                     \
+        sub[1] = ns1;                                                                                     \
+        sub[2] = ns2;                                                                                     \
+        sub[3] = ns3;                                                                                     \
         qv[0] = n0;                                                                                       \
         qv[1] = n1;                                                                                       \
         qv[2] = n2;                                                                                       \
@@ -410,7 +464,25 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
 #define MGL_LEAN_BLOCK(CAP, NEXT)                                                                         \
     {                                                                                                     \
         const unsigned n0 = qcur[4], n1 = qcur[5], n2 = qcur[6], n3 = qcur[7];                            \
-        lean4_16<CAP>(st, rA, rB, NEXT, qv, tt, s, L, ql, c, ring_wr, lane15);                            \
+        unsigned ns0 = 0, ns1 = 0, ns2 = 0, ns3 = 0;                                                      \
+        if (MATRIX) {                                                                                     \
+            if (CAP) { /* the next block opens the next period's window: lane L adopts tt_next at its step L */ \
+                ns0 = lut2(lut, tt_at<0>(tt, tt_next), n0);                                               \
+                ns1 = lut2(lut, tt_at<1>(tt, tt_next), n1);                                               \
+                ns2 = lut2(lut, tt_at<2>(tt, tt_next), n2);                                               \
+                ns3 = lut2(lut, tt_at<3>(tt, tt_next), n3);                                               \
+            } else {                                                                                      \
+                ns0 = lut2(lut, tt, n0);                                                                  \
+                ns1 = lut2(lut, tt, n1);                                                                  \
+                ns2 = lut2(lut, tt, n2);                                                                  \
+                ns3 = lut2(lut, tt, n3);                                                                  \
+            }                                                                                             \
+        }                                                                                                 \
+        lean4_16<CAP, MATRIX>(st, rA, rB, NEXT, qv, tt, s, L, ql, c, ring_wr, lane15, sub);               \
+        sub[0] = ns0;                                                                                     \
+        sub[1] = ns1;                                                                                     \
+        sub[2] = ns2;                                                                                     \
+        sub[3] = ns3;                                                                                     \
         qv[0] = n0;                                                                                       \
         qv[1] = n1;                                                                                       \
         qv[2] = n2;                                                                                       \
@@ -437,7 +509,7 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
         const int row_i = row_next;
         const unsigned tt = tt_next;
         row_next += 16;
-        tt_next = (row_next <= tl) ? ((unsigned)a.t.at(tA, row_next - 1) | ((unsigned)a.t.at(tB, row_next - 1) << 16)) : 0u;
+        tt_next = (row_next <= tl) ? MGL_TT_PACK(row_next) : 0u;
 
         const int hbv = border(row_i, gopen, gext, indel) + row_i * gext + base; // column 0
         const unsigned hb = pack2(hbv, hbv);
@@ -450,12 +522,30 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
         const unsigned *qrd = qq + 15 - L; // step s reads q index s - L - 1  ->  qq[s - L + 15]
         uint4 rA = ring_rd[0], rB = ring_rd[1];
         unsigned qv[4] = {qrd[0], qrd[1], qrd[2], qrd[3]};
+        unsigned sub[4] = {0u, 0u, 0u, 0u};
+        if (MATRIX) {
+            sub[0] = lut2(lut, tt, qv[0]);
+            sub[1] = lut2(lut, tt, qv[1]);
+            sub[2] = lut2(lut, tt, qv[2]);
+            sub[3] = lut2(lut, tt, qv[3]);
+        }
 
         int s = 0;
 #define MGL_SW_BLOCK16(PRO, EPI)                                                                          \
     {                                                                                                     \
         const unsigned n0 = qrd[4], n1 = qrd[5], n2 = qrd[6], n3 = qrd[7];                                \
-        step4_16<PRO, EPI>(st, rA, rB, ring_rd + 2, qv, tt, s, L, hb, ql, c, ring_wr, writer);            \
+        unsigned ns0 = 0, ns1 = 0, ns2 = 0, ns3 = 0;                                                      \
+        if (MATRIX) {                                                                                     \
+            ns0 = lut2(lut, tt, n0);                                                                      \
+            ns1 = lut2(lut, tt, n1);                                                                      \
+            ns2 = lut2(lut, tt, n2);                                                                      \
+            ns3 = lut2(lut, tt, n3);                                                                      \
+        }                                                                                                 \
+        step4_16<PRO, EPI, MATRIX>(st, rA, rB, ring_rd + 2, qv, tt, s, L, hb, ql, c, ring_wr, writer, sub); \
+        sub[0] = ns0;                                                                                     \
+        sub[1] = ns1;                                                                                     \
+        sub[2] = ns2;                                                                                     \
+        sub[3] = ns3;                                                                                     \
         qv[0] = n0;                                                                                       \
         qv[1] = n1;                                                                                       \
         qv[2] = n2;                                                                                       \
@@ -535,6 +625,26 @@ __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
         a.diag[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - diag_t0;
         a.diag[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - diag_w0;
     }
+#undef MGL_TT_PACK
+}
+
+} // namespace
+
+__global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    sw_dp16_body<false>(a, smem, nullptr);
+}
+
+// substitution-matrix scoring (protein extension, no reference path): a.match = the largest matrix entry; the table
+// S - max S (int16, 2 KB) sits in LDS behind the per-group carves
+__global__ __launch_bounds__(256) void sw_dp16_matrix_kernel(const DpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    short *lut = reinterpret_cast<short *>(smem + a.matrix_lds_offset);
+    for (int x = threadIdx.x; x < MATRIX_DIM * MATRIX_DIM; x += blockDim.x) lut[x] = (short)((int)a.matrix[x] - a.match);
+    __syncthreads();
+    sw_dp16_body<true>(a, smem, lut);
 }
 
 int dp16_lds_bytes(int sps, int waves_per_block)
@@ -569,6 +679,18 @@ hipError_t launch_dp16(const DpArgs &a, int waves_per_block, hipStream_t stream)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_dp16_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
+    }
+    if (a.matrix) {
+        DpArgs b = a;
+        b.matrix_lds_offset = lds;
+        const int lds_m = lds + MATRIX_DIM * MATRIX_DIM * 2;
+        if (lds_m > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_dp16_matrix_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_m);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(sw_dp16_matrix_kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), lds_m, stream, b);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(sw_dp16_kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), lds, stream, a);
     return hipGetLastError();

@@ -88,8 +88,12 @@ class IndexedBatch:
         self.status = torch.empty(self.n, dtype=torch.int32, device=dev)
 
 
-def run_matrix(batch, aligner, code, matrix, gap_open=11, gap_extend=1, overhang_strategy=1, stream=None, binary_cigar=False):
-    """mgl_sw_align_batch_device_matrix on a device_batch.DeviceBatch (ASCII wire format); no sync."""
+def run_matrix(batch, aligner, code, matrix, gap_open=11, gap_extend=1, overhang_strategy=1, stream=None, binary_cigar=False,
+               grouped=False):
+    """mgl_sw_align_batch_device_matrix on a device_batch.DeviceBatch / IndexedBatch (ASCII wire format); no sync.
+    ``grouped``: every aligned block of eight pairs has one (tl, ql) (MGL_SW_FLAG_GROUPED_GEOMETRY) -- true for a
+    database search laid out as pair = d * Q + q with Q a multiple of eight -- which makes the packed-int16 kernel
+    eligible."""
     import torch
 
     if stream is None:
@@ -105,6 +109,7 @@ def run_matrix(batch, aligner, code, matrix, gap_open=11, gap_extend=1, overhang
         batch.max_ql, matrix.ctypes.data, code.ctypes.data,
         int(gap_open), int(gap_extend), int(overhang_strategy), batch.offsets.data_ptr(), batch.scores.data_ptr(),
         batch.cigars.data_ptr(), batch.cigar_stride, batch.cigar_len.data_ptr(), batch.status.data_ptr(),
-        _lib.FLAG_BINARY_CIGAR if binary_cigar else 0)
+        (_lib.FLAG_BINARY_CIGAR if binary_cigar else 0) | (_lib.FLAG_GROUPED_GEOMETRY if grouped else 0) |
+        (_lib.FLAG_UNIFORM_GEOMETRY if getattr(batch, "uniform", False) else 0))
     if rc != _lib.OK:
         raise _lib.MglSwError(rc, L.mgl_sw_last_error(aligner.ctx).decode())

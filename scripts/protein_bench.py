@@ -50,16 +50,17 @@ b = protein.IndexedBatch(torch.from_numpy(db).to(dev), t_start, t_len, torch.fro
 cells = int(lens.sum()) * Q * QL
 a = sw.MicrosoftSmithWaterman(0)
 a.set_workspace(int(args.workspace_gib * (1 << 30)))
-protein.run_matrix(b, a, code, mat, 11, 1); torch.cuda.synchronize()
+grouped = (Q % 8 == 0) and not os.environ.get("MGL_PROTEIN_INT32")
+protein.run_matrix(b, a, code, mat, 11, 1, grouped=grouped); torch.cuda.synchronize()
 a.set_profiling(1)
 t0 = time.perf_counter()
 for _ in range(args.steps):
-    protein.run_matrix(b, a, code, mat, 11, 1)
+    protein.run_matrix(b, a, code, mat, 11, 1, grouped=grouped)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
 tm = a.timing()
 over = int((b.status != 0).sum())
-print(f"protein SW (BLOSUM62, 11/1, SOFTCLIP): {Q} queries of {QL} aa x {args.db} database sequences (mean {lens.mean():.0f} aa) = "
+print(f"protein SW (BLOSUM62, 11/1, SOFTCLIP, {'packed int16' if tm.packed16 else 'int32'} kernel): {Q} queries of {QL} aa x {args.db} database sequences (mean {lens.mean():.0f} aa) = "
       f"{n} pairs, {dt*1e3:.1f} ms per pass = {cells/dt/1e9:.1f} GCUPS, {n/dt/1e6:.2f} M alignments/s (fill {tm.dp_ms:.1f} ms in "
       f"{tm.dp_launches} launches, traceback {tm.tb_ms:.1f} ms; {over} CIGARs longer than {args.stride} bytes flagged)", flush=True)
 if args.check:

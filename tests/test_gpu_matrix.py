@@ -96,6 +96,31 @@ def test_blosum62_batches_bit_exact():
         assert (b.offsets.cpu().numpy() == off).all()
         assert (b.scores.cpu().numpy() == sc).all()
         assert b.cigar_strings() == cg
+    # one geometry per block of eight pairs: the packed-int16 kernel with the table S - max S in LDS, all strategies
+    for strategy, (o, e) in zip(ol.STRATEGIES, [(11, 1), (10, 2), (7, 3), (12, 1)]):
+        ts, qs = [], []
+        for g in range(40):
+            tl, ql = int(rng.integers(20, 500)), int(rng.integers(33, 330))
+            for k in range(8):
+                t = protein.random_proteins(rng, 1, tl)[0]
+                if k % 2 and tl > ql:
+                    s0 = int(rng.integers(0, tl - ql + 1)); q = t[s0:s0 + ql].copy()
+                    mut = rng.random(ql) < 0.35
+                    q[mut] = protein.random_proteins(rng, 1, int(mut.sum()))[0] if mut.any() else q[mut]
+                else:
+                    q = protein.random_proteins(rng, 1, ql)[0]
+                ts.append(t.tobytes()); qs.append(q.tobytes())
+        td, toff = sw.concat(ts); qd, qoff = sw.concat(qs)
+        b = device_batch.from_host(td, toff, qd, qoff, "cuda:0", cigar_stride=1200)
+        protein.run_matrix(b, a, code, mat, o, e, strategy, grouped=True)
+        torch.cuda.synchronize()
+        assert a.timing().packed16 == 1 and int((b.status != 0).sum()) == 0
+        off, sc, cg = oracle_matrix_batch(ts, qs, code, mat, o, e, strategy, 1200)
+        assert (b.offsets.cpu().numpy() == off).all() and (b.scores.cpu().numpy() == sc).all() and b.cigar_strings() == cg
+        protein.run_matrix(b, a, code, mat, o, e, strategy, grouped=False)   # the same pairs through the int32 kernel
+        torch.cuda.synchronize()
+        assert a.timing().packed16 == 0
+        assert (b.offsets.cpu().numpy() == off).all() and (b.scores.cpu().numpy() == sc).all() and b.cigar_strings() == cg
     # a DNA match / mismatch matrix reproduces the reference's scoring exactly
     dcode = np.zeros(256, np.uint8)
     for k, ch in enumerate(b"ACGT"): dcode[ch] = k + 1
