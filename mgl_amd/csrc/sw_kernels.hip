@@ -459,8 +459,9 @@ struct TbView {
     __device__ __forceinline__ unsigned cell(int i, int j) const
     {
         const int r = i - 1;
-        const int lane = r % rows;
-        const int k = r / rows;
+        const int sh_rows = rows == 64 ? 6 : 4; // rows is 16 or 64: no integer division in the walk
+        const int lane = r & (rows - 1);
+        const int k = r >> sh_rows;
         const int g = (g_tail > 0 && k >= nc ? g_tail + (k - nc) * sps_tail : k * sps) + j + lane;
         if (packed16) {
             // sw_dp16.hip: dword per lane per 4 steps (two per 8-step block);
@@ -714,8 +715,8 @@ struct WaveMoves {
     __device__ __forceinline__ unsigned cell(int i, int j)
     {
         const int r = i - 1;
-        const int lane = r % rows;
-        const int g = (r / rows) * sps + j + lane;
+        const int lane = r & (rows - 1); // rows is 16 or 64
+        const int g = (r >> (rows == 64 ? 6 : 4)) * sps + j + lane;
         const int blk = g >> 5;
         if (blk != cur_blk) {
             cur = blk == nxt_blk ? nxt : load(blk);
