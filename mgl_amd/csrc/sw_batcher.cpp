@@ -193,7 +193,7 @@ class Coalescer {
                 for (Request *r : batch) r->rc = rc;
                 return;
             }
-            mgl_sw_ctx_set_workspace(ctx_, 1ll << 30);
+            mgl_sw_ctx_set_workspace(ctx_, 8ll << 30); // a cap: the workspace grows with what the batches need
             // small batches are latency bound: one workgroup of four waves per pair (sw_dp_coop.hip) finishes a
             // 256 x 150 pair in a quarter of the time of one wave walking its 16 stripes (tests/cpp/coalesce_bench)
             mgl_sw_ctx_set_cooperative(ctx_, 4);

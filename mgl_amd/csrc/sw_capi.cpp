@@ -213,21 +213,23 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const int64_t per_pair = stride_words * 4 / (use16 ? 2 : 1) + (int64_t)sizeof(DpRecord);
     // the workspace is split in two halves so that the traceback of one chunk can run (on ctx->aux)
     // while the next chunk is being filled; a batch that fits one half is a single chunk
-    if (per_pair * 16 > ctx->ws_limit / 2) {
-        char msg[160];
-        snprintf(msg, sizeof msg, "traceback of 16 pairs (%lld bytes) does not fit half the workspace: raise it with "
-                                  "mgl_sw_ctx_set_workspace", (long long)(per_pair * 16));
+    // chunks are whole waves' worth of pairs (8: packed kernel, and the blocks of MGL_SW_FLAG_GROUPED_GEOMETRY; 4: 16-row
+    // int32 kernel; 1: one pair per wave or workgroup); the last chunk may be shorter (idle lanes store nothing)
+    const int64_t gran = use16 ? 8 : rows == 64 ? 1 : 4;
+    if (per_pair * gran > ctx->ws_limit / 2) {
+        char msg[192];
+        snprintf(msg, sizeof msg, "traceback of %lld pair(s) (%lld bytes) does not fit half the workspace: raise it with "
+                                  "mgl_sw_ctx_set_workspace", (long long)gran, (long long)(per_pair * gran));
         return fail(ctx, MGL_SW_ERR_NOMEM, msg);
     }
-    int64_t chunk = std::max<int64_t>(16, ctx->ws_limit / 2 / per_pair);
+    int64_t chunk = std::max<int64_t>(gran, ctx->ws_limit / 2 / per_pair / gran * gran);
     chunk = std::min<int64_t>(chunk, n);
-    chunk = (chunk + 15) / 16 * 16;
     const bool overlap = n > chunk;
     const int halves = n > chunk ? 2 : 1;
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int h = 0; h < halves; ++h) {
-        HIP_TRY(ctx, ctx->tb[h].reserve((size_t)(use16 ? chunk / 2 : chunk) * stride_words * 4));
+        HIP_TRY(ctx, ctx->tb[h].reserve((size_t)(use16 ? (chunk + 1) / 2 : chunk) * stride_words * 4));
         HIP_TRY(ctx, ctx->rec[h].reserve((size_t)chunk * sizeof(DpRecord)));
     }
 
@@ -849,7 +851,7 @@ static mgl_sw_ctx *thread_ctx(int *rc)
         if (const char *e = getenv("MGL_SW_DEVICE")) dev = atoi(e);
         *rc = mgl_sw_ctx_create(dev, &h.ctx);
         if (*rc != MGL_SW_OK) return nullptr;
-        h.ctx->ws_limit = 256ll << 20;
+        h.ctx->ws_limit = 8ll << 30; // a cap, not an allocation: the workspace grows with what the calls need
         h.ctx->cooperative = 4; // one pair per call: latency, not occupancy (see sw_batcher.cpp)
     }
     *rc = MGL_SW_OK;

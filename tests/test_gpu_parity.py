@@ -310,6 +310,22 @@ def test_grouped_geometry_variable_length_reads(aligner):
     assert (gb.offsets.cpu().numpy() == off[o]).all() and (gb.scores.cpu().numpy() == sc[o]).all()
 
 
+def test_single_long_pair_through_the_one_pair_entry():
+    """mgl_sw_align (the alignNative replacement, per-thread context) on the 10 kb x 10 kb golden pair: its 50 MB
+    traceback must fit without the caller configuring anything, and one pair must not reserve sixteen pairs' worth."""
+    g = [r for r in golden_io.load("long") if r.suite == "long"][0]
+    cigar, off, ez = sw.align(g.t, g.q, g.params, g.strategy)
+    assert off == g.offset and "sha1:" + hashlib.sha1(cigar.encode()).hexdigest() == g.cigar
+    assert tuple(ez) == g.score
+    # a small workspace holds exactly as many pairs as fit, down to one per chunk
+    a = sw.MicrosoftSmithWaterman(0)
+    a.set_workspace(150 << 20)   # two halves of 75 MB: one 50 MB traceback each
+    res = a.align_batch([g.t] * 3, [g.q] * 3, g.params, g.strategy, cigar_stride=24000)
+    assert all(int(res.offsets[k]) == g.offset and "sha1:" + hashlib.sha1(res.cigars[k].encode()).hexdigest() == g.cigar for k in range(3))
+    assert a.timing().dp_launches == 3
+    a.close()
+
+
 def test_native_threads_through_the_coalescer():
     """GATK's calling pattern from native threads (tests/cpp/coalesce_bench.cpp): 48 threads, one pair per
     mgl_sw_align call, merged into device batches by the dispatcher; every answer equals the direct call's."""
