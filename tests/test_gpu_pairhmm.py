@@ -124,6 +124,35 @@ def test_quality_bytes_are_masked_like_the_reference(hmm):
         assert abs(got[k] - want) < (1e-9 * max(1.0, abs(want)) if used else 1e-5), (k, got[k], want)
 
 
+@pytest.mark.parametrize("use_double", [False, True])
+def test_long_reads_and_haplotypes(hmm, use_double):
+    """Reads far beyond one stripe (4 rows x 64 lanes): several stripes with the carry ring between them, haplotypes
+    near the LDS limit."""
+    rng = np.random.default_rng(31)
+    hmm.initialize(pairhmm.PairHMMNativeArguments(use_double, 1))
+    limit = pairhmm.lib().mgl_pairhmm_max_haplotype_len(0)
+    reads, haps = [], []
+    for R, H in ((257, 300), (600, 700), (1000, 1500), (1234, limit)):
+        hap = rng.choice(list(b"ACGT"), size=H).astype(np.uint8)
+        s = int(rng.integers(0, H - R + 1))
+        r = hap[s:s + R].copy()
+        flips = rng.random(R) < 0.02
+        r[flips] = rng.choice(list(b"ACGT"), size=int(flips.sum()))
+        reads.append(pairhmm.ReadDataHolder(r.tobytes(), rng.integers(10, 41, size=R).astype(np.uint8).tobytes(),
+                                            np.full(R, 45, np.uint8).tobytes(), np.full(R, 45, np.uint8).tobytes(),
+                                            np.full(R, 10, np.uint8).tobytes()))
+        haps.append(pairhmm.HaplotypeDataHolder(hap.tobytes()))
+    rd, roff = pairhmm.pack_reads(reads)
+    hd, hoff = pairhmm.pack_haps(haps)
+    pr = np.arange(4, dtype=np.int32)
+    ph = np.arange(4, dtype=np.int32)
+    got = hmm.compute_pairs(rd, roff, hd, hoff, pr, ph)
+    want, used = pol.compute_pairs(rd, roff, hd, hoff, pr, ph, use_double, 4)
+    for k in range(4):
+        tol = 1e-9 * max(1.0, abs(want[k])) if (use_double or used[k]) else 1e-5
+        assert abs(got[k] - want[k]) < tol, (k, got[k], want[k], used[k])
+
+
 def test_pair_list_and_errors(hmm):
     hmm.initialize(None)
     rng = np.random.default_rng(3)
