@@ -179,6 +179,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // four waves per block while their LDS carve fits, else two or one
     const int lds_extra = d_matrix ? MATRIX_DIM * MATRIX_DIM * 2 : 0;
     int wpb16 = 4;
+    if (const char *e = getenv("MGL_SW_WPB16")) wpb16 = std::max(1, std::min(4, atoi(e))); // launch-shape experiments only
     while (wpb16 > 1 && dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra > 64 * 1024) wpb16 >>= 1;
     const bool use16 = uniform && ctx->precision != 32 && dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra <= 64 * 1024 &&
                        match > 0 && dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
