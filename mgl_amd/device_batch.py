@@ -139,31 +139,45 @@ def from_host(targets, t_off, queries, q_off, device, cigar_stride=None):
 # ---------------------------------------------------------------------------------------------
 # variable-length batches at packed-kernel speed: sort by geometry, pad every geometry to a multiple of eight
 class GroupedBatch(DeviceBatch):
-    """ASCII pairs addressed by (start, length) (mgl_sw_align_batch_device_indexed), reordered so that every aligned
-    block of eight pairs has one (tl, ql) (MGL_SW_FLAG_GROUPED_GEOMETRY).  ``order[k]`` is the original pair index of
-    slot k (a geometry whose count is not a multiple of eight repeats its last pair to fill the block);
-    ``first_slot[i]`` is a slot holding original pair i: results of pair i are ``offsets[first_slot[i]]`` etc."""
+    """ASCII pairs addressed by (start, length) (mgl_sw_align_batch_device_indexed), reordered for the packed kernel:
+    pairs are sorted by (tl, ql); every geometry with at least ``min_bucket`` pairs is padded to a multiple of eight
+    (its last pair repeated) and goes into the GROUPED part, where every aligned block of eight slots has one geometry
+    (MGL_SW_FLAG_GROUPED_GEOMETRY); the pairs of rarer geometries follow as an ordinary mixed part (int32 kernel),
+    still sorted so that wave mates are alike.  ``order[k]`` is the original pair index of slot k;
+    ``first_slot[i]`` is a slot holding original pair i: its results are ``offsets[first_slot[i]]`` etc.
+    (``gather()`` returns them in the original order)."""
 
-    def __init__(self, targets, t_start, t_len, queries, q_start, q_len, cigar_stride=64):
+    def __init__(self, targets, t_start, t_len, queries, q_start, q_len, cigar_stride=64, min_bucket=8):
         dev = targets.device
+        n = t_start.numel()
         tl, ql = t_len.to(torch.int64), q_len.to(torch.int64)
         key = tl * (1 << 32) + ql
         order = torch.argsort(key, stable=True)
-        skey = key[order]
-        uniq, counts = torch.unique_consecutive(skey, return_counts=True)
-        padded = (counts + 7) // 8 * 8
-        ends = torch.cumsum(counts, 0)
-        # slot -> index into `order`: the bucket's own pairs, then its last pair repeated
-        bucket = torch.repeat_interleave(torch.arange(len(uniq), device=dev), padded)
-        pos = torch.arange(int(padded.sum()), device=dev) - torch.repeat_interleave(torch.cumsum(padded, 0) - padded, padded)
-        src = (ends - counts)[bucket] + torch.minimum(pos, counts[bucket] - 1)
-        self.order = order[src]
-        self.first_slot = torch.full_like(order, len(self.order)).scatter_reduce_(
-            0, self.order, torch.arange(len(self.order), device=dev), "amin")
+        uniq, inverse, counts = torch.unique_consecutive(key[order], return_inverse=True, return_counts=True)
+        big = counts >= min_bucket
+        in_big = big[inverse]                                  # per sorted pair
+        # ---- grouped part: the big buckets, each padded to a multiple of eight
+        cb = counts[big]
+        padded = (cb + 7) // 8 * 8
+        n_grouped = int(padded.sum())
+        sorted_big = order[in_big]                             # pairs of big buckets, bucket by bucket
+        if n_grouped:
+            ends = torch.cumsum(cb, 0)
+            bucket = torch.repeat_interleave(torch.arange(len(cb), device=dev), padded)
+            pos = torch.arange(n_grouped, device=dev) - torch.repeat_interleave(torch.cumsum(padded, 0) - padded, padded)
+            src = (ends - cb)[bucket] + torch.minimum(pos, cb[bucket] - 1)
+            grouped = sorted_big[src]
+        else:
+            grouped = order[:0]
+        rest = order[~in_big]
+        self.n_grouped, self.n_rest = n_grouped, int(rest.numel())
+        self.order = torch.cat([grouped, rest])
+        self.n = self.n_grouped + self.n_rest
+        self.first_slot = torch.full((n,), self.n, dtype=torch.int64, device=dev).scatter_reduce_(
+            0, self.order, torch.arange(self.n, device=dev), "amin")
         self.targets, self.queries = targets, queries
         self.t_off, self.q_off = t_start[self.order].contiguous(), q_start[self.order].contiguous()
         self.t_len, self.q_len = t_len[self.order].to(torch.int32).contiguous(), q_len[self.order].to(torch.int32).contiguous()
-        self.n = len(self.order)
         self.max_tl, self.max_ql = int(tl.max()), int(ql.max())
         self.cigar_stride = int(cigar_stride)
         self.uniform = False
@@ -177,19 +191,33 @@ class GroupedBatch(DeviceBatch):
     def cells(self):
         return int((self.t_len.to(torch.int64) * self.q_len.to(torch.int64)).sum())
 
+    def _launch(self, aligner, stream, lo, count, p, overhang_strategy, flags):
+        if count == 0:
+            return
+        sl = slice(lo, lo + count)
+        rc = _lib.lib().mgl_sw_align_batch_device_indexed(
+            aligner.ctx, C.c_void_p(stream.cuda_stream), count, self.targets.data_ptr(), self.t_off[sl].data_ptr(),
+            self.t_len[sl].data_ptr(), self.queries.data_ptr(), self.q_off[sl].data_ptr(), self.q_len[sl].data_ptr(),
+            int(self.t_len[sl].max()), int(self.q_len[sl].max()), p.match, p.mismatch, p.gap_open, p.gap_extend,
+            int(overhang_strategy), self.offsets[sl].data_ptr(), self.scores[sl].data_ptr(), self.cigars[sl].data_ptr(),
+            self.cigar_stride, self.cigar_len[sl].data_ptr(), self.status[sl].data_ptr(), flags)
+        _check(rc, aligner.ctx)
+
     def run(self, aligner, parameters=GATK_PARAMETERS, overhang_strategy=SWOverhangStrategy.SOFTCLIP, stream=None,
             binary_cigar=False):
+        """Two enqueues on ``stream``: the grouped part (packed kernel when its score range allows), then the rest."""
         if stream is None:
             stream = torch.cuda.current_stream(self.targets.device)
         p = SWParameters(*parameters)
-        flags = _lib.FLAG_GROUPED_GEOMETRY | (_lib.FLAG_BINARY_CIGAR if binary_cigar else 0)
-        rc = _lib.lib().mgl_sw_align_batch_device_indexed(
-            aligner.ctx, C.c_void_p(stream.cuda_stream), self.n, self.targets.data_ptr(), self.t_off.data_ptr(),
-            self.t_len.data_ptr(), self.queries.data_ptr(), self.q_off.data_ptr(), self.q_len.data_ptr(), self.max_tl,
-            self.max_ql, p.match, p.mismatch, p.gap_open, p.gap_extend, int(overhang_strategy), self.offsets.data_ptr(),
-            self.scores.data_ptr(), self.cigars.data_ptr(), self.cigar_stride, self.cigar_len.data_ptr(),
-            self.status.data_ptr(), flags)
-        _check(rc, aligner.ctx)
+        bc = _lib.FLAG_BINARY_CIGAR if binary_cigar else 0
+        self._launch(aligner, stream, 0, self.n_grouped, p, overhang_strategy, _lib.FLAG_GROUPED_GEOMETRY | bc)
+        self.grouped_packed16 = bool(aligner.timing().packed16) if (self.n_grouped and not self.n_rest) else None
+        self._launch(aligner, stream, self.n_grouped, self.n_rest, p, overhang_strategy, bc)
+
+    def gather(self):
+        """(offsets, scores, cigars, cigar_len, status) in the ORIGINAL pair order (device tensors)."""
+        s = self.first_slot
+        return self.offsets[s], self.scores[s], self.cigars[s], self.cigar_len[s], self.status[s]
 
 
 # ---------------------------------------------------------------------------------------------
