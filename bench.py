@@ -57,6 +57,18 @@ def host_cores():
     return n
 
 
+def pmc_valu(tl, ql, kernel):
+    """VALU counters of the committed PMC passes for this kernel and geometry (or None)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        for r in rec[kernel]:
+            if (r["tl"], r["ql"]) == (tl, ql):
+                return r.get("valu")
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def pmc_traffic_per_pair(tl, ql, kernel="sw_dp_kernel"):
     """HBM bytes per pair of sw_dp_kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json: WRITE_SIZE + 2 x FETCH_SIZE, the gfx950 correction of
@@ -281,6 +293,17 @@ def main():
     pairs_per_launch = args.pairs / max(1, tm.dp_launches)
     tpp = pmc_traffic_per_pair(args.tl, args.ql, fill_kernel)
     traffic = None if tpp is None else round(tpp * pairs_per_launch)  # HBM bytes per launch (PMC)
+    valu = pmc_valu(args.tl, args.ql, fill_kernel)
+    valu_obj = None
+    if valu:
+        # what actually bounds this integer kernel: VALU issue.  SIMD-cycles the committed instruction count needs at the
+        # measured per-class issue costs / SIMD-cycles available in the measured launch duration (1024 SIMDs x clock)
+        clock_hz = (tm.clock_mhz or 2400) * 1e6
+        need = valu["wave_insts_per_pair"] * pairs_per_launch * valu["avg_cycles_per_inst"]
+        have = (tm.dp_ms / max(1, tm.dp_launches)) * 1e-3 * clock_hz * 1024
+        valu_obj = {"issue_frac": round(need / have, 3), "wave_insts_per_pair": valu["wave_insts_per_pair"],
+                    "avg_cycles_per_inst": valu["avg_cycles_per_inst"], "lds_bank_conflict_rate": valu["lds_bank_conflict_rate"],
+                    "clock_mhz": int(clock_hz / 1e6), "source": "profiles/pmc_traffic.json (rocprofv3 --pmc, r01_d_final.txt)"}
     out = {
         "metric": "GCUPS (+ aligned reads/s) for 150 bp short-read batch",
         "value": round(total_cells / elapsed / 1e9, 2),
@@ -317,6 +340,7 @@ def main():
             "avg_launch_ms": round(tm.dp_ms / max(1, tm.dp_launches), 4),
             "kernel_gcups": round(cells / dp_s / 1e9, 2),
             "note": "integer DP: the kernel is VALU-issue bound, the HBM fraction is small by construction",
+            "valu": valu_obj,
         },
     }
     if world == 1 and not args.no_cpu:
