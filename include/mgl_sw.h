@@ -168,6 +168,11 @@ int mgl_sw_align_batch(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const
  * padded per length to a multiple of eight.  Such a batch is eligible for the packed-int16 kernel like a uniform
  * one (each wave of that kernel works on one block).  Results are undefined if the promise is broken. */
 #define MGL_SW_FLAG_GROUPED_GEOMETRY 0x4
+/* MGL_SW_FLAG_SCORE_ONLY: the caller only wants d_score_out (all six ScoreMax fields, bit-identical to the full
+ * call).  A hint: batches that run on the packed-int16 kernel then skip the traceback flags and the path walk
+ * (offsets are written as 0, cigar_len as 0, the CIGAR slots are left untouched); every other batch runs the full
+ * path.  Not a reference feature (align_* always builds the CIGAR): a pre-filter mode for database searches. */
+#define MGL_SW_FLAG_SCORE_ONLY 0x8
 int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_targets,
                               const int64_t *d_t_off, const uint8_t *d_queries,
                               const int64_t *d_q_off, int max_tl, int max_ql, int match,

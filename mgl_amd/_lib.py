@@ -16,6 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 FLAG_UNIFORM_GEOMETRY = 1
 FLAG_BINARY_CIGAR = 2
 FLAG_GROUPED_GEOMETRY = 4
+FLAG_SCORE_ONLY = 8
 OK, ERR_BAD_ARG, ERR_CIGAR_OVERFLOW, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED = range(6)
 
 # every symbol include/mgl_sw.h declares (tests check that the library exports them all)

@@ -160,7 +160,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                int max_ql, int match, int mismatch, int gopen, int gext, int strategy, int32_t *d_offset, Score *d_score,
                char *d_cigar, int cigar_stride, int32_t *d_cigar_len, int32_t *d_status, int64_t cells_hint, bool uniform,
                bool binary_cigar = false, const ChunkHooks *hooks = nullptr, const int8_t *d_matrix = nullptr,
-               const uint8_t *d_code = nullptr)
+               const uint8_t *d_code = nullptr, bool score_only_hint = false)
 {
     if (n == 0) return MGL_SW_OK;
     if (n < 0 || !tset.data || !tset.off || !qset.data || !qset.off || !d_offset || !d_cigar || cigar_stride < 1 ||
@@ -183,6 +183,8 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     while (wpb16 > 1 && dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra > 64 * 1024) wpb16 >>= 1;
     const bool use16 = uniform && ctx->precision != 32 && dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra <= 64 * 1024 &&
                        match > 0 && dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
+    // MGL_SW_FLAG_SCORE_ONLY is honoured by the packed kernel only; elsewhere the full path runs (a superset of the result)
+    const bool score_only = score_only_hint && use16 && d_score != nullptr && !hooks;
     int rows = use16 ? 16 : ctx->stripe_rows ? ctx->stripe_rows : (max_ql >= kRows64MinQuery ? 64 : 16);
     // substitution-matrix mode: 16 rows x four pairs per wave while that carve fits LDS (queries up to ~800 residues;
     // measured faster than one pair per wave at 300 residues: 1 006 vs 960 GCUPS), else 64 rows x one pair (to ~3 300)
@@ -211,7 +213,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "matrix larger than 2^34 cells");
     // traceback words per pair (int32 layout) or per group of two pairs (packed16 layout)
     const int64_t stride_words = use16 ? tb_words16_for(max_tl, max_ql) : tb_words_for(max_tl, sps_cap, rows);
-    const int64_t per_pair = stride_words * 4 / (use16 ? 2 : 1) + (int64_t)sizeof(DpRecord);
+    const int64_t per_pair = (score_only ? 0 : stride_words * 4 / (use16 ? 2 : 1)) + (int64_t)sizeof(DpRecord);
     // the workspace is split in two halves so that the traceback of one chunk can run (on ctx->aux)
     // while the next chunk is being filled; a batch that fits one half is a single chunk
     // chunks are whole waves' worth of pairs (8: packed kernel, and the blocks of MGL_SW_FLAG_GROUPED_GEOMETRY; 4: 16-row
@@ -230,7 +232,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int h = 0; h < halves; ++h) {
-        HIP_TRY(ctx, ctx->tb[h].reserve((size_t)(use16 ? (chunk + 1) / 2 : chunk) * stride_words * 4));
+        if (!score_only) HIP_TRY(ctx, ctx->tb[h].reserve((size_t)(use16 ? (chunk + 1) / 2 : chunk) * stride_words * 4));
         HIP_TRY(ctx, ctx->rec[h].reserve((size_t)chunk * sizeof(DpRecord)));
     }
 
@@ -278,6 +280,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         da.matrix = d_matrix;
         da.code = d_code;
         da.matrix_lds_offset = 0;
+        da.score_only = score_only ? 1 : 0;
         const int per_block = use16 ? wpb * 8 : wpb * (64 / rows);
         const int64_t n_blocks = (count + per_block - 1) / per_block;
         if (ctx->profiling >= 2) {
@@ -327,7 +330,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->fill_done[h], 0));
         }
         if (pe[2]) HIP_TRY(ctx, hipEventRecord(pe[2], tb_stream));
-        HIP_TRY(ctx, launch_traceback(ta, tb_stream));
+        HIP_TRY(ctx, score_only ? launch_scores_only(ta, tb_stream) : launch_traceback(ta, tb_stream));
         if (pe[3]) HIP_TRY(ctx, hipEventRecord(pe[3], tb_stream));
         if (overlap) {
             HIP_TRY(ctx, hipEventRecord(ctx->tb_done[h], ctx->aux));
@@ -565,7 +568,7 @@ int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const ui
     return run_device(ctx, static_cast<hipStream_t>(stream), n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext,
                       strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride,
                       d_cigar_len_out, d_status_out, 0, (flags & (MGL_SW_FLAG_UNIFORM_GEOMETRY | MGL_SW_FLAG_GROUPED_GEOMETRY)) != 0,
-                      (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0);
+                      (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, nullptr, nullptr, nullptr, (flags & MGL_SW_FLAG_SCORE_ONLY) != 0);
 }
 
 int mgl_sw_align_batch_device_indexed(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_targets,
@@ -582,7 +585,7 @@ int mgl_sw_align_batch_device_indexed(mgl_sw_ctx *ctx, void *stream, int64_t n, 
     return run_device(ctx, static_cast<hipStream_t>(stream), n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext,
                       strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride,
                       d_cigar_len_out, d_status_out, 0, (flags & (MGL_SW_FLAG_UNIFORM_GEOMETRY | MGL_SW_FLAG_GROUPED_GEOMETRY)) != 0,
-                      (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0);
+                      (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, nullptr, nullptr, nullptr, (flags & MGL_SW_FLAG_SCORE_ONLY) != 0);
 }
 
 int mgl_sw_align_batch_device_matrix(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_targets,
@@ -622,7 +625,7 @@ int mgl_sw_align_batch_device_matrix(mgl_sw_ctx *ctx, void *stream, int64_t n, c
     return run_device(ctx, st, n, ts, qs, max_tl, max_ql, cmax, cmin, gopen, gext, strategy, d_offset_out,
                       reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride, d_cigar_len_out, d_status_out, 0,
                       (flags & (MGL_SW_FLAG_UNIFORM_GEOMETRY | MGL_SW_FLAG_GROUPED_GEOMETRY)) != 0,
-                      (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, nullptr, dm, dc);
+                      (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, nullptr, dm, dc, (flags & MGL_SW_FLAG_SCORE_ONLY) != 0);
 }
 
 int mgl_sw_align_batch_device_2bit(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_target_bases,

@@ -64,6 +64,7 @@ struct DpArgs {
     const int8_t *matrix;     // MATRIX_DIM x MATRIX_DIM scores, row = target code, column = query code
     const uint8_t *code;      // byte -> 0 .. MATRIX_DIM-1
     int matrix_lds_offset;    // set by the launcher
+    int score_only;           // packed kernel: no traceback flags (MGL_SW_FLAG_SCORE_ONLY)
 };
 
 struct TbArgs {
@@ -130,6 +131,7 @@ hipError_t launch_dp(const DpArgs &a, int waves_per_block, int rows, hipStream_t
 int coop_lds_bytes(int sps_cap, int waves_per_block);
 hipError_t launch_dp_coop(const DpArgs &a, int waves_per_block, hipStream_t stream);
 hipError_t launch_traceback(const TbArgs &a, hipStream_t stream);
+hipError_t launch_scores_only(const TbArgs &a, hipStream_t stream); // DpRecord -> ScoreMax, no path walk
 hipError_t launch_cigar_from_matrix(const int32_t *btr, int tl, int ql, int strategy, const Score &ez, char *cigar,
                                     int cap, int32_t *out3, hipStream_t stream);
 hipError_t launch_expand(const uint32_t *tbw, const DpRecord *rec, int tl, int ql, int packed16, int half, int rows,

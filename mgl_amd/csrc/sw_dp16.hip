@@ -100,11 +100,13 @@ __device__ __forceinline__ unsigned sel_mask(unsigned a, unsigned b, unsigned lo
 // shifts the four decision flags into st.acc.  rh / re: carry for lane 0 of each group.
 // MATRIX (substitution-matrix scoring, sw_dp16_matrix_kernel): sub = {S[tA][qA] - max S, S[tB][qB] - max S}, looked up one
 // block ahead; the representation then uses max S where the DNA kernel uses `match`.
-template <bool MATRIX>
+// MODE bit 0: MATRIX; bit 1: score only (no traceback flags are formed or stored: MGL_SW_FLAG_SCORE_ONLY)
+template <int MODE>
 __device__ __forceinline__ void cell16(Lane16 &st, const unsigned rh, const unsigned re, const unsigned q,
                                        const unsigned tt, const Consts16 &c, unsigned &h, unsigned &eo, unsigned &fo,
                                        unsigned &hup_new, const unsigned sub)
 {
+    constexpr bool MATRIX = (MODE & 1) != 0, NOTB = (MODE & 2) != 0;
     hup_new = row_shr1(rh, st.h_prev);
     const unsigned ein = row_shr1(re, st.e_prev);
     unsigned diag;
@@ -114,22 +116,24 @@ __device__ __forceinline__ void cell16(Lane16 &st, const unsigned rh, const unsi
         const unsigned m = pk_min_u(q ^ tt, c.one);     // 1 where the bases differ
         diag = pk_mad(m, c.delta, st.hup);              // + (mismatch - match) on a mismatch
     }
-    const unsigned d1 = pk_sub_sat(diag, st.f);         // < 0 <=> F > diag
     const unsigned sm = pk_max(diag, st.f);
-    const unsigned d2 = pk_sub_sat(sm, ein);            // < 0 <=> E > max(diag, F)
     h = pk_max(sm, ein);
     const unsigned open_e = pk_sub(h, c.o_e);
     const unsigned open_f = pk_sub(h, c.o_f);
-    const unsigned d3 = pk_sub_sat(ein, open_e);        // < 0 <=> a new vertical gap wins
     eo = pk_max(open_e, ein);                           // extension is free in this representation
     const unsigned fe = pk_sub(st.f, c.e_f);
-    const unsigned d4 = pk_sub_sat(fe, open_f);         // < 0 <=> a new horizontal gap wins
     fo = pk_max(open_f, fe);
-    // sign bytes: [d2.A, d2.B, d1.A, d1.B] and [d4.A, d4.B, d3.A, d3.B]
-    const unsigned p12 = __builtin_amdgcn_perm(d1, d2, 0x07050301u);
-    const unsigned p34 = __builtin_amdgcn_perm(d3, d4, 0x07050301u);
-    const unsigned y = (p12 & 0x80808080u) | ((p34 >> 1) & ~0x80808080u);      // v_bfi_b32
-    st.acc = (y & 0xC0C0C0C0u) | ((st.acc >> 2) & ~0xC0C0C0C0u);                // v_bfi_b32
+    if (!NOTB) {
+        const unsigned d1 = pk_sub_sat(diag, st.f);     // < 0 <=> F > diag
+        const unsigned d2 = pk_sub_sat(sm, ein);        // < 0 <=> E > max(diag, F)
+        const unsigned d3 = pk_sub_sat(ein, open_e);    // < 0 <=> a new vertical gap wins
+        const unsigned d4 = pk_sub_sat(fe, open_f);     // < 0 <=> a new horizontal gap wins
+        // sign bytes: [d2.A, d2.B, d1.A, d1.B] and [d4.A, d4.B, d3.A, d3.B]
+        const unsigned p12 = __builtin_amdgcn_perm(d1, d2, 0x07050301u);
+        const unsigned p34 = __builtin_amdgcn_perm(d3, d4, 0x07050301u);
+        const unsigned y = (p12 & 0x80808080u) | ((p34 >> 1) & ~0x80808080u);      // v_bfi_b32
+        st.acc = (y & 0xC0C0C0C0u) | ((st.acc >> 2) & ~0xC0C0C0C0u);                // v_bfi_b32
+    }
 }
 
 __device__ __forceinline__ void commit16(Lane16 &st, unsigned h, unsigned eo, unsigned fo, unsigned hup_new)
@@ -145,7 +149,7 @@ __device__ __forceinline__ void commit16(Lane16 &st, unsigned h, unsigned eo, un
 // Stand-alone stripe (own pipeline fill and drain), four steps.
 //   PRO : some lane may still be at column <= 0 (forced border values)
 //   EPI : some lane may be at its last column (capture H[i][ql])
-template <bool PRO, bool EPI, bool MATRIX>
+template <bool PRO, bool EPI, int MODE>
 __device__ __forceinline__ void step4_16(Lane16 &st, uint4 &ringA, uint4 &ringB, const uint4 *ring_next,
                                          const unsigned (&qq)[4], const unsigned tt, const int s0, const int L,
                                          const unsigned hb, const int ql, const Consts16 &c, uint2 *ring_wr,
@@ -156,7 +160,7 @@ __device__ __forceinline__ void step4_16(Lane16 &st, uint4 &ringA, uint4 &ringB,
         const unsigned rh = RING_U(u, ringA, ringB, x, z), re = RING_U(u, ringA, ringB, y, w);
         if (u == 2) ringA = ring_next[0];
         unsigned h, eo, fo, hup_new;
-        cell16<MATRIX>(st, rh, re, qq[u], tt, c, h, eo, fo, hup_new, sub[u]);
+        cell16<MODE>(st, rh, re, qq[u], tt, c, h, eo, fo, hup_new, sub[u]);
         if (PRO) {
             const bool at_border = (s0 + u) <= L; // column <= 0
             h = at_border ? hb : h;
@@ -171,7 +175,7 @@ __device__ __forceinline__ void step4_16(Lane16 &st, uint4 &ringA, uint4 &ringB,
 
 // Chained stripes, lean part of a period: no lane is at a border; with CAP the lanes that reach the
 // last column inside this block (lanes < P - ql, last block of the period) capture it.
-template <bool CAP, bool MATRIX>
+template <bool CAP, int MODE>
 __device__ __forceinline__ void lean4_16(Lane16 &st, uint4 &ringA, uint4 &ringB, const uint4 *ring_next,
                                          const unsigned (&qq)[4], const unsigned tt, const int col0, const int L,
                                          const int ql, const Consts16 &c, uint2 *ring_wr, const bool writer,
@@ -182,7 +186,7 @@ __device__ __forceinline__ void lean4_16(Lane16 &st, uint4 &ringA, uint4 &ringB,
         const unsigned rh = RING_U(u, ringA, ringB, x, z), re = RING_U(u, ringA, ringB, y, w);
         if (u == 2) ringA = ring_next[0];
         unsigned h, eo, fo, hup_new;
-        cell16<MATRIX>(st, rh, re, qq[u], tt, c, h, eo, fo, hup_new, sub[u]);
+        cell16<MODE>(st, rh, re, qq[u], tt, c, h, eo, fo, hup_new, sub[u]);
         if (CAP) st.cap = ((col0 + u - L) == ql) ? h : st.cap;
         if (writer) ring_wr[u] = make_uint2(h, eo);
         commit16(st, h, eo, fo, hup_new);
@@ -195,7 +199,7 @@ __device__ __forceinline__ void lean4_16(Lane16 &st, uint4 &ringA, uint4 &ringB,
 // k-1.  All lane selections use constant SGPR masks.  Block b covers window steps 4b .. 4b+3.
 //   FIRST : k == 0, nothing to finish or publish yet (lane 15 has not started)
 //   LAST  : k == number of chained stripes: lanes leave into nothing; lane 15 must not publish column 0
-template <int B, bool FIRST, bool LAST, bool MATRIX>
+template <int B, bool FIRST, bool LAST, int MODE>
 __device__ __forceinline__ void window4_16(Lane16 &st, uint4 &ringA, uint4 &ringB, const uint4 *ring_next,
                                            const unsigned (&qq)[4], unsigned &tt, const unsigned tt_nxt,
                                            const unsigned hb_nxt, const unsigned hbf_nxt, const int cgap,
@@ -209,7 +213,7 @@ __device__ __forceinline__ void window4_16(Lane16 &st, uint4 &ringA, uint4 &ring
         const unsigned rh = RING_U(t, ringA, ringB, x, z), re = RING_U(t, ringA, ringB, y, w);
         if (t == 2) ringA = ring_next[0];
         unsigned h, eo, fo, hup_new;
-        cell16<MATRIX>(st, rh, re, qq[t], tt, c, h, eo, fo, hup_new, sub[t]);
+        cell16<MODE>(st, rh, re, qq[t], tt, c, h, eo, fo, hup_new, sub[t]);
         const unsigned long long m_u = ROWS << u;
         if (!FIRST) {
             // lane u + cgap sits on column ql of the stripe it is finishing
@@ -252,9 +256,10 @@ __device__ __forceinline__ unsigned tt_at(const unsigned tt, const unsigned tt_n
     return sel_mask(tt, tt_new, LE);
 }
 
-template <bool MATRIX>
+template <int MODE>
 __device__ __forceinline__ void sw_dp16_body(const DpArgs &a, unsigned char *smem, const short *lut)
 {
+    constexpr bool MATRIX = (MODE & 1) != 0, NOTB = (MODE & 2) != 0;
     unsigned long long diag_t0 = 0, diag_w0 = 0;
     if (a.diag) { // in-kernel clock probe (MI355X_MICROARCH.md, DVFS give-back item 6); off in normal runs
         diag_t0 = __builtin_amdgcn_s_memtime();
@@ -346,7 +351,7 @@ __device__ __forceinline__ void sw_dp16_body(const DpArgs &a, unsigned char *sme
     unsigned tb_hold = 0;
 
 #define MGL_TB_ADVANCE()                                                                                  \
-    {                                                                                                     \
+    if (!NOTB) {                                                                                          \
         gsteps += 4;                                                                                      \
         if (gsteps & 4) {                                                                                 \
             tb_hold = st.acc;                                                                             \
@@ -418,7 +423,7 @@ __device__ __forceinline__ void sw_dp16_body(const DpArgs &a, unsigned char *sme
             ns2 = lut2(lut, tt_at<4 * (B) + 6>(tt, tt_new), n2);                                          \
             ns3 = lut2(lut, tt_at<4 * (B) + 7>(tt, tt_new), n3);                                          \
         }                                                                                                 \
-        window4_16<B, FIRST, LAST, MATRIX>(st, rA, rB, ring_rd + 2, qv, tt, tt_new, hb_new, hbf_new, cgap, c, \
+        window4_16<B, FIRST, LAST, MODE>(st, rA, rB, ring_rd + 2, qv, tt, tt_new, hb_new, hbf_new, cgap, c, \
                                            ring_tail, ring + 16, lane15, sub);                            \
         sub[0] = ns0;                                                                                     \
         sub[1] = ns1;                                                                                     \
@@ -478,7 +483,7 @@ __device__ __forceinline__ void sw_dp16_body(const DpArgs &a, unsigned char *sme
                 ns3 = lut2(lut, tt, n3);                                                                  \
             }                                                                                             \
         }                                                                                                 \
-        lean4_16<CAP, MATRIX>(st, rA, rB, NEXT, qv, tt, s, L, ql, c, ring_wr, lane15, sub);               \
+        lean4_16<CAP, MODE>(st, rA, rB, NEXT, qv, tt, s, L, ql, c, ring_wr, lane15, sub);               \
         sub[0] = ns0;                                                                                     \
         sub[1] = ns1;                                                                                     \
         sub[2] = ns2;                                                                                     \
@@ -541,7 +546,7 @@ __device__ __forceinline__ void sw_dp16_body(const DpArgs &a, unsigned char *sme
             ns2 = lut2(lut, tt, n2);                                                                      \
             ns3 = lut2(lut, tt, n3);                                                                      \
         }                                                                                                 \
-        step4_16<PRO, EPI, MATRIX>(st, rA, rB, ring_rd + 2, qv, tt, s, L, hb, ql, c, ring_wr, writer, sub); \
+        step4_16<PRO, EPI, MODE>(st, rA, rB, ring_rd + 2, qv, tt, s, L, hb, ql, c, ring_wr, writer, sub); \
         sub[0] = ns0;                                                                                     \
         sub[1] = ns1;                                                                                     \
         sub[2] = ns2;                                                                                     \
@@ -570,7 +575,7 @@ __device__ __forceinline__ void sw_dp16_body(const DpArgs &a, unsigned char *sme
 #undef MGL_TB_ADVANCE
 #undef MGL_TAKE_CAP
 
-    if ((gsteps & 4) && gvalid) *reinterpret_cast<uint2 *>(tbp) = make_uint2(tb_hold, 0u);
+    if (!NOTB && (gsteps & 4) && gvalid) *reinterpret_cast<uint2 *>(tbp) = make_uint2(tb_hold, 0u);
 
     // global step at which the stand-alone stripes start (the traceback kernel needs it to find their cells)
     const int g_tail = nc ? nc * P + 16 : 0;
@@ -633,7 +638,14 @@ __device__ __forceinline__ void sw_dp16_body(const DpArgs &a, unsigned char *sme
 __global__ __launch_bounds__(256) void sw_dp16_kernel(const DpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    sw_dp16_body<false>(a, smem, nullptr);
+    sw_dp16_body<0>(a, smem, nullptr);
+}
+
+// MGL_SW_FLAG_SCORE_ONLY: the same fill without the four traceback flags (10 of its 22 instructions per step)
+__global__ __launch_bounds__(256) void sw_dp16_score_kernel(const DpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    sw_dp16_body<2>(a, smem, nullptr);
 }
 
 // substitution-matrix scoring (protein extension, no reference path): a.match = the largest matrix entry; the table
@@ -644,7 +656,16 @@ __global__ __launch_bounds__(256) void sw_dp16_matrix_kernel(const DpArgs a)
     short *lut = reinterpret_cast<short *>(smem + a.matrix_lds_offset);
     for (int x = threadIdx.x; x < MATRIX_DIM * MATRIX_DIM; x += blockDim.x) lut[x] = (short)((int)a.matrix[x] - a.match);
     __syncthreads();
-    sw_dp16_body<true>(a, smem, lut);
+    sw_dp16_body<1>(a, smem, lut);
+}
+
+__global__ __launch_bounds__(256) void sw_dp16_matrix_score_kernel(const DpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    short *lut = reinterpret_cast<short *>(smem + a.matrix_lds_offset);
+    for (int x = threadIdx.x; x < MATRIX_DIM * MATRIX_DIM; x += blockDim.x) lut[x] = (short)((int)a.matrix[x] - a.match);
+    __syncthreads();
+    sw_dp16_body<3>(a, smem, lut);
 }
 
 int dp16_lds_bytes(int sps, int waves_per_block)
@@ -684,12 +705,21 @@ hipError_t launch_dp16(const DpArgs &a, int waves_per_block, hipStream_t stream)
         DpArgs b = a;
         b.matrix_lds_offset = lds;
         const int lds_m = lds + MATRIX_DIM * MATRIX_DIM * 2;
+        auto kernel = a.score_only ? sw_dp16_matrix_score_kernel : sw_dp16_matrix_kernel;
         if (lds_m > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_dp16_matrix_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_m);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_m);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(sw_dp16_matrix_kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), lds_m, stream, b);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), lds_m, stream, b);
+        return hipGetLastError();
+    }
+    if (a.score_only) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_dp16_score_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(sw_dp16_score_kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), lds, stream, a);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(sw_dp16_kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), lds, stream, a);

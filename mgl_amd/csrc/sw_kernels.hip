@@ -908,6 +908,34 @@ hipError_t launch_dp(const DpArgs &a, int waves_per_block, int rows, hipStream_t
     return hipGetLastError();
 }
 
+// MGL_SW_FLAG_SCORE_ONLY: hand the fill kernel's ScoreMax to the caller, no path walk (offset 0, empty CIGAR)
+__global__ __launch_bounds__(256) void sw_scores_only_kernel(const TbArgs a)
+{
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.count) return;
+    const int64_t p = a.first + slot;
+    const DpRecord r = a.rec[slot];
+    a.offset[p] = 0;
+    if (a.cigar_len) a.cigar_len[p] = 0;
+    if (a.status) a.status[p] = 0;
+    if (a.score) {
+        Score sc;
+        sc.mqe = r.mqe;
+        sc.mqe_t = r.mqe_t;
+        sc.max = r.max;
+        sc.max_t = r.max_t;
+        sc.max_q = r.max_q;
+        sc.seg_length = r.seg;
+        a.score[p] = sc;
+    }
+}
+
+hipError_t launch_scores_only(const TbArgs &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(sw_scores_only_kernel, dim3((unsigned)((a.count + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_traceback(const TbArgs &a, hipStream_t stream)
 {
     if (!a.packed16 && a.rows_per_stripe == 64) {

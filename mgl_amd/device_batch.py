@@ -40,12 +40,14 @@ class DeviceBatch:
         return int((tl * ql).sum().item())
 
     def run(self, aligner, parameters=GATK_PARAMETERS, overhang_strategy=SWOverhangStrategy.SOFTCLIP, stream=None,
-            binary_cigar=False):
-        """Enqueue fill + traceback on ``stream`` (default: torch's current stream); no sync."""
+            binary_cigar=False, score_only=False):
+        """Enqueue fill + traceback on ``stream`` (default: torch's current stream); no sync.  ``score_only``:
+        MGL_SW_FLAG_SCORE_ONLY (only ``scores`` is wanted; batches on the packed kernel skip the traceback)."""
         if stream is None:
             stream = torch.cuda.current_stream(self.targets.device)
         p = SWParameters(*parameters)
-        flags = (_lib.FLAG_UNIFORM_GEOMETRY if self.uniform else 0) | (_lib.FLAG_BINARY_CIGAR if binary_cigar else 0)
+        flags = (_lib.FLAG_UNIFORM_GEOMETRY if self.uniform else 0) | (_lib.FLAG_BINARY_CIGAR if binary_cigar else 0) | (
+            _lib.FLAG_SCORE_ONLY if score_only else 0)
         rc = _lib.lib().mgl_sw_align_batch_device(
             aligner.ctx, C.c_void_p(stream.cuda_stream), self.n, self.targets.data_ptr(), self.t_off.data_ptr(),
             self.queries.data_ptr(), self.q_off.data_ptr(), self.max_tl, self.max_ql, p.match, p.mismatch,

@@ -89,7 +89,7 @@ class IndexedBatch:
 
 
 def run_matrix(batch, aligner, code, matrix, gap_open=11, gap_extend=1, overhang_strategy=1, stream=None, binary_cigar=False,
-               grouped=False):
+               grouped=False, score_only=False):
     """mgl_sw_align_batch_device_matrix on a device_batch.DeviceBatch / IndexedBatch (ASCII wire format); no sync.
     ``grouped``: every aligned block of eight pairs has one (tl, ql) (MGL_SW_FLAG_GROUPED_GEOMETRY) -- true for a
     database search laid out as pair = d * Q + q with Q a multiple of eight -- which makes the packed-int16 kernel
@@ -110,6 +110,6 @@ def run_matrix(batch, aligner, code, matrix, gap_open=11, gap_extend=1, overhang
         int(gap_open), int(gap_extend), int(overhang_strategy), batch.offsets.data_ptr(), batch.scores.data_ptr(),
         batch.cigars.data_ptr(), batch.cigar_stride, batch.cigar_len.data_ptr(), batch.status.data_ptr(),
         (_lib.FLAG_BINARY_CIGAR if binary_cigar else 0) | (_lib.FLAG_GROUPED_GEOMETRY if grouped else 0) |
-        (_lib.FLAG_UNIFORM_GEOMETRY if getattr(batch, "uniform", False) else 0))
+        (_lib.FLAG_UNIFORM_GEOMETRY if getattr(batch, "uniform", False) else 0) | (_lib.FLAG_SCORE_ONLY if score_only else 0))
     if rc != _lib.OK:
         raise _lib.MglSwError(rc, L.mgl_sw_last_error(aligner.ctx).decode())

