@@ -9,6 +9,7 @@
 // the direct call would have produced.  Host code only: queues, one std::thread, condition variables.
 #include "../../include/mgl_sw.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -119,12 +120,13 @@ class Coalescer {
             // pick the queue that is full, or whose oldest request has waited long enough; otherwise sleep until
             // the earliest deadline (new arrivals wake us up too)
             const auto now = std::chrono::steady_clock::now();
+            const int max_batch = std::max(1, max_batch_); // coalescing switched off with requests still queued: drain them
             const Key *ready = nullptr;
             auto earliest = now + std::chrono::hours(1);
             for (auto &kv : queues_) {
                 if (kv.second.empty()) continue;
                 const auto deadline = oldest_[kv.first] + std::chrono::microseconds(max_wait_us_);
-                if ((int)kv.second.size() >= max_batch_ || deadline <= now) {
+                if ((int)kv.second.size() >= max_batch || deadline <= now) {
                     ready = &kv.first;
                     break;
                 }
@@ -137,7 +139,7 @@ class Coalescer {
             const Key key = *ready;
             auto &qd = queues_[key];
             std::vector<Request *> batch;
-            while (!qd.empty() && (int)batch.size() < max_batch_) {
+            while (!qd.empty() && (int)batch.size() < max_batch) {
                 batch.push_back(qd.front());
                 qd.pop_front();
             }

@@ -75,6 +75,8 @@ struct mgl_sw_ctx {
     hipEvent_t fill_done[2] = {nullptr, nullptr};    // fill of the chunk in half h finished (caller's stream)
     hipEvent_t tb_done[2] = {nullptr, nullptr};      // traceback of the chunk in half h finished (aux stream)
     int last_half = 0;
+    hipEvent_t ws_idle = nullptr;   // recorded when a call's last kernel has been enqueued: the next call (possibly on
+    bool ws_idle_set = false;       // another stream) waits for it before it reuses the workspace
     // profiling: event pairs around every fill (caller's stream) and traceback (aux or caller's stream) launch of
     // the last call; read back lazily by mgl_sw_ctx_get_timing so that the run itself is not serialised
     std::vector<hipEvent_t> pool;
@@ -242,6 +244,9 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     }
     if (coop_waves) HIP_TRY(ctx, ctx->scratch.reserve((size_t)chunk * coop_wrap_cols(sps_cap) * 8)); // one carry row per pair
 
+    // the workspace belongs to the context, not to a stream: order this call behind the previous one's kernels
+    if (ctx->ws_idle_set) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ws_idle, 0));
+
     ctx->timing = mgl_sw_timing{};
     ctx->timing.cells = cells_hint;
     ctx->pool_used = 0;
@@ -364,6 +369,8 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // everything this call enqueued is ordered before whatever the caller enqueues next on `stream`
     for (int h = 0; h < 2; ++h)
         if (tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->tb_done[h], 0));
+    HIP_TRY(ctx, hipEventRecord(ctx->ws_idle, stream));
+    ctx->ws_idle_set = true;
     return MGL_SW_OK;
 }
 
@@ -431,6 +438,7 @@ int mgl_sw_ctx_create(int device, mgl_sw_ctx **out)
     ok = ok && hipEventCreateWithFlags(&ctx->in_done, hipEventDisableTiming) == hipSuccess;
     for (auto &e : ctx->out_ready) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->ws_idle, hipEventDisableTiming) == hipSuccess;
     for (auto *set : {ctx->fill_done, ctx->tb_done})
         for (int h = 0; h < 2; ++h) ok = ok && hipEventCreateWithFlags(&set[h], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
@@ -459,6 +467,7 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
             if (set[h]) (void)hipEventDestroy(set[h]);
     if (ctx->pin_matrix) (void)hipHostFree(ctx->pin_matrix);
     if (ctx->matrix_copied) (void)hipEventDestroy(ctx->matrix_copied);
+    if (ctx->ws_idle) (void)hipEventDestroy(ctx->ws_idle);
     if (ctx->pin_in) (void)hipHostFree(ctx->pin_in);
     if (ctx->pin_out) (void)hipHostFree(ctx->pin_out);
     ctx->stage_in.release();
@@ -611,6 +620,7 @@ int mgl_sw_align_batch_device_matrix(mgl_sw_ctx *ctx, void *stream, int64_t n, c
     } else {
         HIP_TRY(ctx, hipEventSynchronize(ctx->matrix_copied)); // the previous call's copy has left the staging buffer
     }
+    if (ctx->ws_idle_set) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ws_idle, 0)); // the previous call's kernels read d_matrix
     memcpy(ctx->pin_matrix, matrix, MATRIX_DIM * MATRIX_DIM);
     memcpy(static_cast<char *>(ctx->pin_matrix) + MATRIX_DIM * MATRIX_DIM, code, 256);
     HIP_TRY(ctx, hipMemcpyAsync(dm, ctx->pin_matrix, MATRIX_DIM * MATRIX_DIM + 256, hipMemcpyHostToDevice, st));
@@ -646,7 +656,8 @@ int mgl_sw_align_batch_device_2bit(mgl_sw_ctx *ctx, void *stream, int64_t n, con
         qs{d_query_bases, d_q_start, uniform ? nullptr : d_q_len, max_ql, 1};
     return run_device(ctx, static_cast<hipStream_t>(stream), n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext,
                       strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride,
-                      d_cigar_len_out, d_status_out, 0, uniform || grouped, (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0);
+                      d_cigar_len_out, d_status_out, 0, uniform || grouped, (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, nullptr, nullptr,
+                      nullptr, (flags & MGL_SW_FLAG_SCORE_ONLY) != 0);
 }
 
 // mgl_sw_align_batch with an optional per-pair status array: with it, a CIGAR overflow of one pair does not
@@ -862,14 +873,10 @@ static mgl_sw_ctx *thread_ctx(int *rc)
     return h.ctx;
 }
 
-int mgl_sw_align(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen, int gext,
-                 int strategy, char *cigar, int cigar_cap, int *cigar_len, int *offset, mgl_sw_score *ez)
+// one pair on the calling thread's own context (no coalescing)
+static int align_direct(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen, int gext,
+                        int strategy, char *cigar, int cigar_cap, int *cigar_len, int *offset, mgl_sw_score *ez)
 {
-    if (!t || !q || tl < 1 || ql < 1 || !cigar || cigar_cap < 1 || !cigar_len || !offset || !strategy_ok(strategy))
-        return MGL_SW_ERR_BAD_ARG;
-    if (mgl_sw_coalescing_enabled())
-        return mgl_sw_coalesced_align(t, tl, q, ql, match, mismatch, gopen, gext, strategy, cigar, cigar_cap, cigar_len,
-                                      offset, ez);
     int rc;
     mgl_sw_ctx *ctx = thread_ctx(&rc);
     if (!ctx) return rc;
@@ -885,6 +892,17 @@ int mgl_sw_align(const char *t, int tl, const char *q, int ql, int match, int mi
     *offset = off;
     if (ez) *ez = sc;
     return MGL_SW_OK;
+}
+
+int mgl_sw_align(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen, int gext,
+                 int strategy, char *cigar, int cigar_cap, int *cigar_len, int *offset, mgl_sw_score *ez)
+{
+    if (!t || !q || tl < 1 || ql < 1 || !cigar || cigar_cap < 1 || !cigar_len || !offset || !strategy_ok(strategy))
+        return MGL_SW_ERR_BAD_ARG;
+    if (mgl_sw_coalescing_enabled())
+        return mgl_sw_coalesced_align(t, tl, q, ql, match, mismatch, gopen, gext, strategy, cigar, cigar_cap, cigar_len,
+                                      offset, ez);
+    return align_direct(t, tl, q, ql, match, mismatch, gopen, gext, strategy, cigar, cigar_cap, cigar_len, offset, ez);
 }
 
 int mgl_sw_ctx_expand_slot(mgl_sw_ctx *ctx, int64_t slot, int tl, int ql, int32_t *btr)
@@ -957,7 +975,8 @@ int mgl_sw_backtrack_matrix(const char *t, int tl, const char *q, int ql, int ma
     std::vector<char> cig((size_t)(tl + ql + 4) * 12);
     int len = 0, off = 0;
     mgl_sw_score sc;
-    rc = mgl_sw_align(t, tl, q, ql, match, mismatch, gopen, gext, strategy, cig.data(), (int)cig.size(), &len, &off, &sc);
+    // always on this thread's context (never through the coalescing front-end): the expansion below reads its workspace
+    rc = align_direct(t, tl, q, ql, match, mismatch, gopen, gext, strategy, cig.data(), (int)cig.size(), &len, &off, &sc);
     if (rc != MGL_SW_OK) return rc;
     rc = mgl_sw_ctx_expand_slot(ctx, 0, tl, ql, btr);
     if (rc == MGL_SW_OK && ez) *ez = sc;

@@ -100,7 +100,10 @@ __host__ __device__ inline int64_t tb_words_for(int tl, int sps, int rows)
 
 // ---- schedule of sw_dp16_kernel (sw_dp16.hip): the first nc stripes run as one continuous pipeline with
 // period P steps per stripe (+ one 16-step drain window), the rest stand-alone with sps_for(ql) steps each
-__host__ __device__ inline int dp16_base(int tl, int gext) { return 32767 - gext * tl; }
+__host__ __device__ inline int dp16_base(int tl, int ql, int match, int gext)
+{
+    return 32767 - match * (tl < ql ? tl : ql) - gext * (tl + ql);
+}
 __host__ __device__ inline int dp16_period(int ql) { return (ql + 1 + 3) & ~3; }
 __host__ __device__ inline int dp16_chained_stripes(int tl, int ql)
 {

@@ -8,16 +8,15 @@
 // two cells.
 //
 // 16-bit representation.  A cell value is stored as
-//        v = X[i][j] + i*e - j*(match+e) + BASE      (X = H, E or F;  e = gap extend)
+//        v = X[i][j] + (i + j)*e + BASE               (X = H, E or F;  e = gap extend)
 // i.e. a per-cell offset that is linear in (i, j).  Consequences:
-//   * diag = H[i-1][j-1] + s(t,q)  becomes  v_diag = v_hup + (t==q ? 0 : mismatch-match): the constant of
-//     the match case vanishes, so the substitution score is  m*delta  with m = min(t^q, 1) -- one
-//     v_pk_mad_i16, no compare/select (there is no packed compare on CDNA4);
-//   * E moves one row down: E' = max(H - (o-e), E) -- extending a vertical gap costs NO instruction;
-//     F moves one column right: F' = max(H - (o+match+e), F - (match+2e));
-//   * H <= match*min(i,j), so v <= BASE + e*(i-j) <= BASE + e*tl, and v >= BASE - (match+2e)*ql - (gap
-//     terms): the span is about match*ql + e*(tl+2ql), checked by the host (dp16_range_ok()); BASE
-//     puts the top of that span at +32767;
+//   * extending a gap costs NO instruction in either direction: E moves one row down, F one column right, and
+//     both become  max(H - (o-e), E or F)  with ONE shared  H - (o-e);
+//   * diag = H[i-1][j-1] + s(t,q)  becomes  v_hup + (match+2e) + m*(mismatch-match)  with m = min(t^q, 1): one
+//     v_pk_mad_i16 off the dependency chain plus one add -- no compare/select (there is no packed compare on CDNA4);
+//   * H <= match*min(i,j), so v <= BASE + match*min(tl,ql) + e*(tl+ql), and X >= -2o - (i+j-2)*e (the all-gap path
+//     from a border), so v >= BASE - 2o + 2e: the span is match*min(tl,ql) + e*(tl+ql) + 3o + |mismatch|, checked by
+//     the host (dp16_range_ok()); BASE puts the top of that span at +32767;
 //   * comparisons between cells of the same (i,j) are unaffected, so all decisions -- hence the
 //     traceback -- are bit-identical to the int32 kernel; true scores are recovered where they are
 //     read (last column, last row).
@@ -32,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+
+#include <algorithm>
 
 #include "sw_device.h"
 
@@ -85,7 +86,7 @@ struct Lane16 {
 };
 
 struct Consts16 {
-    unsigned delta, one, o_e, o_f, e_f; // packed constants (both halves equal)
+    unsigned delta, one, o_e, k2; // packed constants (both halves equal): mismatch-match, 1, o-e, match+2e
 };
 
 // mask bit set ? b : a   (mask is a wave-uniform 64-bit lane mask held in SGPRs: no VALU compare)
@@ -114,20 +115,19 @@ __device__ __forceinline__ void cell16(Lane16 &st, const unsigned rh, const unsi
         diag = as_u(as_s2(st.hup) + as_s2(sub));
     } else {
         const unsigned m = pk_min_u(q ^ tt, c.one);     // 1 where the bases differ
-        diag = pk_mad(m, c.delta, st.hup);              // + (mismatch - match) on a mismatch
+        const unsigned s = pk_mad(m, c.delta, c.k2);    // match + 2e, or mismatch + 2e (not on the dependency chain)
+        diag = as_u(as_s2(st.hup) + as_s2(s));
     }
     const unsigned sm = pk_max(diag, st.f);
     h = pk_max(sm, ein);
-    const unsigned open_e = pk_sub(h, c.o_e);
-    const unsigned open_f = pk_sub(h, c.o_f);
-    eo = pk_max(open_e, ein);                           // extension is free in this representation
-    const unsigned fe = pk_sub(st.f, c.e_f);
-    fo = pk_max(open_f, fe);
+    const unsigned open = pk_sub(h, c.o_e);             // a new gap, either direction
+    eo = pk_max(open, ein);                             // extension is free in this representation
+    fo = pk_max(open, st.f);
     if (!NOTB) {
         const unsigned d1 = pk_sub_sat(diag, st.f);     // < 0 <=> F > diag
         const unsigned d2 = pk_sub_sat(sm, ein);        // < 0 <=> E > max(diag, F)
-        const unsigned d3 = pk_sub_sat(ein, open_e);    // < 0 <=> a new vertical gap wins
-        const unsigned d4 = pk_sub_sat(fe, open_f);     // < 0 <=> a new horizontal gap wins
+        const unsigned d3 = pk_sub_sat(ein, open);      // < 0 <=> a new vertical gap wins
+        const unsigned d4 = pk_sub_sat(st.f, open);     // < 0 <=> a new horizontal gap wins
         // sign bytes: [d2.A, d2.B, d1.A, d1.B] and [d4.A, d4.B, d3.A, d3.B]
         const unsigned p12 = __builtin_amdgcn_perm(d1, d2, 0x07050301u);
         const unsigned p34 = __builtin_amdgcn_perm(d3, d4, 0x07050301u);
@@ -164,7 +164,7 @@ __device__ __forceinline__ void step4_16(Lane16 &st, uint4 &ringA, uint4 &ringB,
         if (PRO) {
             const bool at_border = (s0 + u) <= L; // column <= 0
             h = at_border ? hb : h;
-            fo = at_border ? pk_sub(hb, c.o_f) : fo;
+            fo = at_border ? pk_sub(hb, c.o_e) : fo;
         }
         if (EPI) st.cap = ((s0 + u - L) == ql) ? h : st.cap;
         if (writer) ring_wr[u] = make_uint2(h, eo);
@@ -308,12 +308,11 @@ __device__ __forceinline__ void sw_dp16_body(const DpArgs &a, unsigned char *sme
     Consts16 c;
     c.delta = pack2(a.mismatch - match, a.mismatch - match);
     c.one = pack2(1, 1);
-    const int colw = match + gext;          // column offset per j
-    const int base = dp16_base(tl, gext);    // BASE: the largest stored value is exactly 32767
+    const int colw = -gext;                  // stored = X + i*gext - j*colw + BASE
+    const int base = dp16_base(tl, ql, match, gext); // BASE: no stored value of a valid cell exceeds 32767
     c.o_e = pack2(gopen - gext, gopen - gext);
-    c.o_f = pack2(gopen + colw, gopen + colw);
-    c.e_f = pack2(gext + colw, gext + colw);
-    asm volatile("" : "+v"(c.delta), "+v"(c.one), "+v"(c.o_e), "+v"(c.o_f), "+v"(c.e_f));
+    c.k2 = pack2(match + 2 * gext, match + 2 * gext);
+    asm volatile("" : "+v"(c.delta), "+v"(c.one), "+v"(c.o_e), "+v"(c.k2));
 
     // ---- stage the two queries interleaved.  qq[x] is the base of column x - 15 (x - 16 as 0-based query
     // index); beyond column P - 1 the array repeats with period P, so a chained lane keeps incrementing its
@@ -406,7 +405,7 @@ __device__ __forceinline__ void sw_dp16_body(const DpArgs &a, unsigned char *sme
             const unsigned tt_new = tt_next;
             const int hbv = border(row_new, gopen, gext, indel) + row_new * gext + base; // column 0 of the new row
             const unsigned hb_new = pack2(hbv, hbv);
-            const unsigned hbf_new = pk_sub(hb_new, c.o_f);
+            const unsigned hbf_new = pk_sub(hb_new, c.o_e);
             if (k < nc) {
                 row_next += 16;
                 tt_next = (row_next <= tl) ? MGL_TT_PACK(row_next) : 0u;
@@ -648,13 +647,13 @@ __global__ __launch_bounds__(256) void sw_dp16_score_kernel(const DpArgs a)
     sw_dp16_body<2>(a, smem, nullptr);
 }
 
-// substitution-matrix scoring (protein extension, no reference path): a.match = the largest matrix entry; the table
-// S - max S (int16, 2 KB) sits in LDS behind the per-group carves
+// substitution-matrix scoring (protein extension, no reference path): a.match = the largest matrix entry (range check
+// and BASE); the table S + 2e (int16, 2 KB) sits in LDS behind the per-group carves
 __global__ __launch_bounds__(256) void sw_dp16_matrix_kernel(const DpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     short *lut = reinterpret_cast<short *>(smem + a.matrix_lds_offset);
-    for (int x = threadIdx.x; x < MATRIX_DIM * MATRIX_DIM; x += blockDim.x) lut[x] = (short)((int)a.matrix[x] - a.match);
+    for (int x = threadIdx.x; x < MATRIX_DIM * MATRIX_DIM; x += blockDim.x) lut[x] = (short)((int)a.matrix[x] + 2 * a.gext);
     __syncthreads();
     sw_dp16_body<1>(a, smem, lut);
 }
@@ -663,7 +662,7 @@ __global__ __launch_bounds__(256) void sw_dp16_matrix_score_kernel(const DpArgs 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     short *lut = reinterpret_cast<short *>(smem + a.matrix_lds_offset);
-    for (int x = threadIdx.x; x < MATRIX_DIM * MATRIX_DIM; x += blockDim.x) lut[x] = (short)((int)a.matrix[x] - a.match);
+    for (int x = threadIdx.x; x < MATRIX_DIM * MATRIX_DIM; x += blockDim.x) lut[x] = (short)((int)a.matrix[x] + 2 * a.gext);
     __syncthreads();
     sw_dp16_body<3>(a, smem, lut);
 }
@@ -674,20 +673,17 @@ int dp16_lds_bytes(int sps, int waves_per_block)
 }
 
 // Can every stored value of a tl x ql problem with these (normalised) parameters be held in 16 bits?
-// stored = X + i*e - j*(match+e) + BASE with BASE = 32767 - e*tl (dp16_base): X <= match*min(i,j) gives
-// stored <= BASE + e*(i-j) <= 32767.
+// stored = X + (i+j)*e + BASE: X <= match*min(i,j) bounds the top (dp16_base puts it at 32767); the all-gap path from a
+// border bounds every H, E, F of a valid cell from below by -2o - (i+j-2)*e, i.e. stored >= BASE - 2o + 2e; the
+// intermediates (H - (o-e), diag on a mismatch) go at most max(o, |mismatch|) lower.
 bool dp16_range_ok(int tl, int ql, int match, int mismatch, int gopen, int gext, int strategy)
 {
-    const bool indel = (strategy & (OS_INDEL | OS_LEAD_ID)) != 0;
-    const int64_t colw = (int64_t)match + gext;
-    // lowest H: the cheapest gap path from a border (sw.cpp:29-40), at i >= 0, j = ql
-    int64_t low = -(gopen + (int64_t)(ql - 1) * gext) - colw * ql;
-    if (indel) low -= gopen + (int64_t)(tl - 1) * gext;
-    // E / F / open / extend / diag intermediates below H
-    low -= 2 * (gopen + colw) + (gext + colw) + ((int64_t)match - mismatch);
-    const int64_t base = 32767 - (int64_t)gext * tl;
-    return low + base >= -32768 + 16 && match > 0 && (int64_t)match - mismatch <= 30000 && gopen + colw <= 30000 &&
-           gext + colw <= 30000 && (int64_t)gext * tl <= 30000;
+    (void)strategy; // the bound holds for every border rule (sw.cpp:29-40: INDEL borders are the lowest)
+    if (match <= 0 || gopen < gext) return false;
+    const int64_t top = (int64_t)match * std::min(tl, ql) + (int64_t)gext * ((int64_t)tl + ql);
+    const int64_t low = -3 * (int64_t)gopen - ((int64_t)match - mismatch) - 2 * (int64_t)gext - 64;
+    return 32767 - top + low >= -32768 && (int64_t)match - mismatch <= 30000 && gopen <= 10000 && gext <= 5000 &&
+           (int64_t)match + 2 * gext <= 30000;
 }
 
 hipError_t launch_dp16(const DpArgs &a, int waves_per_block, hipStream_t stream)

@@ -466,13 +466,15 @@ def test_packed16_equals_forced_int32(aligner):
 def test_packed16_range_guard(aligner):
     """Scores that do not fit 16 bits must fall back to the int32 kernel -- and still be exact."""
     rng = np.random.default_rng(99)
-    ts, qs = _uniform_batch(rng, 9, 200, 300)  # match * ql = 60000: with the gap terms beyond a 16-bit span
+    ts, qs = _uniform_batch(rng, 9, 400, 300)  # match * ql = 60000: with the gap terms beyond a 16-bit span
     res = aligner.align_batch(ts, qs, (200, -150, 260, 11), ol.INDEL)
     assert aligner.timing().packed16 == 0
     off, sc, cg = ol.oracle_align_batch(ts, qs, (200, -150, 260, 11), ol.INDEL, nthreads=4)
     assert (res.offsets == off).all() and (res.scores == sc).all() and res.cigars == cg
     # just inside the guard: homopolymer pairs drive H to its extremes (all-match and all-mismatch)
-    for t, q in ((b"A" * 300, b"A" * 150), (b"A" * 300, b"C" * 150), (b"AC" * 150, b"CA" * 75)):
+    for t, q in ((b"A" * 300, b"A" * 150), (b"A" * 300, b"C" * 150), (b"AC" * 150, b"CA" * 75),
+                 (b"A" * 300, b"A" * 289), (b"A" * 300, b"C" * 289), (b"A" * 289, b"A" * 300), (b"C" * 289, b"A" * 300),
+                 (b"AC" * 144, b"CA" * 144), (b"A" * 1200, b"A" * 240), (b"A" * 1200, b"C" * 240)):
         for strategy in ol.STRATEGIES:
             r = aligner.align_batch([t] * 3, [q] * 3, (200, -150, 260, 11), strategy)
             assert aligner.timing().packed16 == 1
