@@ -303,7 +303,7 @@ def main():
         have = (tm.dp_ms / max(1, tm.dp_launches)) * 1e-3 * clock_hz * 1024
         valu_obj = {"issue_frac": round(need / have, 3), "wave_insts_per_pair": valu["wave_insts_per_pair"],
                     "avg_cycles_per_inst": valu["avg_cycles_per_inst"], "lds_bank_conflict_rate": valu["lds_bank_conflict_rate"],
-                    "clock_mhz": int(clock_hz / 1e6), "source": "profiles/pmc_traffic.json (rocprofv3 --pmc, r01_d_final.txt)"}
+                    "clock_mhz": int(clock_hz / 1e6), "source": "profiles/pmc_traffic.json (rocprofv3 --pmc, r01_h_packed_trimmed.txt)"}
     out = {
         "metric": "GCUPS (+ aligned reads/s) for 150 bp short-read batch",
         "value": round(total_cells / elapsed / 1e9, 2),

@@ -103,7 +103,7 @@ __device__ __forceinline__ unsigned sel_mask(unsigned a, unsigned b, unsigned lo
 // block ahead; the representation then uses max S where the DNA kernel uses `match`.
 // MODE bit 0: MATRIX; bit 1: score only (no traceback flags are formed or stored: MGL_SW_FLAG_SCORE_ONLY)
 template <int MODE>
-__device__ __forceinline__ void cell16(Lane16 &st, const unsigned rh, const unsigned re, const unsigned q,
+__device__ __forceinline__ void cell16(const int U, Lane16 &st, const unsigned rh, const unsigned re, const unsigned q,
                                        const unsigned tt, const Consts16 &c, unsigned &h, unsigned &eo, unsigned &fo,
                                        unsigned &hup_new, const unsigned sub)
 {
@@ -128,11 +128,13 @@ __device__ __forceinline__ void cell16(Lane16 &st, const unsigned rh, const unsi
         const unsigned d2 = pk_sub_sat(sm, ein);        // < 0 <=> E > max(diag, F)
         const unsigned d3 = pk_sub_sat(ein, open);      // < 0 <=> a new vertical gap wins
         const unsigned d4 = pk_sub_sat(st.f, open);     // < 0 <=> a new horizontal gap wins
-        // sign bytes: [d2.A, d2.B, d1.A, d1.B] and [d4.A, d4.B, d3.A, d3.B]
-        const unsigned p12 = __builtin_amdgcn_perm(d1, d2, 0x07050301u);
-        const unsigned p34 = __builtin_amdgcn_perm(d3, d4, 0x07050301u);
-        const unsigned y = (p12 & 0x80808080u) | ((p34 >> 1) & ~0x80808080u);      // v_bfi_b32
-        st.acc = (y & 0xC0C0C0C0u) | ((st.acc >> 2) & ~0xC0C0C0C0u);                // v_bfi_b32
+        // v_perm_b32 selectors 8..11 replicate the sign bit of bytes 1 / 3 / 5 / 7: clean 0x00 / 0xff bytes
+        // [d2.A, d2.B, d1.A, d1.B] and [d4.A, d4.B, d3.A, d3.B]; step U of the block owns bits 2U+1 and 2U of every byte
+        const unsigned p12 = __builtin_amdgcn_perm(d1, d2, 0x0b0a0908u);
+        const unsigned p34 = __builtin_amdgcn_perm(d3, d4, 0x0b0a0908u);
+        const unsigned k12 = 0x02020202u << (2 * U), k34 = 0x01010101u << (2 * U);
+        const unsigned low = U == 0 ? 0u : st.acc;                                  // a new block starts from zero
+        st.acc = (p34 & k34) | ((p12 & k12) | low);                                 // v_and_or_b32 x 2 (v_and + v_and_or at U == 0)
     }
 }
 
@@ -160,7 +162,7 @@ __device__ __forceinline__ void step4_16(Lane16 &st, uint4 &ringA, uint4 &ringB,
         const unsigned rh = RING_U(u, ringA, ringB, x, z), re = RING_U(u, ringA, ringB, y, w);
         if (u == 2) ringA = ring_next[0];
         unsigned h, eo, fo, hup_new;
-        cell16<MODE>(st, rh, re, qq[u], tt, c, h, eo, fo, hup_new, sub[u]);
+        cell16<MODE>(u, st, rh, re, qq[u], tt, c, h, eo, fo, hup_new, sub[u]);
         if (PRO) {
             const bool at_border = (s0 + u) <= L; // column <= 0
             h = at_border ? hb : h;
@@ -186,7 +188,7 @@ __device__ __forceinline__ void lean4_16(Lane16 &st, uint4 &ringA, uint4 &ringB,
         const unsigned rh = RING_U(u, ringA, ringB, x, z), re = RING_U(u, ringA, ringB, y, w);
         if (u == 2) ringA = ring_next[0];
         unsigned h, eo, fo, hup_new;
-        cell16<MODE>(st, rh, re, qq[u], tt, c, h, eo, fo, hup_new, sub[u]);
+        cell16<MODE>(u, st, rh, re, qq[u], tt, c, h, eo, fo, hup_new, sub[u]);
         if (CAP) st.cap = ((col0 + u - L) == ql) ? h : st.cap;
         if (writer) ring_wr[u] = make_uint2(h, eo);
         commit16(st, h, eo, fo, hup_new);
@@ -213,7 +215,7 @@ __device__ __forceinline__ void window4_16(Lane16 &st, uint4 &ringA, uint4 &ring
         const unsigned rh = RING_U(t, ringA, ringB, x, z), re = RING_U(t, ringA, ringB, y, w);
         if (t == 2) ringA = ring_next[0];
         unsigned h, eo, fo, hup_new;
-        cell16<MODE>(st, rh, re, qq[t], tt, c, h, eo, fo, hup_new, sub[t]);
+        cell16<MODE>(t, st, rh, re, qq[t], tt, c, h, eo, fo, hup_new, sub[t]);
         const unsigned long long m_u = ROWS << u;
         if (!FIRST) {
             // lane u + cgap sits on column ql of the stripe it is finishing
