@@ -196,7 +196,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // long reads: one pair per WORKGROUP (sw_dp_coop_kernel), its waves pipelined over the 64-row stripes.  Taken
     // when the one-wave-per-pair carve does not fit LDS, or when forced; needs at least two stripes to share.
     int coop_waves = 0;
-    if (!use16 && !d_matrix && ctx->cooperative != 1 && ctx->carry_memory == 0 && gopen < 65536 && (ctx->stripe_rows == 0 || ctx->cooperative >= 2) &&
+    if (!use16 && !d_matrix && ctx->cooperative != 1 && ctx->carry_memory == 0 && gopen < 65536 && gopen >= gext && (ctx->stripe_rows == 0 || ctx->cooperative >= 2) &&
         ((rows == 64 && wpb == 0) || ctx->cooperative >= 2) && coop_lds_bytes(coop_sps_for(max_ql), 2) <= 160 * 1024) {
         const int stripes = (max_tl + 63) / 64;
         coop_waves = ctx->cooperative >= 2 ? ctx->cooperative : 16;
@@ -213,6 +213,9 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     if (use_scratch) wpb = 4;
     if ((int64_t)max_tl * max_ql > (1ll << 34) || max_ql > (1 << 24) || max_tl > (1 << 24))
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "matrix larger than 2^34 cells");
+    // the kernels hold X + (i + j) * gext in 32 bits; the reference's own int arithmetic overflows beyond this too
+    if (((int64_t)match - mismatch + gopen + 2 * (int64_t)gext) * ((int64_t)max_tl + max_ql) >= (1ll << 30))
+        return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "scores of this geometry and these parameters leave the 32-bit range");
     // traceback words per pair (int32 layout) or per group of two pairs (packed16 layout)
     const int64_t stride_words = use16 ? tb_words16_for(max_tl, max_ql) : tb_words_for(max_tl, sps_cap, rows);
     const int64_t per_pair = (score_only ? 0 : stride_words * 4 / (use16 ? 2 : 1)) + (int64_t)sizeof(DpRecord);

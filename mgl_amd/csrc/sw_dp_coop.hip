@@ -18,8 +18,8 @@
 //   * the LAST wave's carry cannot go through a small ring: wave 0 only comes back for stripe W after it has
 //     finished stripe 0, so that hop must hold a whole row or the back-pressure closes a cycle (deadlock).  It
 //     goes through a per-pair row in HBM instead, with NO back-pressure and no fence: every column is one
-//     64-bit agent-scope atomic {H : 32, H - E' : 16, tag : 16} (0 < H - E' <= gap open for every valid cell,
-//     sw.cpp:73-82; tag = round number, never 0, the row is zeroed when the kernel starts).  Wave 0 loads its
+//     64-bit agent-scope atomic {H : 32, H - E' : 16, tag : 16} (0 <= H - E' <= gap open - gap extend in the stored form for
+//     every valid cell, sw.cpp:73-82; tag = round number, never 0, the row is zeroed when the kernel starts).  Wave 0 loads its
 //     columns two 32-step groups ahead, checks the tags when it needs them (re-loading a column that is not
 //     there yet) and drops them into its private LDS ring, from where the step code reads them like any other
 //     carry;
@@ -64,8 +64,10 @@ struct CoopLane {
     int rm, rd, rj;          // last stripe only: running best of the last row (score, |tl-j|, j)
 };
 
+// Stored values are X[i][j] + (i + j) * gext, as in sw_dp_body (sw_kernels.hip): match / mismatch include the 2 * gext
+// of a diagonal step, o_e = gap open - gap extend starts a gap in either direction, extensions are free.
 struct CoopConsts {
-    int match, mismatch, gopen, gext, tl, ql;
+    int match, mismatch, o_e, gopen, gext, tl, ql;
 };
 
 __device__ __forceinline__ bool wait_at_least(const int *ctr, int need)
@@ -118,7 +120,7 @@ __device__ __forceinline__ void coop_group32(CoopLane &st, int4 &rA, int4 &rB, c
                                              unsigned long long *wrap_out, const unsigned tag_out, const unsigned *qrd,
                                              unsigned &q_lo, const int q_shift, const int tb, const int s_begin,
                                              const int L, const int hb, const int qcap, const int row_i,
-                                             const CoopConsts &c, const bool writer)
+                                             const int cap_unshift, const CoopConsts &c, const bool writer)
 {
 #pragma unroll 1
     for (int b = 0; b < 8; ++b) {
@@ -142,20 +144,19 @@ __device__ __forceinline__ void coop_group32(CoopLane &st, int4 &rA, int4 &rB, c
             const int sm = max(diag, st.f);
             const int d2 = sm - ein; // < 0 <=> E > max(diag, F)
             int h = max(sm, ein);
-            const int open_from = h - c.gopen;
-            const int ee = ein - c.gext;
-            const int d3 = ee - open_from; // < 0 <=> a new vertical gap beats extending
-            const int eo = max(open_from, ee);
-            const int fe = st.f - c.gext;
-            const int d4 = fe - open_from; // < 0 <=> a new horizontal gap beats extending
-            int fo = max(open_from, fe);
+            const int open_from = h - c.o_e;
+            const int d3 = ein - open_from; // < 0 <=> a new vertical gap beats extending
+            const int eo = max(open_from, ein);
+            const int d4 = st.f - open_from; // < 0 <=> a new horizontal gap beats extending
+            int fo = max(open_from, st.f);
             const int j = s0 + u - L; // this lane's column
             if (EDGE) {
                 const bool at_border = j <= 0;
                 h = at_border ? hb : h;
-                fo = at_border ? hb - c.gopen : fo;
-                const bool take = j == qcap && h >= st.best; // sw.cpp:100-104 (>=: later row wins)
-                st.best = take ? h : st.best;
+                fo = at_border ? hb - c.o_e : fo;
+                const int score = h - cap_unshift;            // rows carry different offsets: compare scores
+                const bool take = j == qcap && score >= st.best; // sw.cpp:100-104 (>=: later row wins)
+                st.best = take ? score : st.best;
                 st.best_i = take ? row_i : st.best_i;
             }
             st.a0 = shift_in_sign(st.a0, d1);
@@ -165,8 +166,9 @@ __device__ __forceinline__ void coop_group32(CoopLane &st, int4 &rA, int4 &rB, c
             if (OUT == OUT_LAST) {
                 // sw.cpp:116-127 in column order: better score, or same score closer to the diagonal
                 const int d = abs(c.tl - j);
-                const bool take = j >= 1 && j <= c.ql && (h > st.rm || (h == st.rm && d < st.rd));
-                st.rm = take ? h : st.rm;
+                const int score = h - (c.tl + j) * c.gext;
+                const bool take = j >= 1 && j <= c.ql && (score > st.rm || (score == st.rm && d < st.rd));
+                st.rm = take ? score : st.rm;
                 st.rd = take ? d : st.rd;
                 st.rj = take ? j : st.rj;
             } else if (!EDGE || s0 + u >= 63) {
@@ -175,7 +177,7 @@ __device__ __forceinline__ void coop_group32(CoopLane &st, int4 &rA, int4 &rB, c
                 if (OUT == OUT_RING) {
                     if (writer) ring_out[col & RING_MASK] = make_int2(h, eo);
                 } else {
-                    // {H, H - E' (16 bits), tag}: in the lean part lane 63 is on a valid cell, 0 < H - E' <= gap open
+                    // {H, H - E' (16 bits), tag}: in the lean part lane 63 is on a valid cell, 0 <= H - E' <= gap open - gap extend
                     const unsigned hi = EDGE ? (((unsigned)(h - eo) & 0xffffu) | tag_out) : (unsigned)(h - eo) + tag_out;
                     if (writer)
                         __hip_atomic_store(wrap_out + col, (unsigned long long)(unsigned)h | ((unsigned long long)hi << 32),
@@ -240,8 +242,9 @@ __global__ __launch_bounds__(1024) void sw_dp_coop_kernel(const DpArgs a)
     }
 
     CoopConsts c;
-    c.match = a.match;
-    c.mismatch = a.mismatch;
+    c.match = a.match + 2 * a.gext;
+    c.mismatch = a.mismatch + 2 * a.gext;
+    c.o_e = a.gopen - a.gext;
     asm volatile("" : "+v"(c.match), "+v"(c.mismatch)); // both feed a v_cndmask every step
     c.gopen = a.gopen;
     c.gext = a.gext;
@@ -273,7 +276,8 @@ __global__ __launch_bounds__(1024) void sw_dp_coop_kernel(const DpArgs a)
         const int out = last ? OUT_LAST : (wave == W - 1 ? OUT_WRAP : OUT_RING);
         const int row_i = k * 64 + 1 + L;
         const int tb = row_i <= tl ? a.t.at(t0, row_i - 1) : 0;
-        const int hb = border(row_i, c.gopen, c.gext, indel);
+        const int hb = border(row_i, c.gopen, c.gext, indel) + row_i * c.gext; // column 0
+        const int cap_unshift = (row_i + ql) * c.gext;                          // offset of this row's last column
         const int qcap = row_i <= tl ? ql : NEG_INF;
         const int base_in = (k / W) * S, base_out = ((k + 1) / W) * S;
         const unsigned tag_in = wrap_tag(k, W), tag_out = wrap_tag(k + 1, W) << 16;
@@ -288,8 +292,8 @@ __global__ __launch_bounds__(1024) void sw_dp_coop_kernel(const DpArgs a)
                 if (first) {
                     // row 0: H[0][j], E[1][j] = H[0][j] - o
                     for (int col = (s == 0 ? 0 : s + AHEAD - 32) + L; col < s + AHEAD; col += 64) {
-                        const int hb0 = border(col, c.gopen, c.gext, indel);
-                        ring_in[col & RING_MASK] = make_int2(hb0, hb0 - c.gopen);
+                        const int hb0 = border(col, c.gopen, c.gext, indel) + col * c.gext;
+                        ring_in[col & RING_MASK] = make_int2(hb0, hb0 - c.o_e);
                     }
                 } else if (s == 0) {
                     const unsigned long long v = wrap_load(wrap, L, wrap_cols);
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(1024) void sw_dp_coop_kernel(const DpArgs a)
             }
             const bool lean = s >= main_lo && s + 32 <= main_hi;
 #define MGL_COOP_GROUP(EDGE, OUT)                                                                                      \
-    coop_group32<EDGE, OUT>(st, rA, rB, ring_in, ring_out, wrap, tag_out, qrd, q_lo, q_shift, tb, s, L, hb, qcap, row_i, c, \
+    coop_group32<EDGE, OUT>(st, rA, rB, ring_in, ring_out, wrap, tag_out, qrd, q_lo, q_shift, tb, s, L, hb, qcap, row_i, cap_unshift, c, \
                             writer)
             if (out == OUT_RING) {
                 if (lean)

@@ -130,8 +130,8 @@ struct Carry {
 template <bool PRO, bool EPI, bool SCRATCH, int G, bool MATRIX = false>
 __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, const int4 *ring_next,
                                       const unsigned qw, const int tb, const int s0, const int L, const int hb,
-                                      const int qcap, const int row_i, const int match, const int mismatch,
-                                      const int gopen, const int gext, int2 *ring_wr, const bool writer,
+                                      const int qcap, const int row_i, const int match2, const int mismatch2,
+                                      const int o_e, const int cap_unshift, int2 *ring_wr, const bool writer,
                                       const int (&sub)[4] = {0, 0, 0, 0})
 {
 #pragma unroll
@@ -144,23 +144,23 @@ __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, c
         const int hup_new = lane_shr1<G>(rh, st.h_prev);
         const int ein = lane_shr1<G>(re, st.e_prev);
         const int qb = (int)((qw >> (8 * u)) & 0xffu);
+        // stored values carry the offset (i + j) * gext (see sw_dp_body): the diagonal adds 2 * gext (folded into match2 /
+        // mismatch2 / sub), extending a gap costs nothing, and both new gaps start from the same H - (o - e)
         // substitution-matrix mode (protein extension): the score was looked up one block ahead
-        const int diag = st.hup + (MATRIX ? sub[u] : (qb == tb ? match : mismatch));
+        const int diag = st.hup + (MATRIX ? sub[u] : (qb == tb ? match2 : mismatch2));
         const int d1 = diag - st.f; // < 0 <=> F > diag
         const int sm = max(diag, st.f);
         const int d2 = sm - ein; // < 0 <=> E > max(diag, F)
         int h = max(sm, ein);
-        const int open_from = h - gopen;
-        const int ee = ein - gext;
-        const int d3 = ee - open_from; // < 0 <=> a new vertical gap beats extending
-        int eo = max(open_from, ee);
-        const int fe = st.f - gext;
-        const int d4 = fe - open_from; // < 0 <=> a new horizontal gap beats extending
-        int fo = max(open_from, fe);
+        const int open_from = h - o_e;
+        const int d3 = ein - open_from; // < 0 <=> a new vertical gap beats extending
+        int eo = max(open_from, ein);
+        const int d4 = st.f - open_from; // < 0 <=> a new horizontal gap beats extending
+        int fo = max(open_from, st.f);
         if (PRO) {
             const bool at_border = (s0 + u) <= L; // column j = s - L <= 0
             h = at_border ? hb : h;
-            fo = at_border ? hb - gopen : fo;
+            fo = at_border ? hb - o_e : fo;
         }
 #ifndef MGL_ABLATE_TB
         st.a0 = shift_in_sign(st.a0, d1);
@@ -170,8 +170,9 @@ __device__ __forceinline__ void step4(LaneState &st, int4 &ringA, int4 &ringB, c
 #endif
         if (EPI) {
             const bool last_col = (s0 + u - L) == qcap;
-            const bool take = last_col && h >= st.best; // sw.cpp:100-104 (>=: later row wins)
-            st.best = take ? h : st.best;
+            const int score = h - cap_unshift;           // rows carry different offsets: compare scores
+            const bool take = last_col && score >= st.best; // sw.cpp:100-104 (>=: later row wins)
+            st.best = take ? score : st.best;
             st.best_i = take ? row_i : st.best_i;
         }
 #ifndef MGL_ABLATE_RINGWRITE
@@ -244,9 +245,13 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem,
 
     // match / mismatch feed a v_cndmask every step: pin them in VGPRs (two SGPR sources
     // would be re-materialised into VGPRs each step)
-    int match = a.match, mismatch = a.mismatch;
-    asm volatile("" : "+v"(match), "+v"(mismatch));
+    // Stored values are X[i][j] + (i + j) * gext (X = H, E, F): every comparison is between values of one cell, so the
+    // decisions are those of sw.cpp:51-96, but E - e and F - e need no instruction and the two gap-open candidates
+    // are one value.  Scores are restored where they are read (last column, last row).
     const int gopen = a.gopen, gext = a.gext;
+    const int o_e = gopen - gext;
+    int match = a.match + 2 * gext, mismatch = a.mismatch + 2 * gext;
+    asm volatile("" : "+v"(match), "+v"(mismatch));
     const bool indel = (a.strategy & (OS_INDEL | OS_LEAD_ID)) != 0;
 
     // ---- stage the query: copy k holds q shifted right by G + k bytes, zero elsewhere
@@ -263,8 +268,8 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem,
         }
         // ---- border row into the ring: H[0][j], E[1][j] = H[0][j] - o   (sw.cpp:14-18,31-35)
         for (int j = L; j <= ql_max; j += G) {
-            const int hb0 = border(j, gopen, gext, indel);
-            Carry<SCRATCH>::store1col(ring + j + G, hb0, hb0 - gopen);
+            const int hb0 = border(j, gopen, gext, indel) + j * gext;   // row 0; E[1][j] = H[0][j] - o sits one row lower
+            Carry<SCRATCH>::store1col(ring + j + G, hb0, hb0 - o_e);
         }
         if (SCRATCH)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the plain byte stores above reach L2 before any read
@@ -298,7 +303,8 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem,
         tb_next = (row_next >= 1 && row_next <= tl) ? a.t.at(t0, row_next - 1) : 0;
         if (MATRIX) tb_next = a.code[tb_next & 0xff] * MATRIX_DIM;
 
-        const int hb = border(row_i, gopen, gext, indel);
+        const int hb = border(row_i, gopen, gext, indel) + row_i * gext; // column 0
+        const int cap_unshift = (row_i + ql) * gext;                      // offset of this row's last column
         const int qcap = row_i <= tl ? ql : NEG_INF; // s - L > -G never equals NEG_INF
         // the lane owning this stripe's last row publishes the carry (sw_avx.cpp:196-197)
         const int wl = (k == nstripes - 1) ? last_lane : G - 1;
@@ -312,7 +318,7 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem,
         int sub[4] = {0, 0, 0, 0}; // matrix mode: scores of this block's four columns, looked up one block ahead
         if (MATRIX) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) sub[u] = mat_lds[tb + (int)((qw >> (8 * u)) & 0xffu)];
+            for (int u = 0; u < 4; ++u) sub[u] = mat_lds[tb + (int)((qw >> (8 * u)) & 0xffu)] + 2 * gext;
         }
 
         int s = 0;
@@ -321,10 +327,10 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem,
         const unsigned nq = MGL_QREAD(qrd);                                                                \
         int nsub[4] = {0, 0, 0, 0};                                                                        \
         if (MATRIX) {                                                                                      \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u) nsub[u] = mat_lds[tb + (int)((nq >> (8 * u)) & 0xffu)]; \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) nsub[u] = mat_lds[tb + (int)((nq >> (8 * u)) & 0xffu)] + 2 * gext; \
         }                                                                                                  \
         step4<PRO, EPI, SCRATCH, G, MATRIX>(st, rA, rB, ring_rd + 2, qw, tb, s, L, hb, qcap, row_i, match, \
-                                            mismatch, gopen, gext, ring_wr, writer, sub);                  \
+                                            mismatch, o_e, cap_unshift, ring_wr, writer, sub);             \
         if (MATRIX) {                                                                                      \
             _Pragma("unroll") for (int u = 0; u < 4; ++u) sub[u] = nsub[u];                               \
         }                                                                                                  \
@@ -359,7 +365,7 @@ __device__ __forceinline__ void sw_dp_body(const DpArgs &a, unsigned char *smem,
             // last row: best score, then closest to the diagonal, then smallest column
             int rm = NEG_INF, rd = 0x7fffffff, rj = 0x7fffffff;
             for (int j = L + 1; j <= ql; j += G) {
-                const int sc = Carry<SCRATCH>::load1col(ring + j + G).x;
+                const int sc = Carry<SCRATCH>::load1col(ring + j + G).x - (tl + j) * gext;
                 const int d = abs(tl - j);
                 const bool take = sc > rm || (sc == rm && d < rd);
                 rm = take ? sc : rm;
