@@ -189,7 +189,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const bool score_only = score_only_hint && use16 && d_score != nullptr && !hooks;
     int rows = use16 ? 16 : ctx->stripe_rows ? ctx->stripe_rows : (max_ql >= kRows64MinQuery ? 64 : 16);
     // substitution-matrix mode: 16 rows x four pairs per wave while that carve fits LDS (queries up to ~800 residues;
-    // measured faster than one pair per wave at 300 residues: 1 006 vs 960 GCUPS), else 64 rows x one pair (to ~3 300)
+    // measured faster than one pair per wave at 300 residues: 1 056 vs about 1 000 GCUPS), else 64 rows x one pair (to ~3 300)
     if (d_matrix && !use16 && !ctx->stripe_rows) rows = pick_waves_per_block(sps_for_rows(max_ql, 16), 16) == 0 ? 64 : 16;
     int sps_cap = sps_for_rows(max_ql, rows);
     int wpb = use16 ? wpb16 : pick_waves_per_block(sps_cap, rows);
