@@ -2,6 +2,7 @@
 the compiled reference and against the CPU restatement (oracle) on fresh seeded inputs.
 Bit-exact: offset, CIGAR text, all six ScoreMax fields and the logical backtrack matrix."""
 import hashlib
+import os
 import zlib
 from collections import defaultdict
 
@@ -482,6 +483,17 @@ def test_packed16_range_guard(aligner):
             for k in range(3):
                 assert (int(r.offsets[k]), r.cigars[k], tuple(int(x) for x in r.scores[k])) == (
                     o["offset"], o["cigar"], o["score"])
+
+
+def test_packed16_guard_edge_fuzz():
+    """Random parameter sets at the largest geometry dp16_range_ok admits, extreme sequences (scripts/range_fuzz.py)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("range_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "range_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, packed = mod.run(24, 11, lambda *x: None)
+    assert bad == 0 and packed > 20
 
 
 def test_coalescing_front_end():
