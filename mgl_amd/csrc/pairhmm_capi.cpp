@@ -85,7 +85,7 @@ struct mgl_pairhmm_ctx {
     std::string err;
     int use_double = 0;
     int profiling = 0;
-    int stripe_rows = 0; // 0 = per batch, 16 / 64 = forced (mgl_pairhmm_set_stripe_rows; MGL_PAIRHMM_ROWS for the bench scripts)
+    int stripe_rows = 0; // 0 = per batch, 16 / 32 / 64 = forced (mgl_pairhmm_set_stripe_rows; MGL_PAIRHMM_ROWS for the bench scripts)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false, ran_float = false;
     mgl_pairhmm_timing timing{};
@@ -164,18 +164,25 @@ int run_device(mgl_pairhmm_ctx *ctx, hipStream_t stream, int64_t n_pairs, const 
     int rows = ctx->stripe_rows;
     if (!rows) {
         if (const char *e = getenv("MGL_PAIRHMM_ROWS")) rows = atoi(e);
-        if (rows != 16 && rows != 64)
+        if (rows != 16 && rows != 32 && rows != 64) {
             rows = (max_read_len >= 48 && ph_lds_bytes(max_hap_len, 16, 4) > 12 * 1024) ? 64 : 16;
+            // reads of 65 .. 160 bases: two pairs per wave, 32 lanes x up to 5 rows each, waste fewer row slots and half the
+            // pipeline depth of one pair per wave (150 bases: 150 of 160 slots instead of 150 of 192); measured faster up to
+            // haplotypes of ~800 bases (150 x 300: 2 560 vs 1 908 GCUPS; x 700: 2 358 vs 2 199; x 1000: 2 051 vs 2 076)
+            if (rows == 64 && max_read_len > 64 && max_read_len <= 160 && ph_lds_bytes(max_hap_len, 32, 4) <= 24 * 1024) rows = 32;
+        }
     }
+    if (rows == 32 && (max_read_len > 160 || ph_lds_bytes(max_hap_len, 32, 4) > 160 * 1024)) rows = 64; // one stripe of 32 x 5 rows
     if (ph_lds_bytes(max_hap_len, rows, 4) > 160 * 1024) rows = 64; // four rings would not fit LDS at all
     const int rows_d = ph_lds_bytes(max_hap_len, 16, 8) <= 160 * 1024 && rows == 16 ? 16 : 64;
-    const int rows_per_lane = std::min(4, (max_read_len + 63) / 64);
+    const int rows_per_lane = std::min(4, (max_read_len + 63) / 64);           // one pair per wave (and the double pass)
+    const int rows_per_lane_f = rows == 32 ? std::max(3, (max_read_len + 31) / 32) : rows_per_lane;
     const bool prof = ctx->profiling != 0;
     ctx->ev_valid = false;
     ctx->ran_float = !ctx->use_double;
     if (!ctx->use_double) {
         if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
-        HIP_TRY(ctx, launch_pairhmm_float(a, rows, rows_per_lane, stream));
+        HIP_TRY(ctx, launch_pairhmm_float(a, rows, rows_per_lane_f, stream));
         if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
     }
     if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
@@ -275,7 +282,7 @@ int mgl_pairhmm_initialize(mgl_pairhmm_ctx *ctx, int use_double, int max_threads
 
 int mgl_pairhmm_set_stripe_rows(mgl_pairhmm_ctx *ctx, int rows)
 {
-    if (!ctx || (rows != 0 && rows != 16 && rows != 64)) return MGL_PAIRHMM_ERR_BAD_ARG;
+    if (!ctx || (rows != 0 && rows != 16 && rows != 32 && rows != 64)) return MGL_PAIRHMM_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->stripe_rows = rows;
     return MGL_PAIRHMM_OK;

@@ -34,9 +34,12 @@ constexpr double MIN_ACCEPTED = (double)1e-28f; // pairhmm_common.h:32, compared
 template <int G>
 __device__ __forceinline__ int dpp_shr1(int lane0_value, int src)
 {
-    return __builtin_amdgcn_update_dpp(lane0_value, src, G == 16 ? DPP_ROW_SHR1 : DPP_WAVE_SHR1, 0xf, 0xf, false);
+    const int r = __builtin_amdgcn_update_dpp(lane0_value, src, G == 16 ? DPP_ROW_SHR1 : DPP_WAVE_SHR1, 0xf, 0xf, false);
+    if (G != 32) return r;
+    // two groups of 32 lanes: lane 32 must not see lane 31 (one v_cndmask on a wave-constant lane mask)
+    return (threadIdx.x & 31) == 0 ? lane0_value : r;
 }
-// every lane takes src from the lane below it inside its group of G lanes (16: one DPP row; 64: the wave);
+// every lane takes src from the lane below it inside its group of G lanes (16: one DPP row; 32: half a wave; 64: the wave);
 // lane 0 of the group takes lane0_value
 template <int G>
 __device__ __forceinline__ float shift_in(float lane0_value, float src)
@@ -182,7 +185,7 @@ __device__ __forceinline__ void pairhmm_body(const PhArgs &a, unsigned char *sme
 
     // LDS carve per group: ring[hap_cap + 2G + 16] carries of 12 (float) / 24 (double) bytes (ring[j + G] = column j) | hap bytes (G zeros, hap, zeros)
     const int ring_entries = a.hap_cap + 2 * G + 16;
-    const int hap_bytes = (a.hap_cap + 2 * G + 28 + 3) & ~3;
+    const int hap_bytes = (a.hap_cap + 2 * G + 28 + 7) & ~7; // keeps the next group's ring 8-byte aligned
     const int group_bytes = ring_entries * (int)sizeof(Carry<T>) + hap_bytes;
     unsigned char *gbase = smem + (size_t)(wave * PW + grp) * group_bytes;
     Carry<T> *ring = reinterpret_cast<Carry<T> *>(gbase);
@@ -321,7 +324,7 @@ struct RowConstK {
     int rs[K];
 };
 
-template <typename T, int K, bool PRO, bool EPI, bool HAP_N, bool ACC>
+template <typename T, int G, int K, bool PRO, bool EPI, bool HAP_N, bool ACC>
 __device__ __forceinline__ void phk_step4(LaneK<T, K> &st, const Carry<T> (&cin)[4], Carry<T> (&nxt)[4], const Carry<T> *ring_next,
                                           Carry<T> *ring_wr, const unsigned hw, const RowConstK<T, K> &rc, const int s0, const int L,
                                           const int hap_len, const bool writer)
@@ -333,9 +336,9 @@ __device__ __forceinline__ void phk_step4(LaneK<T, K> &st, const Carry<T> (&cin)
     Carry<T> o[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const T um = shift_in<64>(cin[u].m, st.m[K - 1]);
-        const T ux = shift_in<64>(cin[u].x, st.x[K - 1]);
-        const T uxy = shift_in<64>(cin[u].xy, st.xy[K - 1]);
+        const T um = shift_in<G>(cin[u].m, st.m[K - 1]);
+        const T ux = shift_in<G>(cin[u].x, st.x[K - 1]);
+        const T uxy = shift_in<G>(cin[u].xy, st.xy[K - 1]);
         const int hb = (int)((hw >> (8 * u)) & 0xffu);
         const int c = s0 + u - L; // this lane's column
         const bool border = PRO && c <= 0;
@@ -387,22 +390,32 @@ __device__ __forceinline__ void phk_step4(LaneK<T, K> &st, const Carry<T> (&cin)
     }
 }
 
-template <typename T, int K, bool RESCUE>
-__device__ __forceinline__ void pairhmm_body_k(const PhArgs &a, unsigned char *smem, const int64_t p, const int R, const int H,
-                                               const uint8_t *rbase, const int64_t h0)
+// G = lanes per pair: 64 (one pair per wave; R, H wave-uniform) or 32 (two pairs per wave, each with its own R, H, LDS
+// carve and result lane; reads up to 32 * K rows, a single stripe: 150-base reads fill 150 of 160 row slots instead of
+// 150 of 192, and the pipeline is 32 steps deep instead of 64).  `store`: this group holds a real pair.
+template <typename T, int G, int K, bool RESCUE>
+__device__ __forceinline__ void pairhmm_body_k(const PhArgs &a, unsigned char *smem, const int64_t p, const bool store, const int R,
+                                               const int H, const uint8_t *rbase, const int64_t h0)
 {
-    constexpr int G = 64;
-    const int L = threadIdx.x & 63;
+    const int L = threadIdx.x & (G - 1);
     const int pad = (K - R % K) % K;         // virtual rows in front
     const int rows_v = R + pad;              // a multiple of K
-    const int nstripes = (rows_v + G * K - 1) / (G * K);
-    const int sps8 = (H + G + 7) & ~7;
-    const int lean_end8 = max(G, H & ~7);
+    // loop bounds are wave-uniform: the larger / smaller of the two groups' (G == 32)
+    int ns_w = (rows_v + G * K - 1) / (G * K), h_max = H, h_min = H;
+    if (G == 32) {
+        ns_w = max(ns_w, __shfl_xor(ns_w, 32));
+        h_max = max(h_max, __shfl_xor(h_max, 32));
+        h_min = min(h_min, __shfl_xor(h_min, 32));
+    }
+    const int nstripes = __builtin_amdgcn_readfirstlane(ns_w);
+    const int sps8 = (__builtin_amdgcn_readfirstlane(h_max) + G + 7) & ~7;
+    const int lean_end8 = max(G, __builtin_amdgcn_readfirstlane(h_min) & ~7);
 
     const int ring_entries = a.hap_cap + 2 * G + 16;
-    const int hap_bytes = (a.hap_cap + 2 * G + 28 + 3) & ~3;
-    Carry<T> *ring = reinterpret_cast<Carry<T> *>(smem);
-    unsigned char *hbuf = smem + ring_entries * sizeof(Carry<T>);
+    const int hap_bytes = (a.hap_cap + 2 * G + 28 + 7) & ~7; // keeps the next group's ring 8-byte aligned
+    unsigned char *gbase = smem + (size_t)((threadIdx.x & 63) / G) * ((size_t)ring_entries * sizeof(Carry<T>) + hap_bytes);
+    Carry<T> *ring = reinterpret_cast<Carry<T> *>(gbase);
+    unsigned char *hbuf = gbase + ring_entries * sizeof(Carry<T>);
 
     const T y_initial = Num<T>::initial() / (T)H; // :101
     bool hap_has_n = false;
@@ -481,7 +494,7 @@ __device__ __forceinline__ void pairhmm_body_k(const PhArgs &a, unsigned char *s
         const unsigned hw = __builtin_amdgcn_alignbyte(h_hi, h_lo, (unsigned)q_shift);                   \
         h_lo = h_hi;                                                                                     \
         h_hi = hrd[2];                                                                                   \
-        phk_step4<T, K, PRO, EPI, HAP_N, ACC>(st, CUR, NXT, ring_rd + 4, ring_wr, hw, rc, s, L, H, writer); \
+        phk_step4<T, G, K, PRO, EPI, HAP_N, ACC>(st, CUR, NXT, ring_rd + 4, ring_wr, hw, rc, s, L, H, writer); \
         ring_rd += 4;                                                                                    \
         ring_wr += 4;                                                                                    \
         hrd += 1;                                                                                        \
@@ -506,7 +519,7 @@ __device__ __forceinline__ void pairhmm_body_k(const PhArgs &a, unsigned char *s
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    if (L == last_lane) {
+    if (L == last_lane && store) {
         const double rd = (double)result;
         if (!RESCUE) {
             const bool small = rd < MIN_ACCEPTED; // …PairHmm.cc:179-195
@@ -533,17 +546,52 @@ __device__ __forceinline__ void pairhmm_wave(const PhArgs &a, unsigned char *sme
     // (the kernel is compiled per KMAX so that batches of short reads do not pay the registers of the 4-row variant)
     const int k = min(KMAX, (R + 63) >> 6);
     if (KMAX == 1 || k <= 1)
-        pairhmm_body_k<T, 1, RESCUE>(a, smem, slot, R, H, rbase, h0);
+        pairhmm_body_k<T, 64, 1, RESCUE>(a, smem, slot, true, R, H, rbase, h0);
     else if (KMAX == 2 || k == 2)
-        pairhmm_body_k<T, 2, RESCUE>(a, smem, slot, R, H, rbase, h0);
+        pairhmm_body_k<T, 64, 2, RESCUE>(a, smem, slot, true, R, H, rbase, h0);
     else if (KMAX == 3 || k == 3)
-        pairhmm_body_k<T, 3, RESCUE>(a, smem, slot, R, H, rbase, h0);
+        pairhmm_body_k<T, 64, 3, RESCUE>(a, smem, slot, true, R, H, rbase, h0);
     else
-        pairhmm_body_k<T, 4, RESCUE>(a, smem, slot, R, H, rbase, h0);
+        pairhmm_body_k<T, 64, 4, RESCUE>(a, smem, slot, true, R, H, rbase, h0);
+}
+
+// two pairs per wave, 32 lanes x K rows each (reads up to 32 * KMAX bases: one stripe); K is the wave's: ceil(longer read / 32)
+template <typename T, bool RESCUE, int KMAX>
+__device__ __forceinline__ void pairhmm_wave32(const PhArgs &a, unsigned char *smem)
+{
+    const int grp = (threadIdx.x & 63) >> 5;
+    const int64_t slot = (int64_t)blockIdx.x * 2 + grp;
+    if ((int64_t)blockIdx.x * 2 >= a.n_pairs) return;
+    const bool store = slot < a.n_pairs;
+    const int64_t p = store ? slot : a.n_pairs - 1; // an odd batch: the idle half repeats the last pair, stores nothing
+    if (RESCUE && a.rescue_only) {
+        const bool need = store && a.need_double[p] != 0;
+        if (!__builtin_amdgcn_ballot_w64(need)) return;
+    }
+    const int32_t ri = a.pair_read[p], hi = a.pair_hap[p];
+    const int64_t r0 = a.read_off[ri], h0 = a.hap_off[hi];
+    const int R = (int)(a.read_off[ri + 1] - r0), H = (int)(a.hap_off[hi + 1] - h0);
+    const uint8_t *rbase = a.reads + 5 * r0;
+    const int r_max = __builtin_amdgcn_readfirstlane(max(R, __shfl_xor(R, 32)));
+    const int k = min(KMAX, (r_max + 31) >> 5);
+    if (k <= 2)
+        pairhmm_body_k<T, 32, 2, RESCUE>(a, smem, p, store, R, H, rbase, h0);
+    else if (k == 3)
+        pairhmm_body_k<T, 32, 3, RESCUE>(a, smem, p, store, R, H, rbase, h0);
+    else if (KMAX == 4 || k == 4)
+        pairhmm_body_k<T, 32, 4, RESCUE>(a, smem, p, store, R, H, rbase, h0);
+    else
+        pairhmm_body_k<T, 32, 5, RESCUE>(a, smem, p, store, R, H, rbase, h0);
 }
 
 } // namespace
 
+template <int KMAX>
+__global__ __launch_bounds__(64) void pairhmm_float32_kernel(const PhArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    pairhmm_wave32<float, false, KMAX>(a, smem);
+}
 __global__ __launch_bounds__(64) void pairhmm_float_kernel(const PhArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -570,7 +618,7 @@ __global__ __launch_bounds__(64) void pairhmm_double64_kernel(const PhArgs a)
 int ph_lds_bytes(int hap_cap, int rows, int elem_bytes)
 {
     const int ring_entries = hap_cap + 2 * rows + 16;
-    const int hap_bytes = (hap_cap + 2 * rows + 28 + 3) & ~3;
+    const int hap_bytes = (hap_cap + 2 * rows + 28 + 7) & ~7;
     const int64_t b = (int64_t)(64 / rows) * ((int64_t)ring_entries * 3 * elem_bytes + hap_bytes);
     return b > (1 << 30) ? (1 << 30) : (int)b;
 }
@@ -592,6 +640,8 @@ static hipError_t launch(K kernel, const PhArgs &a, int rows, int elem_bytes, hi
 // rows_per_lane: read rows per lane of the one-pair-per-wave kernels = min(4, ceil(longest read / 64))
 hipError_t launch_pairhmm_float(const PhArgs &a, int rows, int rows_per_lane, hipStream_t stream)
 {
+    if (rows == 32) // two pairs per wave; rows_per_lane = ceil(longest read / 32), 3 .. 5 (the host layer picks the range)
+        return rows_per_lane <= 4 ? launch(pairhmm_float32_kernel<4>, a, 32, 4, stream) : launch(pairhmm_float32_kernel<5>, a, 32, 4, stream);
     if (rows != 64) return launch(pairhmm_float_kernel, a, 16, 4, stream);
     switch (rows_per_lane) {
     case 1: return launch(pairhmm_float64_kernel<1>, a, 64, 4, stream);

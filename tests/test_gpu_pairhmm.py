@@ -124,6 +124,39 @@ def test_quality_bytes_are_masked_like_the_reference(hmm):
         assert abs(got[k] - want) < (1e-9 * max(1.0, abs(want)) if used else 1e-5), (k, got[k], want)
 
 
+@pytest.mark.parametrize("rows", [0, 32])
+def test_two_pairs_per_wave(hmm, rows):
+    """Reads of up to 160 bases: 32 lanes x up to five rows per pair, two pairs per wave (forced, and as the per-batch
+    choice); ragged lengths from 1, odd pair counts (a half-empty last wave), N bases, pairs that need the double rescue."""
+    rng = np.random.default_rng(57)
+    hmm.initialize(pairhmm.PairHMMNativeArguments(False, 1))
+    hmm.set_stripe_rows(rows)
+    for trial, max_read in enumerate((160, 150, 129, 97, 70, 160)):
+        reads, haps = _region(rng, 2 * int(rng.integers(1, 16)) + 1, 2 * int(rng.integers(0, 4)) + 1, with_n=(trial % 2 == 1),
+                              max_read=max_read, max_hap=330)
+        got = np.zeros(len(reads) * len(haps))
+        hmm.computeLikelihoods(reads, haps, got)
+        rd, roff = pairhmm.pack_reads(reads)
+        hd, hoff = pairhmm.pack_haps(haps)
+        pr = np.repeat(np.arange(len(reads), dtype=np.int32), len(haps))
+        ph = np.tile(np.arange(len(haps), dtype=np.int32), len(reads))
+        want, used = pol.compute_pairs(rd, roff, hd, hoff, pr, ph, False, nthreads=4)
+        assert np.isfinite(got).all()
+        err = np.abs(got - want)
+        dbl = used != 0
+        assert (err[dbl] < 1e-9 * np.maximum(1.0, np.abs(want[dbl]))).all(), err[dbl].max()
+        assert (err[~dbl] < 1e-5).all(), err[~dbl].max()
+        assert hmm.timing().rescued == int(used.sum())
+        # the same region one pair per wave: same cells, same summation order (the compiler may contract the
+        # multiply-adds of the two instantiations differently, so equal only to float rounding)
+        hmm.set_stripe_rows(64)
+        again = np.zeros_like(got)
+        hmm.computeLikelihoods(reads, haps, again)
+        hmm.set_stripe_rows(rows)
+        assert (np.abs(again - got) < 2e-6).all(), np.abs(again - got).max()
+    hmm.set_stripe_rows(0)
+
+
 @pytest.mark.parametrize("use_double", [False, True])
 def test_long_reads_and_haplotypes(hmm, use_double):
     """Reads far beyond one stripe (4 rows x 64 lanes): several stripes with the carry ring between them, haplotypes
