@@ -13,6 +13,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -104,6 +105,11 @@ class Coalescer {
             cv_work_.notify_all();
         }
         if (worker_.joinable()) worker_.join();
+        if (timing_ && n_batches_)
+            fprintf(stderr, "[mgl_sw] coalescer: %lld batches, mean %.1f pairs; per batch: %.1f us collecting, %.1f us processing "
+                            "(%.1f layout, %.1f device round trip, %.1f hand-out), %.1f us waking the callers\n",
+                    (long long)n_batches_, (double)n_pairs_ / n_batches_, t_wait_ / n_batches_, t_process_ / n_batches_,
+                    t_layout_ / n_batches_, t_device_ / n_batches_, t_scatter_ / n_batches_, t_release_ / n_batches_);
         if (ctx_) mgl_sw_ctx_destroy(ctx_);
     }
 
@@ -145,12 +151,22 @@ class Coalescer {
             }
             if (!qd.empty()) oldest_[key] = now; // the rest starts a new waiting period
             pending_ -= (int)batch.size();
+            const auto t_first = oldest_[key];
             lk.unlock();
+            const auto t_a = std::chrono::steady_clock::now();
             process(key, batch);
+            const auto t_b = std::chrono::steady_clock::now();
             release(batch);
+            const auto t_c = std::chrono::steady_clock::now();
             lk.lock();
             ++n_batches_;
             n_pairs_ += (int64_t)batch.size();
+            if (timing_) { // diagnostic (MGL_SW_COALESCE_TIMING): where a batch's round trip goes, microseconds
+                auto us = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::micro>(d).count(); };
+                t_wait_ += us(now - t_first);
+                t_process_ += us(t_b - t_a);
+                t_release_ += us(t_c - t_b);
+            }
         }
     }
 
@@ -215,6 +231,8 @@ class Coalescer {
         const size_t in_bytes = 2 * offs + t_pad + q_pad;
         const size_t out_bytes = (size_t)n * (12 + sizeof(mgl_sw_score)) + (size_t)n * stride;
         void *in = nullptr, *out = nullptr;
+        const auto t_0 = std::chrono::steady_clock::now();
+        auto t_1 = t_0, t_2 = t_0;
         int rc = mgl_sw_stage_buffers(ctx_, in_bytes, out_bytes, &in, &out);
         if (rc == MGL_SW_OK) {
             int64_t *toff = static_cast<int64_t *>(in), *qoff = toff + (n + 1);
@@ -227,8 +245,10 @@ class Coalescer {
                 toff[k + 1] = toff[k] + r->tl;
                 qoff[k + 1] = qoff[k] + r->ql;
             }
+            t_1 = std::chrono::steady_clock::now();
             rc = mgl_sw_align_batch_staged(ctx_, n, in_bytes, t_pad, max_tl, max_ql, std::get<0>(key), std::get<1>(key),
                                            std::get<2>(key), std::get<3>(key), std::get<4>(key), stride, out_bytes);
+            t_2 = std::chrono::steady_clock::now();
         }
         const int32_t *off_ = static_cast<const int32_t *>(out), *len_ = off_ + n, *status_ = len_ + n;
         const mgl_sw_score *score_ = reinterpret_cast<const mgl_sw_score *>(status_ + n);
@@ -249,6 +269,12 @@ class Coalescer {
             if (r->ez) *r->ez = score_[(size_t)k];
             r->rc = MGL_SW_OK;
         }
+        if (timing_) {
+            auto us = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::micro>(d).count(); };
+            t_layout_ += us(t_1 - t_0);
+            t_device_ += us(t_2 - t_1);
+            t_scatter_ += us(std::chrono::steady_clock::now() - t_2);
+        }
     }
 
     std::mutex mu_;
@@ -263,6 +289,8 @@ class Coalescer {
     std::thread worker_;
     mgl_sw_ctx *ctx_ = nullptr;
     int64_t n_batches_ = 0, n_pairs_ = 0;
+    const bool timing_ = getenv("MGL_SW_COALESCE_TIMING") != nullptr;
+    double t_wait_ = 0, t_process_ = 0, t_release_ = 0, t_layout_ = 0, t_device_ = 0, t_scatter_ = 0;
 };
 
 struct EnvInit {

@@ -832,12 +832,28 @@ int mgl_sw_align_batch_staged(mgl_sw_ctx *ctx, int n, size_t in_bytes, size_t t_
     if (in_bytes > ctx->pin_in_cap || out_bytes > ctx->pin_out_cap) return fail(ctx, MGL_SW_ERR_BAD_ARG, "staged batch larger than its buffers");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_in.p, ctx->pin_in, in_bytes, hipMemcpyHostToDevice, st));
+    // small batches are latency bound: the kernels then read the pinned (device-mapped, coherent) staging buffer in place
+    // and write their results straight into the pinned output buffer -- no copy commands at all (a copy costs more in
+    // launch latency than the few hundred bytes per pair cost over PCIe); large batches are copied to HBM first
+    static const size_t zero_copy_max = [] {
+        const char *e = getenv("MGL_SW_ZERO_COPY_BYTES");
+        return e ? (size_t)atoll(e) : (size_t)(2u << 20);
+    }();
+    const bool zero_copy = in_bytes + out_bytes <= zero_copy_max;
     const uint8_t *din = static_cast<const uint8_t *>(ctx->stage_in.p);
+    uint8_t *dout = static_cast<uint8_t *>(ctx->stage_out.p);
+    if (zero_copy) {
+        void *pi = nullptr, *po = nullptr;
+        HIP_TRY(ctx, hipHostGetDevicePointer(&pi, ctx->pin_in, 0));
+        HIP_TRY(ctx, hipHostGetDevicePointer(&po, ctx->pin_out, 0));
+        din = static_cast<const uint8_t *>(pi);
+        dout = static_cast<uint8_t *>(po);
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_in.p, ctx->pin_in, in_bytes, hipMemcpyHostToDevice, st));
+    }
     const size_t offs_bytes = (size_t)(n + 1) * 8;
     const SeqSet ts{din + 2 * offs_bytes, reinterpret_cast<const int64_t *>(din), nullptr, max_tl, 0},
         qs{din + 2 * offs_bytes + t_bytes_padded, reinterpret_cast<const int64_t *>(din + offs_bytes), nullptr, max_ql, 0};
-    uint8_t *dout = static_cast<uint8_t *>(ctx->stage_out.p);
     int32_t *d_off = reinterpret_cast<int32_t *>(dout), *d_len = d_off + n, *d_status = d_len + n;
     Score *d_score = reinterpret_cast<Score *>(d_status + n);
     char *d_cig = reinterpret_cast<char *>(d_score + n);
@@ -847,7 +863,7 @@ int mgl_sw_align_batch_staged(mgl_sw_ctx *ctx, int n, size_t in_bytes, size_t t_
         (void)hipStreamSynchronize(st);
         return rc;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_out, ctx->stage_out.p, out_bytes, hipMemcpyDeviceToHost, st));
+    if (!zero_copy) HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_out, ctx->stage_out.p, out_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return MGL_SW_OK;
 }
