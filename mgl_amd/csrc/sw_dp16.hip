@@ -99,8 +99,8 @@ __device__ __forceinline__ unsigned sel_mask(unsigned a, unsigned b, unsigned lo
 
 // The arithmetic of one anti-diagonal step for both packed pairs: returns H, E', F' of the cell and
 // shifts the four decision flags into st.acc.  rh / re: carry for lane 0 of each group.
-// MATRIX (substitution-matrix scoring, sw_dp16_matrix_kernel): sub = {S[tA][qA] - max S, S[tB][qB] - max S}, looked up one
-// block ahead; the representation then uses max S where the DNA kernel uses `match`.
+// MATRIX (substitution-matrix scoring, sw_dp16_matrix_kernel): sub = {S[tA][qA] + 2e, S[tB][qB] + 2e}, looked up one
+// block ahead; the range check and BASE then use max S where the DNA kernel uses `match`.
 // MODE bit 0: MATRIX; bit 1: score only (no traceback flags are formed or stored: MGL_SW_FLAG_SCORE_ONLY)
 template <int MODE>
 __device__ __forceinline__ void cell16(const int U, Lane16 &st, const unsigned rh, const unsigned re, const unsigned q,
@@ -238,7 +238,7 @@ __device__ __forceinline__ void window4_16(Lane16 &st, uint4 &ringA, uint4 &ring
     ringB = ring_next[1];
 }
 
-// ---- substitution-matrix mode: the table in LDS holds int16 S[t][q] - max S, 32 x 32; tt = row byte offsets (code * 64)
+// ---- substitution-matrix mode: the table in LDS holds int16 S[t][q] + 2e, 32 x 32; tt = row byte offsets (code * 64)
 // of the two pairs packed, q = column byte offsets (code * 2) packed, so one add gives both table offsets
 __device__ __forceinline__ unsigned lut2(const short *lut, const unsigned tt, const unsigned q)
 {
