@@ -124,11 +124,12 @@ int mgl_sw_align(const char *t, int tl, const char *q, int ql, int match, int mi
 
 /*
  * Coalescing of concurrent one-pair calls (the way GATK drives alignNative: many threads, one pair each,
- * MicrosoftSmithWaterman.java:66-86).  With max_batch > 0 every mgl_sw_align call (hence the JNI export)
- * is parked and merged with the calls of other threads that use the same parameters and strategy into one
- * device batch, flushed when max_batch calls are waiting or the oldest has waited max_wait_us.  Results are
- * exactly those of the direct call.  max_batch = 0 switches it off again.  Also enabled at load time by the
- * environment variables MGL_SW_COALESCE_US (and MGL_SW_COALESCE_BATCH, default 4096).
+ * MicrosoftSmithWaterman.java:66-86).  Every mgl_sw_align call (hence the JNI export) is parked and merged
+ * with the calls of other threads that use the same parameters and strategy into one device batch, flushed
+ * when as many calls are waiting as the previous batch held (a lone caller never waits), when max_batch are,
+ * or when the oldest has waited max_wait_us.  Results are exactly those of the direct call.  ON by default
+ * (max_batch 4096, max_wait_us 50; environment: MGL_SW_COALESCE_US, -1 = off, and MGL_SW_COALESCE_BATCH);
+ * max_batch = 0 switches it off: every call is then its own device round trip on the calling thread's context.
  */
 int mgl_sw_set_coalescing(int max_batch, int max_wait_us);
 /* device batches flushed / pairs served by the coalescer so far */

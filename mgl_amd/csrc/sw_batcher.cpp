@@ -2,8 +2,8 @@
 //
 // GATK reaches the aligner through alignNative, one pair per call, from many threads
 // (/root/reference/src/main/java/com/microsoft/mgl/smithwaterman/MicrosoftSmithWaterman.java:66-86,
-// ..._MicrosoftSmithWaterman.cpp:44-71).  One pair per launch cannot feed a GPU, so when coalescing is switched
-// on (mgl_sw_set_coalescing or the environment variable MGL_SW_COALESCE_US) mgl_sw_align -- and therefore the
+// ..._MicrosoftSmithWaterman.cpp:44-71).  One pair per launch cannot feed a GPU, so unless coalescing is switched
+// off (mgl_sw_set_coalescing(0, 0) or the environment variable MGL_SW_COALESCE_US=-1) mgl_sw_align -- and therefore the
 // JNI export built on it -- parks the calling thread, a dispatcher thread merges the requests that share one
 // parameter set and strategy into a device batch (mgl_sw_align_batch), and every caller gets exactly the answer
 // the direct call would have produced.  Host code only: queues, one std::thread, condition variables.
@@ -82,7 +82,10 @@ class Coalescer {
             auto &qd = queues_[key];
             if (qd.empty()) oldest_[key] = std::chrono::steady_clock::now();
             qd.push_back(&r);
-            if (++pending_ == 1 || (int)qd.size() >= max_batch_) cv_work_.notify_one(); // the dispatcher is idle, or a batch is full
+            const auto ex = expect_.find(key);
+            const int expect = ex == expect_.end() ? 1 : ex->second;
+            // wake the dispatcher when it is idle, when a batch is full, or when the callers it expects are all back
+            if (++pending_ == 1 || (int)qd.size() >= max_batch_ || (int)qd.size() == expect) cv_work_.notify_one();
         }
         Shard &sh = shards_[my_shard];
         std::unique_lock<std::mutex> lk(sh.mu);
@@ -132,7 +135,11 @@ class Coalescer {
             for (auto &kv : queues_) {
                 if (kv.second.empty()) continue;
                 const auto deadline = oldest_[kv.first] + std::chrono::microseconds(max_wait_us_);
-                if ((int)kv.second.size() >= max_batch || deadline <= now) {
+                // as many callers as the previous batch held are back: nobody else is expected, go at once (a lone caller
+                // never waits; sixteen steady callers are dispatched when the sixteenth arrives, not at the deadline)
+                const auto ex = expect_.find(kv.first);
+                const int expect = ex == expect_.end() ? 1 : ex->second;
+                if ((int)kv.second.size() >= std::min(max_batch, expect) || deadline <= now) {
                     ready = &kv.first;
                     break;
                 }
@@ -151,6 +158,7 @@ class Coalescer {
             }
             if (!qd.empty()) oldest_[key] = now; // the rest starts a new waiting period
             pending_ -= (int)batch.size();
+            expect_[key] = (int)batch.size();
             const auto t_first = oldest_[key];
             lk.unlock();
             const auto t_a = std::chrono::steady_clock::now();
@@ -282,6 +290,7 @@ class Coalescer {
     Shard shards_[kShards];
     std::map<Key, std::deque<Request *>> queues_;
     std::map<Key, std::chrono::steady_clock::time_point> oldest_;
+    std::map<Key, int> expect_; // size of the previous batch of this key
     int pending_ = 0;
     int max_batch_ = 0, max_wait_us_ = 0;
     std::atomic<bool> enabled_{false};
@@ -296,12 +305,12 @@ class Coalescer {
 struct EnvInit {
     EnvInit()
     {
-        if (const char *e = getenv("MGL_SW_COALESCE_US")) {
-            const int us = atoi(e);
-            int mb = 4096;
-            if (const char *b = getenv("MGL_SW_COALESCE_BATCH")) mb = atoi(b);
-            if (us >= 0 && mb > 0) Coalescer::instance().configure(mb, us);
-        }
+        // on by default (50 us window): one pair per call from many threads is the reference's calling pattern, and an
+        // uncoalesced call is a full device round trip per pair; MGL_SW_COALESCE_US=-1 switches it off
+        int us = 50, mb = 4096;
+        if (const char *e = getenv("MGL_SW_COALESCE_US")) us = atoi(e);
+        if (const char *b = getenv("MGL_SW_COALESCE_BATCH")) mb = atoi(b);
+        if (us >= 0 && mb > 0) Coalescer::instance().configure(mb, us);
     }
 };
 

@@ -663,6 +663,11 @@ int mgl_sw_align_batch_device_2bit(mgl_sw_ctx *ctx, void *stream, int64_t n, con
                       nullptr, (flags & MGL_SW_FLAG_SCORE_ONLY) != 0);
 }
 
+static int stage_buffers_nolock(mgl_sw_ctx *ctx, size_t in_bytes, size_t out_bytes, void **in, void **out);
+static int align_batch_staged_nolock(mgl_sw_ctx *ctx, int n, size_t in_bytes, size_t t_bytes_padded, int max_tl, int max_ql, int match,
+                                     int mismatch, int gopen, int gext, int strategy, int cigar_stride, size_t out_bytes, bool uniform,
+                                     int64_t cells_hint);
+
 // mgl_sw_align_batch with an optional per-pair status array: with it, a CIGAR overflow of one pair does not
 // fail the call (used by the coalescing front-end, where every caller has its own buffer size)
 int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const int64_t *t_off,
@@ -711,6 +716,41 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     const size_t t_bytes = (size_t)(t_off[n] - t_off[0]), q_bytes = (size_t)(q_off[n] - q_off[0]);
     if (t_off[0] != 0 || q_off[0] != 0)
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: offsets must start at 0");
+
+    // ---- small batches are latency bound: one pinned staging buffer each way instead of eleven copy commands
+    {
+        const size_t offs = (size_t)(n + 1) * 8, t_pad = (t_bytes + 7) & ~(size_t)7, q_pad = (q_bytes + 7) & ~(size_t)7;
+        const size_t in_bytes = 2 * offs + t_pad + q_pad;
+        const size_t out_bytes = (size_t)n * (12 + sizeof(mgl_sw_score)) + (size_t)n * (size_t)cigar_stride;
+        if (n <= (1 << 20) && (cigar_stride & 3) == 0 && in_bytes + out_bytes <= (1u << 20)) {
+            void *in = nullptr, *out = nullptr;
+            int rc = stage_buffers_nolock(ctx, in_bytes, out_bytes, &in, &out);
+            if (rc != MGL_SW_OK) return rc;
+            uint8_t *hin = static_cast<uint8_t *>(in);
+            memcpy(hin, t_off, offs);
+            memcpy(hin + offs, q_off, offs);
+            memcpy(hin + 2 * offs, targets, t_bytes);
+            memcpy(hin + 2 * offs + t_pad, queries, q_bytes);
+            rc = align_batch_staged_nolock(ctx, (int)n, in_bytes, t_pad, max_tl, max_ql, match, mismatch, gopen, gext, strategy,
+                                           cigar_stride, out_bytes, uniform, cells);
+            if (rc != MGL_SW_OK) return rc;
+            const int32_t *off_ = static_cast<const int32_t *>(out), *len_ = off_ + n, *status_ = len_ + n;
+            const mgl_sw_score *score_ = reinterpret_cast<const mgl_sw_score *>(status_ + n);
+            const char *cig_ = reinterpret_cast<const char *>(score_ + n);
+            memcpy(offset_out, off_, (size_t)n * 4);
+            if (score_out) memcpy(score_out, score_, (size_t)n * sizeof(mgl_sw_score));
+            memcpy(cigar_out, cig_, (size_t)n * (size_t)cigar_stride);
+            if (cigar_len_out) memcpy(cigar_len_out, len_, (size_t)n * 4);
+            int32_t any = 0;
+            for (int64_t k = 0; k < n; ++k) any = std::max(any, status_[k]);
+            if (status_out) {
+                memcpy(status_out, status_, (size_t)n * 4);
+                return MGL_SW_OK;
+            }
+            if (any != 0) return fail(ctx, any, any == MGL_SW_ERR_CIGAR_OVERFLOW ? "a CIGAR did not fit cigar_stride" : "device error");
+            return MGL_SW_OK;
+        }
+    }
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, ctx->d_t.reserve(t_bytes));
@@ -800,10 +840,8 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
 // and one synchronisation instead of the eleven copies of the general host entry.
 //   in : int64 t_off[n+1] | int64 q_off[n+1] | target bytes | query bytes      (sections 8-byte aligned)
 //   out: int32 offset[n] | int32 cigar_len[n] | int32 status[n] | mgl_sw_score[n] | char cigar[n][stride]
-int mgl_sw_stage_buffers(mgl_sw_ctx *ctx, size_t in_bytes, size_t out_bytes, void **in, void **out)
+static int stage_buffers_nolock(mgl_sw_ctx *ctx, size_t in_bytes, size_t out_bytes, void **in, void **out)
 {
-    if (!ctx || !in || !out) return MGL_SW_ERR_BAD_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     auto grow = [&](void *&p, size_t &cap, size_t want) -> hipError_t {
         if (want <= cap) return hipSuccess;
@@ -824,11 +862,17 @@ int mgl_sw_stage_buffers(mgl_sw_ctx *ctx, size_t in_bytes, size_t out_bytes, voi
     return MGL_SW_OK;
 }
 
-int mgl_sw_align_batch_staged(mgl_sw_ctx *ctx, int n, size_t in_bytes, size_t t_bytes_padded, int max_tl, int max_ql, int match,
-                              int mismatch, int gopen, int gext, int strategy, int cigar_stride, size_t out_bytes)
+int mgl_sw_stage_buffers(mgl_sw_ctx *ctx, size_t in_bytes, size_t out_bytes, void **in, void **out)
 {
-    if (!ctx || n < 1) return MGL_SW_ERR_BAD_ARG;
+    if (!ctx || !in || !out) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    return stage_buffers_nolock(ctx, in_bytes, out_bytes, in, out);
+}
+
+static int align_batch_staged_nolock(mgl_sw_ctx *ctx, int n, size_t in_bytes, size_t t_bytes_padded, int max_tl, int max_ql, int match,
+                                     int mismatch, int gopen, int gext, int strategy, int cigar_stride, size_t out_bytes, bool uniform,
+                                     int64_t cells_hint)
+{
     if (in_bytes > ctx->pin_in_cap || out_bytes > ctx->pin_out_cap) return fail(ctx, MGL_SW_ERR_BAD_ARG, "staged batch larger than its buffers");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -858,7 +902,7 @@ int mgl_sw_align_batch_staged(mgl_sw_ctx *ctx, int n, size_t in_bytes, size_t t_
     Score *d_score = reinterpret_cast<Score *>(d_status + n);
     char *d_cig = reinterpret_cast<char *>(d_score + n);
     const int rc = run_device(ctx, st, n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext, strategy, d_off, d_score, d_cig,
-                              cigar_stride, d_len, d_status, 0, false);
+                              cigar_stride, d_len, d_status, cells_hint, uniform);
     if (rc != MGL_SW_OK) {
         (void)hipStreamSynchronize(st);
         return rc;
@@ -866,6 +910,15 @@ int mgl_sw_align_batch_staged(mgl_sw_ctx *ctx, int n, size_t in_bytes, size_t t_
     if (!zero_copy) HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_out, ctx->stage_out.p, out_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return MGL_SW_OK;
+}
+
+int mgl_sw_align_batch_staged(mgl_sw_ctx *ctx, int n, size_t in_bytes, size_t t_bytes_padded, int max_tl, int max_ql, int match,
+                              int mismatch, int gopen, int gext, int strategy, int cigar_stride, size_t out_bytes)
+{
+    if (!ctx || n < 1) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return align_batch_staged_nolock(ctx, n, in_bytes, t_bytes_padded, max_tl, max_ql, match, mismatch, gopen, gext, strategy,
+                                     cigar_stride, out_bytes, false, 0);
 }
 
 // sw_batcher.cpp

@@ -38,7 +38,7 @@ int main(int argc, char **argv)
         }
         want[k].assign(cigar, (size_t)len);
     }
-    if (wait_us >= 0) mgl_sw_set_coalescing(4096, wait_us);
+    mgl_sw_set_coalescing(wait_us >= 0 ? 4096 : 0, wait_us >= 0 ? wait_us : 0);
     std::atomic<int> bad{0};
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;
