@@ -202,6 +202,21 @@ def secondary_workloads():
                 out[name] = {"error": (r.stderr or r.stdout)[-200:]}
         except Exception as e:  # noqa: BLE001 -- a secondary line must never take the headline down
             out[name] = {"error": repr(e)[:200]}
+    # the reference's own calling pattern: one pair per call from 16 native threads through the
+    # coalescing front-end, and one active region per call through the JNI-shaped PairHMM entry -- latency, not throughput
+    try:
+        exe = os.path.join(ROOT, "tests", "cpp", "coalesce_bench")
+        if os.path.exists(exe):
+            r = subprocess.run([exe, "16", "3000", "50"], capture_output=True, text=True, timeout=120)
+            m = re.search(r"coalesced: ([0-9.]+) pairs/s .* wrong results (\d+)", r.stdout)
+            if m:
+                out["one_pair_per_call, 16 native threads (mgl_sw_align, 256x150)"] = {"pairs_per_s": float(m.group(1)), "checked": m.group(2) == "0"}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pairhmm_region_latency.py")], capture_output=True, text=True, timeout=120)
+        m = re.search(r"= 800 pairs: ([0-9.]+) us per call", r.stdout)
+        if m:
+            out["pairhmm, one region per call (100 reads x 8 haplotypes, host buffers)"] = {"us_per_call": float(m.group(1))}
+    except Exception as e:  # noqa: BLE001
+        out["latency_probes"] = {"error": repr(e)[:200]}
     return out
 
 
