@@ -186,6 +186,29 @@ def test_long_reads_and_haplotypes(hmm, use_double):
         assert abs(got[k] - want[k]) < tol, (k, got[k], want[k], used[k])
 
 
+def test_large_host_call_takes_the_copy_path(hmm):
+    """More than 1 MiB of inputs: the host entry copies each array to HBM instead of staging one pinned buffer
+    (pairhmm_capi.cpp); same answers."""
+    rng = np.random.default_rng(77)
+    hmm.initialize(pairhmm.PairHMMNativeArguments(False, 1))
+    reads, haps = _region(rng, 4000, 4, max_read=160, max_hap=330)
+    rd, roff = pairhmm.pack_reads(reads)
+    hd, hoff = pairhmm.pack_haps(haps)
+    assert rd.nbytes > (1 << 20)
+    pr = np.arange(len(reads), dtype=np.int32)
+    ph = (pr % len(haps)).astype(np.int32)
+    got = hmm.compute_pairs(rd, roff, hd, hoff, pr, ph)
+    want, used = pol.compute_pairs(rd, roff, hd, hoff, pr, ph, False, nthreads=4)
+    err = np.abs(got - want)
+    dbl = used != 0
+    assert (err[dbl] < 1e-9 * np.maximum(1.0, np.abs(want[dbl]))).all()
+    assert (err[~dbl] < 1e-5).all()
+    assert hmm.timing().rescued == int(used.sum())
+    # and a slice of it through the staged path gives the same numbers
+    small = hmm.compute_pairs(rd, roff, hd, hoff, pr[:64], ph[:64])
+    assert (small == got[:64]).all()
+
+
 def test_pair_list_and_errors(hmm):
     hmm.initialize(None)
     rng = np.random.default_rng(3)
