@@ -552,15 +552,19 @@ struct BitsMoves {
         if (c & 1u) return -tb.hrun(i, j);
         return 0;
     }
+    __device__ __forceinline__ int diag_run(int, int) const { return 0; } // one lane per pair: nothing to look ahead with
 };
 struct MatrixMoves {
     const int32_t *btr;
     int m; // ql + 1
     __device__ __forceinline__ int at(int i, int j) const { return btr[(size_t)i * m + j]; }
+    __device__ __forceinline__ int diag_run(int, int) const { return 0; }
 };
 
 // calculateCigar (sw.cpp:149-255): walk from the strategy's start cell, merge equal states,
 // post-process the overhangs, emit text.  Returns the alignment offset.
+// Moves::diag_run(i, j): optional shortcut, the number of consecutive diagonal moves from (i, j) that can be taken at once
+// (0 = unknown, take the ordinary single step)
 template <typename Moves>
 __device__ __forceinline__ int walk_and_write(Moves &mv, int tl, int ql, int strategy, int max_t, int max_q,
                                               int mqe_t, int seg_length, CigarWriter &cw)
@@ -584,6 +588,19 @@ __device__ __forceinline__ int walk_and_write(Moves &mv, int tl, int ql, int str
     }
     char state = 'M';
     do { // sw.cpp:182-214
+        const int run = mv.diag_run(I, J);
+        if (run > 0) { // `run` times the third branch below
+            if (state == 'M') {
+                seg += run;
+            } else {
+                cw.push_front(state, seg);
+                seg = run;
+                state = 'M';
+            }
+            I -= run;
+            J -= run;
+            continue;
+        }
         const int b = mv.at(I, J);
         char next;
         int step = 1;
@@ -699,7 +716,7 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
 // lanes run the same walk (wave-uniform state, scalar branches); a lane keeps ITS 16 bytes of the current
 // 32-step traceback block in registers (one coalesced 1 KB load per block), the cell of lane l is fetched
 // with v_readlane, and the block below (where an up-left path goes next inside a stripe) is already on its
-// way.  int32 layout only (rows = 16 or 64).
+// way; a run of diagonal moves inside those two blocks is taken in one go (diag_run).  int32 layout only (rows = 16 or 64).
 struct WaveMoves {
     const uint4 *base; // this pair's traceback, as [block][rows] x 16 bytes
     int sps, rows, L;
@@ -749,6 +766,31 @@ struct WaveMoves {
             return -n;
         }
         return 0;
+    }
+    // Length of the run of diagonal moves that starts at (i, j), as far as it can be seen without loading anything:
+    // cell k of the run, (i - k, j - k), belongs to lane (lane0 - k) of the same stripe and to global step g0 - 2k, i.e. to
+    // the block in `cur` or the one below it in `nxt` -- every lane tests ITS cell of the run in its own registers and one
+    // ballot finds the first cell that is not a diagonal move.  Returns 0 when (i, j) itself is not known to be one.
+    // (Measured: 256 x 150 pairs 40 -> 16 us per launch, 10 kb x 10 kb 2.7 -> 1.1 ms per 256 pairs; a four-block window
+    // fetched at once was no faster: 18 us / 1.6 ms.)
+    __device__ __forceinline__ int diag_run(int i, int j)
+    {
+        const int r = i - 1;
+        const int lane0 = r & (rows - 1);
+        const int g0 = (r >> (rows == 64 ? 6 : 4)) * sps + j + lane0;
+        if ((g0 >> 5) != cur_blk) return 0;
+        const int k = lane0 - L;                 // this lane's position in the run (valid for 0 <= k)
+        const int g = g0 - 2 * k;
+        const int blk = g >> 5;
+        const bool in_cur = blk == cur_blk, in_nxt = blk == nxt_blk && nxt_blk >= 0;
+        const uint4 v = in_cur ? cur : nxt;
+        const int sh = 31 - (g & 31);
+        const bool is_diag = (((v.x | v.y) >> sh) & 1u) == 0u; // neither F > diag nor E > S (sw.cpp:60-71)
+        // the run also ends at the matrix border: rows i - k >= 1 is k <= i - 1 (and k <= lane0 inside the stripe), columns k <= j - 1
+        const bool ok = k >= 0 && k <= j - 1 && k <= i - 1 && (in_cur || in_nxt) && is_diag;
+        const unsigned long long stop = __builtin_amdgcn_ballot_w64(!ok) & ((2ull << lane0) - 1ull); // lanes lane0, lane0-1, ..
+        if (stop == 0ull) return lane0 + 1;      // every lane down to lane 0 continues the run
+        return lane0 - (63 - __builtin_clzll(stop));
     }
 };
 
