@@ -172,7 +172,10 @@ int run_device(mgl_pairhmm_ctx *ctx, hipStream_t stream, int64_t n_pairs, const 
             // reads of 65 .. 160 bases: two pairs per wave, 32 lanes x up to 5 rows each, waste fewer row slots and half the
             // pipeline depth of one pair per wave (150 bases: 150 of 160 slots instead of 150 of 192); measured faster up to
             // haplotypes of ~800 bases (150 x 300: 2 560 vs 1 908 GCUPS; x 700: 2 358 vs 2 199; x 1000: 2 051 vs 2 076)
-            if (rows == 64 && max_read_len > 64 && max_read_len <= 160 && ph_lds_bytes(max_hap_len, 32, 4) <= 24 * 1024) rows = 32;
+            // ... when there are more pairs than SIMDs: a call of up to 1 024 pairs (one active region) is latency bound, and
+            // one pair per wave has fewer rows per lane, i.e. a shorter dependent chain per step (800 pairs: 74 vs 80 us)
+            if (rows == 64 && n_pairs > 1024 && max_read_len > 64 && max_read_len <= 160 && ph_lds_bytes(max_hap_len, 32, 4) <= 24 * 1024)
+                rows = 32;
         }
     }
     if (rows == 32 && (max_read_len > 160 || ph_lds_bytes(max_hap_len, 32, 4) > 160 * 1024)) rows = 64; // one stripe of 32 x 5 rows

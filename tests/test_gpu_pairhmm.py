@@ -204,9 +204,10 @@ def test_large_host_call_takes_the_copy_path(hmm):
     assert (err[dbl] < 1e-9 * np.maximum(1.0, np.abs(want[dbl]))).all()
     assert (err[~dbl] < 1e-5).all()
     assert hmm.timing().rescued == int(used.sum())
-    # and a slice of it through the staged path gives the same numbers
+    # and a slice of it through the staged path gives the same numbers (a small call runs one pair per wave, the large
+    # one two: equal to the rounding of differently contracted multiply-adds)
     small = hmm.compute_pairs(rd, roff, hd, hoff, pr[:64], ph[:64])
-    assert (small == got[:64]).all()
+    assert (np.abs(small - got[:64]) < 2e-6).all()
 
 
 def test_pair_list_and_errors(hmm):
