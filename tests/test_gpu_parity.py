@@ -496,6 +496,17 @@ def test_packed16_guard_edge_fuzz():
     assert bad == 0 and packed > 20
 
 
+def test_odd_parameter_sets():
+    """Gap open < gap extend, zero penalties, a mismatch of -30000: uniform, mixed and forced-cooperative batches
+    (scripts/odd_params_check.py)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("odd_params_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "odd_params_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(lambda *x: None) == 0
+
+
 def test_coalescing_front_end():
     """Many threads calling the one-pair entry (the way GATK drives alignNative) are merged into device
     batches by the coalescer and each gets exactly the answer of the direct call."""
