@@ -119,15 +119,24 @@ bool strategy_ok(int s)
     return s == MGL_SW_OS_SOFTCLIP || s == MGL_SW_OS_INDEL || s == MGL_SW_OS_LEAD_ID || s == MGL_SW_OS_IGNORE;
 }
 
-// largest waves-per-block whose LDS carve fits; 0 if even one wave does not
-int pick_waves_per_block(int sps_cap, int rows)
+// waves per block (4 .. 1) that puts the most waves on a CU's 160 KB of LDS with a block within 64 KB; 0 if even one wave
+// does not fit.  `extra`: bytes every block adds (the substitution matrix)
+int pick_waves_per_block(int sps_cap, int rows, int extra = 0)
 {
     // a wave whose carve exceeds 40 KiB would leave fewer than four waves per CU: such queries keep their
     // carry in the HBM scratch instead (return 0)
     if (dp_lds_bytes(sps_cap, 1, rows) > 40 * 1024) return 0;
-    for (int w = 4; w >= 1; w >>= 1)
-        if (dp_lds_bytes(sps_cap, w, rows) <= 64 * 1024) return w;
-    return 1;
+    int best = -1, pick = 1;
+    for (int w = 4; w >= 1; --w) {
+        const int lds = dp_lds_bytes(sps_cap, w, rows) + extra;
+        if (lds > 64 * 1024) continue;
+        const int occ = (160 * 1024 / lds) * w;
+        if (best < 0 || occ * 10 > best * 11) { // fewer waves per block only for a real gain (> 10 %): 17 one-wave blocks
+            best = occ;                         // per CU instead of 4 x 4 waves measured 7 % slower on 150-base reads
+            pick = w;
+        }
+    }
+    return pick;
 }
 
 // queries from this length on run one pair per wave (64-row stripes): the pipeline fill/drain is then
@@ -180,9 +189,25 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // packed-int16 kernel: one geometry per batch (or per block of eight pairs) and a score range that fits 16 bits;
     // four waves per block while their LDS carve fits, else two or one
     const int lds_extra = d_matrix ? MATRIX_DIM * MATRIX_DIM * 2 : 0;
-    int wpb16 = 4;
+    // waves per block of the packed kernel: the count (4 .. 1) that puts the most waves on a CU's 160 KB of LDS, a block
+    // staying within 64 KB (bench batch: 4 x 9.5 KB -> 16 waves per CU either way; 300-residue protein queries: three
+    // waves of 16.7 KB + the table -> 9 waves per CU instead of 8, +17 % measured)
+    int wpb16 = 1;
+    {
+        const int per_wave = dp16_lds_bytes(sps_for(max_ql), 1);
+        int best = -1;
+        for (int w = 4; w >= 1; --w) {
+            const int lds = w * per_wave + lds_extra;
+            if (lds > 64 * 1024) continue;
+            const int occ = (160 * 1024 / lds) * w;
+            if (best < 0 || occ * 10 > best * 11) { // fewer waves per block only for a real gain (> 10 %)
+                best = occ;
+                wpb16 = w;
+            }
+        }
+    }
     if (const char *e = getenv("MGL_SW_WPB16")) wpb16 = std::max(1, std::min(4, atoi(e))); // launch-shape experiments only
-    while (wpb16 > 1 && dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra > 64 * 1024) wpb16 >>= 1;
+    while (wpb16 > 1 && dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra > 64 * 1024) --wpb16;
     const bool use16 = uniform && ctx->precision != 32 && dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra <= 64 * 1024 &&
                        match > 0 && dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
     // MGL_SW_FLAG_SCORE_ONLY is honoured by the packed kernel only; elsewhere the full path runs (a superset of the result)
@@ -192,7 +217,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // measured faster than one pair per wave at 300 residues: 1 056 vs about 1 000 GCUPS), else 64 rows x one pair (to ~3 300)
     if (d_matrix && !use16 && !ctx->stripe_rows) rows = pick_waves_per_block(sps_for_rows(max_ql, 16), 16) == 0 ? 64 : 16;
     int sps_cap = sps_for_rows(max_ql, rows);
-    int wpb = use16 ? wpb16 : pick_waves_per_block(sps_cap, rows);
+    int wpb = use16 ? wpb16 : pick_waves_per_block(sps_cap, rows, d_matrix ? 1024 : 0);
     // long reads: one pair per WORKGROUP (sw_dp_coop_kernel), its waves pipelined over the 64-row stripes.  Taken
     // when the one-wave-per-pair carve does not fit LDS, or when forced; needs at least two stripes to share.
     int coop_waves = 0;
@@ -206,7 +231,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         wpb = coop_waves;
     }
     // queries too long for the LDS carve: carry ring and query copies in an HBM scratch area instead
-    while (d_matrix && !use16 && wpb > 1 && dp_lds_bytes(sps_cap, wpb, rows) + 1024 > 64 * 1024) wpb >>= 1; // room for the matrix
+    while (d_matrix && !use16 && wpb > 1 && dp_lds_bytes(sps_cap, wpb, rows) + 1024 > 64 * 1024) --wpb; // room for the matrix
     if (d_matrix && !use16 && (wpb == 0 || dp_lds_bytes(sps_cap, wpb, rows) + 1024 > 64 * 1024))
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "substitution-matrix scoring: query too long for the LDS carve (about 3 300 residues)");
     const bool use_scratch = !use16 && !coop_waves && !d_matrix && (wpb == 0 || ctx->carry_memory == 1);
