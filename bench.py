@@ -247,10 +247,11 @@ def main():
     rank, local_rank, world = dist.init()
     distributed = torch.distributed.is_initialized()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())  # (== local_rank; ranks share a GPU only in a gloo rehearsal)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
-    aligner = MicrosoftSmithWaterman(local_rank)
+    aligner = MicrosoftSmithWaterman(dev_index)
     aligner.set_workspace(int(args.workspace_gib * (1 << 30)))
     data_label = "synthetic"
     if args.dataset != "synthetic":

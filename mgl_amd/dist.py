@@ -19,13 +19,16 @@ def init(backend=None):
     rank, local_rank, world = env_world()
     if "RANK" in os.environ and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MGL_DIST_BACKEND=gloo: rehearsal of the multi-rank path where the ranks share one GPU (RCCL refuses that)
+            backend = os.environ.get("MGL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)  # binds the communicator to this rank's GPU
+        elif torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
@@ -64,6 +67,9 @@ def gather_scores(local_scores, n_total=None, dst=0):
         send = torch.zeros(width, dtype=local_scores.dtype, device=local_scores.device)
         send[: local_scores.numel()] = local_scores
     send = send.contiguous()
+    dev = send.device
+    if dist.get_backend() == "gloo" and send.is_cuda:
+        send = send.cpu()  # gloo moves host memory
     recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
     try:
         dist.gather(send, recv, dst=dst)
@@ -74,14 +80,14 @@ def gather_scores(local_scores, n_total=None, dst=0):
         recv = list(full.view(world, width).unbind(0))
     if rank != dst:
         return None
-    return torch.cat([recv[r][: counts[r]] for r in range(world)])
+    return torch.cat([recv[r][: counts[r]] for r in range(world)]).to(dev)
 
 
 def max_over_ranks(value, device):
     """MAX of a python float over all ranks (for timing)."""
     if not dist.is_initialized():
         return float(value)
-    t = torch.tensor([float(value)], device=device, dtype=torch.float64)
+    t = torch.tensor([float(value)], device="cpu" if dist.get_backend() == "gloo" else device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
