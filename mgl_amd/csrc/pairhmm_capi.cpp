@@ -166,7 +166,8 @@ int run_device(mgl_pairhmm_ctx *ctx, hipStream_t stream, int64_t n_pairs, const 
     // haplotype base each) can leave a CU with one or two waves; 64 rows x one pair keeps the CU full
     int rows = ctx->stripe_rows;
     if (!rows) {
-        if (const char *e = getenv("MGL_PAIRHMM_ROWS")) rows = atoi(e);
+        static const int rows_env = [] { const char *e = getenv("MGL_PAIRHMM_ROWS"); return e ? atoi(e) : 0; }(); // bench scripts
+        rows = rows_env;
         if (rows != 16 && rows != 32 && rows != 64) {
             rows = (max_read_len >= 48 && ph_lds_bytes(max_hap_len, 16, 4) > 12 * 1024) ? 64 : 16;
             // reads of 65 .. 160 bases: two pairs per wave, 32 lanes x up to 5 rows each, waste fewer row slots and half the

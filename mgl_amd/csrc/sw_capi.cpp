@@ -206,7 +206,8 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             }
         }
     }
-    if (const char *e = getenv("MGL_SW_WPB16")) wpb16 = std::max(1, std::min(4, atoi(e))); // launch-shape experiments only
+    static const int wpb16_env = [] { const char *e = getenv("MGL_SW_WPB16"); return e ? std::max(1, std::min(4, atoi(e))) : 0; }();
+    if (wpb16_env) wpb16 = wpb16_env; // launch-shape experiments only
     while (wpb16 > 1 && dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra > 64 * 1024) --wpb16;
     const bool use16 = uniform && ctx->precision != 32 && dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra <= 64 * 1024 &&
                        match > 0 && dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
