@@ -258,6 +258,16 @@ int mgl_sw_cigar_from_backtrack(const int32_t *btr, int tl, int ql, int strategy
  */
 int mgl_sw_ctx_expand_slot(mgl_sw_ctx *ctx, int64_t slot, int tl, int ql, int32_t *btr);
 
+/*
+ * Host helper for MGL_SW_FLAG_GROUPED_GEOMETRY (no device work, usable without a GPU): a permutation of 0 .. n-1 that
+ * puts pairs of equal (t_len, q_len) next to each other.  order_out[0 .. *n_grouped_out) are FULL blocks of eight pairs
+ * with one geometry each (a multiple of eight entries: pass them, through the (start, length) arrays of
+ * mgl_sw_align_batch_device_indexed / _2bit permuted by order_out, with the flag set); the rest -- fewer than eight
+ * pairs per distinct geometry -- follows, sorted by geometry (an ordinary mixed batch, no flag).  O(n) when the lengths
+ * span at most 2^22 distinct (t_len, q_len) cells, else O(n log n).
+ */
+int mgl_sw_group_by_geometry(int64_t n, const int32_t *t_len, const int32_t *q_len, int64_t *order_out, int64_t *n_grouped_out);
+
 #ifdef __cplusplus
 }
 #endif

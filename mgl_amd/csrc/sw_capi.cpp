@@ -1081,4 +1081,48 @@ int mgl_sw_backtrack_matrix(const char *t, int tl, const char *q, int ql, int ma
     return rc;
 }
 
+int mgl_sw_group_by_geometry(int64_t n, const int32_t *t_len, const int32_t *q_len, int64_t *order_out, int64_t *n_grouped_out)
+{
+    if (n < 0 || (n > 0 && (!t_len || !q_len || !order_out)) || !n_grouped_out) return MGL_SW_ERR_BAD_ARG;
+    *n_grouped_out = 0;
+    if (n == 0) return MGL_SW_OK;
+    int32_t lo_t = t_len[0], hi_t = t_len[0], lo_q = q_len[0], hi_q = q_len[0];
+    for (int64_t k = 0; k < n; ++k) {
+        lo_t = std::min(lo_t, t_len[k]);
+        hi_t = std::max(hi_t, t_len[k]);
+        lo_q = std::min(lo_q, q_len[k]);
+        hi_q = std::max(hi_q, q_len[k]);
+    }
+    if (lo_t < 0 || lo_q < 0) return MGL_SW_ERR_BAD_ARG;
+    std::vector<int64_t> sorted((size_t)n); // pair indices, sorted by (t_len, q_len), original order inside a geometry
+    const int64_t range_t = (int64_t)hi_t - lo_t + 1, range_q = (int64_t)hi_q - lo_q + 1;
+    if (range_t * range_q <= (1ll << 22)) {
+        // counting sort over the (t_len, q_len) grid
+        std::vector<int64_t> start((size_t)(range_t * range_q) + 1, 0);
+        auto cell = [&](int64_t k) { return (size_t)(((int64_t)t_len[k] - lo_t) * range_q + ((int64_t)q_len[k] - lo_q)); };
+        for (int64_t k = 0; k < n; ++k) ++start[cell(k) + 1];
+        for (size_t c = 1; c < start.size(); ++c) start[c] += start[c - 1];
+        for (int64_t k = 0; k < n; ++k) sorted[(size_t)start[cell(k)]++] = k;
+    } else {
+        for (int64_t k = 0; k < n; ++k) sorted[(size_t)k] = k;
+        std::stable_sort(sorted.begin(), sorted.end(), [&](int64_t a, int64_t b) {
+            return t_len[a] != t_len[b] ? t_len[a] < t_len[b] : q_len[a] < q_len[b];
+        });
+    }
+    // full blocks of eight go to the front, the remainder of every geometry behind them
+    std::vector<int64_t> rest;
+    int64_t g = 0;
+    for (int64_t s0 = 0; s0 < n;) {
+        int64_t s1 = s0 + 1;
+        while (s1 < n && t_len[sorted[(size_t)s1]] == t_len[sorted[(size_t)s0]] && q_len[sorted[(size_t)s1]] == q_len[sorted[(size_t)s0]]) ++s1;
+        const int64_t full = (s1 - s0) & ~(int64_t)7;
+        for (int64_t s = s0; s < s0 + full; ++s) order_out[g++] = sorted[(size_t)s];
+        for (int64_t s = s0 + full; s < s1; ++s) rest.push_back(sorted[(size_t)s]);
+        s0 = s1;
+    }
+    *n_grouped_out = g;
+    for (int64_t r : rest) order_out[g++] = r;
+    return MGL_SW_OK;
+}
+
 } // extern "C"

@@ -107,3 +107,33 @@ def test_synthetic_workloads_are_deterministic():
     # error model sanity: ~1 % substitutions => most reads differ from their source in a few bases
     g, ws, rd = synth.window_batch(3, 64, genome_len=1 << 14)
     assert rd.shape == (64, 150) and (ws >= 0).all() and (ws + 256 <= len(g)).all()
+
+
+def test_group_by_geometry_helper():
+    """mgl_sw_group_by_geometry (host only): a permutation whose front part is full blocks of eight pairs with one
+    geometry each, fewer than eight leftovers per geometry behind it; both sort strategies; degenerate inputs."""
+    import ctypes as C
+
+    import numpy as np
+
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    for n, t_hi, q_hi in ((0, 1, 1), (1, 5, 5), (7, 1, 1), (8, 1, 1), (1000, 3, 4), (20011, 300, 200), (5000, 1 << 20, 1 << 12)):
+        tl = rng.integers(1, t_hi + 1, n).astype(np.int32)
+        ql = rng.integers(1, q_hi + 1, n).astype(np.int32)
+        order = np.full(max(n, 1), -1, np.int64)
+        ng = C.c_int64(-1)
+        assert L.mgl_sw_group_by_geometry(n, tl.ctypes.data, ql.ctypes.data, order.ctypes.data, C.byref(ng)) == 0
+        order = order[:n]
+        assert sorted(order.tolist()) == list(range(n))
+        g = ng.value
+        assert 0 <= g <= n and g % 8 == 0
+        blocks = order[:g].reshape(-1, 8)
+        assert (tl[blocks] == tl[blocks][:, :1]).all() and (ql[blocks] == ql[blocks][:, :1]).all()
+        key = tl[order[g:]].astype(np.int64) << 32 | ql[order[g:]]
+        assert (np.diff(key) >= 0).all()                         # the rest is sorted by geometry
+        if len(key):
+            assert np.unique(key, return_counts=True)[1].max() < 8    # nothing left that would fill a block
+        total = np.unique(tl.astype(np.int64) << 32 | ql, return_counts=True)[1] if n else np.zeros(0, np.int64)
+        assert g == int((total // 8 * 8).sum())
+    assert L.mgl_sw_group_by_geometry(-1, None, None, None, C.byref(C.c_int64())) == _lib.ERR_BAD_ARG

@@ -316,6 +316,66 @@ def test_grouped_geometry_variable_length_reads(aligner):
     assert (gb.offsets.cpu().numpy() == off[o]).all() and (gb.scores.cpu().numpy() == sc[o]).all()
 
 
+def test_grouping_helper_feeds_the_indexed_entry(aligner):
+    """What a C caller does with variable-length reads: mgl_sw_group_by_geometry on the host, then the grouped part through
+    mgl_sw_align_batch_device_indexed with MGL_SW_FLAG_GROUPED_GEOMETRY (packed kernel) and the rest without the flag."""
+    import ctypes as C
+
+    import torch
+
+    from mgl_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(21)
+    n = 3000
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    tl = np.full(n, 256, np.int32)
+    ql = rng.integers(120, 151, n).astype(np.int32)
+    ts = [alpha[rng.integers(0, 4, 256)] for _ in range(n)]
+    qs = []
+    for k in range(n):
+        a = int(rng.integers(0, 256 - ql[k] + 1))
+        q = ts[k][a:a + ql[k]].copy()
+        q[rng.integers(0, ql[k])] = alpha[rng.integers(0, 4)]
+        qs.append(q)
+    order = np.zeros(n, np.int64)
+    ng = C.c_int64()
+    assert L.mgl_sw_group_by_geometry(n, tl.ctypes.data, ql.ctypes.data, order.ctypes.data, C.byref(ng)) == 0
+    assert ng.value > n - 8 * 31
+    dev = torch.device("cuda", 0)
+    t_start = np.arange(n, dtype=np.int64) * 256
+    q_start = np.concatenate([[0], np.cumsum(ql[:-1], dtype=np.int64)])
+    d_t = torch.from_numpy(np.concatenate(ts)).to(dev)
+    d_q = torch.from_numpy(np.concatenate(qs)).to(dev)
+    perm = lambda a: torch.from_numpy(np.ascontiguousarray(a[order])).to(dev)
+    d_ts, d_tl, d_qs, d_ql = perm(t_start), perm(tl), perm(q_start), perm(ql)
+    off = torch.zeros(n, dtype=torch.int32, device=dev)
+    sc = torch.zeros((n, 6), dtype=torch.int32, device=dev)
+    cg = torch.zeros((n, 64), dtype=torch.uint8, device=dev)
+    ln = torch.zeros(n, dtype=torch.int32, device=dev)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    for lo, cnt, flags in ((0, ng.value, _lib.FLAG_GROUPED_GEOMETRY), (ng.value, n - ng.value, 0)):
+        if cnt == 0:
+            continue
+        rc = L.mgl_sw_align_batch_device_indexed(
+            aligner.ctx, C.c_void_p(stream.cuda_stream), cnt, d_t.data_ptr(), d_ts[lo:].data_ptr(), d_tl[lo:].data_ptr(),
+            d_q.data_ptr(), d_qs[lo:].data_ptr(), d_ql[lo:].data_ptr(), 256, 150, 200, -150, 260, 11, ol.SOFTCLIP,
+            off[lo:].data_ptr(), sc[lo:].data_ptr(), cg[lo:].data_ptr(), 64, ln[lo:].data_ptr(), st[lo:].data_ptr(), flags)
+        assert rc == 0
+        if flags:
+            assert aligner.timing().packed16 == 1
+    torch.cuda.synchronize()
+    assert int((st != 0).sum()) == 0
+    want_off, want_sc, want_cg = ol.oracle_align_batch([t.tobytes() for t in ts], [q.tobytes() for q in qs], (200, -150, 260, 11),
+                                                      ol.SOFTCLIP, nthreads=4)
+    got_off, got_sc, got_ln, got_cg = off.cpu().numpy(), sc.cpu().numpy(), ln.cpu().numpy(), cg.cpu().numpy()
+    for slot in range(n):
+        k = int(order[slot])
+        assert got_off[slot] == want_off[k] and (got_sc[slot] == want_sc[k]).all()
+        assert got_cg[slot, : got_ln[slot]].tobytes().decode() == want_cg[k]
+
+
 def test_single_long_pair_through_the_one_pair_entry():
     """mgl_sw_align (the alignNative replacement, per-thread context) on the 10 kb x 10 kb golden pair: its 50 MB
     traceback must fit without the caller configuring anything, and one pair must not reserve sixteen pairs' worth."""
