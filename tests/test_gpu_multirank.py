@@ -13,9 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_two_ranks_share_the_gpu_over_gloo():
+    import socket
+
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, MGL_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--pairs", "200000", "--steps", "2",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--pairs", "200000", "--steps", "2",
            "--warmup", "1", "--no-secondary"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
