@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <functional>
+#include <future>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -721,19 +722,46 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     if (n < 0 || !targets || !t_off || !queries || !q_off || !offset_out || !cigar_out || cigar_stride < 1 ||
         !strategy_ok(strategy))
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: bad argument");
-    int64_t lo_t = INT64_MAX, hi_t = 0, lo_q = INT64_MAX, hi_q = 0, cells = 0, ungrouped = 0;
-    for (int64_t k = 0; k < n; ++k) {   // branch-free so that it vectorises: 16 bytes of offsets per pair
-        const int64_t tl = t_off[k + 1] - t_off[k], ql = q_off[k + 1] - q_off[k];
-        lo_t = std::min(lo_t, tl);
-        hi_t = std::max(hi_t, tl);
-        lo_q = std::min(lo_q, ql);
-        hi_q = std::max(hi_q, ql);
-        cells += tl * ql;
-        // does every aligned block of eight pairs have one geometry (a batch sorted by read length)?
-        const int64_t kp = k > 0 ? k - 1 : 0;
-        const int64_t d = ((t_off[kp + 1] - t_off[kp]) ^ tl) | ((q_off[kp + 1] - q_off[kp]) ^ ql);
-        ungrouped |= (k & 7) != 0 ? d : 0;
+    // one pass over the offsets (16 bytes per pair): length ranges, cell count, and whether every aligned block of eight pairs
+    // has one geometry (a batch sorted by read length).  Large batches split it over a few threads (160 MB at 10 M pairs:
+    // 15 ms on one core, ahead of the first launch)
+    struct Scan {
+        int64_t lo_t = INT64_MAX, hi_t = 0, lo_q = INT64_MAX, hi_q = 0, cells = 0, ungrouped = 0;
+    };
+    auto scan_range = [&](int64_t a, int64_t b) {
+        Scan r;
+        for (int64_t k = a; k < b; ++k) {   // branch-free so that it vectorises
+            const int64_t tl = t_off[k + 1] - t_off[k], ql = q_off[k + 1] - q_off[k];
+            r.lo_t = std::min(r.lo_t, tl);
+            r.hi_t = std::max(r.hi_t, tl);
+            r.lo_q = std::min(r.lo_q, ql);
+            r.hi_q = std::max(r.hi_q, ql);
+            r.cells += tl * ql;
+            const int64_t kp = k > 0 ? k - 1 : 0;
+            const int64_t d = ((t_off[kp + 1] - t_off[kp]) ^ tl) | ((q_off[kp + 1] - q_off[kp]) ^ ql);
+            r.ungrouped |= (k & 7) != 0 ? d : 0;
+        }
+        return r;
+    };
+    Scan sc;
+    if (n >= (1 << 21)) {
+        constexpr int kParts = 8;
+        std::future<Scan> part[kParts];
+        for (int p = 0; p < kParts; ++p)
+            part[p] = std::async(std::launch::async, scan_range, n * p / kParts, n * (p + 1) / kParts);
+        for (int p = 0; p < kParts; ++p) {
+            const Scan r = part[p].get();
+            sc.lo_t = std::min(sc.lo_t, r.lo_t);
+            sc.hi_t = std::max(sc.hi_t, r.hi_t);
+            sc.lo_q = std::min(sc.lo_q, r.lo_q);
+            sc.hi_q = std::max(sc.hi_q, r.hi_q);
+            sc.cells += r.cells;
+            sc.ungrouped |= r.ungrouped;
+        }
+    } else {
+        sc = scan_range(0, n);
     }
+    const int64_t lo_t = sc.lo_t, hi_t = sc.hi_t, lo_q = sc.lo_q, hi_q = sc.hi_q, cells = sc.cells, ungrouped = sc.ungrouped;
     // the reference reads out of bounds for empty sequences (sw.cpp:162-163,184): rejected here
     if (lo_t < 1 || lo_q < 1 || hi_t > 0x3fffffff || hi_q > 0x3fffffff)
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: sequence length < 1 or too large");
