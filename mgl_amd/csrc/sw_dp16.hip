@@ -52,7 +52,11 @@ __device__ __forceinline__ unsigned row_shr1(unsigned lane0_value, unsigned src)
 }
 __device__ __forceinline__ short2_t as_s2(unsigned x) { return __builtin_bit_cast(short2_t, x); }
 __device__ __forceinline__ unsigned as_u(short2_t x) { return __builtin_bit_cast(unsigned, x); }
-__device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b) { return as_u(as_s2(a) - as_s2(b)); }
+__device__ __forceinline__ ushort2_t as_us2(unsigned x) { return __builtin_bit_cast(ushort2_t, x); }
+// wrapping 16-bit arithmetic on the unsigned type: the bits are those of the signed operation, and lanes that hold no
+// valid cell (columns > ql, rows > tl) may wrap without that being undefined behaviour
+__device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, as_us2(a) + as_us2(b)); }
+__device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, as_us2(a) - as_us2(b)); }
 __device__ __forceinline__ unsigned pk_sub_sat(unsigned a, unsigned b)
 {
     return as_u(__builtin_elementwise_sub_sat(as_s2(a), as_s2(b)));
@@ -68,7 +72,7 @@ __device__ __forceinline__ unsigned pk_min_u(unsigned a, unsigned b)
 }
 __device__ __forceinline__ unsigned pk_mad(unsigned a, unsigned b, unsigned c)
 {
-    return as_u(as_s2(a) * as_s2(b) + as_s2(c));
+    return __builtin_bit_cast(unsigned, as_us2(a) * as_us2(b) + as_us2(c));
 }
 __device__ __forceinline__ unsigned pack2(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
 __device__ __forceinline__ int lo16(unsigned x) { return (int)(short)(x & 0xffffu); }
@@ -112,11 +116,11 @@ __device__ __forceinline__ void cell16(const int U, Lane16 &st, const unsigned r
     const unsigned ein = row_shr1(re, st.e_prev);
     unsigned diag;
     if (MATRIX) {
-        diag = as_u(as_s2(st.hup) + as_s2(sub));
+        diag = pk_add(st.hup, sub);
     } else {
         const unsigned m = pk_min_u(q ^ tt, c.one);     // 1 where the bases differ
         const unsigned s = pk_mad(m, c.delta, c.k2);    // match + 2e, or mismatch + 2e (not on the dependency chain)
-        diag = as_u(as_s2(st.hup) + as_s2(s));
+        diag = pk_add(st.hup, s);
     }
     const unsigned sm = pk_max(diag, st.f);
     h = pk_max(sm, ein);
