@@ -47,11 +47,12 @@ void mgl_pairhmm_ctx_destroy(mgl_pairhmm_ctx *ctx);
 /* replaces initNative(use_double, max_threads), …PairHmm.cc:47-70 (max_threads is ignored there too) */
 int mgl_pairhmm_initialize(mgl_pairhmm_ctx *ctx, int use_double, int max_threads);
 
-/* lanes per pair of the kernels: 0 (default) = per batch (16 lanes x four pairs per wave while the four LDS carry rings
- * leave the CU occupied; 32 lanes x two pairs, up to five read rows per lane, for reads of 65 .. 160 bases; else 64
- * lanes x one pair per wave, up to four rows per lane and as many stripes as the read needs); 16 / 32 / 64 force one
- * (tests; 32 falls back to 64 for longer reads; every cell and the column-order final sum are computed the same way,
- * so the results agree to float rounding: only the contraction of multiply-adds may differ between the variants) */
+/* lanes per pair of the kernels: 0 (default) = per batch (16 lanes x four pairs per wave for very short reads; 21 lanes x
+ * three pairs or 32 lanes x two pairs per wave, up to five read rows per lane, for reads of 24 .. 160 bases and more
+ * than 1 024 pairs; else 64 lanes x one pair per wave, up to four rows per lane and as many stripes as the read needs);
+ * 16 / 21 / 32 / 64 force one (tests; 21 and 32 fall back to 64 for reads beyond 105 / 160 bases; every cell and the
+ * column-order final sum are computed the same way, so the results agree to float rounding: only the contraction of
+ * multiply-adds may differ between the variants) */
 int mgl_pairhmm_set_stripe_rows(mgl_pairhmm_ctx *ctx, int rows);
 
 /* replaces computeLikelihoodsNative(lengthBuffer, readsBuffer, haplotypesBuffer, likelihoodBuffer),

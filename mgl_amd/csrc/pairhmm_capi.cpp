@@ -168,22 +168,35 @@ int run_device(mgl_pairhmm_ctx *ctx, hipStream_t stream, int64_t n_pairs, const 
     if (!rows) {
         static const int rows_env = [] { const char *e = getenv("MGL_PAIRHMM_ROWS"); return e ? atoi(e) : 0; }(); // bench scripts
         rows = rows_env;
-        if (rows != 16 && rows != 32 && rows != 64) {
+        if (rows != 16 && rows != 21 && rows != 32 && rows != 64) {
             rows = (max_read_len >= 48 && ph_lds_bytes(max_hap_len, 16, 4) > 12 * 1024) ? 64 : 16;
-            // reads of 65 .. 160 bases: two pairs per wave, 32 lanes x up to 5 rows each, waste fewer row slots and half the
-            // pipeline depth of one pair per wave (150 bases: 150 of 160 slots instead of 150 of 192); measured faster up to
-            // haplotypes of ~800 bases (150 x 300: 2 560 vs 1 908 GCUPS; x 700: 2 358 vs 2 199; x 1000: 2 051 vs 2 076)
-            // ... when there are more pairs than SIMDs: a call of up to 1 024 pairs (one active region) is latency bound, and
-            // one pair per wave has fewer rows per lane, i.e. a shorter dependent chain per step (800 pairs: 74 vs 80 us)
-            if (rows == 64 && n_pairs > 1024 && max_read_len > 64 && max_read_len <= 160 && ph_lds_bytes(max_hap_len, 32, 4) <= 24 * 1024)
-                rows = 32;
+            // Reads of 24 .. 160 bases, more pairs than SIMDs: several pairs per wave -- 32 lanes x up to 5 rows (two pairs) or
+            // 21 lanes x up to 5 rows (three pairs, reads up to 105), whichever wastes fewer row slots -- instead of one pair
+            // on 64 lanes: 150 bases fill 150 of 160 slots instead of 150 of 192 and the pipeline is 32 (21) steps deep
+            // instead of 64.  Measured (1.6 M pairs): 150 x 300 2 560 vs 1 908 GCUPS; 100 x 250 2 470 (21 lanes) vs 1 964
+            // (32) vs 1 639 (64); 76 x 100 1 739 vs 1 436 (16 lanes); 64 x 200 1 837 (32) vs 1 805 (21); 150 x 1000 2 051
+            // vs 2 076 (64): the carry rings of long haplotypes cost occupancy, hence the LDS bounds.
+            // A call of up to 1 024 pairs (one active region) is latency bound instead: one pair per wave has the fewest
+            // rows per lane, i.e. the shortest dependent chain per step (800 pairs: 74 vs 80 us).
+            if (n_pairs > 1024 && max_read_len >= 24 && max_read_len <= 160) {
+                const int slots21 = 21 * ((max_read_len + 20) / 21), slots32 = 32 * ((max_read_len + 31) / 32);
+                const bool ok21 = max_read_len <= 105 && ph_lds_bytes(max_hap_len, 21, 4) <= 24 * 1024;
+                const bool ok32 = ph_lds_bytes(max_hap_len, 32, 4) <= 24 * 1024;
+                if (ok21 && (slots21 <= slots32 || !ok32))
+                    rows = 21;
+                else if (ok32)
+                    rows = 32;
+                else if (max_read_len > 64)
+                    rows = 64;
+            }
         }
     }
     if (rows == 32 && (max_read_len > 160 || ph_lds_bytes(max_hap_len, 32, 4) > 160 * 1024)) rows = 64; // one stripe of 32 x 5 rows
+    if (rows == 21 && (max_read_len > 105 || ph_lds_bytes(max_hap_len, 21, 4) > 160 * 1024)) rows = 64; // one stripe of 21 x 5 rows
     if (ph_lds_bytes(max_hap_len, rows, 4) > 160 * 1024) rows = 64; // four rings would not fit LDS at all
     const int rows_d = ph_lds_bytes(max_hap_len, 16, 8) <= 160 * 1024 && rows == 16 ? 16 : 64;
     const int rows_per_lane = std::min(4, (max_read_len + 63) / 64);           // one pair per wave (and the double pass)
-    const int rows_per_lane_f = rows == 32 ? std::max(3, (max_read_len + 31) / 32) : rows_per_lane;
+    const int rows_per_lane_f = rows == 32 ? std::max(3, (max_read_len + 31) / 32) : rows == 21 ? std::max(3, (max_read_len + 20) / 21) : rows_per_lane;
     const bool prof = ctx->profiling != 0;
     ctx->ev_valid = false;
     ctx->ran_float = !ctx->use_double;
@@ -290,7 +303,7 @@ int mgl_pairhmm_initialize(mgl_pairhmm_ctx *ctx, int use_double, int max_threads
 
 int mgl_pairhmm_set_stripe_rows(mgl_pairhmm_ctx *ctx, int rows)
 {
-    if (!ctx || (rows != 0 && rows != 16 && rows != 32 && rows != 64)) return MGL_PAIRHMM_ERR_BAD_ARG;
+    if (!ctx || (rows != 0 && rows != 16 && rows != 21 && rows != 32 && rows != 64)) return MGL_PAIRHMM_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->stripe_rows = rows;
     return MGL_PAIRHMM_OK;

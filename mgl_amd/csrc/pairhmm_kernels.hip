@@ -35,11 +35,12 @@ template <int G>
 __device__ __forceinline__ int dpp_shr1(int lane0_value, int src)
 {
     const int r = __builtin_amdgcn_update_dpp(lane0_value, src, G == 16 ? DPP_ROW_SHR1 : DPP_WAVE_SHR1, 0xf, 0xf, false);
-    if (G != 32) return r;
-    // two groups of 32 lanes: lane 32 must not see lane 31 (one v_cndmask on a wave-constant lane mask)
-    return (threadIdx.x & 31) == 0 ? lane0_value : r;
+    if (G == 16 || G == 64) return r;
+    // two groups of 32 lanes or three of 21: the first lane of a group must not see the last lane of the group before
+    // (one v_cndmask on a wave-constant lane mask)
+    return (threadIdx.x & 63) % G == 0 ? lane0_value : r;
 }
-// every lane takes src from the lane below it inside its group of G lanes (16: one DPP row; 32: half a wave; 64: the wave);
+// every lane takes src from the lane below it inside its group of G lanes (16: one DPP row; 21 / 32: a third / half of the wave; 64: the wave);
 // lane 0 of the group takes lane0_value
 template <int G>
 __device__ __forceinline__ float shift_in(float lane0_value, float src)
@@ -390,22 +391,25 @@ __device__ __forceinline__ void phk_step4(LaneK<T, K> &st, const Carry<T> (&cin)
     }
 }
 
-// G = lanes per pair: 64 (one pair per wave; R, H wave-uniform) or 32 (two pairs per wave, each with its own R, H, LDS
+// G = lanes per pair: 64 (one pair per wave; R, H wave-uniform), 32 or 21 (two / three pairs per wave, each with its own R, H, LDS
 // carve and result lane; reads up to 32 * K rows, a single stripe: 150-base reads fill 150 of 160 row slots instead of
 // 150 of 192, and the pipeline is 32 steps deep instead of 64).  `store`: this group holds a real pair.
 template <typename T, int G, int K, bool RESCUE>
 __device__ __forceinline__ void pairhmm_body_k(const PhArgs &a, unsigned char *smem, const int64_t p, const bool store, const int R,
                                                const int H, const uint8_t *rbase, const int64_t h0)
 {
-    const int L = threadIdx.x & (G - 1);
+    constexpr int PW = 64 / G;               // pairs per wave (G = 21: lane 63 rides along as a 22nd lane of the last group)
+    const int grp = min((int)(threadIdx.x & 63) / G, PW - 1);
+    const int L = (int)(threadIdx.x & 63) - grp * G;
     const int pad = (K - R % K) % K;         // virtual rows in front
     const int rows_v = R + pad;              // a multiple of K
-    // loop bounds are wave-uniform: the larger / smaller of the two groups' (G == 32)
+    // loop bounds are wave-uniform: the largest / smallest of the groups'
     int ns_w = (rows_v + G * K - 1) / (G * K), h_max = H, h_min = H;
-    if (G == 32) {
-        ns_w = max(ns_w, __shfl_xor(ns_w, 32));
-        h_max = max(h_max, __shfl_xor(h_max, 32));
-        h_min = min(h_min, __shfl_xor(h_min, 32));
+#pragma unroll
+    for (int g = 1; g < PW; ++g) {
+        ns_w = max(ns_w, max(__shfl(ns_w, 0), __shfl(ns_w, g * G)));
+        h_max = max(h_max, max(__shfl(h_max, 0), __shfl(h_max, g * G)));
+        h_min = min(h_min, min(__shfl(h_min, 0), __shfl(h_min, g * G)));
     }
     const int nstripes = __builtin_amdgcn_readfirstlane(ns_w);
     const int sps8 = (__builtin_amdgcn_readfirstlane(h_max) + G + 7) & ~7;
@@ -413,7 +417,7 @@ __device__ __forceinline__ void pairhmm_body_k(const PhArgs &a, unsigned char *s
 
     const int ring_entries = a.hap_cap + 2 * G + 16;
     const int hap_bytes = (a.hap_cap + 2 * G + 28 + 7) & ~7; // keeps the next group's ring 8-byte aligned
-    unsigned char *gbase = smem + (size_t)((threadIdx.x & 63) / G) * ((size_t)ring_entries * sizeof(Carry<T>) + hap_bytes);
+    unsigned char *gbase = smem + (size_t)grp * ((size_t)ring_entries * sizeof(Carry<T>) + hap_bytes);
     Carry<T> *ring = reinterpret_cast<Carry<T> *>(gbase);
     unsigned char *hbuf = gbase + ring_entries * sizeof(Carry<T>);
 
@@ -555,15 +559,17 @@ __device__ __forceinline__ void pairhmm_wave(const PhArgs &a, unsigned char *sme
         pairhmm_body_k<T, 64, 4, RESCUE>(a, smem, slot, true, R, H, rbase, h0);
 }
 
-// two pairs per wave, 32 lanes x K rows each (reads up to 32 * KMAX bases: one stripe); K is the wave's: ceil(longer read / 32)
-template <typename T, bool RESCUE, int KMAX>
-__device__ __forceinline__ void pairhmm_wave32(const PhArgs &a, unsigned char *smem)
+// several pairs per wave, G = 32 or 21 lanes x K rows each (reads up to G * KMAX bases: one stripe); K is the wave's:
+// ceil(longest read / G)
+template <typename T, int G, bool RESCUE, int KMAX>
+__device__ __forceinline__ void pairhmm_wave_multi(const PhArgs &a, unsigned char *smem)
 {
-    const int grp = (threadIdx.x & 63) >> 5;
-    const int64_t slot = (int64_t)blockIdx.x * 2 + grp;
-    if ((int64_t)blockIdx.x * 2 >= a.n_pairs) return;
+    constexpr int PW = 64 / G;
+    const int grp = min((int)(threadIdx.x & 63) / G, PW - 1);
+    const int64_t slot = (int64_t)blockIdx.x * PW + grp;
+    if ((int64_t)blockIdx.x * PW >= a.n_pairs) return;
     const bool store = slot < a.n_pairs;
-    const int64_t p = store ? slot : a.n_pairs - 1; // an odd batch: the idle half repeats the last pair, stores nothing
+    const int64_t p = store ? slot : a.n_pairs - 1; // a partly filled last wave: the idle groups repeat the last pair, store nothing
     if (RESCUE && a.rescue_only) {
         const bool need = store && a.need_double[p] != 0;
         if (!__builtin_amdgcn_ballot_w64(need)) return;
@@ -572,16 +578,19 @@ __device__ __forceinline__ void pairhmm_wave32(const PhArgs &a, unsigned char *s
     const int64_t r0 = a.read_off[ri], h0 = a.hap_off[hi];
     const int R = (int)(a.read_off[ri + 1] - r0), H = (int)(a.hap_off[hi + 1] - h0);
     const uint8_t *rbase = a.reads + 5 * r0;
-    const int r_max = __builtin_amdgcn_readfirstlane(max(R, __shfl_xor(R, 32)));
-    const int k = min(KMAX, (r_max + 31) >> 5);
+    int r_w = R;
+#pragma unroll
+    for (int g = 1; g < PW; ++g) r_w = max(r_w, max(__shfl(r_w, 0), __shfl(r_w, g * G)));
+    const int r_max = __builtin_amdgcn_readfirstlane(r_w);
+    const int k = min(KMAX, (r_max + G - 1) / G);
     if (k <= 2)
-        pairhmm_body_k<T, 32, 2, RESCUE>(a, smem, p, store, R, H, rbase, h0);
+        pairhmm_body_k<T, G, 2, RESCUE>(a, smem, p, store, R, H, rbase, h0);
     else if (k == 3)
-        pairhmm_body_k<T, 32, 3, RESCUE>(a, smem, p, store, R, H, rbase, h0);
+        pairhmm_body_k<T, G, 3, RESCUE>(a, smem, p, store, R, H, rbase, h0);
     else if (KMAX == 4 || k == 4)
-        pairhmm_body_k<T, 32, 4, RESCUE>(a, smem, p, store, R, H, rbase, h0);
+        pairhmm_body_k<T, G, 4, RESCUE>(a, smem, p, store, R, H, rbase, h0);
     else
-        pairhmm_body_k<T, 32, 5, RESCUE>(a, smem, p, store, R, H, rbase, h0);
+        pairhmm_body_k<T, G, 5, RESCUE>(a, smem, p, store, R, H, rbase, h0);
 }
 
 } // namespace
@@ -590,7 +599,13 @@ template <int KMAX>
 __global__ __launch_bounds__(64) void pairhmm_float32_kernel(const PhArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    pairhmm_wave32<float, false, KMAX>(a, smem);
+    pairhmm_wave_multi<float, 32, false, KMAX>(a, smem);
+}
+template <int KMAX>
+__global__ __launch_bounds__(64) void pairhmm_float21_kernel(const PhArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    pairhmm_wave_multi<float, 21, false, KMAX>(a, smem);
 }
 __global__ __launch_bounds__(64) void pairhmm_float_kernel(const PhArgs a)
 {
@@ -642,6 +657,8 @@ hipError_t launch_pairhmm_float(const PhArgs &a, int rows, int rows_per_lane, hi
 {
     if (rows == 32) // two pairs per wave; rows_per_lane = ceil(longest read / 32), 3 .. 5 (the host layer picks the range)
         return rows_per_lane <= 4 ? launch(pairhmm_float32_kernel<4>, a, 32, 4, stream) : launch(pairhmm_float32_kernel<5>, a, 32, 4, stream);
+    if (rows == 21) // three pairs per wave; rows_per_lane = ceil(longest read / 21), up to 5 (reads up to 105 bases)
+        return rows_per_lane <= 4 ? launch(pairhmm_float21_kernel<4>, a, 21, 4, stream) : launch(pairhmm_float21_kernel<5>, a, 21, 4, stream);
     if (rows != 64) return launch(pairhmm_float_kernel, a, 16, 4, stream);
     switch (rows_per_lane) {
     case 1: return launch(pairhmm_float64_kernel<1>, a, 64, 4, stream);

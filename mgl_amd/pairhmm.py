@@ -187,7 +187,7 @@ class MicrosoftPairHmm:
         return out
 
     def set_stripe_rows(self, rows):
-        """Lanes per pair of the kernels: 0 = per batch, 16 (four pairs per wave), 32 (two) or 64 (one pair per wave)."""
+        """Lanes per pair of the kernels: 0 = per batch, 16 (four pairs per wave), 21 (three), 32 (two) or 64 (one pair per wave)."""
         _check(lib().mgl_pairhmm_set_stripe_rows(self._ensure(), int(rows)))
 
     def set_profiling(self, on=True):

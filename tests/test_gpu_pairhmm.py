@@ -124,14 +124,16 @@ def test_quality_bytes_are_masked_like_the_reference(hmm):
         assert abs(got[k] - want) < (1e-9 * max(1.0, abs(want)) if used else 1e-5), (k, got[k], want)
 
 
-@pytest.mark.parametrize("rows", [0, 32])
-def test_two_pairs_per_wave(hmm, rows):
-    """Reads of up to 160 bases: 32 lanes x up to five rows per pair, two pairs per wave (forced, and as the per-batch
-    choice); ragged lengths from 1, odd pair counts (a half-empty last wave), N bases, pairs that need the double rescue."""
+@pytest.mark.parametrize("rows,max_reads", [(0, (160, 150, 129, 97, 70, 160)), (32, (160, 150, 129, 97, 70, 160)),
+                                            (21, (105, 101, 84, 64, 42, 21, 105)), (0, (105, 101, 76))])
+def test_two_pairs_per_wave(hmm, rows, max_reads):
+    """Reads of up to 160 bases: 32 lanes x up to five rows per pair, two pairs per wave; up to 105 bases: 21 lanes, three
+    pairs per wave (forced, and as the per-batch choice); ragged lengths from 1, odd pair counts (a partly filled last
+    wave), N bases, pairs that need the double rescue."""
     rng = np.random.default_rng(57)
     hmm.initialize(pairhmm.PairHMMNativeArguments(False, 1))
     hmm.set_stripe_rows(rows)
-    for trial, max_read in enumerate((160, 150, 129, 97, 70, 160)):
+    for trial, max_read in enumerate(max_reads):
         reads, haps = _region(rng, 2 * int(rng.integers(1, 16)) + 1, 2 * int(rng.integers(0, 4)) + 1, with_n=(trial % 2 == 1),
                               max_read=max_read, max_hap=330)
         got = np.zeros(len(reads) * len(haps))
