@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "pairhmm_device.h"
 
 namespace mgl_ph_dev {
@@ -537,9 +539,8 @@ __device__ __forceinline__ void pairhmm_body_k(const PhArgs &a, unsigned char *s
 
 // one pair per wave: picks the rows-per-lane variant for this pair's read length
 template <typename T, bool RESCUE, int KMAX>
-__device__ __forceinline__ void pairhmm_wave(const PhArgs &a, unsigned char *smem)
+__device__ __forceinline__ void pairhmm_wave(const PhArgs &a, unsigned char *smem, const int64_t slot)
 {
-    const int64_t slot = (int64_t)blockIdx.x;
     if (slot >= a.n_pairs) return;
     if (RESCUE && a.rescue_only && a.need_double[slot] == 0) return;
     const int32_t ri = a.pair_read[slot], hi = a.pair_hap[slot];
@@ -616,7 +617,7 @@ template <int KMAX>
 __global__ __launch_bounds__(64) void pairhmm_float64_kernel(const PhArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    pairhmm_wave<float, false, KMAX>(a, smem);
+    pairhmm_wave<float, false, KMAX>(a, smem, (int64_t)blockIdx.x);
 }
 __global__ __launch_bounds__(64) void pairhmm_double_kernel(const PhArgs a)
 {
@@ -627,7 +628,24 @@ template <int KMAX>
 __global__ __launch_bounds__(64) void pairhmm_double64_kernel(const PhArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    pairhmm_wave<double, true, KMAX>(a, smem);
+    if (!a.rescue_only) {
+        pairhmm_wave<double, true, KMAX>(a, smem, (int64_t)blockIdx.x);
+        return;
+    }
+    // rescue pass after the float pass: almost no pair needs it.  A few thousand waves sweep the flags 64 at a time (one
+    // coalesced load + a ballot) instead of one wave per pair launching only to return: 0.33 -> 0.02 ms per 1.6 M pairs
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < a.n_pairs; base += (int64_t)gridDim.x * 64) {
+        const bool flagged = base + lane < a.n_pairs && a.need_double[base + lane] != 0;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(flagged);
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            pairhmm_wave<double, true, KMAX>(a, smem, base + l);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the next pair reuses the LDS carve
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
 }
 
 int ph_lds_bytes(int hap_cap, int rows, int elem_bytes)
@@ -639,7 +657,7 @@ int ph_lds_bytes(int hap_cap, int rows, int elem_bytes)
 }
 
 template <typename K>
-static hipError_t launch(K kernel, const PhArgs &a, int rows, int elem_bytes, hipStream_t stream)
+static hipError_t launch(K kernel, const PhArgs &a, int rows, int elem_bytes, hipStream_t stream, bool sweep = false)
 {
     const int lds = ph_lds_bytes(a.hap_cap, rows, elem_bytes);
     if (lds > 64 * 1024) { // per device and rare (haplotypes beyond ~1 300 bases): set every time, no cache to go stale
@@ -647,7 +665,8 @@ static hipError_t launch(K kernel, const PhArgs &a, int rows, int elem_bytes, hi
         if (e != hipSuccess) return e;
     }
     const int per_wave = 64 / rows;
-    const int64_t blocks = (a.n_pairs + per_wave - 1) / per_wave; // one wave per block: the LDS carve, not the wave count, limits a CU
+    int64_t blocks = (a.n_pairs + per_wave - 1) / per_wave; // one wave per block: the LDS carve, not the wave count, limits a CU
+    if (sweep) blocks = std::min<int64_t>((a.n_pairs + 63) / 64, 4096); // rescue pass of the 64-lane double kernels: see there
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
@@ -672,10 +691,10 @@ hipError_t launch_pairhmm_double(const PhArgs &a, int rows, int rows_per_lane, h
 {
     if (rows != 64) return launch(pairhmm_double_kernel, a, 16, 8, stream);
     switch (rows_per_lane) {
-    case 1: return launch(pairhmm_double64_kernel<1>, a, 64, 8, stream);
-    case 2: return launch(pairhmm_double64_kernel<2>, a, 64, 8, stream);
-    case 3: return launch(pairhmm_double64_kernel<3>, a, 64, 8, stream);
-    default: return launch(pairhmm_double64_kernel<4>, a, 64, 8, stream);
+    case 1: return launch(pairhmm_double64_kernel<1>, a, 64, 8, stream, a.rescue_only != 0);
+    case 2: return launch(pairhmm_double64_kernel<2>, a, 64, 8, stream, a.rescue_only != 0);
+    case 3: return launch(pairhmm_double64_kernel<3>, a, 64, 8, stream, a.rescue_only != 0);
+    default: return launch(pairhmm_double64_kernel<4>, a, 64, 8, stream, a.rescue_only != 0);
     }
 }
 
