@@ -16,27 +16,36 @@
 #ifdef MGL_PAIRHMM_HAVE_JNI
 #include <jni.h>
 
+#include <atomic>
 #include <cstdlib>
-#include <mutex>
 
 #include "../../include/mgl_pairhmm.h"
 
 namespace {
-// initNative is static in the reference (globals g_use_double, …PairHmm.cc:36-38); one context per process here
-std::mutex g_mu;
-mgl_pairhmm_ctx *g_ctx = nullptr;
-int g_use_double = 0;
+// initNative is static in the reference (globals g_use_double, …PairHmm.cc:36-38); here the flag is process-wide too, the GPU
+// context is per calling thread (calls on one context are serialised; regions computed by different threads overlap on the GPU)
+std::atomic<int> g_use_double{0};
+
+struct Holder {
+    mgl_pairhmm_ctx *ctx = nullptr;
+    int use_double = -1;
+    ~Holder() { mgl_pairhmm_ctx_destroy(ctx); }
+};
 
 mgl_pairhmm_ctx *context()
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_ctx) {
+    static thread_local Holder h;
+    if (!h.ctx) {
         int dev = 0;
         if (const char *e = getenv("MGL_PAIRHMM_DEVICE")) dev = atoi(e);
-        if (mgl_pairhmm_ctx_create(dev, &g_ctx) != MGL_PAIRHMM_OK) return nullptr;
-        mgl_pairhmm_initialize(g_ctx, g_use_double, 1);
+        if (mgl_pairhmm_ctx_create(dev, &h.ctx) != MGL_PAIRHMM_OK) return nullptr;
     }
-    return g_ctx;
+    const int want = g_use_double.load();
+    if (h.use_double != want) {
+        mgl_pairhmm_initialize(h.ctx, want, 1);
+        h.use_double = want;
+    }
+    return h.ctx;
 }
 } // namespace
 
@@ -45,8 +54,8 @@ extern "C" {
 JNIEXPORT void JNICALL Java_com_microsoft_mgl_pairhmm_MicrosoftPairHmm_initNative(JNIEnv *, jclass, jboolean use_double,
                                                                                   jint max_threads)
 {
-    g_use_double = use_double ? 1 : 0; // …PairHmm.cc:50-53
-    if (mgl_pairhmm_ctx *ctx = context()) mgl_pairhmm_initialize(ctx, g_use_double, max_threads);
+    (void)max_threads;                          // ignored by the reference as well (…PairHmm.cc:50-70)
+    g_use_double.store(use_double ? 1 : 0);     // …PairHmm.cc:50-53; picked up by every thread's context at its next call
 }
 
 JNIEXPORT void JNICALL Java_com_microsoft_mgl_pairhmm_MicrosoftPairHmm_computeLikelihoodsNative(JNIEnv *env, jobject,
@@ -71,9 +80,7 @@ JNIEXPORT void JNICALL Java_com_microsoft_mgl_pairhmm_MicrosoftPairHmm_computeLi
 
 JNIEXPORT void JNICALL Java_com_microsoft_mgl_pairhmm_MicrosoftPairHmm_doneNative(JNIEnv *, jobject)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    mgl_pairhmm_ctx_destroy(g_ctx);
-    g_ctx = nullptr;
+    // a no-op in the reference (…PairHmm.cc:224-226); the per-thread contexts are released when their threads end
 }
 
 } // extern "C"
