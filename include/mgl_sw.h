@@ -15,8 +15,9 @@
  * Threading: like the reference's alignNative (stateless, re-entrant,
  * ..._MicrosoftSmithWaterman.cpp:44-71) every function may be called from any
  * thread.  An mgl_sw_ctx serialises the calls made on it; use one ctx per
- * host thread (or per GPU) for concurrency.  mgl_sw_align() uses a
- * thread-local ctx.
+ * host thread (or per GPU) for concurrency.  mgl_sw_align() goes through the
+ * coalescing front-end (mgl_sw_set_coalescing, on by default); with that
+ * switched off it uses a thread-local ctx.
  */
 #ifndef MGL_SW_H
 #define MGL_SW_H
@@ -43,7 +44,8 @@ typedef enum mgl_sw_status {
     MGL_SW_ERR_CIGAR_OVERFLOW = 2, /* a CIGAR did not fit; *cigar_len holds the size needed */
     MGL_SW_ERR_NOMEM = 3,          /* host or device allocation failed */
     MGL_SW_ERR_DEVICE = 4,         /* no HIP device / HIP runtime error (see mgl_sw_last_error) */
-    MGL_SW_ERR_UNSUPPORTED = 5     /* geometry outside what the kernels cover (see mgl_sw_max_query_len) */
+    MGL_SW_ERR_UNSUPPORTED = 5     /* geometry outside what the kernels cover (see mgl_sw_max_query_len), or scores that
+                                      would leave the 32-bit range (parameters x lengths >= 2^30) */
 } mgl_sw_status;
 
 /* ScoreMax, sw_common.h:36-40: best score of the last column (mqe, row mqe_t,
@@ -75,7 +77,8 @@ const char *mgl_sw_strerror(int status);
 int mgl_sw_device_count(void);
 /* longest query accepted (2^24; the matrix must also stay below 2^34 cells) */
 int mgl_sw_max_query_len(void);
-/* longest query whose stripe carry fits LDS; longer ones keep it in an HBM scratch area (slower fill) */
+/* longest query whose stripe carry fits LDS with one wave per pair; longer ones run one pair per workgroup
+ * (sw_dp_coop.hip), the waves handing the carry on through small LDS rings */
 int mgl_sw_max_lds_query_len(void);
 
 int mgl_sw_ctx_create(int device, mgl_sw_ctx **out);
