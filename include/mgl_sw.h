@@ -222,8 +222,9 @@ int mgl_sw_align_batch_device_indexed(mgl_sw_ctx *ctx, void *stream, int64_t n, 
  *     diag = H[i-1][j-1] + matrix[code[t[i-1]] * 32 + code[q[j-1]]]
  * code: 256 bytes -> 0..31, matrix: 32 x 32 int8 (both HOST pointers, copied per call); gopen / gext as in the
  * other entries.  d_t_len / d_q_len (optional, int32 per pair): with them d_t_off[k] / d_q_off[k] are per-pair START
- * positions, so one database sequence can serve many pairs; NULL = pair k is [off[k], off[k+1]).  int32 kernel only; queries up to about 3 300 residues (MGL_SW_ERR_UNSUPPORTED beyond), targets any
- * length.  No parity claim exists for this mode: it is validated against the CPU restatement's own extension and
+ * positions, so one database sequence can serve many pairs; NULL = pair k is [off[k], off[k+1]).  Uniform / grouped batches (flags) whose score range fits 16 bits
+ * take the packed kernel, all others the int32 kernel; queries up to about 3 300 residues (MGL_SW_ERR_UNSUPPORTED
+ * beyond), targets any length.  No parity claim exists for this mode: it is validated against the CPU restatement's own extension and
  * an independent textbook DP (tests/test_gpu_matrix.py).
  */
 int mgl_sw_align_batch_device_matrix(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_targets,
