@@ -108,11 +108,13 @@ class Coalescer {
             cv_work_.notify_all();
         }
         if (worker_.joinable()) worker_.join();
-        if (timing_ && n_batches_)
+        if (timing_ && n_batches_) {
+            const double nb = (double)n_batches_;
             fprintf(stderr, "[mgl_sw] coalescer: %lld batches, mean %.1f pairs; per batch: %.1f us collecting, %.1f us processing "
                             "(%.1f layout, %.1f device round trip, %.1f hand-out), %.1f us waking the callers\n",
-                    (long long)n_batches_, (double)n_pairs_ / n_batches_, t_wait_ / n_batches_, t_process_ / n_batches_,
-                    t_layout_ / n_batches_, t_device_ / n_batches_, t_scatter_ / n_batches_, t_release_ / n_batches_);
+                    (long long)n_batches_, (double)n_pairs_ / nb, t_wait_ / nb, t_process_ / nb, t_layout_ / nb, t_device_ / nb,
+                    t_scatter_ / nb, t_release_ / nb);
+        }
         if (ctx_) mgl_sw_ctx_destroy(ctx_);
     }
 
