@@ -153,6 +153,17 @@ int mgl_sw_align_batch(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const
                        int32_t *cigar_len_out);
 
 /*
+ * The same with a per-pair status array (int32[n], mgl_sw_status values): with status_out non-NULL a CIGAR that
+ * does not fit its slot -- or a device-side failure of one pair -- is reported there and does not fail the call
+ * (*cigar_len_out still receives the size needed).  status_out == NULL is exactly mgl_sw_align_batch.
+ */
+int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const int64_t *t_off,
+                              const uint8_t *queries, const int64_t *q_off, int match, int mismatch,
+                              int gopen, int gext, int strategy, int32_t *offset_out,
+                              mgl_sw_score *score_out, char *cigar_out, int cigar_stride,
+                              int32_t *cigar_len_out, int32_t *status_out);
+
+/*
  * Batch, device-resident: every pointer is a device pointer on ctx's GPU and
  * the work is enqueued on `stream` (a hipStream_t; NULL = the null stream)
  * without synchronising -- unless profiling is enabled.  max_tl / max_ql are

@@ -23,7 +23,7 @@ OK, ERR_BAD_ARG, ERR_CIGAR_OVERFLOW, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED = ra
 SYMBOLS = (
     "mgl_sw_version", "mgl_sw_strerror", "mgl_sw_device_count", "mgl_sw_max_query_len", "mgl_sw_max_lds_query_len", "mgl_sw_ctx_set_carry_memory", "mgl_sw_ctx_set_stripe_rows", "mgl_sw_ctx_set_cooperative", "mgl_sw_ctx_create",
     "mgl_sw_ctx_destroy", "mgl_sw_last_error", "mgl_sw_ctx_set_workspace", "mgl_sw_ctx_set_profiling", "mgl_sw_ctx_set_precision",
-    "mgl_sw_ctx_get_timing", "mgl_sw_normalize_params", "mgl_sw_align", "mgl_sw_align_batch",
+    "mgl_sw_ctx_get_timing", "mgl_sw_normalize_params", "mgl_sw_align", "mgl_sw_align_batch", "mgl_sw_align_batch_status",
     "mgl_sw_align_batch_device", "mgl_sw_align_batch_device_2bit", "mgl_sw_align_batch_device_matrix", "mgl_sw_align_batch_device_indexed", "mgl_sw_backtrack_matrix", "mgl_sw_ctx_expand_slot",
     "mgl_sw_cigar_from_backtrack", "mgl_sw_set_coalescing", "mgl_sw_coalescing_stats", "mgl_sw_group_by_geometry",
 )

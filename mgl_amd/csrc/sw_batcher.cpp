@@ -23,9 +23,10 @@
 #include <tuple>
 #include <vector>
 
-// sw_capi.cpp (library-internal, not part of include/mgl_sw.h)
-extern "C" int mgl_sw_stage_buffers(mgl_sw_ctx *ctx, size_t in_bytes, size_t out_bytes, void **in, void **out);
-extern "C" int mgl_sw_align_batch_staged(mgl_sw_ctx *ctx, int n, size_t in_bytes, size_t t_bytes_padded, int max_tl, int max_ql,
+// sw_capi.cpp (library-internal, not part of include/mgl_sw.h: hidden visibility, not exported from the .so)
+#define MGL_SW_INTERNAL __attribute__((visibility("hidden")))
+extern "C" MGL_SW_INTERNAL int mgl_sw_stage_buffers(mgl_sw_ctx *ctx, size_t in_bytes, size_t out_bytes, void **in, void **out);
+extern "C" MGL_SW_INTERNAL int mgl_sw_align_batch_staged(mgl_sw_ctx *ctx, int n, size_t in_bytes, size_t t_bytes_padded, int max_tl, int max_ql,
                                          int match, int mismatch, int gopen, int gext, int strategy, int cigar_stride,
                                          size_t out_bytes);
 
@@ -270,7 +271,13 @@ class Coalescer {
                 continue;
             }
             *r->cigar_len = len_[(size_t)k];
-            if (status_[(size_t)k] != 0 || len_[(size_t)k] > r->cigar_cap) {
+            // the pair's own status goes back verbatim (a device-side failure must not read as "CIGAR does not fit");
+            // the slot may be wider than this caller's buffer, so a text that fits the slot can still overflow the caller
+            if (status_[(size_t)k] != 0) {
+                r->rc = status_[(size_t)k];
+                continue;
+            }
+            if (len_[(size_t)k] > r->cigar_cap) {
                 r->rc = MGL_SW_ERR_CIGAR_OVERFLOW;
                 continue;
             }
@@ -319,13 +326,13 @@ struct EnvInit {
 } // namespace
 
 // library-internal entry points used by mgl_sw_align (sw_capi.cpp); C linkage, not in include/mgl_sw.h
-extern "C" bool mgl_sw_coalescing_enabled()
+extern "C" MGL_SW_INTERNAL bool mgl_sw_coalescing_enabled()
 {
     static EnvInit once;
     return Coalescer::instance().enabled();
 }
 
-extern "C" int mgl_sw_coalesced_align(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen, int gext,
+extern "C" MGL_SW_INTERNAL int mgl_sw_coalesced_align(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen, int gext,
                            int strategy, char *cigar, int cigar_cap, int *cigar_len, int *offset, mgl_sw_score *ez)
 {
     mgl_sw_normalize_params(&match, &mismatch, &gopen, &gext);

@@ -25,9 +25,17 @@ using namespace mgl_sw_dev;
 
 static_assert(sizeof(mgl_sw_score) == sizeof(Score), "mgl_sw_score layout");
 
+// library-internal entry points shared with sw_batcher.cpp: C linkage, but not exported from the .so
+#define MGL_SW_INTERNAL __attribute__((visibility("hidden")))
+
 namespace {
 
 constexpr int64_t kDefaultWorkspace = 4ll << 30;
+
+// what the caller knows about the pair geometries of a batch
+enum { GEOM_MIXED = 0,    // anything
+       GEOM_UNIFORM = 1,  // every pair exactly max_tl x max_ql
+       GEOM_GROUPED = 2 };// every aligned block of eight pairs has one (tl, ql) <= (max_tl, max_ql)
 
 struct DevBuf {
     void *p = nullptr;
@@ -95,6 +103,11 @@ struct mgl_sw_ctx {
 };
 
 namespace {
+
+int geom_of(int flags)
+{
+    return (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) ? GEOM_UNIFORM : (flags & MGL_SW_FLAG_GROUPED_GEOMETRY) ? GEOM_GROUPED : GEOM_MIXED;
+}
 
 int fail(mgl_sw_ctx *ctx, int status, const std::string &what)
 {
@@ -170,11 +183,12 @@ struct ChunkHooks {
 // Enqueue fill + traceback for a device-resident batch on `stream`.
 int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tset, const SeqSet &qset, int max_tl,
                int max_ql, int match, int mismatch, int gopen, int gext, int strategy, int32_t *d_offset, Score *d_score,
-               char *d_cigar, int cigar_stride, int32_t *d_cigar_len, int32_t *d_status, int64_t cells_hint, bool uniform,
+               char *d_cigar, int cigar_stride, int32_t *d_cigar_len, int32_t *d_status, int64_t cells_hint, int geom,
                bool binary_cigar = false, const ChunkHooks *hooks = nullptr, const int8_t *d_matrix = nullptr,
                const uint8_t *d_code = nullptr, bool score_only_hint = false)
 {
     if (n == 0) return MGL_SW_OK;
+    const bool uniform = geom != GEOM_MIXED;
     if (n < 0 || !tset.data || !tset.off || !qset.data || !qset.off || !d_offset || !d_cigar || cigar_stride < 1 ||
         max_tl < 1 || max_ql < 1 || !strategy_ok(strategy))
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch_device: bad argument");
@@ -244,7 +258,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     if (((int64_t)match - mismatch + gopen + 2 * (int64_t)gext) * ((int64_t)max_tl + max_ql) >= (1ll << 30))
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "scores of this geometry and these parameters leave the 32-bit range");
     // traceback words per pair (int32 layout) or per group of two pairs (packed16 layout)
-    const int64_t stride_words = use16 ? tb_words16_for(max_tl, max_ql) : tb_words_for(max_tl, sps_cap, rows);
+    // (packed layout: the step count of a pair is not monotone in tl or ql -- a partial last stripe runs stand-alone, short
+    // queries are not chained -- so a grouped batch, whose waves each run their own geometry, is sized by a bound that is)
+    const int64_t stride_words = use16 ? (geom == GEOM_UNIFORM ? tb_words16_for(max_tl, max_ql) : tb_words16_bound(max_tl, max_ql))
+                                       : tb_words_for(max_tl, sps_cap, rows);
     const int64_t per_pair = (score_only ? 0 : stride_words * 4 / (use16 ? 2 : 1)) + (int64_t)sizeof(DpRecord);
     // the workspace is split in two halves so that the traceback of one chunk can run (on ctx->aux)
     // while the next chunk is being filled; a batch that fits one half is a single chunk
@@ -606,7 +623,7 @@ int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const ui
     const SeqSet ts{d_targets, d_t_off, nullptr, max_tl, 0}, qs{d_queries, d_q_off, nullptr, max_ql, 0};
     return run_device(ctx, static_cast<hipStream_t>(stream), n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext,
                       strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride,
-                      d_cigar_len_out, d_status_out, 0, (flags & (MGL_SW_FLAG_UNIFORM_GEOMETRY | MGL_SW_FLAG_GROUPED_GEOMETRY)) != 0,
+                      d_cigar_len_out, d_status_out, 0, geom_of(flags),
                       (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, nullptr, nullptr, nullptr, (flags & MGL_SW_FLAG_SCORE_ONLY) != 0);
 }
 
@@ -623,7 +640,7 @@ int mgl_sw_align_batch_device_indexed(mgl_sw_ctx *ctx, void *stream, int64_t n, 
     const SeqSet ts{d_targets, d_t_start, d_t_len, max_tl, 0}, qs{d_queries, d_q_start, d_q_len, max_ql, 0};
     return run_device(ctx, static_cast<hipStream_t>(stream), n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext,
                       strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride,
-                      d_cigar_len_out, d_status_out, 0, (flags & (MGL_SW_FLAG_UNIFORM_GEOMETRY | MGL_SW_FLAG_GROUPED_GEOMETRY)) != 0,
+                      d_cigar_len_out, d_status_out, 0, geom_of(flags),
                       (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, nullptr, nullptr, nullptr, (flags & MGL_SW_FLAG_SCORE_ONLY) != 0);
 }
 
@@ -664,7 +681,7 @@ int mgl_sw_align_batch_device_matrix(mgl_sw_ctx *ctx, void *stream, int64_t n, c
     }
     return run_device(ctx, st, n, ts, qs, max_tl, max_ql, cmax, cmin, gopen, gext, strategy, d_offset_out,
                       reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride, d_cigar_len_out, d_status_out, 0,
-                      (flags & (MGL_SW_FLAG_UNIFORM_GEOMETRY | MGL_SW_FLAG_GROUPED_GEOMETRY)) != 0,
+                      geom_of(flags),
                       (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, nullptr, dm, dc, (flags & MGL_SW_FLAG_SCORE_ONLY) != 0);
 }
 
@@ -686,21 +703,14 @@ int mgl_sw_align_batch_device_2bit(mgl_sw_ctx *ctx, void *stream, int64_t n, con
         qs{d_query_bases, d_q_start, uniform ? nullptr : d_q_len, max_ql, 1};
     return run_device(ctx, static_cast<hipStream_t>(stream), n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext,
                       strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride,
-                      d_cigar_len_out, d_status_out, 0, uniform || grouped, (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, nullptr, nullptr,
+                      d_cigar_len_out, d_status_out, 0, uniform ? GEOM_UNIFORM : grouped ? GEOM_GROUPED : GEOM_MIXED, (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, nullptr, nullptr,
                       nullptr, (flags & MGL_SW_FLAG_SCORE_ONLY) != 0);
 }
 
 static int stage_buffers_nolock(mgl_sw_ctx *ctx, size_t in_bytes, size_t out_bytes, void **in, void **out);
 static int align_batch_staged_nolock(mgl_sw_ctx *ctx, int n, size_t in_bytes, size_t t_bytes_padded, int max_tl, int max_ql, int match,
-                                     int mismatch, int gopen, int gext, int strategy, int cigar_stride, size_t out_bytes, bool uniform,
+                                     int mismatch, int gopen, int gext, int strategy, int cigar_stride, size_t out_bytes, int uniform,
                                      int64_t cells_hint);
-
-// mgl_sw_align_batch with an optional per-pair status array: with it, a CIGAR overflow of one pair does not
-// fail the call (used by the coalescing front-end, where every caller has its own buffer size)
-int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const int64_t *t_off,
-                              const uint8_t *queries, const int64_t *q_off, int match, int mismatch, int gopen,
-                              int gext, int strategy, int32_t *offset_out, mgl_sw_score *score_out, char *cigar_out,
-                              int cigar_stride, int32_t *cigar_len_out, int32_t *status_out);
 
 int mgl_sw_align_batch(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const int64_t *t_off,
                        const uint8_t *queries, const int64_t *q_off, int match, int mismatch, int gopen, int gext,
@@ -766,7 +776,7 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     if (lo_t < 1 || lo_q < 1 || hi_t > 0x3fffffff || hi_q > 0x3fffffff)
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: sequence length < 1 or too large");
     const int max_tl = (int)hi_t, max_ql = (int)hi_q;
-    const bool uniform = (lo_t == hi_t && lo_q == hi_q) || ungrouped == 0; // one geometry per batch, or per block of eight
+    const int uniform = (lo_t == hi_t && lo_q == hi_q) ? GEOM_UNIFORM : ungrouped == 0 ? GEOM_GROUPED : GEOM_MIXED; // one geometry per batch, or per block of eight
     const size_t t_bytes = (size_t)(t_off[n] - t_off[0]), q_bytes = (size_t)(q_off[n] - q_off[0]);
     if (t_off[0] != 0 || q_off[0] != 0)
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch: offsets must start at 0");
@@ -916,7 +926,7 @@ static int stage_buffers_nolock(mgl_sw_ctx *ctx, size_t in_bytes, size_t out_byt
     return MGL_SW_OK;
 }
 
-int mgl_sw_stage_buffers(mgl_sw_ctx *ctx, size_t in_bytes, size_t out_bytes, void **in, void **out)
+MGL_SW_INTERNAL int mgl_sw_stage_buffers(mgl_sw_ctx *ctx, size_t in_bytes, size_t out_bytes, void **in, void **out)
 {
     if (!ctx || !in || !out) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -924,7 +934,7 @@ int mgl_sw_stage_buffers(mgl_sw_ctx *ctx, size_t in_bytes, size_t out_bytes, voi
 }
 
 static int align_batch_staged_nolock(mgl_sw_ctx *ctx, int n, size_t in_bytes, size_t t_bytes_padded, int max_tl, int max_ql, int match,
-                                     int mismatch, int gopen, int gext, int strategy, int cigar_stride, size_t out_bytes, bool uniform,
+                                     int mismatch, int gopen, int gext, int strategy, int cigar_stride, size_t out_bytes, int uniform,
                                      int64_t cells_hint)
 {
     if (in_bytes > ctx->pin_in_cap || out_bytes > ctx->pin_out_cap) return fail(ctx, MGL_SW_ERR_BAD_ARG, "staged batch larger than its buffers");
@@ -966,18 +976,18 @@ static int align_batch_staged_nolock(mgl_sw_ctx *ctx, int n, size_t in_bytes, si
     return MGL_SW_OK;
 }
 
-int mgl_sw_align_batch_staged(mgl_sw_ctx *ctx, int n, size_t in_bytes, size_t t_bytes_padded, int max_tl, int max_ql, int match,
+MGL_SW_INTERNAL int mgl_sw_align_batch_staged(mgl_sw_ctx *ctx, int n, size_t in_bytes, size_t t_bytes_padded, int max_tl, int max_ql, int match,
                               int mismatch, int gopen, int gext, int strategy, int cigar_stride, size_t out_bytes)
 {
     if (!ctx || n < 1) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     return align_batch_staged_nolock(ctx, n, in_bytes, t_bytes_padded, max_tl, max_ql, match, mismatch, gopen, gext, strategy,
-                                     cigar_stride, out_bytes, false, 0);
+                                     cigar_stride, out_bytes, GEOM_MIXED, 0);
 }
 
 // sw_batcher.cpp
-bool mgl_sw_coalescing_enabled();
-int mgl_sw_coalesced_align(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen, int gext,
+MGL_SW_INTERNAL bool mgl_sw_coalescing_enabled();
+MGL_SW_INTERNAL int mgl_sw_coalesced_align(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen, int gext,
                            int strategy, char *cigar, int cigar_cap, int *cigar_len, int *offset, mgl_sw_score *ez);
 
 static mgl_sw_ctx *thread_ctx(int *rc)

@@ -118,6 +118,9 @@ __host__ __device__ inline int64_t dp16_total_steps(int tl, int ql)
 }
 // packed16 layout: two dwords per lane per 8 steps, per group of two pairs
 __host__ __device__ inline int64_t tb_words16_for(int tl, int ql) { return ((dp16_total_steps(tl, ql) + 7) >> 3) * 32; }
+// monotone upper bound of tb_words16_for over every (tl', ql') <= (tl, ql): P(ql) <= sps_for(ql), so a pair never takes
+// more than stripes * sps_for(ql) + 16 steps (sizes the regions of MGL_SW_FLAG_GROUPED_GEOMETRY batches)
+__host__ __device__ inline int64_t tb_words16_bound(int tl, int ql) { return (((int64_t)stripes_for(tl) * sps_for(ql) + 16 + 7) >> 3) * 32; }
 
 // ---- sw_dp_coop_kernel (sw_dp_coop.hip): one pair per workgroup, 64-row stripes, steps per stripe rounded to
 // the 32-step traceback block so that every stripe (= every wave) owns whole blocks

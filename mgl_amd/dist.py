@@ -58,7 +58,6 @@ def gather_scores(local_scores, n_total=None, dst=0):
         n = torch.tensor([local_scores.numel()], device=local_scores.device, dtype=torch.int64)
         dist.all_reduce(n)
         n_total = int(n.item())
-        counts = None
     counts = shard_counts(n_total, world)
     assert local_scores.numel() == counts[rank], (local_scores.numel(), counts[rank])
     width = max(counts)
@@ -70,14 +69,10 @@ def gather_scores(local_scores, n_total=None, dst=0):
     dev = send.device
     if dist.get_backend() == "gloo" and send.is_cuda:
         send = send.cpu()  # gloo moves host memory
+    # one collective, the same on every rank (both backends have gather); an error propagates: after a failed
+    # collective the communicator is unusable and the ranks must not fall into different calls
     recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    try:
-        dist.gather(send, recv, dst=dst)
-    except RuntimeError:
-        # a backend without a gather primitive: every rank receives everything instead
-        full = torch.empty(world * width, dtype=send.dtype, device=send.device)
-        dist.all_gather_into_tensor(full, send)
-        recv = list(full.view(world, width).unbind(0))
+    dist.gather(send, recv, dst=dst)
     if rank != dst:
         return None
     return torch.cat([recv[r][: counts[r]] for r in range(world)]).to(dev)

@@ -6,8 +6,8 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/ablate
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags -o gpurun_out/ablate/lib_$name.so \
-      mgl_amd/csrc/sw_kernels.hip mgl_amd/csrc/sw_dp16.hip -x hip mgl_amd/csrc/sw_capi.cpp mgl_amd/csrc/sw_batcher.cpp mgl_amd/csrc/jni_exports.cpp
+  # the Makefile's own source list (every .hip / .cpp of the library), into a side-by-side .so
+  make -s -B -C mgl_amd/csrc OUT="$PWD/gpurun_out/ablate/lib_$name.so" EXTRA="$flags" "$PWD/gpurun_out/ablate/lib_$name.so"
 done
 for spec in "$@"; do
   name="${spec%%:*}"

@@ -26,7 +26,24 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/mgl_sw.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared
-    assert L.mgl_sw_version() == 100
+    assert L.mgl_sw_version() >= 100
+
+
+def test_library_exports_nothing_undeclared():
+    """Every dynamic mgl_sw_* / mgl_pairhmm_* symbol of the two libraries is declared in include/ (library-internal
+    helpers have hidden visibility)."""
+    import subprocess
+
+    from mgl_amd import pairhmm
+
+    for path, header, prefix in ((_lib.LIB_PATH, "mgl_sw.h", "mgl_sw_"), (pairhmm.LIB_PATH, "mgl_pairhmm.h", "mgl_pairhmm_")):
+        _lib.lib()
+        pairhmm.lib()
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith(prefix)})
+        text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", header)).read(), flags=re.S)
+        declared = sorted(set(re.findall(r"\b(%s[a-z_0-9]+)\s*\(" % prefix, text)))
+        assert exported == declared, (set(exported) ^ set(declared))
 
 
 def test_header_constants_match_reference_codes():

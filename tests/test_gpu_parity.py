@@ -316,6 +316,36 @@ def test_grouped_geometry_variable_length_reads(aligner):
     assert (gb.offsets.cpu().numpy() == off[o]).all() and (gb.scores.cpu().numpy() == sc[o]).all()
 
 
+def test_grouped_geometry_traceback_regions_do_not_overlap(aligner):
+    """Grouped batches run one geometry per wave, and the packed kernel's step count is not monotone in tl or ql (a
+    partial last stripe runs stand-alone; queries below 28 bases are not chained): a group just under the batch
+    maximum must not write past its traceback region into its neighbour's.  Blocks of eight at the maxima sit between
+    blocks that need MORE steps than the maximum geometry; reads come from the first rows of their windows, so a
+    clobbered first block of a region would show in the CIGAR / offset."""
+    rng = np.random.default_rng(99)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    for geoms in ([(256, 150), (255, 150), (241, 148), (256, 150), (250, 149), (256, 150), (243, 150)],
+                  [(256, 28), (256, 25), (256, 28), (250, 9), (256, 27), (256, 28), (255, 26)],
+                  [(32, 150), (31, 150), (17, 149), (32, 150)]):
+        ts, qs = [], []
+        for tl, ql in geoms * 3:
+            for _ in range(8):
+                t = alpha[rng.integers(0, 4, tl)]
+                a = int(rng.integers(0, min(6, max(1, tl - ql + 1))))
+                q = np.resize(t[a:a + ql], ql).copy()
+                if ql > 12:
+                    q[rng.integers(0, ql)] = alpha[rng.integers(0, 4)]
+                    cut = int(rng.integers(4, ql - 4))
+                    q = np.concatenate([q[:cut], q[cut + 2:], alpha[rng.integers(0, 4, 2)]])  # a short deletion
+                ts.append(t.tobytes())
+                qs.append(q.tobytes())
+        for strategy in (ol.SOFTCLIP, ol.INDEL):
+            res = aligner.align_batch(ts, qs, (200, -150, 260, 11), strategy, cigar_stride=256)
+            assert aligner.timing().packed16 == 1
+            off, sc, cg = ol.oracle_align_batch(ts, qs, (200, -150, 260, 11), strategy, nthreads=4)
+            assert (res.offsets == off).all() and (res.scores == sc).all() and list(res.cigars) == cg
+
+
 def test_grouping_helper_feeds_the_indexed_entry(aligner):
     """What a C caller does with variable-length reads: mgl_sw_group_by_geometry on the host, then the grouped part through
     mgl_sw_align_batch_device_indexed with MGL_SW_FLAG_GROUPED_GEOMETRY (packed kernel) and the rest without the flag."""
