@@ -9,8 +9,10 @@ A "step" is one pass of the hot path (fill kernel + traceback kernel, every pair
 ScoreMax and CIGAR text) over one batch of synthetic input that is already resident in HBM:
 by default 10 M Illumina-style 150 bp reads, each against its own 256-base reference window
 (BASELINE.json configs[1], SURVEY.md 8d "Config 2"), GATK parameters, SOFTCLIP, full matrix.
-Every rank processes its own 10 M pairs (weak scaling, no data-path collective); with N > 1 the
-step ends with the RCCL gather of the int32 scores onto rank 0 (north_star).
+With N > 1 the ONE seeded 10 M-pair workload is sharded contiguously over the ranks (strong scaling, BASELINE.json
+configs[2] / SURVEY.md 8d config 3: 1.25 M pairs per GPU at N = 8; each rank generates only its shard), there is no
+data-path collective, and the step ends with the RCCL gather of the int32 scores onto rank 0 (north_star);
+`--scaling weak` gives every rank its own --pairs instead.
 
 Rank 0 prints ONE JSON line.  `value` = whole-job GCUPS = sum(tl*ql) over all ranks and steps /
 max-over-ranks wall time.  `roofline` prices the dominant kernel (sw_dp_kernel) against HBM
@@ -220,17 +222,87 @@ def secondary_workloads():
     return out
 
 
+def pcie_inclusive_leg(aligner, batch, args):
+    """SURVEY.md 8d's wall-time definition: the same pairs through the host-buffer entry mgl_sw_align_batch -- inputs in
+    pageable host memory (the reference is always called with host buffers, MicrosoftSmithWaterman.java:66-86), H2D of
+    the ASCII bases, kernels, D2H of every result -- timed around the one blocking call and cross-checked against the
+    arrays the device-resident headline run left in HBM.  Never `value`."""
+    import ctypes as C
+
+    from mgl_amd import _lib
+
+    n, tl, ql, stride = batch.n, batch.max_tl, batch.max_ql, batch.cigar_stride
+    t, q = batch.targets.cpu().numpy(), batch.queries.cpu().numpy()
+    toff, qoff = batch.t_off.cpu().numpy(), batch.q_off.cpu().numpy()
+    off, sc = np.zeros(n, np.int32), np.zeros((n, 6), np.int32)
+    cg, ln = np.zeros(n * stride, np.uint8), np.zeros(n, np.int32)
+    m, x, o, e = GATK_PARAMETERS
+    L = _lib.lib()
+
+    def call(k):
+        t0 = time.perf_counter()
+        rc = L.mgl_sw_align_batch(aligner.ctx, k, t.ctypes.data, toff.ctypes.data, q.ctypes.data, qoff.ctypes.data, m, x, o, e,
+                                  int(SWOverhangStrategy.SOFTCLIP), off.ctypes.data, sc.ctypes.data, cg.ctypes.data, stride,
+                                  ln.ctypes.data)
+        assert rc == 0, rc
+        return time.perf_counter() - t0
+
+    call(min(n, 100_000))                     # staging buffers of the context exist from here on
+    times = [call(n) for _ in range(max(1, args.steps))]
+    dt = sum(times) / len(times)
+    mism = int((batch.offsets.cpu().numpy() != off).sum()
+               + (batch.cigars.cpu().numpy() != cg.reshape(n, stride)).any(axis=1).sum()
+               + (batch.scores.cpu().numpy() != sc).any(axis=1).sum())
+    return {"ms_per_step": round(dt * 1e3, 3), "gcups": round(n * tl * ql / dt / 1e9, 2), "reads_per_s": round(n / dt, 1),
+            "calls": len(times), "bytes_in": int(t.nbytes + q.nbytes + toff.nbytes + qoff.nbytes),
+            "bytes_out": int(off.nbytes + sc.nbytes + cg.nbytes + ln.nbytes), "host_memory": "pageable",
+            "mismatches_vs_headline": mism}
+
+
+def tl1000_leg(aligner, args, dev):
+    """the tl = 1000 variant of config 2 (same cell count: pairs/4 windows of 1000 bases), device resident
+    like the headline, cross-checked against the CPU checker on a sample."""
+    n = max(8, args.pairs * args.tl // 1000 // 8 * 8)
+    b = device_batch.window_batch(args.seed, n, dev, window=1000, read_len=args.ql)
+    b.run(aligner, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(max(1, args.steps)):
+        b.run(aligner, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / max(1, args.steps)
+    out = {"pairs": n, "target_len": 1000, "query_len": args.ql, "ms_per_step": round(dt * 1e3, 3),
+           "gcups": round(n * 1000 * args.ql / dt / 1e9, 2), "reads_per_s": round(n / dt, 1),
+           "cigar_overflows": int((b.status != 0).sum().item())}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+
+    idx = list(range(0, n, max(1, n // 4000)))[:4000]
+    ts, qs = b.host_pairs(idx)
+    woff, wsc, wcg = ol.oracle_align_batch(ts, qs, GATK_PARAMETERS, ol.SOFTCLIP, nthreads=host_cores())
+    out["sample_checked"] = len(idx)
+    out["mismatches_vs_cpu"] = int((b.offsets[idx].cpu().numpy() != woff).sum() + (b.scores[idx].cpu().numpy() != wsc).any(axis=1).sum()
+                                   + sum(a != c for a, c in zip(b.cigar_strings(idx), wcg)))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=10_000_000, help="pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=10_000_000,
+                    help="pairs per step: of the whole job with --scaling strong (default), per GPU with --scaling weak")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong (default, BASELINE configs[2]): ONE seeded --pairs workload, rank r aligns the contiguous "
+                         "shard dist.shard_range(pairs, r, N) of it; weak: every rank its own --pairs pairs")
     ap.add_argument("--tl", type=int, default=256, help="reference window length")
     ap.add_argument("--ql", type=int, default=150, help="read length")
     ap.add_argument("--workspace-gib", type=float, default=8.0, help="traceback workspace per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (long reads, PairHMM, protein)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the PCIe-inclusive and tl=1000 legs (SURVEY 8d)")
+    ap.add_argument("--dump-scores", help="rank 0 writes the gathered int32 score vector of the last step here (.npy)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--input", choices=("ascii", "2bit"), default="ascii",
                     help="ascii: concatenated bytes (the reference's ByteBuffer contract); 2bit: one 2-bit packed "
@@ -251,33 +323,44 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
+    # this rank's pairs: a contiguous shard of the one global workload (strong), or a workload of its own (weak)
+    if args.scaling == "strong":
+        lo, hi = dist.shard_range(args.pairs, rank, world)
+        n_total, seed = args.pairs, args.seed
+    else:
+        lo, hi = 0, args.pairs
+        n_total, seed = args.pairs * world, args.seed + rank
+    n_local = hi - lo
+
     aligner = MicrosoftSmithWaterman(dev_index)
     aligner.set_workspace(int(args.workspace_gib * (1 << 30)))
     data_label = "synthetic"
     if args.dataset != "synthetic":
         assert args.input == "ascii", "--dataset bam/fastx use the ASCII wire format"
+        assert world == 1, "--dataset bam/fastx are single-GPU lines"
         batch, data_label = file_batch(args, dev)
         args.ql = batch.max_ql
         ascii_twin = batch
     elif args.input == "2bit":
-        batch, ascii_twin = device_batch.window_batch_2bit(args.seed + rank, args.pairs, dev, window=args.tl,
-                                                           read_len=args.ql)
+        batch, ascii_twin = device_batch.window_batch_2bit(seed, n_local, dev, window=args.tl, read_len=args.ql, first=lo)
         if args.no_cpu or world > 1:
             del ascii_twin  # only the CPU-baseline leg needs the unpacked bases
             ascii_twin = None
     else:
-        batch = device_batch.window_batch(args.seed + rank, args.pairs, dev, window=args.tl, read_len=args.ql)
+        batch = device_batch.window_batch(seed, n_local, dev, window=args.tl, read_len=args.ql, first=lo)
         ascii_twin = batch
-    cells = args.pairs * args.tl * args.ql
-    n_total = args.pairs * world
+    cells = n_local * args.tl * args.ql   # of this rank, per step
 
     def step():
         batch.run(aligner, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP)
         if distributed:
-            # the only inter-GPU exchange: ScoreMax.max of every pair onto rank 0 (RCCL gather)
+            # the only inter-GPU exchange: ScoreMax.max of every pair onto rank 0 (RCCL gather), in shard order
+            if args.scaling == "strong":
+                return dist.gather_scores(batch.scores[:, 2].contiguous(), n_total, dst=0)
             return dist.gather_scores(batch.scores[:, 2].contiguous(), n_total, dst=0)
         return batch.scores[:, 2]
 
+    gathered = None
     for _ in range(args.warmup):
         step()
     # HIP events around every kernel launch, on the streams the kernels run on (asynchronous: they are
@@ -287,7 +370,7 @@ def main():
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        gathered = step()
     torch.cuda.synchronize(dev)
     dist.barrier()
     elapsed = dist.max_over_ranks(time.perf_counter() - t0, dev)
@@ -301,12 +384,14 @@ def main():
         if distributed:
             torch.distributed.destroy_process_group()
         return
-    fill_kernel = "sw_dp16_kernel" if tm.packed16 else "sw_dp_kernel"
-    total_cells = cells * world * args.steps
+    if args.dump_scores and gathered is not None:
+        np.save(args.dump_scores, gathered.cpu().numpy().astype(np.int32))
+    fill_kernel = aligner.fill_kernel_name(tm)
+    total_cells = n_total * args.tl * args.ql * args.steps
     per_pair = algorithmic_bytes_per_pair(args.tl, args.ql, args.input == "2bit")
     dp_s = tm.dp_ms / 1e3
-    achieved = args.pairs * per_pair / dp_s / 1e9
-    pairs_per_launch = args.pairs / max(1, tm.dp_launches)
+    achieved = n_local * per_pair / dp_s / 1e9
+    pairs_per_launch = n_local / max(1, tm.dp_launches)
     tpp = pmc_traffic_per_pair(args.tl, args.ql, fill_kernel)
     traffic = None if tpp is None else round(tpp * pairs_per_launch)  # HBM bytes per launch (PMC)
     valu = pmc_valu(args.tl, args.ql, fill_kernel)
@@ -319,7 +404,14 @@ def main():
         have = (tm.dp_ms / max(1, tm.dp_launches)) * 1e-3 * clock_hz * 1024
         valu_obj = {"issue_frac": round(need / have, 3), "wave_insts_per_pair": valu["wave_insts_per_pair"],
                     "avg_cycles_per_inst": valu["avg_cycles_per_inst"], "lds_bank_conflict_rate": valu["lds_bank_conflict_rate"],
-                    "clock_mhz": int(clock_hz / 1e6), "source": "profiles/pmc_traffic.json (rocprofv3 --pmc, r01_h_packed_trimmed.txt)"}
+                    "clock_mhz": int(clock_hz / 1e6), "source": valu.get("source", "profiles/pmc_traffic.json (rocprofv3 --pmc)")}
+    if args.dataset == "synthetic":
+        workload = (f"BASELINE.json configs[{1 if world == 1 else 2}]: {n_total} Illumina-style {args.ql} bp reads x {args.tl}-base "
+                    f"reference windows" + (f", one seeded workload sharded contiguously over {world} GPUs ({n_local} pairs on rank 0)"
+                                            if world > 1 and args.scaling == "strong" else
+                                            f", {args.pairs} pairs per GPU (weak scaling)" if world > 1 else ""))
+    else:
+        workload = f"{n_total} pairs ({data_label}), {args.ql} bp reads x {args.tl}-base windows"
     out = {
         "metric": "GCUPS (+ aligned reads/s) for 150 bp short-read batch",
         "value": round(total_cells / elapsed / 1e9, 2),
@@ -329,20 +421,18 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "int16" if tm.packed16 else "int32",
         "data": data_label,
         "config": {
-            "workload": (f"BASELINE.json configs[1]: {args.pairs} Illumina-style {args.ql} bp reads x {args.tl}-base "
-                         f"reference windows per GPU" if args.dataset == "synthetic" else
-                         f"{args.pairs} pairs per GPU ({data_label}), {args.ql} bp reads x {args.tl}-base windows") +
-                        ", affine-gap SW, full matrix, GATK params (200,-150,260,11), SOFTCLIP, scores+offset+CIGAR "
-                        "for every pair",
-            "pairs_per_gpu": args.pairs, "target_len": args.tl, "query_len": args.ql, "input": args.input,
-            "parallelism": f"pairs sharded over {world} GPU(s), score gather only" if world > 1 else "1 GPU",
+            "workload": workload + ", affine-gap SW, full matrix, GATK params (200,-150,260,11), SOFTCLIP, scores+offset+CIGAR "
+                                   "for every pair",
+            "pairs_total": n_total, "pairs_per_gpu": n_local, "target_len": args.tl, "query_len": args.ql, "input": args.input,
+            "parallelism": (f"pairs sharded over {world} GPU(s), one process per GPU, score gather onto rank 0 only"
+                            if world > 1 else "1 GPU"),
         },
-        "reads_per_s": round(args.pairs * world * args.steps / elapsed, 1),
+        "reads_per_s": round(n_total * args.steps / elapsed, 1),
         "kernel_ms": {fill_kernel: round(tm.dp_ms, 3), "sw_traceback_kernel": round(tm.tb_ms, 3),
                       "launches_each": tm.dp_launches},
         "cigar_overflows": status_bad,
@@ -363,6 +453,20 @@ def main():
         if ascii_twin is not batch:  # the CPU leg reads ASCII bases and compares with the GPU's result arrays
             ascii_twin.offsets, ascii_twin.cigars = batch.offsets, batch.cigars
         out["cpu_baseline"] = cpu_baseline(ascii_twin)
+    if world == 1 and not args.no_extra and args.dataset == "synthetic" and args.input == "ascii":
+        # "wall time includes H2D of packed inputs, kernel(s), D2H of results" and the tl = 1000 variant,
+        # after the timed headline (which keeps its inputs resident, as the bench contract asks)
+        try:
+            out["pcie_inclusive"] = pcie_inclusive_leg(aligner, batch, args)
+        except Exception as e:  # noqa: BLE001 -- an extra leg must never take the headline down
+            out["pcie_inclusive"] = {"error": repr(e)[:200]}
+        del batch, ascii_twin
+        torch.cuda.empty_cache()
+        try:
+            out["tl1000"] = tl1000_leg(aligner, args, dev)
+        except Exception as e:  # noqa: BLE001
+            out["tl1000"] = {"error": repr(e)[:200]}
+        batch = ascii_twin = None
     if world == 1 and not args.no_cpu and not args.no_secondary and args.dataset == "synthetic":
         del batch, ascii_twin
         aligner.close()

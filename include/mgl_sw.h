@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MGL_SW_VERSION 100
+#define MGL_SW_VERSION 101
 
 /* overhang strategies: sw_common.h:22-25 (= MicrosoftSmithWaterman.java:39-56) */
 #define MGL_SW_OS_SOFTCLIP 0x01
@@ -67,7 +67,14 @@ typedef struct mgl_sw_timing {
     int64_t tb_bytes;   /* traceback bytes written to HBM by the last call */
     int32_t packed16;   /* 1 when the packed-int16 fill kernel (sw_dp16_kernel) ran */
     int32_t clock_mhz;  /* profiling level 2: shader clock seen inside the fill kernel (s_memtime / s_memrealtime) */
+    int32_t fill_kernel; /* which fill kernel the last chunk ran: MGL_SW_KERNEL_* */
+    int32_t reserved;
 } mgl_sw_timing;
+#define MGL_SW_KERNEL_DP32 0      /* sw_dp_kernel: int32, 16 rows x four pairs per wave          */
+#define MGL_SW_KERNEL_DP16 1      /* sw_dp16_kernel: packed int16, two pairs per lane, systolic  */
+#define MGL_SW_KERNEL_DP32_64 2   /* sw_dp64_kernel: int32, 64 rows, one pair per wave           */
+#define MGL_SW_KERNEL_COOP 3      /* sw_dp_coop_kernel: one pair per workgroup (long reads)      */
+#define MGL_SW_KERNEL_LANE16 4    /* sw_dp16_lane_kernel: packed int16, two pairs per LANE       */
 
 typedef struct mgl_sw_ctx mgl_sw_ctx; /* opaque: one GPU, its workspace and stream */
 
@@ -162,6 +169,35 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
                               int gopen, int gext, int strategy, int32_t *offset_out,
                               mgl_sw_score *score_out, char *cigar_out, int cigar_stride,
                               int32_t *cigar_len_out, int32_t *status_out);
+
+/*
+ * Several GPUs from ONE process ("single process, one host thread per device").  Pairs are independent
+ * -- alignNative holds no state, ..._MicrosoftSmithWaterman.cpp:44-71 -- so mgl_sw_align_batch_multi cuts the host
+ * batch into contiguous shards, one per device of the set, balanced by the DP cells (sum tl * ql) they hold, and runs
+ * every shard through mgl_sw_align_batch_status on that device's own context from its own host thread.  Results are
+ * written straight into the caller's arrays (shards are disjoint slices); no inter-GPU traffic.  Arguments and error
+ * behaviour are those of mgl_sw_align_batch_status.  `devices` = n_devices HIP ordinals (NULL: 0 .. n_devices-1; an
+ * ordinal may be listed more than once -- each entry gets its own context and host thread).
+ */
+typedef struct mgl_sw_multi mgl_sw_multi;
+int mgl_sw_multi_create(int n_devices, const int *devices, mgl_sw_multi **out);
+void mgl_sw_multi_destroy(mgl_sw_multi *m);
+int mgl_sw_multi_device_count(const mgl_sw_multi *m);
+/* the context of entry `index` (to tune it with the mgl_sw_ctx_set_* calls); owned by the set */
+mgl_sw_ctx *mgl_sw_multi_ctx(mgl_sw_multi *m, int index);
+int mgl_sw_multi_set_workspace(mgl_sw_multi *m, int64_t bytes_per_device);
+const char *mgl_sw_multi_last_error(const mgl_sw_multi *m);
+int mgl_sw_align_batch_multi(mgl_sw_multi *m, int64_t n, const uint8_t *targets, const int64_t *t_off,
+                             const uint8_t *queries, const int64_t *q_off, int match, int mismatch,
+                             int gopen, int gext, int strategy, int32_t *offset_out,
+                             mgl_sw_score *score_out, char *cigar_out, int cigar_stride,
+                             int32_t *cigar_len_out, int32_t *status_out);
+/* first pair of every shard of the last mgl_sw_align_batch_multi call: first_out[0 .. n_devices] */
+int mgl_sw_multi_last_shards(mgl_sw_multi *m, int64_t *first_out);
+/* The sharding rule by itself (host only, no device needed): contiguous parts of pairs 0 .. n-1 with equal shares of
+ * sum tl * ql, every boundary a multiple of `align` pairs; first_out[0 .. parts], first_out[parts] == n. */
+int mgl_sw_shard_by_cells(int64_t n, const int64_t *t_off, const int64_t *q_off, int parts, int64_t align,
+                          int64_t *first_out);
 
 /*
  * Batch, device-resident: every pointer is a device pointer on ctx's GPU and

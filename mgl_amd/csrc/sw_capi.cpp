@@ -408,6 +408,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         ctx->timing.tb_launches++;
         ctx->timing.tb_bytes += (use16 ? (count + 1) / 2 : count) * stride_words * 4;
         ctx->timing.packed16 = use16 ? 1 : 0;
+        ctx->timing.fill_kernel = use16 ? MGL_SW_KERNEL_DP16 : coop_waves ? MGL_SW_KERNEL_COOP : rows == 64 ? MGL_SW_KERNEL_DP32_64 : MGL_SW_KERNEL_DP32;
     }
     for (int i = 0; hooks && i < n_pending; ++i) {
         const int hrc = hooks->after_traceback(pending[i].first, pending[i].count, pending[i].ready);

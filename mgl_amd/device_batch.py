@@ -20,7 +20,7 @@ class DeviceBatch:
     """
 
     def __init__(self, targets, t_off, queries, q_off, max_tl, max_ql, cigar_stride=64, uniform=False):
-        assert targets.is_cuda and targets.dtype == torch.uint8 and t_off.dtype == torch.int64
+        assert targets.dtype == torch.uint8 and t_off.dtype == torch.int64
         self.targets, self.t_off, self.queries, self.q_off = targets, t_off, queries, q_off
         self.n = t_off.numel() - 1
         self.max_tl, self.max_ql = int(max_tl), int(max_ql)
@@ -43,6 +43,7 @@ class DeviceBatch:
             binary_cigar=False, score_only=False):
         """Enqueue fill + traceback on ``stream`` (default: torch's current stream); no sync.  ``score_only``:
         MGL_SW_FLAG_SCORE_ONLY (only ``scores`` is wanted; batches on the packed kernel skip the traceback)."""
+        assert self.targets.is_cuda, "the batch must be resident on a GPU (there is no CPU path)"
         if stream is None:
             stream = torch.cuda.current_stream(self.targets.device)
         p = SWParameters(*parameters)
@@ -85,41 +86,57 @@ class DeviceBatch:
         return ts, qs
 
 
+WORKLOAD_BLOCK = 1 << 20  # pairs per generation block of the window workload
+
+
 def window_batch(seed, n_pairs, device, window=256, read_len=150, genome_len=1 << 24, sub=0.01, ins=0.001,
-                 dele=0.001, cigar_stride=64):
+                 dele=0.001, cigar_stride=64, first=0):
     """BASELINE.json configs[1] generated on the GPU: per-pair ``window``-base target cut from a
     seeded random genome, ``read_len``-bp read copied from inside the window with Illumina-style
-    errors (the model of synth.illumina_reads).  Deterministic in (seed, arguments, device type)."""
+    errors (the model of synth.illumina_reads).  Deterministic in (seed, arguments, device type).
+
+    The workload is ONE seeded sequence of pairs, defined block by block (WORKLOAD_BLOCK pairs, each block from its
+    own generator seeded by (seed, block index)); this call materialises pairs [first, first + n_pairs) of it, so
+    the ranks of a multi-GPU run each generate only their own contiguous shard of the same global batch
+     and a one-rank run of the whole range reproduces their concatenation."""
     g = torch.Generator(device=device)
     g.manual_seed(int(seed))
     bases = torch.tensor(list(_BASES), dtype=torch.uint8, device=device)
     genome = torch.randint(0, 4, (genome_len,), generator=g, device=device, dtype=torch.uint8)
-    win = torch.randint(0, genome_len - window, (n_pairs,), generator=g, device=device, dtype=torch.int64)
-    inner = torch.randint(0, window - read_len - 8 + 1, (n_pairs,), generator=g, device=device, dtype=torch.int64)
     ar_w = torch.arange(window, device=device, dtype=torch.int64)
     targets = torch.empty((n_pairs, window), dtype=torch.uint8, device=device)
     reads = torch.empty((n_pairs, read_len), dtype=torch.uint8, device=device)
-    step = 1 << 20  # bound the temporaries
-    for a in range(0, n_pairs, step):
-        b = min(n_pairs, a + step)
-        m = b - a
-        targets[a:b] = bases[genome[win[a:b, None] + ar_w].long()]
-        r = torch.rand((3, m, read_len), generator=g, device=device)
+    win_all = torch.empty(n_pairs, dtype=torch.int64, device=device)
+    first, last = int(first), int(first) + int(n_pairs)
+    for blk in range(first // WORKLOAD_BLOCK, (last + WORKLOAD_BLOCK - 1) // WORKLOAD_BLOCK if n_pairs else 0):
+        m = WORKLOAD_BLOCK
+        gb = torch.Generator(device=device)
+        gb.manual_seed((int(seed) * 1_000_003 + blk + 1) & 0x7FFFFFFFFFFFFFFF)
+        win = torch.randint(0, genome_len - window, (m,), generator=gb, device=device, dtype=torch.int64)
+        inner = torch.randint(0, window - read_len - 8 + 1, (m,), generator=gb, device=device, dtype=torch.int64)
+        r = torch.rand((3, m, read_len), generator=gb, device=device)
         is_ins, is_del, is_sub = r[0] < ins, r[1] < dele, r[2] < sub
         copied = ~is_ins
         src = torch.cumsum(copied, 1) - copied.long() + torch.cumsum(is_del & copied, 1)
-        src = (src + (win[a:b] + inner[a:b])[:, None]).clamp_(0, genome_len - 1)
+        src = (src + (win + inner)[:, None]).clamp_(0, genome_len - 1)
         code = genome[src]
-        shift = torch.randint(1, 4, (m, read_len), generator=g, device=device, dtype=torch.uint8)
+        shift = torch.randint(1, 4, (m, read_len), generator=gb, device=device, dtype=torch.uint8)
         code = torch.where(is_sub, (code + shift) & 3, code)
-        rnd = torch.randint(0, 4, (m, read_len), generator=g, device=device, dtype=torch.uint8)
+        rnd = torch.randint(0, 4, (m, read_len), generator=gb, device=device, dtype=torch.uint8)
         code = torch.where(is_ins, rnd, code)
-        reads[a:b] = bases[code.long()]
-        del r, is_ins, is_del, is_sub, copied, src, code, shift, rnd
+        # the part of this block inside [first, last)
+        lo, hi = max(first, blk * WORKLOAD_BLOCK), min(last, (blk + 1) * WORKLOAD_BLOCK)
+        a, b = lo - blk * WORKLOAD_BLOCK, hi - blk * WORKLOAD_BLOCK
+        reads[lo - first:hi - first] = bases[code[a:b].long()]
+        targets[lo - first:hi - first] = bases[genome[win[a:b, None] + ar_w].long()]
+        win_all[lo - first:hi - first] = win[a:b]
+        del r, is_ins, is_del, is_sub, copied, src, code, shift, rnd, win, inner
     t_off = torch.arange(n_pairs + 1, device=device, dtype=torch.int64) * window
     q_off = torch.arange(n_pairs + 1, device=device, dtype=torch.int64) * read_len
-    return DeviceBatch(targets.reshape(-1), t_off, reads.reshape(-1), q_off, window, read_len, cigar_stride,
-                       uniform=True)
+    out = DeviceBatch(targets.reshape(-1), t_off, reads.reshape(-1), q_off, window, read_len, cigar_stride,
+                      uniform=True)
+    out.win = win_all  # window start of every pair in the genome (window_batch_2bit addresses the packed genome by it)
+    return out
 
 
 def from_host(targets, t_off, queries, q_off, device, cigar_stride=None):
@@ -289,7 +306,7 @@ def window_batch_2bit(seed, n_pairs, device, window=256, read_len=150, genome_le
     g = torch.Generator(device=device)
     g.manual_seed(int(seed))
     genome = torch.randint(0, 4, (genome_len,), generator=g, device=device, dtype=torch.uint8)
-    win = torch.randint(0, genome_len - window, (n_pairs,), generator=g, device=device, dtype=torch.int64)
+    win = b.win
     lut = torch.zeros(256, dtype=torch.uint8, device=device)
     for k, ch in enumerate(_BASES):
         lut[ch] = k

@@ -184,6 +184,11 @@ class MicrosoftSmithWaterman:
         _check(_lib.lib().mgl_sw_ctx_get_timing(self._ensure(), C.byref(t)))
         return t
 
+    @staticmethod
+    def fill_kernel_name(timing):
+        """Name of the fill kernel a Timing record belongs to (MGL_SW_KERNEL_*)."""
+        return _lib.FILL_KERNEL_NAMES[timing.fill_kernel]
+
     @property
     def ctx(self):
         return self._ensure()
@@ -197,6 +202,76 @@ class MicrosoftSmithWaterman:
 
     def __enter__(self):
         self._ensure()
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiGpuSmithWaterman:
+    """Several GPUs from one process (mgl_sw_align_batch_multi): contiguous shards of a host batch, one per device,
+    balanced by DP cells, each on its own context and host thread; results in the caller's order.
+    ``devices``: HIP ordinals (an ordinal may repeat: every entry gets its own context and thread)."""
+
+    def __init__(self, devices):
+        self._devices = [int(d) for d in devices]
+        arr = (C.c_int * len(self._devices))(*self._devices)
+        h = C.c_void_p()
+        rc = _lib.lib().mgl_sw_multi_create(len(self._devices), arr, C.byref(h))
+        if rc != _lib.OK:
+            raise _lib.MglSwError(rc, "mgl_sw_multi_create")
+        self._h = h
+
+    def set_workspace(self, nbytes_per_device):
+        rc = _lib.lib().mgl_sw_multi_set_workspace(self._h, int(nbytes_per_device))
+        if rc != _lib.OK:
+            raise _lib.MglSwError(rc, "mgl_sw_multi_set_workspace")
+
+    def align_packed(self, targets, t_off, queries, q_off, parameters=GATK_PARAMETERS,
+                     overhang_strategy=SWOverhangStrategy.SOFTCLIP, cigar_stride=64, per_pair_status=False):
+        L = _lib.lib()
+        n = len(t_off) - 1
+        targets = np.ascontiguousarray(targets, dtype=np.uint8)
+        queries = np.ascontiguousarray(queries, dtype=np.uint8)
+        t_off = np.ascontiguousarray(t_off, dtype=np.int64)
+        q_off = np.ascontiguousarray(q_off, dtype=np.int64)
+        off = np.empty(n, np.int32)
+        sc = np.empty((n, 6), np.int32)
+        cg = np.empty(n * cigar_stride, np.uint8)
+        ln = np.empty(n, np.int32)
+        st = np.zeros(n, np.int32) if per_pair_status else None
+        p = SWParameters(*parameters)
+        rc = L.mgl_sw_align_batch_multi(self._h, n, targets.ctypes.data, t_off.ctypes.data, queries.ctypes.data, q_off.ctypes.data,
+                                        p.match, p.mismatch, p.gap_open, p.gap_extend, int(overhang_strategy), off.ctypes.data,
+                                        sc.ctypes.data, cg.ctypes.data, cigar_stride, ln.ctypes.data,
+                                        st.ctypes.data if st is not None else None)
+        if rc != _lib.OK:
+            raise _lib.MglSwError(rc, L.mgl_sw_multi_last_error(self._h).decode())
+        res = BatchResult(off, sc, CigarColumn(cg.reshape(n, cigar_stride), ln), ln)
+        return (res, st) if per_pair_status else res
+
+    def align_batch(self, refs, alts, parameters=GATK_PARAMETERS, overhang_strategy=SWOverhangStrategy.SOFTCLIP, cigar_stride=64):
+        td, toff = concat([bytes(x) for x in refs])
+        qd, qoff = concat([bytes(x) for x in alts])
+        return self.align_packed(td, toff, qd, qoff, parameters, overhang_strategy, cigar_stride)
+
+    def last_shards(self):
+        first = np.zeros(len(self._devices) + 1, np.int64)
+        _lib.lib().mgl_sw_multi_last_shards(self._h, first.ctypes.data)
+        return first
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().mgl_sw_multi_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
         return self
 
     def __exit__(self, *exc):

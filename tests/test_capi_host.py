@@ -154,3 +154,30 @@ def test_group_by_geometry_helper():
         total = np.unique(tl.astype(np.int64) << 32 | ql, return_counts=True)[1] if n else np.zeros(0, np.int64)
         assert g == int((total // 8 * 8).sum())
     assert L.mgl_sw_group_by_geometry(-1, None, None, None, C.byref(C.c_int64())) == _lib.ERR_BAD_ARG
+
+
+def test_shard_by_cells_helper():
+    """mgl_sw_shard_by_cells (the multi-device entry's sharding rule, host only): contiguous, aligned, balanced by
+    sum tl * ql rather than by pair count."""
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    for n, parts, align in ((0, 4, 8), (5, 4, 8), (1000, 1, 8), (1000, 8, 8), (100_003, 8, 8), (4096, 3, 1)):
+        tl = rng.integers(1, 400, n)
+        ql = rng.integers(1, 300, n)
+        if n > 100:
+            tl[: n // 4] *= 20   # a heavy head: equal pair counts would be badly unbalanced
+        toff = np.concatenate([[0], np.cumsum(tl)]).astype(np.int64)
+        qoff = np.concatenate([[0], np.cumsum(ql)]).astype(np.int64)
+        first = np.full(parts + 1, -1, np.int64)
+        assert L.mgl_sw_shard_by_cells(n, toff.ctypes.data, qoff.ctypes.data, parts, align, first.ctypes.data) == 0
+        assert first[0] == 0 and first[-1] == n and (np.diff(first) >= 0).all()
+        assert all(f % align == 0 for f in first[1:-1])
+        if n > 1000:
+            cells = np.add.reduceat((tl * ql).astype(np.float64), first[:-1]) if parts > 1 else np.array([float((tl * ql).sum())])
+            assert cells.max() / cells.mean() < 1.02
+    assert L.mgl_sw_shard_by_cells(-1, None, None, 2, 8, np.zeros(3, np.int64).ctypes.data) == _lib.ERR_BAD_ARG
+    h = C.c_void_p()
+    import torch
+
+    if not torch.cuda.is_available():
+        assert L.mgl_sw_multi_create(2, None, C.byref(h)) == _lib.ERR_DEVICE

@@ -82,3 +82,23 @@ def test_world_size_one_under_torchrun_env(tmp_path):
     out = str(tmp_path / "solo.pt")
     mp.spawn(_solo_worker, args=(_free_port(), out), nprocs=1, join=True)
     assert torch.load(out).tolist() == list(range(7))
+
+
+def test_workload_shards_concatenate_to_the_global_batch(monkeypatch):
+    """bench.py --gpus N (strong scaling, BASELINE configs[2]): rank r generates only pairs shard_range(n, r, N) of the
+    ONE seeded workload; the shards of any world size concatenate to what a single rank generates."""
+    from mgl_amd import device_batch as db
+
+    monkeypatch.setattr(db, "WORKLOAD_BLOCK", 1 << 10)   # several blocks at test size
+    cpu = torch.device("cpu")
+    n = 5000
+    full = db.window_batch(5, n, cpu, genome_len=1 << 16)
+    assert full.n == n and full.uniform
+    for world in (2, 3, 8):
+        parts = [db.window_batch(5, hi - lo, cpu, genome_len=1 << 16, first=lo)
+                 for lo, hi in (dist.shard_range(n, r, world) for r in range(world))]
+        assert torch.equal(torch.cat([b.targets for b in parts]), full.targets)
+        assert torch.equal(torch.cat([b.queries for b in parts]), full.queries)
+        assert torch.equal(torch.cat([b.win for b in parts]), full.win)
+    other = db.window_batch(6, 64, cpu, genome_len=1 << 16)
+    assert not torch.equal(other.queries, full.queries[:64 * 150])

@@ -1,34 +1,106 @@
 """The N > 1 path of bench.py end to end on ONE GPU: two ranks launched by torch.distributed.run share the device and
 exchange over gloo (RCCL refuses two ranks on one GPU; MGL_DIST_BACKEND=gloo, mgl_amd/dist.py) -- shards, seeds, barrier,
-max-over-ranks timing, the score gather onto rank 0 and the single JSON line are the code the 8-GPU run executes."""
+max-over-ranks timing, the score gather onto rank 0 and the single JSON line are the code the 8-GPU run executes.
+BASELINE.json configs[2]: ONE seeded workload sharded contiguously; the gathered score vector must be the one a single
+rank computes for the whole workload, and the CPU checker's on a sample.  Also the library-level multi-device entry
+(mgl_sw_align_batch_multi) with two contexts / host threads on the one GPU."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PAIRS = 200_000
 
 
-@pytest.mark.gpu
-def test_two_ranks_share_the_gpu_over_gloo():
-    import socket
-
+def _bench(nproc, extra, tmp_path, tag):
+    dump = str(tmp_path / f"scores_{tag}.npy")
     with socket.socket() as sk:  # a free rendezvous port
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, MGL_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--pairs", "200000", "--steps", "2",
-           "--warmup", "1", "--no-secondary"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--pairs", str(PAIRS), "--steps", "2",
+           "--warmup", "1", "--no-secondary", "--no-extra", "--no-cpu", "--dump-scores", dump] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]      # rank 0 alone prints the line
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["value"] > 0 and d["unit"] == "GCUPS" and d["config"]["pairs_per_gpu"] == 200000
-    assert d["cigar_overflows"] == 0
-    assert "cpu_baseline" not in d                # timed on rank 0 at N = 1 only
-    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    return json.loads(lines[0]), np.load(dump)
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_the_gpu_over_gloo(tmp_path):
+    import torch
+
+    import oracle_lib as ol
+    from mgl_amd import device_batch
+
+    d2, s2 = _bench(2, [], tmp_path, "n2")
+    assert d2["n_gpus"] == 2 and d2["steps"] == 2 and d2["warmup"] == 1 and d2["scaling"] == "strong"
+    assert d2["value"] > 0 and d2["unit"] == "GCUPS"
+    assert d2["config"]["pairs_total"] == PAIRS and d2["config"]["pairs_per_gpu"] == PAIRS // 2
+    assert d2["cigar_overflows"] == 0
+    assert "cpu_baseline" not in d2                # timed on rank 0 at N = 1 only
+    assert d2["roofline"]["bound"] == "hbm" and 0 < d2["roofline"]["frac"] < 1
+    # the same global workload on one rank: identical gathered vector (shard order, shard seeds, padding of the gather)
+    d1, s1 = _bench(1, [], tmp_path, "n1")
+    assert d1["n_gpus"] == 1 and d1["config"]["pairs_total"] == PAIRS
+    assert s1.shape == s2.shape == (PAIRS,) and s1.dtype == np.int32
+    assert (s1 == s2).all()
+    # ... and the CPU checker's ScoreMax.max on a sample of that workload, both halves of the split included
+    b = device_batch.window_batch(42, PAIRS, torch.device("cuda", 0))
+    idx = sorted(set(range(0, PAIRS, 397)) | {PAIRS // 2 - 1, PAIRS // 2, PAIRS - 1})
+    ts, qs = b.host_pairs(idx)
+    _, wsc, _ = ol.oracle_align_batch(ts, qs, (200, -150, 260, 11), ol.SOFTCLIP, nthreads=8)
+    assert (s2[idx] == wsc[:, 2]).all()
+    # weak scaling stays available behind the flag: every rank its own PAIRS pairs
+    dw, sw_ = _bench(2, ["--scaling", "weak"], tmp_path, "weak")
+    assert dw["scaling"] == "weak" and dw["config"]["pairs_total"] == 2 * PAIRS and sw_.shape == (2 * PAIRS,)
+    assert (sw_[:PAIRS] == s1).all()              # rank 0's batch is the seed-42 workload
+
+
+@pytest.mark.gpu
+def test_multi_device_entry_two_contexts_on_one_gpu():
+    """mgl_sw_align_batch_multi with the device list (0, 0): two contexts, two host threads, shards balanced by cells --
+    results in the caller's order, identical to the single-context entry and the CPU checker; per-pair status; errors."""
+    import oracle_lib as ol
+    from mgl_amd import _lib, smithwaterman as sw
+
+    rng = np.random.default_rng(17)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    ts, qs = [], []
+    for k in range(3000):
+        tl = int(rng.integers(20, 400)) * (6 if k < 300 else 1)   # a heavy head: the split is far from the middle
+        ql = int(rng.integers(8, 200))
+        t = alpha[rng.integers(0, 4, tl)]
+        a = int(rng.integers(0, max(1, tl - ql)))
+        q = np.resize(t[a:a + ql], ql).copy()
+        q[rng.integers(0, ql)] = alpha[rng.integers(0, 4)]
+        ts.append(t.tobytes())
+        qs.append(q.tobytes())
+    params = (200, -150, 260, 11)
+    with sw.MultiGpuSmithWaterman([0, 0]) as m, sw.MicrosoftSmithWaterman(0) as one:
+        for strategy in (ol.SOFTCLIP, ol.LEAD_INDEL):
+            res = m.align_batch(ts, qs, params, strategy, cigar_stride=1024)
+            first = m.last_shards()
+            assert first[0] == 0 and first[2] == 3000 and 0 < first[1] < 1200 and first[1] % 8 == 0
+            ref = one.align_batch(ts, qs, params, strategy, cigar_stride=1024)
+            off, sc, cg = ol.oracle_align_batch(ts, qs, params, strategy, nthreads=8)
+            assert (res.offsets == off).all() and (res.scores == sc).all() and list(res.cigars) == cg
+            assert (ref.offsets == off).all() and list(ref.cigars) == cg
+        # a uniform batch keeps its packed kernel on both shards
+        us = [alpha[rng.integers(0, 4, 256)].tobytes() for _ in range(4000)]
+        uq = [u[40:190] for u in us]
+        res = m.align_batch(us, uq, params, ol.SOFTCLIP)
+        assert (res.offsets == 40).all() and set(res.cigars) == {"150M"}
+        # per-pair status instead of a failed call when one CIGAR does not fit its slot
+        res, st = m.align_packed(*sw.concat(ts[:64]), *sw.concat(qs[:64]), params, ol.SOFTCLIP, cigar_stride=4, per_pair_status=True)
+        assert set(st.tolist()) <= {0, _lib.ERR_CIGAR_OVERFLOW} and (st != 0).any()
+        with pytest.raises(_lib.MglSwError) as e:
+            m.align_packed(*sw.concat(ts[:64]), *sw.concat(qs[:64]), params, ol.SOFTCLIP, cigar_stride=4)
+        assert e.value.status == _lib.ERR_CIGAR_OVERFLOW
