@@ -41,7 +41,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 def algorithmic_bytes_per_pair(tl, ql, packed2=False):
     """DESIGN.md "algorithmic bytes": what the fill kernel must move per pair whatever the schedule:
     the two sequences as shipped (ASCII like the reference's ByteBuffer, or 2-bit packed), two int64
-    offsets each (amortised 16 B), the 4-bit-per-cell traceback spilled to HBM, and the 32-byte fill record."""
+    offsets each (amortised 16 B), the 4-bit-per-cell traceback spilled to HBM, and the 32-byte fill record.
+    (What a particular schedule moves on top -- the lane kernel's strip carries and its path walk's re-reads --
+    shows in `traffic`, not here.)"""
     seq = (tl + 3) // 4 + (ql + 3) // 4 if packed2 else tl + ql
     return seq + 16 + (tl * ql) // 2 + 32
 
@@ -298,7 +300,8 @@ def main():
                          "shard dist.shard_range(pairs, r, N) of it; weak: every rank its own --pairs pairs")
     ap.add_argument("--tl", type=int, default=256, help="reference window length")
     ap.add_argument("--ql", type=int, default=150, help="read length")
-    ap.add_argument("--workspace-gib", type=float, default=8.0, help="traceback workspace per GPU")
+    ap.add_argument("--workspace-gib", type=float, default=208.0,
+                    help="traceback workspace per GPU (208 GiB: the 10 M-pair batch is one launch; the card has 288 GB)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (long reads, PairHMM, protein)")
     ap.add_argument("--no-extra", action="store_true", help="skip the PCIe-inclusive and tl=1000 legs (SURVEY 8d)")
@@ -433,8 +436,9 @@ def main():
                             if world > 1 else "1 GPU"),
         },
         "reads_per_s": round(n_total * args.steps / elapsed, 1),
-        "kernel_ms": {fill_kernel: round(tm.dp_ms, 3), "sw_traceback_kernel": round(tm.tb_ms, 3),
-                      "launches_each": tm.dp_launches},
+        "kernel_ms": ({fill_kernel: round(tm.dp_ms, 3), "path_walk": "inside the fill kernel (every lane walks its own two pairs)",
+                       "launches_each": tm.dp_launches} if fill_kernel == "sw_dp16_lane_kernel" else
+                      {fill_kernel: round(tm.dp_ms, 3), "sw_traceback_kernel": round(tm.tb_ms, 3), "launches_each": tm.dp_launches}),
         "cigar_overflows": status_bad,
         "roofline": {
             "bound": "hbm", "kernel": fill_kernel,

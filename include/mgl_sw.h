@@ -92,8 +92,8 @@ int mgl_sw_ctx_create(int device, mgl_sw_ctx **out);
 void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx);
 /* text of the last HIP / argument error seen on this ctx ("" if none) */
 const char *mgl_sw_last_error(const mgl_sw_ctx *ctx);
-/* cap on the device traceback workspace (bytes); default 4 GiB.  Batches are
- * processed in chunks that fit. */
+/* cap on the device traceback workspace (bytes); default: a quarter of the device's memory (72 GB on an
+ * MI355X), at least 4 GiB; memory is only reserved as batches need it.  Batches are processed in chunks that fit. */
 int mgl_sw_ctx_set_workspace(mgl_sw_ctx *ctx, int64_t bytes);
 /* fill-kernel arithmetic: 0 (default) = per batch, the packed-int16 kernel when every pair has
  * the same tl and ql and the score range fits 16 bits, else int32; 32 = always int32.  Results are
@@ -110,6 +110,11 @@ int mgl_sw_ctx_set_stripe_rows(mgl_sw_ctx *ctx, int rows);
  * mgl_sw_max_lds_query_len); 1 = never; 2..16 = always, with that many waves per pair (tests; identical
  * results) */
 int mgl_sw_ctx_set_cooperative(mgl_sw_ctx *ctx, int mode);
+/* uniform batches whose scores fit 16 bits: which packed kernel runs.  0 (default) = by launch size: from 524 288 pairs on
+ * the two-pairs-per-LANE kernel (sw_dp16_lane.hip: 128 pairs per wave, nothing shared between lanes), below that the
+ * two-pairs-per-lane-of-a-16-lane-group kernel (sw_dp16.hip: eight pairs per wave); 1 = never the lane kernel;
+ * 2 = the lane kernel whenever the batch is eligible (tests; results are identical) */
+int mgl_sw_ctx_set_lane_kernel(mgl_sw_ctx *ctx, int mode);
 /* 1 = HIP events around every kernel launch of a call, on the streams the kernels run on, read back by
  * mgl_sw_ctx_get_timing (the call itself stays asynchronous); 2 = additionally stamp the shader clock
  * inside the fill kernel (diagnostic; a few extra instructions per workgroup); 0 = off */

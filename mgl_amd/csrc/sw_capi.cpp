@@ -62,10 +62,11 @@ struct DevBuf {
 
 struct mgl_sw_ctx {
     int device = 0;
+    int n_cus = 256;
     hipStream_t stream = nullptr; // used by the host-buffer entry points
     int64_t ws_limit = kDefaultWorkspace;
     // kernel workspace, two halves: the traceback of chunk k (aux stream) overlaps the fill of chunk k+1
-    DevBuf tb[2], rec[2], diag, scratch;
+    DevBuf tb[2], rec[2], bnd[2], diag, scratch;
     // small-batch entry of the coalescing front-end: one pinned host buffer each way, mirrored on the device
     void *pin_in = nullptr, *pin_out = nullptr;
     size_t pin_in_cap = 0, pin_out_cap = 0;
@@ -76,6 +77,7 @@ struct mgl_sw_ctx {
     int carry_memory = 0; // 0 = LDS when it fits, 1 = always the HBM scratch (tests)
     int stripe_rows = 0;  // 0 = choose per batch, 16 / 64 = force (tests)
     int cooperative = 0;  // 0 = choose per batch, 1 = never, 2..16 = always, that many waves per pair (tests)
+    int lane_kernel = 0;  // two-pairs-per-lane packed kernel: 0 = large uniform batches, 1 = never, 2 = whenever eligible (tests)
     int last_rows = 16;
     hipStream_t aux = nullptr;                       // traceback stream
     hipStream_t h2d = nullptr;                       // host-buffer entry: input copies of the next chunk
@@ -156,6 +158,9 @@ int pick_waves_per_block(int sps_cap, int rows, int extra = 0)
 // queries from this length on run one pair per wave (64-row stripes): the pipeline fill/drain is then
 // 63/(ql+64) <= 6 %, and a batch needs four times fewer pairs to occupy the machine
 constexpr int kRows64MinQuery = 1024;
+// uniform batches (launches) from this size on take the two-pairs-per-lane kernel: 4 096 waves of 128 pairs, a good round
+// of the chip (measured crossover with the eight-pairs-per-wave kernel at 256 x 150: scripts/kernel_crossover.py)
+constexpr int64_t kLaneMinPairs = 128 * 4096;
 
 int max_lds_query_len()
 {
@@ -224,20 +229,34 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     static const int wpb16_env = [] { const char *e = getenv("MGL_SW_WPB16"); return e ? std::max(1, std::min(4, atoi(e))) : 0; }();
     if (wpb16_env) wpb16 = wpb16_env; // launch-shape experiments only
     while (wpb16 > 1 && dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra > 64 * 1024) --wpb16;
-    const bool use16 = uniform && ctx->precision != 32 && dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra <= 64 * 1024 &&
+    const bool use16_eligible = uniform && ctx->precision != 32 && dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra <= 64 * 1024 &&
                        match > 0 && dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
-    // MGL_SW_FLAG_SCORE_ONLY is honoured by the packed kernel only; elsewhere the full path runs (a superset of the result)
-    const bool score_only = score_only_hint && use16 && d_score != nullptr && !hooks;
-    int rows = use16 ? 16 : ctx->stripe_rows ? ctx->stripe_rows : (max_ql >= kRows64MinQuery ? 64 : 16);
+    // two pairs per LANE (sw_dp16_lane.hip): uniform ASCII batches with enough pairs to give every lane its own --
+    // 128 pairs per wave, so a chunk should hold a few thousand waves; smaller batches fill the chip better with the
+    // eight-pairs-per-wave kernel above
+    // strips of 32 rows (three waves per SIMD) unless 16-row strips (four waves, twice the carry traffic) save at least a
+    // tenth of the rows: strips are whole, rows past tl are computed and thrown away
+    static const int lane_rows_env = [] { const char *e = getenv("MGL_SW_LANE_ROWS"); return e ? atoi(e) : 0; }();
+    const int lane_rows = lane_rows_env == 16 || lane_rows_env == 32 ? lane_rows_env
+                          : ((max_tl + 31) / 32 * 32 - (max_tl + 15) / 16 * 16) * 10 >= max_tl ? 16 : 32;
+    // (what counts is the size of a launch: a batch that the workspace cuts into small chunks is no better than a small batch)
+    const int64_t lane_launch = std::min<int64_t>(n, ctx->ws_limit / (lane_tb_words(max_tl, max_ql, lane_rows) * 4 / 128 + 1));
+    const bool use_lane = geom == GEOM_UNIFORM && ctx->precision != 32 && !d_matrix && match > 0 && ctx->lane_kernel != 1 &&
+                          (ctx->lane_kernel == 2 || lane_launch >= kLaneMinPairs) && lane16_supported(tset, qset) &&
+                          dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
+    const bool use16 = use16_eligible && !use_lane;
+    // MGL_SW_FLAG_SCORE_ONLY is honoured by the packed kernels only; elsewhere the full path runs (a superset of the result)
+    const bool score_only = score_only_hint && (use16 || use_lane) && d_score != nullptr && !hooks;
+    int rows = use_lane ? lane_rows : use16 ? 16 : ctx->stripe_rows ? ctx->stripe_rows : (max_ql >= kRows64MinQuery ? 64 : 16);
     // substitution-matrix mode: 16 rows x four pairs per wave while that carve fits LDS (queries up to ~800 residues;
     // measured faster than one pair per wave at 300 residues: 1 056 vs about 1 000 GCUPS), else 64 rows x one pair (to ~3 300)
     if (d_matrix && !use16 && !ctx->stripe_rows) rows = pick_waves_per_block(sps_for_rows(max_ql, 16), 16) == 0 ? 64 : 16;
-    int sps_cap = sps_for_rows(max_ql, rows);
-    int wpb = use16 ? wpb16 : pick_waves_per_block(sps_cap, rows, d_matrix ? 1024 : 0);
+    int sps_cap = use_lane ? max_ql : sps_for_rows(max_ql, rows);
+    int wpb = use_lane ? 4 : use16 ? wpb16 : pick_waves_per_block(sps_cap, rows, d_matrix ? 1024 : 0);
     // long reads: one pair per WORKGROUP (sw_dp_coop_kernel), its waves pipelined over the 64-row stripes.  Taken
     // when the one-wave-per-pair carve does not fit LDS, or when forced; needs at least two stripes to share.
     int coop_waves = 0;
-    if (!use16 && !d_matrix && ctx->cooperative != 1 && ctx->carry_memory == 0 && gopen < 65536 && gopen >= gext && (ctx->stripe_rows == 0 || ctx->cooperative >= 2) &&
+    if (!use16 && !use_lane && !d_matrix && ctx->cooperative != 1 && ctx->carry_memory == 0 && gopen < 65536 && gopen >= gext && (ctx->stripe_rows == 0 || ctx->cooperative >= 2) &&
         ((rows == 64 && wpb == 0) || ctx->cooperative >= 2) && coop_lds_bytes(coop_sps_for(max_ql), 2) <= 160 * 1024) {
         const int stripes = (max_tl + 63) / 64;
         coop_waves = ctx->cooperative >= 2 ? ctx->cooperative : 16;
@@ -250,7 +269,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     while (d_matrix && !use16 && wpb > 1 && dp_lds_bytes(sps_cap, wpb, rows) + 1024 > 64 * 1024) --wpb; // room for the matrix
     if (d_matrix && !use16 && (wpb == 0 || dp_lds_bytes(sps_cap, wpb, rows) + 1024 > 64 * 1024))
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "substitution-matrix scoring: query too long for the LDS carve (about 3 300 residues)");
-    const bool use_scratch = !use16 && !coop_waves && !d_matrix && (wpb == 0 || ctx->carry_memory == 1);
+    const bool use_scratch = !use16 && !use_lane && !coop_waves && !d_matrix && (wpb == 0 || ctx->carry_memory == 1);
     if (use_scratch) wpb = 4;
     if ((int64_t)max_tl * max_ql > (1ll << 34) || max_ql > (1 << 24) || max_tl > (1 << 24))
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "matrix larger than 2^34 cells");
@@ -260,28 +279,38 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // traceback words per pair (int32 layout) or per group of two pairs (packed16 layout)
     // (packed layout: the step count of a pair is not monotone in tl or ql -- a partial last stripe runs stand-alone, short
     // queries are not chained -- so a grouped batch, whose waves each run their own geometry, is sized by a bound that is)
-    const int64_t stride_words = use16 ? (geom == GEOM_UNIFORM ? tb_words16_for(max_tl, max_ql) : tb_words16_bound(max_tl, max_ql))
-                                       : tb_words_for(max_tl, sps_cap, rows);
-    const int64_t per_pair = (score_only ? 0 : stride_words * 4 / (use16 ? 2 : 1)) + (int64_t)sizeof(DpRecord);
+    // (lane layout: words per WAVE of 128 pairs, plus the wave's carry row)
+    const int64_t stride_words = use_lane ? lane_tb_words(max_tl, max_ql, rows)
+                                 : use16 ? (geom == GEOM_UNIFORM ? tb_words16_for(max_tl, max_ql) : tb_words16_bound(max_tl, max_ql))
+                                         : tb_words_for(max_tl, sps_cap, rows);
+    const int64_t per_pair = use_lane ? ((score_only ? 0 : stride_words * 4) + lane_scratch_bytes(max_tl, max_ql, rows)) / 128 + 1 + (int64_t)sizeof(DpRecord)
+                                      : (score_only ? 0 : stride_words * 4 / (use16 ? 2 : 1)) + (int64_t)sizeof(DpRecord);
     // the workspace is split in two halves so that the traceback of one chunk can run (on ctx->aux)
     // while the next chunk is being filled; a batch that fits one half is a single chunk
     // chunks are whole waves' worth of pairs (8: packed kernel, and the blocks of MGL_SW_FLAG_GROUPED_GEOMETRY; 4: 16-row
     // int32 kernel; 1: one pair per wave or workgroup); the last chunk may be shorter (idle lanes store nothing)
-    const int64_t gran = use16 ? 8 : rows == 64 ? 1 : 4;
-    if (per_pair * gran > ctx->ws_limit / 2) {
+    const int64_t gran = use_lane ? 128 : use16 ? 8 : rows == 64 ? 1 : 4;
+    // lane kernel: every lane walks the paths of its own two pairs at the end of its fill -- no traceback kernel, nothing
+    // to overlap, so the whole workspace is one buffer and the chunks are twice as large
+    static const bool lane_fuse = [] { const char *e = getenv("MGL_SW_LANE_FUSE"); return !e || atoi(e) != 0; }();
+    const bool fused_walk = use_lane && !score_only && lane_fuse;
+    const int64_t ws_part = fused_walk ? ctx->ws_limit : ctx->ws_limit / 2;
+    if (per_pair * gran > ws_part) {
         char msg[192];
         snprintf(msg, sizeof msg, "traceback of %lld pair(s) (%lld bytes) does not fit half the workspace: raise it with "
                                   "mgl_sw_ctx_set_workspace", (long long)gran, (long long)(per_pair * gran));
         return fail(ctx, MGL_SW_ERR_NOMEM, msg);
     }
-    int64_t chunk = std::max<int64_t>(gran, ctx->ws_limit / 2 / per_pair / gran * gran);
+    int64_t chunk = std::max<int64_t>(gran, ws_part / per_pair / gran * gran);
     chunk = std::min<int64_t>(chunk, n);
-    const bool overlap = n > chunk;
-    const int halves = n > chunk ? 2 : 1;
+    const bool overlap = !fused_walk && n > chunk;
+    const int halves = overlap ? 2 : 1;
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int h = 0; h < halves; ++h) {
-        if (!score_only) HIP_TRY(ctx, ctx->tb[h].reserve((size_t)(use16 ? (chunk + 1) / 2 : chunk) * stride_words * 4));
+        const size_t regions = (size_t)(use_lane ? (chunk + 127) / 128 : use16 ? (chunk + 1) / 2 : chunk);
+        if (!score_only) HIP_TRY(ctx, ctx->tb[h].reserve(regions * (size_t)stride_words * 4));
+        if (use_lane) HIP_TRY(ctx, ctx->bnd[h].reserve(regions * (size_t)lane_scratch_bytes(max_tl, max_ql, rows)));
         HIP_TRY(ctx, ctx->rec[h].reserve((size_t)chunk * sizeof(DpRecord)));
     }
 
@@ -327,13 +356,13 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         da.tb = static_cast<uint32_t *>(ctx->tb[h].p);
         da.tb_stride_words = stride_words;
         da.rec = static_cast<DpRecord *>(ctx->rec[h].p);
-        da.scratch = (use_scratch || coop_waves) ? static_cast<unsigned char *>(ctx->scratch.p) : nullptr;
+        da.scratch = use_lane ? static_cast<unsigned char *>(ctx->bnd[h].p) : (use_scratch || coop_waves) ? static_cast<unsigned char *>(ctx->scratch.p) : nullptr;
         da.diag = nullptr;
         da.matrix = d_matrix;
         da.code = d_code;
         da.matrix_lds_offset = 0;
         da.score_only = score_only ? 1 : 0;
-        const int per_block = use16 ? wpb * 8 : wpb * (64 / rows);
+        const int per_block = use_lane ? wpb * 128 : use16 ? wpb * 8 : wpb * (64 / rows);
         const int64_t n_blocks = (count + per_block - 1) / per_block;
         if (ctx->profiling >= 2) {
             HIP_TRY(ctx, ctx->diag.reserve((size_t)n_blocks * 16));
@@ -348,8 +377,9 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         ta.strategy = strategy;
         ta.tb = da.tb;
         ta.tb_stride_words = stride_words;
-        ta.packed16 = use16 ? 1 : 0;
+        ta.packed16 = use_lane ? 2 : use16 ? 1 : 0;
         ta.rows_per_stripe = rows;
+        ta.uni_ql = max_ql;
         ta.rec = da.rec;
         ta.offset = d_offset;
         ta.score = d_score;
@@ -375,14 +405,16 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         // this half was last read by the traceback of chunk k-2
         if (overlap && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->tb_done[h], 0));
         if (pe[0]) HIP_TRY(ctx, hipEventRecord(pe[0], stream));
-        HIP_TRY(ctx, use16 ? launch_dp16(da, wpb, stream) : coop_waves ? launch_dp_coop(da, coop_waves, stream) : launch_dp(da, wpb, rows, stream));
+        TbArgs walk = ta;
+        if (!fused_walk) walk.cigar = nullptr;
+        HIP_TRY(ctx, use_lane ? launch_dp16_lane(da, walk, rows, stream) : use16 ? launch_dp16(da, wpb, stream) : coop_waves ? launch_dp_coop(da, coop_waves, stream) : launch_dp(da, wpb, rows, stream));
         if (pe[1]) HIP_TRY(ctx, hipEventRecord(pe[1], stream));
         if (overlap) {
             HIP_TRY(ctx, hipEventRecord(ctx->fill_done[h], stream));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->fill_done[h], 0));
         }
         if (pe[2]) HIP_TRY(ctx, hipEventRecord(pe[2], tb_stream));
-        HIP_TRY(ctx, score_only ? launch_scores_only(ta, tb_stream) : launch_traceback(ta, tb_stream));
+        if (!fused_walk) HIP_TRY(ctx, score_only ? launch_scores_only(ta, tb_stream) : launch_traceback(ta, tb_stream));
         if (pe[3]) HIP_TRY(ctx, hipEventRecord(pe[3], tb_stream));
         if (overlap) {
             HIP_TRY(ctx, hipEventRecord(ctx->tb_done[h], ctx->aux));
@@ -403,12 +435,12 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         ctx->last_chunk_count = count;
         ctx->last_half = h;
         ctx->last_rows = rows;
-        ctx->last_packed16 = use16 ? 1 : 0;
+        ctx->last_packed16 = use_lane ? 2 : use16 ? 1 : 0;
         ctx->timing.dp_launches++;
         ctx->timing.tb_launches++;
-        ctx->timing.tb_bytes += (use16 ? (count + 1) / 2 : count) * stride_words * 4;
-        ctx->timing.packed16 = use16 ? 1 : 0;
-        ctx->timing.fill_kernel = use16 ? MGL_SW_KERNEL_DP16 : coop_waves ? MGL_SW_KERNEL_COOP : rows == 64 ? MGL_SW_KERNEL_DP32_64 : MGL_SW_KERNEL_DP32;
+        ctx->timing.tb_bytes += (use_lane ? (count + 127) / 128 : use16 ? (count + 1) / 2 : count) * stride_words * 4;
+        ctx->timing.packed16 = (use16 || use_lane) ? 1 : 0;
+        ctx->timing.fill_kernel = use_lane ? MGL_SW_KERNEL_LANE16 : use16 ? MGL_SW_KERNEL_DP16 : coop_waves ? MGL_SW_KERNEL_COOP : rows == 64 ? MGL_SW_KERNEL_DP32_64 : MGL_SW_KERNEL_DP32;
     }
     for (int i = 0; hooks && i < n_pending; ++i) {
         const int hrc = hooks->after_traceback(pending[i].first, pending[i].count, pending[i].ready);
@@ -473,6 +505,15 @@ int mgl_sw_ctx_create(int device, mgl_sw_ctx **out)
     mgl_sw_ctx *ctx = new (std::nothrow) mgl_sw_ctx;
     if (!ctx) return MGL_SW_ERR_NOMEM;
     ctx->device = device;
+    {
+        // default cap of the (grow-only) workspace: a quarter of the device's memory, at least 4 GiB -- 72 GB on an MI355X
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b / 4 > (size_t)kDefaultWorkspace) ctx->ws_limit = (int64_t)(total_b / 4);
+    }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = cus;
+    }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return MGL_SW_ERR_DEVICE;
@@ -503,7 +544,7 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
-    for (DevBuf *b : {&ctx->tb[0], &ctx->tb[1], &ctx->rec[0], &ctx->rec[1], &ctx->diag, &ctx->scratch, &ctx->d_t, &ctx->d_toff, &ctx->d_q, &ctx->d_qoff, &ctx->d_off, &ctx->d_score,
+    for (DevBuf *b : {&ctx->tb[0], &ctx->tb[1], &ctx->rec[0], &ctx->rec[1], &ctx->bnd[0], &ctx->bnd[1], &ctx->diag, &ctx->scratch, &ctx->d_t, &ctx->d_toff, &ctx->d_q, &ctx->d_qoff, &ctx->d_off, &ctx->d_score,
                       &ctx->d_cig, &ctx->d_len, &ctx->d_status, &ctx->d_btr, &ctx->d_any, &ctx->d_matrix})
         b->release();
     for (auto &e : ctx->ev)
@@ -568,6 +609,14 @@ int mgl_sw_ctx_set_cooperative(mgl_sw_ctx *ctx, int mode)
     if (!ctx || mode < 0 || mode > 16) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->cooperative = mode;
+    return MGL_SW_OK;
+}
+
+int mgl_sw_ctx_set_lane_kernel(mgl_sw_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->lane_kernel = mode;
     return MGL_SW_OK;
 }
 
@@ -1052,11 +1101,11 @@ int mgl_sw_ctx_expand_slot(mgl_sw_ctx *ctx, int64_t slot, int tl, int ql, int32_
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, ctx->d_btr.reserve(cells * 4));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_btr.p, 0, cells * 4, ctx->stream));
-    const int64_t region = ctx->last_packed16 ? slot >> 1 : slot;
+    const int64_t region = ctx->last_packed16 == 2 ? slot >> 7 : ctx->last_packed16 ? slot >> 1 : slot;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
     HIP_TRY(ctx, launch_expand(static_cast<const uint32_t *>(ctx->tb[ctx->last_half].p) + region * ctx->last_stride_words,
                                static_cast<const DpRecord *>(ctx->rec[ctx->last_half].p) + slot, tl, ql, ctx->last_packed16,
-                               (int)(slot & 1), ctx->last_rows, static_cast<int32_t *>(ctx->d_btr.p), ctx->stream));
+                               (int)(slot & 1), ctx->last_rows, static_cast<int32_t *>(ctx->d_btr.p), ctx->stream, (int)((slot >> 1) & 63)));
     HIP_TRY(ctx, hipMemcpyAsync(btr, ctx->d_btr.p, cells * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MGL_SW_OK;

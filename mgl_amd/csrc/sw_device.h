@@ -73,8 +73,9 @@ struct TbArgs {
     int strategy;
     const uint32_t *tb;
     int64_t tb_stride_words; // per pair (int32 layout) or per group of two pairs (packed16 layout)
-    int packed16;            // traceback layout written by sw_dp16_kernel
-    int rows_per_stripe;     // 16 or 64 (int32 layout)
+    int packed16;            // traceback layout: 0 = int32 kernels, 1 = sw_dp16_kernel, 2 = sw_dp16_lane_kernel (stride per wave)
+    int rows_per_stripe;     // 16 or 64 (int32 layout); rows per strip (lane layout)
+    int uni_ql;              // lane layout: the batch's one query length
     const DpRecord *rec;
     int32_t *offset; // indexed by batch pair index
     Score *score;    // optional
@@ -122,6 +123,18 @@ __host__ __device__ inline int64_t tb_words16_for(int tl, int ql) { return ((dp1
 // more than stripes * sps_for(ql) + 16 steps (sizes the regions of MGL_SW_FLAG_GROUPED_GEOMETRY batches)
 __host__ __device__ inline int64_t tb_words16_bound(int tl, int ql) { return (((int64_t)stripes_for(tl) * sps_for(ql) + 16 + 7) >> 3) * 32; }
 
+// ---- sw_dp16_lane_kernel (sw_dp16_lane.hip): two pairs per lane, 128 per wave; strips of `rows` target rows
+__host__ __device__ inline int lane_strips(int tl, int rows) { return (tl + rows - 1) / rows; }
+// traceback dwords per WAVE: [strip][column][rows / 16][lane] uint4
+__host__ __device__ inline int64_t lane_tb_words(int tl, int ql, int rows) { return (int64_t)lane_strips(tl, rows) * ql * (rows / 16) * 64 * 4; }
+// carry row per wave: [column 0 .. ql][lane] uint2 {H, E}; entries of 8 bytes
+__host__ __device__ inline int64_t lane_bnd_entries(int ql) { return (int64_t)(ql + 1) * 64; }
+// per-wave scratch: the carry row, then both queries and both targets of every lane transposed to [4-base block][A | B][lane] dwords
+__host__ __device__ inline int64_t lane_scratch_bytes(int tl, int ql, int rows)
+{
+    return lane_bnd_entries(ql) * 8 + ((int64_t)((ql + 3) / 4) + (int64_t)lane_strips(tl, rows) * (rows / 4)) * 2 * 64 * 4;
+}
+
 // ---- sw_dp_coop_kernel (sw_dp_coop.hip): one pair per workgroup, 64-row stripes, steps per stripe rounded to
 // the 32-step traceback block so that every stripe (= every wave) owns whole blocks
 __host__ __device__ inline int coop_sps_for(int ql) { return (ql + 64 + 31) & ~31; }
@@ -133,6 +146,10 @@ int dp_lds_bytes(int sps_cap, int waves_per_block, int rows);
 int dp16_lds_bytes(int sps, int waves_per_block);
 bool dp16_range_ok(int tl, int ql, int match, int mismatch, int gopen, int gext, int strategy);
 hipError_t launch_dp16(const DpArgs &a, int waves_per_block, hipStream_t stream);
+bool lane16_supported(const SeqSet &t, const SeqSet &q);
+struct TbArgs;
+// a.scratch = per-wave scratch, a.tb_stride_words per wave; walk.cigar != null: every lane also walks the paths of its two pairs
+hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &walk, int rows, hipStream_t stream);
 hipError_t launch_dp(const DpArgs &a, int waves_per_block, int rows, hipStream_t stream);
 int coop_lds_bytes(int sps_cap, int waves_per_block);
 hipError_t launch_dp_coop(const DpArgs &a, int waves_per_block, hipStream_t stream);
@@ -141,7 +158,7 @@ hipError_t launch_scores_only(const TbArgs &a, hipStream_t stream); // DpRecord 
 hipError_t launch_cigar_from_matrix(const int32_t *btr, int tl, int ql, int strategy, const Score &ez, char *cigar,
                                     int cap, int32_t *out3, hipStream_t stream);
 hipError_t launch_expand(const uint32_t *tbw, const DpRecord *rec, int tl, int ql, int packed16, int half, int rows,
-                         int32_t *btr, hipStream_t stream);
+                         int32_t *btr, hipStream_t stream, int lane = 0);
 
 } // namespace mgl_sw_dev
 #endif

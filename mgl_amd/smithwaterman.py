@@ -176,6 +176,10 @@ class MicrosoftSmithWaterman:
         1 = never, 2..16 = always with that many waves per pair."""
         _check(_lib.lib().mgl_sw_ctx_set_cooperative(self._ensure(), int(mode)))
 
+    def set_lane_kernel(self, mode):
+        """Packed kernel for uniform batches: 0 = by batch size, 1 = never the two-pairs-per-lane kernel, 2 = always when eligible."""
+        _check(_lib.lib().mgl_sw_ctx_set_lane_kernel(self._ensure(), int(mode)))
+
     def set_profiling(self, on=True):
         _check(_lib.lib().mgl_sw_ctx_set_profiling(self._ensure(), int(on)))
 

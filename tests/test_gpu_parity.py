@@ -539,6 +539,81 @@ def test_packed16_uniform_batches(aligner, tl, ql):
                 assert (btr[1:, 1:] == o["btr"][1:, 1:]).all(), (params, strategy, slot)
 
 
+# ---------------------------------------------------------------------------------------------
+# two pairs per LANE (sw_dp16_lane_kernel): large uniform batches; forced here onto small ones.  Strips of 16 / 32 rows,
+# partial last strips, tl below one strip, every strategy, the traceback layout through the expansion to the
+# reference's int32 matrix.
+
+@pytest.fixture(scope="module")
+def lane_aligner():
+    a = sw.MicrosoftSmithWaterman(0)
+    a.set_lane_kernel(2)
+    yield a
+    a.close()
+
+
+@pytest.mark.parametrize("tl,ql", [(256, 150), (1000, 150), (16, 16), (17, 15), (1, 1), (5, 3), (33, 8), (64, 65), (100, 151),
+                                   (300, 7), (32, 149), (31, 150), (48, 2), (250, 150), (255, 1)])
+def test_lane_kernel_uniform_batches(lane_aligner, tl, ql):
+    from mgl_amd import _lib
+
+    rng = np.random.default_rng(tl * 1000 + ql + 1)
+    n = 131  # more than one wave (128 pairs), odd: the last lane has a lone pair
+    ts, qs = _uniform_batch(rng, n, tl, ql, b"ACGT" if ql % 2 else b"AC")
+    for params in [(200, -150, 260, 11), (25, -50, 110, 6), (1, -1, 1, 1), (5, -4, 10, 1)]:
+        for strategy in ol.STRATEGIES:
+            res = lane_aligner.align_batch(ts, qs, params, strategy)
+            tm = lane_aligner.timing()
+            assert tm.packed16 == 1 and tm.fill_kernel == 4, "a uniform small-range batch should take the lane kernel when forced"
+            off, sc, cg = ol.oracle_align_batch(ts, qs, params, strategy, nthreads=4)
+            assert (res.offsets == off).all(), (params, strategy)
+            assert (res.scores == sc).all(), (params, strategy)
+            assert res.cigars == cg, (params, strategy)
+            for slot in (0, 1, 77, n - 1):
+                btr = lane_aligner.expand_slot(slot, tl, ql)
+                o = ol.oracle_align(ts[slot], qs[slot], params, strategy, want_btr=True)
+                assert (btr[1:, 1:] == o["btr"][1:, 1:]).all(), (params, strategy, slot)
+
+
+def test_lane_kernel_goldens_unaligned_chunked_score_only(lane_aligner):
+    """The window goldens (one geometry) through the lane kernel: sequences at odd byte offsets (the kernel reads aligned
+    dwords and shifts), several chunks, and the score-only hint."""
+    import torch
+    from mgl_amd import _lib, device_batch
+
+    rows = [g for g in golden_io.load("window") if g.strategy == ol.SOFTCLIP]
+    assert len(rows) > 100 and len({(len(g.t), len(g.q)) for g in rows}) == 1
+    rows = (rows * 12)[:1500]
+    res = lane_aligner.align_batch([g.t for g in rows], [g.q for g in rows], rows[0].params, ol.SOFTCLIP)
+    assert lane_aligner.timing().fill_kernel == 4
+    for k, g in enumerate(rows):
+        assert (int(res.offsets[k]), res.cigars[k], tuple(int(x) for x in res.scores[k])) == (g.offset, g.cigar, g.score)
+    # device-resident, with a pad byte in front of both arrays: every sequence starts at an odd address
+    td, toff = sw.concat([g.t for g in rows])
+    qd, qoff = sw.concat([g.q for g in rows])
+    tl, ql = len(rows[0].t), len(rows[0].q)
+    for pad in (1, 2, 3):
+        b = device_batch.from_host(np.concatenate([np.zeros(pad, np.uint8), td]), toff + pad,
+                                   np.concatenate([np.zeros(pad, np.uint8), qd]), qoff + pad, "cuda:0", cigar_stride=64)
+        assert b.uniform
+        small = sw.MicrosoftSmithWaterman(0)
+        small.set_lane_kernel(2)
+        small.set_workspace(12 << 20)    # a few waves per chunk (one buffer: the lanes walk their own paths, nothing overlaps)
+        b.run(small)
+        torch.cuda.synchronize()
+        tm = small.timing()
+        assert tm.fill_kernel == 4 and tm.dp_launches > 2
+        cg = b.cigar_strings()
+        for k, g in enumerate(rows):
+            assert (int(b.offsets[k]), cg[k], tuple(int(x) for x in b.scores[k])) == (g.offset, g.cigar, g.score)
+        full = b.scores.clone()
+        b.scores.zero_()
+        b.run(small, score_only=True)
+        torch.cuda.synchronize()
+        assert torch.equal(full, b.scores)
+        small.close()
+
+
 def test_packed16_equals_forced_int32(aligner):
     rows = [g for g in golden_io.load("window") if g.strategy == ol.SOFTCLIP][:128]
     ts, qs = [g.t for g in rows], [g.q for g in rows]
