@@ -307,6 +307,26 @@ int mgl_sw_cigar_from_backtrack(const int32_t *btr, int tl, int ql, int strategy
                                 char *cigar, int cigar_cap, int *cigar_len, int *offset);
 
 /*
+ * One band of the matrix fill over the caller's arrays: the reference's calculateMatrix_avx (sw_avx.h:7 /
+ * sw_avx.cpp:110-322), the stage its driver runs once per band of default_bw = 8 target rows (sw_avx.cpp:71-80).
+ * Layouts are the reference's, all host pointers: `target` one base per int32, zero padded to a
+ * multiple of default_bw; `query` reversed, query[default_bw + query_length - 1 - j] = q[j], default_bw zeros on each
+ * side; `gap` indexed like `query` (vertical run lengths per column); `score` / `step` = H and E of the row above the
+ * band for columns 0 .. query_length (on return: of the band's last row); the band's backtrack values go to
+ * bcktrack[(query_length + default_bw - 1) * default_bw * band_count + (j - 1 + J) * default_bw + J] for row J of the
+ * band and column j -- cells of that region outside the matrix are left as the caller had them (the reference leaves
+ * garbage there, and in the padding entries of `gap`; after a band of fewer than default_bw rows -- the last one --
+ * `gap` holds the run lengths of the band's last real row where the reference leaves those of its padding rows:
+ * nothing reads it any more); ez->mqe / ez->mqe_t are updated with the band's last-column
+ * values ('>=': later rows win).  A compatibility entry for callers that drive the band loop themselves (one small
+ * kernel and a round trip per band), not a fast path.
+ */
+int mgl_sw_band_fill(const int32_t *target, int target_length, const int32_t *query, int query_length,
+                     int32_t *bcktrack, int band_count, int default_bw, int actual_bw, int32_t *score,
+                     int32_t *step, int32_t *gap, int match, int mismatch, int gopen, int gext, int strategy,
+                     mgl_sw_score *ez);
+
+/*
  * Same expansion for pair `slot` of the LAST chunk a batch call processed on ctx
  * (slot = pair index when the whole batch fitted one chunk).  The traceback
  * workspace is only valid until the next call on ctx.  tl / ql must be that

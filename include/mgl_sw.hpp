@@ -15,9 +15,11 @@
 //   int calculateCigar(...)             (sw_scalar.h:8)      -> mgl_sw_cigar_from_backtrack
 //   (new) int align_gpu(..., ScoreMax* ez = nullptr)         -> mgl_sw_align, also returns the score
 //
-// Also: bcktrMatrix_index and calculateCigar_avx (sw_avx.h:8,33-40) on the AVX2 path's band layout, and
-// calculateMatrix_banded producing that layout.  Not provided: the per-band step calculateMatrix_avx (sw_avx.h:7),
-// an internal stage of the reference's AVX2 driver (one band per call, with its score / step / gap carry arrays).
+//   void calculateMatrix_avx(...)       (sw_avx.h:7)         -> mgl_sw_band_fill (one band per call, the caller's arrays)
+//   int calculateCigar_avx(...)         (sw_avx.h:8)         -> mgl_sw_cigar_from_backtrack on the band layout
+//   bcktrMatrix_index                   (sw_avx.h:33-40)     same
+//
+// Also calculateMatrix_banded: the whole matrix in the AVX2 path's band layout in one call.
 //
 // Error behaviour: the reference's functions cannot fail.  These throw std::runtime_error
 // carrying the mgl_sw_status text when the library reports an error (no GPU, bad length, ...).
@@ -191,10 +193,23 @@ inline std::vector<int> calculateMatrix_banded(const char *target, int target_le
     return banded;
 }
 
+// sw_avx.h:7 -- one band of `actual_bw` target rows (band number band_count, default_bw = 8 rows per band) over the
+// caller's arrays in the reference's layouts: what align_avx's driver loop calls once per band (sw_avx.cpp:71-80).
+inline void calculateMatrix_avx(int *target, int target_length, int *query, int query_length, int *bcktrack, int band_count,
+                                int default_bw, int actual_bw, int *score, int *step, int *gap, swParameters parameters,
+                                int overhangStrategy, ScoreMax *ez)
+{
+    mgl_sw_score sc = mgl_sw_detail::from_ref(*ez);
+    mgl_sw_detail::check(mgl_sw_band_fill(target, target_length, query, query_length, bcktrack, band_count, default_bw, actual_bw,
+                                          score, step, gap, parameters.sc_match, parameters.sc_mismatch, parameters.g_open,
+                                          parameters.g_ext, overhangStrategy, &sc),
+                         "mgl_sw_band_fill");
+    ez->mqe = sc.mqe;
+    ez->mqe_t = sc.mqe_t;
+}
+
 // sw_avx.h:8 -- traceback on a band-layout matrix (n = target_length + 1, m = query_length + 1, bw = the band
-// width it was written with, 8 in the reference); appends to *cigar, returns the offset.  The per-band fill
-// calculateMatrix_avx (sw_avx.h:7) is an internal step of the reference's AVX2 driver -- one band per call with its
-// score / step / gap carry arrays -- and has no counterpart here: calculateMatrix[_banded] give the whole matrix.
+// width it was written with, 8 in the reference); appends to *cigar, returns the offset.
 inline int calculateCigar_avx(int *bcktrack, int n, int m, int bw, int overhangStrategy, ScoreMax *ez, std::string *cigar)
 {
     const int tl = n - 1, ql = m - 1, n_col = ql + bw - 1;

@@ -25,7 +25,7 @@ SYMBOLS = (
     "mgl_sw_ctx_destroy", "mgl_sw_last_error", "mgl_sw_ctx_set_workspace", "mgl_sw_ctx_set_profiling", "mgl_sw_ctx_set_precision",
     "mgl_sw_ctx_get_timing", "mgl_sw_normalize_params", "mgl_sw_align", "mgl_sw_align_batch", "mgl_sw_align_batch_status",
     "mgl_sw_align_batch_device", "mgl_sw_align_batch_device_2bit", "mgl_sw_align_batch_device_matrix", "mgl_sw_align_batch_device_indexed", "mgl_sw_backtrack_matrix", "mgl_sw_ctx_expand_slot",
-    "mgl_sw_cigar_from_backtrack", "mgl_sw_set_coalescing", "mgl_sw_coalescing_stats", "mgl_sw_group_by_geometry",
+    "mgl_sw_cigar_from_backtrack", "mgl_sw_band_fill", "mgl_sw_set_coalescing", "mgl_sw_coalescing_stats", "mgl_sw_group_by_geometry",
     "mgl_sw_multi_create", "mgl_sw_multi_destroy", "mgl_sw_multi_device_count", "mgl_sw_multi_ctx", "mgl_sw_multi_set_workspace",
     "mgl_sw_multi_last_error", "mgl_sw_align_batch_multi", "mgl_sw_multi_last_shards", "mgl_sw_shard_by_cells",
 )
@@ -109,6 +109,7 @@ def lib():
     L.mgl_sw_cigar_from_backtrack.argtypes = [i32p, C.c_int, C.c_int, C.c_int, C.POINTER(Score), cp, C.c_int,
                                               C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mgl_sw_set_coalescing.argtypes = [C.c_int, C.c_int]
+    L.mgl_sw_band_fill.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp] + [C.c_int] * 5 + [C.POINTER(Score)]
     L.mgl_sw_group_by_geometry.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     L.mgl_sw_coalescing_stats.argtypes = [i64p, i64p]
     L.mgl_sw_ctx_expand_slot.argtypes = [vp, C.c_int64, C.c_int, C.c_int, i32p]

@@ -1169,6 +1169,52 @@ int mgl_sw_backtrack_matrix(const char *t, int tl, const char *q, int ql, int ma
     return rc;
 }
 
+int mgl_sw_band_fill(const int32_t *target, int target_length, const int32_t *query, int query_length, int32_t *bcktrack,
+                     int band_count, int default_bw, int actual_bw, int32_t *score, int32_t *step, int32_t *gap, int match,
+                     int mismatch, int gopen, int gext, int strategy, mgl_sw_score *ez)
+{
+    if (!target || !query || !bcktrack || !score || !step || !gap || !ez || target_length < 1 || query_length < 1 ||
+        default_bw < 1 || default_bw > 64 || actual_bw < 1 || actual_bw > default_bw || band_count < 0 ||
+        (int64_t)band_count * default_bw + actual_bw > target_length || !strategy_ok(strategy) || query_length > (1 << 24))
+        return MGL_SW_ERR_BAD_ARG;
+    mgl_sw_normalize_params(&match, &mismatch, &gopen, &gext);
+    int rc;
+    mgl_sw_ctx *ctx = thread_ctx(&rc);
+    if (!ctx) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int bw = default_bw, ql = query_length;
+    const size_t n_q = (size_t)ql + 2 * (size_t)bw, n_sc = (size_t)ql + 1, n_band = (size_t)(ql + bw - 1) * (size_t)bw;
+    // one device buffer: target rows of the band | reversed query | score | step | gap | the band's backtrack cells | mqe, mqe_t
+    const size_t words = (size_t)bw + n_q + 2 * n_sc + n_q + n_band + 2;
+    HIP_TRY(ctx, ctx->d_btr.reserve(words * 4));
+    int32_t *d = static_cast<int32_t *>(ctx->d_btr.p);
+    int32_t *d_t = d, *d_q = d_t + bw, *d_score = d_q + n_q, *d_step = d_score + n_sc, *d_gap = d_step + n_sc, *d_band = d_gap + n_q,
+            *d_mqe = d_band + n_band;
+    hipStream_t st = ctx->stream;
+    int32_t *h_band = bcktrack + (size_t)(ql + bw - 1) * (size_t)bw * (size_t)band_count; // sw_avx.cpp:173
+    const int32_t mqe_in[2] = {ez->mqe, ez->mqe_t};
+    HIP_TRY(ctx, hipMemcpyAsync(d_t, target + (size_t)bw * band_count, (size_t)actual_bw * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_q, query, n_q * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_score, score, n_sc * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_step, step, n_sc * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_gap, gap, n_q * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_band, h_band, n_band * 4, hipMemcpyHostToDevice, st)); // cells outside the matrix keep the caller's values
+    HIP_TRY(ctx, hipMemcpyAsync(d_mqe, mqe_in, 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, launch_band_fill(d_t, d_q, ql, d_band, band_count, bw, actual_bw, d_score, d_step, d_gap, match, mismatch, gopen, gext,
+                                  strategy, d_mqe, st));
+    int32_t mqe_out[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(score, d_score, n_sc * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(step, d_step, n_sc * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(gap, d_gap, n_q * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(h_band, d_band, n_band * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(mqe_out, d_mqe, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    ez->mqe = mqe_out[0];
+    ez->mqe_t = mqe_out[1];
+    return MGL_SW_OK;
+}
+
 int mgl_sw_group_by_geometry(int64_t n, const int32_t *t_len, const int32_t *q_len, int64_t *order_out, int64_t *n_grouped_out)
 {
     if (n < 0 || (n > 0 && (!t_len || !q_len || !order_out)) || !n_grouped_out) return MGL_SW_ERR_BAD_ARG;

@@ -160,5 +160,9 @@ hipError_t launch_cigar_from_matrix(const int32_t *btr, int tl, int ql, int stra
 hipError_t launch_expand(const uint32_t *tbw, const DpRecord *rec, int tl, int ql, int packed16, int half, int rows,
                          int32_t *btr, hipStream_t stream, int lane = 0);
 
+hipError_t launch_band_fill(const int32_t *target, const int32_t *query, int ql, int32_t *band_btr, int band, int bw, int actual_bw,
+                            int32_t *score, int32_t *step, int32_t *gap, int match, int mismatch, int gopen, int gext,
+                            int strategy, int32_t *mqe_io, hipStream_t stream);
+
 } // namespace mgl_sw_dev
 #endif

@@ -673,6 +673,77 @@ __global__ __launch_bounds__(256) void sw_expand_kernel(const uint32_t *tbw, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// calculateMatrix_avx (sw_avx.h:7, sw_avx.cpp:110-322) as a stage: ONE band of `actual_bw` target rows over the caller's
+// arrays, in the reference's layouts: `query` reversed with `bw` ints of padding on each side, `gap`
+// indexed like it, `score` / `step` = H and E of the row above the band per column (0 .. ql), the band's backtrack cells at
+// bcktrack[bw * band * (ql + bw - 1) + (j - 1 + J) * bw + J] for row J of the band, column j.  A compatibility entry for
+// callers that drive the band loop themselves (sw_avx.cpp:71-80), not a fast path: one lane walks the band row by row,
+// which yields every cell the anti-diagonal order of the reference yields (same recurrence, same comparisons).
+__global__ void sw_band_fill_kernel(const int32_t *target, const int32_t *query, int ql, int32_t *band_btr, int band, int bw,
+                                    int actual_bw, int32_t *score, int32_t *step, int32_t *gap, int match, int mismatch,
+                                    int gopen, int gext, int strategy, int32_t *mqe_io)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const bool indel = (strategy & (OS_INDEL | OS_LEAD_ID)) != 0;
+    const int n_col = ql + bw - 1;
+    int mqe = mqe_io[0], mqe_t = mqe_io[1];
+    int e0 = step[0]; // E running down column 0 (never feeds a cell; kept so that step[0] leaves as the reference leaves it)
+    const int score0_in = score[0];
+    for (int J = 0; J < actual_bw; ++J) {
+        const int row = bw * band + J + 1;                                   // 1-based target row
+        const int hb = indel ? -gopen - (row - 1) * gext : 0;                // H[row][0]: _s_col, sw_avx.cpp:117-124
+        const int tbase = target[J];                                         // (the caller hands over the band's rows)
+        int diag = score[0];                                                 // H[row-1][0]
+        score[0] = hb;
+        e0 = max(hb - gopen, e0 - gext);
+        int F = hb - gopen, gap_h = -1;                                      // _f_col, sw_avx.cpp:114,123
+        for (int j = 1; j <= ql; ++j) {
+            const int gi = bw + ql - 1 - (j - 1);                            // reversed index of column j (sw_avx.cpp:161-162)
+            const int up = score[j];
+            const int E = step[j];
+            int gv = gap[gi];
+            int S = diag + (query[gi] == tbase ? match : mismatch);          // sw_avx.cpp:163-165
+            int dir = F > S ? gap_h : 0;                                     // :167-169
+            S = max(S, F);
+            dir = E > S ? gv : dir;                                          // :171-174
+            S = max(S, E);
+            band_btr[(size_t)(j - 1 + J) * bw + J] = dir;
+            const int tmp = S - gopen;                                       // :179-191 (extension wins ties)
+            const int Ee = E - gext;
+            gv = tmp > Ee ? 1 : gv + 1;
+            const int Fe = F - gext;
+            gap_h = tmp > Fe ? -1 : gap_h - 1;
+            F = max(tmp, Fe);
+            diag = up;
+            score[j] = S;
+            step[j] = max(tmp, Ee);
+            gap[gi] = gv;
+        }
+        if (score[ql] >= mqe) { // last column, later rows win ties (sw_avx.cpp:313-321)
+            mqe = score[ql];
+            mqe_t = row;
+        }
+    }
+    if (actual_bw > 1) {
+        step[0] = e0;
+    } else {
+        score[0] = score0_in; // a band of one row: the reference's first-triangle loop (sw_avx.cpp:159-206) does not run and
+    }                         // column 0 of score[] / step[] keeps the previous band's values (nothing reads them any more)
+    (void)n_col;
+    mqe_io[0] = mqe;
+    mqe_io[1] = mqe_t;
+}
+
+hipError_t launch_band_fill(const int32_t *target, const int32_t *query, int ql, int32_t *band_btr, int band, int bw, int actual_bw,
+                            int32_t *score, int32_t *step, int32_t *gap, int match, int mismatch, int gopen, int gext,
+                            int strategy, int32_t *mqe_io, hipStream_t stream)
+{
+    hipLaunchKernelGGL(sw_band_fill_kernel, dim3(1), dim3(64), 0, stream, target, query, ql, band_btr, band, bw, actual_bw, score,
+                       step, gap, match, mismatch, gopen, gext, strategy, mqe_io);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // launch wrappers (called from sw_capi.cpp)
 
 int64_t dp_group_bytes(int sps_cap, int rows)

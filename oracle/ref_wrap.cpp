@@ -126,4 +126,18 @@ int ref_align_batch(int n, const char *targets, const long long *t_off, const ch
 }
 
 int ref_has_avx2(void) { return __builtin_cpu_supports("avx2") ? 1 : 0; }
+
+/* One band through the reference's calculateMatrix_avx (sw_avx.h:7, sw_avx.cpp:110-322) on the caller's arrays, laid
+ * out as align_avx lays them out (sw_avx.cpp:16-49); mqe2 = {mqe, mqe_t} in and out. */
+void ref_band_fill(int *target, int tl, int *query_rev, int ql, int *bcktrack, int band_count, int default_bw, int actual_bw,
+                   int *score, int *step, int *gap, int match, int mismatch, int gopen, int gext, int strategy, int *mqe2)
+{
+    ScoreMax ez;
+    ez.mqe = mqe2[0];
+    ez.mqe_t = mqe2[1];
+    calculateMatrix_avx(target, tl, query_rev, ql, bcktrack, band_count, default_bw, actual_bw, score, step, gap,
+                        make_params(match, mismatch, gopen, gext), strategy, &ez);
+    mqe2[0] = ez.mqe;
+    mqe2[1] = ez.mqe_t;
+}
 }

@@ -79,6 +79,9 @@ def ref():
         lib.ref_calculate_matrix.restype = None
         lib.ref_calculate_cigar.argtypes = [i32p, C.c_int, C.c_int, C.c_int, i32p, C.c_char_p, C.c_int,
                                             C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        if hasattr(lib, "ref_band_fill"):
+            lib.ref_band_fill.argtypes = [i32p, C.c_int, i32p, C.c_int, i32p, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p] + [C.c_int] * 5 + [i32p]
+            lib.ref_band_fill.restype = None
         lib.ref_align_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [
             C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _ref = lib

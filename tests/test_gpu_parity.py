@@ -266,6 +266,79 @@ def test_cpp_dropin_api():
         assert int(f[10]) == g.crc
 
 
+def test_band_stage_matches_the_reference_band_by_band():
+    """calculateMatrix_avx (sw_avx.h:7) as a stage: mgl_sw_band_fill on the caller's arrays against the reference's own
+    calculateMatrix_avx (oracle/_ref), compared after EVERY band -- score[], step[], the in-matrix entries of gap[], the
+    band's backtrack cells, mqe / mqe_t -- then the finished band-layout matrix against the reference's logical one."""
+    import ctypes as C
+
+    from mgl_amd import _lib
+
+    if not ol.have_ref() or not hasattr(ol.ref(), "ref_band_fill"):
+        pytest.skip("oracle/_ref (the compiled reference) is not available")
+    R, L = ol.ref(), _lib.lib()
+    i32p = C.POINTER(C.c_int32)
+    # (queries of eight bases and more: below that the reference dispatches to its scalar path and its AVX2 stage is not valid)
+    rows = [g for g in golden_io.load("known")] + golden_io.load("random")[:40] + golden_io.load("ties")[:24] + \
+           [g for g in golden_io.load("shapes") if len(g.q) >= 1][:80]
+    rows = [g for g in rows if len(g.q) >= 8]
+    checked = 0
+    for g in rows:
+        tl, ql, bw = len(g.t), len(g.q), 8
+        m, x, o, e = g.params
+        ncol, pad_t = ql + 1, (bw - tl % bw) % bw
+        rq = np.zeros(ql + 2 * bw, np.int32)
+        rq[bw + ql - 1 - np.arange(ql)] = np.frombuffer(g.q, np.uint8)
+        et = np.zeros(tl + pad_t, np.int32)
+        et[:tl] = np.frombuffer(g.t, np.uint8)
+        state = []
+        for _ in range(2):  # [reference, ours]
+            score, step, gap = np.zeros(ncol + bw, np.int32), np.zeros(ncol + bw, np.int32), np.ones(ql + 2 * bw, np.int32)
+            step[:ncol] = -abs(o)
+            if g.strategy in (ol.INDEL, ol.LEAD_INDEL):
+                k = np.arange(1, ncol)
+                score[1:ncol] = -abs(o) - (k - 1) * abs(e)
+                step[1:ncol] += -abs(o) - (k - 1) * abs(e)
+            state.append(dict(score=score, step=step, gap=gap, bt=np.zeros((ql + bw - 1) * (tl + pad_t), np.int32),
+                              mqe=np.array([-0x40000000, -1], np.int32)))
+        ref, mine = state
+        ez = _lib.Score(-0x40000000, -1, -0x40000000, -1, -1, 0)
+        P = lambda a: a.ctypes.data_as(i32p)
+        rows_left, band = tl, 0
+        while rows_left > 0:
+            nrow = min(bw, rows_left)
+            rows_left -= nrow
+            R.ref_band_fill(P(et), tl, P(rq), ql, P(ref["bt"]), band, bw, nrow, P(ref["score"]), P(ref["step"]), P(ref["gap"]), m, x, o, e,
+                            g.strategy, P(ref["mqe"]))
+            rc = L.mgl_sw_band_fill(et.ctypes.data, tl, rq.ctypes.data, ql, mine["bt"].ctypes.data, band, bw, nrow, mine["score"].ctypes.data,
+                                    mine["step"].ctypes.data, mine["gap"].ctypes.data, m, x, o, e, g.strategy, C.byref(ez))
+            assert rc == 0
+            ctx = (g.t, g.q, g.params, g.strategy, band)
+            assert (mine["score"][:ncol] == ref["score"][:ncol]).all(), ctx
+            assert (mine["step"][:ncol] == ref["step"][:ncol]).all(), ctx
+            if nrow == bw:  # (after the last, partial band the reference's gap[] holds the run lengths of its PADDING rows -- lane 7
+                assert (mine["gap"][bw:bw + ql] == ref["gap"][bw:bw + ql]).all(), ctx  # stores last -- and nothing reads it any more)
+            assert (ez.mqe, ez.mqe_t) == (int(ref["mqe"][0]), int(ref["mqe"][1])), ctx
+            for J in range(nrow):  # the band's in-matrix cells: row J of the band, column j -> diagonal j - 1 + J
+                idx = (ql + bw - 1) * bw * band + (np.arange(ql) + J) * bw + J
+                assert (mine["bt"][idx] == ref["bt"][idx]).all(), ctx + (J,)
+            band += 1
+        # the finished band-layout matrix == the reference's logical matrix (sw_avx.h:33-40 indexing)
+        o_full = ol.ref_full(g.t, g.q, g.params, g.strategy, want_btr=True)
+        ii, jj = np.meshgrid(np.arange(tl), np.arange(ql), indexing="ij")
+        pos = (ii // bw) * bw * (ql + bw - 1) + (jj + ii % bw) * bw + ii % bw
+        assert (mine["bt"][pos] == o_full["btr"][1:, 1:]).all(), (g.t, g.q, g.strategy)
+        assert (ez.mqe, ez.mqe_t) == (g.score[0], g.score[1])
+        checked += 1
+    assert checked == len(rows) and checked > 80
+    # argument checks: band outside the target, more rows than the band width
+    z = np.zeros(64, np.int32)
+    assert L.mgl_sw_band_fill(z.ctypes.data, 4, z.ctypes.data, 4, z.ctypes.data, 1, 8, 4, z.ctypes.data, z.ctypes.data, z.ctypes.data,
+                              1, -1, 1, 1, 1, C.byref(ez)) == _lib.ERR_BAD_ARG
+    assert L.mgl_sw_band_fill(z.ctypes.data, 4, z.ctypes.data, 4, z.ctypes.data, 0, 8, 9, z.ctypes.data, z.ctypes.data, z.ctypes.data,
+                              1, -1, 1, 1, 1, C.byref(ez)) == _lib.ERR_BAD_ARG
+
+
 def test_grouped_geometry_variable_length_reads(aligner):
     """Reads of varying length (trimmed reads) against windows of two sizes, addressed by (start, length), sorted by
     geometry and padded to blocks of eight (MGL_SW_FLAG_GROUPED_GEOMETRY): the packed-int16 kernel runs one geometry
