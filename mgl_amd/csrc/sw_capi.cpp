@@ -71,6 +71,12 @@ struct mgl_sw_ctx {
     void *pin_in = nullptr, *pin_out = nullptr;
     size_t pin_in_cap = 0, pin_out_cap = 0;
     DevBuf stage_in, stage_out;
+    // host entry, batches of mixed geometries: per workspace half the chunk's index arrays (start / length / caller index per
+    // slot, sorted by geometry), built in pinned memory and mirrored on the device
+    void *pin_grp[2] = {nullptr, nullptr};
+    size_t pin_grp_cap[2] = {0, 0};
+    DevBuf d_grp[2];
+    hipEvent_t grp_copied[2] = {nullptr, nullptr};
     // substitution matrix + code table: copied here first, so the caller's buffers may go away when the call returns
     void *pin_matrix = nullptr;
     hipEvent_t matrix_copied = nullptr;
@@ -179,9 +185,19 @@ int max_lds_query_len()
 // Host-buffer entry only: per-chunk hooks that move a chunk's inputs in before its fill is launched and its
 // results out after the NEXT chunk has been launched (pageable copies block the calling thread, so this order
 // is what lets the copies of one chunk overlap the kernels of its neighbours).
+// What the host entry hands back for a chunk of a batch of mixed geometries that it has sorted by (tl, ql) itself: the chunk's
+// pairs in the new order as (start, length) index arrays over the caller's bases, the caller's pair index of every
+// slot, and how many leading slots form full blocks of eight with one geometry each (the packed kernel's food).
+struct Regroup {
+    const int64_t *d_t_start = nullptr, *d_q_start = nullptr, *d_dest = nullptr;
+    const int32_t *d_t_len = nullptr, *d_q_len = nullptr;
+    int64_t n_grouped = 0;
+};
 struct ChunkHooks {
     std::function<int(int64_t first, int64_t count, hipStream_t fill_stream)> before_fill;
     std::function<int(int64_t first, int64_t count, hipEvent_t results_ready)> after_traceback;
+    // optional: sort the chunk by geometry (slot buffers `half` are free to overwrite when this is called)
+    std::function<int(int64_t first, int64_t count, int half, hipStream_t fill_stream, Regroup *out)> regroup;
     int32_t *d_status_any = nullptr;   // device word receiving the largest per-pair status
 };
 
@@ -240,11 +256,19 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const int lane_rows = lane_rows_env == 16 || lane_rows_env == 32 ? lane_rows_env
                           : ((max_tl + 31) / 32 * 32 - (max_tl + 15) / 16 * 16) * 10 >= max_tl ? 16 : 32;
     // (what counts is the size of a launch: a batch that the workspace cuts into small chunks is no better than a small batch)
-    const int64_t lane_launch = std::min<int64_t>(n, ctx->ws_limit / (lane_tb_words(max_tl, max_ql, lane_rows) * 4 / 128 + 1));
+    const int64_t lane_launch = std::min<int64_t>(hooks ? std::max<int64_t>(n / 32, (int64_t)256 * 1024) : n,
+                                                  std::min<int64_t>(n, ctx->ws_limit / (lane_tb_words(max_tl, max_ql, lane_rows) * 4 / 128 + 1)));
     const bool use_lane = geom == GEOM_UNIFORM && ctx->precision != 32 && !d_matrix && match > 0 && ctx->lane_kernel != 1 &&
                           (ctx->lane_kernel == 2 || lane_launch >= kLaneMinPairs) && lane16_supported(tset, qset) &&
                           dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
-    const bool use16 = use16_eligible && !use_lane;
+    // a batch of mixed geometries whose chunks the host entry sorts by geometry (hooks->regroup): full blocks of eight pairs
+    // with one geometry go through the packed kernel, the few left over through the int32 kernel, results land in the
+    // caller's order (TbArgs.dest) -- the reference takes any pair (sw_avx.cpp:6-108), so must the fast path
+    const bool auto_group = geom == GEOM_MIXED && hooks && hooks->regroup && ctx->precision != 32 && !d_matrix && match > 0 &&
+                            !ctx->stripe_rows && ctx->cooperative < 2 && ctx->carry_memory == 0 && max_ql < kRows64MinQuery &&
+                            dp16_lds_bytes(sps_for(max_ql), wpb16) <= 64 * 1024 && pick_waves_per_block(sps_for_rows(max_ql, 16), 16) > 0 &&
+                            dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
+    const bool use16 = (use16_eligible && !use_lane) || auto_group;
     // MGL_SW_FLAG_SCORE_ONLY is honoured by the packed kernels only; elsewhere the full path runs (a superset of the result)
     const bool score_only = score_only_hint && (use16 || use_lane) && d_score != nullptr && !hooks;
     int rows = use_lane ? lane_rows : use16 ? 16 : ctx->stripe_rows ? ctx->stripe_rows : (max_ql >= kRows64MinQuery ? 64 : 16);
@@ -283,8 +307,12 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const int64_t stride_words = use_lane ? lane_tb_words(max_tl, max_ql, rows)
                                  : use16 ? (geom == GEOM_UNIFORM ? tb_words16_for(max_tl, max_ql) : tb_words16_bound(max_tl, max_ql))
                                          : tb_words_for(max_tl, sps_cap, rows);
+    // (auto-grouped chunks: the packed regions first, the int32 regions of the left-over pairs behind them)
+    const int sps32 = sps_for_rows(max_ql, 16);
+    const int64_t stride32_words = tb_words_for(max_tl, sps32, 16);
     const int64_t per_pair = use_lane ? ((score_only ? 0 : stride_words * 4) + lane_scratch_bytes(max_tl, max_ql, rows)) / 128 + 1 + (int64_t)sizeof(DpRecord)
-                                      : (score_only ? 0 : stride_words * 4 / (use16 ? 2 : 1)) + (int64_t)sizeof(DpRecord);
+                             : auto_group ? std::max(stride_words * 2, stride32_words * 4) + (int64_t)sizeof(DpRecord)
+                                          : (score_only ? 0 : stride_words * 4 / (use16 ? 2 : 1)) + (int64_t)sizeof(DpRecord);
     // the workspace is split in two halves so that the traceback of one chunk can run (on ctx->aux)
     // while the next chunk is being filled; a batch that fits one half is a single chunk
     // chunks are whole waves' worth of pairs (8: packed kernel, and the blocks of MGL_SW_FLAG_GROUPED_GEOMETRY; 4: 16-row
@@ -302,6 +330,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         return fail(ctx, MGL_SW_ERR_NOMEM, msg);
     }
     int64_t chunk = std::max<int64_t>(gran, ws_part / per_pair / gran * gran);
+    // host-buffer entry: the chunks are also the units of the copy / compute pipeline (inputs of chunk k+1 and results of
+    // chunk k-1 move while chunk k computes), so a batch is cut into ~32 even when the workspace would hold it whole
+    // (10 M pairs: 133 ms in 46 chunks, 143 in 12, scripts/host_entry_probe.py)
+    if (hooks) chunk = std::min<int64_t>(chunk, std::max<int64_t>((n / 32 + gran - 1) / gran * gran, (int64_t)256 * 1024));
     chunk = std::min<int64_t>(chunk, n);
     const bool overlap = !fused_walk && n > chunk;
     const int halves = overlap ? 2 : 1;
@@ -309,7 +341,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int h = 0; h < halves; ++h) {
         const size_t regions = (size_t)(use_lane ? (chunk + 127) / 128 : use16 ? (chunk + 1) / 2 : chunk);
-        if (!score_only) HIP_TRY(ctx, ctx->tb[h].reserve(regions * (size_t)stride_words * 4));
+        if (auto_group)
+            HIP_TRY(ctx, ctx->tb[h].reserve((size_t)chunk * (size_t)(per_pair - (int64_t)sizeof(DpRecord)) + 64));
+        else if (!score_only)
+            HIP_TRY(ctx, ctx->tb[h].reserve(regions * (size_t)stride_words * 4));
         if (use_lane) HIP_TRY(ctx, ctx->bnd[h].reserve(regions * (size_t)lane_scratch_bytes(max_tl, max_ql, rows)));
         HIP_TRY(ctx, ctx->rec[h].reserve((size_t)chunk * sizeof(DpRecord)));
     }
@@ -340,55 +375,91 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             const int hrc = hooks->before_fill(first, count, stream);
             if (hrc != MGL_SW_OK) return hrc;
         }
-        DpArgs da;
-        da.t = tset;
-        da.q = qset;
-        da.first = first;
-        da.count = count;
-        da.match = match;
-        da.mismatch = mismatch;
-        da.gopen = gopen;
-        da.gext = gext;
-        da.strategy = strategy;
-        da.sps_cap = sps_cap;
-        da.uni_tl = max_tl;
-        da.uni_ql = max_ql;
-        da.tb = static_cast<uint32_t *>(ctx->tb[h].p);
-        da.tb_stride_words = stride_words;
-        da.rec = static_cast<DpRecord *>(ctx->rec[h].p);
-        da.scratch = use_lane ? static_cast<unsigned char *>(ctx->bnd[h].p) : (use_scratch || coop_waves) ? static_cast<unsigned char *>(ctx->scratch.p) : nullptr;
-        da.diag = nullptr;
-        da.matrix = d_matrix;
-        da.code = d_code;
-        da.matrix_lds_offset = 0;
-        da.score_only = score_only ? 1 : 0;
-        const int per_block = use_lane ? wpb * 128 : use16 ? wpb * 8 : wpb * (64 / rows);
-        const int64_t n_blocks = (count + per_block - 1) / per_block;
-        if (ctx->profiling >= 2) {
-            HIP_TRY(ctx, ctx->diag.reserve((size_t)n_blocks * 16));
-            da.diag = static_cast<unsigned long long *>(ctx->diag.p);
+        // what this chunk launches: one part normally; a chunk the host entry has sorted by geometry has a packed part
+        // (full blocks of eight) and an int32 part (the left-over pairs), each with its own kernels and workspace regions
+        struct Part {
+            bool lane, packed;
+            int64_t first, count;
+            SeqSet t, q;
+            uint32_t *tb;
+            int64_t stride;
+            DpRecord *rec;
+            const int64_t *dest;
+            int rows, wpb, sps_cap;
+        } parts[2];
+        int n_parts = 0;
+        uint32_t *const tb_base = static_cast<uint32_t *>(ctx->tb[h].p);
+        DpRecord *const rec_base = static_cast<DpRecord *>(ctx->rec[h].p);
+        if (!auto_group) {
+            parts[n_parts++] = Part{use_lane, use16, first, count, tset, qset, tb_base, stride_words, rec_base, nullptr, rows, wpb, sps_cap};
+        } else {
+            // the index arrays of this half were last read by the kernels of chunk k-2
+            if (overlap && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->h2d, ctx->tb_done[h], 0));
+            Regroup rg;
+            const int hrc = hooks->regroup(first, count, h, stream, &rg);
+            if (hrc != MGL_SW_OK) return hrc;
+            const SeqSet ts{tset.data, rg.d_t_start, rg.d_t_len, max_tl, 0}, qs{qset.data, rg.d_q_start, rg.d_q_len, max_ql, 0};
+            const int64_t ng = rg.n_grouped;
+            if (ng > 0) parts[n_parts++] = Part{false, true, 0, ng, ts, qs, tb_base, stride_words, rec_base, rg.d_dest, 16, wpb16, sps_for(max_ql)};
+            if (count > ng)
+                parts[n_parts++] = Part{false, false, ng, count - ng, ts, qs, tb_base + (size_t)(ng / 2) * (size_t)stride_words, stride32_words,
+                                        rec_base + ng, rg.d_dest, 16, pick_waves_per_block(sps32, 16), sps32};
         }
-
-        TbArgs ta;
-        ta.t = tset;
-        ta.q = qset;
-        ta.first = first;
-        ta.count = count;
-        ta.strategy = strategy;
-        ta.tb = da.tb;
-        ta.tb_stride_words = stride_words;
-        ta.packed16 = use_lane ? 2 : use16 ? 1 : 0;
-        ta.rows_per_stripe = rows;
-        ta.uni_ql = max_ql;
-        ta.rec = da.rec;
-        ta.offset = d_offset;
-        ta.score = d_score;
-        ta.cigar = d_cigar;
-        ta.cigar_stride = cigar_stride;
-        ta.binary_cigar = binary_cigar ? 1 : 0;
-        ta.cigar_len = d_cigar_len;
-        ta.status = d_status;
-        ta.status_any = hooks ? hooks->d_status_any : nullptr;
+        DpArgs das[2];
+        TbArgs tas[2];
+        int64_t n_blocks = 0;
+        for (int i = 0; i < n_parts; ++i) {
+            const Part &pt = parts[i];
+            DpArgs &da = das[i];
+            da.t = pt.t;
+            da.q = pt.q;
+            da.first = pt.first;
+            da.count = pt.count;
+            da.match = match;
+            da.mismatch = mismatch;
+            da.gopen = gopen;
+            da.gext = gext;
+            da.strategy = strategy;
+            da.sps_cap = pt.sps_cap;
+            da.uni_tl = max_tl;
+            da.uni_ql = max_ql;
+            da.tb = pt.tb;
+            da.tb_stride_words = pt.stride;
+            da.rec = pt.rec;
+            da.scratch = pt.lane ? static_cast<unsigned char *>(ctx->bnd[h].p) : (use_scratch || coop_waves) ? static_cast<unsigned char *>(ctx->scratch.p) : nullptr;
+            da.diag = nullptr;
+            da.matrix = d_matrix;
+            da.code = d_code;
+            da.matrix_lds_offset = 0;
+            da.score_only = score_only ? 1 : 0;
+            const int per_block = pt.lane ? pt.wpb * 128 : pt.packed ? pt.wpb * 8 : pt.wpb * (64 / pt.rows);
+            if (i == 0) n_blocks = (pt.count + per_block - 1) / per_block;
+            if (ctx->profiling >= 2 && i == 0) {
+                HIP_TRY(ctx, ctx->diag.reserve((size_t)n_blocks * 16));
+                da.diag = static_cast<unsigned long long *>(ctx->diag.p);
+            }
+            TbArgs &ta = tas[i];
+            ta.t = pt.t;
+            ta.q = pt.q;
+            ta.first = pt.first;
+            ta.count = pt.count;
+            ta.strategy = strategy;
+            ta.tb = pt.tb;
+            ta.tb_stride_words = pt.stride;
+            ta.packed16 = pt.lane ? 2 : pt.packed ? 1 : 0;
+            ta.rows_per_stripe = pt.rows;
+            ta.uni_ql = max_ql;
+            ta.rec = pt.rec;
+            ta.offset = d_offset;
+            ta.score = d_score;
+            ta.cigar = d_cigar;
+            ta.cigar_stride = cigar_stride;
+            ta.binary_cigar = binary_cigar ? 1 : 0;
+            ta.cigar_len = d_cigar_len;
+            ta.status = d_status;
+            ta.status_any = hooks ? hooks->d_status_any : nullptr;
+            ta.dest = pt.dest;
+        }
 
         hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
         if (ctx->profiling) {
@@ -405,16 +476,22 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         // this half was last read by the traceback of chunk k-2
         if (overlap && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->tb_done[h], 0));
         if (pe[0]) HIP_TRY(ctx, hipEventRecord(pe[0], stream));
-        TbArgs walk = ta;
-        if (!fused_walk) walk.cigar = nullptr;
-        HIP_TRY(ctx, use_lane ? launch_dp16_lane(da, walk, rows, stream) : use16 ? launch_dp16(da, wpb, stream) : coop_waves ? launch_dp_coop(da, coop_waves, stream) : launch_dp(da, wpb, rows, stream));
+        for (int i = 0; i < n_parts; ++i) {
+            const Part &pt = parts[i];
+            TbArgs walk = tas[i];
+            if (!fused_walk) walk.cigar = nullptr;
+            HIP_TRY(ctx, pt.lane ? launch_dp16_lane(das[i], walk, pt.rows, stream)
+                         : pt.packed ? launch_dp16(das[i], pt.wpb, stream)
+                         : coop_waves ? launch_dp_coop(das[i], coop_waves, stream) : launch_dp(das[i], pt.wpb, pt.rows, stream));
+        }
         if (pe[1]) HIP_TRY(ctx, hipEventRecord(pe[1], stream));
         if (overlap) {
             HIP_TRY(ctx, hipEventRecord(ctx->fill_done[h], stream));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->fill_done[h], 0));
         }
         if (pe[2]) HIP_TRY(ctx, hipEventRecord(pe[2], tb_stream));
-        if (!fused_walk) HIP_TRY(ctx, score_only ? launch_scores_only(ta, tb_stream) : launch_traceback(ta, tb_stream));
+        for (int i = 0; i < n_parts && !fused_walk; ++i)
+            HIP_TRY(ctx, score_only ? launch_scores_only(tas[i], tb_stream) : launch_traceback(tas[i], tb_stream));
         if (pe[3]) HIP_TRY(ctx, hipEventRecord(pe[3], tb_stream));
         if (overlap) {
             HIP_TRY(ctx, hipEventRecord(ctx->tb_done[h], ctx->aux));
@@ -432,7 +509,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             pending[n_pending++] = Pending{first, count, ctx->out_ready[k & 1]};
         }
         ctx->last_stride_words = stride_words;
-        ctx->last_chunk_count = count;
+        ctx->last_chunk_count = auto_group ? 0 : count; // (a chunk sorted by geometry has no caller-order slots to expand)
         ctx->last_half = h;
         ctx->last_rows = rows;
         ctx->last_packed16 = use_lane ? 2 : use16 ? 1 : 0;
@@ -557,6 +634,11 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     if (ctx->pin_matrix) (void)hipHostFree(ctx->pin_matrix);
     if (ctx->matrix_copied) (void)hipEventDestroy(ctx->matrix_copied);
     if (ctx->ws_idle) (void)hipEventDestroy(ctx->ws_idle);
+    for (int h = 0; h < 2; ++h) {
+        if (ctx->pin_grp[h]) (void)hipHostFree(ctx->pin_grp[h]);
+        if (ctx->grp_copied[h]) (void)hipEventDestroy(ctx->grp_copied[h]);
+        ctx->d_grp[h].release();
+    }
     if (ctx->pin_in) (void)hipHostFree(ctx->pin_in);
     if (ctx->pin_out) (void)hipHostFree(ctx->pin_out);
     ctx->stage_in.release();
@@ -922,6 +1004,97 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
         t_out += now() - t0;
         return MGL_SW_OK;
     };
+
+    // ---- a batch of mixed geometries: every chunk is sorted by (tl, ql) here, on the host, while the GPU works on the
+    // chunk before it -- a counting sort over the (tl, ql) grid of the batch, full blocks of eight pairs of one geometry
+    // first (packed kernel), the left-over pairs behind them (int32 kernel); run_device decides whether it applies
+    const int64_t range_t = hi_t - lo_t + 1, range_q = hi_q - lo_q + 1;
+    static const bool auto_group_on = [] { const char *e = getenv("MGL_SW_AUTO_GROUP"); return !e || atoi(e) != 0; }();
+    std::vector<int32_t> grid_pos, grid_nfull, grid_full, grid_rest;
+    std::future<int64_t> next_job;   // the sort of the NEXT chunk runs on a helper thread while this thread is inside the
+    int64_t next_first = -1;         // (blocking) pageable copies of the current one
+    if (uniform == GEOM_MIXED && auto_group_on && n >= 1024 && range_t * range_q <= (1ll << 20)) {
+        const size_t cells_n = (size_t)(range_t * range_q);
+        grid_pos.resize(cells_n);
+        grid_nfull.resize(cells_n);
+        grid_full.resize(cells_n);
+        grid_rest.resize(cells_n);
+        // slot arrays of a chunk in pinned memory: int64 t_start | int64 q_start | int64 dest | int32 t_len | int32 q_len
+        auto build = [&, cells_n](int64_t first, int64_t count, int h) -> int64_t {
+            if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+            if (hipEventSynchronize(ctx->grp_copied[h]) != hipSuccess) return -1; // the copy of chunk k-2 has left the pinned buffer
+            int64_t *ts_ = static_cast<int64_t *>(ctx->pin_grp[h]), *qs_ = ts_ + count, *dest_ = qs_ + count;
+            int32_t *tl_ = reinterpret_cast<int32_t *>(dest_ + count), *ql_ = tl_ + count;
+            auto cell = [&](int64_t k) { return (size_t)((t_off[k + 1] - t_off[k] - lo_t) * range_q + (q_off[k + 1] - q_off[k] - lo_q)); };
+            // counting sort over the (tl, ql) grid: a cell's first (count & ~7) pairs are its full blocks of eight (grouped part,
+            // cells in grid order), the others its left-over pairs (behind all the full blocks, in grid order too)
+            std::fill(grid_pos.begin(), grid_pos.end(), 0);
+            for (int64_t k = first; k < first + count; ++k) ++grid_pos[cell(k)];
+            int64_t full_total = 0, rest_total = 0;
+            for (size_t c = 0; c < cells_n; ++c) {
+                grid_nfull[c] = grid_pos[c] & ~7;
+                grid_full[c] = (int32_t)full_total;
+                full_total += grid_nfull[c];
+            }
+            for (size_t c = 0; c < cells_n; ++c) {
+                grid_rest[c] = (int32_t)(full_total + rest_total);
+                rest_total += grid_pos[c] & 7;
+                grid_pos[c] = 0;
+            }
+            for (int64_t k = first; k < first + count; ++k) {
+                const size_t c = cell(k);
+                const int32_t p = grid_pos[c]++;
+                const int64_t slot = p < grid_nfull[c] ? (int64_t)grid_full[c] + p : (int64_t)grid_rest[c] + (p - grid_nfull[c]);
+                ts_[slot] = t_off[k];
+                qs_[slot] = q_off[k];
+                dest_[slot] = k;
+                tl_[slot] = (int32_t)(t_off[k + 1] - t_off[k]);
+                ql_[slot] = (int32_t)(q_off[k + 1] - q_off[k]);
+            }
+            return full_total;
+        };
+        hooks.regroup = [&, build](int64_t first, int64_t count, int h, hipStream_t fill_stream, Regroup *out) -> int {
+            const size_t bytes = (size_t)count * 32;
+            for (int hh = 0; hh < 2; ++hh) { // both halves sized for the first (= largest) chunk, events made, before any helper runs
+                if (!ctx->grp_copied[hh]) {
+                    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->grp_copied[hh], hipEventDisableTiming));
+                    HIP_TRY(ctx, hipEventRecord(ctx->grp_copied[hh], ctx->h2d));
+                }
+                if (bytes > ctx->pin_grp_cap[hh]) {
+                    if (next_job.valid()) next_job.wait();
+                    HIP_TRY(ctx, hipEventSynchronize(ctx->grp_copied[hh]));
+                    if (ctx->pin_grp[hh]) (void)hipHostFree(ctx->pin_grp[hh]);
+                    ctx->pin_grp[hh] = nullptr;
+                    ctx->pin_grp_cap[hh] = 0;
+                    HIP_TRY(ctx, hipHostMalloc(&ctx->pin_grp[hh], bytes, hipHostMallocDefault));
+                    ctx->pin_grp_cap[hh] = bytes;
+                }
+                HIP_TRY(ctx, ctx->d_grp[hh].reserve(bytes));
+            }
+            int64_t ng;
+            if (next_job.valid() && next_first == first) {
+                ng = next_job.get();
+            } else {
+                if (next_job.valid()) next_job.wait();
+                ng = build(first, count, h);
+            }
+            if (ng < 0) return fail(ctx, MGL_SW_ERR_DEVICE, "mgl_sw_align_batch: sorting a chunk by geometry failed");
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_grp[h].p, ctx->pin_grp[h], bytes, hipMemcpyHostToDevice, ctx->h2d));
+            HIP_TRY(ctx, hipEventRecord(ctx->grp_copied[h], ctx->h2d));
+            HIP_TRY(ctx, hipStreamWaitEvent(fill_stream, ctx->grp_copied[h], 0));
+            // the next chunk (the other half's buffers) is sorted while this thread copies and launches
+            next_first = first + count;
+            if (next_first < n) next_job = std::async(std::launch::async, build, next_first, std::min(count, n - next_first), h ^ 1);
+            const int64_t *d = static_cast<const int64_t *>(ctx->d_grp[h].p);
+            out->d_t_start = d;
+            out->d_q_start = d + count;
+            out->d_dest = d + 2 * count;
+            out->d_t_len = reinterpret_cast<const int32_t *>(d + 3 * count);
+            out->d_q_len = out->d_t_len + count;
+            out->n_grouped = ng;
+            return MGL_SW_OK;
+        };
+    }
 
     const SeqSet ts{static_cast<const uint8_t *>(ctx->d_t.p), static_cast<const int64_t *>(ctx->d_toff.p), nullptr, max_tl, 0},
         qs{static_cast<const uint8_t *>(ctx->d_q.p), static_cast<const int64_t *>(ctx->d_qoff.p), nullptr, max_ql, 0};

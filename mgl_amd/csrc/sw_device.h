@@ -85,7 +85,8 @@ struct TbArgs {
     int32_t *cigar_len; // optional
     int32_t *status;    // optional
     int32_t *status_any; // optional: max of all non-zero statuses of the call
-};
+    const int64_t *dest; // optional: output index of input pair p (results of pair p go to offset[dest[p]], cigar slot dest[p], ...);
+};                       // null: p itself.  (Batches the host layer has reordered by geometry hand results back in the caller's order.)
 
 // geometry helpers (host and device agree on these); rows = target rows per stripe = lanes per pair (16 or 64)
 __host__ __device__ inline int sps_for_rows(int ql, int rows) { return (ql + rows + 3) & ~3; }

@@ -456,11 +456,12 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
     const DpRecord r = a.rec[slot];
     if (r.sps < 0) {
         // the fill kernel gave up on this pair (sw_dp_coop_kernel: a bounded wait ran out)
-        a.offset[p] = 0;
-        if (a.cigar_len) a.cigar_len[p] = 0;
-        if (a.status) a.status[p] = ERR_DEVICE;
+        const int64_t o = a.dest ? a.dest[p] : p;
+        a.offset[o] = 0;
+        if (a.cigar_len) a.cigar_len[o] = 0;
+        if (a.status) a.status[o] = ERR_DEVICE;
         if (a.status_any) atomicMax(a.status_any, ERR_DEVICE);
-        for (int k = 0; k < a.cigar_stride; ++k) a.cigar[(size_t)p * a.cigar_stride + k] = 0;
+        for (int k = 0; k < a.cigar_stride; ++k) a.cigar[(size_t)o * a.cigar_stride + k] = 0;
         return;
     }
 
@@ -567,14 +568,15 @@ __global__ __launch_bounds__(256) void sw_traceback_wave_kernel(const TbArgs a)
     const int tl = a.t.length(p);
     const int ql = a.q.length(p);
     const DpRecord r = a.rec[slot];
-    char *const slot_out = a.cigar + (size_t)p * a.cigar_stride;
+    const int64_t o = a.dest ? a.dest[p] : p;
+    char *const slot_out = a.cigar + (size_t)o * a.cigar_stride;
     if (r.sps < 0) {
         // the fill kernel gave up on this pair (sw_dp_coop_kernel: a bounded wait ran out)
         for (int k = lane; k < a.cigar_stride; k += 64) slot_out[k] = 0;
         if (lane == 0) {
-            a.offset[p] = 0;
-            if (a.cigar_len) a.cigar_len[p] = 0;
-            if (a.status) a.status[p] = ERR_DEVICE;
+            a.offset[o] = 0;
+            if (a.cigar_len) a.cigar_len[o] = 0;
+            if (a.status) a.status[o] = ERR_DEVICE;
             if (a.status_any) atomicMax(a.status_any, ERR_DEVICE);
         }
         return;
@@ -611,9 +613,9 @@ __global__ __launch_bounds__(256) void sw_traceback_wave_kernel(const TbArgs a)
         for (int k = len + lane; k < a.cigar_stride; k += 64) slot_out[k] = 0;
     }
     if (lane == 0) {
-        a.offset[p] = off;
-        if (a.cigar_len) a.cigar_len[p] = cw.need;
-        if (a.status) a.status[p] = status;
+        a.offset[o] = off;
+        if (a.cigar_len) a.cigar_len[o] = cw.need;
+        if (a.status) a.status[o] = status;
         if (a.status_any && status != 0) atomicMax(a.status_any, status);
         if (a.score) {
             Score sc;
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(256) void sw_traceback_wave_kernel(const TbArgs a)
             sc.max_t = r.max_t;
             sc.max_q = r.max_q;
             sc.seg_length = r.seg;
-            a.score[p] = sc;
+            a.score[o] = sc;
         }
     }
 }
@@ -800,9 +802,10 @@ __global__ __launch_bounds__(256) void sw_scores_only_kernel(const TbArgs a)
     if (slot >= a.count) return;
     const int64_t p = a.first + slot;
     const DpRecord r = a.rec[slot];
-    a.offset[p] = 0;
-    if (a.cigar_len) a.cigar_len[p] = 0;
-    if (a.status) a.status[p] = 0;
+    const int64_t o = a.dest ? a.dest[p] : p;
+    a.offset[o] = 0;
+    if (a.cigar_len) a.cigar_len[o] = 0;
+    if (a.status) a.status[o] = 0;
     if (a.score) {
         Score sc;
         sc.mqe = r.mqe;
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(256) void sw_scores_only_kernel(const TbArgs a)
         sc.max_t = r.max_t;
         sc.max_q = r.max_q;
         sc.seg_length = r.seg;
-        a.score[p] = sc;
+        a.score[o] = sc;
     }
 }
 

@@ -265,7 +265,8 @@ __device__ __forceinline__ void traceback_one_pair(const TbArgs &a, const TbView
     BitsMoves mv;
     mv.tb = view;
     CigarWriter cw;
-    cw.slot = a.cigar + (size_t)p * a.cigar_stride;
+    const int64_t o = a.dest ? a.dest[p] : p; // where this pair's results go
+    cw.slot = a.cigar + (size_t)o * a.cigar_stride;
     cw.binary = a.binary_cigar;
     cw.cap = a.binary_cigar ? (a.cigar_stride & ~3) : a.cigar_stride;
     cw.pos = cw.cap;
@@ -275,9 +276,9 @@ __device__ __forceinline__ void traceback_one_pair(const TbArgs &a, const TbView
     const int status = finish_cigar(cw);
     for (int k = cw.cap; k < a.cigar_stride; ++k) cw.slot[k] = 0;
 
-    a.offset[p] = off;
-    if (a.cigar_len) a.cigar_len[p] = cw.need;
-    if (a.status) a.status[p] = status;
+    a.offset[o] = off;
+    if (a.cigar_len) a.cigar_len[o] = cw.need;
+    if (a.status) a.status[o] = status;
     if (a.status_any && status != 0) atomicMax(a.status_any, status);
     if (a.score) {
         Score sc;
@@ -287,7 +288,7 @@ __device__ __forceinline__ void traceback_one_pair(const TbArgs &a, const TbView
         sc.max_t = r.max_t;
         sc.max_q = r.max_q;
         sc.seg_length = r.seg;
-        a.score[p] = sc;
+        a.score[o] = sc;
     }
 }
 

@@ -17,7 +17,7 @@ ql = torch.randint(lo, 151, (n,), generator=g, device=dev, dtype=torch.int32)
 tl = torch.full((n,), 256, dtype=torch.int32, device=dev)
 t_start, q_start = b.t_off[:-1].contiguous(), b.q_off[:-1].contiguous()
 a = MicrosoftSmithWaterman(0)
-a.set_workspace(8 << 30)
+a.set_workspace(int(os.environ.get("WS_GIB", "8")) << 30)
 cells = int((ql.to(torch.int64) * 256).sum())
 
 def timed(run, label):
@@ -48,3 +48,31 @@ ref = (gb.offsets.clone(), gb.scores.clone(), gb.cigars.clone())
 timed(run_mixed, "same pairs, no promise (int32 kernel)")
 assert torch.equal(ref[0], gb.offsets) and torch.equal(ref[1], gb.scores) and torch.equal(ref[2], gb.cigars)
 print("identical results")
+
+# the same reads as a HOST batch of mixed lengths with no flag and no sorting by the caller: mgl_sw_align_batch sorts every
+# chunk by geometry itself (PCIe inclusive: pageable host memory in, every result back on the host)
+import numpy as np
+ql_h = ql.cpu().numpy().astype(np.int64)
+reads = b.queries.view(n, 150).cpu().numpy()
+keep = np.arange(150)[None, :] < ql_h[:, None]
+qd = reads[keep]                                   # ragged reads, concatenated
+qoff = np.concatenate([[0], np.cumsum(ql_h)]).astype(np.int64)
+td = b.targets.cpu().numpy()
+toff = b.t_off.cpu().numpy()
+off = np.zeros(n, np.int32); sc = np.zeros((n, 6), np.int32); cg = np.zeros(n * 64, np.uint8); ln = np.zeros(n, np.int32)
+L = _lib.lib()
+for env, label in (("1", "host batch of mixed lengths, sorted per chunk by the library"), ("0", "same, MGL_SW_AUTO_GROUP=0 (int32 kernel)")):
+    if env == "0":
+        break  # (the switch is read once per process: run the script again with MGL_SW_AUTO_GROUP=0 for the other line)
+    for rep in range(3):
+        t0 = time.perf_counter()
+        rc = L.mgl_sw_align_batch(a.ctx, n, td.ctypes.data, toff.ctypes.data, qd.ctypes.data, qoff.ctypes.data, 200, -150, 260, 11, 1,
+                                  off.ctypes.data, sc.ctypes.data, cg.ctypes.data, 64, ln.ctypes.data)
+        dt = time.perf_counter() - t0
+        assert rc == 0
+    print(f"{label} (MGL_SW_AUTO_GROUP={os.environ.get('MGL_SW_AUTO_GROUP', '1')}): {dt*1e3:.1f} ms = {cells/dt/1e9:.1f} GCUPS, "
+          f"{n/dt/1e6:.2f} M reads/s (packed16={a.timing().packed16})", flush=True)
+# same answers as the device-resident grouped run (caller order)
+g_off, g_sc = gb.gather()[0].cpu().numpy(), gb.gather()[1].cpu().numpy()
+assert (g_off == off).all() and (g_sc == sc).all()
+print("host batch identical to the grouped device batch")

@@ -419,6 +419,47 @@ def test_grouped_geometry_traceback_regions_do_not_overlap(aligner):
             assert (res.offsets == off).all() and (res.scores == sc).all() and list(res.cigars) == cg
 
 
+def test_host_entry_sorts_mixed_batches_by_geometry_itself():
+    """The reference takes any pair (sw_avx.cpp:6-108): a host batch of variable-length reads, unsorted and unflagged, must
+    reach the packed kernel without the caller's help.  mgl_sw_align_batch sorts every chunk by (tl, ql) on the host, runs
+    full blocks of eight through the packed kernel and the left-over pairs through the int32 kernel, and hands the
+    results back in the caller's order -- identical to the oracle and to the int32-only run; several chunks; real reads."""
+    from mgl_amd import synth
+
+    rng = synth.rng_for(5)
+    n = 30000
+    genome = synth.random_genome(rng, 1 << 16)
+    tl = rng.choice([200, 256], size=n)
+    ql = rng.integers(100, 151, size=n)
+    ql[::211] = rng.integers(1, 30, size=len(ql[::211]))          # a sprinkling of odd geometries (left-over pairs)
+    ts = rng.integers(0, len(genome) - 300, size=n)
+    reads = synth.illumina_reads(rng, genome, ts + rng.integers(0, 40, size=n), 150)
+    tseqs = [genome[ts[k]:ts[k] + tl[k]].tobytes() for k in range(n)]
+    qseqs = [reads[k, :ql[k]].tobytes() for k in range(n)]
+    a = sw.MicrosoftSmithWaterman(0)
+    a.set_workspace(200 << 20)                                      # ~9 000 pairs per chunk: four chunks, both halves reused
+    for strategy in (ol.SOFTCLIP, ol.LEAD_INDEL):
+        res = a.align_batch(tseqs, qseqs, (200, -150, 260, 11), strategy, cigar_stride=128)
+        tm = a.timing()
+        assert tm.packed16 == 1 and tm.fill_kernel == 1 and tm.dp_launches >= 3, "a mixed host batch should be sorted onto the packed kernel"
+        woff, wsc, wcg = ol.oracle_align_batch(tseqs, qseqs, (200, -150, 260, 11), strategy, nthreads=8)
+        assert (res.offsets == woff).all() and (res.scores == wsc).all() and list(res.cigars) == wcg
+    a.set_precision(32)                                             # no packed kernel: nothing to sort for
+    res32 = a.align_batch(tseqs, qseqs, (200, -150, 260, 11), ol.LEAD_INDEL, cigar_stride=128)
+    assert a.timing().packed16 == 0
+    assert (res32.offsets == res.offsets).all() and (res32.scores == res.scores).all() and list(res32.cigars) == list(res.cigars)
+    a.close()
+    # real Illumina reads against their exact reference spans (variable tl): the golden records of the reference's BAM resource
+    rows = [g for g in golden_io.load("bam") if g.suite != "bamwin" and g.strategy == ol.SOFTCLIP]
+    assert len(rows) > 1024 and len({(len(g.t), len(g.q)) for g in rows}) > 10
+    b = sw.MicrosoftSmithWaterman(0)
+    res = b.align_batch([g.t for g in rows], [g.q for g in rows], rows[0].params, ol.SOFTCLIP)
+    assert b.timing().packed16 == 1
+    for k, g in enumerate(rows):
+        assert (int(res.offsets[k]), res.cigars[k], tuple(int(x) for x in res.scores[k])) == (g.offset, g.cigar, g.score)
+    b.close()
+
+
 def test_grouping_helper_feeds_the_indexed_entry(aligner):
     """What a C caller does with variable-length reads: mgl_sw_group_by_geometry on the host, then the grouped part through
     mgl_sw_align_batch_device_indexed with MGL_SW_FLAG_GROUPED_GEOMETRY (packed kernel) and the rest without the flag."""
