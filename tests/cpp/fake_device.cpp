@@ -1,0 +1,110 @@
+// fake_device.cpp -- stands where the HIP kernels stand when the library's HOST side is built against the fake runtime
+// (tests/cpp/fake_hip/) for the CPU sanitizer runs.  TEST CODE, never shipped.  The fill launches do nothing; whatever
+// would walk the paths (the traceback launch, or the lane kernel's fused walk) computes each pair with the CPU checker
+// (oracle/sw_oracle.c) and writes the results exactly where the kernels write them -- slot, stride, dest map, per-pair
+// status -- so the driver can tell whether the host layer chunked, sorted, sharded and scattered correctly.
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../mgl_amd/csrc/sw_device.h"
+#include "../../oracle/sw_oracle.h"
+
+int fake_hip_device_count(void)
+{
+    static const int n = [] { const char *e = getenv("FAKE_HIP_DEVICES"); return e ? atoi(e) : 2; }();
+    return n;
+}
+
+namespace mgl_sw_dev {
+
+std::atomic<long long> fake_fill_launches{0}, fake_walk_pairs{0}, fake_packed_pairs{0};
+static thread_local int g_match, g_mismatch, g_gopen, g_gext; // parameters of the fill launch(es) of the chunk being walked
+
+static void remember(const DpArgs &a)
+{
+    g_match = a.match;
+    g_mismatch = a.mismatch;
+    g_gopen = a.gopen;
+    g_gext = a.gext;
+    ++fake_fill_launches;
+}
+
+static void walk(const TbArgs &a, bool scores_only)
+{
+    for (int64_t slot = 0; slot < a.count; ++slot) {
+        const int64_t p = a.first + slot;
+        const int tl = a.t.length(p), ql = a.q.length(p);
+        const uint8_t *t = a.t.data + a.t.off[p], *q = a.q.data + a.q.off[p];
+        const int64_t o = a.dest ? a.dest[p] : p;
+        std::vector<char> text((size_t)(tl + ql + 4) * 12);
+        int len = 0, off = 0;
+        swo_score ez;
+        const int rc = swo_align(t, tl, q, ql, g_match, g_mismatch, g_gopen, g_gext, a.strategy, text.data(), (int)text.size(), &len, &off, &ez, nullptr);
+        if (rc != SWO_OK) abort();
+        char *slot_out = a.cigar + (size_t)o * a.cigar_stride;
+        int status = 0;
+        if (ql >= 8 && memcmp(q, "NNNNNNNN", 8) == 0) { // fault injection: this pair's walk "fails on the device" (what the
+            memset(slot_out, 0, (size_t)a.cigar_stride);  // traceback kernel reports when a fill kernel gave a pair up)
+            status = ERR_DEVICE;
+            len = 0;
+        } else if (scores_only) {
+            off = 0;
+            len = 0;
+        } else if (a.binary_cigar) {
+            abort(); // not exercised by the host-sanitizer driver
+        } else if (len > a.cigar_stride) {
+            memset(slot_out, 0, (size_t)a.cigar_stride);
+            status = ERR_CIGAR_OVERFLOW;
+        } else {
+            memcpy(slot_out, text.data(), (size_t)len);
+            memset(slot_out + len, 0, (size_t)(a.cigar_stride - len));
+        }
+        a.offset[o] = status ? 0 : off;
+        if (a.cigar_len) a.cigar_len[o] = len;
+        if (a.status) a.status[o] = status;
+        if (a.status_any && status) *a.status_any = *a.status_any > status ? *a.status_any : status;
+        if (a.score) {
+            Score sc{ez.mqe, ez.mqe_t, ez.max, ez.max_t, ez.max_q, ez.seg_length};
+            a.score[o] = sc;
+        }
+        ++fake_walk_pairs;
+        if (a.packed16) ++fake_packed_pairs;
+    }
+}
+
+int64_t dp_group_bytes(int sps_cap, int rows) { return (int64_t)dp_ring_entries(sps_cap, rows) * 8 + 4ll * dp_qcopy_bytes(sps_cap, rows); }
+int dp_lds_bytes(int sps_cap, int waves_per_block, int rows)
+{
+    const int64_t b = waves_per_block * (64 / rows) * dp_group_bytes(sps_cap, rows);
+    return b > (1 << 30) ? (1 << 30) : (int)b;
+}
+int dp16_lds_bytes(int sps, int waves_per_block) { return waves_per_block * 4 * ((sps + 24) * 8 + (sps + 48) * 4); }
+bool dp16_range_ok(int tl, int ql, int match, int mismatch, int gopen, int gext, int)
+{
+    if (match <= 0 || gopen < gext) return false;
+    const int64_t top = (int64_t)match * (tl < ql ? tl : ql) + (int64_t)gext * ((int64_t)tl + ql);
+    const int64_t low = -3 * (int64_t)gopen - ((int64_t)match - mismatch) - 2 * (int64_t)gext - 64;
+    return 32767 - top + low >= -32768 && (int64_t)match - mismatch <= 30000 && gopen <= 10000 && gext <= 5000;
+}
+int coop_lds_bytes(int sps_cap, int waves_per_block) { return coop_query_bytes(sps_cap) + waves_per_block * 2048 + 1024; }
+bool lane16_supported(const SeqSet &t, const SeqSet &q) { return !t.packed2 && !q.packed2; }
+
+hipError_t launch_dp16(const DpArgs &a, int, hipStream_t) { remember(a); return hipSuccess; }
+hipError_t launch_dp(const DpArgs &a, int, int, hipStream_t) { remember(a); return hipSuccess; }
+hipError_t launch_dp_coop(const DpArgs &a, int, hipStream_t) { remember(a); return hipSuccess; }
+hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &w, int, hipStream_t)
+{
+    remember(a);
+    if (w.cigar) walk(w, false);
+    return hipSuccess;
+}
+hipError_t launch_traceback(const TbArgs &a, hipStream_t) { walk(a, false); return hipSuccess; }
+hipError_t launch_scores_only(const TbArgs &a, hipStream_t) { walk(a, true); return hipSuccess; }
+hipError_t launch_cigar_from_matrix(const int32_t *, int, int, int, const Score &, char *, int, int32_t *, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t launch_expand(const uint32_t *, const DpRecord *, int, int, int, int, int, int32_t *, hipStream_t, int) { return hipErrorInvalidValue; }
+hipError_t launch_band_fill(const int32_t *, const int32_t *, int, int32_t *, int, int, int, int32_t *, int32_t *, int32_t *, int, int, int, int, int,
+                            int32_t *, hipStream_t) { return hipErrorInvalidValue; }
+
+} // namespace mgl_sw_dev

@@ -1,0 +1,208 @@
+// host_san_driver.cpp -- drives the HOST side of the library (built against the fake HIP runtime and the fake device
+// backend of this directory) under AddressSanitizer + UBSan, and again under ThreadSanitizer.  TEST CODE.
+//   * mgl_sw_align_batch_status on a batch of mixed geometries cut into several chunks: the per-chunk sort by geometry on
+//     its helper thread, both workspace halves reused, results scattered back through the dest map, per-pair overflow status
+//   * a uniform batch through the lane-kernel path (fused walk, one buffer) and through the packed path
+//   * mgl_sw_align_batch_multi over two (fake) devices: shard boundaries, one host thread per device
+//   * 48 threads through mgl_sw_align (the coalescing front-end): parking, batching, wake-up by shard, the caller whose
+//     buffer is too small (CIGAR_OVERFLOW) and the pair whose walk fails on the "device" (status handed back verbatim)
+// Every answer is compared with the CPU checker called directly.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mgl_sw.h"
+#include "../../oracle/sw_oracle.h"
+
+namespace mgl_sw_dev {
+extern std::atomic<long long> fake_fill_launches, fake_walk_pairs, fake_packed_pairs;
+}
+
+#define CHECK(x)                                                          \
+    do {                                                                  \
+        if (!(x)) {                                                       \
+            std::fprintf(stderr, "host-san: %s:%d: %s\n", __FILE__, __LINE__, #x); \
+            std::exit(1);                                                 \
+        }                                                                 \
+    } while (0)
+
+struct Batch {
+    std::vector<uint8_t> t, q;
+    std::vector<int64_t> toff{0}, qoff{0};
+    int64_t n() const { return (int64_t)toff.size() - 1; }
+    void add(const std::string &a, const std::string &b)
+    {
+        t.insert(t.end(), a.begin(), a.end());
+        q.insert(q.end(), b.begin(), b.end());
+        toff.push_back((int64_t)t.size());
+        qoff.push_back((int64_t)q.size());
+    }
+};
+
+static std::string rnd(std::mt19937 &g, int n)
+{
+    std::string s((size_t)n, 'A');
+    for (char &c : s) c = "ACGT"[g() & 3];
+    return s;
+}
+
+struct Expect {
+    std::vector<int32_t> off, len;
+    std::vector<swo_score> sc;
+    std::vector<std::string> cg;
+};
+
+static Expect expect(const Batch &b, int strategy)
+{
+    Expect e;
+    for (int64_t k = 0; k < b.n(); ++k) {
+        const int tl = (int)(b.toff[k + 1] - b.toff[k]), ql = (int)(b.qoff[k + 1] - b.qoff[k]);
+        std::vector<char> buf((size_t)(tl + ql + 4) * 12);
+        int len = 0, off = 0;
+        swo_score ez;
+        CHECK(swo_align(b.t.data() + b.toff[k], tl, b.q.data() + b.qoff[k], ql, 200, -150, 260, 11, strategy, buf.data(), (int)buf.size(), &len, &off, &ez, nullptr) == 0);
+        e.off.push_back(off);
+        e.len.push_back(len);
+        e.sc.push_back(ez);
+        e.cg.emplace_back(buf.data(), (size_t)len);
+    }
+    return e;
+}
+
+static void compare(const Batch &b, const Expect &e, const std::vector<int32_t> &off, const std::vector<mgl_sw_score> &sc, const std::vector<char> &cg,
+                    int stride, const std::vector<int32_t> &len, const std::vector<int32_t> *status)
+{
+    for (int64_t k = 0; k < b.n(); ++k) {
+        if (status && (*status)[(size_t)k] != 0) {
+            CHECK((*status)[(size_t)k] == MGL_SW_ERR_CIGAR_OVERFLOW && e.len[(size_t)k] > stride && len[(size_t)k] == e.len[(size_t)k]);
+            continue;
+        }
+        CHECK(off[(size_t)k] == e.off[(size_t)k] && len[(size_t)k] == e.len[(size_t)k]);
+        CHECK(memcmp(&sc[(size_t)k], &e.sc[(size_t)k], sizeof(mgl_sw_score)) == 0);
+        CHECK(std::string(cg.data() + (size_t)k * stride, (size_t)len[(size_t)k]) == e.cg[(size_t)k]);
+        for (int x = len[(size_t)k]; x < stride; ++x) CHECK(cg[(size_t)k * stride + x] == 0);
+    }
+}
+
+int main()
+{
+    std::mt19937 g(12345);
+    // ---- a batch of mixed geometries: windows of two sizes, reads of 100 .. 150 bases, a sprinkling of odd ones
+    Batch mixed;
+    for (int k = 0; k < 6000; ++k) {
+        const int tl = (g() & 1) ? 200 : 256, ql = (k % 97 == 0) ? 1 + (int)(g() % 40) : 100 + (int)(g() % 51);
+        std::string t = rnd(g, tl), q = t.substr(g() % 40, (size_t)ql);
+        q.resize((size_t)ql, 'C');
+        q[g() % q.size()] = "ACGT"[g() & 3];
+        mixed.add(t, q);
+    }
+    const Expect em = expect(mixed, MGL_SW_OS_SOFTCLIP);
+    mgl_sw_ctx *ctx = nullptr;
+    CHECK(mgl_sw_ctx_create(0, &ctx) == 0);
+    for (int stride : {128, 4}) {
+        CHECK(mgl_sw_ctx_set_workspace(ctx, 96ll << 20) == 0); // ~2 200 pairs per half: three chunks, the halves are reused
+        const int64_t n = mixed.n();
+        std::vector<int32_t> off((size_t)n), len((size_t)n), st((size_t)n);
+        std::vector<mgl_sw_score> sc((size_t)n);
+        std::vector<char> cg((size_t)n * stride, 1);
+        const long long packed0 = mgl_sw_dev::fake_packed_pairs.load();
+        CHECK(mgl_sw_align_batch_status(ctx, n, mixed.t.data(), mixed.toff.data(), mixed.q.data(), mixed.qoff.data(), 200, -150, 260, 11,
+                                        MGL_SW_OS_SOFTCLIP, off.data(), sc.data(), cg.data(), stride, len.data(), st.data()) == 0);
+        compare(mixed, em, off, sc, cg, stride, len, &st);
+        CHECK(mgl_sw_dev::fake_packed_pairs.load() - packed0 > n * 8 / 10); // most pairs reached the packed kernel's part
+        mgl_sw_timing tm;
+        CHECK(mgl_sw_ctx_get_timing(ctx, &tm) == 0 && tm.dp_launches >= 3 && tm.packed16 == 1);
+        if (stride == 4) { // without the status array the same batch fails as a whole
+            const int rc2 = mgl_sw_align_batch(ctx, n, mixed.t.data(), mixed.toff.data(), mixed.q.data(), mixed.qoff.data(), 200, -150, 260, 11,
+                                               MGL_SW_OS_SOFTCLIP, off.data(), sc.data(), cg.data(), stride, len.data());
+            if (rc2 != MGL_SW_ERR_CIGAR_OVERFLOW) std::fprintf(stderr, "rc2 = %d (%s)\n", rc2, mgl_sw_last_error(ctx));
+            CHECK(rc2 == MGL_SW_ERR_CIGAR_OVERFLOW);
+        }
+    }
+    // ---- a uniform batch: the lane-kernel path (forced; fused walk, one buffer, chunks of 128), then the packed path
+    Batch uni;
+    for (int k = 0; k < 3000; ++k) {
+        std::string t = rnd(g, 256), q = t.substr(g() % 100, 150);
+        q[g() % 150] = 'A';
+        uni.add(t, q);
+    }
+    const Expect eu = expect(uni, MGL_SW_OS_INDEL);
+    for (int lane_mode : {2, 1}) {
+        CHECK(mgl_sw_ctx_set_lane_kernel(ctx, lane_mode) == 0 && mgl_sw_ctx_set_workspace(ctx, 24ll << 20) == 0);
+        const int64_t n = uni.n();
+        std::vector<int32_t> off((size_t)n), len((size_t)n);
+        std::vector<mgl_sw_score> sc((size_t)n);
+        std::vector<char> cg((size_t)n * 64, 1);
+        CHECK(mgl_sw_align_batch(ctx, n, uni.t.data(), uni.toff.data(), uni.q.data(), uni.qoff.data(), 200, -150, 260, 11, MGL_SW_OS_INDEL, off.data(),
+                                 sc.data(), cg.data(), 64, len.data()) == 0);
+        compare(uni, eu, off, sc, cg, 64, len, nullptr);
+        mgl_sw_timing tm;
+        CHECK(mgl_sw_ctx_get_timing(ctx, &tm) == 0 && tm.fill_kernel == (lane_mode == 2 ? MGL_SW_KERNEL_LANE16 : MGL_SW_KERNEL_DP16));
+    }
+    mgl_sw_ctx_destroy(ctx);
+
+    // ---- several devices from one process
+    {
+        mgl_sw_multi *m = nullptr;
+        const int devs[3] = {0, 1, 0};
+        CHECK(mgl_sw_multi_create(3, devs, &m) == 0 && mgl_sw_multi_device_count(m) == 3);
+        CHECK(mgl_sw_multi_set_workspace(m, 64ll << 20) == 0);
+        const int64_t n = mixed.n();
+        std::vector<int32_t> off((size_t)n), len((size_t)n), st((size_t)n);
+        std::vector<mgl_sw_score> sc((size_t)n);
+        std::vector<char> cg((size_t)n * 128, 1);
+        CHECK(mgl_sw_align_batch_multi(m, n, mixed.t.data(), mixed.toff.data(), mixed.q.data(), mixed.qoff.data(), 200, -150, 260, 11, MGL_SW_OS_SOFTCLIP,
+                                       off.data(), sc.data(), cg.data(), 128, len.data(), st.data()) == 0);
+        compare(mixed, em, off, sc, cg, 128, len, &st);
+        int64_t first[4];
+        CHECK(mgl_sw_multi_last_shards(m, first) == 0 && first[0] == 0 && first[3] == n && first[1] % 8 == 0 && first[1] > n / 4 && first[2] > first[1]);
+        mgl_sw_multi_destroy(m);
+    }
+
+    // ---- 48 threads, one pair per call (the way GATK drives alignNative), through the coalescing front-end
+    {
+        CHECK(mgl_sw_set_coalescing(64, 200) == 0);
+        std::atomic<int> bad{0}, overflow_seen{0}, device_seen{0};
+        auto worker = [&](int id) {
+            std::mt19937 r((unsigned)id * 7919u + 1u);
+            for (int it = 0; it < 120; ++it) {
+                const int tl = 40 + (int)(r() % 200), ql = 8 + (int)(r() % 100);
+                std::string t = rnd(r, tl), q = rnd(r, ql);
+                const bool poison = id == 5 && it % 40 == 7; // the fake device fails this pair (see below)
+                if (poison) q.replace(0, 8, "NNNNNNNN");
+                const int cap = (id == 9 && it % 10 == 0) ? 2 : 4096;
+                std::vector<char> buf((size_t)cap), ref(4096);
+                int len = 0, off = 0, rlen = 0, roff = 0;
+                mgl_sw_score ez;
+                swo_score rz;
+                const int rc = mgl_sw_align(t.data(), tl, q.data(), ql, 200, -150, 260, 11, MGL_SW_OS_SOFTCLIP, buf.data(), cap, &len, &off, &ez);
+                CHECK(swo_align((const uint8_t *)t.data(), tl, (const uint8_t *)q.data(), ql, 200, -150, 260, 11, MGL_SW_OS_SOFTCLIP, ref.data(), 4096, &rlen,
+                                &roff, &rz, nullptr) == 0);
+                if (poison) { // a device-side failure of one pair reaches its caller as such, not as "CIGAR does not fit"
+                    if (rc != MGL_SW_ERR_DEVICE) ++bad;
+                    ++device_seen;
+                } else if (rc == MGL_SW_ERR_CIGAR_OVERFLOW && cap < rlen) {
+                    if (len != rlen) ++bad;
+                    ++overflow_seen;
+                } else if (rc != MGL_SW_OK || len != rlen || off != roff || memcmp(buf.data(), ref.data(), (size_t)rlen) != 0 ||
+                           memcmp(&ez, &rz, sizeof ez) != 0) {
+                    ++bad;
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int id = 0; id < 48; ++id) th.emplace_back(worker, id);
+        for (auto &x : th) x.join();
+        int64_t batches = 0, pairs = 0;
+        CHECK(mgl_sw_coalescing_stats(&batches, &pairs) == 0 && pairs == 48 * 120 && batches < pairs);
+        CHECK(bad.load() == 0 && overflow_seen.load() > 0 && device_seen.load() == 3);
+        CHECK(mgl_sw_set_coalescing(0, 0) == 0);
+    }
+    std::printf("host-san ok: %lld fill launches, %lld pairs walked\n", mgl_sw_dev::fake_fill_launches.load(), mgl_sw_dev::fake_walk_pairs.load());
+    return 0;
+}
