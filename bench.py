@@ -185,16 +185,25 @@ def secondary_workloads():
 
     out = {}
     runs = {
-        "long_reads_10kb (configs[3] shape, 256 pairs)": ["scripts/long_read_bench.py", "256", "32", "10000", "1"],
-        "pairhmm_150x300 (SURVEY 8f rank 3, 1.6 M pairs)": ["scripts/pairhmm_bench.py", "--steps", "3", "--cpu-seconds", "3"],
+        # "a seeded subset sized to >= 30 s of GPU time": 2 048 pairs of ~10 kb x ~10 kb per pass (97 GiB of
+        # traceback), passes repeated for 30 s; CPU baseline (the reference's align_avx) on 64 of the pairs
+        "long_reads_10kb (configs[3] shape, 2048 pairs per pass, >= 30 s)": ["scripts/long_read_bench.py", "2048", "220", "10000", "1", "--seconds", "30",
+                                                                             "--cpu-pairs", "64", "--json"],
+        "pairhmm_150x300 (SURVEY 8f rank 3, 1.6 M pairs)": ["scripts/pairhmm_bench.py", "--steps", "3", "--cpu-seconds", "3", "--json"],
         "protein_blosum62 (configs[4] shape, 2 M alignments, no reference path)": ["scripts/protein_bench.py", "--steps", "2", "--check", "50"],
     }
     for name, cmd in runs.items():
         try:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, cmd[0])] + cmd[1:], capture_output=True, text=True, timeout=240)
+            r = subprocess.run([sys.executable, os.path.join(ROOT, cmd[0])] + cmd[1:], capture_output=True, text=True, timeout=400)
             m = re.search(r"= ([0-9.]+) GCUPS", r.stdout)
             if r.returncode == 0 and m:
                 out[name] = {"gcups": float(m.group(1)), "checked": ("identical" in r.stdout) or None}
+                for ln in r.stdout.splitlines():   # the script's own JSON line (figures over the whole run + its roofline object)
+                    if ln.startswith("{"):
+                        out[name].update(json.loads(ln))
+                mm = re.search(r"mismatches vs GPU: (\d+)", r.stdout)
+                if mm:
+                    out[name]["cpu_mismatches_vs_gpu"] = int(mm.group(1))
                 d = re.search(r"max \|log10 difference\| vs GPU: ([0-9.e+-]+)", r.stdout)
                 c = re.search(r"CPU baseline[^:]*: .* = ([0-9.]+) GCUPS", r.stdout)
                 if d:

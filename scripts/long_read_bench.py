@@ -21,6 +21,7 @@ ap.add_argument("check", nargs="?", type=int, default=2, help="pairs compared wi
 ap.add_argument("--seconds", type=float, default=0, help="repeat the batch until this much GPU time has been spent")
 ap.add_argument("--cpu-pairs", type=int, default=0, help="time the reference's CPU path (oracle/_ref) on this many pairs")
 ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic pairs (the batch cycles through them)")
+ap.add_argument("--json", action="store_true", help="print one JSON line with the figures and a roofline object (bench.py reads it)")
 args = ap.parse_args()
 PARAMS = (200, -150, 260, 11)  # GATK_PARAMETERS after the sign normalisation of the JNI boundary
 n, length = args.pairs, args.length
@@ -51,6 +52,20 @@ print(f"{n} pairs of ~{length} x {length}, {reps} pass(es): {dt*1e3/reps:.1f} ms
       f"{dt:.1f} s (last pass: fill {tm.dp_ms:.1f} ms in {tm.dp_launches} launches, traceback {tm.tb_ms:.1f} ms, "
       f"traceback workspace {tm.tb_bytes/2**30:.1f} GiB)", flush=True)
 assert int((b.status != 0).sum()) == 0
+if args.json:
+    import json
+    # HBM roofline of the fill kernel (north_star's roofline; the kernel is VALU-issue bound): algorithmic bytes per pair =
+    # both sequences + offsets + the 4-bit-per-cell traceback spilled to HBM + the fill record
+    alg = sum(len(ts[k]) + len(qs[k]) + 16 + len(ts[k]) * len(qs[k]) // 2 + 32 for k in range(n))
+    fill_s = tm.dp_ms / 1e3
+    print(json.dumps({"gcups": round(cells * reps / dt / 1e9, 1), "pairs": n, "length": length, "passes": reps, "seconds": round(dt, 1),
+                      "ms_per_pass": round(dt * 1e3 / reps, 2),
+                      "kernel_ms": {a.fill_kernel_name(tm): round(tm.dp_ms, 2), "sw_traceback_wave_kernel": round(tm.tb_ms, 2), "launches": tm.dp_launches},
+                      "roofline": {"bound": "hbm", "kernel": a.fill_kernel_name(tm), "achieved": round(alg / fill_s / 1e9, 1), "peak": 8000.0,
+                                   "unit": "GB/s", "frac": round(alg / fill_s / 1e9 / 8000.0, 4), "traffic": None,
+                                   "algorithmic_bytes_per_pass": alg, "kernel_gcups": round(cells / fill_s / 1e9, 1),
+                                   "note": "int32 wavefront, VALU-issue bound (26 instructions per 64-cell step); traffic: no PMC pass at this size"}}),
+          flush=True)
 import oracle_lib as ol
 if args.check:
     idx = list(range(min(args.check, len(base))))

@@ -23,6 +23,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--double", action="store_true")
 ap.add_argument("--cpu-seconds", type=float, default=10.0)
 ap.add_argument("--no-cpu", action="store_true")
+ap.add_argument("--json", action="store_true", help="print one JSON line with the figures and a roofline object (bench.py reads it)")
 args = ap.parse_args()
 
 rng = np.random.default_rng(42)
@@ -75,6 +76,20 @@ tm = hmm.timing()
 print(f"PairHMM {'double' if args.double else 'float + double rescue'}: {n_pairs} pairs ({G} regions x {NR} reads x {NH} haplotypes, "
       f"{RL} x ~{HL}), {dt*1e3:.2f} ms per pass = {cells/dt/1e9:.1f} GCUPS, {n_pairs/dt/1e6:.2f} M pairs/s "
       f"(float kernel {tm.float_ms:.2f} ms, double kernel {tm.double_ms:.2f} ms, rescued {int(used.sum())})", flush=True)
+if args.json:
+    import json
+    # fp32 vector roofline: 13 flops per cell of the recurrence (compute_prob_scalar.cc:39-43: M 5, X 3, Y 3, sum 2) against
+    # the 157.3 TFLOP/s fp32 VALU peak (MI355X_MICROARCH.md); HBM bytes per pair for comparison: the read's five tracks and
+    # the haplotype (both shared by many pairs: an upper bound), two int32 indices, the float64 result, the int32 flag
+    k_s = (tm.float_ms + tm.double_ms) / 1e3
+    hbm = int((5 * RL + (hap_off[ph + 1] - hap_off[ph]) + 8 + 8 + 4).sum())
+    print(json.dumps({"gcups": round(cells / dt / 1e9, 1), "pairs": int(n_pairs), "pairs_per_s": round(n_pairs / dt, 1), "ms_per_pass": round(dt * 1e3, 3),
+                      "kernel_ms": {"float": round(tm.float_ms, 3), "double_rescue": round(tm.double_ms, 3)},
+                      "roofline": {"bound": "valu_fp32", "achieved": round(13 * cells / k_s / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
+                                   "frac": round(13 * cells / k_s / 1e12 / 157.3, 4), "flops_per_cell": 13,
+                                   "hbm": {"algorithmic_bytes_per_pass_upper_bound": hbm, "achieved_gb_s": round(hbm / k_s / 1e9, 1), "frac_of_8_tb_s": round(hbm / k_s / 8e12, 4)},
+                                   "note": "shuffle- and issue-bound wavefront (14.3 VALU instructions per cell, no MFMA shape); inputs resident"}}),
+          flush=True)
 if not args.no_cpu:
     import pairhmm_oracle_lib as pol
     from bench import host_cores

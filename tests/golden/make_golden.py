@@ -195,6 +195,35 @@ def suite_long():
     return rows
 
 
+def suite_long2():
+    """Ten more long pairs (ONT-style 5 % substitutions / insertions / deletions), CIGARs hashed: every overhang strategy at
+    10 kb x 10 kb, unequal lengths either way, target lengths that are not multiples of 64 (the long-read kernel's stripe
+    height) or 32, a second parameter set, and one pair beyond 30 kb."""
+    rng = synth.rng_for(11)
+    rows = []
+
+    def pair(tl, ql):
+        # a noisy copy of the target's middle, cut or padded with random flanks to the lengths asked for
+        t, q = synth.ont_pair(rng, max(tl, ql) + 64, 0.05, 0.05, 0.05)
+        t = t[:tl]
+        if len(q) >= ql:
+            a = (len(q) - ql) // 2
+            q = q[a:a + ql]
+        else:
+            q = np.concatenate([q, synth.random_genome(rng, ql - len(q))])
+        return t.tobytes(), q.tobytes()
+
+    t, q = pair(10000, 10000)
+    for s in (ol.INDEL, ol.LEAD_INDEL, ol.IGNORE):
+        rows.append(record("long2", t, q, GATK, s, hash_cigar=True))
+    for tl, ql, params, s in ((12000, 7000, GATK, ol.SOFTCLIP), (6500, 9000, GATK, ol.INDEL), (10007, 10000, GATK, ol.SOFTCLIP),
+                              (5000, 11000, GATK, ol.IGNORE), (8001, 8100, (5, -4, 10, 1), ol.LEAD_INDEL),
+                              (9999, 4097, (25, -50, 110, 6), ol.SOFTCLIP), (31000, 30500, GATK, ol.SOFTCLIP)):
+        t, q = pair(tl, ql)
+        rows.append(record("long2", t, q, params, s, hash_cigar=True))
+    return rows
+
+
 def suite_bam():
     # real Illumina reads: the reference repo's own test resource (src/test/resources/HiSeq.1mb.1RG.2k_lines.bam,
     # kept here as a data fixture); target = the reference bases under the read rebuilt from CIGAR + MD
@@ -212,7 +241,7 @@ def suite_bam():
 
 
 SUITE_FUNCS = {"known": suite_known, "tiny": suite_tiny, "random": suite_random, "ties": suite_ties,
-               "shapes": suite_shapes, "config1": suite_config1, "window": suite_window, "long": suite_long,
+               "shapes": suite_shapes, "config1": suite_config1, "window": suite_window, "long": suite_long, "long2": suite_long2,
                "bam": suite_bam}
 
 

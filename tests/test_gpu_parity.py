@@ -99,6 +99,25 @@ def test_golden_long(aligner):
     assert run_groups(aligner, rows) == len(rows) == 9
 
 
+def test_golden_long2(aligner):
+    """Ten more long pairs from the compiled reference (tests/golden/make_golden.py::suite_long2): every overhang strategy
+    at 10 kb x 10 kb, unequal lengths either way, target lengths that are no multiple of the stripe height, a second and a
+    third parameter set, one pair beyond 30 kb; offset, all six ScoreMax fields, CIGAR by hash.  Default kernel choice (one
+    pair per workgroup for these query lengths), then the same through 3 and 16 waves per pair and through the one-pair entry."""
+    rows = golden_io.load("long2")
+    assert len(rows) == 10 and max(len(g.t) for g in rows) >= 30000
+    assert run_groups(aligner, rows) == 10
+    assert aligner.timing().fill_kernel == 3
+    for waves in (3, 16):
+        forced = sw.MicrosoftSmithWaterman(0)
+        forced.set_cooperative(waves)
+        assert run_groups(forced, rows) == 10
+        forced.close()
+    g = rows[5]  # 10 007 x 10 000
+    cigar, off, ez = sw.align(g.t, g.q, g.params, g.strategy)
+    assert off == g.offset and "sha1:" + hashlib.sha1(cigar.encode()).hexdigest() == g.cigar and tuple(ez) == g.score
+
+
 @pytest.mark.parametrize("rows,carry", [(64, 0), (64, 1), (16, 1)])
 def test_stripe_rows_and_carry_variants(rows, carry):
     """The int32 fill kernel with 64-row stripes (one pair per wave, wave_shr DPP) and / or the carry in the HBM
