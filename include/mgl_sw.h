@@ -75,6 +75,7 @@ typedef struct mgl_sw_timing {
 #define MGL_SW_KERNEL_DP32_64 2   /* sw_dp64_kernel: int32, 64 rows, one pair per wave           */
 #define MGL_SW_KERNEL_COOP 3      /* sw_dp_coop_kernel: one pair per workgroup (long reads)      */
 #define MGL_SW_KERNEL_LANE16 4    /* sw_dp16_lane_kernel: packed int16, two pairs per LANE       */
+#define MGL_SW_KERNEL_COOP16 5    /* sw_dp_coop16_kernel: long reads, packed int16, 128 rows/wave */
 
 typedef struct mgl_sw_ctx mgl_sw_ctx; /* opaque: one GPU, its workspace and stream */
 
@@ -96,8 +97,10 @@ const char *mgl_sw_last_error(const mgl_sw_ctx *ctx);
  * MI355X), at least 4 GiB; memory is only reserved as batches need it.  Batches are processed in chunks that fit. */
 int mgl_sw_ctx_set_workspace(mgl_sw_ctx *ctx, int64_t bytes);
 /* fill-kernel arithmetic: 0 (default) = per batch, the packed-int16 kernel when every pair has
- * the same tl and ql and the score range fits 16 bits, else int32; 32 = always int32.  Results are
- * bit-identical either way. */
+ * the same tl and ql and the score range fits 16 bits, else int32; long reads: the 16-bit one-pair-per-workgroup
+ * kernel, which checks its own score window and redoes a pair in 32 bits if it must, when the scoring parameters make
+ * that worthwhile; 32 = always int32; 16 = like 0, but the long-read kernel is tried whenever its constants fit at
+ * all (tests of the fall-back).  Results are bit-identical either way. */
 int mgl_sw_ctx_set_precision(mgl_sw_ctx *ctx, int bits);
 /* where the int32 fill kernel keeps its stripe carry: 0 (default) = LDS whenever the query fits, 1 = always the
  * HBM scratch used for long queries (for tests; results are identical) */
@@ -333,6 +336,9 @@ int mgl_sw_band_fill(const int32_t *target, int target_length, const int32_t *qu
  * pair's lengths.  Parity / debugging entry.
  */
 int mgl_sw_ctx_expand_slot(mgl_sw_ctx *ctx, int64_t slot, int tl, int ql, int32_t *btr);
+/* Traceback layout pair `slot` of the last chunk was filled in: 0 = an int32 kernel, 1 = sw_dp16_kernel, 2 =
+ * sw_dp16_lane_kernel, 3 = sw_dp_coop16_kernel (which reports 0 for a pair it had to redo in 32 bits).  Tests. */
+int mgl_sw_ctx_slot_layout(mgl_sw_ctx *ctx, int64_t slot, int *layout);
 
 /*
  * Host helper for MGL_SW_FLAG_GROUPED_GEOMETRY (no device work, usable without a GPU): a permutation of 0 .. n-1 that

@@ -24,7 +24,7 @@ SYMBOLS = (
     "mgl_sw_version", "mgl_sw_strerror", "mgl_sw_device_count", "mgl_sw_max_query_len", "mgl_sw_max_lds_query_len", "mgl_sw_ctx_set_carry_memory", "mgl_sw_ctx_set_stripe_rows", "mgl_sw_ctx_set_cooperative", "mgl_sw_ctx_set_lane_kernel", "mgl_sw_ctx_create",
     "mgl_sw_ctx_destroy", "mgl_sw_last_error", "mgl_sw_ctx_set_workspace", "mgl_sw_ctx_set_profiling", "mgl_sw_ctx_set_precision",
     "mgl_sw_ctx_get_timing", "mgl_sw_normalize_params", "mgl_sw_align", "mgl_sw_align_batch", "mgl_sw_align_batch_status",
-    "mgl_sw_align_batch_device", "mgl_sw_align_batch_device_2bit", "mgl_sw_align_batch_device_matrix", "mgl_sw_align_batch_device_indexed", "mgl_sw_backtrack_matrix", "mgl_sw_ctx_expand_slot",
+    "mgl_sw_align_batch_device", "mgl_sw_align_batch_device_2bit", "mgl_sw_align_batch_device_matrix", "mgl_sw_align_batch_device_indexed", "mgl_sw_backtrack_matrix", "mgl_sw_ctx_expand_slot", "mgl_sw_ctx_slot_layout",
     "mgl_sw_cigar_from_backtrack", "mgl_sw_band_fill", "mgl_sw_set_coalescing", "mgl_sw_coalescing_stats", "mgl_sw_group_by_geometry",
     "mgl_sw_multi_create", "mgl_sw_multi_destroy", "mgl_sw_multi_device_count", "mgl_sw_multi_ctx", "mgl_sw_multi_set_workspace",
     "mgl_sw_multi_last_error", "mgl_sw_align_batch_multi", "mgl_sw_multi_last_shards", "mgl_sw_shard_by_cells",
@@ -42,7 +42,7 @@ class Timing(C.Structure):
                 ("fill_kernel", C.c_int32), ("reserved", C.c_int32)]
 
 
-FILL_KERNEL_NAMES = ("sw_dp_kernel", "sw_dp16_kernel", "sw_dp64_kernel", "sw_dp_coop_kernel", "sw_dp16_lane_kernel")
+FILL_KERNEL_NAMES = ("sw_dp_kernel", "sw_dp16_kernel", "sw_dp64_kernel", "sw_dp_coop_kernel", "sw_dp16_lane_kernel", "sw_dp_coop16_kernel")
 
 
 def _sources_newer():
@@ -113,6 +113,7 @@ def lib():
     L.mgl_sw_group_by_geometry.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     L.mgl_sw_coalescing_stats.argtypes = [i64p, i64p]
     L.mgl_sw_ctx_expand_slot.argtypes = [vp, C.c_int64, C.c_int, C.c_int, i32p]
+    L.mgl_sw_ctx_slot_layout.argtypes = [vp, C.c_int64, C.POINTER(C.c_int)]
     L.mgl_sw_align_batch_status.argtypes = [vp, C.c_int64, vp, vp, vp, vp] + [C.c_int] * 5 + [vp, vp, vp, C.c_int, vp, vp]
     L.mgl_sw_multi_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     L.mgl_sw_multi_destroy.argtypes = [vp]

@@ -102,7 +102,7 @@ struct mgl_sw_ctx {
     DevBuf d_t, d_toff, d_q, d_qoff, d_off, d_score, d_cig, d_len, d_status, d_btr, d_any, d_matrix; // host-API staging
     int64_t last_stride_words = 0, last_chunk_count = 0; // geometry of the last chunk (for expand_slot)
     int last_packed16 = 0;
-    int precision = 0; // 0 = choose per batch, 32 = always the int32 kernel
+    int precision = 0; // 0 = choose per batch, 32 = always the int32 kernels, 16 = try the self-checking 16-bit long-read kernel whenever its constants fit
     int profiling = 0; // 0 off, 1 per-kernel HIP events, 2 also the in-kernel clock probe
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     mgl_sw_timing timing{};
@@ -280,6 +280,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // long reads: one pair per WORKGROUP (sw_dp_coop_kernel), its waves pipelined over the 64-row stripes.  Taken
     // when the one-wave-per-pair carve does not fit LDS, or when forced; needs at least two stripes to share.
     int coop_waves = 0;
+    bool coop16 = false;
     if (!use16 && !use_lane && !d_matrix && ctx->cooperative != 1 && ctx->carry_memory == 0 && gopen < 65536 && gopen >= gext && (ctx->stripe_rows == 0 || ctx->cooperative >= 2) &&
         ((rows == 64 && wpb == 0) || ctx->cooperative >= 2) && coop_lds_bytes(coop_sps_for(max_ql), 2) <= 160 * 1024) {
         const int stripes = (max_tl + 63) / 64;
@@ -287,6 +288,19 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         while (coop_waves > 2 && (coop_waves > stripes || coop_lds_bytes(coop_sps_for(max_ql), coop_waves) > 160 * 1024)) --coop_waves;
         rows = 64;
         sps_cap = coop_sps_for(max_ql);
+        // packed int16 form (sw_dp_coop16_kernel): 128 rows per wave; it checks its own score window and redoes a pair in
+        // 32 bits when that fails, so what is decided here is only whether trying is worthwhile
+        static const int coop16_env = [] { const char *e = getenv("MGL_SW_COOP16"); return e ? atoi(e) : -1; }();
+        if (ctx->precision != 32 && coop16_env != 0 && (ctx->precision == 16 ? coop16_possible(match, mismatch, gopen, gext) : coop16_worthwhile(match, mismatch, gopen, gext))) {
+            const int sps16 = coop16_sps_for(max_ql), dstripes = (max_tl + 127) / 128;
+            int w16 = coop_waves;
+            while (w16 > 2 && (w16 > dstripes || coop_lds_bytes(sps16, w16) > 160 * 1024)) --w16;
+            if (coop_lds_bytes(sps16, w16) <= 160 * 1024) {
+                coop16 = true;
+                coop_waves = w16;
+                sps_cap = sps16;
+            }
+        }
         wpb = coop_waves;
     }
     // queries too long for the LDS carve: carry ring and query copies in an HBM scratch area instead
@@ -306,6 +320,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // (lane layout: words per WAVE of 128 pairs, plus the wave's carry row)
     const int64_t stride_words = use_lane ? lane_tb_words(max_tl, max_ql, rows)
                                  : use16 ? (geom == GEOM_UNIFORM ? tb_words16_for(max_tl, max_ql) : tb_words16_bound(max_tl, max_ql))
+                                 : coop16 ? std::max(tb_words_for(max_tl, coop_sps_for(max_ql), 64), tb_words_coop16(max_tl, max_ql)) // either layout
                                          : tb_words_for(max_tl, sps_cap, rows);
     // (auto-grouped chunks: the packed regions first, the int32 regions of the left-over pairs behind them)
     const int sps32 = sps_for_rows(max_ql, 16);
@@ -446,7 +461,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             ta.strategy = strategy;
             ta.tb = pt.tb;
             ta.tb_stride_words = pt.stride;
-            ta.packed16 = pt.lane ? 2 : pt.packed ? 1 : 0;
+            ta.packed16 = pt.lane ? 2 : pt.packed ? 1 : coop16 ? 3 : 0;
             ta.rows_per_stripe = pt.rows;
             ta.uni_ql = max_ql;
             ta.rec = pt.rec;
@@ -482,7 +497,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             if (!fused_walk) walk.cigar = nullptr;
             HIP_TRY(ctx, pt.lane ? launch_dp16_lane(das[i], walk, pt.rows, stream)
                          : pt.packed ? launch_dp16(das[i], pt.wpb, stream)
-                         : coop_waves ? launch_dp_coop(das[i], coop_waves, stream) : launch_dp(das[i], pt.wpb, pt.rows, stream));
+                         : coop16 ? launch_dp_coop16(das[i], coop_waves, stream) : coop_waves ? launch_dp_coop(das[i], coop_waves, stream) : launch_dp(das[i], pt.wpb, pt.rows, stream));
         }
         if (pe[1]) HIP_TRY(ctx, hipEventRecord(pe[1], stream));
         if (overlap) {
@@ -512,12 +527,12 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         ctx->last_chunk_count = auto_group ? 0 : count; // (a chunk sorted by geometry has no caller-order slots to expand)
         ctx->last_half = h;
         ctx->last_rows = rows;
-        ctx->last_packed16 = use_lane ? 2 : use16 ? 1 : 0;
+        ctx->last_packed16 = use_lane ? 2 : use16 ? 1 : coop16 ? 3 : 0;
         ctx->timing.dp_launches++;
         ctx->timing.tb_launches++;
         ctx->timing.tb_bytes += (use_lane ? (count + 127) / 128 : use16 ? (count + 1) / 2 : count) * stride_words * 4;
         ctx->timing.packed16 = (use16 || use_lane) ? 1 : 0;
-        ctx->timing.fill_kernel = use_lane ? MGL_SW_KERNEL_LANE16 : use16 ? MGL_SW_KERNEL_DP16 : coop_waves ? MGL_SW_KERNEL_COOP : rows == 64 ? MGL_SW_KERNEL_DP32_64 : MGL_SW_KERNEL_DP32;
+        ctx->timing.fill_kernel = use_lane ? MGL_SW_KERNEL_LANE16 : use16 ? MGL_SW_KERNEL_DP16 : coop16 ? MGL_SW_KERNEL_COOP16 : coop_waves ? MGL_SW_KERNEL_COOP : rows == 64 ? MGL_SW_KERNEL_DP32_64 : MGL_SW_KERNEL_DP32;
     }
     for (int i = 0; hooks && i < n_pending; ++i) {
         const int hrc = hooks->after_traceback(pending[i].first, pending[i].count, pending[i].ready);
@@ -664,7 +679,7 @@ int mgl_sw_ctx_set_workspace(mgl_sw_ctx *ctx, int64_t bytes)
 
 int mgl_sw_ctx_set_precision(mgl_sw_ctx *ctx, int bits)
 {
-    if (!ctx || (bits != 0 && bits != 32)) return MGL_SW_ERR_BAD_ARG;
+    if (!ctx || (bits != 0 && bits != 16 && bits != 32)) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->precision = bits;
     return MGL_SW_OK;
@@ -1274,13 +1289,28 @@ int mgl_sw_ctx_expand_slot(mgl_sw_ctx *ctx, int64_t slot, int tl, int ql, int32_
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, ctx->d_btr.reserve(cells * 4));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_btr.p, 0, cells * 4, ctx->stream));
-    const int64_t region = ctx->last_packed16 == 2 ? slot >> 7 : ctx->last_packed16 ? slot >> 1 : slot;
+    const int64_t region = ctx->last_packed16 == 2 ? slot >> 7 : ctx->last_packed16 == 1 ? slot >> 1 : slot;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
     HIP_TRY(ctx, launch_expand(static_cast<const uint32_t *>(ctx->tb[ctx->last_half].p) + region * ctx->last_stride_words,
                                static_cast<const DpRecord *>(ctx->rec[ctx->last_half].p) + slot, tl, ql, ctx->last_packed16,
                                (int)(slot & 1), ctx->last_rows, static_cast<int32_t *>(ctx->d_btr.p), ctx->stream, (int)((slot >> 1) & 63)));
     HIP_TRY(ctx, hipMemcpyAsync(btr, ctx->d_btr.p, cells * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MGL_SW_OK;
+}
+
+int mgl_sw_ctx_slot_layout(mgl_sw_ctx *ctx, int64_t slot, int *layout)
+{
+    if (!ctx || !layout) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (slot < 0 || slot >= ctx->last_chunk_count)
+        return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_ctx_slot_layout: slot outside the last chunk");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
+    mgl_sw_dev::DpRecord r;
+    HIP_TRY(ctx, hipMemcpyAsync(&r, static_cast<const mgl_sw_dev::DpRecord *>(ctx->rec[ctx->last_half].p) + slot, sizeof r, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *layout = ctx->last_packed16 == 3 && r.g_tail != -16 ? 0 : ctx->last_packed16; // TbView::layout_of
     return MGL_SW_OK;
 }
 

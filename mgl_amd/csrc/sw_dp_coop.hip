@@ -32,6 +32,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "sw_device.h"
 
 namespace mgl_sw_dev {
@@ -195,12 +197,9 @@ __device__ __forceinline__ void coop_group32(CoopLane &st, int4 &rA, int4 &rB, c
 
 __device__ __forceinline__ unsigned wrap_tag(int consumer_stripe, int W) { return (unsigned)((consumer_stripe / W) & 0x7fff) + 1u; }
 
-} // namespace
-
-// grid = pairs of the chunk, block = 64 * W threads
-__global__ __launch_bounds__(1024) void sw_dp_coop_kernel(const DpArgs a)
+// the int32 kernel's body (also the fall-back of sw_dp_coop16_kernel below)
+__device__ __forceinline__ void coop32_body(const DpArgs &a, unsigned char *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform, and the compiler knows it
     const int W = blockDim.x >> 6;
@@ -403,9 +402,498 @@ __global__ __launch_bounds__(1024) void sw_dp_coop_kernel(const DpArgs a)
     }
 }
 
+// =====================================================================================================================
+// 16-bit form of the long-read kernel: TWO 64-row half-stripes per wave, packed in the low / high half of every register.
+//
+// A wave runs a "double stripe" of 128 target rows as 128 processing elements (PE p = row k*128 + p + 1 at column s - p in
+// step s): PEs 0..63 are the low halves of lanes 0..63, PEs 64..127 the high halves.  One DPP move shifts both halves to
+// the next lane; at the seam PE 63 -> PE 64 the low half of lane 63 becomes the high-half input of lane 0.  Scores reach
+// 2 * 10^6 on 10 kb reads, so a half-stripe is held relative to a BASELINE of its own (B_lo, B_hi: wave-uniform int32):
+//     stored16 = X[i][j] + (i + j) * e - B_half                      (X = H, E or F; the int32 kernel's form minus B)
+// and the baseline is moved every 32 steps.  Exactness does not rest on an a-priori range claim: at every move the wave
+// reduces the exact minimum and maximum of H over its 64 PEs per half and checks that the window they span, widened by
+// what 32 more steps can add, fits 16 bits; the widening uses only one-step facts of the recurrence (sw.cpp:60-93), in
+// stored units and for ANY sequences -- the padded rows > tl and columns > ql are cells of a larger matrix and obey them too:
+//     E'[i+1][j], F'[i][j+1] in [H - (o-e), H];   H[i-1][j] (the next step's diagonal) in [H - (match+o+e), H + o];
+//     per step the maximum over a half rises by at most match + 2e (a diagonal step), its minimum falls by at most o - e
+//     (H' >= F), and the two intermediates go at most max(o - e, |mismatch + 2e|) below.
+// If the check ever fails the pair is marked and the WORKGROUP redoes it with the int32 body (coop32_body) -- never a wrong
+// answer.  For GATK parameters the 64 PEs span <= 63 * (match + 2e) + 2 * (o - e) ~ 14.5 k (measured 14.7 k on adversarial
+// pairs) against a limit of ~49 k, so the fall-back is for exotic parameter sets; the host does not even try when
+// 64 * (match + 2e) + 34 * (match + o + e) cannot fit.
+// Hand-over between waves, the HBM hop, tags and counters are those of the int32 kernel, in true (int32) values: the
+// consumer subtracts its own baseline.  Traceback layout ("coop16", DpRecord.g_tail == -16): per double stripe and 16
+// steps one uint4 per lane, dword = 4 steps in the byte layout of sw_dp16.hip (byte0 = low half {E>S, F opened}, byte1 =
+// high half, byte2 = low {F>diag, E opened}, byte3 = high; step t in bits 2t+1, 2t): 4 bits per cell, 1 KB per store.
+
+typedef short short2c_t __attribute__((ext_vector_type(2)));
+typedef unsigned short ushort2c_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned c_pk_add(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(ushort2c_t, a) + __builtin_bit_cast(ushort2c_t, b)); }
+__device__ __forceinline__ unsigned c_pk_sub(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(ushort2c_t, a) - __builtin_bit_cast(ushort2c_t, b)); }
+__device__ __forceinline__ unsigned c_pk_sub_sat(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(short2c_t, a), __builtin_bit_cast(short2c_t, b)));
+}
+__device__ __forceinline__ unsigned c_pk_max(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2c_t, a), __builtin_bit_cast(short2c_t, b)));
+}
+__device__ __forceinline__ unsigned c_pk_min(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(short2c_t, a), __builtin_bit_cast(short2c_t, b)));
+}
+__device__ __forceinline__ unsigned c_pk_min_u(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(ushort2c_t, a), __builtin_bit_cast(ushort2c_t, b)));
+}
+__device__ __forceinline__ unsigned c_pk_mad(unsigned a, unsigned b, unsigned c)
+{
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(ushort2c_t, a) * __builtin_bit_cast(ushort2c_t, b) + __builtin_bit_cast(ushort2c_t, c));
+}
+__device__ __forceinline__ unsigned c_pack2(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
+__device__ __forceinline__ int c_lo16(unsigned x) { return (int)(short)(x & 0xffffu); }
+__device__ __forceinline__ int c_hi16(unsigned x) { return (int)x >> 16; }
+__device__ __forceinline__ unsigned c_and_or(unsigned a, unsigned k, unsigned b)
+{
+    unsigned r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(b));
+    return r;
+}
+
+// What the window check adds below the minimum and above the maximum of H found when the baselines move.  Between two
+// moves lie 32 steps; the registers also hold values up to two steps old, hence 34:
+//   below: 34 steps of falling (o-e each), the diagonal input (match+o+e) and the E' input of PE 0 / PE 64 another
+//          (match+o+e) + (o-e) under the H they feed, and the intermediate diag = hup + (mismatch + 2e)
+//   above: 34 steps of rising -- match+2e inside a half, but match+o+e for PE 0 / PE 64 whose inputs come from outside the
+//          half (H[i][j+1] <= H[i][j] + match + o + e for any cell) --, the diagonal input (o) and diag = hup + match + 2e
+__host__ __device__ inline int coop16_below(int match, int mismatch, int gopen, int gext)
+{
+    const int mis2 = mismatch + 2 * gext;
+    return 34 * (gopen - gext) + 2 * (match + gopen + gext) + (gopen - gext) + (mis2 < 0 ? -mis2 : mis2) + 64;
+}
+__host__ __device__ inline int coop16_above(int match, int gopen, int gext) { return 34 * (match + gopen + gext) + gopen + (match + 2 * gext) + 64; }
+
+struct Coop16Lane {
+    unsigned h_prev, e_prev, hup, f; // low | high half-stripe, stored form
+    unsigned w[3];                   // traceback dwords of the last three 4-step blocks
+    int best_lo, best_lo_i, best_hi, best_hi_i; // last-column maxima of this lane's low / high rows (true scores; ties: later row)
+    int rm, rd, rj;                  // the double stripe that holds row tl: running best of the last row
+};
+
+struct Coop16Consts {
+    unsigned delta, one, o_e, k2; // packed (both halves equal): mismatch - match, 1, o - e, match + 2e
+    unsigned k12[4], k34[4];      // SGPR bit masks of the four steps of a traceback dword
+    int o_e32, gopen, gext, tl, ql;
+    int floor16, check_margin;    // where a re-based half puts its minimum; what the window check adds to the spread
+};
+
+// wave-wide packed min and max (per 16-bit half) of x, the same in every lane
+__device__ __forceinline__ void wave_minmax_pk(unsigned x, unsigned &mn, unsigned &mx)
+{
+    mn = mx = x;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const unsigned a = (unsigned)__shfl_xor((int)mn, m), b = (unsigned)__shfl_xor((int)mx, m);
+        mn = c_pk_min(mn, a);
+        mx = c_pk_max(mx, b);
+    }
+}
+
+// 32 anti-diagonal steps of one 128-row double stripe.  EDGE / OUT as in coop_group32.  B_lo / B_hi: the baselines.
+template <bool EDGE, int OUT>
+__device__ __forceinline__ void coop16_group32(Coop16Lane &st, int4 &rA, int4 &rB, const int2 *ring_in, int2 *ring_out,
+                                               unsigned long long *wrap_out, const unsigned tag_out, const unsigned *qrd_lo,
+                                               const unsigned *qrd_hi, unsigned &qlo_lo, unsigned &qlo_hi, const int q_shift,
+                                               const unsigned tt, const int s_begin, const int L, const int hb_lo, const int hb_hi,
+                                               const int qcap_lo, const int qcap_hi, const int row_lo, const int B_lo, const int B_hi,
+                                               const Coop16Consts &c, const bool writer, const int last_half, uint4 *&tbp)
+{
+    const int dB = B_lo - B_hi;
+#pragma unroll 1
+    for (int b = 0; b < 8; ++b) {
+        const int s0 = s_begin + 4 * b;
+        unsigned wnew = 0u;
+        // bases of the four columns of this block for both halves: bytes (s0 - L + 127) .. +3 and (s0 - L + 63) .. +3 of the padded query
+        const unsigned qh_lo = qrd_lo[(s0 >> 2) + 1], qh_hi = qrd_hi[(s0 >> 2) + 1];
+        const unsigned qw_lo = __builtin_amdgcn_alignbyte(qh_lo, qlo_lo, (unsigned)q_shift);
+        const unsigned qw_hi = __builtin_amdgcn_alignbyte(qh_hi, qlo_hi, (unsigned)q_shift);
+        qlo_lo = qh_lo;
+        qlo_hi = qh_hi;
+        const int4 *nxt = reinterpret_cast<const int4 *>(ring_in + ((s0 + 4) & RING_MASK));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int rh = u == 0 ? rA.x : u == 1 ? rA.z : u == 2 ? rB.x : rB.z;
+            int re = u == 0 ? rA.y : u == 1 ? rA.w : u == 2 ? rB.y : rB.w;
+            if (u == 2) rA = nxt[0];
+            // ---- what PE 0 (carry of the row above, minus this half's baseline) and PE 64 (PE 63 of the last step, re-based) take in
+            const unsigned s_h63 = (unsigned)__builtin_amdgcn_readlane((int)st.h_prev, 63);
+            const unsigned s_e63 = (unsigned)__builtin_amdgcn_readlane((int)st.e_prev, 63);
+            unsigned in_h_lo = (unsigned)(rh - B_lo), in_e_lo = (unsigned)(re - B_lo);
+            if (EDGE && s0 + u > c.ql) {
+                // PE 0 is past the last column: the carry row ends there; the cells it keeps computing feed nothing, but they must
+                // stay inside the window, so they see their own last values as the row above
+                in_h_lo = (unsigned)__builtin_amdgcn_readlane((int)st.h_prev, 0);
+                in_e_lo = (unsigned)__builtin_amdgcn_readlane((int)st.e_prev, 0);
+            }
+            const unsigned in_h = (in_h_lo & 0xffffu) | ((s_h63 + (unsigned)dB) << 16);
+            const unsigned in_e = (in_e_lo & 0xffffu) | ((s_e63 + (unsigned)dB) << 16);
+            const unsigned hup_new = (unsigned)wave_shr1((int)in_h, (int)st.h_prev);
+            const unsigned ein = (unsigned)wave_shr1((int)in_e, (int)st.e_prev);
+            // ---- the cell, both halves (sw_dp16.hip's cell16)
+            const unsigned q = __builtin_amdgcn_perm(qw_hi, qw_lo, 0x0c040c00u + 0x00010001u * (unsigned)u);
+            const unsigned m = c_pk_min_u(q ^ tt, c.one);
+            const unsigned sc = c_pk_mad(m, c.delta, c.k2);
+            const unsigned diag = c_pk_add(st.hup, sc);
+            const unsigned sm = c_pk_max(diag, st.f);
+            unsigned h = c_pk_max(sm, ein);
+            const unsigned open = c_pk_sub(h, c.o_e);
+            const unsigned eo = c_pk_max(open, ein);
+            unsigned fo = c_pk_max(open, st.f);
+            const unsigned d1 = c_pk_sub_sat(diag, st.f), d2 = c_pk_sub_sat(sm, ein), d3 = c_pk_sub_sat(ein, open), d4 = c_pk_sub_sat(st.f, open);
+            const unsigned p12 = __builtin_amdgcn_perm(d1, d2, 0x0b0a0908u), p34 = __builtin_amdgcn_perm(d3, d4, 0x0b0a0908u);
+            wnew = c_and_or(p34, c.k34[u], u == 0 ? (p12 & c.k12[0]) : c_and_or(p12, c.k12[u], wnew));
+            const int j_lo = s0 + u - L, j_hi = j_lo - 64; // this lane's columns
+            if (EDGE) {
+                // column <= 0: the border values H[i][0], F[i][1] (sw.cpp:24,38,47-49), relative to the half's baseline
+                const unsigned hb = c_pack2(hb_lo - B_lo, hb_hi - B_hi);
+                const unsigned hbf = c_pk_sub(hb, c.o_e);
+                const unsigned msk = (j_lo <= 0 ? 0x0000ffffu : 0u) | (j_hi <= 0 ? 0xffff0000u : 0u);
+                h = (hb & msk) | (h & ~msk);
+                fo = (hbf & msk) | (fo & ~msk);
+                // last column of this lane's rows (sw.cpp:100-104: >= so the later row wins): true scores
+                const int sc_lo = c_lo16(h) + B_lo - (row_lo + c.ql) * c.gext, sc_hi = c_hi16(h) + B_hi - (row_lo + 64 + c.ql) * c.gext;
+                const bool t_lo = j_lo == qcap_lo && sc_lo >= st.best_lo, t_hi = j_hi == qcap_hi && sc_hi >= st.best_hi;
+                st.best_lo = t_lo ? sc_lo : st.best_lo;
+                st.best_lo_i = t_lo ? row_lo : st.best_lo_i;
+                st.best_hi = t_hi ? sc_hi : st.best_hi;
+                st.best_hi_i = t_hi ? row_lo + 64 : st.best_hi_i;
+            }
+            if (OUT == OUT_LAST) {
+                // the half that holds row tl: sw.cpp:116-127 in column order -- better score, or same score closer to the diagonal
+                const int j = last_half ? j_hi : j_lo;
+                const int d = abs(c.tl - j);
+                const int score = (last_half ? c_hi16(h) + B_hi : c_lo16(h) + B_lo) - (c.tl + j) * c.gext;
+                const bool take = j >= 1 && j <= c.ql && (score > st.rm || (score == st.rm && d < st.rd));
+                st.rm = take ? score : st.rm;
+                st.rd = take ? d : st.rd;
+                st.rj = take ? j : st.rj;
+            } else if (!EDGE || s0 + u >= 127) {
+                // PE 127 (lane 63, high half) finishes column s - 127 of the double stripe's last row: hand it on in true values
+                const int col = s0 + u - 127;
+                const int ht = c_hi16(h) + B_hi;
+                if (OUT == OUT_RING) {
+                    if (writer) ring_out[col & RING_MASK] = make_int2(ht, c_hi16(eo) + B_hi);
+                } else {
+                    const unsigned diff = (unsigned)(c_hi16(h) - c_hi16(eo)) & 0xffffu; // 0 <= H - E' <= o - e
+                    if (writer)
+                        __hip_atomic_store(wrap_out + col, (unsigned long long)(unsigned)ht | ((unsigned long long)(diff | tag_out) << 32),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            st.h_prev = h;
+            st.e_prev = eo;
+            st.hup = hup_new;
+            st.f = fo;
+        }
+        rB = nxt[1];
+        // the dwords of 16 steps rotate through three registers (a dynamic register index would go through scratch)
+        if ((b & 3) == 3) {
+            *tbp = make_uint4(st.w[0], st.w[1], st.w[2], wnew); // 1 KB per wave
+            tbp += 64;
+        }
+        st.w[0] = st.w[1];
+        st.w[1] = st.w[2];
+        st.w[2] = wnew;
+    }
+}
+
+// returns false (workgroup-uniform) when some window check failed: the pair must be redone in 32 bits
+__device__ __forceinline__ bool coop16_body(const DpArgs &a, unsigned char *smem)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = blockDim.x >> 6;
+    const int L = lane;
+    const int64_t slot = blockIdx.x;
+    const int64_t p = a.first + slot;
+
+    const int64_t t0 = a.t.off[p], q0 = a.q.off[p];
+    const int tl = a.t.length(p);
+    const int ql = a.q.length(p);
+    const int nds = (tl + 127) >> 7;                    // double stripes
+    const int sps = coop16_sps_for(ql);                 // steps per double stripe, a multiple of 32
+    const int S = (sps + 64 + RING_MASK) & ~RING_MASK;  // sequence numbers per double stripe
+    const int main_lo = 128, main_hi = ql & ~31;        // groups inside [main_lo, main_hi) touch no edge
+
+    // LDS: query bytes (128 zero bytes, q, zeros) | W rings | produced[W] | consumed[W] | per-wave results
+    const int qbytes = coop_query_bytes(a.sps_cap);
+    unsigned char *qbuf = smem;
+    int2 *rings = reinterpret_cast<int2 *>(smem + qbytes);
+    int *produced = reinterpret_cast<int *>(rings + (size_t)W * RING_COLS);
+    int *consumed = produced + W;
+    int *wres = consumed + W; // [W][2] last-column best, then [5] last row {rm, rd, rj, failed, needs32}
+
+    const int wrap_cols = coop_wrap_cols(a.sps_cap);
+    unsigned long long *wrap = reinterpret_cast<unsigned long long *>(a.scratch) + (size_t)slot * wrap_cols;
+    {
+        unsigned *qz = reinterpret_cast<unsigned *>(qbuf);
+        for (int w = threadIdx.x; w < (qbytes >> 2); w += blockDim.x) qz[w] = 0u;
+        if ((int)threadIdx.x < 2 * W) produced[threadIdx.x] = 0;
+        if (threadIdx.x < 5) wres[2 * W + threadIdx.x] = threadIdx.x == 0 ? NEG_INF : threadIdx.x >= 3 ? 0 : 0x7fffffff;
+        if (nds > W)
+            for (int x = threadIdx.x; x < wrap_cols; x += blockDim.x) wrap[x] = 0ull; // tag 0 = not written
+        __threadfence();
+        __syncthreads();
+        for (int x = threadIdx.x; x < ql; x += blockDim.x) qbuf[128 + x] = (unsigned char)a.q.at(q0, x);
+        __syncthreads();
+    }
+
+    const int match = a.match, gopen = a.gopen, gext = a.gext;
+    Coop16Consts c;
+    c.delta = c_pack2(a.mismatch - match, a.mismatch - match);
+    c.one = c_pack2(1, 1);
+    c.o_e = c_pack2(gopen - gext, gopen - gext);
+    c.k2 = c_pack2(match + 2 * gext, match + 2 * gext);
+    asm volatile("" : "+v"(c.delta), "+v"(c.one), "+v"(c.o_e), "+v"(c.k2));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        c.k12[u] = 0x02020202u << (2 * u);
+        c.k34[u] = 0x01010101u << (2 * u);
+        asm volatile("" : "+s"(c.k12[u]), "+s"(c.k34[u]));
+    }
+    c.o_e32 = gopen - gext;
+    c.gopen = gopen;
+    c.gext = gext;
+    c.tl = tl;
+    c.ql = ql;
+    // Window bookkeeping: coop16_below / coop16_above, see the header of this section
+    const int below = coop16_below(match, a.mismatch, gopen, gext), above = coop16_above(match, gopen, gext);
+    c.floor16 = -32768 + below;
+    c.check_margin = below + above;
+    const bool indel = (a.strategy & (OS_INDEL | OS_LEAD_ID)) != 0;
+
+    Coop16Lane st;
+    st.h_prev = st.e_prev = st.hup = st.f = 0u;
+    st.w[0] = st.w[1] = st.w[2] = 0u;
+    st.best_lo = st.best_hi = NEG_INF;
+    st.best_lo_i = st.best_hi_i = -1;
+    st.rm = NEG_INF;
+    st.rd = 0x7fffffff;
+    st.rj = 0x7fffffff;
+    int failed = 0, needs32 = 0; // wave-uniform
+
+    const int q_shift = (127 - L) & 3;
+    const unsigned *qrd_lo = reinterpret_cast<const unsigned *>(qbuf) + ((127 - L) >> 2); // byte (s - L + 127): column s - L of the low half
+    const unsigned *qrd_hi = reinterpret_cast<const unsigned *>(qbuf) + ((63 - L) >> 2);  // column s - 64 - L of the high half
+    const bool writer = (L == 63);
+    const int last_lane = (tl - 1) & 63, last_half = ((tl - 1) >> 6) & 1;
+    const int b_in = (wave + W - 1) % W, b_out = wave;
+    int2 *ring_in = rings + (size_t)b_in * RING_COLS;
+    int2 *ring_out = rings + (size_t)b_out * RING_COLS;
+
+    for (int k = wave; k < nds; k += W) {
+        const bool first = (k == 0), last = (k == nds - 1);
+        const int out = last ? OUT_LAST : (wave == W - 1 ? OUT_WRAP : OUT_RING);
+        const int row_lo = k * 128 + 1 + L, row_hi = row_lo + 64;
+        const unsigned tt = (unsigned)(row_lo <= tl ? a.t.at(t0, row_lo - 1) : 0) | ((unsigned)(row_hi <= tl ? a.t.at(t0, row_hi - 1) : 0) << 16);
+        const int hb_lo = border(row_lo, gopen, gext, indel) + row_lo * gext, hb_hi = border(row_hi, gopen, gext, indel) + row_hi * gext; // column 0
+        const int qcap_lo = row_lo <= tl ? ql : NEG_INF, qcap_hi = row_hi <= tl ? ql : NEG_INF;
+        const int base_in = (k / W) * S, base_out = ((k + 1) / W) * S;
+        const unsigned tag_in = wrap_tag(k, W), tag_out = wrap_tag(k + 1, W) << 16;
+        uint4 *tbp = reinterpret_cast<uint4 *>(a.tb + (size_t)slot * a.tb_stride_words) + (size_t)k * (sps >> 4) * 64 + L;
+
+        // every PE starts on its column-0 border value; the baselines start on PE 0 / PE 64 of the double stripe
+        int B_lo = __builtin_amdgcn_readfirstlane(hb_lo), B_hi = __builtin_amdgcn_readfirstlane(hb_hi);
+        st.h_prev = c_pack2(hb_lo - B_lo, hb_hi - B_hi);
+        st.hup = st.h_prev;
+        st.e_prev = st.f = c_pk_sub(st.h_prev, c.o_e);
+
+        int4 rA = make_int4(0, 0, 0, 0), rB = rA;
+        unsigned qlo_lo = qrd_lo[0], qlo_hi = qrd_hi[0];
+        unsigned long long pend_a = 0, pend_b = 0;
+        for (int s = 0; s < sps; s += 32) {
+            // ---- move the baselines: exact minimum / maximum of H per half, window check, re-base the four state registers
+            {
+                unsigned mn, mx;
+                wave_minmax_pk(st.h_prev, mn, mx);
+                const unsigned smn = (unsigned)__builtin_amdgcn_readfirstlane((int)mn), smx = (unsigned)__builtin_amdgcn_readfirstlane((int)mx);
+                const int lo_l = c_lo16(smn), hi_l = c_lo16(smx), lo_h = c_hi16(smn), hi_h = c_hi16(smx);
+                if ((hi_l - lo_l) + c.check_margin > 65535 || (hi_h - lo_h) + c.check_margin > 65535) needs32 = 1;
+                const int d_l = lo_l - c.floor16, d_h = lo_h - c.floor16;
+                const unsigned dd = c_pack2(d_l, d_h);
+                B_lo += d_l;
+                B_hi += d_h;
+                st.h_prev = c_pk_sub(st.h_prev, dd);
+                st.e_prev = c_pk_sub(st.e_prev, dd);
+                st.hup = c_pk_sub(st.hup, dd);
+                st.f = c_pk_sub(st.f, dd);
+            }
+            // ---- carry in: columns < s + AHEAD of the row above this double stripe
+            if (wave == 0) {
+                if (first) {
+                    for (int col = (s == 0 ? 0 : s + AHEAD - 32) + L; col < s + AHEAD; col += 64) {
+                        const int hb0 = border(col, gopen, gext, indel) + col * gext;
+                        ring_in[col & RING_MASK] = make_int2(hb0, hb0 - c.o_e32);
+                    }
+                } else if (s == 0) {
+                    const unsigned long long v = wrap_load(wrap, L, wrap_cols);
+                    pend_a = wrap_load(wrap, AHEAD + L, wrap_cols);
+                    pend_b = wrap_load(wrap, AHEAD + 32 + L, wrap_cols);
+                    if (!failed) failed = !stage_wrap(v, L, true, ql, tag_in, wrap, wrap_cols, ring_in);
+                } else {
+                    const int col = s + AHEAD - 32 + L;
+                    if (!failed) failed = !stage_wrap(pend_a, col, L < 32, ql, tag_in, wrap, wrap_cols, ring_in);
+                    pend_a = pend_b;
+                    pend_b = wrap_load(wrap, col + 64, wrap_cols);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else if (!failed) {
+                failed = !wait_at_least(produced + b_in, base_in + s + AHEAD);
+            }
+            // ---- carry out through a ring: the slots of columns (s - 127) .. (s - 96) must have been read one lap ago
+            if (out == OUT_RING && !failed && s + 31 - 127 >= 0) {
+                const int need = base_out + s + 31 - 127 - RING_MASK;
+                if (need > 0) failed = !wait_at_least(consumed + b_out, need);
+            }
+            if (s == 0) {
+                const int4 *r0 = reinterpret_cast<const int4 *>(ring_in);
+                rA = r0[0];
+                rB = r0[1];
+            }
+            const bool lean = s >= main_lo && s + 32 <= main_hi;
+#define MGL_COOP16_GROUP(EDGE, OUT)                                                                                                \
+    coop16_group32<EDGE, OUT>(st, rA, rB, ring_in, ring_out, wrap, tag_out, qrd_lo, qrd_hi, qlo_lo, qlo_hi, q_shift, tt, s, L, hb_lo, hb_hi, \
+                              qcap_lo, qcap_hi, row_lo, B_lo, B_hi, c, writer, last_half, tbp)
+            if (out == OUT_RING) {
+                if (lean)
+                    MGL_COOP16_GROUP(false, OUT_RING);
+                else
+                    MGL_COOP16_GROUP(true, OUT_RING);
+            } else if (out == OUT_WRAP) {
+                if (lean)
+                    MGL_COOP16_GROUP(false, OUT_WRAP);
+                else
+                    MGL_COOP16_GROUP(true, OUT_WRAP);
+            } else {
+                if (lean)
+                    MGL_COOP16_GROUP(false, OUT_LAST);
+                else
+                    MGL_COOP16_GROUP(true, OUT_LAST);
+            }
+#undef MGL_COOP16_GROUP
+            // ---- publish progress (the release orders lane 63's ring stores before the counter)
+            if (L == 0) {
+                if (out == OUT_RING && s + 32 - 127 > 0)
+                    __hip_atomic_store(produced + b_out, base_out + s + 32 - 127, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (wave != 0)
+                    __hip_atomic_store(consumed + b_in, base_in + s + 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (L == 0) {
+            if (out == OUT_RING)
+                __hip_atomic_store(produced + b_out, base_out + S, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (wave != 0) __hip_atomic_store(consumed + b_in, base_in + S, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (last && L == last_lane) {
+            wres[2 * W + 0] = st.rm;
+            wres[2 * W + 1] = st.rd;
+            wres[2 * W + 2] = st.rj;
+        }
+    }
+
+    // ---- last column: this lane's two candidates, then the lanes of the wave, then the waves (ties: larger row)
+    int mqe = st.best_lo, mqe_t = st.best_lo_i;
+    {
+        const bool take = st.best_hi > mqe || (st.best_hi == mqe && st.best_hi_i > mqe_t);
+        mqe = take ? st.best_hi : mqe;
+        mqe_t = take ? st.best_hi_i : mqe_t;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int ob = __shfl_xor(mqe, m), oi = __shfl_xor(mqe_t, m);
+        const bool take = ob > mqe || (ob == mqe && oi > mqe_t);
+        mqe = take ? ob : mqe;
+        mqe_t = take ? oi : mqe_t;
+    }
+    if (L == 0) {
+        wres[2 * wave] = mqe;
+        wres[2 * wave + 1] = mqe_t;
+        if (failed) wres[2 * W + 3] = 1;
+        if (needs32) wres[2 * W + 4] = 1;
+    }
+    __syncthreads();
+    const bool ok16 = wres[2 * W + 4] == 0;
+    if (threadIdx.x == 0 && ok16) {
+        for (int w = 1; w < W; ++w) {
+            const int ob = wres[2 * w], oi = wres[2 * w + 1];
+            const bool take = ob > mqe || (ob == mqe && oi > mqe_t);
+            mqe = take ? ob : mqe;
+            mqe_t = take ? oi : mqe_t;
+        }
+        const int rm = wres[2 * W], rd = wres[2 * W + 1], rj = wres[2 * W + 2];
+        const bool row_wins = rm > mqe || (rm == mqe && rd < abs(mqe_t - ql));
+        DpRecord r;
+        r.mqe = mqe;
+        r.mqe_t = mqe_t;
+        r.max = row_wins ? rm : mqe;
+        r.max_t = row_wins ? tl : mqe_t;
+        r.max_q = row_wins ? rj : ql;
+        r.seg = row_wins ? ql - rj : 0;
+        r.g_tail = -16; // the coop16 traceback layout
+        r.sps = wres[2 * W + 3] ? -1 : sps;
+        a.rec[slot] = r;
+    }
+    __syncthreads();
+    return ok16;
+}
+
+} // namespace
+
+// grid = pairs of the chunk, block = 64 * W threads: the 16-bit form, and the int32 body for a pair whose window check failed
+__global__ __launch_bounds__(1024) void sw_dp_coop16_kernel(const DpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (!coop16_body(a, smem)) coop32_body(a, smem);
+}
+
+// grid = pairs of the chunk, block = 64 * W threads
+__global__ __launch_bounds__(1024) void sw_dp_coop_kernel(const DpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    coop32_body(a, smem);
+}
+
 int coop_lds_bytes(int sps_cap, int waves_per_block)
 {
-    return coop_query_bytes(sps_cap) + waves_per_block * (RING_COLS * 8 + 8 + 8) + 16;
+    return coop_query_bytes(sps_cap) + waves_per_block * (RING_COLS * 8 + 8 + 8) + 32;
+}
+
+// Is the 16-bit form worth trying for these (normalised) parameters?  The 64 PEs of a half-stripe span about
+// 64 * (match + 2e) (+ 2(o - e)); with the window check's margins that must stay inside 16 bits, else every pair would only
+// fall back.  (Exactness never depends on this estimate: the kernel checks the real window.)
+// Can the kernel run at all: its packed constants and the margins of the window check must fit 16 bits
+bool coop16_possible(int match, int mismatch, int gopen, int gext)
+{
+    if (match <= 0 || mismatch > match || gext < 0 || gopen < gext || match > 4000 || mismatch < -4000 || gopen > 4000 || gext > 4000) return false;
+    return coop16_below(match, mismatch, gopen, gext) + coop16_above(match, gopen, gext) <= 60000;
+}
+bool coop16_worthwhile(int match, int mismatch, int gopen, int gext)
+{
+    if (!coop16_possible(match, mismatch, gopen, gext)) return false;
+    const int margin = coop16_below(match, mismatch, gopen, gext) + coop16_above(match, gopen, gext);
+    return 64 * (match + 2 * gext) + 2 * (gopen - gext) + margin <= 60000;
+}
+
+hipError_t launch_dp_coop16(const DpArgs &a, int waves_per_block, hipStream_t stream)
+{
+    const int lds = coop_lds_bytes(a.sps_cap, waves_per_block);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_dp_coop16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(sw_dp_coop16_kernel, dim3((unsigned)a.count), dim3(64 * waves_per_block), lds, stream, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_dp_coop(const DpArgs &a, int waves_per_block, hipStream_t stream)

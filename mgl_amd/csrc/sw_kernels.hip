@@ -466,9 +466,9 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
     }
 
     TbView view;
-    view.base = a.tb + (size_t)(a.packed16 == 2 ? slot >> 7 : a.packed16 ? slot >> 1 : slot) * a.tb_stride_words;
+    view.base = a.tb + (size_t)(a.packed16 == 2 ? slot >> 7 : a.packed16 == 1 ? slot >> 1 : slot) * a.tb_stride_words;
     view.set_schedule(r, ql, a.rows_per_stripe);
-    view.packed16 = a.packed16;
+    view.packed16 = TbView::layout_of(a.packed16, r);
     view.half = (int)(slot & 1);
     view.lane = (int)((slot >> 1) & 63);
     view.ql = a.uni_ql;
@@ -559,6 +559,80 @@ struct WaveMoves {
     }
 };
 
+// The same walk over the layout of sw_dp_coop16_kernel: a block is 16 steps of a 128-row double stripe, lane l holds the
+// flags of PE l (low bytes) and PE 64 + l (high bytes); the block below is the same double stripe's previous 16 steps.
+struct WaveMoves16 {
+    const uint4 *base; // this pair's traceback, as [block][lane] x 16 bytes
+    int bps, L;        // blocks per double stripe
+    int cur_blk, nxt_blk;
+    uint4 cur, nxt;
+    __device__ __forceinline__ uint4 load(int blk) const { return base[(size_t)blk * 64 + L]; }
+    __device__ __forceinline__ void init(const uint32_t *words, int sps, int lane)
+    {
+        base = reinterpret_cast<const uint4 *>(words);
+        bps = sps >> 4;
+        L = lane;
+        cur_blk = nxt_blk = -1;
+        cur = nxt = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __device__ __forceinline__ static unsigned dword_of(const uint4 &v, int d) { return d == 0 ? v.x : d == 1 ? v.y : d == 2 ? v.z : v.w; }
+    __device__ __forceinline__ static unsigned nibble(unsigned w, int h, int s)
+    {
+        const int t2 = (s & 3) * 2;
+        const unsigned be = (w >> (8 * h)) >> t2, bf = (w >> (16 + 8 * h)) >> t2;
+        return ((bf >> 1) & 1u) | (((be >> 1) & 1u) << 1) | ((bf & 1u) << 2) | ((be & 1u) << 3);
+    }
+    __device__ __forceinline__ unsigned cell(int i, int j)
+    {
+        const int r = i - 1;
+        const int pe = r & 127, s = j + pe;
+        const int blk = (r >> 7) * bps + (s >> 4);
+        if (blk != cur_blk) {
+            cur = blk == nxt_blk ? nxt : load(blk);
+            cur_blk = blk;
+            nxt_blk = blk - 1;
+            if (nxt_blk >= 0) nxt = load(nxt_blk);
+        }
+        const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)dword_of(cur, (s >> 2) & 3), pe & 63);
+        return nibble(w, pe >> 6, s);
+    }
+    __device__ __forceinline__ int at(int i, int j)
+    {
+        const unsigned c = cell(i, j);
+        if (c & 2u) {
+            int n = 1;
+            for (int r = i - 1; r >= 1 && !(cell(r, j) & 4u); --r) ++n;
+            return n;
+        }
+        if (c & 1u) {
+            int n = 1;
+            for (int q = j - 1; q >= 1 && !(cell(i, q) & 8u); --q) ++n;
+            return -n;
+        }
+        return 0;
+    }
+    // cell k of a diagonal run from (i, j) is PE pe0 - k at step s0 - 2k: lane (pe0 - k) mod 64 tests it in its own registers
+    // (`cur` holds 8 cells of the run, `nxt` 8 more); the ballot, rotated so that k = 0 is the top bit, gives the first stop
+    __device__ __forceinline__ int diag_run(int i, int j)
+    {
+        const int r = i - 1;
+        const int pe0 = r & 127, s0 = j + pe0;
+        if ((r >> 7) * bps + (s0 >> 4) != cur_blk) return 0;
+        const int l0 = pe0 & 63;
+        const int k = (l0 - L) & 63;
+        const int pe = pe0 - k, s = s0 - 2 * k;
+        const bool inside = k <= pe0 && k <= j - 1 && k <= i - 1; // (then s >= 1)
+        const int blk = (r >> 7) * bps + (s >> 4);
+        const bool in_cur = blk == cur_blk, in_nxt = blk == nxt_blk && nxt_blk >= 0;
+        const unsigned w = dword_of(in_cur ? cur : nxt, (s >> 2) & 3);
+        const bool is_diag = (nibble(w, (pe >> 6) & 1, s) & 3u) == 0u; // neither F > diag nor E > S (sw.cpp:60-71)
+        const bool ok = inside && (in_cur || in_nxt) && is_diag;
+        const unsigned long long stop = __builtin_amdgcn_ballot_w64(!ok);
+        const unsigned long long rot = l0 == 63 ? stop : (stop << (63 - l0)) | (stop >> (l0 + 1)); // bit 63 - k = cell k
+        return rot == 0ull ? 64 : __builtin_clzll(rot);
+    }
+};
+
 __global__ __launch_bounds__(256) void sw_traceback_wave_kernel(const TbArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -582,9 +656,6 @@ __global__ __launch_bounds__(256) void sw_traceback_wave_kernel(const TbArgs a)
         return;
     }
 
-    WaveMoves mv;
-    mv.init(a.tb + (size_t)slot * a.tb_stride_words, r.sps, a.rows_per_stripe, lane);
-
     CigarWriter cw;
     cw.slot = slot_out;
     cw.binary = a.binary_cigar;
@@ -593,7 +664,16 @@ __global__ __launch_bounds__(256) void sw_traceback_wave_kernel(const TbArgs a)
     cw.need = 0;
     cw.store = (lane == 0);
 
-    const int off = walk_and_write(mv, tl, ql, a.strategy, r.max_t, r.max_q, r.mqe_t, r.seg, cw);
+    int off;
+    if (TbView::layout_of(a.packed16, r) == 3) {
+        WaveMoves16 mv;
+        mv.init(a.tb + (size_t)slot * a.tb_stride_words, r.sps, lane);
+        off = walk_and_write(mv, tl, ql, a.strategy, r.max_t, r.max_q, r.mqe_t, r.seg, cw);
+    } else {
+        WaveMoves mv;
+        mv.init(a.tb + (size_t)slot * a.tb_stride_words, r.sps, a.rows_per_stripe, lane);
+        off = walk_and_write(mv, tl, ql, a.strategy, r.max_t, r.max_q, r.mqe_t, r.seg, cw);
+    }
 
     // the text was built right-aligned by lane 0: move it to the front and zero the rest, 64 bytes at a time
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -661,7 +741,7 @@ __global__ __launch_bounds__(256) void sw_expand_kernel(const uint32_t *tbw, con
     TbView tb;
     tb.base = tbw;
     tb.set_schedule(rec[0], ql, rows);
-    tb.packed16 = packed16;
+    tb.packed16 = TbView::layout_of(packed16, rec[0]);
     tb.half = half;
     tb.lane = lane;
     tb.ql = ql;
@@ -826,7 +906,7 @@ hipError_t launch_scores_only(const TbArgs &a, hipStream_t stream)
 
 hipError_t launch_traceback(const TbArgs &a, hipStream_t stream)
 {
-    if (!a.packed16 && a.rows_per_stripe == 64) {
+    if ((!a.packed16 && a.rows_per_stripe == 64) || a.packed16 == 3) {
         // long reads: one wave per pair (the path walk is the latency, not the lane count)
         hipLaunchKernelGGL(sw_traceback_wave_kernel, dim3((unsigned)a.count), dim3(64), 0, stream, a);
         return hipGetLastError();

@@ -20,7 +20,8 @@ struct TbView {
     const uint32_t *base; // this pair's (int32 layout) or this group's (packed16 layout) traceback words
     int sps;
     int rows;                 // target rows per stripe (= lanes per pair) of the fill kernel: 16 or 64; lane layout: rows per strip
-    int packed16, half;       // packed16: 0 int32 layout, 1 sw_dp16_kernel, 2 sw_dp16_lane_kernel (base = the WAVE's words)
+    int packed16, half;       // packed16: 0 int32 layout, 1 sw_dp16_kernel, 2 sw_dp16_lane_kernel (base = the WAVE's words),
+                              // 3 sw_dp_coop16_kernel (per pair; a pair the kernel redid in 32 bits has layout 0: layout_of)
     int lane = 0, ql = 0;     // lane layout: this pair's lane in its wave, the batch's query length
     int g_tail, nc, sps_tail; // packed16 only: stripes >= nc are stand-alone, starting at global step g_tail
     __device__ __forceinline__ void set_schedule(const DpRecord &r, int ql, int rows_per_stripe)
@@ -31,10 +32,21 @@ struct TbView {
         nc = r.g_tail > 0 ? (r.g_tail - 16) / r.sps : 0;
         sps_tail = sps_for_rows(ql, 16);
     }
+    // the layout of ONE pair of a launch whose layout is `launch_layout`: sw_dp_coop16_kernel marks the pairs it kept in 16 bits
+    __device__ __forceinline__ static int layout_of(int launch_layout, const DpRecord &r) { return launch_layout == 3 && r.g_tail != -16 ? 0 : launch_layout; }
     // nibble of cell (i, j), 1-based: bit0 F>diag, bit1 E>max(diag,F), bit2 E opened, bit3 F opened
     __device__ __forceinline__ unsigned cell(int i, int j) const
     {
         const int r = i - 1;
+        if (packed16 == 3) {
+            // sw_dp_coop.hip, 16-bit form: [128-row double stripe][16 steps][lane] uint4; PE = row within the double stripe,
+            // lane = PE mod 64, half = PE / 64, step = column + PE; dword = 4 steps, bytes as in the packed16 layout
+            const int pe = r & 127, s = j + pe, h = pe >> 6;
+            const uint32_t w = base[(((size_t)(r >> 7) * (sps >> 4) + (s >> 4)) * 64 + (pe & 63)) * 4 + ((s >> 2) & 3)];
+            const int t2 = (s & 3) * 2;
+            const unsigned be = (w >> (8 * h)) >> t2, bf = (w >> (16 + 8 * h)) >> t2;
+            return ((bf >> 1) & 1u) | (((be >> 1) & 1u) << 1) | ((bf & 1u) << 2) | ((be & 1u) << 3);
+        }
         if (packed16 == 2) {
             // sw_dp16_lane.hip: [strip][column][rows/16][lane] uint4, dword = four rows, bytes as in the packed16 layout
             const int sh = rows == 32 ? 5 : 4; // rows is 16 or 32

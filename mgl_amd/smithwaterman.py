@@ -155,12 +155,19 @@ class MicrosoftSmithWaterman:
                                                  btr.ctypes.data_as(C.POINTER(C.c_int32))), self._ctx)
         return btr
 
+    def slot_layout(self, slot):
+        """Traceback layout of pair ``slot`` of the last chunk (0 int32, 1 packed16, 2 lane16, 3 coop16)."""
+        v = C.c_int(-1)
+        _check(_lib.lib().mgl_sw_ctx_slot_layout(self._ensure(), slot, C.byref(v)), self._ctx)
+        return v.value
+
     # -- extras the reference keeps internal -----------------------------------------------
     def set_workspace(self, nbytes):
         _check(_lib.lib().mgl_sw_ctx_set_workspace(self._ensure(), int(nbytes)))
 
     def set_precision(self, bits):
-        """0 = per batch (packed int16 when possible), 32 = always the int32 fill kernel."""
+        """0 = per batch (packed int16 when possible), 32 = always the int32 fill kernels, 16 = like 0 but the self-checking
+        16-bit long-read kernel is tried whenever its constants fit."""
         _check(_lib.lib().mgl_sw_ctx_set_precision(self._ensure(), int(bits)))
 
     def set_carry_memory(self, mode):
