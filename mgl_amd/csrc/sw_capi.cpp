@@ -294,8 +294,8 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         if (ctx->precision != 32 && coop16_env != 0 && (ctx->precision == 16 ? coop16_possible(match, mismatch, gopen, gext) : coop16_worthwhile(match, mismatch, gopen, gext))) {
             const int sps16 = coop16_sps_for(max_ql), dstripes = (max_tl + 127) / 128;
             int w16 = coop_waves;
-            while (w16 > 2 && (w16 > dstripes || coop_lds_bytes(sps16, w16) > 160 * 1024)) --w16;
-            if (coop_lds_bytes(sps16, w16) <= 160 * 1024) {
+            while (w16 > 2 && (w16 > dstripes || coop16_lds_bytes(sps16, w16) > 160 * 1024)) --w16;
+            if (coop16_lds_bytes(sps16, w16) <= 160 * 1024) {
                 coop16 = true;
                 coop_waves = w16;
                 sps_cap = sps16;

@@ -141,7 +141,7 @@ __host__ __device__ inline int64_t lane_scratch_bytes(int tl, int ql, int rows)
 __host__ __device__ inline int coop_sps_for(int ql) { return (ql + 64 + 31) & ~31; }
 // 16-bit form (two 64-row half-stripes per wave): steps per 128-row double stripe; traceback dwords per pair:
 // [double stripe][16 steps][lane] uint4
-__host__ __device__ inline int coop16_sps_for(int ql) { return (ql + 128 + 31) & ~31; }
+__host__ __device__ inline int coop16_sps_for(int ql) { return (ql + 129 + 31) & ~31; } // PE 127 reaches column ql one step before the last
 __host__ __device__ inline int64_t tb_words_coop16(int tl, int ql) { return (int64_t)((tl + 127) >> 7) * (coop16_sps_for(ql) >> 4) * 64 * 4; }
 __host__ __device__ inline int coop_query_bytes(int sps_cap) { return (sps_cap + 192 + 15) & ~15; } // 64 + ql + slack
 __host__ __device__ inline int coop_wrap_cols(int sps_cap) { return sps_cap + 192; }                // 8 bytes each, per pair
@@ -160,6 +160,7 @@ int coop_lds_bytes(int sps_cap, int waves_per_block);
 hipError_t launch_dp_coop(const DpArgs &a, int waves_per_block, hipStream_t stream);
 bool coop16_possible(int match, int mismatch, int gopen, int gext);   // constants and margins fit 16 bits
 bool coop16_worthwhile(int match, int mismatch, int gopen, int gext); // ... and a typical score window does too
+int coop16_lds_bytes(int sps_cap, int waves_per_block);
 hipError_t launch_dp_coop16(const DpArgs &a, int waves_per_block, hipStream_t stream); // a.sps_cap = coop16_sps_for(max_ql)
 hipError_t launch_traceback(const TbArgs &a, hipStream_t stream);
 hipError_t launch_scores_only(const TbArgs &a, hipStream_t stream); // DpRecord -> ScoreMax, no path walk

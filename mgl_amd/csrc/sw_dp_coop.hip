@@ -403,24 +403,24 @@ __device__ __forceinline__ void coop32_body(const DpArgs &a, unsigned char *smem
 }
 
 // =====================================================================================================================
-// 16-bit form of the long-read kernel: TWO 64-row half-stripes per wave, packed in the low / high half of every register.
+// 16-bit form of the long-read kernel: 128 target rows per wave, two per lane, packed in the low / high half of every register.
 //
-// A wave runs a "double stripe" of 128 target rows as 128 processing elements (PE p = row k*128 + p + 1 at column s - p in
-// step s): PEs 0..63 are the low halves of lanes 0..63, PEs 64..127 the high halves.  One DPP move shifts both halves to
-// the next lane; at the seam PE 63 -> PE 64 the low half of lane 63 becomes the high-half input of lane 0.  Scores reach
-// 2 * 10^6 on 10 kb reads, so a half-stripe is held relative to a BASELINE of its own (B_lo, B_hi: wave-uniform int32):
-//     stored16 = X[i][j] + (i + j) * e - B_half                      (X = H, E or F; the int32 kernel's form minus B)
-// and the baseline is moved every 32 steps.  Exactness does not rest on an a-priori range claim: at every move the wave
-// reduces the exact minimum and maximum of H over its 64 PEs per half and checks that the window they span, widened by
-// what 32 more steps can add, fits 16 bits; the widening uses only one-step facts of the recurrence (sw.cpp:60-93), in
+// A wave runs a "double stripe" of 128 target rows as 128 processing elements (PE p = row k*128 + p + 1, at column s - p in
+// step s); lane l holds PE 2l in the low halves of its registers and PE 2l+1 in the high halves.  Handing H and E' to the
+// next PE is then one DPP move plus one v_alignbit: the new low half is the high half of the lane before, the new high
+// half is the lane's own low half; PE 0 takes the row above from the carry ring, PE 127 (lane 63, high) feeds the next
+// wave's.  Scores reach 2 * 10^6 on 10 kb reads, so a wave keeps its values relative to a BASELINE B (wave-uniform int32):
+//     stored16 = X[i][j] + (i + j) * e - B                           (X = H, E or F; the int32 kernel's form minus B)
+// and moves B every 32 steps.  Exactness does not rest on an a-priori range claim: at every move the wave reduces the exact
+// minimum and maximum of H over its 128 PEs and checks that the window they span, widened by what 34 more steps can add
+// (coop16_below / coop16_above), fits 16 bits; the widening uses only one-step facts of the recurrence (sw.cpp:60-93), in
 // stored units and for ANY sequences -- the padded rows > tl and columns > ql are cells of a larger matrix and obey them too:
 //     E'[i+1][j], F'[i][j+1] in [H - (o-e), H];   H[i-1][j] (the next step's diagonal) in [H - (match+o+e), H + o];
-//     per step the maximum over a half rises by at most match + 2e (a diagonal step), its minimum falls by at most o - e
-//     (H' >= F), and the two intermediates go at most max(o - e, |mismatch + 2e|) below.
+//     per step the maximum rises by at most match + o + e (match + 2e inside the wave; the larger figure covers PE 0, whose
+//     inputs come from outside: H[i][j+1] <= H[i][j] + match + o + e for any cell), the minimum falls by at most o - e.
 // If the check ever fails the pair is marked and the WORKGROUP redoes it with the int32 body (coop32_body) -- never a wrong
-// answer.  For GATK parameters the 64 PEs span <= 63 * (match + 2e) + 2 * (o - e) ~ 14.5 k (measured 14.7 k on adversarial
-// pairs) against a limit of ~49 k, so the fall-back is for exotic parameter sets; the host does not even try when
-// 64 * (match + 2e) + 34 * (match + o + e) cannot fit.
+// answer.  For GATK parameters the 128 PEs span <= 127 * (match + 2e) + 2 * (o - e) ~ 28.7 k against a limit of ~39 k, so the
+// fall-back is for other parameter sets; the host does not try when that estimate cannot fit (coop16_worthwhile).
 // Hand-over between waves, the HBM hop, tags and counters are those of the int32 kernel, in true (int32) values: the
 // consumer subtracts its own baseline.  Traceback layout ("coop16", DpRecord.g_tail == -16): per double stripe and 16
 // steps one uint4 per lane, dword = 4 steps in the byte layout of sw_dp16.hip (byte0 = low half {E>S, F opened}, byte1 =
@@ -460,12 +460,11 @@ __device__ __forceinline__ unsigned c_and_or(unsigned a, unsigned k, unsigned b)
     return r;
 }
 
-// What the window check adds below the minimum and above the maximum of H found when the baselines move.  Between two
+// What the window check adds below the minimum and above the maximum of H found when the baseline moves.  Between two
 // moves lie 32 steps; the registers also hold values up to two steps old, hence 34:
-//   below: 34 steps of falling (o-e each), the diagonal input (match+o+e) and the E' input of PE 0 / PE 64 another
+//   below: 34 steps of falling (o-e each), the diagonal input (match+o+e) and the E' input of PE 0 another
 //          (match+o+e) + (o-e) under the H they feed, and the intermediate diag = hup + (mismatch + 2e)
-//   above: 34 steps of rising -- match+2e inside a half, but match+o+e for PE 0 / PE 64 whose inputs come from outside the
-//          half (H[i][j+1] <= H[i][j] + match + o + e for any cell) --, the diagonal input (o) and diag = hup + match + 2e
+//   above: 34 steps of rising (match+o+e, see above), the diagonal input (o) and diag = hup + match + 2e
 __host__ __device__ inline int coop16_below(int match, int mismatch, int gopen, int gext)
 {
     const int mis2 = mismatch + 2 * gext;
@@ -474,73 +473,71 @@ __host__ __device__ inline int coop16_below(int match, int mismatch, int gopen, 
 __host__ __device__ inline int coop16_above(int match, int gopen, int gext) { return 34 * (match + gopen + gext) + gopen + (match + 2 * gext) + 64; }
 
 struct Coop16Lane {
-    unsigned h_prev, e_prev, hup, f; // low | high half-stripe, stored form
+    unsigned h_prev, e_prev, hup, f; // PE 2l | PE 2l+1, stored form
     unsigned w[3];                   // traceback dwords of the last three 4-step blocks
-    int best_lo, best_lo_i, best_hi, best_hi_i; // last-column maxima of this lane's low / high rows (true scores; ties: later row)
+    unsigned keep_h, keep_e;         // PE 127's column of the previous block's last step (ring stores go four aligned columns at a time)
+    int best_lo, best_lo_i, best_hi, best_hi_i; // last-column maxima of this lane's two rows (true scores)
     int rm, rd, rj;                  // the double stripe that holds row tl: running best of the last row
 };
 
 struct Coop16Consts {
     unsigned delta, one, o_e, k2; // packed (both halves equal): mismatch - match, 1, o - e, match + 2e
     unsigned k12[4], k34[4];      // SGPR bit masks of the four steps of a traceback dword
+    unsigned qsel[4];             // v_perm selectors: the query bytes of step u for the low (byte u+1) and high (byte u) PE
     int o_e32, gopen, gext, tl, ql;
-    int floor16, check_margin;    // where a re-based half puts its minimum; what the window check adds to the spread
+    int floor16, check_margin;    // where a move of the baseline puts the minimum; what the window check adds to the spread
 };
 
-// wave-wide packed min and max (per 16-bit half) of x, the same in every lane
-__device__ __forceinline__ void wave_minmax_pk(unsigned x, unsigned &mn, unsigned &mx)
+// wave-wide minimum and maximum over both halves of x in all lanes (wave-uniform)
+__device__ __forceinline__ void wave_minmax_pk(unsigned x, int &mn_out, int &mx_out)
 {
-    mn = mx = x;
+    unsigned mn = x, mx = x;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
         const unsigned a = (unsigned)__shfl_xor((int)mn, m), b = (unsigned)__shfl_xor((int)mx, m);
         mn = c_pk_min(mn, a);
         mx = c_pk_max(mx, b);
     }
+    const unsigned smn = (unsigned)__builtin_amdgcn_readfirstlane((int)mn), smx = (unsigned)__builtin_amdgcn_readfirstlane((int)mx);
+    mn_out = min(c_lo16(smn), c_hi16(smn));
+    mx_out = max(c_lo16(smx), c_hi16(smx));
 }
 
-// 32 anti-diagonal steps of one 128-row double stripe.  EDGE / OUT as in coop_group32.  B_lo / B_hi: the baselines.
+// 32 anti-diagonal steps of one 128-row double stripe.  EDGE / OUT as in coop_group32.  B: the baseline.
 template <bool EDGE, int OUT>
 __device__ __forceinline__ void coop16_group32(Coop16Lane &st, int4 &rA, int4 &rB, const int2 *ring_in, int2 *ring_out,
-                                               unsigned long long *wrap_out, const unsigned tag_out, const unsigned *qrd_lo,
-                                               const unsigned *qrd_hi, unsigned &qlo_lo, unsigned &qlo_hi, const int q_shift,
-                                               const unsigned tt, const int s_begin, const int L, const int hb_lo, const int hb_hi,
-                                               const int qcap_lo, const int qcap_hi, const int row_lo, const int B_lo, const int B_hi,
-                                               const Coop16Consts &c, const bool writer, const int last_half, uint4 *&tbp)
+                                               unsigned long long *wrap_out, const unsigned tag_out, const unsigned *qrd, unsigned &q_lo,
+                                               const unsigned tt, const int s_begin, const int L, const unsigned hb, const int qcap_lo,
+                                               const int qcap_hi, const int row_lo, const int B, const Coop16Consts &c, const bool writer,
+                                               const int last_half, uint4 *&tbp, const int vzero)
 {
-    const int dB = B_lo - B_hi;
+    const unsigned negB16 = 0u - ((unsigned)B << 16);
 #pragma unroll 1
     for (int b = 0; b < 8; ++b) {
         const int s0 = s_begin + 4 * b;
-        unsigned wnew = 0u;
-        // bases of the four columns of this block for both halves: bytes (s0 - L + 127) .. +3 and (s0 - L + 63) .. +3 of the padded query
-        const unsigned qh_lo = qrd_lo[(s0 >> 2) + 1], qh_hi = qrd_hi[(s0 >> 2) + 1];
-        const unsigned qw_lo = __builtin_amdgcn_alignbyte(qh_lo, qlo_lo, (unsigned)q_shift);
-        const unsigned qw_hi = __builtin_amdgcn_alignbyte(qh_hi, qlo_hi, (unsigned)q_shift);
-        qlo_lo = qh_lo;
-        qlo_hi = qh_hi;
-        const int4 *nxt = reinterpret_cast<const int4 *>(ring_in + ((s0 + 4) & RING_MASK));
+        // the five query bytes of this block: columns s0 - 2L - 1 (high PE, first step) .. s0 - 2L + 3 (low PE, last step) start a dword
+        // of this lane's copy of the query (even lanes read the copy shifted by two bytes)
+        const unsigned q_hi = qrd[(s0 >> 2) + 1];
+        unsigned wnew = 0u, oh[4], oe[4];
+        // carry of the NEXT block (every lane reads the same two addresses; `vzero` keeps the values in vector registers)
+        const int4 *nxt = reinterpret_cast<const int4 *>(ring_in + ((s0 + 4) & RING_MASK)) + vzero;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            int rh = u == 0 ? rA.x : u == 1 ? rA.z : u == 2 ? rB.x : rB.z;
-            int re = u == 0 ? rA.y : u == 1 ? rA.w : u == 2 ? rB.y : rB.w;
+            const int rh = u == 0 ? rA.x : u == 1 ? rA.z : u == 2 ? rB.x : rB.z;
+            const int re = u == 0 ? rA.y : u == 1 ? rA.w : u == 2 ? rB.y : rB.w;
             if (u == 2) rA = nxt[0];
-            // ---- what PE 0 (carry of the row above, minus this half's baseline) and PE 64 (PE 63 of the last step, re-based) take in
-            const unsigned s_h63 = (unsigned)__builtin_amdgcn_readlane((int)st.h_prev, 63);
-            const unsigned s_e63 = (unsigned)__builtin_amdgcn_readlane((int)st.e_prev, 63);
-            unsigned in_h_lo = (unsigned)(rh - B_lo), in_e_lo = (unsigned)(re - B_lo);
+            // ---- shift H and E' by one PE; PE 0 takes the carry of the row above, minus the baseline
+            unsigned in_h = ((unsigned)rh << 16) + negB16, in_e = ((unsigned)re << 16) + negB16;
             if (EDGE && s0 + u > c.ql) {
                 // PE 0 is past the last column: the carry row ends there; the cells it keeps computing feed nothing, but they must
                 // stay inside the window, so they see their own last values as the row above
-                in_h_lo = (unsigned)__builtin_amdgcn_readlane((int)st.h_prev, 0);
-                in_e_lo = (unsigned)__builtin_amdgcn_readlane((int)st.e_prev, 0);
+                in_h = st.h_prev << 16;
+                in_e = st.e_prev << 16;
             }
-            const unsigned in_h = (in_h_lo & 0xffffu) | ((s_h63 + (unsigned)dB) << 16);
-            const unsigned in_e = (in_e_lo & 0xffffu) | ((s_e63 + (unsigned)dB) << 16);
-            const unsigned hup_new = (unsigned)wave_shr1((int)in_h, (int)st.h_prev);
-            const unsigned ein = (unsigned)wave_shr1((int)in_e, (int)st.e_prev);
+            const unsigned hup_new = __builtin_amdgcn_alignbit(st.h_prev, (unsigned)wave_shr1((int)in_h, (int)st.h_prev), 16);
+            const unsigned ein = __builtin_amdgcn_alignbit(st.e_prev, (unsigned)wave_shr1((int)in_e, (int)st.e_prev), 16);
             // ---- the cell, both halves (sw_dp16.hip's cell16)
-            const unsigned q = __builtin_amdgcn_perm(qw_hi, qw_lo, 0x0c040c00u + 0x00010001u * (unsigned)u);
+            const unsigned q = __builtin_amdgcn_perm(q_hi, q_lo, c.qsel[u]);
             const unsigned m = c_pk_min_u(q ^ tt, c.one);
             const unsigned sc = c_pk_mad(m, c.delta, c.k2);
             const unsigned diag = c_pk_add(st.hup, sc);
@@ -552,43 +549,41 @@ __device__ __forceinline__ void coop16_group32(Coop16Lane &st, int4 &rA, int4 &r
             const unsigned d1 = c_pk_sub_sat(diag, st.f), d2 = c_pk_sub_sat(sm, ein), d3 = c_pk_sub_sat(ein, open), d4 = c_pk_sub_sat(st.f, open);
             const unsigned p12 = __builtin_amdgcn_perm(d1, d2, 0x0b0a0908u), p34 = __builtin_amdgcn_perm(d3, d4, 0x0b0a0908u);
             wnew = c_and_or(p34, c.k34[u], u == 0 ? (p12 & c.k12[0]) : c_and_or(p12, c.k12[u], wnew));
-            const int j_lo = s0 + u - L, j_hi = j_lo - 64; // this lane's columns
+            const int j_lo = s0 + u - 2 * L, j_hi = j_lo - 1; // this lane's columns
             if (EDGE) {
-                // column <= 0: the border values H[i][0], F[i][1] (sw.cpp:24,38,47-49), relative to the half's baseline
-                const unsigned hb = c_pack2(hb_lo - B_lo, hb_hi - B_hi);
-                const unsigned hbf = c_pk_sub(hb, c.o_e);
+                // column <= 0: the border values H[i][0], F[i][1] (sw.cpp:24,38,47-49), relative to the baseline
+                const unsigned hbr = c_pk_sub(hb, c_pack2(B, B));
+                const unsigned hbf = c_pk_sub(hbr, c.o_e);
                 const unsigned msk = (j_lo <= 0 ? 0x0000ffffu : 0u) | (j_hi <= 0 ? 0xffff0000u : 0u);
-                h = (hb & msk) | (h & ~msk);
+                h = (hbr & msk) | (h & ~msk);
                 fo = (hbf & msk) | (fo & ~msk);
                 // last column of this lane's rows (sw.cpp:100-104: >= so the later row wins): true scores
-                const int sc_lo = c_lo16(h) + B_lo - (row_lo + c.ql) * c.gext, sc_hi = c_hi16(h) + B_hi - (row_lo + 64 + c.ql) * c.gext;
+                const int sc_lo = c_lo16(h) + B - (row_lo + c.ql) * c.gext, sc_hi = c_hi16(h) + B - (row_lo + 1 + c.ql) * c.gext;
                 const bool t_lo = j_lo == qcap_lo && sc_lo >= st.best_lo, t_hi = j_hi == qcap_hi && sc_hi >= st.best_hi;
                 st.best_lo = t_lo ? sc_lo : st.best_lo;
                 st.best_lo_i = t_lo ? row_lo : st.best_lo_i;
                 st.best_hi = t_hi ? sc_hi : st.best_hi;
-                st.best_hi_i = t_hi ? row_lo + 64 : st.best_hi_i;
+                st.best_hi_i = t_hi ? row_lo + 1 : st.best_hi_i;
             }
             if (OUT == OUT_LAST) {
                 // the half that holds row tl: sw.cpp:116-127 in column order -- better score, or same score closer to the diagonal
                 const int j = last_half ? j_hi : j_lo;
                 const int d = abs(c.tl - j);
-                const int score = (last_half ? c_hi16(h) + B_hi : c_lo16(h) + B_lo) - (c.tl + j) * c.gext;
+                const int score = (last_half ? c_hi16(h) : c_lo16(h)) + B - (c.tl + j) * c.gext;
                 const bool take = j >= 1 && j <= c.ql && (score > st.rm || (score == st.rm && d < st.rd));
                 st.rm = take ? score : st.rm;
                 st.rd = take ? d : st.rd;
                 st.rj = take ? j : st.rj;
-            } else if (!EDGE || s0 + u >= 127) {
+            } else if (OUT == OUT_WRAP) {
                 // PE 127 (lane 63, high half) finishes column s - 127 of the double stripe's last row: hand it on in true values
                 const int col = s0 + u - 127;
-                const int ht = c_hi16(h) + B_hi;
-                if (OUT == OUT_RING) {
-                    if (writer) ring_out[col & RING_MASK] = make_int2(ht, c_hi16(eo) + B_hi);
-                } else {
-                    const unsigned diff = (unsigned)(c_hi16(h) - c_hi16(eo)) & 0xffffu; // 0 <= H - E' <= o - e
-                    if (writer)
-                        __hip_atomic_store(wrap_out + col, (unsigned long long)(unsigned)ht | ((unsigned long long)(diff | tag_out) << 32),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                const unsigned diff = (unsigned)(c_hi16(h) - c_hi16(eo)) & 0xffffu; // 0 <= H - E' <= o - e
+                if (writer && (!EDGE || col >= 0))
+                    __hip_atomic_store(wrap_out + col, (unsigned long long)(unsigned)(c_hi16(h) + B) | ((unsigned long long)(diff | tag_out) << 32),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                oh[u] = h;
+                oe[u] = eo;
             }
             st.h_prev = h;
             st.e_prev = eo;
@@ -596,7 +591,19 @@ __device__ __forceinline__ void coop16_group32(Coop16Lane &st, int4 &rA, int4 &r
             st.f = fo;
         }
         rB = nxt[1];
-        // the dwords of 16 steps rotate through three registers (a dynamic register index would go through scratch)
+        q_lo = q_hi;
+        if (OUT == OUT_RING) {
+            // columns s0 - 128 .. s0 - 125 of the last row: the previous block's last step and three of this block's, one aligned 32 bytes
+            if (writer && (!EDGE || s0 >= 128)) {
+                int4 *dst = reinterpret_cast<int4 *>(ring_out + ((s0 - 128) & RING_MASK));
+                dst[0] = make_int4(c_hi16(st.keep_h) + B, c_hi16(st.keep_e) + B, c_hi16(oh[0]) + B, c_hi16(oe[0]) + B);
+                dst[1] = make_int4(c_hi16(oh[1]) + B, c_hi16(oe[1]) + B, c_hi16(oh[2]) + B, c_hi16(oe[2]) + B);
+            }
+            st.keep_h = oh[3];
+            st.keep_e = oe[3];
+        }
+        // the dwords of 16 steps rotate through three registers (a dynamic register index would go through scratch, and
+        // sixteen steps unrolled spill: the compiler hoists the ring loads of all four blocks)
         if ((b & 3) == 3) {
             *tbp = make_uint4(st.w[0], st.w[1], st.w[2], wnew); // 1 KB per wave
             tbp += 64;
@@ -625,10 +632,11 @@ __device__ __forceinline__ bool coop16_body(const DpArgs &a, unsigned char *smem
     const int S = (sps + 64 + RING_MASK) & ~RING_MASK;  // sequence numbers per double stripe
     const int main_lo = 128, main_hi = ql & ~31;        // groups inside [main_lo, main_hi) touch no edge
 
-    // LDS: query bytes (128 zero bytes, q, zeros) | W rings | produced[W] | consumed[W] | per-wave results
+    // LDS: two copies of the query bytes (128 zero bytes, q, zeros; the second shifted by two bytes) | W rings | produced[W] |
+    // consumed[W] | per-wave results
     const int qbytes = coop_query_bytes(a.sps_cap);
     unsigned char *qbuf = smem;
-    int2 *rings = reinterpret_cast<int2 *>(smem + qbytes);
+    int2 *rings = reinterpret_cast<int2 *>(smem + 2 * qbytes);
     int *produced = reinterpret_cast<int *>(rings + (size_t)W * RING_COLS);
     int *consumed = produced + W;
     int *wres = consumed + W; // [W][2] last-column best, then [5] last row {rm, rd, rj, failed, needs32}
@@ -637,14 +645,18 @@ __device__ __forceinline__ bool coop16_body(const DpArgs &a, unsigned char *smem
     unsigned long long *wrap = reinterpret_cast<unsigned long long *>(a.scratch) + (size_t)slot * wrap_cols;
     {
         unsigned *qz = reinterpret_cast<unsigned *>(qbuf);
-        for (int w = threadIdx.x; w < (qbytes >> 2); w += blockDim.x) qz[w] = 0u;
+        for (int w = threadIdx.x; w < (qbytes >> 1); w += blockDim.x) qz[w] = 0u;
         if ((int)threadIdx.x < 2 * W) produced[threadIdx.x] = 0;
         if (threadIdx.x < 5) wres[2 * W + threadIdx.x] = threadIdx.x == 0 ? NEG_INF : threadIdx.x >= 3 ? 0 : 0x7fffffff;
         if (nds > W)
             for (int x = threadIdx.x; x < wrap_cols; x += blockDim.x) wrap[x] = 0ull; // tag 0 = not written
         __threadfence();
         __syncthreads();
-        for (int x = threadIdx.x; x < ql; x += blockDim.x) qbuf[128 + x] = (unsigned char)a.q.at(q0, x);
+        for (int x = threadIdx.x; x < ql; x += blockDim.x) {
+            const unsigned char ch = (unsigned char)a.q.at(q0, x);
+            qbuf[128 + x] = ch;          // column j at byte 127 + j
+            qbuf[qbytes + 126 + x] = ch; // the same, two bytes earlier
+        }
         __syncthreads();
     }
 
@@ -659,14 +671,14 @@ __device__ __forceinline__ bool coop16_body(const DpArgs &a, unsigned char *smem
     for (int u = 0; u < 4; ++u) {
         c.k12[u] = 0x02020202u << (2 * u);
         c.k34[u] = 0x01010101u << (2 * u);
-        asm volatile("" : "+s"(c.k12[u]), "+s"(c.k34[u]));
+        c.qsel[u] = 0x0c000c00u | (unsigned)(u + 1) | ((unsigned)u << 16);
+        asm volatile("" : "+s"(c.k12[u]), "+s"(c.k34[u]), "+s"(c.qsel[u]));
     }
     c.o_e32 = gopen - gext;
     c.gopen = gopen;
     c.gext = gext;
     c.tl = tl;
     c.ql = ql;
-    // Window bookkeeping: coop16_below / coop16_above, see the header of this section
     const int below = coop16_below(match, a.mismatch, gopen, gext), above = coop16_above(match, gopen, gext);
     c.floor16 = -32768 + below;
     c.check_margin = below + above;
@@ -675,18 +687,21 @@ __device__ __forceinline__ bool coop16_body(const DpArgs &a, unsigned char *smem
     Coop16Lane st;
     st.h_prev = st.e_prev = st.hup = st.f = 0u;
     st.w[0] = st.w[1] = st.w[2] = 0u;
+    st.keep_h = st.keep_e = 0u;
     st.best_lo = st.best_hi = NEG_INF;
     st.best_lo_i = st.best_hi_i = -1;
     st.rm = NEG_INF;
     st.rd = 0x7fffffff;
     st.rj = 0x7fffffff;
     int failed = 0, needs32 = 0; // wave-uniform
+    int vzero = 0;
+    asm volatile("" : "+v"(vzero));
 
-    const int q_shift = (127 - L) & 3;
-    const unsigned *qrd_lo = reinterpret_cast<const unsigned *>(qbuf) + ((127 - L) >> 2); // byte (s - L + 127): column s - L of the low half
-    const unsigned *qrd_hi = reinterpret_cast<const unsigned *>(qbuf) + ((63 - L) >> 2);  // column s - 64 - L of the high half
+    // this lane's query dwords: block s0 starts at byte 128 + s0 - 2L - 2 of the first copy, a multiple of four for odd L; even
+    // lanes read the same bytes two positions earlier in the shifted copy
+    const unsigned *qrd = reinterpret_cast<const unsigned *>(qbuf + ((L & 1) ? 0 : qbytes)) + ((128 - 2 * L - 2 - ((L & 1) ? 0 : 2)) >> 2);
     const bool writer = (L == 63);
-    const int last_lane = (tl - 1) & 63, last_half = ((tl - 1) >> 6) & 1;
+    const int last_lane = ((tl - 1) & 127) >> 1, last_half = (tl - 1) & 1;
     const int b_in = (wave + W - 1) % W, b_out = wave;
     int2 *ring_in = rings + (size_t)b_in * RING_COLS;
     int2 *ring_out = rings + (size_t)b_out * RING_COLS;
@@ -694,7 +709,7 @@ __device__ __forceinline__ bool coop16_body(const DpArgs &a, unsigned char *smem
     for (int k = wave; k < nds; k += W) {
         const bool first = (k == 0), last = (k == nds - 1);
         const int out = last ? OUT_LAST : (wave == W - 1 ? OUT_WRAP : OUT_RING);
-        const int row_lo = k * 128 + 1 + L, row_hi = row_lo + 64;
+        const int row_lo = k * 128 + 1 + 2 * L, row_hi = row_lo + 1;
         const unsigned tt = (unsigned)(row_lo <= tl ? a.t.at(t0, row_lo - 1) : 0) | ((unsigned)(row_hi <= tl ? a.t.at(t0, row_hi - 1) : 0) << 16);
         const int hb_lo = border(row_lo, gopen, gext, indel) + row_lo * gext, hb_hi = border(row_hi, gopen, gext, indel) + row_hi * gext; // column 0
         const int qcap_lo = row_lo <= tl ? ql : NEG_INF, qcap_hi = row_hi <= tl ? ql : NEG_INF;
@@ -702,31 +717,31 @@ __device__ __forceinline__ bool coop16_body(const DpArgs &a, unsigned char *smem
         const unsigned tag_in = wrap_tag(k, W), tag_out = wrap_tag(k + 1, W) << 16;
         uint4 *tbp = reinterpret_cast<uint4 *>(a.tb + (size_t)slot * a.tb_stride_words) + (size_t)k * (sps >> 4) * 64 + L;
 
-        // every PE starts on its column-0 border value; the baselines start on PE 0 / PE 64 of the double stripe
-        int B_lo = __builtin_amdgcn_readfirstlane(hb_lo), B_hi = __builtin_amdgcn_readfirstlane(hb_hi);
-        st.h_prev = c_pack2(hb_lo - B_lo, hb_hi - B_hi);
+        // every PE starts on its column-0 border value; the baseline starts on PE 0's
+        int B = __builtin_amdgcn_readfirstlane(hb_lo);
+        const unsigned hb_res = c_pack2(hb_lo, hb_hi); // the 16-bit residues of the border values: minus B (mod 2^16) they are exact
+        st.h_prev = c_pack2(hb_lo - B, hb_hi - B);
         st.hup = st.h_prev;
         st.e_prev = st.f = c_pk_sub(st.h_prev, c.o_e);
 
         int4 rA = make_int4(0, 0, 0, 0), rB = rA;
-        unsigned qlo_lo = qrd_lo[0], qlo_hi = qrd_hi[0];
+        unsigned q_lo = qrd[0];
         unsigned long long pend_a = 0, pend_b = 0;
         for (int s = 0; s < sps; s += 32) {
-            // ---- move the baselines: exact minimum / maximum of H per half, window check, re-base the four state registers
+            // ---- move the baseline: exact minimum / maximum of H over the 128 PEs, window check, re-base the four state registers
             {
-                unsigned mn, mx;
-                wave_minmax_pk(st.h_prev, mn, mx);
-                const unsigned smn = (unsigned)__builtin_amdgcn_readfirstlane((int)mn), smx = (unsigned)__builtin_amdgcn_readfirstlane((int)mx);
-                const int lo_l = c_lo16(smn), hi_l = c_lo16(smx), lo_h = c_hi16(smn), hi_h = c_hi16(smx);
-                if ((hi_l - lo_l) + c.check_margin > 65535 || (hi_h - lo_h) + c.check_margin > 65535) needs32 = 1;
-                const int d_l = lo_l - c.floor16, d_h = lo_h - c.floor16;
-                const unsigned dd = c_pack2(d_l, d_h);
-                B_lo += d_l;
-                B_hi += d_h;
+                int lo, hi;
+                wave_minmax_pk(st.h_prev, lo, hi);
+                if ((hi - lo) + c.check_margin > 65535) needs32 = 1;
+                const int d = lo - c.floor16;
+                const unsigned dd = c_pack2(d, d);
+                B += d;
                 st.h_prev = c_pk_sub(st.h_prev, dd);
                 st.e_prev = c_pk_sub(st.e_prev, dd);
                 st.hup = c_pk_sub(st.hup, dd);
                 st.f = c_pk_sub(st.f, dd);
+                st.keep_h = c_pk_sub(st.keep_h, dd);
+                st.keep_e = c_pk_sub(st.keep_e, dd);
             }
             // ---- carry in: columns < s + AHEAD of the row above this double stripe
             if (wave == 0) {
@@ -751,20 +766,20 @@ __device__ __forceinline__ bool coop16_body(const DpArgs &a, unsigned char *smem
             } else if (!failed) {
                 failed = !wait_at_least(produced + b_in, base_in + s + AHEAD);
             }
-            // ---- carry out through a ring: the slots of columns (s - 127) .. (s - 96) must have been read one lap ago
-            if (out == OUT_RING && !failed && s + 31 - 127 >= 0) {
-                const int need = base_out + s + 31 - 127 - RING_MASK;
+            // ---- carry out through a ring: this group stores columns up to s - 97; their slots must have been read one lap ago
+            if (out == OUT_RING && !failed && s - 97 >= 0) {
+                const int need = base_out + s - 97 - RING_MASK;
                 if (need > 0) failed = !wait_at_least(consumed + b_out, need);
             }
             if (s == 0) {
-                const int4 *r0 = reinterpret_cast<const int4 *>(ring_in);
+                const int4 *r0 = reinterpret_cast<const int4 *>(ring_in) + vzero;
                 rA = r0[0];
                 rB = r0[1];
             }
             const bool lean = s >= main_lo && s + 32 <= main_hi;
 #define MGL_COOP16_GROUP(EDGE, OUT)                                                                                                \
-    coop16_group32<EDGE, OUT>(st, rA, rB, ring_in, ring_out, wrap, tag_out, qrd_lo, qrd_hi, qlo_lo, qlo_hi, q_shift, tt, s, L, hb_lo, hb_hi, \
-                              qcap_lo, qcap_hi, row_lo, B_lo, B_hi, c, writer, last_half, tbp)
+    coop16_group32<EDGE, OUT>(st, rA, rB, ring_in, ring_out, wrap, tag_out, qrd, q_lo, tt, s, L, hb_res, qcap_lo, qcap_hi, row_lo, B, c, \
+                              writer, last_half, tbp, vzero)
             if (out == OUT_RING) {
                 if (lean)
                     MGL_COOP16_GROUP(false, OUT_RING);
@@ -784,8 +799,8 @@ __device__ __forceinline__ bool coop16_body(const DpArgs &a, unsigned char *smem
 #undef MGL_COOP16_GROUP
             // ---- publish progress (the release orders lane 63's ring stores before the counter)
             if (L == 0) {
-                if (out == OUT_RING && s + 32 - 127 > 0)
-                    __hip_atomic_store(produced + b_out, base_out + s + 32 - 127, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (out == OUT_RING && s + 32 - 128 > 0)
+                    __hip_atomic_store(produced + b_out, base_out + s + 32 - 128, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (wave != 0)
                     __hip_atomic_store(consumed + b_in, base_in + s + 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -872,6 +887,8 @@ int coop_lds_bytes(int sps_cap, int waves_per_block)
 // Is the 16-bit form worth trying for these (normalised) parameters?  The 64 PEs of a half-stripe span about
 // 64 * (match + 2e) (+ 2(o - e)); with the window check's margins that must stay inside 16 bits, else every pair would only
 // fall back.  (Exactness never depends on this estimate: the kernel checks the real window.)
+int coop16_lds_bytes(int sps_cap, int waves_per_block) { return coop_lds_bytes(sps_cap, waves_per_block) + coop_query_bytes(sps_cap); } // two query copies
+
 // Can the kernel run at all: its packed constants and the margins of the window check must fit 16 bits
 bool coop16_possible(int match, int mismatch, int gopen, int gext)
 {
@@ -882,12 +899,12 @@ bool coop16_worthwhile(int match, int mismatch, int gopen, int gext)
 {
     if (!coop16_possible(match, mismatch, gopen, gext)) return false;
     const int margin = coop16_below(match, mismatch, gopen, gext) + coop16_above(match, gopen, gext);
-    return 64 * (match + 2 * gext) + 2 * (gopen - gext) + margin <= 60000;
+    return 128 * (match + 2 * gext) + 2 * (gopen - gext) + margin <= 64000;
 }
 
 hipError_t launch_dp_coop16(const DpArgs &a, int waves_per_block, hipStream_t stream)
 {
-    const int lds = coop_lds_bytes(a.sps_cap, waves_per_block);
+    const int lds = coop16_lds_bytes(a.sps_cap, waves_per_block);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_dp_coop16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;

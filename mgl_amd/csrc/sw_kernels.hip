@@ -593,8 +593,8 @@ struct WaveMoves16 {
             nxt_blk = blk - 1;
             if (nxt_blk >= 0) nxt = load(nxt_blk);
         }
-        const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)dword_of(cur, (s >> 2) & 3), pe & 63);
-        return nibble(w, pe >> 6, s);
+        const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)dword_of(cur, (s >> 2) & 3), pe >> 1);
+        return nibble(w, pe & 1, s);
     }
     __device__ __forceinline__ int at(int i, int j)
     {
@@ -611,25 +611,29 @@ struct WaveMoves16 {
         }
         return 0;
     }
-    // cell k of a diagonal run from (i, j) is PE pe0 - k at step s0 - 2k: lane (pe0 - k) mod 64 tests it in its own registers
-    // (`cur` holds 8 cells of the run, `nxt` 8 more); the ballot, rotated so that k = 0 is the top bit, gives the first stop
+    // cell k of a diagonal run from (i, j) is PE pe0 - k at step s0 - 2k: lane l tests the two that are its own, PE 2l+1 and
+    // PE 2l, in its registers (`cur` holds 8 cells of the run, `nxt` 8 more); the run ends at the largest PE that fails
+    __device__ __forceinline__ bool run_cell_ok(int i, int j, int r, int pe0, int s0, int pe) const
+    {
+        const int k = pe0 - pe, s = s0 - 2 * k;
+        const bool inside = k >= 0 && k <= j - 1 && k <= i - 1; // (then s >= 1)
+        const int blk = (r >> 7) * bps + (s >> 4);
+        const bool in_cur = blk == cur_blk, in_nxt = blk == nxt_blk && nxt_blk >= 0;
+        const unsigned w = dword_of(in_cur ? cur : nxt, (s >> 2) & 3);
+        const bool is_diag = (nibble(w, pe & 1, s) & 3u) == 0u; // neither F > diag nor E > S (sw.cpp:60-71)
+        return inside && (in_cur || in_nxt) && is_diag;
+    }
     __device__ __forceinline__ int diag_run(int i, int j)
     {
         const int r = i - 1;
         const int pe0 = r & 127, s0 = j + pe0;
         if ((r >> 7) * bps + (s0 >> 4) != cur_blk) return 0;
-        const int l0 = pe0 & 63;
-        const int k = (l0 - L) & 63;
-        const int pe = pe0 - k, s = s0 - 2 * k;
-        const bool inside = k <= pe0 && k <= j - 1 && k <= i - 1; // (then s >= 1)
-        const int blk = (r >> 7) * bps + (s >> 4);
-        const bool in_cur = blk == cur_blk, in_nxt = blk == nxt_blk && nxt_blk >= 0;
-        const unsigned w = dword_of(in_cur ? cur : nxt, (s >> 2) & 3);
-        const bool is_diag = (nibble(w, (pe >> 6) & 1, s) & 3u) == 0u; // neither F > diag nor E > S (sw.cpp:60-71)
-        const bool ok = inside && (in_cur || in_nxt) && is_diag;
-        const unsigned long long stop = __builtin_amdgcn_ballot_w64(!ok);
-        const unsigned long long rot = l0 == 63 ? stop : (stop << (63 - l0)) | (stop >> (l0 + 1)); // bit 63 - k = cell k
-        return rot == 0ull ? 64 : __builtin_clzll(rot);
+        // PEs above pe0 are not part of the run: they do not stop it
+        const bool stop_hi = 2 * L + 1 <= pe0 && !run_cell_ok(i, j, r, pe0, s0, 2 * L + 1);
+        const bool stop_lo = 2 * L <= pe0 && !run_cell_ok(i, j, r, pe0, s0, 2 * L);
+        const unsigned long long mh = __builtin_amdgcn_ballot_w64(stop_hi), ml = __builtin_amdgcn_ballot_w64(stop_lo);
+        const int top_hi = mh ? 2 * (63 - __builtin_clzll(mh)) + 1 : -1, top_lo = ml ? 2 * (63 - __builtin_clzll(ml)) : -1;
+        return pe0 - max(top_hi, top_lo); // (no stop at all: the run reaches PE 0, pe0 + 1 cells)
     }
 };
 

@@ -40,9 +40,9 @@ struct TbView {
         const int r = i - 1;
         if (packed16 == 3) {
             // sw_dp_coop.hip, 16-bit form: [128-row double stripe][16 steps][lane] uint4; PE = row within the double stripe,
-            // lane = PE mod 64, half = PE / 64, step = column + PE; dword = 4 steps, bytes as in the packed16 layout
-            const int pe = r & 127, s = j + pe, h = pe >> 6;
-            const uint32_t w = base[(((size_t)(r >> 7) * (sps >> 4) + (s >> 4)) * 64 + (pe & 63)) * 4 + ((s >> 2) & 3)];
+            // lane = PE / 2, half = PE mod 2, step = column + PE; dword = 4 steps, bytes as in the packed16 layout
+            const int pe = r & 127, s = j + pe, h = pe & 1;
+            const uint32_t w = base[(((size_t)(r >> 7) * (sps >> 4) + (s >> 4)) * 64 + (pe >> 1)) * 4 + ((s >> 2) & 3)];
             const int t2 = (s & 3) * 2;
             const unsigned be = (w >> (8 * h)) >> t2, bf = (w >> (16 + 8 * h)) >> t2;
             return ((bf >> 1) & 1u) | (((be >> 1) & 1u) << 1) | ((bf & 1u) << 2) | ((be & 1u) << 3);

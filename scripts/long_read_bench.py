@@ -1,5 +1,6 @@
 """BASELINE.json configs[3] shape: ONT-style ~10 kb x ~10 kb pairs (5 % sub /
-5 % ins / 5 % del), int32 scores, full matrix, on-device traceback and full CIGAR.  The traceback needs tl*ql/2
+5 % ins / 5 % del), full matrix, on-device traceback and full CIGAR (scores exceed 16 bits: the fill kernel works in
+16 bits relative to moving baselines and checks its window, sw_dp_coop.hip).  The traceback needs tl*ql/2
 bytes per pair (50 MB), so the number of pairs in flight is set by the workspace; the cooperative fill kernel
 (sw_dp_coop.hip) fills the chip with 256 of them.
 
@@ -64,7 +65,9 @@ if args.json:
                       "roofline": {"bound": "hbm", "kernel": a.fill_kernel_name(tm), "achieved": round(alg / fill_s / 1e9, 1), "peak": 8000.0,
                                    "unit": "GB/s", "frac": round(alg / fill_s / 1e9 / 8000.0, 4), "traffic": None,
                                    "algorithmic_bytes_per_pass": alg, "kernel_gcups": round(cells / fill_s / 1e9, 1),
-                                   "note": "int32 wavefront, VALU-issue bound (26 instructions per 64-cell step); traffic: no PMC pass at this size"}}),
+                                   "note": ("packed int16 wavefront, 128 rows per wave, VALU-issue bound (36 VALU instructions per 128-cell step = 87 % of "
+                                            "the issue peak, profiles/r02_b_long_reads.txt)" if tm.fill_kernel == 5 else
+                                            "int32 wavefront, VALU-issue bound (about 22 instructions per 64-cell step)") + "; traffic: PMC pass at 1024 pairs only"}}),
           flush=True)
 import oracle_lib as ol
 if args.check:
