@@ -86,6 +86,7 @@ struct mgl_sw_ctx {
     int lane_kernel = 0;  // two-pairs-per-lane packed kernel: 0 = large uniform batches, 1 = never, 2 = whenever eligible (tests)
     int last_rows = 16;
     hipStream_t aux = nullptr;                       // traceback stream
+    hipStream_t fill2 = nullptr;                     // host-buffer entry, lane kernel: odd chunks (their tails overlap the next chunk)
     hipStream_t h2d = nullptr;                       // host-buffer entry: input copies of the next chunk
     hipEvent_t in_done = nullptr;
     hipEvent_t out_ready[2] = {nullptr, nullptr};    // host-buffer entry: traceback of chunk k done (k & 1)
@@ -255,8 +256,13 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     static const int lane_rows_env = [] { const char *e = getenv("MGL_SW_LANE_ROWS"); return e ? atoi(e) : 0; }();
     const int lane_rows = lane_rows_env == 16 || lane_rows_env == 32 ? lane_rows_env
                           : ((max_tl + 31) / 32 * 32 - (max_tl + 15) / 16 * 16) * 10 >= max_tl ? 16 : 32;
-    // (what counts is the size of a launch: a batch that the workspace cuts into small chunks is no better than a small batch)
-    const int64_t lane_launch = std::min<int64_t>(hooks ? std::max<int64_t>(n / 32, (int64_t)256 * 1024) : n,
+    // (what counts is the size of a launch: a batch that the workspace cuts into small chunks is no better than a small batch.
+    // Behind the host-buffer entry the chunks are the units of the copy pipeline: there a large batch goes one ROUND of the
+    // chip at a time -- 128 pairs per wave, three (32-row strips) or four waves per SIMD -- on two alternating streams)
+    const int64_t lane_round = (int64_t)ctx->n_cus * (lane_rows == 16 ? 16 : 12) * 128;
+    static const int host_chunks_l = [] { const char *e = getenv("MGL_SW_HOST_CHUNKS"); return e ? std::max(1, atoi(e)) : 32; }();
+    const bool lane_rounds = hooks && n >= 4 * lane_round;
+    const int64_t lane_launch = std::min<int64_t>(lane_rounds ? n : hooks ? std::max<int64_t>(n / host_chunks_l, (int64_t)256 * 1024) : n,
                                                   std::min<int64_t>(n, ctx->ws_limit / (lane_tb_words(max_tl, max_ql, lane_rows) * 4 / 128 + 1)));
     const bool use_lane = geom == GEOM_UNIFORM && ctx->precision != 32 && !d_matrix && match > 0 && ctx->lane_kernel != 1 &&
                           (ctx->lane_kernel == 2 || lane_launch >= kLaneMinPairs) && lane16_supported(tset, qset) &&
@@ -337,7 +343,12 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // to overlap, so the whole workspace is one buffer and the chunks are twice as large
     static const bool lane_fuse = [] { const char *e = getenv("MGL_SW_LANE_FUSE"); return !e || atoi(e) != 0; }();
     const bool fused_walk = use_lane && !score_only && lane_fuse;
-    const int64_t ws_part = fused_walk ? ctx->ws_limit : ctx->ws_limit / 2;
+    // ... except behind the host-buffer entry, whose chunks are the units of its copy pipeline anyway: there consecutive chunks
+    // alternate between two streams and two halves, so that the last waves of one launch (the launch's tail, 1-2 ms of a
+    // 14 ms chunk with most CUs idle) run beside the first waves of the next
+    static const bool lane_dual = [] { const char *e = getenv("MGL_SW_LANE_DUAL"); return !e || atoi(e) != 0; }();
+    const bool dual_ok = fused_walk && hooks && lane_dual;
+    const int64_t ws_part = fused_walk && !dual_ok ? ctx->ws_limit : ctx->ws_limit / 2;
     if (per_pair * gran > ws_part) {
         char msg[192];
         snprintf(msg, sizeof msg, "traceback of %lld pair(s) (%lld bytes) does not fit half the workspace: raise it with "
@@ -348,10 +359,18 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // host-buffer entry: the chunks are also the units of the copy / compute pipeline (inputs of chunk k+1 and results of
     // chunk k-1 move while chunk k computes), so a batch is cut into ~32 even when the workspace would hold it whole
     // (10 M pairs: 133 ms in 46 chunks, 143 in 12, scripts/host_entry_probe.py)
-    if (hooks) chunk = std::min<int64_t>(chunk, std::max<int64_t>((n / 32 + gran - 1) / gran * gran, (int64_t)256 * 1024));
+    static const int host_chunks = [] { const char *e = getenv("MGL_SW_HOST_CHUNKS"); return e ? std::max(1, atoi(e)) : 32; }();
+    if (hooks && !(use_lane && lane_rounds))
+        chunk = std::min<int64_t>(chunk, std::max<int64_t>((n / host_chunks + gran - 1) / gran * gran, (int64_t)256 * 1024));
+    // lane kernel behind the host entry: one round of the chip per chunk.  A chunk that is not a whole number of rounds leaves
+    // most CUs idle during its last one (1.25 M pairs = 3.2 rounds ran as 4), and nothing computes while the first chunk's
+    // inputs cross the link, so small is good; the tails of consecutive launches overlap on the two streams (10 M pairs:
+    // 8 chunks 122 ms, 13 chunks 115 ms, 26 chunks of one round 112 ms; one stream: 136-148 ms; scripts/host_sweep.sh)
+    if (use_lane && hooks && chunk > lane_round) chunk = lane_rounds ? lane_round : chunk / lane_round * lane_round;
     chunk = std::min<int64_t>(chunk, n);
     const bool overlap = !fused_walk && n > chunk;
-    const int halves = overlap ? 2 : 1;
+    const bool dual = dual_ok && n > chunk;
+    const int halves = overlap || dual ? 2 : 1;
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int h = 0; h < halves; ++h) {
@@ -372,6 +391,11 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
 
     // the workspace belongs to the context, not to a stream: order this call behind the previous one's kernels
     if (ctx->ws_idle_set) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ws_idle, 0));
+    if (ctx->ws_idle_set && dual) HIP_TRY(ctx, hipStreamWaitEvent(ctx->fill2, ctx->ws_idle, 0));
+    if (dual) { // whatever the caller enqueued on `stream` before this call comes first on the second stream too
+        HIP_TRY(ctx, hipEventRecord(ctx->fill_done[0], stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->fill2, ctx->fill_done[0], 0));
+    }
 
     ctx->timing = mgl_sw_timing{};
     ctx->timing.cells = cells_hint;
@@ -386,8 +410,9 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     for (int64_t first = 0; first < n; first += chunk, ++k) {
         const int64_t count = std::min(chunk, n - first);
         const int h = (int)(k & (halves - 1));
+        hipStream_t const fs = dual && (k & 1) ? ctx->fill2 : stream; // this chunk's fill stream (same half => same stream: ordered)
         if (hooks) {
-            const int hrc = hooks->before_fill(first, count, stream);
+            const int hrc = hooks->before_fill(first, count, fs);
             if (hrc != MGL_SW_OK) return hrc;
         }
         // what this chunk launches: one part normally; a chunk the host entry has sorted by geometry has a packed part
@@ -411,7 +436,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             // the index arrays of this half were last read by the kernels of chunk k-2
             if (overlap && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->h2d, ctx->tb_done[h], 0));
             Regroup rg;
-            const int hrc = hooks->regroup(first, count, h, stream, &rg);
+            const int hrc = hooks->regroup(first, count, h, fs, &rg);
             if (hrc != MGL_SW_OK) return hrc;
             const SeqSet ts{tset.data, rg.d_t_start, rg.d_t_len, max_tl, 0}, qs{qset.data, rg.d_q_start, rg.d_q_len, max_ql, 0};
             const int64_t ng = rg.n_grouped;
@@ -487,21 +512,21 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             ctx->pool_used += 4;
             ctx->diag_blocks = n_blocks;
         }
-        hipStream_t tb_stream = overlap ? ctx->aux : stream;
+        hipStream_t tb_stream = overlap ? ctx->aux : fs;
         // this half was last read by the traceback of chunk k-2
-        if (overlap && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->tb_done[h], 0));
-        if (pe[0]) HIP_TRY(ctx, hipEventRecord(pe[0], stream));
+        if (overlap && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(fs, ctx->tb_done[h], 0));
+        if (pe[0]) HIP_TRY(ctx, hipEventRecord(pe[0], fs));
         for (int i = 0; i < n_parts; ++i) {
             const Part &pt = parts[i];
             TbArgs walk = tas[i];
             if (!fused_walk) walk.cigar = nullptr;
-            HIP_TRY(ctx, pt.lane ? launch_dp16_lane(das[i], walk, pt.rows, stream)
-                         : pt.packed ? launch_dp16(das[i], pt.wpb, stream)
-                         : coop16 ? launch_dp_coop16(das[i], coop_waves, stream) : coop_waves ? launch_dp_coop(das[i], coop_waves, stream) : launch_dp(das[i], pt.wpb, pt.rows, stream));
+            HIP_TRY(ctx, pt.lane ? launch_dp16_lane(das[i], walk, pt.rows, fs)
+                         : pt.packed ? launch_dp16(das[i], pt.wpb, fs)
+                         : coop16 ? launch_dp_coop16(das[i], coop_waves, fs) : coop_waves ? launch_dp_coop(das[i], coop_waves, fs) : launch_dp(das[i], pt.wpb, pt.rows, fs));
         }
-        if (pe[1]) HIP_TRY(ctx, hipEventRecord(pe[1], stream));
+        if (pe[1]) HIP_TRY(ctx, hipEventRecord(pe[1], fs));
         if (overlap) {
-            HIP_TRY(ctx, hipEventRecord(ctx->fill_done[h], stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->fill_done[h], fs));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->fill_done[h], 0));
         }
         if (pe[2]) HIP_TRY(ctx, hipEventRecord(pe[2], tb_stream));
@@ -541,6 +566,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // everything this call enqueued is ordered before whatever the caller enqueues next on `stream`
     for (int h = 0; h < 2; ++h)
         if (tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->tb_done[h], 0));
+    if (dual) {
+        HIP_TRY(ctx, hipEventRecord(ctx->tb_done[1], ctx->fill2));
+        HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->tb_done[1], 0));
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ws_idle, stream));
     ctx->ws_idle_set = true;
     return MGL_SW_OK;
@@ -616,6 +645,7 @@ int mgl_sw_ctx_create(int device, mgl_sw_ctx **out)
     if (const char *e = getenv("MGL_SW_AUX_PRIO")) prio_lo = atoi(e);
     bool ok = hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, prio_lo) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&ctx->h2d, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&ctx->fill2, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ctx->in_done, hipEventDisableTiming) == hipSuccess;
     for (auto &e : ctx->out_ready) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -662,6 +692,7 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     for (auto &e : ctx->out_ready)
         if (e) (void)hipEventDestroy(e);
     if (ctx->h2d) (void)hipStreamDestroy(ctx->h2d);
+    if (ctx->fill2) (void)hipStreamDestroy(ctx->fill2);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -976,9 +1007,7 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     HIP_TRY(ctx, ctx->d_any.reserve(16));
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_any.p, 0, 4, st));
-    // offsets first (16 bytes per pair); the bases follow chunk by chunk, overlapped with the kernels
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_toff.p, t_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_qoff.p, q_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    // everything moves chunk by chunk, overlapped with the kernels: a chunk's offsets (16 bytes per pair) go with its bases
 
     ChunkHooks hooks;
     hooks.d_status_any = static_cast<int32_t *>(ctx->d_any.p);
@@ -989,6 +1018,8 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     hooks.before_fill = [&](int64_t first, int64_t count, hipStream_t fill_stream) -> int {
         const double t0 = now();
         const int64_t ta = t_off[first], tb = t_off[first + count], qa = q_off[first], qb = q_off[first + count];
+        HIP_TRY(ctx, hipMemcpyAsync(static_cast<int64_t *>(ctx->d_toff.p) + first, t_off + first, (size_t)(count + 1) * 8, hipMemcpyHostToDevice, ctx->h2d));
+        HIP_TRY(ctx, hipMemcpyAsync(static_cast<int64_t *>(ctx->d_qoff.p) + first, q_off + first, (size_t)(count + 1) * 8, hipMemcpyHostToDevice, ctx->h2d));
         HIP_TRY(ctx, hipMemcpyAsync(static_cast<uint8_t *>(ctx->d_t.p) + ta, targets + ta, (size_t)(tb - ta),
                                     hipMemcpyHostToDevice, ctx->h2d));
         HIP_TRY(ctx, hipMemcpyAsync(static_cast<uint8_t *>(ctx->d_q.p) + qa, queries + qa, (size_t)(qb - qa),
@@ -998,6 +1029,8 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
         t_in += now() - t0;
         return MGL_SW_OK;
     };
+    // (Result copies from a helper thread with a stream of its own, so that both directions of the link run at once, were
+    // tried: 138-151 ms against 136 -- two threads inside the runtime's pageable-copy path slow each other down.)
     hooks.after_traceback = [&](int64_t first, int64_t count, hipEvent_t results_ready) -> int {
         const double t0 = now();
         hipStream_t tb_stream = ctx->h2d;   // the copy stream: never queued behind a later chunk's kernels
@@ -1117,6 +1150,7 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
                         static_cast<int32_t *>(ctx->d_off.p), static_cast<Score *>(ctx->d_score.p),
                         static_cast<char *>(ctx->d_cig.p), cigar_stride, static_cast<int32_t *>(ctx->d_len.p),
                         static_cast<int32_t *>(ctx->d_status.p), cells, uniform, false, &hooks);
+    if (next_job.valid()) next_job.wait();
     if (rc != MGL_SW_OK) {
         (void)hipStreamSynchronize(ctx->h2d);
         (void)hipStreamSynchronize(ctx->aux);
