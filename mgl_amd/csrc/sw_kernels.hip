@@ -564,16 +564,16 @@ struct WaveMoves {
 struct WaveMoves16 {
     const uint4 *base; // this pair's traceback, as [block][lane] x 16 bytes
     int bps, L;        // blocks per double stripe
-    int cur_blk, nxt_blk;
-    uint4 cur, nxt;
-    __device__ __forceinline__ uint4 load(int blk) const { return base[(size_t)blk * 64 + L]; }
+    int cur_blk;       // win[d] = block cur_blk - d: the block of the current cell and the three below it, where an up-left path goes next
+    uint4 win[4];
+    __device__ __forceinline__ uint4 load(int blk) const { return blk >= 0 ? base[(size_t)blk * 64 + L] : make_uint4(0u, 0u, 0u, 0u); }
     __device__ __forceinline__ void init(const uint32_t *words, int sps, int lane)
     {
         base = reinterpret_cast<const uint4 *>(words);
         bps = sps >> 4;
         L = lane;
-        cur_blk = nxt_blk = -1;
-        cur = nxt = make_uint4(0u, 0u, 0u, 0u);
+        cur_blk = -8;
+        win[0] = win[1] = win[2] = win[3] = make_uint4(0u, 0u, 0u, 0u);
     }
     __device__ __forceinline__ static unsigned dword_of(const uint4 &v, int d) { return d == 0 ? v.x : d == 1 ? v.y : d == 2 ? v.z : v.w; }
     __device__ __forceinline__ static unsigned nibble(unsigned w, int h, int s)
@@ -582,18 +582,30 @@ struct WaveMoves16 {
         const unsigned be = (w >> (8 * h)) >> t2, bf = (w >> (16 + 8 * h)) >> t2;
         return ((bf >> 1) & 1u) | (((be >> 1) & 1u) << 1) | ((bf & 1u) << 2) | ((be & 1u) << 3);
     }
+    __device__ __forceinline__ void move_to(int blk) // wave-uniform
+    {
+        const int d = cur_blk - blk;
+        if (d >= 1 && d <= 3) { // the window slides down: one new block per step, three blocks ahead of where the path is
+            for (int t = 0; t < d; ++t) {
+                win[0] = win[1];
+                win[1] = win[2];
+                win[2] = win[3];
+                --cur_blk;
+                win[3] = load(cur_blk - 3);
+            }
+        } else {
+            cur_blk = blk;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) win[t] = load(blk - t);
+        }
+    }
     __device__ __forceinline__ unsigned cell(int i, int j)
     {
         const int r = i - 1;
         const int pe = r & 127, s = j + pe;
         const int blk = (r >> 7) * bps + (s >> 4);
-        if (blk != cur_blk) {
-            cur = blk == nxt_blk ? nxt : load(blk);
-            cur_blk = blk;
-            nxt_blk = blk - 1;
-            if (nxt_blk >= 0) nxt = load(nxt_blk);
-        }
-        const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)dword_of(cur, (s >> 2) & 3), pe >> 1);
+        if (blk != cur_blk) move_to(blk);
+        const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)dword_of(win[0], (s >> 2) & 3), pe >> 1);
         return nibble(w, pe & 1, s);
     }
     __device__ __forceinline__ int at(int i, int j)
@@ -612,16 +624,15 @@ struct WaveMoves16 {
         return 0;
     }
     // cell k of a diagonal run from (i, j) is PE pe0 - k at step s0 - 2k: lane l tests the two that are its own, PE 2l+1 and
-    // PE 2l, in its registers (`cur` holds 8 cells of the run, `nxt` 8 more); the run ends at the largest PE that fails
+    // PE 2l, in its registers (each block of the window holds 8 cells of the run); the run ends at the largest PE that fails
     __device__ __forceinline__ bool run_cell_ok(int i, int j, int r, int pe0, int s0, int pe) const
     {
         const int k = pe0 - pe, s = s0 - 2 * k;
-        const bool inside = k >= 0 && k <= j - 1 && k <= i - 1; // (then s >= 1)
-        const int blk = (r >> 7) * bps + (s >> 4);
-        const bool in_cur = blk == cur_blk, in_nxt = blk == nxt_blk && nxt_blk >= 0;
-        const unsigned w = dword_of(in_cur ? cur : nxt, (s >> 2) & 3);
-        const bool is_diag = (nibble(w, pe & 1, s) & 3u) == 0u; // neither F > diag nor E > S (sw.cpp:60-71)
-        return inside && (in_cur || in_nxt) && is_diag;
+        const bool inside = k >= 0 && k <= j - 1 && k <= i - 1; // (then s >= 1: the same double stripe)
+        const int d = cur_blk - ((r >> 7) * bps + (s >> 4));
+        const uint4 v = d == 0 ? win[0] : d == 1 ? win[1] : d == 2 ? win[2] : win[3];
+        const bool is_diag = (nibble(dword_of(v, (s >> 2) & 3), pe & 1, s) & 3u) == 0u; // neither F > diag nor E > S (sw.cpp:60-71)
+        return inside && d >= 0 && d <= 3 && is_diag;
     }
     __device__ __forceinline__ int diag_run(int i, int j)
     {
