@@ -208,6 +208,31 @@ def test_cooperative_16bit_kernel_and_its_fallback(waves):
     forced.close()
 
 
+def test_cooperative_16bit_kernel_adversarial_windows():
+    """Sequences chosen to stretch the 16-bit window of sw_dp_coop16_kernel: identical sequences (the steepest rise along the
+    diagonal against the flattest fall beside it), nothing in common, a long insertion / deletion in the middle, tandem
+    repeats, one base repeated -- under two parameter sets.  Whatever the kernel decides per pair (16 bits or its int32
+    body), the results are the oracle's."""
+    from mgl_amd import synth
+
+    rng = synth.rng_for(99)
+    g = synth.random_genome(rng, 3000).tobytes()
+    h = synth.random_genome(rng, 2600).tobytes()
+    rep = (b"ACGTTGCA" * 400)[:2900]
+    pairs = [(g, g), (g, h), (g[:1500] + g[2100:], g), (g, g[:1200] + g[1900:]), (rep, rep[3:2500]), (b"A" * 2000, b"A" * 1700),
+             (b"A" * 1500, b"C" * 1500), (g[:700], g), (g, g[1000:1400])]
+    forced = sw.MicrosoftSmithWaterman(0)
+    forced.set_cooperative(7)
+    for params in ((200, -150, 260, 11), (100, -100, 300, 10), (50, -200, 400, 1)):
+        for strategy in (ol.SOFTCLIP, ol.INDEL):
+            res = forced.align_batch([p[0] for p in pairs], [p[1] for p in pairs], params, strategy, cigar_stride=8192)
+            assert forced.timing().fill_kernel == 5
+            for k, (t, q) in enumerate(pairs):
+                o = ol.oracle_align(t, q, params, strategy)
+                assert (int(res.offsets[k]), res.cigars[k], tuple(int(x) for x in res.scores[k])) == (o["offset"], o["cigar"], o["score"]), (params, strategy, k)
+    forced.close()
+
+
 def test_scratch_carry_equals_lds():
     """The long-query path (carry ring + query copies in HBM, agent-scope accesses) forced onto ordinary
     batches must reproduce the goldens exactly."""
