@@ -214,8 +214,13 @@ int mgl_sw_shard_by_cells(int64_t n, const int64_t *t_off, const int64_t *q_off,
  * upper bounds of the pair lengths (they size the workspace).  status_out
  * (optional, int32[n]) receives a per-pair mgl_sw_status (0 or
  * MGL_SW_ERR_CIGAR_OVERFLOW).  flags: MGL_SW_FLAG_UNIFORM_GEOMETRY promises that every
- * pair has exactly tl == max_tl and ql == max_ql (enables the packed-int16 fill kernel; the
- * host-buffer entry detects this by itself).
+ * pair has exactly tl == max_tl and ql == max_ql (enables the packed-int16 fill kernels; the
+ * host-buffer entry detects this by itself).  Without a promise a batch of 1024 pairs or more whose
+ * (max_tl, max_ql) grid has at most 2^20 cells is sorted by geometry on the device, chunk by chunk
+ * (counting sort, sw_regroup_*_kernel): blocks of eight pairs of one geometry go through the packed
+ * kernel, the few left over through the int32 kernel, every result lands at its pair's own index.  The
+ * host reads one word per chunk back to size those launches, so such a call waits for the sorts (not for
+ * the alignments) before it returns; MGL_SW_AUTO_GROUP=0 in the environment keeps the int32 kernel.
  */
 #define MGL_SW_FLAG_UNIFORM_GEOMETRY 0x1
 /* MGL_SW_FLAG_BINARY_CIGAR: the CIGAR slot receives BAM-style little-endian uint32 elements

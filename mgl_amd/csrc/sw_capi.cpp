@@ -76,6 +76,11 @@ struct mgl_sw_ctx {
     void *pin_grp[2] = {nullptr, nullptr};
     size_t pin_grp_cap[2] = {0, 0};
     DevBuf d_grp[2];
+    DevBuf d_srt[4];               // device-side sort by geometry: the index arrays of four consecutive chunks, so that the sort
+    hipEvent_t srt_free[4] = {nullptr, nullptr, nullptr, nullptr}; // of chunk k waits for the walk of chunk k-4, long done, not k-2
+    hipEvent_t srt_done[4] = {nullptr, nullptr, nullptr, nullptr}; // the sort of chunk k has finished (the host reads its block total)
+    DevBuf d_grid;                 // ... four ints per cell of the (tl, ql) grid + the block totals
+    int64_t *pin_total = nullptr;  // pinned word the block total is read back through
     hipEvent_t grp_copied[2] = {nullptr, nullptr};
     // substitution matrix + code table: copied here first, so the caller's buffers may go away when the call returns
     void *pin_matrix = nullptr;
@@ -270,7 +275,12 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // a batch of mixed geometries whose chunks the host entry sorts by geometry (hooks->regroup): full blocks of eight pairs
     // with one geometry go through the packed kernel, the few left over through the int32 kernel, results land in the
     // caller's order (TbArgs.dest) -- the reference takes any pair (sw_avx.cpp:6-108), so must the fast path
-    const bool auto_group = geom == GEOM_MIXED && hooks && hooks->regroup && ctx->precision != 32 && !d_matrix && match > 0 &&
+    // ... and a device-resident batch is sorted on the device (launch_regroup), at the price of one short synchronisation per
+    // chunk: the host has to know how many pairs landed in full blocks before it can size the two launches
+    static const bool auto_group_dev_on = [] { const char *e = getenv("MGL_SW_AUTO_GROUP"); return !e || atoi(e) != 0; }();
+    const bool regroup_dev = !hooks && auto_group_dev_on && n >= 1024 && (int64_t)max_tl * max_ql <= (1ll << 20) && !score_only_hint &&
+                             (tset.len != nullptr || !tset.packed2) && (qset.len != nullptr || !qset.packed2);
+    const bool auto_group = geom == GEOM_MIXED && ((hooks && hooks->regroup) || regroup_dev) && ctx->precision != 32 && !d_matrix && match > 0 &&
                             !ctx->stripe_rows && ctx->cooperative < 2 && ctx->carry_memory == 0 && max_ql < kRows64MinQuery &&
                             dp16_lds_bytes(sps_for(max_ql), wpb16) <= 64 * 1024 && pick_waves_per_block(sps_for_rows(max_ql, 16), 16) > 0 &&
                             dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
@@ -402,6 +412,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     ctx->pool_used = 0;
 
     bool tb_pending[2] = {false, false};
+    bool srt_used[4] = {false, false, false, false};
     int64_t k = 0;
     // result copies trail the launches by two chunks: the traceback of chunk k-2 is what the fill of chunk k waits
     // for anyway, so the (blocking) copy of its results never stalls behind the low-priority traceback stream
@@ -436,9 +447,83 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             // the index arrays of this half were last read by the kernels of chunk k-2
             if (overlap && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->h2d, ctx->tb_done[h], 0));
             Regroup rg;
-            const int hrc = hooks->regroup(first, count, h, fs, &rg);
-            if (hrc != MGL_SW_OK) return hrc;
-            const SeqSet ts{tset.data, rg.d_t_start, rg.d_t_len, max_tl, 0}, qs{qset.data, rg.d_q_start, rg.d_q_len, max_ql, 0};
+            if (hooks) {
+                const int hrc = hooks->regroup(first, count, h, fs, &rg);
+                if (hrc != MGL_SW_OK) return hrc;
+            } else {
+                // the sort of chunk k runs on the copy stream (idle for a device-resident batch) while chunk k-1 is being filled:
+                // it is enqueued one chunk ahead, and only that stream is synchronised to read the block total
+                auto sort_chunk = [&](int64_t f, int64_t c, int hh, RegroupArgs *out) -> int { // hh = chunk number mod 4
+                    const size_t cells_n = (size_t)max_tl * max_ql;
+                    int64_t *d = static_cast<int64_t *>(ctx->d_srt[hh].p);
+                    int32_t *g = static_cast<int32_t *>(ctx->d_grid.p);
+                    RegroupArgs ra;
+                    ra.t = tset;
+                    ra.q = qset;
+                    ra.first = f;
+                    ra.count = c;
+                    ra.max_tl = max_tl;
+                    ra.max_ql = max_ql;
+                    ra.cnt = g;
+                    ra.nfull = g + cells_n;
+                    ra.full_start = g + 2 * cells_n;
+                    ra.rest_start = g + 3 * cells_n;
+                    ra.total = reinterpret_cast<int64_t *>(g + 4 * cells_n) + hh;
+                    ra.t_start = d;
+                    ra.q_start = d + c;
+                    ra.dest = d + 2 * c;
+                    ra.t_len = reinterpret_cast<int32_t *>(d + 3 * c);
+                    ra.q_len = ra.t_len + c;
+                    if (out) {
+                        *out = ra;
+                        return MGL_SW_OK;
+                    }
+                    // these index arrays were last read by the kernels of the chunk four before this one
+                    if (srt_used[hh]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->h2d, ctx->srt_free[hh], 0));
+                    HIP_TRY(ctx, launch_regroup(ra, ctx->h2d));
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_total + hh, ra.total, 8, hipMemcpyDeviceToHost, ctx->h2d));
+                    HIP_TRY(ctx, hipEventRecord(ctx->srt_done[hh], ctx->h2d));
+                    return MGL_SW_OK;
+                };
+                // chunk j = pairs [j * chunk, ...): the sorts run two chunks ahead of the fills (beside a fill kernel that has the
+                // chip a sort of unsorted reads takes 2-3 ms, longer than one chunk's fill)
+                auto sort_ahead = [&](int64_t j) -> int {
+                    const int64_t f = j * chunk;
+                    return f < n ? sort_chunk(f, std::min(chunk, n - f), (int)(j & 3), nullptr) : MGL_SW_OK;
+                };
+                if (k == 0) {
+                    const size_t cells_n = (size_t)max_tl * max_ql;
+                    for (int b = 0; b < 4; ++b) {
+                        HIP_TRY(ctx, ctx->d_srt[b].reserve((size_t)chunk * 32));
+                        if (!ctx->srt_free[b]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->srt_free[b], hipEventDisableTiming));
+                        if (!ctx->srt_done[b]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->srt_done[b], hipEventDisableTiming));
+                    }
+                    HIP_TRY(ctx, ctx->d_grid.reserve(cells_n * 16 + 64));
+                    if (!ctx->pin_total) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->pin_total), 64, hipHostMallocDefault));
+                    // (the caller's stream may still be producing the inputs)
+                    HIP_TRY(ctx, hipEventRecord(ctx->fill_done[0], stream));
+                    HIP_TRY(ctx, hipStreamWaitEvent(ctx->h2d, ctx->fill_done[0], 0));
+                    for (int64_t j = 0; j < 2; ++j) {
+                        const int src = sort_ahead(j);
+                        if (src != MGL_SW_OK) return src;
+                    }
+                }
+                HIP_TRY(ctx, hipEventSynchronize(ctx->srt_done[k & 3])); // the sort of THIS chunk, enqueued two iterations ago
+                RegroupArgs ra;
+                (void)sort_chunk(first, count, (int)(k & 3), &ra);
+                rg.d_t_start = ra.t_start;
+                rg.d_q_start = ra.q_start;
+                rg.d_dest = ra.dest;
+                rg.d_t_len = ra.t_len;
+                rg.d_q_len = ra.q_len;
+                rg.n_grouped = ctx->pin_total[k & 3];
+                if (rg.n_grouped < 0 || rg.n_grouped > count || (rg.n_grouped & 7)) return fail(ctx, MGL_SW_ERR_DEVICE, "sorting a chunk by geometry failed");
+                {
+                    const int src = sort_ahead(k + 2);
+                    if (src != MGL_SW_OK) return src;
+                }
+            }
+            const SeqSet ts{tset.data, rg.d_t_start, rg.d_t_len, max_tl, tset.packed2}, qs{qset.data, rg.d_q_start, rg.d_q_len, max_ql, qset.packed2};
             const int64_t ng = rg.n_grouped;
             if (ng > 0) parts[n_parts++] = Part{false, true, 0, ng, ts, qs, tb_base, stride_words, rec_base, rg.d_dest, 16, wpb16, sps_for(max_ql)};
             if (count > ng)
@@ -536,6 +621,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         if (overlap) {
             HIP_TRY(ctx, hipEventRecord(ctx->tb_done[h], ctx->aux));
             tb_pending[h] = true;
+        }
+        if (auto_group && !hooks) { // this chunk's index arrays are free once its walk is done
+            HIP_TRY(ctx, hipEventRecord(ctx->srt_free[k & 3], tb_stream));
+            srt_used[k & 3] = true;
         }
         if (hooks) {
             if (n_pending == 2) {
@@ -683,6 +772,16 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
         if (ctx->pin_grp[h]) (void)hipHostFree(ctx->pin_grp[h]);
         if (ctx->grp_copied[h]) (void)hipEventDestroy(ctx->grp_copied[h]);
         ctx->d_grp[h].release();
+        if (h == 0) {
+            for (int b = 0; b < 4; ++b) {
+                ctx->d_srt[b].release();
+                if (ctx->srt_free[b]) (void)hipEventDestroy(ctx->srt_free[b]);
+                if (ctx->srt_done[b]) (void)hipEventDestroy(ctx->srt_done[b]);
+            }
+            ctx->d_grid.release();
+            if (ctx->pin_total) (void)hipHostFree(ctx->pin_total);
+            ctx->pin_total = nullptr;
+        }
     }
     if (ctx->pin_in) (void)hipHostFree(ctx->pin_in);
     if (ctx->pin_out) (void)hipHostFree(ctx->pin_out);

@@ -163,6 +163,20 @@ bool coop16_worthwhile(int match, int mismatch, int gopen, int gext); // ... and
 int coop16_lds_bytes(int sps_cap, int waves_per_block);
 hipError_t launch_dp_coop16(const DpArgs &a, int waves_per_block, hipStream_t stream); // a.sps_cap = coop16_sps_for(max_ql)
 hipError_t launch_traceback(const TbArgs &a, hipStream_t stream);
+
+// Device-side sort of a chunk by geometry (sw_kernels.hip): a counting sort over the (tl, ql) grid [1, max_tl] x [1, max_ql].
+// Slots [0, total[0]) hold the full blocks of eight pairs of one geometry, cell after cell; the left-over pairs (fewer than
+// eight per cell) follow.  Slot arrays are in the indexed form of SeqSet (start, length) plus dest = the pair's index in the batch.
+struct RegroupArgs {
+    SeqSet t, q;
+    int64_t first, count; // pairs [first, first + count) of the batch
+    int max_tl, max_ql;
+    int32_t *cnt, *nfull, *full_start, *rest_start; // max_tl * max_ql each
+    int64_t *total;                                 // [0] = number of pairs in full blocks
+    int64_t *t_start, *q_start, *dest;              // count each
+    int32_t *t_len, *q_len;
+};
+hipError_t launch_regroup(const RegroupArgs &a, hipStream_t stream);
 hipError_t launch_scores_only(const TbArgs &a, hipStream_t stream); // DpRecord -> ScoreMax, no path walk
 hipError_t launch_cigar_from_matrix(const int32_t *btr, int tl, int ql, int strategy, const Score &ez, char *cigar,
                                     int cap, int32_t *out3, hipStream_t stream);

@@ -913,6 +913,128 @@ __global__ __launch_bounds__(256) void sw_scores_only_kernel(const TbArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sort of a chunk by geometry on the device (RegroupArgs, sw_device.h): what mgl_sw_align_batch does on the host for a
+// host batch of mixed geometries, for batches that are already resident.  The order of the pairs inside a cell is whatever
+// the atomics make it; every pair's results land at its own index (dest), so the outputs do not depend on it.
+__device__ __forceinline__ int regroup_cell(const RegroupArgs &a, int64_t p)
+{
+    const int tl = min(max(a.t.length(p), 1), a.max_tl), ql = min(max(a.q.length(p), 1), a.max_ql); // (lengths outside the promise: stay inside the grid)
+    return (tl - 1) * a.max_ql + (ql - 1);
+}
+// One global atomic per WORKGROUP and distinct cell instead of one per pair.  Reads of one length arrive together (a batch
+// that is sorted already has one cell per block) and returning atomics on one address are serialised (measured: 2 ms per
+// 190 k pairs for each of the two passes, as long as the alignment itself); and even aggregated per wave, the atomics of an
+// unsorted chunk all land on the two cache lines that hold the 51 counters in use, and the fill kernel running beside the
+// sort lost a third of its speed behind that L2 channel.  So a block of 1024 pairs first counts its cells in an LDS hash
+// table (LDS atomics), then adds each distinct cell's count to the global counter once; a pair's rank is the block's base
+// for the cell plus its rank inside the block.
+constexpr int RG_BLOCK = 1024, RG_TABLE = 2048;
+struct RegroupTable {
+    int key[RG_TABLE], num[RG_TABLE], base[RG_TABLE];
+};
+__device__ __forceinline__ int regroup_take(int32_t *cnt, int c, bool valid, RegroupTable &tab, bool want_rank)
+{
+    for (int x = threadIdx.x; x < RG_TABLE; x += blockDim.x) {
+        tab.key[x] = -1;
+        tab.num[x] = 0;
+    }
+    __syncthreads();
+    int h = (int)(((unsigned)c * 2654435761u) >> 21) & (RG_TABLE - 1), local = 0;
+    if (valid) {
+        for (;;) {
+            const int old = atomicCAS(&tab.key[h], -1, c);
+            if (old == -1 || old == c) {
+                local = atomicAdd(&tab.num[h], 1);
+                break;
+            }
+            h = (h + 1) & (RG_TABLE - 1); // (at most 1024 distinct keys in 2048 entries: the probe ends)
+        }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < RG_TABLE; x += blockDim.x)
+        if (tab.key[x] >= 0) {
+            if (want_rank)
+                tab.base[x] = atomicAdd(cnt + tab.key[x], tab.num[x]);
+            else
+                atomicAdd(cnt + tab.key[x], tab.num[x]);
+        }
+    __syncthreads();
+    return valid && want_rank ? tab.base[h] + local : 0;
+}
+__global__ __launch_bounds__(RG_BLOCK) void sw_regroup_count_kernel(const RegroupArgs a)
+{
+    __shared__ RegroupTable tab;
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = k < a.count;
+    (void)regroup_take(a.cnt, valid ? regroup_cell(a, a.first + k) : 0, valid, tab, false);
+}
+// one workgroup: exclusive prefix sums over the grid, of the pairs in full blocks (high word) and of the left-over pairs (low
+// word), 1024 cells at a time; rest_start is relative to the end of the full blocks (total[0], added by the scatter)
+__global__ __launch_bounds__(1024) void sw_regroup_scan_kernel(const RegroupArgs a)
+{
+    __shared__ unsigned long long s_wave[16];
+    const int cells = a.max_tl * a.max_ql, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long run = 0; // totals of the tiles before this one
+    for (int c0 = 0; c0 < cells; c0 += 1024) {
+        const int c = c0 + (int)threadIdx.x;
+        const int n = c < cells ? a.cnt[c] : 0;
+        const unsigned long long mine = ((unsigned long long)(unsigned)(n & ~7) << 32) | (unsigned)(n & 7);
+        unsigned long long incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        unsigned long long before = 0, tile = 0;
+        for (int w = 0; w < 16; ++w) {
+            const unsigned long long v = s_wave[w];
+            if (w < wave) before += v;
+            tile += v;
+        }
+        const unsigned long long excl = run + before + incl - mine;
+        if (c < cells) {
+            a.nfull[c] = n & ~7;
+            a.full_start[c] = (int)(excl >> 32);
+            a.rest_start[c] = (int)(excl & 0xffffffffu);
+            a.cnt[c] = 0; // the scatter counts again
+        }
+        run += tile;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.total[0] = (int64_t)(run >> 32);
+}
+__global__ __launch_bounds__(RG_BLOCK) void sw_regroup_scatter_kernel(const RegroupArgs a)
+{
+    __shared__ RegroupTable tab;
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = k < a.count;
+    const int64_t p = a.first + (valid ? k : 0);
+    const int c = regroup_cell(a, p);
+    const int pos = regroup_take(a.cnt, c, valid, tab, true);
+    if (!valid) return;
+    const int nf = a.nfull[c];
+    const int64_t slot = pos < nf ? (int64_t)a.full_start[c] + pos : a.total[0] + a.rest_start[c] + (pos - nf);
+    a.t_start[slot] = a.t.off[p];
+    a.q_start[slot] = a.q.off[p];
+    a.dest[slot] = p;
+    a.t_len[slot] = a.t.length(p);
+    a.q_len[slot] = a.q.length(p);
+}
+
+hipError_t launch_regroup(const RegroupArgs &a, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(a.cnt, 0, (size_t)a.max_tl * a.max_ql * 4, stream);
+    if (e != hipSuccess) return e;
+    const unsigned blocks = (unsigned)((a.count + RG_BLOCK - 1) / RG_BLOCK);
+    hipLaunchKernelGGL(sw_regroup_count_kernel, dim3(blocks), dim3(RG_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL(sw_regroup_scan_kernel, dim3(1), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(sw_regroup_scatter_kernel, dim3(blocks), dim3(RG_BLOCK), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_scores_only(const TbArgs &a, hipStream_t stream)
 {
     hipLaunchKernelGGL(sw_scores_only_kernel, dim3((unsigned)((a.count + 255) / 256)), dim3(256), 0, stream, a);

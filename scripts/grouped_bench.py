@@ -26,7 +26,8 @@ def timed(run, label):
     for _ in range(3): run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
-    print(f"{label}: {dt*1e3:.1f} ms = {cells/dt/1e9:.1f} GCUPS, {n/dt/1e6:.2f} M reads/s (packed16={a.timing().packed16})", flush=True)
+    tm = a.timing()
+    print(f"{label}: {dt*1e3:.1f} ms = {cells/dt/1e9:.1f} GCUPS, {n/dt/1e6:.2f} M reads/s (packed16={tm.packed16}, {tm.dp_launches} chunk(s))", flush=True)
 
 t0 = time.perf_counter()
 gb = device_batch.GroupedBatch(b.targets, t_start, tl, b.queries, q_start, ql)
@@ -45,9 +46,22 @@ def run_mixed():
         gb.offsets.data_ptr(), gb.scores.data_ptr(), gb.cigars.data_ptr(), gb.cigar_stride, gb.cigar_len.data_ptr(), gb.status.data_ptr(), 0)
     assert rc == 0
 ref = (gb.offsets.clone(), gb.scores.clone(), gb.cigars.clone())
-timed(run_mixed, "same pairs, no promise (int32 kernel)")
+timed(run_mixed, "same slots, no promise (sorted on the device by the library; MGL_SW_AUTO_GROUP=0: int32 kernel)")
 assert torch.equal(ref[0], gb.offsets) and torch.equal(ref[1], gb.scores) and torch.equal(ref[2], gb.cigars)
 print("identical results")
+# the pairs in their original (unsorted) order, no promise: mgl_sw_align_batch_device_indexed sorts every chunk on the device
+u_off = torch.zeros(n, dtype=torch.int32, device=dev); u_sc = torch.zeros((n, 6), dtype=torch.int32, device=dev)
+u_cg = torch.zeros((n, 64), dtype=torch.uint8, device=dev); u_ln = torch.zeros(n, dtype=torch.int32, device=dev); u_st = torch.zeros(n, dtype=torch.int32, device=dev)
+def run_unsorted():
+    st = torch.cuda.current_stream(dev)
+    rc = _lib.lib().mgl_sw_align_batch_device_indexed(a.ctx, C.c_void_p(st.cuda_stream), n, b.targets.data_ptr(), t_start.data_ptr(),
+        tl.data_ptr(), b.queries.data_ptr(), q_start.data_ptr(), ql.data_ptr(), 256, 150, 200, -150, 260, 11, 1,
+        u_off.data_ptr(), u_sc.data_ptr(), u_cg.data_ptr(), 64, u_ln.data_ptr(), u_st.data_ptr(), 0)
+    assert rc == 0
+timed(run_unsorted, "original order, no promise (device-resident, sorted by the library)")
+g0 = gb.gather()
+assert torch.equal(g0[0], u_off) and torch.equal(g0[1], u_sc)
+print("identical to the grouped batch, pair for pair")
 
 # the same reads as a HOST batch of mixed lengths with no flag and no sorting by the caller: mgl_sw_align_batch sorts every
 # chunk by geometry itself (PCIe inclusive: pageable host memory in, every result back on the host)

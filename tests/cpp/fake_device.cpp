@@ -3,6 +3,7 @@
 // would walk the paths (the traceback launch, or the lane kernel's fused walk) computes each pair with the CPU checker
 // (oracle/sw_oracle.c) and writes the results exactly where the kernels write them -- slot, stride, dest map, per-pair
 // status -- so the driver can tell whether the host layer chunked, sorted, sharded and scattered correctly.
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -105,6 +106,40 @@ hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &w, int, hipStream_t)
     return hipSuccess;
 }
 hipError_t launch_traceback(const TbArgs &a, hipStream_t) { walk(a, false); return hipSuccess; }
+hipError_t launch_regroup(const RegroupArgs &a, hipStream_t)
+{
+    // the device's counting sort, sequentially (fake device memory is host memory)
+    const int cells = a.max_tl * a.max_ql;
+    auto cell = [&](int64_t p) {
+        const int tl = std::min(std::max(a.t.length(p), 1), a.max_tl), ql = std::min(std::max(a.q.length(p), 1), a.max_ql);
+        return (tl - 1) * a.max_ql + (ql - 1);
+    };
+    for (int c = 0; c < cells; ++c) a.cnt[c] = 0;
+    for (int64_t k = 0; k < a.count; ++k) ++a.cnt[cell(a.first + k)];
+    int full = 0, rest = 0;
+    for (int c = 0; c < cells; ++c) {
+        a.nfull[c] = a.cnt[c] & ~7;
+        a.full_start[c] = full;
+        full += a.nfull[c];
+    }
+    for (int c = 0; c < cells; ++c) {
+        a.rest_start[c] = full + rest;
+        rest += a.cnt[c] & 7;
+        a.cnt[c] = 0;
+    }
+    a.total[0] = full;
+    for (int64_t k = 0; k < a.count; ++k) {
+        const int64_t p = a.first + k;
+        const int c = cell(p), pos = a.cnt[c]++;
+        const int64_t slot = pos < a.nfull[c] ? (int64_t)a.full_start[c] + pos : (int64_t)a.rest_start[c] + (pos - a.nfull[c]);
+        a.t_start[slot] = a.t.off[p];
+        a.q_start[slot] = a.q.off[p];
+        a.dest[slot] = p;
+        a.t_len[slot] = a.t.length(p);
+        a.q_len[slot] = a.q.length(p);
+    }
+    return hipSuccess;
+}
 hipError_t launch_scores_only(const TbArgs &a, hipStream_t) { walk(a, true); return hipSuccess; }
 hipError_t launch_cigar_from_matrix(const int32_t *, int, int, int, const Score &, char *, int, int32_t *, hipStream_t) { return hipErrorInvalidValue; }
 hipError_t launch_expand(const uint32_t *, const DpRecord *, int, int, int, int, int, int32_t *, hipStream_t, int) { return hipErrorInvalidValue; }

@@ -208,6 +208,59 @@ def test_cooperative_16bit_kernel_and_its_fallback(waves):
     forced.close()
 
 
+@pytest.mark.parametrize("two_bit", [False, True])
+def test_device_batch_of_mixed_lengths_is_sorted_on_the_device(two_bit):
+    """The same promise for a DEVICE-resident batch (mgl_sw_align_batch_device[_2bit], no flag): the library sorts every chunk
+    by geometry with a counting sort on the GPU (sw_regroup_*_kernel), full blocks of eight through the packed kernel, the
+    left-over pairs through the int32 kernel, results at the caller's indices; several chunks (small workspace)."""
+    import torch
+    from mgl_amd import device_batch, synth
+
+    rng = synth.rng_for(78)
+    n = 30_000
+    genome = synth.random_genome(rng, 1 << 20)
+    starts = rng.integers(0, len(genome) - 300, size=n)
+    tls = rng.choice([200, 256], size=n)
+    reads = synth.illumina_reads(rng, genome, starts + 40, read_len=150, sub=0.02, ins=0.004, dele=0.004)
+    qls = rng.integers(100, 151, size=n)
+    qls[::101] = rng.integers(1, 40, size=len(qls[::101]))
+    tseqs = [genome[s: s + tl].tobytes() for s, tl in zip(starts, tls)]
+    qseqs = [r[:q].tobytes() for r, q in zip(reads, qls)]
+    td, toff = sw.concat(tseqs)
+    qd, qoff = sw.concat(qseqs)
+    a = sw.MicrosoftSmithWaterman(0)
+    a.set_workspace(160 << 20)  # about four chunks
+    if two_bit:
+        dev = torch.device("cuda", 0)
+        pb = device_batch.PackedBatch(torch.from_numpy(device_batch.pack2bit(td)).to(dev), torch.from_numpy(toff[:-1].copy()).to(dev),
+                                      torch.from_numpy(np.diff(toff).astype(np.int32)).to(dev), torch.from_numpy(device_batch.pack2bit(qd)).to(dev),
+                                      torch.from_numpy(qoff[:-1].copy()).to(dev), torch.from_numpy(np.diff(qoff).astype(np.int32)).to(dev),
+                                      256, 150, cigar_stride=256)
+        b = pb
+    else:
+        b = device_batch.from_host(td, toff, qd, qoff, "cuda:0", cigar_stride=256)
+        assert not b.uniform
+    b.run(a)
+    torch.cuda.synchronize()
+    tm = a.timing()
+    assert tm.packed16 == 1 and tm.dp_launches >= 3
+    woff, wsc, wcg = ol.oracle_align_batch(tseqs, qseqs, (200, -150, 260, 11), ol.SOFTCLIP, nthreads=8)
+    assert int((b.status != 0).sum()) == 0
+    assert (b.offsets.cpu().numpy() == woff).all() and (b.scores.cpu().numpy() == wsc).all()
+    cg = b.cigar_strings()
+    assert all(cg[k] == wcg[k] for k in range(n))
+    # the same batch with the int32 kernel forced: identical bytes
+    forced = sw.MicrosoftSmithWaterman(0)
+    forced.set_precision(32)
+    keep = (b.offsets.clone(), b.scores.clone(), b.cigars.clone(), b.cigar_len.clone())
+    b.run(forced)
+    torch.cuda.synchronize()
+    assert forced.timing().packed16 == 0
+    assert torch.equal(b.offsets, keep[0]) and torch.equal(b.scores, keep[1]) and torch.equal(b.cigars, keep[2]) and torch.equal(b.cigar_len, keep[3])
+    forced.close()
+    a.close()
+
+
 def test_cooperative_16bit_kernel_adversarial_windows():
     """Sequences chosen to stretch the 16-bit window of sw_dp_coop16_kernel: identical sequences (the steepest rise along the
     diagonal against the flattest fall beside it), nothing in common, a long insertion / deletion in the middle, tandem
