@@ -189,6 +189,7 @@ def secondary_workloads():
         # traceback), passes repeated for 30 s; CPU baseline (the reference's align_avx) on 64 of the pairs
         "long_reads_10kb (configs[3] shape, 2048 pairs per pass, >= 30 s)": ["scripts/long_read_bench.py", "2048", "220", "10000", "1", "--seconds", "30",
                                                                              "--cpu-pairs", "64", "--json"],
+        "mixed_read_lengths (4 M reads of 100-150 bases x 256-base windows, no geometry promise from the caller)": ["scripts/grouped_bench.py", "4000000", "100", "--json"],
         "pairhmm_150x300 (SURVEY 8f rank 3, 1.6 M pairs)": ["scripts/pairhmm_bench.py", "--steps", "3", "--cpu-seconds", "3", "--json"],
         "protein_blosum62 (configs[4] shape, 2 M alignments, no reference path)": ["scripts/protein_bench.py", "--steps", "2", "--check", "50"],
     }

@@ -8,8 +8,9 @@ import torch
 from mgl_amd import device_batch
 from mgl_amd.smithwaterman import MicrosoftSmithWaterman
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
-lo = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+pos = [x for x in sys.argv[1:] if not x.startswith("--")]
+n = int(pos[0]) if len(pos) > 0 else 4_000_000
+lo = int(pos[1]) if len(pos) > 1 else 100
 dev = torch.device("cuda", 0)
 b = device_batch.window_batch(42, n, dev, window=256, read_len=150)
 g = torch.Generator(device=dev); g.manual_seed(1)
@@ -20,6 +21,7 @@ a = MicrosoftSmithWaterman(0)
 a.set_workspace(int(os.environ.get("WS_GIB", "8")) << 30)
 cells = int((ql.to(torch.int64) * 256).sum())
 
+figures = {}
 def timed(run, label):
     run(); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -27,6 +29,7 @@ def timed(run, label):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
     tm = a.timing()
+    figures[label.split(":")[0].split(",")[0]] = round(cells / dt / 1e9, 1)
     print(f"{label}: {dt*1e3:.1f} ms = {cells/dt/1e9:.1f} GCUPS, {n/dt/1e6:.2f} M reads/s (packed16={tm.packed16}, {tm.dp_launches} chunk(s))", flush=True)
 
 t0 = time.perf_counter()
@@ -90,3 +93,11 @@ for env, label in (("1", "host batch of mixed lengths, sorted per chunk by the l
 g_off, g_sc = gb.gather()[0].cpu().numpy(), gb.gather()[1].cpu().numpy()
 assert (g_off == off).all() and (g_sc == sc).all()
 print("host batch identical to the grouped device batch")
+if "--json" in sys.argv:
+    import json
+    print(json.dumps({"gcups": figures.get("original order"), "pairs": n, "read_lengths": [lo, 150], "window": 256,
+                      "device_resident_no_promise_gcups": figures.get("original order"),
+                      "device_resident_sorted_by_caller_with_promise_gcups": figures.get("grouped geometry"),
+                      "host_buffers_pcie_inclusive_gcups": round(cells / dt / 1e9, 1),
+                      "note": "mixed geometries: the library sorts every chunk by (tl, ql) itself -- counting sort on the GPU for device-resident "
+                              "batches, on the host for host buffers -- full blocks of eight through the packed kernel, the rest through int32"}))
