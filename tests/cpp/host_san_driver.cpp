@@ -124,6 +124,23 @@ int main()
             CHECK(rc2 == MGL_SW_ERR_CIGAR_OVERFLOW);
         }
     }
+    // ---- the same mixed batch as a DEVICE-resident one (the fake device's memory is host memory): sorted by geometry by the
+    // "device" (launch_regroup), two chunks ahead of the fills, four rotating sets of index arrays, six or more chunks
+    {
+        CHECK(mgl_sw_ctx_set_workspace(ctx, 48ll << 20) == 0);
+        const int64_t n = mixed.n();
+        const int stride = 128;
+        std::vector<int32_t> off((size_t)n), len((size_t)n), st((size_t)n);
+        std::vector<mgl_sw_score> sc((size_t)n);
+        std::vector<char> cg((size_t)n * stride, 1);
+        const long long packed0 = mgl_sw_dev::fake_packed_pairs.load();
+        CHECK(mgl_sw_align_batch_device(ctx, nullptr, n, mixed.t.data(), mixed.toff.data(), mixed.q.data(), mixed.qoff.data(), 256, 150, 200, -150,
+                                        260, 11, MGL_SW_OS_SOFTCLIP, off.data(), sc.data(), cg.data(), stride, len.data(), st.data(), 0) == 0);
+        mgl_sw_timing tm;
+        CHECK(mgl_sw_ctx_get_timing(ctx, &tm) == 0 && tm.dp_launches >= 5 && tm.packed16 == 1);
+        compare(mixed, em, off, sc, cg, stride, len, &st);
+        CHECK(mgl_sw_dev::fake_packed_pairs.load() - packed0 > n / 5); // (chunks of ~1 100 pairs over ~100 geometries: up to seven left-over pairs each)
+    }
     // ---- a uniform batch: the lane-kernel path (forced; fused walk, one buffer, chunks of 128), then the packed path
     Batch uni;
     for (int k = 0; k < 3000; ++k) {
