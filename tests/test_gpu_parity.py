@@ -261,6 +261,41 @@ def test_device_batch_of_mixed_lengths_is_sorted_on_the_device(two_bit):
     a.close()
 
 
+def test_cooperative_16bit_equals_32bit_on_many_long_pairs():
+    """160 ONT-style pairs of 1.5 kb .. 12 kb (lengths no multiple of anything, both sequences of a pair different in
+    length), every overhang strategy: the 16-bit long-read kernel and the int32 kernel must agree on every output byte;
+    a sample is checked against the oracle."""
+    import torch
+    from mgl_amd import device_batch, synth
+
+    rng = synth.rng_for(2024)
+    lens = rng.integers(1500, 12001, size=160)
+    pairs = [tuple(x.tobytes() for x in synth.ont_pair(rng, int(n))) for n in lens]
+    td, toff = sw.concat([p[0] for p in pairs])
+    qd, qoff = sw.concat([p[1] for p in pairs])
+    b = device_batch.from_host(td, toff, qd, qoff, "cuda:0", cigar_stride=2 * 14000)
+    a16, a32 = sw.MicrosoftSmithWaterman(0), sw.MicrosoftSmithWaterman(0)
+    a32.set_precision(32)
+    for strategy in (ol.SOFTCLIP, ol.INDEL, ol.LEAD_INDEL, ol.IGNORE):
+        b.run(a16, overhang_strategy=strategy)
+        torch.cuda.synchronize()
+        assert a16.timing().fill_kernel == 5
+        got = (b.offsets.clone(), b.scores.clone(), b.cigars.clone(), b.cigar_len.clone(), b.status.clone())
+        b.run(a32, overhang_strategy=strategy)
+        torch.cuda.synchronize()
+        assert a32.timing().fill_kernel == 3
+        assert all(torch.equal(x, y) for x, y in zip(got, (b.offsets, b.scores, b.cigars, b.cigar_len, b.status)))
+        assert int((b.status != 0).sum()) == 0
+        if strategy == ol.SOFTCLIP:
+            idx = [0, 57, 159]
+            cg = b.cigar_strings(idx)
+            for k, c in zip(idx, cg):
+                o = ol.oracle_align(pairs[k][0], pairs[k][1], (200, -150, 260, 11), strategy)
+                assert (int(b.offsets[k]), c, tuple(int(x) for x in b.scores[k])) == (o["offset"], o["cigar"], o["score"])
+    a16.close()
+    a32.close()
+
+
 def test_cooperative_16bit_kernel_adversarial_windows():
     """Sequences chosen to stretch the 16-bit window of sw_dp_coop16_kernel: identical sequences (the steepest rise along the
     diagonal against the flattest fall beside it), nothing in common, a long insertion / deletion in the middle, tandem
