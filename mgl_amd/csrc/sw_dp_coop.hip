@@ -90,8 +90,13 @@ __device__ __forceinline__ unsigned long long wrap_load(const unsigned long long
 // Wave 0, stripes W, 2W, ...: put columns col_base + (0..31) of the row above (written by the last wave one
 // round earlier, into the pair's HBM row) into the private LDS ring.  v was loaded two groups ago; a column
 // whose tag is not this round's has not been written yet and is loaded again.
+// ring entry formats: int2 {H, E'} in true values (int32 kernel); unsigned {H mod 2^16 | E' mod 2^16 << 16} (16-bit kernel: the
+// consumer subtracts its baseline modulo 2^16, and what it gets is exact because the true difference fits its window)
+__device__ __forceinline__ void ring_put(int2 *ring, int col, int h, int e) { ring[col & RING_MASK] = make_int2(h, e); }
+__device__ __forceinline__ void ring_put(unsigned *ring, int col, int h, int e) { ring[col & RING_MASK] = ((unsigned)h & 0xffffu) | ((unsigned)e << 16); }
+template <typename RingT>
 __device__ __forceinline__ bool stage_wrap(unsigned long long v, const int col, const bool active, const int ql,
-                                           const unsigned tag, const unsigned long long *row, const int cols, int2 *ring)
+                                           const unsigned tag, const unsigned long long *row, const int cols, RingT *ring)
 {
     bool ok = true;
     for (int spin = 0;; ++spin) {
@@ -106,7 +111,7 @@ __device__ __forceinline__ bool stage_wrap(unsigned long long v, const int col, 
     }
     if (active) {
         const int h = (int)(unsigned)v;
-        ring[col & RING_MASK] = make_int2(h, h - (int)((unsigned)(v >> 32) & 0xffffu));
+        ring_put(ring, col, h, h - (int)((unsigned)(v >> 32) & 0xffffu));
     }
     return ok;
 }
@@ -475,7 +480,7 @@ __host__ __device__ inline int coop16_above(int match, int gopen, int gext) { re
 struct Coop16Lane {
     unsigned h_prev, e_prev, hup, f; // PE 2l | PE 2l+1, stored form
     unsigned w[3];                   // traceback dwords of the last three 4-step blocks
-    unsigned keep_h, keep_e;         // PE 127's column of the previous block's last step (ring stores go four aligned columns at a time)
+    unsigned keep;                   // PE 127's column of the previous block's last step (ring stores go four aligned columns at a time)
     int best_lo, best_lo_i, best_hi, best_hi_i; // last-column maxima of this lane's two rows (true scores)
     int rm, rd, rj;                  // the double stripe that holds row tl: running best of the last row
 };
@@ -505,7 +510,7 @@ __device__ __forceinline__ void wave_minmax_pk(unsigned x, int &mn_out, int &mx_
 
 // 32 anti-diagonal steps of one 128-row double stripe.  EDGE / OUT as in coop_group32.  B: the baseline.
 template <bool EDGE, int OUT>
-__device__ __forceinline__ void coop16_group32(Coop16Lane &st, int4 &rA, int4 &rB, const int2 *ring_in, int2 *ring_out,
+__device__ __forceinline__ void coop16_group32(Coop16Lane &st, uint4 &rA, const unsigned *ring_in, unsigned *ring_out,
                                                unsigned long long *wrap_out, const unsigned tag_out, const unsigned *qrd, unsigned &q_lo,
                                                const unsigned tt, const int s_begin, const int L, const unsigned hb, const int qcap_lo,
                                                const int qcap_hi, const int row_lo, const int B, const Coop16Consts &c, const bool writer,
@@ -518,16 +523,17 @@ __device__ __forceinline__ void coop16_group32(Coop16Lane &st, int4 &rA, int4 &r
         // the five query bytes of this block: columns s0 - 2L - 1 (high PE, first step) .. s0 - 2L + 3 (low PE, last step) start a dword
         // of this lane's copy of the query (even lanes read the copy shifted by two bytes)
         const unsigned q_hi = qrd[(s0 >> 2) + 1];
-        unsigned wnew = 0u, oh[4], oe[4];
-        // carry of the NEXT block (every lane reads the same two addresses; `vzero` keeps the values in vector registers)
-        const int4 *nxt = reinterpret_cast<const int4 *>(ring_in + ((s0 + 4) & RING_MASK)) + vzero;
+        unsigned wnew = 0u, po[4];
+        // this block's four carry columns, one dword each, and the NEXT block's (every lane reads the same address; `vzero` keeps
+        // the values in vector registers), loaded here and used one block later
+        const uint4 cur = rA;
+        rA = *(reinterpret_cast<const uint4 *>(ring_in + ((s0 + 4) & RING_MASK)) + vzero);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int rh = u == 0 ? rA.x : u == 1 ? rA.z : u == 2 ? rB.x : rB.z;
-            const int re = u == 0 ? rA.y : u == 1 ? rA.w : u == 2 ? rB.y : rB.w;
-            if (u == 2) rA = nxt[0];
-            // ---- shift H and E' by one PE; PE 0 takes the carry of the row above, minus the baseline
-            unsigned in_h = ((unsigned)rh << 16) + negB16, in_e = ((unsigned)re << 16) + negB16;
+            const unsigned rp = u == 0 ? cur.x : u == 1 ? cur.y : u == 2 ? cur.z : cur.w;
+            // ---- shift H and E' by one PE; PE 0 takes the carry of the row above minus the baseline, modulo 2^16 (only the high
+            // half of either operand is used)
+            unsigned in_h = (rp << 16) + negB16, in_e = rp + negB16;
             if (EDGE && s0 + u > c.ql) {
                 // PE 0 is past the last column: the carry row ends there; the cells it keeps computing feed nothing, but they must
                 // stay inside the window, so they see their own last values as the row above
@@ -582,25 +588,20 @@ __device__ __forceinline__ void coop16_group32(Coop16Lane &st, int4 &rA, int4 &r
                     __hip_atomic_store(wrap_out + col, (unsigned long long)(unsigned)(c_hi16(h) + B) | ((unsigned long long)(diff | tag_out) << 32),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
-                oh[u] = h;
-                oe[u] = eo;
+                // PE 127's column, {H | E'} of the high halves as residues of the true values
+                po[u] = c_pk_add(__builtin_amdgcn_perm(eo, h, 0x07060302u), c_pack2(B, B));
             }
             st.h_prev = h;
             st.e_prev = eo;
             st.hup = hup_new;
             st.f = fo;
         }
-        rB = nxt[1];
         q_lo = q_hi;
         if (OUT == OUT_RING) {
-            // columns s0 - 128 .. s0 - 125 of the last row: the previous block's last step and three of this block's, one aligned 32 bytes
-            if (writer && (!EDGE || s0 >= 128)) {
-                int4 *dst = reinterpret_cast<int4 *>(ring_out + ((s0 - 128) & RING_MASK));
-                dst[0] = make_int4(c_hi16(st.keep_h) + B, c_hi16(st.keep_e) + B, c_hi16(oh[0]) + B, c_hi16(oe[0]) + B);
-                dst[1] = make_int4(c_hi16(oh[1]) + B, c_hi16(oe[1]) + B, c_hi16(oh[2]) + B, c_hi16(oe[2]) + B);
-            }
-            st.keep_h = oh[3];
-            st.keep_e = oe[3];
+            // columns s0 - 128 .. s0 - 125 of the last row: the previous block's last step and three of this block's, one aligned 16 bytes
+            if (writer && (!EDGE || s0 >= 128))
+                *reinterpret_cast<uint4 *>(ring_out + ((s0 - 128) & RING_MASK)) = make_uint4(st.keep, po[0], po[1], po[2]);
+            st.keep = po[3];
         }
         // the dwords of 16 steps rotate through three registers (a dynamic register index would go through scratch, and
         // sixteen steps unrolled spill: the compiler hoists the ring loads of all four blocks)
@@ -636,7 +637,7 @@ __device__ __forceinline__ bool coop16_body(const DpArgs &a, unsigned char *smem
     // consumed[W] | per-wave results
     const int qbytes = coop_query_bytes(a.sps_cap);
     unsigned char *qbuf = smem;
-    int2 *rings = reinterpret_cast<int2 *>(smem + 2 * qbytes);
+    int2 *rings = reinterpret_cast<int2 *>(smem + 2 * qbytes); // (sized for the int32 body; this one uses 4 bytes per column)
     int *produced = reinterpret_cast<int *>(rings + (size_t)W * RING_COLS);
     int *consumed = produced + W;
     int *wres = consumed + W; // [W][2] last-column best, then [5] last row {rm, rd, rj, failed, needs32}
@@ -687,7 +688,7 @@ __device__ __forceinline__ bool coop16_body(const DpArgs &a, unsigned char *smem
     Coop16Lane st;
     st.h_prev = st.e_prev = st.hup = st.f = 0u;
     st.w[0] = st.w[1] = st.w[2] = 0u;
-    st.keep_h = st.keep_e = 0u;
+    st.keep = 0u;
     st.best_lo = st.best_hi = NEG_INF;
     st.best_lo_i = st.best_hi_i = -1;
     st.rm = NEG_INF;
@@ -703,8 +704,8 @@ __device__ __forceinline__ bool coop16_body(const DpArgs &a, unsigned char *smem
     const bool writer = (L == 63);
     const int last_lane = ((tl - 1) & 127) >> 1, last_half = (tl - 1) & 1;
     const int b_in = (wave + W - 1) % W, b_out = wave;
-    int2 *ring_in = rings + (size_t)b_in * RING_COLS;
-    int2 *ring_out = rings + (size_t)b_out * RING_COLS;
+    unsigned *ring_in = reinterpret_cast<unsigned *>(rings) + (size_t)b_in * RING_COLS;
+    unsigned *ring_out = reinterpret_cast<unsigned *>(rings) + (size_t)b_out * RING_COLS;
 
     for (int k = wave; k < nds; k += W) {
         const bool first = (k == 0), last = (k == nds - 1);
@@ -724,7 +725,7 @@ __device__ __forceinline__ bool coop16_body(const DpArgs &a, unsigned char *smem
         st.hup = st.h_prev;
         st.e_prev = st.f = c_pk_sub(st.h_prev, c.o_e);
 
-        int4 rA = make_int4(0, 0, 0, 0), rB = rA;
+        uint4 rA = make_uint4(0u, 0u, 0u, 0u);
         unsigned q_lo = qrd[0];
         unsigned long long pend_a = 0, pend_b = 0;
         for (int s = 0; s < sps; s += 32) {
@@ -740,15 +741,13 @@ __device__ __forceinline__ bool coop16_body(const DpArgs &a, unsigned char *smem
                 st.e_prev = c_pk_sub(st.e_prev, dd);
                 st.hup = c_pk_sub(st.hup, dd);
                 st.f = c_pk_sub(st.f, dd);
-                st.keep_h = c_pk_sub(st.keep_h, dd);
-                st.keep_e = c_pk_sub(st.keep_e, dd);
             }
             // ---- carry in: columns < s + AHEAD of the row above this double stripe
             if (wave == 0) {
                 if (first) {
                     for (int col = (s == 0 ? 0 : s + AHEAD - 32) + L; col < s + AHEAD; col += 64) {
                         const int hb0 = border(col, gopen, gext, indel) + col * gext;
-                        ring_in[col & RING_MASK] = make_int2(hb0, hb0 - c.o_e32);
+                        ring_put(ring_in, col, hb0, hb0 - c.o_e32);
                     }
                 } else if (s == 0) {
                     const unsigned long long v = wrap_load(wrap, L, wrap_cols);
@@ -772,13 +771,11 @@ __device__ __forceinline__ bool coop16_body(const DpArgs &a, unsigned char *smem
                 if (need > 0) failed = !wait_at_least(consumed + b_out, need);
             }
             if (s == 0) {
-                const int4 *r0 = reinterpret_cast<const int4 *>(ring_in) + vzero;
-                rA = r0[0];
-                rB = r0[1];
+                rA = *(reinterpret_cast<const uint4 *>(ring_in) + vzero);
             }
             const bool lean = s >= main_lo && s + 32 <= main_hi;
 #define MGL_COOP16_GROUP(EDGE, OUT)                                                                                                \
-    coop16_group32<EDGE, OUT>(st, rA, rB, ring_in, ring_out, wrap, tag_out, qrd, q_lo, tt, s, L, hb_res, qcap_lo, qcap_hi, row_lo, B, c, \
+    coop16_group32<EDGE, OUT>(st, rA, ring_in, ring_out, wrap, tag_out, qrd, q_lo, tt, s, L, hb_res, qcap_lo, qcap_hi, row_lo, B, c, \
                               writer, last_half, tbp, vzero)
             if (out == OUT_RING) {
                 if (lean)
