@@ -18,7 +18,8 @@ ql = torch.randint(lo, 151, (n,), generator=g, device=dev, dtype=torch.int32)
 tl = torch.full((n,), 256, dtype=torch.int32, device=dev)
 t_start, q_start = b.t_off[:-1].contiguous(), b.q_off[:-1].contiguous()
 a = MicrosoftSmithWaterman(0)
-a.set_workspace(int(os.environ.get("WS_GIB", "8")) << 30)
+if os.environ.get("WS_GIB"):   # default: the context's own (a quarter of the device's memory); 8 GiB gives 21 chunks of 190 k pairs
+    a.set_workspace(int(os.environ["WS_GIB"]) << 30)
 cells = int((ql.to(torch.int64) * 256).sum())
 
 figures = {}
