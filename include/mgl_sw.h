@@ -76,6 +76,7 @@ typedef struct mgl_sw_timing {
 #define MGL_SW_KERNEL_COOP 3      /* sw_dp_coop_kernel: one pair per workgroup (long reads)      */
 #define MGL_SW_KERNEL_LANE16 4    /* sw_dp16_lane_kernel: packed int16, two pairs per LANE       */
 #define MGL_SW_KERNEL_COOP16 5    /* sw_dp_coop16_kernel: long reads, packed int16, 128 rows/wave */
+#define MGL_SW_KERNEL_STRIP16 6   /* sw_dp16_strip_kernel: long reads, one 32-row strip per lane-half */
 
 typedef struct mgl_sw_ctx mgl_sw_ctx; /* opaque: one GPU, its workspace and stream */
 
@@ -113,6 +114,10 @@ int mgl_sw_ctx_set_stripe_rows(mgl_sw_ctx *ctx, int rows);
  * mgl_sw_max_lds_query_len); 1 = never; 2..16 = always, with that many waves per pair (tests; identical
  * results) */
 int mgl_sw_ctx_set_cooperative(mgl_sw_ctx *ctx, int mode);
+/* long reads with targets of 4 096 .. 16 384 bases: one pair per workgroup, every lane-half a strip of 32 target rows kept
+ * in registers (sw_dp16_strip.hip), per-strip 16-bit baselines.  0 (default) = taken for such batches when the scoring
+ * parameters fit its static 16-bit window; 1 = never; 2 = whenever eligible, whatever the lengths (tests; identical results) */
+int mgl_sw_ctx_set_strip_kernel(mgl_sw_ctx *ctx, int mode);
 /* uniform batches whose scores fit 16 bits: which packed kernel runs.  0 (default) = by launch size: from 524 288 pairs on
  * the two-pairs-per-LANE kernel (sw_dp16_lane.hip: 128 pairs per wave, nothing shared between lanes), below that the
  * two-pairs-per-lane-of-a-16-lane-group kernel (sw_dp16.hip: eight pairs per wave); 1 = never the lane kernel;

@@ -88,6 +88,7 @@ struct mgl_sw_ctx {
     int carry_memory = 0; // 0 = LDS when it fits, 1 = always the HBM scratch (tests)
     int stripe_rows = 0;  // 0 = choose per batch, 16 / 64 = force (tests)
     int cooperative = 0;  // 0 = choose per batch, 1 = never, 2..16 = always, that many waves per pair (tests)
+    int strip_kernel = 0; // long reads, one strip per lane-half (sw_dp16_strip.hip): 0 = by size, 1 = never, 2 = whenever eligible (tests)
     int lane_kernel = 0;  // two-pairs-per-lane packed kernel: 0 = large uniform batches, 1 = never, 2 = whenever eligible (tests)
     int last_rows = 16;
     hipStream_t aux = nullptr;                       // traceback stream
@@ -319,11 +320,31 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         }
         wpb = coop_waves;
     }
+    // long reads whose targets span a few thousand rows: one strip of 32 rows per lane-half, the lane kernel's cell code with
+    // per-strip baselines (sw_dp16_strip.hip); W waves per pair hold 128 W strips, W <= 4 keeps three workgroups' worth of
+    // registers per SIMD
+    bool strip16 = false;
+    int strip_waves = 0;
+    {
+        static const int strip_env = [] { const char *e = getenv("MGL_SW_STRIP16"); return e ? atoi(e) : -1; }();
+        const int sw_ = ((max_tl + 31) / 32 + 127) / 128;
+        const bool want = ctx->strip_kernel == 2 || (ctx->strip_kernel == 0 && coop_waves && ctx->cooperative < 2 && max_tl >= 4096);
+        if (want && strip_env != 0 && !use16 && !use_lane && !d_matrix && ctx->precision != 32 && ctx->carry_memory == 0 && !ctx->stripe_rows && sw_ <= 4 &&
+            strip16_lds_bytes(max_ql, sw_) <= 64 * 1024 && strip16_range_ok(match, mismatch, gopen, gext)) {
+            strip16 = true;
+            strip_waves = sw_;
+            coop16 = false;
+            coop_waves = 0;
+            rows = 32;
+            wpb = sw_;
+            sps_cap = strip16_steps(max_ql, sw_);
+        }
+    }
     // queries too long for the LDS carve: carry ring and query copies in an HBM scratch area instead
     while (d_matrix && !use16 && wpb > 1 && dp_lds_bytes(sps_cap, wpb, rows) + 1024 > 64 * 1024) --wpb; // room for the matrix
     if (d_matrix && !use16 && (wpb == 0 || dp_lds_bytes(sps_cap, wpb, rows) + 1024 > 64 * 1024))
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "substitution-matrix scoring: query too long for the LDS carve (about 3 300 residues)");
-    const bool use_scratch = !use16 && !use_lane && !coop_waves && !d_matrix && (wpb == 0 || ctx->carry_memory == 1);
+    const bool use_scratch = !use16 && !use_lane && !coop_waves && !strip16 && !d_matrix && (wpb == 0 || ctx->carry_memory == 1);
     if (use_scratch) wpb = 4;
     if ((int64_t)max_tl * max_ql > (1ll << 34) || max_ql > (1 << 24) || max_tl > (1 << 24))
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "matrix larger than 2^34 cells");
@@ -336,6 +357,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // (lane layout: words per WAVE of 128 pairs, plus the wave's carry row)
     const int64_t stride_words = use_lane ? lane_tb_words(max_tl, max_ql, rows)
                                  : use16 ? (geom == GEOM_UNIFORM ? tb_words16_for(max_tl, max_ql) : tb_words16_bound(max_tl, max_ql))
+                                 : strip16 ? tb_words_strip16(max_ql, strip_waves)
                                  : coop16 ? std::max(tb_words_for(max_tl, coop_sps_for(max_ql), 64), tb_words_coop16(max_tl, max_ql)) // either layout
                                          : tb_words_for(max_tl, sps_cap, rows);
     // (auto-grouped chunks: the packed regions first, the int32 regions of the left-over pairs behind them)
@@ -348,7 +370,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // while the next chunk is being filled; a batch that fits one half is a single chunk
     // chunks are whole waves' worth of pairs (8: packed kernel, and the blocks of MGL_SW_FLAG_GROUPED_GEOMETRY; 4: 16-row
     // int32 kernel; 1: one pair per wave or workgroup); the last chunk may be shorter (idle lanes store nothing)
-    const int64_t gran = use_lane ? 128 : use16 ? 8 : rows == 64 ? 1 : 4;
+    const int64_t gran = use_lane ? 128 : use16 ? 8 : (rows == 64 || strip16) ? 1 : 4;
     // lane kernel: every lane walks the paths of its own two pairs at the end of its fill -- no traceback kernel, nothing
     // to overlap, so the whole workspace is one buffer and the chunks are twice as large
     static const bool lane_fuse = [] { const char *e = getenv("MGL_SW_LANE_FUSE"); return !e || atoi(e) != 0; }();
@@ -398,6 +420,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         HIP_TRY(ctx, ctx->scratch.reserve((size_t)(groups * dp_group_bytes(sps_cap, rows))));
     }
     if (coop_waves) HIP_TRY(ctx, ctx->scratch.reserve((size_t)chunk * coop_wrap_cols(sps_cap) * 8)); // one carry row per pair
+    if (strip16) HIP_TRY(ctx, ctx->scratch.reserve((size_t)chunk * (size_t)(max_ql + 8) * 4));          // the last row's scores per pair
 
     // the workspace belongs to the context, not to a stream: order this call behind the previous one's kernels
     if (ctx->ws_idle_set) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ws_idle, 0));
@@ -551,13 +574,13 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             da.tb = pt.tb;
             da.tb_stride_words = pt.stride;
             da.rec = pt.rec;
-            da.scratch = pt.lane ? static_cast<unsigned char *>(ctx->bnd[h].p) : (use_scratch || coop_waves) ? static_cast<unsigned char *>(ctx->scratch.p) : nullptr;
+            da.scratch = pt.lane ? static_cast<unsigned char *>(ctx->bnd[h].p) : (use_scratch || coop_waves || strip16) ? static_cast<unsigned char *>(ctx->scratch.p) : nullptr;
             da.diag = nullptr;
             da.matrix = d_matrix;
             da.code = d_code;
             da.matrix_lds_offset = 0;
             da.score_only = score_only ? 1 : 0;
-            const int per_block = pt.lane ? pt.wpb * 128 : pt.packed ? pt.wpb * 8 : pt.wpb * (64 / pt.rows);
+            const int per_block = pt.lane ? pt.wpb * 128 : pt.packed ? pt.wpb * 8 : strip16 ? 1 : pt.wpb * (64 / pt.rows);
             if (i == 0) n_blocks = (pt.count + per_block - 1) / per_block;
             if (ctx->profiling >= 2 && i == 0) {
                 HIP_TRY(ctx, ctx->diag.reserve((size_t)n_blocks * 16));
@@ -571,7 +594,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             ta.strategy = strategy;
             ta.tb = pt.tb;
             ta.tb_stride_words = pt.stride;
-            ta.packed16 = pt.lane ? 2 : pt.packed ? 1 : coop16 ? 3 : 0;
+            ta.packed16 = pt.lane ? 2 : pt.packed ? 1 : strip16 ? 4 : coop16 ? 3 : 0;
             ta.rows_per_stripe = pt.rows;
             ta.uni_ql = max_ql;
             ta.rec = pt.rec;
@@ -607,6 +630,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             if (!fused_walk) walk.cigar = nullptr;
             HIP_TRY(ctx, pt.lane ? launch_dp16_lane(das[i], walk, pt.rows, fs)
                          : pt.packed ? launch_dp16(das[i], pt.wpb, fs)
+                         : strip16 ? launch_dp16_strip(das[i], strip_waves, fs)
                          : coop16 ? launch_dp_coop16(das[i], coop_waves, fs) : coop_waves ? launch_dp_coop(das[i], coop_waves, fs) : launch_dp(das[i], pt.wpb, pt.rows, fs));
         }
         if (pe[1]) HIP_TRY(ctx, hipEventRecord(pe[1], fs));
@@ -641,12 +665,12 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         ctx->last_chunk_count = auto_group ? 0 : count; // (a chunk sorted by geometry has no caller-order slots to expand)
         ctx->last_half = h;
         ctx->last_rows = rows;
-        ctx->last_packed16 = use_lane ? 2 : use16 ? 1 : coop16 ? 3 : 0;
+        ctx->last_packed16 = use_lane ? 2 : use16 ? 1 : strip16 ? 4 : coop16 ? 3 : 0;
         ctx->timing.dp_launches++;
         ctx->timing.tb_launches++;
         ctx->timing.tb_bytes += (use_lane ? (count + 127) / 128 : use16 ? (count + 1) / 2 : count) * stride_words * 4;
         ctx->timing.packed16 = (use16 || use_lane) ? 1 : 0;
-        ctx->timing.fill_kernel = use_lane ? MGL_SW_KERNEL_LANE16 : use16 ? MGL_SW_KERNEL_DP16 : coop16 ? MGL_SW_KERNEL_COOP16 : coop_waves ? MGL_SW_KERNEL_COOP : rows == 64 ? MGL_SW_KERNEL_DP32_64 : MGL_SW_KERNEL_DP32;
+        ctx->timing.fill_kernel = use_lane ? MGL_SW_KERNEL_LANE16 : use16 ? MGL_SW_KERNEL_DP16 : strip16 ? MGL_SW_KERNEL_STRIP16 : coop16 ? MGL_SW_KERNEL_COOP16 : coop_waves ? MGL_SW_KERNEL_COOP : rows == 64 ? MGL_SW_KERNEL_DP32_64 : MGL_SW_KERNEL_DP32;
     }
     for (int i = 0; hooks && i < n_pending; ++i) {
         const int hrc = hooks->after_traceback(pending[i].first, pending[i].count, pending[i].ready);
@@ -812,6 +836,14 @@ int mgl_sw_ctx_set_precision(mgl_sw_ctx *ctx, int bits)
     if (!ctx || (bits != 0 && bits != 16 && bits != 32)) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->precision = bits;
+    return MGL_SW_OK;
+}
+
+int mgl_sw_ctx_set_strip_kernel(mgl_sw_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->strip_kernel = mode;
     return MGL_SW_OK;
 }
 

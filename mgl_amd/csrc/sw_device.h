@@ -161,6 +161,13 @@ hipError_t launch_dp_coop(const DpArgs &a, int waves_per_block, hipStream_t stre
 bool coop16_possible(int match, int mismatch, int gopen, int gext);   // constants and margins fit 16 bits
 bool coop16_worthwhile(int match, int mismatch, int gopen, int gext); // ... and a typical score window does too
 int coop16_lds_bytes(int sps_cap, int waves_per_block);
+// long reads, one strip of 32 rows per lane-half (sw_dp16_strip.hip): W waves per pair hold 128 W strips; steps of four columns
+__host__ __device__ inline int strip16_steps(int ql, int waves) { return ((ql + 3) >> 2) + 2 * 64 * waves - 1; }
+__host__ __device__ inline int strip16_qwords(int ql) { return ((((ql + 3) >> 2) + 4) + 3) & ~3; }
+__host__ __device__ inline int64_t tb_words_strip16(int ql, int waves) { return (int64_t)waves * strip16_steps(ql, waves) * 8 * 64 * 4; } // [wave][step][4][2][lane] uint4
+int strip16_lds_bytes(int max_ql, int waves);
+bool strip16_range_ok(int match, int mismatch, int gopen, int gext);
+hipError_t launch_dp16_strip(const DpArgs &a, int waves, hipStream_t stream); // a.uni_ql = max_ql sizes the regions; a.scratch: (max_ql + 8) ints per pair
 hipError_t launch_dp_coop16(const DpArgs &a, int waves_per_block, hipStream_t stream); // a.sps_cap = coop16_sps_for(max_ql)
 hipError_t launch_traceback(const TbArgs &a, hipStream_t stream);
 

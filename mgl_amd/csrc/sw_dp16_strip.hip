@@ -1,0 +1,305 @@
+// sw_dp16_strip.hip -- long reads with the lane kernel's economy: one pair per WORKGROUP, every lane-half owns one STRIP of
+// 32 target rows of that pair and sweeps the query columns with its strip in registers (column<32>() of sw_lane_cell.h, the
+// same code sw_dp16_lane.hip runs for two whole pairs per lane).  Same function as every other fill kernel here (the
+// reference's sw.cpp:5-146), same decisions, hence the same traceback bits.
+//
+// Schedule.  NL = 64 * W lanes per workgroup; the low halves of the registers of lane l hold strip l, the high halves strip
+// NL + l; strip g works on column group cg = step - g (four columns per step), so a strip is always one step behind the
+// strip above it and what that strip's last row produced in the previous step -- H and E' of four columns -- is exactly
+// what it needs now.  That hand-over is a DPP move to the next lane (both halves at once), a 32-byte LDS mailbox from the
+// last lane of a wave to the first lane of the next (and from the very last lane's low half to the first lane's high half:
+// strip NL - 1 -> strip NL), and one workgroup barrier per step.  Everything else stays in the lane: no ring, no carry row.
+// The price is the pipeline: a pair of tl x ql keeps ceil(tl / 32) of the 2 NL strip slots busy for ql / 4 of ql / 4 + 2 NL - 1
+// steps (10 kb x 10 kb, W = 3: 71 %).
+//
+// 16 bits.  Scores of long reads leave 16 bits, but a strip only ever sees its own 32 rows of one column, the row above and
+// the column before: every lane-half keeps its values relative to a baseline of its own (stored = X + (i+j)e - B, B an
+// int32 per half), moved every 16 columns so that the strip's first row sits at a fixed level.  What crosses between strips
+// crosses as the residue modulo 2^16 of the TRUE value; the receiver subtracts its own baseline modulo 2^16, which is exact
+// because the true difference fits its window.  The window is a static property of the scoring parameters (strip16_range_ok):
+// rows of one column differ by at most match + o + e (upwards) or o - e (downwards) per row, a row's value moves by at most
+// match + o + e per column -- 31 rows + 16 columns of drift + the intermediates -- so there is no run-time check and no fall-back.
+//
+// Traceback layout ("strip16", layout 4, DpRecord.g_tail = -(100 + W), DpRecord.sps = steps): per pair
+// [wave][step][column of the group][16-row group][lane] uint4, the byte layout of the lane kernel (low bytes = low half);
+// a wave stores 1 KB per instruction although its lanes are at different columns.  Cell (i, j): strip g = (i-1)/32,
+// lane = g mod NL, half = g / NL, step = (j-1)/4 + g.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "sw_device.h"
+#include "sw_lane_cell.h"
+
+namespace mgl_sw_dev {
+
+namespace {
+
+constexpr int SR = 32;               // rows per strip
+constexpr int STRIP_LEVEL = -14000;  // where a move of the baseline puts the strip's first row
+
+__device__ __forceinline__ unsigned dpp_wave_shr1(unsigned lane0_value, unsigned src)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)lane0_value, (int)src, 0x138, 0xf, 0xf, false);
+}
+// replace one half of x by the same half of v
+__device__ __forceinline__ unsigned put_half(unsigned x, unsigned v, bool high) { return high ? ((x & 0x0000ffffu) | (v & 0xffff0000u)) : ((x & 0xffff0000u) | (v & 0x0000ffffu)); }
+
+template <bool NOTB>
+__device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned char *smem)
+{
+    const int L = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = blockDim.x >> 6, NL = 64 * W;
+    const int ell = w * 64 + L;
+    const int64_t slot = blockIdx.x;
+    const int64_t p = a.first + slot;
+    const int64_t t0 = a.t.off[p], q0 = a.q.off[p];
+    const int tl = a.t.length(p), ql = a.q.length(p);
+    const int NCG = (ql + 3) >> 2;            // column groups
+    const int steps = NCG + 2 * NL - 1;
+    const int steps_cap = strip16_steps(a.uni_ql, W); // what the regions are sized for
+    const int match = a.match, gopen = a.gopen, gext = a.gext;
+    const bool indel = (a.strategy & (OS_INDEL | OS_LEAD_ID)) != 0;
+
+    // LDS: query as dwords (group cg = bases 4cg+1 .. 4cg+4, zero padded) | mailbox[2][W][8] | last-column key (u64) | scan results
+    const int qwords = strip16_qwords(a.uni_ql);
+    unsigned *const Q = reinterpret_cast<unsigned *>(smem);
+    unsigned *const mbox = Q + qwords;
+    unsigned long long *const key = reinterpret_cast<unsigned long long *>(mbox + 2 * W * 8);
+    int *const wres = reinterpret_cast<int *>(key + 1);
+    int *const rowbuf = reinterpret_cast<int *>(a.scratch) + (size_t)slot * (size_t)(a.uni_ql + 8); // H[tl][j] as true scores, j = 1 .. ql
+    {
+        for (int x = threadIdx.x; x < qwords; x += blockDim.x) Q[x] = 0u;
+        for (int x = threadIdx.x; x < 2 * W * 8; x += blockDim.x) mbox[x] = 0u;
+        if (threadIdx.x == 0) key[0] = 0ull;
+        __syncthreads();
+        unsigned char *qb = reinterpret_cast<unsigned char *>(Q);
+        for (int x = threadIdx.x; x < ql; x += blockDim.x) qb[x] = (unsigned char)a.q.at(q0, x);
+        __syncthreads();
+    }
+
+    LaneConsts c;
+    c.delta = pack2(a.mismatch - match, a.mismatch - match);
+    c.one = pack2(1, 1);
+    c.o_e = pack2(gopen - gext, gopen - gext);
+    c.k2 = pack2(match + 2 * gext, match + 2 * gext);
+    asm volatile("" : "+v"(c.delta), "+v"(c.one), "+v"(c.o_e), "+v"(c.k2));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        c.k12[u] = 0x02020202u << (2 * u);
+        c.k34[u] = 0x01010101u << (2 * u);
+        asm volatile("" : "+s"(c.k12[u]), "+s"(c.k34[u]));
+    }
+    const unsigned level = pack2(STRIP_LEVEL, STRIP_LEVEL);
+
+    const int gA = ell, gB = NL + ell;         // this lane's two strips
+    const int i0A = SR * gA, i0B = SR * gB;    // rows i0 + 1 .. i0 + 32
+    unsigned h[SR], f[SR], t[SR];
+#pragma unroll
+    for (int r = 0; r < SR; ++r) {
+        const int ra = i0A + r, rb = i0B + r; // 0-based row indices
+        t[r] = (unsigned)(ra < tl ? a.t.at(t0, ra) : 0) | ((unsigned)(rb < tl ? a.t.at(t0, rb) : 0) << 16);
+        h[r] = f[r] = 0u;
+    }
+    unsigned hd = 0u;
+    int base_a = 0, base_b = 0;                // the halves' baselines (int32): true stored value = register + baseline
+    unsigned bres = 0u;                        // the same, modulo 2^16, packed
+    unsigned out_h[4] = {0u, 0u, 0u, 0u}, out_e[4] = {0u, 0u, 0u, 0u}; // what this lane hands on: TRUE residues of (H, E') of its last rows
+    const int ulast = (ql - 1) & 3;
+    const int gl = (tl - 1) >> 5, rl = (tl - 1) & 31; // the strip and register row of target row tl
+    const bool own_last_a = gA == gl, own_last_b = gB == gl;
+    int best = NEG_INF, best_i = -1;            // last-column candidates of this lane (both halves merged: later row wins)
+
+    uint4 *const tb_wave = reinterpret_cast<uint4 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words) + (size_t)w * steps_cap * 8 * 64 + L;
+
+    for (int s = 0; s < steps; ++s) {
+        const int cgA = s - gA, cgB = s - gB;
+        const bool actA = cgA >= 0 && cgA < NCG && i0A < tl, actB = cgB >= 0 && cgB < NCG && i0B < tl;
+        // ---- 1. what the strip above handed on in the previous step (lane 0: the wave before, or the border row and the seam)
+        unsigned l0h[4], l0e[4];
+        {
+            const unsigned *mb = mbox + (((s + 1) & 1) * W + (w == 0 ? W - 1 : w - 1)) * 8;
+            const uint4 m0 = *reinterpret_cast<const uint4 *>(mb), m1 = *reinterpret_cast<const uint4 *>(mb + 4);
+            const unsigned mh[4] = {m0.x, m0.y, m0.z, m0.w}, me[4] = {m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (w == 0) {
+                    // strip 0 takes the border row (sw.cpp:14-18,31-35: H[0][j], E'[1][j] = H[0][j] - o), strip NL the last lane's low half
+                    const int j = 4 * s + u + 1;
+                    const int hb0 = border(j, gopen, gext, indel) + j * gext;
+                    l0h[u] = ((unsigned)hb0 & 0xffffu) | (mh[u] << 16);
+                    l0e[u] = ((unsigned)(hb0 - (gopen - gext)) & 0xffffu) | (me[u] << 16);
+                } else {
+                    l0h[u] = mh[u];
+                    l0e[u] = me[u];
+                }
+            }
+        }
+        unsigned in_h[4], in_e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            in_h[u] = dpp_wave_shr1(l0h[u], out_h[u]);
+            in_e[u] = dpp_wave_shr1(l0e[u], out_e[u]);
+        }
+        if (actA || actB) {
+            // ---- 2. a half that starts now: column 0 of its rows (sw.cpp:24,38,47-49), its baseline on its first row
+            if (cgA == 0 || cgB == 0) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if (half ? cgB == 0 : cgA == 0) {
+                        const int i0 = half ? i0B : i0A;
+                        const int b0 = border(i0 + 1, gopen, gext, indel) + (i0 + 1) * gext - STRIP_LEVEL;
+                        if (half)
+                            base_b = b0;
+                        else
+                            base_a = b0;
+                        bres = put_half(bres, pack2(b0, b0), half);
+#pragma unroll
+                        for (int r = 0; r < SR; ++r) {
+                            const int row = i0 + r + 1;
+                            const int hb = border(row, gopen, gext, indel) + row * gext - b0;
+                            h[r] = put_half(h[r], pack2(hb, hb), half);
+                            f[r] = put_half(f[r], pack2(hb - (gopen - gext), hb - (gopen - gext)), half);
+                        }
+                        const int hd0 = border(i0, gopen, gext, indel) + i0 * gext - b0; // H[i0][0]
+                        hd = put_half(hd, pack2(hd0, hd0), half);
+                    }
+                }
+            }
+            // ---- 3. every 16 columns the baselines move: the strip's first row back to its level (both halves are in the same phase)
+            if ((cgA & 3) == 0) {
+                const unsigned d = pk_sub(h[0], level);
+#pragma unroll
+                for (int r = 0; r < SR; ++r) {
+                    h[r] = pk_sub(h[r], d);
+                    f[r] = pk_sub(f[r], d);
+                }
+                hd = pk_sub(hd, d);
+                base_a += lo16(d);
+                base_b += hi16(d);
+                bres = pk_add(bres, d);
+            }
+            // ---- 4. four columns
+            const unsigned qa = Q[min(max(cgA, 0), qwords - 1)], qb = Q[min(max(cgB, 0), qwords - 1)];
+            uint4 *tbp = tb_wave + (size_t)s * 8 * 64;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                unsigned e = pk_sub(in_e[u], bres);
+                const unsigned q = __builtin_amdgcn_perm(qb, qa, 0x0c040c00u + 0x00010001u * (unsigned)u);
+                column<SR, NOTB>(h, f, t, q, hd, e, c, tbp + (size_t)u * 2 * 64);
+                hd = pk_sub(in_h[u], bres);
+                out_h[u] = pk_add(h[SR - 1], bres);
+                out_e[u] = pk_add(e, bres);
+                if (u == ulast && (cgA == NCG - 1 || cgB == NCG - 1)) {
+                    // last column of this strip's rows (sw.cpp:100-104: >= so the later row wins); compare scores, not stored values
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        if (half ? (cgB == NCG - 1 && actB) : (cgA == NCG - 1 && actA)) {
+                            const int i0 = half ? i0B : i0A, bb = half ? base_b : base_a;
+#pragma unroll
+                            for (int r = 0; r < SR; ++r) {
+                                const int row = i0 + r + 1;
+                                const int sc = (half ? hi16(h[r]) : lo16(h[r])) + bb - (row + ql) * gext;
+                                if (row <= tl && sc >= best) {
+                                    best = sc;
+                                    best_i = row;
+                                }
+                            }
+                        }
+                    }
+                }
+                if ((own_last_a && actA) || (own_last_b && actB)) {
+                    // the strip that holds row tl: H[tl][j] as a true score, for the scan of the last row below
+                    const bool half = own_last_b;
+                    const int j = 4 * (half ? cgB : cgA) + u + 1;
+                    unsigned v = h[SR - 1];
+#pragma unroll
+                    for (int r = 0; r < SR - 1; ++r) v = (r == rl) ? h[r] : v;
+                    if (j <= ql) rowbuf[j] = (half ? hi16(v) + base_b : lo16(v) + base_a) - (tl + j) * gext;
+                }
+            }
+        }
+        // ---- 5. the last lane of every wave posts what it hands on; one barrier per step
+        if (L == 63) {
+            unsigned *mb = mbox + ((s & 1) * W + w) * 8;
+            *reinterpret_cast<uint4 *>(mb) = make_uint4(out_h[0], out_h[1], out_h[2], out_h[3]);
+            *reinterpret_cast<uint4 *>(mb + 4) = make_uint4(out_e[0], out_e[1], out_e[2], out_e[3]);
+        }
+        __syncthreads();
+    }
+
+    // ---- last column: the lanes' candidates through one 64-bit LDS atomic (score first, then the larger row)
+    if (best_i > 0) atomicMax(key, ((unsigned long long)(unsigned)(best + 0x40000000) << 32) | (unsigned)best_i);
+    __threadfence();
+    __syncthreads();
+    // ---- last row (sw.cpp:116-127), order-free form: best score, among those the smallest |tl - j|, among those the smallest j
+    if (w == 0) {
+        int rm = NEG_INF, rd = 0x7fffffff, rj = 0x7fffffff;
+        for (int j = 1 + L; j <= ql; j += 64) {
+            const int sc = __builtin_nontemporal_load(rowbuf + j), d = abs(tl - j);
+            const bool take = sc > rm || (sc == rm && (d < rd || (d == rd && j < rj)));
+            rm = take ? sc : rm;
+            rd = take ? d : rd;
+            rj = take ? j : rj;
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const int om = __shfl_xor(rm, m), od = __shfl_xor(rd, m), oj = __shfl_xor(rj, m);
+            const bool take = om > rm || (om == rm && (od < rd || (od == rd && oj < rj)));
+            rm = take ? om : rm;
+            rd = take ? od : rd;
+            rj = take ? oj : rj;
+        }
+        if (L == 0) {
+            const unsigned long long k = key[0];
+            const int mqe = (int)(unsigned)(k >> 32) - 0x40000000, mqe_t = (int)(unsigned)k;
+            const bool row_wins = rm > mqe || (rm == mqe && rd < abs(mqe_t - ql));
+            DpRecord r;
+            r.mqe = mqe;
+            r.mqe_t = mqe_t;
+            r.max = row_wins ? rm : mqe;
+            r.max_t = row_wins ? tl : mqe_t;
+            r.max_q = row_wins ? rj : ql;
+            r.seg = row_wins ? ql - rj : 0;
+            r.g_tail = -(100 + W);
+            r.sps = steps_cap;
+            a.rec[slot] = r;
+        }
+    }
+    (void)wres;
+}
+
+} // namespace
+
+// grid = pairs of the chunk, block = 64 * W threads (W <= 4), dynamic LDS = strip16_lds_bytes
+__global__ __launch_bounds__(256, 3) void sw_dp16_strip_kernel(const DpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    sw_dp16_strip_body<false>(a, smem);
+}
+
+int strip16_lds_bytes(int max_ql, int waves) { return strip16_qwords(max_ql) * 4 + 2 * waves * 8 * 4 + 8 + 16 + 64; }
+
+// The static window of a strip (see the header): 31 rows of one column, 16 + 4 columns of drift, the intermediates of a cell.
+bool strip16_range_ok(int match, int mismatch, int gopen, int gext)
+{
+    if (match <= 0 || mismatch > match || gext < 0 || gopen < gext || match > 4000 || mismatch < -4000 || gopen > 4000 || gext > 4000) return false;
+    const int up = match + gopen + gext, down = gopen - gext, mis2 = mismatch + 2 * gext;
+    const int above = 31 * up + 20 * up + gopen + (match + 2 * gext) + 64;                     // over the first row's level
+    const int below = 31 * down + 20 * up + up + down + (mis2 < 0 ? -mis2 : mis2) + 64;        // under it
+    return STRIP_LEVEL + above <= 32767 && STRIP_LEVEL - below >= -32768;
+}
+
+hipError_t launch_dp16_strip(const DpArgs &a, int waves, hipStream_t stream)
+{
+    const int lds = strip16_lds_bytes(a.uni_ql, waves);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_dp16_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(sw_dp16_strip_kernel, dim3((unsigned)a.count), dim3(64 * waves), lds, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace mgl_sw_dev

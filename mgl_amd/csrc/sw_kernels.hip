@@ -469,6 +469,7 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const TbArgs a)
     view.base = a.tb + (size_t)(a.packed16 == 2 ? slot >> 7 : a.packed16 == 1 ? slot >> 1 : slot) * a.tb_stride_words;
     view.set_schedule(r, ql, a.rows_per_stripe);
     view.packed16 = TbView::layout_of(a.packed16, r);
+    view.waves = TbView::waves_of(r);
     view.half = (int)(slot & 1);
     view.lane = (int)((slot >> 1) & 63);
     view.ql = a.uni_ql;
@@ -757,6 +758,7 @@ __global__ __launch_bounds__(256) void sw_expand_kernel(const uint32_t *tbw, con
     tb.base = tbw;
     tb.set_schedule(rec[0], ql, rows);
     tb.packed16 = TbView::layout_of(packed16, rec[0]);
+    tb.waves = TbView::waves_of(rec[0]);
     tb.half = half;
     tb.lane = lane;
     tb.ql = ql;

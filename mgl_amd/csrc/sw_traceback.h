@@ -23,6 +23,7 @@ struct TbView {
     int packed16, half;       // packed16: 0 int32 layout, 1 sw_dp16_kernel, 2 sw_dp16_lane_kernel (base = the WAVE's words),
                               // 3 sw_dp_coop16_kernel (per pair; a pair the kernel redid in 32 bits has layout 0: layout_of)
     int lane = 0, ql = 0;     // lane layout: this pair's lane in its wave, the batch's query length
+    int waves = 0;            // strip layout (4): waves per pair
     int g_tail, nc, sps_tail; // packed16 only: stripes >= nc are stand-alone, starting at global step g_tail
     __device__ __forceinline__ void set_schedule(const DpRecord &r, int ql, int rows_per_stripe)
     {
@@ -34,10 +35,22 @@ struct TbView {
     }
     // the layout of ONE pair of a launch whose layout is `launch_layout`: sw_dp_coop16_kernel marks the pairs it kept in 16 bits
     __device__ __forceinline__ static int layout_of(int launch_layout, const DpRecord &r) { return launch_layout == 3 && r.g_tail != -16 ? 0 : launch_layout; }
+    __device__ __forceinline__ static int waves_of(const DpRecord &r) { return r.g_tail <= -100 ? -100 - r.g_tail : 0; } // layout 4
     // nibble of cell (i, j), 1-based: bit0 F>diag, bit1 E>max(diag,F), bit2 E opened, bit3 F opened
     __device__ __forceinline__ unsigned cell(int i, int j) const
     {
         const int r = i - 1;
+        if (packed16 == 4) {
+            // sw_dp16_strip.hip: [wave][step][column of the group][16-row group][lane] uint4; strip g = row / 32 sits in the low
+            // (g < NL) or high half of lane g mod NL and works on column group cg at step cg + g; NL = 64 * waves
+            const int g = r >> 5, rr = r & 31, nl = 64 * waves;
+            const int h = g >= nl, ell = g - h * nl;
+            const size_t u4 = (((((size_t)(ell >> 6) * sps + ((j - 1) >> 2) + g) * 4 + ((j - 1) & 3)) * 2) + (rr >> 4)) * 64 + (ell & 63);
+            const uint32_t w = base[u4 * 4 + ((rr >> 2) & 3)];
+            const int t2 = (rr & 3) * 2;
+            const unsigned be = (w >> (8 * h)) >> t2, bf = (w >> (16 + 8 * h)) >> t2;
+            return ((bf >> 1) & 1u) | (((be >> 1) & 1u) << 1) | ((bf & 1u) << 2) | ((be & 1u) << 3);
+        }
         if (packed16 == 3) {
             // sw_dp_coop.hip, 16-bit form: [128-row double stripe][16 steps][lane] uint4; PE = row within the double stripe,
             // lane = PE / 2, half = PE mod 2, step = column + PE; dword = 4 steps, bytes as in the packed16 layout
@@ -150,7 +163,7 @@ struct BitsMoves {
     // diagonal moves.  Other layouts: one lane per pair has nothing to look ahead with.
     __device__ __forceinline__ int diag_run(int i, int j) const
     {
-        if (tb.packed16 != 2) return 0;
+        if (tb.packed16 != 2 && tb.packed16 != 4) return 0;
         constexpr int AHEAD = MGL_SW_WALK_AHEAD;
         unsigned c[AHEAD];
 #pragma unroll

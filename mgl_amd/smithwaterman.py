@@ -170,6 +170,10 @@ class MicrosoftSmithWaterman:
         16-bit long-read kernel is tried whenever its constants fit."""
         _check(_lib.lib().mgl_sw_ctx_set_precision(self._ensure(), int(bits)))
 
+    def set_strip_kernel(self, mode):
+        """Long reads, one 32-row strip per lane-half: 0 = by size, 1 = never, 2 = whenever eligible."""
+        _check(_lib.lib().mgl_sw_ctx_set_strip_kernel(self._ensure(), int(mode)))
+
     def set_carry_memory(self, mode):
         """0 = stripe carry in LDS when the query fits, 1 = always in the HBM scratch (long-query path)."""
         _check(_lib.lib().mgl_sw_ctx_set_carry_memory(self._ensure(), int(mode)))

@@ -261,6 +261,38 @@ def test_device_batch_of_mixed_lengths_is_sorted_on_the_device(two_bit):
     a.close()
 
 
+def test_strip_kernel_long_reads():
+    """sw_dp16_strip_kernel (one pair per workgroup, one 32-row strip per lane-half, per-strip 16-bit baselines, hand-over by DPP
+    and an LDS mailbox) forced onto the long goldens, onto pairs of awkward lengths under every strategy, and onto ordinary
+    short pairs (one wave, mostly idle strips): identical results, traceback included."""
+    from mgl_amd import synth
+
+    forced = sw.MicrosoftSmithWaterman(0)
+    forced.set_strip_kernel(2)
+    gs = [g for g in golden_io.load("long") + golden_io.load("long2") if g.params == (200, -150, 260, 11) and len(g.t) <= 16384]
+    assert len(gs) >= 12
+    assert run_groups(forced, gs) == len(gs)
+    assert forced.timing().fill_kernel == 6
+    rng = synth.rng_for(77)
+    pairs = [tuple(x.tobytes() for x in synth.ont_pair(rng, n)) for n in (33, 130, 257, 1000, 4097, 5000, 8191, 9000)]
+    pairs += [(pairs[5][0], pairs[3][1]), (pairs[3][0], pairs[6][1]), (pairs[7][0][:4100], pairs[7][1][:37])]
+    for strategy in (ol.SOFTCLIP, ol.INDEL, ol.LEAD_INDEL, ol.IGNORE):
+        res = forced.align_batch([p[0] for p in pairs], [p[1] for p in pairs], (200, -150, 260, 11), strategy, cigar_stride=24000)
+        assert forced.timing().fill_kernel == 6
+        for k, (t, q) in enumerate(pairs):
+            o = ol.oracle_align(t, q, (200, -150, 260, 11), strategy)
+            assert (int(res.offsets[k]), res.cigars[k], tuple(int(x) for x in res.scores[k])) == (o["offset"], o["cigar"], o["score"]), (strategy, k)
+            assert forced.slot_layout(k) == 4
+    rows_ = golden_io.load("known") + golden_io.load("shapes")[:200] + [g for g in golden_io.load("random")[:400] if g.params[0] <= 300]
+    assert run_groups(forced, rows_) == len(rows_)
+    g24 = [g for g in golden_io.load("random") if g.params == (200, -150, 260, 11) and g.strategy == ol.SOFTCLIP][:24]
+    forced.align_batch([g.t for g in g24], [g.q for g in g24], g24[0].params, ol.SOFTCLIP)
+    for k, g in enumerate(g24):
+        btr = forced.expand_slot(k, len(g.t), len(g.q))
+        assert zlib.crc32(np.ascontiguousarray(btr[1:, 1:]).astype("<i4").tobytes()) & 0xFFFFFFFF == g.crc
+    forced.close()
+
+
 def test_cooperative_16bit_equals_32bit_on_many_long_pairs():
     """160 ONT-style pairs of 1.5 kb .. 12 kb (lengths no multiple of anything, both sequences of a pair different in
     length), every overhang strategy: the 16-bit long-read kernel and the int32 kernel must agree on every output byte;
