@@ -420,7 +420,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         HIP_TRY(ctx, ctx->scratch.reserve((size_t)(groups * dp_group_bytes(sps_cap, rows))));
     }
     if (coop_waves) HIP_TRY(ctx, ctx->scratch.reserve((size_t)chunk * coop_wrap_cols(sps_cap) * 8)); // one carry row per pair
-    if (strip16) HIP_TRY(ctx, ctx->scratch.reserve((size_t)chunk * (size_t)(max_ql + 8) * 4));          // the last row's scores per pair
+    if (strip16) HIP_TRY(ctx, ctx->scratch.reserve((size_t)chunk * (size_t)strip16_scratch_bytes(max_ql, strip_waves))); // last row, parked last columns
 
     // the workspace belongs to the context, not to a stream: order this call behind the previous one's kernels
     if (ctx->ws_idle_set) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ws_idle, 0));

@@ -42,8 +42,6 @@ __device__ __forceinline__ unsigned dpp_wave_shr1(unsigned lane0_value, unsigned
 {
     return (unsigned)__builtin_amdgcn_update_dpp((int)lane0_value, (int)src, 0x138, 0xf, 0xf, false);
 }
-// replace one half of x by the same half of v
-__device__ __forceinline__ unsigned put_half(unsigned x, unsigned v, bool high) { return high ? ((x & 0x0000ffffu) | (v & 0xffff0000u)) : ((x & 0xffff0000u) | (v & 0x0000ffffu)); }
 
 template <bool NOTB>
 __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned char *smem)
@@ -68,7 +66,10 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     unsigned *const mbox = Q + qwords;
     unsigned long long *const key = reinterpret_cast<unsigned long long *>(mbox + 2 * W * 8);
     int *const wres = reinterpret_cast<int *>(key + 1);
-    int *const rowbuf = reinterpret_cast<int *>(a.scratch) + (size_t)slot * (size_t)(a.uni_ql + 8); // H[tl][j] as true scores, j = 1 .. ql
+    // per pair in HBM: the strip that holds row tl parks every column (32 packed rows + its baseline), [column][33] | per lane two
+    // parked last columns of 32 rows + baseline, [lane][half][33]
+    int *const rowbuf = reinterpret_cast<int *>(a.scratch + (size_t)slot * (size_t)strip16_scratch_bytes(a.uni_ql, W));
+    unsigned *const cap = reinterpret_cast<unsigned *>(rowbuf + (size_t)(a.uni_ql + 8) * 33) + (size_t)ell * 66;
     {
         for (int x = threadIdx.x; x < qwords; x += blockDim.x) Q[x] = 0u;
         for (int x = threadIdx.x; x < 2 * W * 8; x += blockDim.x) mbox[x] = 0u;
@@ -116,56 +117,44 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     for (int s = 0; s < steps; ++s) {
         const int cgA = s - gA, cgB = s - gB;
         const bool actA = cgA >= 0 && cgA < NCG && i0A < tl, actB = cgB >= 0 && cgB < NCG && i0B < tl;
-        // ---- 1. what the strip above handed on in the previous step (lane 0: the wave before, or the border row and the seam)
-        unsigned l0h[4], l0e[4];
-        {
-            const unsigned *mb = mbox + (((s + 1) & 1) * W + (w == 0 ? W - 1 : w - 1)) * 8;
-            const uint4 m0 = *reinterpret_cast<const uint4 *>(mb), m1 = *reinterpret_cast<const uint4 *>(mb + 4);
-            const unsigned mh[4] = {m0.x, m0.y, m0.z, m0.w}, me[4] = {m1.x, m1.y, m1.z, m1.w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (w == 0) {
-                    // strip 0 takes the border row (sw.cpp:14-18,31-35: H[0][j], E'[1][j] = H[0][j] - o), strip NL the last lane's low half
-                    const int j = 4 * s + u + 1;
-                    const int hb0 = border(j, gopen, gext, indel) + j * gext;
-                    l0h[u] = ((unsigned)hb0 & 0xffffu) | (mh[u] << 16);
-                    l0e[u] = ((unsigned)(hb0 - (gopen - gext)) & 0xffffu) | (me[u] << 16);
-                } else {
-                    l0h[u] = mh[u];
-                    l0e[u] = me[u];
-                }
+        // ---- 1. what the strip above handed on in the previous step arrives column by column, right before it is used (below):
+        // lane 0 takes it from the mailbox of the wave before -- wave 0: the border row for strip 0 (sw.cpp:14-18,31-35: H[0][j],
+        // E'[1][j] = H[0][j] - o) and the last lane's low half for strip NL
+        const unsigned *const mb_in = mbox + (((s + 1) & 1) * W + (w == 0 ? W - 1 : w - 1)) * 8;
+        auto take = [&](const int u, unsigned &ih, unsigned &ie) {
+            unsigned l0h = mb_in[u], l0e = mb_in[4 + u];
+            if (w == 0) {
+                const int j = 4 * s + u + 1;
+                const int hb0 = border(j, gopen, gext, indel) + j * gext;
+                l0h = ((unsigned)hb0 & 0xffffu) | (l0h << 16);
+                l0e = ((unsigned)(hb0 - (gopen - gext)) & 0xffffu) | (l0e << 16);
             }
-        }
-        unsigned in_h[4], in_e[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            in_h[u] = dpp_wave_shr1(l0h[u], out_h[u]);
-            in_e[u] = dpp_wave_shr1(l0e[u], out_e[u]);
-        }
-        if (actA || actB) {
+            ih = dpp_wave_shr1(l0h, out_h[u]);
+            ie = dpp_wave_shr1(l0e, out_e[u]);
+        };
+        // (wave-uniform: the DPP moves below need the lane before to be enabled; what an idle lane computes feeds nothing real)
+        if (__builtin_amdgcn_ballot_w64(actA || actB)) {
             // ---- 2. a half that starts now: column 0 of its rows (sw.cpp:24,38,47-49), its baseline on its first row
             if (cgA == 0 || cgB == 0) {
+                // column 0 of 32 consecutive rows in stored form, relative to the first of them: H[i][0] + i e is i e (border 0) or
+                // constant (leading / trailing gaps allowed: -o - (i-1) e + i e), so row r sits at level + r * c1
+                const int c1 = indel ? 0 : gext;
+                const bool hb_ = cgB == 0; // (the two halves never start in the same step: they are NL steps apart)
+                const int i0 = hb_ ? i0B : i0A;
+                const int b0 = border(i0 + 1, gopen, gext, indel) + (i0 + 1) * gext - STRIP_LEVEL;
+                base_a = hb_ ? base_a : b0;
+                base_b = hb_ ? b0 : base_b;
+                const unsigned keep = hb_ ? 0x0000ffffu : 0xffff0000u;
+                bres = (bres & keep) | (pack2(b0, b0) & ~keep);
+                int lv = STRIP_LEVEL;
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    if (half ? cgB == 0 : cgA == 0) {
-                        const int i0 = half ? i0B : i0A;
-                        const int b0 = border(i0 + 1, gopen, gext, indel) + (i0 + 1) * gext - STRIP_LEVEL;
-                        if (half)
-                            base_b = b0;
-                        else
-                            base_a = b0;
-                        bres = put_half(bres, pack2(b0, b0), half);
-#pragma unroll
-                        for (int r = 0; r < SR; ++r) {
-                            const int row = i0 + r + 1;
-                            const int hb = border(row, gopen, gext, indel) + row * gext - b0;
-                            h[r] = put_half(h[r], pack2(hb, hb), half);
-                            f[r] = put_half(f[r], pack2(hb - (gopen - gext), hb - (gopen - gext)), half);
-                        }
-                        const int hd0 = border(i0, gopen, gext, indel) + i0 * gext - b0; // H[i0][0]
-                        hd = put_half(hd, pack2(hd0, hd0), half);
-                    }
+                for (int r = 0; r < SR; ++r) {
+                    h[r] = (h[r] & keep) | (pack2(lv, lv) & ~keep);
+                    f[r] = (f[r] & keep) | (pack2(lv - (gopen - gext), lv - (gopen - gext)) & ~keep);
+                    lv += c1;
                 }
+                const int hd0 = border(i0, gopen, gext, indel) + i0 * gext - b0; // H[i0][0]
+                hd = (hd & keep) | (pack2(hd0, hd0) & ~keep);
             }
             // ---- 3. every 16 columns the baselines move: the strip's first row back to its level (both halves are in the same phase)
             if ((cgA & 3) == 0) {
@@ -185,38 +174,33 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
             uint4 *tbp = tb_wave + (size_t)s * 8 * 64;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                unsigned e = pk_sub(in_e[u], bres);
+                unsigned ih, e;
+                take(u, ih, e);
+                e = pk_sub(e, bres);
                 const unsigned q = __builtin_amdgcn_perm(qb, qa, 0x0c040c00u + 0x00010001u * (unsigned)u);
                 column<SR, NOTB>(h, f, t, q, hd, e, c, tbp + (size_t)u * 2 * 64);
-                hd = pk_sub(in_h[u], bres);
+                hd = pk_sub(ih, bres);
                 out_h[u] = pk_add(h[SR - 1], bres);
                 out_e[u] = pk_add(e, bres);
-                if (u == ulast && (cgA == NCG - 1 || cgB == NCG - 1)) {
-                    // last column of this strip's rows (sw.cpp:100-104: >= so the later row wins); compare scores, not stored values
+                if (u == ulast && ((cgA == NCG - 1 && actA) || (cgB == NCG - 1 && actB))) {
+                    // column ql of this strip's rows: parked in the lane's own scratch lines with the baseline that goes with it,
+                    // looked at after the last step (comparing 32 rows here, in the unrolled column code, costs the allocator
+                    // hundreds of spilled registers)
+                    unsigned *cp = cap + (cgB == NCG - 1 && actB ? 33 : 0); // (one base address, 33 immediate offsets)
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        if (half ? (cgB == NCG - 1 && actB) : (cgA == NCG - 1 && actA)) {
-                            const int i0 = half ? i0B : i0A, bb = half ? base_b : base_a;
-#pragma unroll
-                            for (int r = 0; r < SR; ++r) {
-                                const int row = i0 + r + 1;
-                                const int sc = (half ? hi16(h[r]) : lo16(h[r])) + bb - (row + ql) * gext;
-                                if (row <= tl && sc >= best) {
-                                    best = sc;
-                                    best_i = row;
-                                }
-                            }
-                        }
-                    }
+                    for (int r = 0; r < SR; ++r) cp[r] = h[r];
+                    cp[SR] = (unsigned)(cgB == NCG - 1 && actB ? base_b : base_a);
                 }
                 if ((own_last_a && actA) || (own_last_b && actB)) {
-                    // the strip that holds row tl: H[tl][j] as a true score, for the scan of the last row below
-                    const bool half = own_last_b;
-                    const int j = 4 * (half ? cgB : cgA) + u + 1;
-                    unsigned v = h[SR - 1];
+                    // the strip that holds row tl parks the whole column (picking its row here would take a 32-way select or switch
+                    // in the unrolled column code); the scan of the last row below reads row tl of every column
+                    const int j = 4 * (own_last_b ? cgB : cgA) + u + 1;
+                    if (j <= ql) {
+                        int *rp = rowbuf + (size_t)j * 33;
 #pragma unroll
-                    for (int r = 0; r < SR - 1; ++r) v = (r == rl) ? h[r] : v;
-                    if (j <= ql) rowbuf[j] = (half ? hi16(v) + base_b : lo16(v) + base_a) - (tl + j) * gext;
+                        for (int r = 0; r < SR; ++r) rp[r] = (int)h[r];
+                        rp[SR] = own_last_b ? base_b : base_a;
+                    }
                 }
             }
         }
@@ -229,7 +213,26 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
         __syncthreads();
     }
 
-    // ---- last column: the lanes' candidates through one 64-bit LDS atomic (score first, then the larger row)
+    // ---- last column (sw.cpp:100-104: >= so the later row wins; compare scores, not stored values): every lane looks at the two
+    // columns it parked, then the candidates meet in one 64-bit LDS atomic (score first, then the larger row)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int i0 = half ? i0B : i0A;
+        if (i0 < tl) {
+            const unsigned *cp = cap + (half ? 33 : 0);
+            const int bb = (int)__builtin_nontemporal_load(cp + SR);
+            for (int r = 0; r < SR; ++r) {
+                const unsigned v = __builtin_nontemporal_load(cp + r);
+                const int row = i0 + r + 1;
+                const int sc = (half ? hi16(v) : lo16(v)) + bb - (row + ql) * gext;
+                if (row <= tl && sc >= best) {
+                    best = sc;
+                    best_i = row;
+                }
+            }
+        }
+    }
     if (best_i > 0) atomicMax(key, ((unsigned long long)(unsigned)(best + 0x40000000) << 32) | (unsigned)best_i);
     __threadfence();
     __syncthreads();
@@ -237,7 +240,8 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     if (w == 0) {
         int rm = NEG_INF, rd = 0x7fffffff, rj = 0x7fffffff;
         for (int j = 1 + L; j <= ql; j += 64) {
-            const int sc = __builtin_nontemporal_load(rowbuf + j), d = abs(tl - j);
+            const unsigned v = (unsigned)__builtin_nontemporal_load(rowbuf + (size_t)j * 33 + rl);
+            const int sc = (gl >= NL ? hi16(v) : lo16(v)) + __builtin_nontemporal_load(rowbuf + (size_t)j * 33 + SR) - (tl + j) * gext, d = abs(tl - j);
             const bool take = sc > rm || (sc == rm && (d < rd || (d == rd && j < rj)));
             rm = take ? sc : rm;
             rd = take ? d : rd;

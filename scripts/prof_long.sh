@@ -5,7 +5,7 @@ set -e
 NAME=${1:-r02_long}; PAIRS=${2:-1024}
 R=$PWD; O=$R/gpurun_out/$NAME; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $R
-B="python3 scripts/long_read_bench.py $PAIRS 120 10000 0"
+B="python3 scripts/long_read_bench.py $PAIRS ${WS:-120} 10000 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B --seconds 3 > $O.trace.log 2>&1 || echo "trace pass failed"
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $O/pmc_sq -- $B > $O.s.log 2>&1 || echo "sq pass failed"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O.f.log 2>&1 || echo "fetch pass failed"
