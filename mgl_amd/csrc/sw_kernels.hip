@@ -649,6 +649,48 @@ struct WaveMoves16 {
     }
 };
 
+// The same walk over ANY layout TbView knows, one wave per pair, nothing kept in registers: lane k fetches cell k of what may come
+// next -- the diagonal run from (i, j), or the gap run above / left of it -- and one ballot finds where it ends: up to 64 path
+// steps per memory round trip (layout 4, sw_dp16_strip.hip: one lane per pair took 23 ms per 1 024 pairs of 10 kb).
+struct WaveMovesView {
+    TbView tb;
+    int L;
+    __device__ __forceinline__ int diag_run(int i, int j)
+    {
+        const bool inside = L <= i - 1 && L <= j - 1;
+        const bool ok = inside && (tb.cell(inside ? i - L : 1, inside ? j - L : 1) & 3u) == 0u; // neither F > diag nor E > S (sw.cpp:60-71)
+        const unsigned long long stop = __builtin_amdgcn_ballot_w64(!ok);
+        return stop == 0ull ? 64 : __builtin_ctzll(stop);
+    }
+    __device__ __forceinline__ int at(int i, int j)
+    {
+        const unsigned c = (unsigned)__builtin_amdgcn_readfirstlane((int)tb.cell(i, j));
+        if (c & 2u) { // vertical gap: 1 + consecutive extensions above (sw.cpp:73-82): rows i-1, i-2, .. until one that opened
+            int n = 1;
+            for (int top = i - 1; top >= 1; top -= 64) {
+                const int r = top - L;
+                const bool stop = r < 1 || (tb.cell(r < 1 ? 1 : r, j) & 4u) != 0u;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(stop);
+                if (m != 0ull) return n + __builtin_ctzll(m);
+                n += 64;
+            }
+            return n;
+        }
+        if (c & 1u) { // horizontal gap (sw.cpp:84-93)
+            int n = 1;
+            for (int right = j - 1; right >= 1; right -= 64) {
+                const int q = right - L;
+                const bool stop = q < 1 || (tb.cell(i, q < 1 ? 1 : q) & 8u) != 0u;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(stop);
+                if (m != 0ull) return -(n + __builtin_ctzll(m));
+                n += 64;
+            }
+            return -n;
+        }
+        return 0;
+    }
+};
+
 __global__ __launch_bounds__(256) void sw_traceback_wave_kernel(const TbArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -681,7 +723,18 @@ __global__ __launch_bounds__(256) void sw_traceback_wave_kernel(const TbArgs a)
     cw.store = (lane == 0);
 
     int off;
-    if (TbView::layout_of(a.packed16, r) == 3) {
+    if (a.packed16 == 4) {
+        WaveMovesView mv;
+        mv.tb.base = a.tb + (size_t)slot * a.tb_stride_words;
+        mv.tb.set_schedule(r, ql, a.rows_per_stripe);
+        mv.tb.packed16 = 4;
+        mv.tb.waves = TbView::waves_of(r);
+        mv.tb.half = 0;
+        mv.tb.lane = 0;
+        mv.tb.ql = ql;
+        mv.L = lane;
+        off = walk_and_write(mv, tl, ql, a.strategy, r.max_t, r.max_q, r.mqe_t, r.seg, cw);
+    } else if (TbView::layout_of(a.packed16, r) == 3) {
         WaveMoves16 mv;
         mv.init(a.tb + (size_t)slot * a.tb_stride_words, r.sps, lane);
         off = walk_and_write(mv, tl, ql, a.strategy, r.max_t, r.max_q, r.mqe_t, r.seg, cw);
@@ -1045,7 +1098,7 @@ hipError_t launch_scores_only(const TbArgs &a, hipStream_t stream)
 
 hipError_t launch_traceback(const TbArgs &a, hipStream_t stream)
 {
-    if ((!a.packed16 && a.rows_per_stripe == 64) || a.packed16 == 3) {
+    if ((!a.packed16 && a.rows_per_stripe == 64) || a.packed16 == 3 || a.packed16 == 4) {
         // long reads: one wave per pair (the path walk is the latency, not the lane count)
         hipLaunchKernelGGL(sw_traceback_wave_kernel, dim3((unsigned)a.count), dim3(64), 0, stream, a);
         return hipGetLastError();
