@@ -399,6 +399,12 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // inputs cross the link, so small is good; the tails of consecutive launches overlap on the two streams (10 M pairs:
     // 8 chunks 122 ms, 13 chunks 115 ms, 26 chunks of one round 112 ms; one stream: 136-148 ms; scripts/host_sweep.sh)
     if (use_lane && hooks && chunk > lane_round) chunk = lane_rounds ? lane_round : chunk / lane_round * lane_round;
+    // strip kernel: one pair per workgroup of W waves at three waves per SIMD -- a chunk that is not a whole number of rounds of
+    // the chip (n_cus * (12 / W) pairs) ends with a round in which most CUs idle (1 582 pairs per chunk ran as two rounds)
+    if (strip16) {
+        const int64_t round = (int64_t)ctx->n_cus * (12 / strip_waves);
+        if (chunk > round) chunk = chunk / round * round;
+    }
     chunk = std::min<int64_t>(chunk, n);
     const bool overlap = !fused_walk && n > chunk;
     const bool dual = dual_ok && n > chunk;

@@ -107,7 +107,7 @@ def test_golden_long2(aligner):
     rows = golden_io.load("long2")
     assert len(rows) == 10 and max(len(g.t) for g in rows) >= 30000
     assert run_groups(aligner, rows) == 10
-    assert aligner.timing().fill_kernel in (3, 5)  # (the last group's parameters decide which)
+    assert aligner.timing().fill_kernel in (3, 5, 6)  # (the last group's lengths and parameters decide which long-read kernel)
     for waves in (3, 16):
         forced = sw.MicrosoftSmithWaterman(0)
         forced.set_cooperative(waves)
@@ -306,13 +306,19 @@ def test_cooperative_16bit_equals_32bit_on_many_long_pairs():
     td, toff = sw.concat([p[0] for p in pairs])
     qd, qoff = sw.concat([p[1] for p in pairs])
     b = device_batch.from_host(td, toff, qd, qoff, "cuda:0", cigar_stride=2 * 14000)
-    a16, a32 = sw.MicrosoftSmithWaterman(0), sw.MicrosoftSmithWaterman(0)
+    a16, a32, astrip = sw.MicrosoftSmithWaterman(0), sw.MicrosoftSmithWaterman(0), sw.MicrosoftSmithWaterman(0)
+    a16.set_strip_kernel(1)
     a32.set_precision(32)
     for strategy in (ol.SOFTCLIP, ol.INDEL, ol.LEAD_INDEL, ol.IGNORE):
+        b.run(astrip, overhang_strategy=strategy)  # default choice for targets of 4 096 .. 16 384 rows: the strip kernel
+        torch.cuda.synchronize()
+        assert astrip.timing().fill_kernel == 6
+        got_strip = (b.offsets.clone(), b.scores.clone(), b.cigars.clone(), b.cigar_len.clone(), b.status.clone())
         b.run(a16, overhang_strategy=strategy)
         torch.cuda.synchronize()
         assert a16.timing().fill_kernel == 5
         got = (b.offsets.clone(), b.scores.clone(), b.cigars.clone(), b.cigar_len.clone(), b.status.clone())
+        assert all(torch.equal(x, y) for x, y in zip(got, got_strip))
         b.run(a32, overhang_strategy=strategy)
         torch.cuda.synchronize()
         assert a32.timing().fill_kernel == 3
@@ -326,6 +332,7 @@ def test_cooperative_16bit_equals_32bit_on_many_long_pairs():
                 assert (int(b.offsets[k]), c, tuple(int(x) for x in b.scores[k])) == (o["offset"], o["cigar"], o["score"])
     a16.close()
     a32.close()
+    astrip.close()
 
 
 def test_cooperative_16bit_kernel_adversarial_windows():
