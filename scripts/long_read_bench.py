@@ -65,7 +65,10 @@ if args.json:
                       "roofline": {"bound": "hbm", "kernel": a.fill_kernel_name(tm), "achieved": round(alg / fill_s / 1e9, 1), "peak": 8000.0,
                                    "unit": "GB/s", "frac": round(alg / fill_s / 1e9 / 8000.0, 4), "traffic": None,
                                    "algorithmic_bytes_per_pass": alg, "kernel_gcups": round(cells / fill_s / 1e9, 1),
-                                   "note": ("packed int16 wavefront, 128 rows per wave, VALU-issue bound (36 VALU instructions per 128-cell step = 87 % of "
+                                   "note": ("one 32-row strip per lane-half, the lane kernel's column code with per-strip 16-bit baselines; VALU-issue "
+                                            "bound, 71 % of the issued lanes are real cells (strip slots and pipeline ramp), profiles/r02_d_strip_kernel.txt"
+                                            if tm.fill_kernel == 6 else
+                                            "packed int16 wavefront, 128 rows per wave, VALU-issue bound (36 VALU instructions per 128-cell step = 87 % of "
                                             "the issue peak, profiles/r02_b_long_reads.txt)" if tm.fill_kernel == 5 else
                                             "int32 wavefront, VALU-issue bound (about 22 instructions per 64-cell step)") + "; traffic: PMC pass at 1024 pairs only"}}),
           flush=True)
