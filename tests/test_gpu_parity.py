@@ -283,6 +283,26 @@ def test_strip_kernel_long_reads():
             o = ol.oracle_align(t, q, (200, -150, 260, 11), strategy)
             assert (int(res.offsets[k]), res.cigars[k], tuple(int(x) for x in res.scores[k])) == (o["offset"], o["cigar"], o["score"]), (strategy, k)
             assert forced.slot_layout(k) == 4
+    # four waves per pair (targets of 12 289 .. 16 384 rows), a short query against a long target and the reverse
+    wide = [(synth.random_genome(rng, 15000).tobytes(), synth.random_genome(rng, 1800).tobytes())]
+    wide.append((wide[0][0][:16384 - 3], wide[0][0][200:1500]))
+    wide.append((wide[0][1][:1700], wide[0][0][:9000]))
+    for strategy in (ol.SOFTCLIP, ol.LEAD_INDEL):
+        res = forced.align_batch([p[0] for p in wide], [p[1] for p in wide], (200, -150, 260, 11), strategy, cigar_stride=40000)
+        assert forced.timing().fill_kernel == 6
+        for k, (t, q) in enumerate(wide):
+            o = ol.oracle_align(t, q, (200, -150, 260, 11), strategy)
+            assert (int(res.offsets[k]), res.cigars[k], tuple(int(x) for x in res.scores[k])) == (o["offset"], o["cigar"], o["score"]), (strategy, k)
+    # sequences that stretch a strip's static window (identical, disjoint, homopolymers, a long gap) under two parameter sets that
+    # pass strip16_range_ok; sets that do not go to the workgroup kernels by themselves (16-bit with its checked window, or int32)
+    g = synth.random_genome(rng, 5000).tobytes()
+    adv = [(g, g), (g, synth.random_genome(rng, 4400).tobytes()), (b"A" * 4200, b"A" * 3900), (b"A" * 4100, b"C" * 2000), (g[:2500] + g[3300:], g)]
+    for params, kernel in (((200, -150, 260, 11), 6), ((100, -100, 300, 10), 6), ((50, -200, 400, 1), 5), ((400, -300, 500, 20), 3)):
+        res = forced.align_batch([p[0] for p in adv], [p[1] for p in adv], params, ol.SOFTCLIP, cigar_stride=16384)
+        assert forced.timing().fill_kernel == kernel, (params, forced.timing().fill_kernel)
+        for k, (t, q) in enumerate(adv):
+            o = ol.oracle_align(t, q, params, ol.SOFTCLIP)
+            assert (int(res.offsets[k]), res.cigars[k], tuple(int(x) for x in res.scores[k])) == (o["offset"], o["cigar"], o["score"]), (params, k)
     rows_ = golden_io.load("known") + golden_io.load("shapes")[:200] + [g for g in golden_io.load("random")[:400] if g.params[0] <= 300]
     assert run_groups(forced, rows_) == len(rows_)
     g24 = [g for g in golden_io.load("random") if g.params == (200, -150, 260, 11) and g.strategy == ol.SOFTCLIP][:24]
