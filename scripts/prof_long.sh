@@ -1,6 +1,6 @@
 #!/bin/bash
 # Long-read path (BASELINE.json configs[3]): kernel trace of scripts/long_read_bench.py, then PMC passes (instruction mix,
-# HBM bytes) on one pass of the same batch.  Run on the GPU box from the repo root: bash scripts/prof_long.sh NAME [PAIRS]
+# HBM bytes) on one pass of the same batch.  Run on the GPU box from the repo root: [WS=GiB] bash scripts/prof_long.sh NAME [PAIRS]
 set -e
 NAME=${1:-r02_long}; PAIRS=${2:-1024}
 R=$PWD; O=$R/gpurun_out/$NAME; mkdir -p $O
