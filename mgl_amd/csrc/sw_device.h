@@ -165,7 +165,7 @@ int coop16_lds_bytes(int sps_cap, int waves_per_block);
 __host__ __device__ inline int strip16_steps(int ql, int waves) { return ((ql + 3) >> 2) + 2 * 64 * waves - 1; }
 __host__ __device__ inline int strip16_qwords(int ql) { return ((((ql + 3) >> 2) + 4) + 3) & ~3; }
 __host__ __device__ inline int64_t tb_words_strip16(int ql, int waves) { return (int64_t)waves * strip16_steps(ql, waves) * 8 * 64 * 4; } // [wave][step][4][2][lane] uint4
-__host__ __device__ inline int64_t strip16_scratch_bytes(int ql, int waves) { return ((int64_t)(ql + 8) * 33 + 2 * 33 * 64 * waves) * 4; } // per pair
+__host__ __device__ inline int64_t strip16_scratch_bytes(int ql, int waves) { return ((int64_t)(ql + 8) * 2 + 2 * 33 * 64 * waves) * 4; } // per pair
 int strip16_lds_bytes(int max_ql, int waves);
 bool strip16_range_ok(int match, int mismatch, int gopen, int gext);
 hipError_t launch_dp16_strip(const DpArgs &a, int waves, hipStream_t stream); // a.uni_ql = max_ql sizes the regions; a.scratch: (max_ql + 8) ints per pair

@@ -66,10 +66,10 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     unsigned *const mbox = Q + qwords;
     unsigned long long *const key = reinterpret_cast<unsigned long long *>(mbox + 2 * W * 8);
     int *const wres = reinterpret_cast<int *>(key + 1);
-    // per pair in HBM: the strip that holds row tl parks every column (32 packed rows + its baseline), [column][33] | per lane two
-    // parked last columns of 32 rows + baseline, [lane][half][33]
+    // per pair in HBM: row tl of every column as {packed register, baseline}, [column][2] | per lane two parked last columns of
+    // 32 rows + baseline, [lane][half][33]
     int *const rowbuf = reinterpret_cast<int *>(a.scratch + (size_t)slot * (size_t)strip16_scratch_bytes(a.uni_ql, W));
-    unsigned *const cap = reinterpret_cast<unsigned *>(rowbuf + (size_t)(a.uni_ql + 8) * 33) + (size_t)ell * 66;
+    unsigned *const cap = reinterpret_cast<unsigned *>(rowbuf + (size_t)(a.uni_ql + 8) * 2) + (size_t)ell * 66;
     {
         for (int x = threadIdx.x; x < qwords; x += blockDim.x) Q[x] = 0u;
         for (int x = threadIdx.x; x < 2 * W * 8; x += blockDim.x) mbox[x] = 0u;
@@ -108,7 +108,8 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     unsigned bres = 0u;                        // the same, modulo 2^16, packed
     unsigned out_h[4] = {0u, 0u, 0u, 0u}, out_e[4] = {0u, 0u, 0u, 0u}; // what this lane hands on: TRUE residues of (H, E') of its last rows
     const int ulast = (ql - 1) & 3;
-    const int gl = (tl - 1) >> 5, rl = (tl - 1) & 31; // the strip and register row of target row tl
+    const int gl = (tl - 1) >> 5;                     // the strip and (as a scalar) the register row of target row tl
+    const int rl_s = __builtin_amdgcn_readfirstlane((tl - 1) & 31);
     const bool own_last_a = gA == gl, own_last_b = gB == gl;
     int best = NEG_INF, best_i = -1;            // last-column candidates of this lane (both halves merged: later row wins)
 
@@ -192,14 +193,22 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                     cp[SR] = (unsigned)(cgB == NCG - 1 && actB ? base_b : base_a);
                 }
                 if ((own_last_a && actA) || (own_last_b && actB)) {
-                    // the strip that holds row tl parks the whole column (picking its row here would take a 32-way select or switch
-                    // in the unrolled column code); the scan of the last row below reads row tl of every column
+                    // the strip that holds row tl: H[tl][j] with its baseline, for the scan of the last row below.  The register row is the
+                    // same for the whole pair: a scalar switch (a 32-way select here costs the allocator its spare registers, and
+                    // parking all 32 rows made this one lane's wave -- and with it, behind the barrier, the pair -- 132 stores a step slower)
                     const int j = 4 * (own_last_b ? cgB : cgA) + u + 1;
                     if (j <= ql) {
-                        int *rp = rowbuf + (size_t)j * 33;
-#pragma unroll
-                        for (int r = 0; r < SR; ++r) rp[r] = (int)h[r];
-                        rp[SR] = own_last_b ? base_b : base_a;
+                        unsigned v;
+                        switch (rl_s) {
+#define MGL_ROW(K) case K: v = h[K]; break;
+                            MGL_ROW(0) MGL_ROW(1) MGL_ROW(2) MGL_ROW(3) MGL_ROW(4) MGL_ROW(5) MGL_ROW(6) MGL_ROW(7) MGL_ROW(8) MGL_ROW(9) MGL_ROW(10)
+                            MGL_ROW(11) MGL_ROW(12) MGL_ROW(13) MGL_ROW(14) MGL_ROW(15) MGL_ROW(16) MGL_ROW(17) MGL_ROW(18) MGL_ROW(19) MGL_ROW(20)
+                            MGL_ROW(21) MGL_ROW(22) MGL_ROW(23) MGL_ROW(24) MGL_ROW(25) MGL_ROW(26) MGL_ROW(27) MGL_ROW(28) MGL_ROW(29) MGL_ROW(30)
+#undef MGL_ROW
+                        default: v = h[SR - 1]; break;
+                        }
+                        rowbuf[2 * j] = (int)v;
+                        rowbuf[2 * j + 1] = own_last_b ? base_b : base_a;
                     }
                 }
             }
@@ -240,8 +249,8 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     if (w == 0) {
         int rm = NEG_INF, rd = 0x7fffffff, rj = 0x7fffffff;
         for (int j = 1 + L; j <= ql; j += 64) {
-            const unsigned v = (unsigned)__builtin_nontemporal_load(rowbuf + (size_t)j * 33 + rl);
-            const int sc = (gl >= NL ? hi16(v) : lo16(v)) + __builtin_nontemporal_load(rowbuf + (size_t)j * 33 + SR) - (tl + j) * gext, d = abs(tl - j);
+            const unsigned v = (unsigned)__builtin_nontemporal_load(rowbuf + 2 * j);
+            const int sc = (gl >= NL ? hi16(v) : lo16(v)) + __builtin_nontemporal_load(rowbuf + 2 * j + 1) - (tl + j) * gext, d = abs(tl - j);
             const bool take = sc > rm || (sc == rm && (d < rd || (d == rd && j < rj)));
             rm = take ? sc : rm;
             rd = take ? d : rd;
