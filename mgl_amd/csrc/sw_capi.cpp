@@ -330,7 +330,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         const int sw_ = ((max_tl + 31) / 32 + 127) / 128;
         // worth it when enough of the issued lanes are real cells: strips of the 128 W slots x useful steps of all steps (10 kb x
         // 10 kb: 0.71, and 2.24 TCUPS against 1.82 for the workgroup pipeline: break-even near 0.58)
-        const double used = (double)((max_tl + 31) / 32) / (128.0 * sw_) * ((max_ql + 3) / 4) / (double)strip16_steps(max_ql, sw_);
+        const double used = (double)((max_tl + 31) / 32) / (128.0 * sw_) * strip16_groups(max_ql) / (double)strip16_steps(max_ql, sw_);
         const bool want = ctx->strip_kernel == 2 || (ctx->strip_kernel == 0 && coop_waves && ctx->cooperative < 2 && max_tl >= 4096 && used >= 0.6);
         if (want && strip_env != 0 && !use16 && !use_lane && !d_matrix && ctx->precision != 32 && ctx->carry_memory == 0 && !ctx->stripe_rows && sw_ <= 4 &&
             strip16_lds_bytes(max_ql, sw_) <= 64 * 1024 && strip16_range_ok(match, mismatch, gopen, gext)) {

@@ -162,9 +162,11 @@ bool coop16_possible(int match, int mismatch, int gopen, int gext);   // constan
 bool coop16_worthwhile(int match, int mismatch, int gopen, int gext); // ... and a typical score window does too
 int coop16_lds_bytes(int sps_cap, int waves_per_block);
 // long reads, one strip of 32 rows per lane-half (sw_dp16_strip.hip): W waves per pair hold 128 W strips; steps of four columns
-__host__ __device__ inline int strip16_steps(int ql, int waves) { return ((ql + 3) >> 2) + 2 * 64 * waves - 1; }
+constexpr int STRIP_CPS = 4; // columns per step (2 or 4).  Two halve the pipeline ramp and the loop body but double the hand-overs: 46.3 ms per 1024 pairs of 10 kb against 45.6
+__host__ __device__ inline int strip16_groups(int ql) { return (ql + STRIP_CPS - 1) / STRIP_CPS; }
+__host__ __device__ inline int strip16_steps(int ql, int waves) { return strip16_groups(ql) + 2 * 64 * waves - 1; }
 __host__ __device__ inline int strip16_qwords(int ql) { return ((((ql + 3) >> 2) + 4) + 3) & ~3; }
-__host__ __device__ inline int64_t tb_words_strip16(int ql, int waves) { return (int64_t)waves * strip16_steps(ql, waves) * 8 * 64 * 4; } // [wave][step][4][2][lane] uint4
+__host__ __device__ inline int64_t tb_words_strip16(int ql, int waves) { return (int64_t)waves * strip16_steps(ql, waves) * STRIP_CPS * 2 * 64 * 4; } // [wave][step][CPS][2][lane] uint4
 __host__ __device__ inline int64_t strip16_scratch_bytes(int ql, int waves) { return ((int64_t)(ql + 8) * 2 + 2 * 33 * 64 * waves) * 4; } // per pair
 int strip16_lds_bytes(int max_ql, int waves);
 bool strip16_range_ok(int match, int mismatch, int gopen, int gext);

@@ -36,6 +36,7 @@ namespace mgl_sw_dev {
 namespace {
 
 constexpr int SR = 32;               // rows per strip
+constexpr int CPS = STRIP_CPS;       // columns per step
 constexpr int STRIP_LEVEL = -14000;  // where a move of the baseline puts the strip's first row
 
 __device__ __forceinline__ unsigned dpp_wave_shr1(unsigned lane0_value, unsigned src)
@@ -54,7 +55,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     const int64_t p = a.first + slot;
     const int64_t t0 = a.t.off[p], q0 = a.q.off[p];
     const int tl = a.t.length(p), ql = a.q.length(p);
-    const int NCG = (ql + 3) >> 2;            // column groups
+    const int NCG = strip16_groups(ql);       // column groups
     const int steps = NCG + 2 * NL - 1;
     const int steps_cap = strip16_steps(a.uni_ql, W); // what the regions are sized for
     const int match = a.match, gopen = a.gopen, gext = a.gext;
@@ -106,14 +107,14 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     unsigned hd = 0u;
     int base_a = 0, base_b = 0;                // the halves' baselines (int32): true stored value = register + baseline
     unsigned bres = 0u;                        // the same, modulo 2^16, packed
-    unsigned out_h[4] = {0u, 0u, 0u, 0u}, out_e[4] = {0u, 0u, 0u, 0u}; // what this lane hands on: TRUE residues of (H, E') of its last rows
-    const int ulast = (ql - 1) & 3;
+    unsigned out_h[CPS] = {}, out_e[CPS] = {}; // what this lane hands on: TRUE residues of (H, E') of its last rows
+    const int ulast = (ql - 1) % CPS;
     const int gl = (tl - 1) >> 5;                     // the strip and (as a scalar) the register row of target row tl
     const int rl_s = __builtin_amdgcn_readfirstlane((tl - 1) & 31);
     const bool own_last_a = gA == gl, own_last_b = gB == gl;
     int best = NEG_INF, best_i = -1;            // last-column candidates of this lane (both halves merged: later row wins)
 
-    uint4 *const tb_wave = reinterpret_cast<uint4 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words) + (size_t)w * steps_cap * 8 * 64 + L;
+    uint4 *const tb_wave = reinterpret_cast<uint4 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words) + (size_t)w * steps_cap * CPS * 2 * 64 + L;
 
     for (int s = 0; s < steps; ++s) {
         const int cgA = s - gA, cgB = s - gB;
@@ -125,7 +126,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
         auto take = [&](const int u, unsigned &ih, unsigned &ie) {
             unsigned l0h = mb_in[u], l0e = mb_in[4 + u];
             if (w == 0) {
-                const int j = 4 * s + u + 1;
+                const int j = CPS * s + u + 1;
                 const int hb0 = border(j, gopen, gext, indel) + j * gext;
                 l0h = ((unsigned)hb0 & 0xffffu) | (l0h << 16);
                 l0e = ((unsigned)(hb0 - (gopen - gext)) & 0xffffu) | (l0e << 16);
@@ -158,7 +159,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                 hd = (hd & keep) | (pack2(hd0, hd0) & ~keep);
             }
             // ---- 3. every 16 columns the baselines move: the strip's first row back to its level (both halves are in the same phase)
-            if ((cgA & 3) == 0) {
+            if ((cgA & (16 / CPS - 1)) == 0) {
                 const unsigned d = pk_sub(h[0], level);
 #pragma unroll
                 for (int r = 0; r < SR; ++r) {
@@ -171,14 +172,17 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                 bres = pk_add(bres, d);
             }
             // ---- 4. four columns
-            const unsigned qa = Q[min(max(cgA, 0), qwords - 1)], qb = Q[min(max(cgB, 0), qwords - 1)];
-            uint4 *tbp = tb_wave + (size_t)s * 8 * 64;
+            // (a query dword holds 4 / CPS groups; the two halves are 64 W groups apart, so they sit in the same place of their dwords)
+            constexpr int GPD = 4 / CPS;
+            const unsigned qa = Q[min(max(cgA / GPD, 0), qwords - 1)], qb = Q[min(max(cgB / GPD, 0), qwords - 1)];
+            const unsigned qsel = 0x0c040c00u + 0x00010001u * (unsigned)(CPS * (cgA & (GPD - 1)));
+            uint4 *tbp = tb_wave + (size_t)s * CPS * 2 * 64;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < CPS; ++u) {
                 unsigned ih, e;
                 take(u, ih, e);
                 e = pk_sub(e, bres);
-                const unsigned q = __builtin_amdgcn_perm(qb, qa, 0x0c040c00u + 0x00010001u * (unsigned)u);
+                const unsigned q = __builtin_amdgcn_perm(qb, qa, qsel + 0x00010001u * (unsigned)u);
                 column<SR, NOTB>(h, f, t, q, hd, e, c, tbp + (size_t)u * 2 * 64);
                 hd = pk_sub(ih, bres);
                 out_h[u] = pk_add(h[SR - 1], bres);
@@ -196,7 +200,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                     // the strip that holds row tl: H[tl][j] with its baseline, for the scan of the last row below.  The register row is the
                     // same for the whole pair: a scalar switch (a 32-way select here costs the allocator its spare registers, and
                     // parking all 32 rows made this one lane's wave -- and with it, behind the barrier, the pair -- 132 stores a step slower)
-                    const int j = 4 * (own_last_b ? cgB : cgA) + u + 1;
+                    const int j = CPS * (own_last_b ? cgB : cgA) + u + 1;
                     if (j <= ql) {
                         unsigned v;
                         switch (rl_s) {
@@ -216,8 +220,11 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
         // ---- 5. the last lane of every wave posts what it hands on; one barrier per step
         if (L == 63) {
             unsigned *mb = mbox + ((s & 1) * W + w) * 8;
-            *reinterpret_cast<uint4 *>(mb) = make_uint4(out_h[0], out_h[1], out_h[2], out_h[3]);
-            *reinterpret_cast<uint4 *>(mb + 4) = make_uint4(out_e[0], out_e[1], out_e[2], out_e[3]);
+#pragma unroll
+            for (int u = 0; u < CPS; ++u) {
+                mb[u] = out_h[u];
+                mb[4 + u] = out_e[u];
+            }
         }
         __syncthreads();
     }

@@ -45,7 +45,7 @@ struct TbView {
             // (g < NL) or high half of lane g mod NL and works on column group cg at step cg + g; NL = 64 * waves
             const int g = r >> 5, rr = r & 31, nl = 64 * waves;
             const int h = g >= nl, ell = g - h * nl;
-            const size_t u4 = (((((size_t)(ell >> 6) * sps + ((j - 1) >> 2) + g) * 4 + ((j - 1) & 3)) * 2) + (rr >> 4)) * 64 + (ell & 63);
+            const size_t u4 = (((((size_t)(ell >> 6) * sps + (j - 1) / STRIP_CPS + g) * STRIP_CPS + (j - 1) % STRIP_CPS) * 2) + (rr >> 4)) * 64 + (ell & 63);
             const uint32_t w = base[u4 * 4 + ((rr >> 2) & 3)];
             const int t2 = (rr & 3) * 2;
             const unsigned be = (w >> (8 * h)) >> t2, bf = (w >> (16 + 8 * h)) >> t2;
