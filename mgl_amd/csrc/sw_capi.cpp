@@ -330,7 +330,11 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         const int sw_ = ((max_tl + 31) / 32 + 127) / 128;
         // worth it when enough of the issued lanes are real cells: strips of the 128 W slots x useful steps of all steps (10 kb x
         // 10 kb: 0.71, and 2.24 TCUPS against 1.82 for the workgroup pipeline: break-even near 0.58)
-        const double used = (double)((max_tl + 31) / 32) / (128.0 * sw_) * strip16_groups(max_ql) / (double)strip16_steps(max_ql, sw_);
+        // rows per strip: as few as still cover the longest target with these waves (fewer rows = fewer instructions per column)
+        int sr_ = 32;
+        for (int cand : {28, 24, 20})
+            if ((max_tl + cand - 1) / cand <= 128 * sw_) sr_ = cand;
+        const double used = (double)((max_tl + sr_ - 1) / sr_) / (128.0 * sw_) * strip16_groups(max_ql) / (double)strip16_steps(max_ql, sw_);
         const bool want = ctx->strip_kernel == 2 || (ctx->strip_kernel == 0 && coop_waves && ctx->cooperative < 2 && max_tl >= 4096 && used >= 0.6);
         if (want && strip_env != 0 && !use16 && !use_lane && !d_matrix && ctx->precision != 32 && ctx->carry_memory == 0 && !ctx->stripe_rows && sw_ <= 4 &&
             strip16_lds_bytes(max_ql, sw_) <= 64 * 1024 && strip16_range_ok(match, mismatch, gopen, gext)) {
@@ -338,7 +342,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             strip_waves = sw_;
             coop16 = false;
             coop_waves = 0;
-            rows = 32;
+            rows = sr_;
             wpb = sw_;
             sps_cap = strip16_steps(max_ql, sw_);
         }
@@ -639,7 +643,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             if (!fused_walk) walk.cigar = nullptr;
             HIP_TRY(ctx, pt.lane ? launch_dp16_lane(das[i], walk, pt.rows, fs)
                          : pt.packed ? launch_dp16(das[i], pt.wpb, fs)
-                         : strip16 ? launch_dp16_strip(das[i], strip_waves, fs)
+                         : strip16 ? launch_dp16_strip(das[i], strip_waves, pt.rows, fs)
                          : coop16 ? launch_dp_coop16(das[i], coop_waves, fs) : coop_waves ? launch_dp_coop(das[i], coop_waves, fs) : launch_dp(das[i], pt.wpb, pt.rows, fs));
         }
         if (pe[1]) HIP_TRY(ctx, hipEventRecord(pe[1], fs));

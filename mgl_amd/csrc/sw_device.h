@@ -170,7 +170,7 @@ __host__ __device__ inline int64_t tb_words_strip16(int ql, int waves) { return 
 __host__ __device__ inline int64_t strip16_scratch_bytes(int ql, int waves) { return ((int64_t)(ql + 8) * 2 + 2 * 33 * 64 * waves) * 4; } // per pair
 int strip16_lds_bytes(int max_ql, int waves);
 bool strip16_range_ok(int match, int mismatch, int gopen, int gext);
-hipError_t launch_dp16_strip(const DpArgs &a, int waves, hipStream_t stream); // a.uni_ql = max_ql sizes the regions; a.scratch: (max_ql + 8) ints per pair
+hipError_t launch_dp16_strip(const DpArgs &a, int waves, int rows, hipStream_t stream); // rows per strip: 20 / 24 / 28 / 32; a.uni_ql = max_ql sizes the regions; a.scratch: strip16_scratch_bytes per pair
 hipError_t launch_dp_coop16(const DpArgs &a, int waves_per_block, hipStream_t stream); // a.sps_cap = coop16_sps_for(max_ql)
 hipError_t launch_traceback(const TbArgs &a, hipStream_t stream);
 

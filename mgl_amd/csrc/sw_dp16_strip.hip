@@ -35,7 +35,6 @@ namespace mgl_sw_dev {
 
 namespace {
 
-constexpr int SR = 32;               // rows per strip
 constexpr int CPS = STRIP_CPS;       // columns per step
 constexpr int STRIP_LEVEL = -14000;  // where a move of the baseline puts the strip's first row
 
@@ -44,7 +43,7 @@ __device__ __forceinline__ unsigned dpp_wave_shr1(unsigned lane0_value, unsigned
     return (unsigned)__builtin_amdgcn_update_dpp((int)lane0_value, (int)src, 0x138, 0xf, 0xf, false);
 }
 
-template <bool NOTB>
+template <int SR, bool NOTB>
 __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned char *smem)
 {
     const int L = threadIdx.x & 63;
@@ -109,8 +108,8 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     unsigned bres = 0u;                        // the same, modulo 2^16, packed
     unsigned out_h[CPS] = {}, out_e[CPS] = {}; // what this lane hands on: TRUE residues of (H, E') of its last rows
     const int ulast = (ql - 1) % CPS;
-    const int gl = (tl - 1) >> 5;                     // the strip and (as a scalar) the register row of target row tl
-    const int rl_s = __builtin_amdgcn_readfirstlane((tl - 1) & 31);
+    const int gl = (tl - 1) / SR;                     // the strip and (as a scalar) the register row of target row tl
+    const int rl_s = __builtin_amdgcn_readfirstlane((tl - 1) % SR);
     const bool own_last_a = gA == gl, own_last_b = gB == gl;
     int best = NEG_INF, best_i = -1;            // last-column candidates of this lane (both halves merged: later row wins)
 
@@ -194,7 +193,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                     unsigned *cp = cap + (cgB == NCG - 1 && actB ? 33 : 0); // (one base address, 33 immediate offsets)
 #pragma unroll
                     for (int r = 0; r < SR; ++r) cp[r] = h[r];
-                    cp[SR] = (unsigned)(cgB == NCG - 1 && actB ? base_b : base_a);
+                    cp[32] = (unsigned)(cgB == NCG - 1 && actB ? base_b : base_a);
                 }
                 if ((own_last_a && actA) || (own_last_b && actB)) {
                     // the strip that holds row tl: H[tl][j] with its baseline, for the scan of the last row below.  The register row is the
@@ -204,7 +203,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                     if (j <= ql) {
                         unsigned v;
                         switch (rl_s) {
-#define MGL_ROW(K) case K: v = h[K]; break;
+#define MGL_ROW(K) case K: v = h[K < SR ? K : 0]; break;
                             MGL_ROW(0) MGL_ROW(1) MGL_ROW(2) MGL_ROW(3) MGL_ROW(4) MGL_ROW(5) MGL_ROW(6) MGL_ROW(7) MGL_ROW(8) MGL_ROW(9) MGL_ROW(10)
                             MGL_ROW(11) MGL_ROW(12) MGL_ROW(13) MGL_ROW(14) MGL_ROW(15) MGL_ROW(16) MGL_ROW(17) MGL_ROW(18) MGL_ROW(19) MGL_ROW(20)
                             MGL_ROW(21) MGL_ROW(22) MGL_ROW(23) MGL_ROW(24) MGL_ROW(25) MGL_ROW(26) MGL_ROW(27) MGL_ROW(28) MGL_ROW(29) MGL_ROW(30)
@@ -237,7 +236,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
         const int i0 = half ? i0B : i0A;
         if (i0 < tl) {
             const unsigned *cp = cap + (half ? 33 : 0);
-            const int bb = (int)__builtin_nontemporal_load(cp + SR);
+            const int bb = (int)__builtin_nontemporal_load(cp + 32);
             for (int r = 0; r < SR; ++r) {
                 const unsigned v = __builtin_nontemporal_load(cp + r);
                 const int row = i0 + r + 1;
@@ -292,12 +291,20 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
 
 } // namespace
 
-// grid = pairs of the chunk, block = 64 * W threads (W <= 4), dynamic LDS = strip16_lds_bytes
-__global__ __launch_bounds__(256, 3) void sw_dp16_strip_kernel(const DpArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    sw_dp16_strip_body<false>(a, smem);
-}
+// grid = pairs of the chunk, block = 64 * W threads (W <= 4), dynamic LDS = strip16_lds_bytes.  Rows per strip: 32, or fewer when
+// that still covers the longest target with the same number of waves (10 000 rows on 384 strip slots: 28 rows each instead of
+// 313 strips of 32 -- an eighth fewer instructions per column)
+#define MGL_STRIP_KERNEL(NAME, ROWS)                                                     \
+    __global__ __launch_bounds__(256, 3) void NAME(const DpArgs a)                       \
+    {                                                                                    \
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem[];             \
+        sw_dp16_strip_body<ROWS, false>(a, smem);                                        \
+    }
+MGL_STRIP_KERNEL(sw_dp16_strip_kernel, 32)
+MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r28, 28)
+MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r24, 24)
+MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r20, 20)
+#undef MGL_STRIP_KERNEL
 
 int strip16_lds_bytes(int max_ql, int waves) { return strip16_qwords(max_ql) * 4 + 2 * waves * 8 * 4 + 8 + 16 + 64; }
 
@@ -311,14 +318,12 @@ bool strip16_range_ok(int match, int mismatch, int gopen, int gext)
     return STRIP_LEVEL + above <= 32767 && STRIP_LEVEL - below >= -32768;
 }
 
-hipError_t launch_dp16_strip(const DpArgs &a, int waves, hipStream_t stream)
+hipError_t launch_dp16_strip(const DpArgs &a, int waves, int rows, hipStream_t stream)
 {
     const int lds = strip16_lds_bytes(a.uni_ql, waves);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_dp16_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(sw_dp16_strip_kernel, dim3((unsigned)a.count), dim3(64 * waves), lds, stream, a);
+    if (lds > 64 * 1024) return hipErrorInvalidValue; // (the host checks)
+    void (*k)(const DpArgs) = rows == 28 ? sw_dp16_strip_kernel_r28 : rows == 24 ? sw_dp16_strip_kernel_r24 : rows == 20 ? sw_dp16_strip_kernel_r20 : sw_dp16_strip_kernel;
+    hipLaunchKernelGGL(k, dim3((unsigned)a.count), dim3(64 * waves), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -119,7 +119,7 @@ __device__ __forceinline__ void column(unsigned (&h)[R], unsigned (&f)[R], const
             w[(r >> 2) & 3] = and_or(p34, c.k34[U], U == 0 ? (p12 & c.k12[0]) : and_or(p12, c.k12[U], low));
             // the 16 rows' flags leave right here (1 KB per wave), in the block that computed them: the differences
             // they are made of must not stay live until the end of the column
-            if ((r & 15) == 15) tbp[(size_t)(r >> 4) * 64] = make_uint4(w[0], w[1], w[2], w[3]);
+            if ((r & 15) == 15 || r == R - 1) tbp[(size_t)(r >> 4) * 64] = make_uint4(w[0], w[1], w[2], w[3]); // (a last group of fewer than 16 rows: R = 20, 24, 28)
         }
         h[r] = hn;
         f[r] = fo;

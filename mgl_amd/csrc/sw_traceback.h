@@ -41,9 +41,9 @@ struct TbView {
     {
         const int r = i - 1;
         if (packed16 == 4) {
-            // sw_dp16_strip.hip: [wave][step][column of the group][16-row group][lane] uint4; strip g = row / 32 sits in the low
+            // sw_dp16_strip.hip: [wave][step][column of the group][16-row group][lane] uint4; strip g = row / rows sits in the low
             // (g < NL) or high half of lane g mod NL and works on column group cg at step cg + g; NL = 64 * waves
-            const int g = r >> 5, rr = r & 31, nl = 64 * waves;
+            const int g = r / rows, rr = r - g * rows, nl = 64 * waves; // rows per strip: 20 .. 32
             const int h = g >= nl, ell = g - h * nl;
             const size_t u4 = (((((size_t)(ell >> 6) * sps + (j - 1) / STRIP_CPS + g) * STRIP_CPS + (j - 1) % STRIP_CPS) * 2) + (rr >> 4)) * 64 + (ell & 63);
             const uint32_t w = base[u4 * 4 + ((rr >> 2) & 3)];
