@@ -332,7 +332,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         // 10 kb: 0.71, and 2.24 TCUPS against 1.82 for the workgroup pipeline: break-even near 0.58)
         // rows per strip: as few as still cover the longest target with these waves (fewer rows = fewer instructions per column)
         int sr_ = 32;
-        for (int cand : {28, 24, 20})
+        for (int cand = 31; cand >= 20; --cand)
             if ((max_tl + cand - 1) / cand <= 128 * sw_) sr_ = cand;
         const double used = (double)((max_tl + sr_ - 1) / sr_) / (128.0 * sw_) * strip16_groups(max_ql) / (double)strip16_steps(max_ql, sw_);
         const bool want = ctx->strip_kernel == 2 || (ctx->strip_kernel == 0 && coop_waves && ctx->cooperative < 2 && max_tl >= 4096 && used >= 0.6);

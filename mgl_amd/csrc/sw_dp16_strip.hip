@@ -292,8 +292,8 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
 } // namespace
 
 // grid = pairs of the chunk, block = 64 * W threads (W <= 4), dynamic LDS = strip16_lds_bytes.  Rows per strip: 32, or fewer when
-// that still covers the longest target with the same number of waves (10 000 rows on 384 strip slots: 28 rows each instead of
-// 313 strips of 32 -- an eighth fewer instructions per column)
+// that still covers the longest target with the same number of waves (10 000 rows on 384 strip slots: 27 rows each instead of
+// 313 strips of 32 -- a sixth fewer instructions per column)
 #define MGL_STRIP_KERNEL(NAME, ROWS)                                                     \
     __global__ __launch_bounds__(256, 3) void NAME(const DpArgs a)                       \
     {                                                                                    \
@@ -301,8 +301,17 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
         sw_dp16_strip_body<ROWS, false>(a, smem);                                        \
     }
 MGL_STRIP_KERNEL(sw_dp16_strip_kernel, 32)
+MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r31, 31)
+MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r30, 30)
+MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r29, 29)
 MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r28, 28)
+MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r27, 27)
+MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r26, 26)
+MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r25, 25)
 MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r24, 24)
+MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r23, 23)
+MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r22, 22)
+MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r21, 21)
 MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r20, 20)
 #undef MGL_STRIP_KERNEL
 
@@ -322,7 +331,12 @@ hipError_t launch_dp16_strip(const DpArgs &a, int waves, int rows, hipStream_t s
 {
     const int lds = strip16_lds_bytes(a.uni_ql, waves);
     if (lds > 64 * 1024) return hipErrorInvalidValue; // (the host checks)
-    void (*k)(const DpArgs) = rows == 28 ? sw_dp16_strip_kernel_r28 : rows == 24 ? sw_dp16_strip_kernel_r24 : rows == 20 ? sw_dp16_strip_kernel_r20 : sw_dp16_strip_kernel;
+    static void (*const table[13])(const DpArgs) = {sw_dp16_strip_kernel_r20, sw_dp16_strip_kernel_r21, sw_dp16_strip_kernel_r22, sw_dp16_strip_kernel_r23,
+                                                    sw_dp16_strip_kernel_r24, sw_dp16_strip_kernel_r25, sw_dp16_strip_kernel_r26, sw_dp16_strip_kernel_r27,
+                                                    sw_dp16_strip_kernel_r28, sw_dp16_strip_kernel_r29, sw_dp16_strip_kernel_r30, sw_dp16_strip_kernel_r31,
+                                                    sw_dp16_strip_kernel};
+    if (rows < 20 || rows > 32) return hipErrorInvalidValue;
+    void (*k)(const DpArgs) = table[rows - 20];
     hipLaunchKernelGGL(k, dim3((unsigned)a.count), dim3(64 * waves), lds, stream, a);
     return hipGetLastError();
 }
