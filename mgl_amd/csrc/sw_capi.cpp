@@ -328,14 +328,15 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     {
         static const int strip_env = [] { const char *e = getenv("MGL_SW_STRIP16"); return e ? atoi(e) : -1; }();
         const int sw_ = ((max_tl + 31) / 32 + 127) / 128;
-        // worth it when enough of the issued lanes are real cells: strips of the 128 W slots x useful steps of all steps (10 kb x
-        // 10 kb: 0.71, and 2.24 TCUPS against 1.82 for the workgroup pipeline: break-even near 0.58)
+        // worth it when enough of the issued lanes are real cells: strips of the 128 W slots x useful steps of all steps
         // rows per strip: as few as still cover the longest target with these waves (fewer rows = fewer instructions per column)
         int sr_ = 32;
         for (int cand = 31; cand >= 20; --cand)
             if ((max_tl + cand - 1) / cand <= 128 * sw_) sr_ = cand;
         const double used = (double)((max_tl + sr_ - 1) / sr_) / (128.0 * sw_) * strip16_groups(max_ql) / (double)strip16_steps(max_ql, sw_);
-        const bool want = ctx->strip_kernel == 2 || (ctx->strip_kernel == 0 && coop_waves && ctx->cooperative < 2 && max_tl >= 4096 && used >= 0.6);
+        // (measured against the kernels it replaces, pairs of n x n: 1.5 kb 1 354 against 1 124 GCUPS at used = 0.44; 2 kb 1 844 / 1 014;
+        // 3 kb 2 474 / 870; 4 kb 2 987 / 1 385; 10 kb 2 480 / 1 824)
+        const bool want = ctx->strip_kernel == 2 || (ctx->strip_kernel == 0 && (coop_waves || rows == 64) && ctx->cooperative < 2 && used >= 0.4);
         if (want && strip_env != 0 && !use16 && !use_lane && !d_matrix && ctx->precision != 32 && ctx->carry_memory == 0 && !ctx->stripe_rows && sw_ <= 4 &&
             strip16_lds_bytes(max_ql, sw_) <= 64 * 1024 && strip16_range_ok(match, mismatch, gopen, gext)) {
             strip16 = true;

@@ -36,6 +36,8 @@ stride = 2 * (length + 2000)
 b = device_batch.from_host(td, toff, qd, qoff, "cuda:0", cigar_stride=stride)
 a = MicrosoftSmithWaterman(0)
 a.set_workspace(int(args.workspace_gib * (1 << 30)))
+if os.environ.get("MGL_STRIP"):
+    a.set_strip_kernel(int(os.environ["MGL_STRIP"]))   # 1 = never, 2 = whenever eligible
 if os.environ.get("MGL_COOP_W"):
     a.set_cooperative(int(os.environ["MGL_COOP_W"]))
 cells = b.cells
