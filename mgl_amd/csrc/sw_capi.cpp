@@ -327,7 +327,12 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     int strip_waves = 0;
     {
         static const int strip_env = [] { const char *e = getenv("MGL_SW_STRIP16"); return e ? atoi(e) : -1; }();
-        const int sw_ = ((max_tl + 31) / 32 + 127) / 128;
+        // waves per pair: as few as hold the target in strips of 32 rows -- but never three: workgroups of three waves run a
+        // quarter slower than those of one, two or four (pairs of 8 / 10 / 12 kb with two or four waves: 3.09 / 2.69 / 2.99
+        // TCUPS, with three: 2.40 / 2.43 / 2.58; three waves do not spread evenly over a CU's four SIMDs)
+        static const int strip_waves_env = [] { const char *e = getenv("MGL_SW_STRIP_WAVES"); return e ? atoi(e) : 0; }();
+        int sw_ = std::max(strip_waves_env, ((max_tl + 31) / 32 + 127) / 128);
+        if (sw_ == 3 && strip_waves_env != 3) sw_ = 4;
         // worth it when enough of the issued lanes are real cells: strips of the 128 W slots x useful steps of all steps
         // rows per strip: as few as still cover the longest target with these waves (fewer rows = fewer instructions per column)
         int sr_ = 32;
