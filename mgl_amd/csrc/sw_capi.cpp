@@ -342,7 +342,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         // (measured against the kernels it replaces, pairs of n x n: 1.5 kb 1 354 against 1 124 GCUPS at used = 0.44; 2 kb 1 844 / 1 014;
         // 3 kb 2 474 / 870; 4 kb 2 987 / 1 385; 10 kb 2 480 / 1 824)
         const bool want = ctx->strip_kernel == 2 || (ctx->strip_kernel == 0 && (coop_waves || rows == 64) && ctx->cooperative < 2 && used >= 0.4);
-        if (want && strip_env != 0 && !use16 && !use_lane && !d_matrix && ctx->precision != 32 && ctx->carry_memory == 0 && !ctx->stripe_rows && sw_ <= 4 &&
+        // (its time-major traceback regions are larger than the workgroup kernel's -- 97 MB against 50 for a 10 kb pair: a workspace
+        // that cannot hold one of them per half keeps the workgroup kernel)
+        const bool fits = tb_words_strip16(max_ql, sw_) * 4 + (int64_t)sizeof(DpRecord) <= ctx->ws_limit / 2;
+        if (want && fits && strip_env != 0 && !use16 && !use_lane && !d_matrix && ctx->precision != 32 && ctx->carry_memory == 0 && !ctx->stripe_rows && sw_ <= 4 &&
             strip16_lds_bytes(max_ql, sw_) <= 64 * 1024 && strip16_range_ok(match, mismatch, gopen, gext)) {
             strip16 = true;
             strip_waves = sw_;
