@@ -77,6 +77,7 @@ typedef struct mgl_sw_timing {
 #define MGL_SW_KERNEL_LANE16 4    /* sw_dp16_lane_kernel: packed int16, two pairs per LANE       */
 #define MGL_SW_KERNEL_COOP16 5    /* sw_dp_coop16_kernel: long reads, packed int16, 128 rows/wave */
 #define MGL_SW_KERNEL_STRIP16 6   /* sw_dp16_strip_kernel: long reads, one 32-row strip per lane-half */
+#define MGL_SW_KERNEL_LANE16_CK 7 /* sw_dp16_lane_ck_kernel: the lane kernel, checkpoints instead of stored flags */
 
 typedef struct mgl_sw_ctx mgl_sw_ctx; /* opaque: one GPU, its workspace and stream */
 
@@ -124,6 +125,12 @@ int mgl_sw_ctx_set_strip_kernel(mgl_sw_ctx *ctx, int mode);
  * two-pairs-per-lane-of-a-16-lane-group kernel (sw_dp16.hip: eight pairs per wave); 1 = never the lane kernel;
  * 2 = the lane kernel whenever the batch is eligible (tests; results are identical) */
 int mgl_sw_ctx_set_lane_kernel(mgl_sw_ctx *ctx, int mode);
+/* the lane kernel stores no traceback by default (sw_dp16_lane_ck.hip): its fill keeps the carry row of every 32-row strip and the
+ * lanes' state every 16 query columns, and the path walk recomputes the 32 x 16 blocks it crosses (same flags, same results, about a
+ * fifth of the matrix twice instead of eight flag instructions for every cell).  0 (default) = that form whenever the lane kernel
+ * runs with 32-row strips and writes CIGARs; 1 = never (the flags of every cell are stored: needed before mgl_sw_ctx_expand_slot);
+ * 2 = same as 0 (tests) */
+int mgl_sw_ctx_set_lane_checkpoint(mgl_sw_ctx *ctx, int mode);
 /* 1 = HIP events around every kernel launch of a call, on the streams the kernels run on, read back by
  * mgl_sw_ctx_get_timing (the call itself stays asynchronous); 2 = additionally stamp the shader clock
  * inside the fill kernel (diagnostic; a few extra instructions per workgroup); 0 = off */

@@ -90,6 +90,7 @@ struct mgl_sw_ctx {
     int cooperative = 0;  // 0 = choose per batch, 1 = never, 2..16 = always, that many waves per pair (tests)
     int strip_kernel = 0; // long reads, one strip per lane-half (sw_dp16_strip.hip): 0 = by size, 1 = never, 2 = whenever eligible (tests)
     int lane_kernel = 0;  // two-pairs-per-lane packed kernel: 0 = large uniform batches, 1 = never, 2 = whenever eligible (tests)
+    int lane_checkpoint = 0; // ... in its checkpointed form (sw_dp16_lane_ck.hip, no stored traceback): 0 = by default, 1 = never, 2 = always
     int last_rows = 16;
     hipStream_t aux = nullptr;                       // traceback stream
     hipStream_t fill2 = nullptr;                     // host-buffer entry, lane kernel: odd chunks (their tails overlap the next chunk)
@@ -367,11 +368,18 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // the kernels hold X + (i + j) * gext in 32 bits; the reference's own int arithmetic overflows beyond this too
     if (((int64_t)match - mismatch + gopen + 2 * (int64_t)gext) * ((int64_t)max_tl + max_ql) >= (1ll << 30))
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "scores of this geometry and these parameters leave the 32-bit range");
+    // the lane kernel without stored flags (sw_dp16_lane_ck.hip): its walk recomputes the blocks the path crosses; strips of 32 rows,
+    // fused walk only (a caller who wants the matrix itself -- mgl_sw_ctx_expand_slot -- switches it off)
+    static const int lane_ck_env = [] { const char *e = getenv("MGL_SW_LANE_CK"); return e ? atoi(e) : -1; }();
+    static const bool lane_fuse_on = [] { const char *e = getenv("MGL_SW_LANE_FUSE"); return !e || atoi(e) != 0; }();
+    const bool lane_ck = use_lane && rows == 32 && !score_only && lane_fuse_on && d_cigar != nullptr && ctx->lane_checkpoint != 1 &&
+                         (ctx->lane_checkpoint == 2 || lane_ck_env != 0);
     // traceback words per pair (int32 layout) or per group of two pairs (packed16 layout)
     // (packed layout: the step count of a pair is not monotone in tl or ql -- a partial last stripe runs stand-alone, short
     // queries are not chained -- so a grouped batch, whose waves each run their own geometry, is sized by a bound that is)
     // (lane layout: words per WAVE of 128 pairs, plus the wave's carry row)
-    const int64_t stride_words = use_lane ? lane_tb_words(max_tl, max_ql, rows)
+    const int64_t stride_words = lane_ck ? lane_ck_words(max_tl, max_ql)
+                                 : use_lane ? lane_tb_words(max_tl, max_ql, rows)
                                  : use16 ? (geom == GEOM_UNIFORM ? tb_words16_for(max_tl, max_ql) : tb_words16_bound(max_tl, max_ql))
                                  : strip16 ? tb_words_strip16(max_ql, strip_waves)
                                  : coop16 ? std::max(tb_words_for(max_tl, coop_sps_for(max_ql), 64), tb_words_coop16(max_tl, max_ql)) // either layout
@@ -650,7 +658,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             const Part &pt = parts[i];
             TbArgs walk = tas[i];
             if (!fused_walk) walk.cigar = nullptr;
-            HIP_TRY(ctx, pt.lane ? launch_dp16_lane(das[i], walk, pt.rows, fs)
+            HIP_TRY(ctx, pt.lane ? (lane_ck ? launch_dp16_lane_ck(das[i], walk, fs) : launch_dp16_lane(das[i], walk, pt.rows, fs))
                          : pt.packed ? launch_dp16(das[i], pt.wpb, fs)
                          : strip16 ? launch_dp16_strip(das[i], strip_waves, pt.rows, fs)
                          : coop16 ? launch_dp_coop16(das[i], coop_waves, fs) : coop_waves ? launch_dp_coop(das[i], coop_waves, fs) : launch_dp(das[i], pt.wpb, pt.rows, fs));
@@ -687,12 +695,12 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         ctx->last_chunk_count = auto_group ? 0 : count; // (a chunk sorted by geometry has no caller-order slots to expand)
         ctx->last_half = h;
         ctx->last_rows = rows;
-        ctx->last_packed16 = use_lane ? 2 : use16 ? 1 : strip16 ? 4 : coop16 ? 3 : 0;
+        ctx->last_packed16 = lane_ck ? 5 : use_lane ? 2 : use16 ? 1 : strip16 ? 4 : coop16 ? 3 : 0;
         ctx->timing.dp_launches++;
         ctx->timing.tb_launches++;
         ctx->timing.tb_bytes += (use_lane ? (count + 127) / 128 : use16 ? (count + 1) / 2 : count) * stride_words * 4;
         ctx->timing.packed16 = (use16 || use_lane) ? 1 : 0;
-        ctx->timing.fill_kernel = use_lane ? MGL_SW_KERNEL_LANE16 : use16 ? MGL_SW_KERNEL_DP16 : strip16 ? MGL_SW_KERNEL_STRIP16 : coop16 ? MGL_SW_KERNEL_COOP16 : coop_waves ? MGL_SW_KERNEL_COOP : rows == 64 ? MGL_SW_KERNEL_DP32_64 : MGL_SW_KERNEL_DP32;
+        ctx->timing.fill_kernel = lane_ck ? MGL_SW_KERNEL_LANE16_CK : use_lane ? MGL_SW_KERNEL_LANE16 : use16 ? MGL_SW_KERNEL_DP16 : strip16 ? MGL_SW_KERNEL_STRIP16 : coop16 ? MGL_SW_KERNEL_COOP16 : coop_waves ? MGL_SW_KERNEL_COOP : rows == 64 ? MGL_SW_KERNEL_DP32_64 : MGL_SW_KERNEL_DP32;
     }
     for (int i = 0; hooks && i < n_pending; ++i) {
         const int hrc = hooks->after_traceback(pending[i].first, pending[i].count, pending[i].ready);
@@ -890,6 +898,14 @@ int mgl_sw_ctx_set_cooperative(mgl_sw_ctx *ctx, int mode)
     if (!ctx || mode < 0 || mode > 16) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->cooperative = mode;
+    return MGL_SW_OK;
+}
+
+int mgl_sw_ctx_set_lane_checkpoint(mgl_sw_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->lane_checkpoint = mode;
     return MGL_SW_OK;
 }
 
@@ -1476,6 +1492,9 @@ int mgl_sw_ctx_expand_slot(mgl_sw_ctx *ctx, int64_t slot, int tl, int ql, int32_
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, ctx->d_btr.reserve(cells * 4));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_btr.p, 0, cells * 4, ctx->stream));
+    if (ctx->last_packed16 == 5)
+        return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "mgl_sw_ctx_expand_slot: the last call kept no traceback (checkpointed lane kernel); "
+                                                  "switch it off with mgl_sw_ctx_set_lane_checkpoint(ctx, 1)");
     const int64_t region = ctx->last_packed16 == 2 ? slot >> 7 : ctx->last_packed16 == 1 ? slot >> 1 : slot;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
     HIP_TRY(ctx, launch_expand(static_cast<const uint32_t *>(ctx->tb[ctx->last_half].p) + region * ctx->last_stride_words,

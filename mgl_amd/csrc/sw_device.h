@@ -146,6 +146,17 @@ __host__ __device__ inline int64_t tb_words_coop16(int tl, int ql) { return (int
 __host__ __device__ inline int coop_query_bytes(int sps_cap) { return (sps_cap + 192 + 15) & ~15; } // 64 + ql + slack
 __host__ __device__ inline int coop_wrap_cols(int sps_cap) { return sps_cap + 192; }                // 8 bytes each, per pair
 
+// ---- sw_dp16_lane_ck_kernel (sw_dp16_lane_ck.hip): the same kernel without stored flags -- carry rows of every 32-row strip and
+// the lanes' register state every LANE_CK_COLS columns are kept, the walk recomputes the blocks its path crosses
+constexpr int LANE_CK_COLS = 16;
+__host__ __device__ inline int lane_ck_blocks(int ql) { return (ql + LANE_CK_COLS - 1) / LANE_CK_COLS; }
+// dwords per WAVE: rows [2 strips + 1][ql + 1][lane] uint2, checkpoints [strip][block][16][lane] uint4, one block of flags [column][lane] uint4
+__host__ __device__ inline int64_t lane_ck_words(int tl, int ql)
+{
+    const int64_t strips = lane_strips(tl, 32);
+    return (2 * strips + 1) * (ql + 1) * 128 + 64 * strips * lane_ck_blocks(ql) * 64 + (int64_t)LANE_CK_COLS * 64 * 4;
+}
+
 int64_t dp_group_bytes(int sps_cap, int rows); // carry ring + query copies of one pair (LDS, or HBM scratch)
 int dp_lds_bytes(int sps_cap, int waves_per_block, int rows);
 int dp16_lds_bytes(int sps, int waves_per_block);
@@ -155,6 +166,7 @@ bool lane16_supported(const SeqSet &t, const SeqSet &q);
 struct TbArgs;
 // a.scratch = per-wave scratch, a.tb_stride_words per wave; walk.cigar != null: every lane also walks the paths of its two pairs
 hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &walk, int rows, hipStream_t stream);
+hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &walk, hipStream_t stream); // a.tb_stride_words = lane_ck_words per wave; walk.cigar != null
 hipError_t launch_dp(const DpArgs &a, int waves_per_block, int rows, hipStream_t stream);
 int coop_lds_bytes(int sps_cap, int waves_per_block);
 hipError_t launch_dp_coop(const DpArgs &a, int waves_per_block, hipStream_t stream);

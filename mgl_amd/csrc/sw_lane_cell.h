@@ -85,9 +85,10 @@ struct LaneConsts {
 // R rows of one column for both packed pairs.  h[r]: H[row r][j-1] on entry, H[row r][j] on exit; f[r]: F of row r (in);
 // hd: H[row -1][j-1] (the strip's top row, previous column); hup / e: H and E coming down from the strip above.
 // On exit e = E leaving the strip's last row, h[R-1] = H of its last row.  w: the R/4 traceback dwords of the column.
-template <int R, bool NOTB>
+// MID: {H, E} leaving row 15 also go to *mid (sw_dp16_lane_ck.hip: the carry row of the strip's lower half).
+template <int R, bool NOTB, bool MID = false>
 __device__ __forceinline__ void column(unsigned (&h)[R], unsigned (&f)[R], const unsigned (&t)[R], const unsigned q, unsigned hd,
-                                       unsigned &e, const LaneConsts &c, uint4 *tbp)
+                                       unsigned &e, const LaneConsts &c, uint4 *tbp, uint2 *mid = nullptr)
 {
     unsigned w[4];
     // the diagonal of row r + 1 is taken from H[r][j-1] BEFORE row r overwrites it with H[r][j] (so that H stays in place,
@@ -124,6 +125,7 @@ __device__ __forceinline__ void column(unsigned (&h)[R], unsigned (&f)[R], const
         h[r] = hn;
         f[r] = fo;
         e = eo;
+        if (MID && r == 15) *mid = make_uint2(hn, eo);
         // F' is only needed in the next column: left alone, the compiler sinks its max to the end of the loop body and keeps
         // `open` and the old F of all R rows alive until there
         asm volatile("" : "+v"(f[r]), "+v"(h[r]));

@@ -191,6 +191,11 @@ class MicrosoftSmithWaterman:
         """Packed kernel for uniform batches: 0 = by batch size, 1 = never the two-pairs-per-lane kernel, 2 = always when eligible."""
         _check(_lib.lib().mgl_sw_ctx_set_lane_kernel(self._ensure(), int(mode)))
 
+    def set_lane_checkpoint(self, mode):
+        """The lane kernel's checkpointed form (no stored traceback, the walk recomputes the blocks it crosses): 0 = default (on),
+        1 = never (needed before expand_slot), 2 = on."""
+        _check(_lib.lib().mgl_sw_ctx_set_lane_checkpoint(self._ensure(), int(mode)))
+
     def set_profiling(self, on=True):
         _check(_lib.lib().mgl_sw_ctx_set_profiling(self._ensure(), int(on)))
 

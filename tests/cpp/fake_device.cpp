@@ -108,6 +108,12 @@ hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &w, int, hipStream_t)
     if (w.cigar) walk(w, false);
     return hipSuccess;
 }
+hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &w, hipStream_t)
+{
+    remember(a);
+    if (w.cigar) walk(w, false);
+    return hipSuccess;
+}
 hipError_t launch_traceback(const TbArgs &a, hipStream_t) { walk(a, false); return hipSuccess; }
 hipError_t launch_regroup(const RegroupArgs &a, hipStream_t)
 {

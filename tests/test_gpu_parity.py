@@ -901,10 +901,15 @@ def test_packed16_uniform_batches(aligner, tl, ql):
 # partial last strips, tl below one strip, every strategy, the traceback layout through the expansion to the
 # reference's int32 matrix.
 
-@pytest.fixture(scope="module")
-def lane_aligner():
+# Both forms: flags of every cell stored (sw_dp16_lane_kernel, 4) and checkpoints + recomputed blocks (sw_dp16_lane_ck_kernel, 7:
+# the default wherever the strips have 32 rows and CIGARs are written).
+
+@pytest.fixture(scope="module", params=[1, 0], ids=["stored", "checkpointed"])
+def lane_aligner(request):
     a = sw.MicrosoftSmithWaterman(0)
     a.set_lane_kernel(2)
+    a.set_lane_checkpoint(request.param)
+    a.lane_kernels = (4,) if request.param == 1 else (4, 7)
     yield a
     a.close()
 
@@ -921,12 +926,18 @@ def test_lane_kernel_uniform_batches(lane_aligner, tl, ql):
         for strategy in ol.STRATEGIES:
             res = lane_aligner.align_batch(ts, qs, params, strategy)
             tm = lane_aligner.timing()
-            assert tm.packed16 == 1 and tm.fill_kernel == 4, "a uniform small-range batch should take the lane kernel when forced"
+            assert tm.packed16 == 1 and tm.fill_kernel in lane_aligner.lane_kernels, "a uniform small-range batch should take the lane kernel when forced"
+            if 7 in lane_aligner.lane_kernels and (tl, ql) in ((256, 150), (1000, 150), (64, 65), (32, 149), (250, 150)):
+                assert tm.fill_kernel == 7, "32-row strips: the checkpointed form is the default"
             off, sc, cg = ol.oracle_align_batch(ts, qs, params, strategy, nthreads=4)
             assert (res.offsets == off).all(), (params, strategy)
             assert (res.scores == sc).all(), (params, strategy)
             assert res.cigars == cg, (params, strategy)
             for slot in (0, 1, 77, n - 1):
+                if tm.fill_kernel == 7:
+                    with pytest.raises(RuntimeError):
+                        lane_aligner.expand_slot(slot, tl, ql)  # no stored traceback to expand
+                    break
                 btr = lane_aligner.expand_slot(slot, tl, ql)
                 o = ol.oracle_align(ts[slot], qs[slot], params, strategy, want_btr=True)
                 assert (btr[1:, 1:] == o["btr"][1:, 1:]).all(), (params, strategy, slot)
@@ -942,7 +953,7 @@ def test_lane_kernel_goldens_unaligned_chunked_score_only(lane_aligner):
     assert len(rows) > 100 and len({(len(g.t), len(g.q)) for g in rows}) == 1
     rows = (rows * 12)[:1500]
     res = lane_aligner.align_batch([g.t for g in rows], [g.q for g in rows], rows[0].params, ol.SOFTCLIP)
-    assert lane_aligner.timing().fill_kernel == 4
+    assert lane_aligner.timing().fill_kernel in lane_aligner.lane_kernels
     for k, g in enumerate(rows):
         assert (int(res.offsets[k]), res.cigars[k], tuple(int(x) for x in res.scores[k])) == (g.offset, g.cigar, g.score)
     # device-resident, with a pad byte in front of both arrays: every sequence starts at an odd address
@@ -959,7 +970,7 @@ def test_lane_kernel_goldens_unaligned_chunked_score_only(lane_aligner):
         b.run(small)
         torch.cuda.synchronize()
         tm = small.timing()
-        assert tm.fill_kernel == 4 and tm.dp_launches > 2
+        assert tm.fill_kernel == 7 and tm.dp_launches > 2
         cg = b.cigar_strings()
         for k, g in enumerate(rows):
             assert (int(b.offsets[k]), cg[k], tuple(int(x) for x in b.scores[k])) == (g.offset, g.cigar, g.score)
