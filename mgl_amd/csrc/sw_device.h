@@ -148,13 +148,15 @@ __host__ __device__ inline int coop_wrap_cols(int sps_cap) { return sps_cap + 19
 
 // ---- sw_dp16_lane_ck_kernel (sw_dp16_lane_ck.hip): the same kernel without stored flags -- carry rows of every 32-row strip and
 // the lanes' register state every LANE_CK_COLS columns are kept, the walk recomputes the blocks its path crosses
-constexpr int LANE_CK_COLS = 16;
+constexpr int LANE_CK_COLS = 32;
 __host__ __device__ inline int lane_ck_blocks(int ql) { return (ql + LANE_CK_COLS - 1) / LANE_CK_COLS; }
-// dwords per WAVE: rows [2 strips + 1][ql + 1][lane] uint2, checkpoints [strip][block][16][lane] uint4, one block of flags [column][lane] uint4
+__host__ __device__ inline int lane_ck_groups(int ql) { return (ql + 7) / 8; } // groups of eight columns
+// dwords per WAVE: records of [lane][32 dwords] -- strips x groups of carry rows, strips x blocks x 2 checkpoints -- and one
+// block of flags [column][lane] uint4
 __host__ __device__ inline int64_t lane_ck_words(int tl, int ql)
 {
     const int64_t strips = lane_strips(tl, 32);
-    return (2 * strips + 1) * (ql + 1) * 128 + 64 * strips * lane_ck_blocks(ql) * 64 + (int64_t)LANE_CK_COLS * 64 * 4;
+    return (strips * lane_ck_groups(ql) + strips * lane_ck_blocks(ql) * 2) * 64 * 32 + (int64_t)LANE_CK_COLS * 64 * 4;
 }
 
 int64_t dp_group_bytes(int sps_cap, int rows); // carry ring + query copies of one pair (LDS, or HBM scratch)

@@ -12,18 +12,28 @@
 //           flag is bit for bit the one the full fill would have stored -- into a small private buffer, walks as far as the
 //           block reaches, and goes on with the block the path leaves into.  Both pairs of the lane do this in lock step
 //           (one packed recomputation serves pair A's block and pair B's block, which are different blocks in general).
-//           Blocks are 16 rows high (half a strip: pass 1 also keeps the row in the middle of every strip) -- a path of a
-//           256 x 150 pair crosses ~20 of them, 5 000 of 38 400 cells -- and a 16-row column needs 48 registers of state
-//           where a 32-row one needs 96 (with 32-row blocks the compiler spilled the target bases into the column loop).
+//           Blocks are 16 rows high (half a strip: pass 1 also keeps the row in the middle of every strip) and LANE_CK_COLS = 32
+//           columns wide -- a path of a 256 x 150 pair crosses ~14 of them, 7 000 of 38 400 cells -- and a 16-row column needs
+//           48 registers of state where a 32-row one needs 96 (with 32-row blocks the compiler spilled the target bases into
+//           the column loop).  Measured on 2 M pairs of 256 x 150: blocks of 16 columns 22.6 ms, of 32 columns 21.7 (half the
+//           checkpoint bytes weigh more than the larger blocks: pass 1 pays ~0.3 ms per KB it writes per pair).
 //
 // Same arithmetic, same range guard (dp16_range_ok), same results as sw_dp16_lane_kernel.
 //
-// Per-wave region (a.tb + wave * a.tb_stride_words, lane_ck_words()):
-//   rows   [band 0 .. 2 strips][column 0 .. ql][lane] uint2 {H, E} packed A|B: row s = what enters the 16-row band s (row 0: the
-//          border; even rows: between strips; odd rows: the middle of a strip; row 2 strips: the last target row, read by the
-//          last-row scan)
-//   ckpt   [strip][block b][16][lane] uint4: h[0..31], f[0..31] at column 16 b
+// What pass 2 fetches is scattered -- every lane is somewhere else on its path -- so it is laid out PER PAIR: a fetch then uses
+// the 64-byte sectors it touches (time-major [column][lane] arrays cost a sector per 8 bytes: 33 sectors per block and pair,
+// more traffic than the flags this kernel saves).  Pass 1 produces its values lane by lane and column by column, so it stages
+// them in LDS (128 bytes per lane) and writes them out transposed, whole lines per store instruction.
+//
+// Per-wave region (a.tb + wave * a.tb_stride_words, lane_ck_words()), in RECORDS of [lane][32 dwords] (8 KB):
+//   rows   record (slot * groups + g): columns 8 g + 1 .. 8 g + 8 of two carry rows, per lane [pair A | pair B][column][mid | bot]
+//          dwords {H : 16, E : 16}: slot k = strip k's middle row (what enters its lower 16 rows) and its last row (what enters
+//          the strip below)
+//   ckpt   record ((strip * blocks + b) * 2 + pair): the pair's state at column 16 b, [upper | lower 16 rows][h x 8 | f x 8]
+//          dwords of two rows each
 //   block  [column of the block][lane] uint4: the recomputed flags of 16 rows, bytes as in sw_dp16_lane.hip
+// The carry row between strips that pass 1 itself reads (time-major, updated in place) lives in the wave's scratch as in
+// sw_dp16_lane.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -40,11 +50,28 @@ constexpr int R = 32;            // target rows per strip
 constexpr int RB = 16;           // rows per recomputed block
 constexpr int CK = LANE_CK_COLS; // query columns per block
 
-// ---- pass 1: one strip, score only, keeping the carry row and the column checkpoints
+// rows of the LDS staging buffer: 32 dwords per lane, padded to 36 (16-byte aligned rows, lanes spread over the banks)
+constexpr int STAGE_ROW = 36;
+
+// two rows of one pair side by side: {row 2i : 16, row 2i + 1 : 16} from the packed A|B registers of both rows
+__device__ __forceinline__ unsigned lows(unsigned r0, unsigned r1) { return __builtin_amdgcn_perm(r1, r0, 0x05040100u); }
+__device__ __forceinline__ unsigned highs(unsigned r0, unsigned r1) { return __builtin_amdgcn_perm(r1, r0, 0x07060302u); }
+
+// the wave writes its staging buffer out as one record: store instruction i covers lanes 8 i .. 8 i + 7, 128 bytes each
+__device__ __forceinline__ void stage_flush(const unsigned *stage, uint4 *rec, const int lane)
+{
+    asm volatile("" ::: "memory"); // LDS instructions of a wave execute in order: all it takes is that the compiler keeps them so
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        rec[i * 64 + lane] = *reinterpret_cast<const uint4 *>(stage + (i * 8 + (lane >> 3)) * STAGE_ROW + (lane & 7) * 4);
+    asm volatile("" ::: "memory");
+}
+
+// ---- pass 1: one strip, score only, keeping the carry rows and the column checkpoints
 template <bool LAST>
-__device__ __forceinline__ void ck_strip(const int i0, const int tl, const int ql, const uint2 *rin, uint2 *rmid, uint2 *rout, uint4 *ckp,
-                                         const unsigned *qst, const unsigned *tst, const LaneConsts &c, const int gopen, const int gext,
-                                         const int base, const bool indel, int &bestA, int &bestA_i, int &bestB, int &bestB_i)
+__device__ __forceinline__ void ck_strip(const int i0, const int tl, const int ql, uint2 *bnd, unsigned *stage, uint4 *rowrec, uint4 *ckrec,
+                                         const int lane, const unsigned *qst, const unsigned *tst, const LaneConsts &c, const int gopen,
+                                         const int gext, const int base, const bool indel, int &bestA, int &bestA_i, int &bestB, int &bestB_i)
 {
     unsigned h[R], f[R], t[R];
 #pragma unroll
@@ -65,60 +92,80 @@ __device__ __forceinline__ void ck_strip(const int i0, const int tl, const int q
     }
     const int hd0 = border(i0, gopen, gext, indel) + i0 * gext + base; // H[i0][0]
     unsigned hd = pack2(hd0, hd0);
-    rmid[0] = make_uint2(h[RB - 1], 0u); // H[i0 + 16][0], H[i0 + 32][0]: where the block recomputations below start
-    rout[0] = make_uint2(h[R - 1], 0u);
     const int rl = tl - 1 - i0;
 
-    const uint2 *ip = rin + 64;
-    uint2 *op = rout + 64, *mp = rmid + 64;
-    auto one_column = [&](const uint2 top, const unsigned q) {
+    unsigned *const my = stage + lane * STAGE_ROW; // this lane's 32 dwords: [A | B][column of the group of eight][mid | bot]
+    uint2 *bp = bnd + 64;                          // column j of the time-major carry row
+    auto one_column = [&](const uint2 top, const unsigned q, const int cidx) {
         unsigned e = top.y;
-        column<R, true, true>(h, f, t, q, hd, e, c, nullptr, mp);
-        mp += 64;
+        uint2 mid;
+        column<R, true, true>(h, f, t, q, hd, e, c, nullptr, &mid);
         hd = top.x;
+        *reinterpret_cast<uint2 *>(my + 2 * cidx) = make_uint2(lows(mid.x, mid.y), lows(h[R - 1], e));
+        *reinterpret_cast<uint2 *>(my + 16 + 2 * cidx) = make_uint2(highs(mid.x, mid.y), highs(h[R - 1], e));
         if (!LAST) {
-            op[0] = make_uint2(h[R - 1], e);
+            bp[0] = make_uint2(h[R - 1], e);
         } else {
             unsigned bot = h[R - 1];
             if (rl != R - 1) {
 #pragma unroll
                 for (int r = 0; r < R - 1; ++r) bot = (r == rl) ? h[r] : bot;
             }
-            op[0] = make_uint2(bot, 0u);
+            bp[0] = make_uint2(bot, 0u);
         }
-        op += 64;
+        bp += 64;
     };
-    auto save = [&]() { // the state BEFORE column j: H[.][j-1] and the horizontal-gap values entering column j
+    auto save = [&]() { // the state BEFORE column j: H[.][j-1] and the horizontal-gap values entering column j; pair A, then pair B
 #pragma unroll
-        for (int r4 = 0; r4 < R / 4; ++r4) {
-            ckp[(size_t)r4 * 64] = make_uint4(h[4 * r4], h[4 * r4 + 1], h[4 * r4 + 2], h[4 * r4 + 3]);
-            ckp[(size_t)(R / 4 + r4) * 64] = make_uint4(f[4 * r4], f[4 * r4 + 1], f[4 * r4 + 2], f[4 * r4 + 3]);
+        for (int x = 0; x < 2; ++x) {
+#pragma unroll
+            for (int band = 0; band < 2; ++band) {
+#pragma unroll
+                for (int i4 = 0; i4 < 2; ++i4) {
+                    const int r = band * RB + i4 * 8;
+                    uint4 hv, fv;
+                    if (x == 0) {
+                        hv = make_uint4(lows(h[r], h[r + 1]), lows(h[r + 2], h[r + 3]), lows(h[r + 4], h[r + 5]), lows(h[r + 6], h[r + 7]));
+                        fv = make_uint4(lows(f[r], f[r + 1]), lows(f[r + 2], f[r + 3]), lows(f[r + 4], f[r + 5]), lows(f[r + 6], f[r + 7]));
+                    } else {
+                        hv = make_uint4(highs(h[r], h[r + 1]), highs(h[r + 2], h[r + 3]), highs(h[r + 4], h[r + 5]), highs(h[r + 6], h[r + 7]));
+                        fv = make_uint4(highs(f[r], f[r + 1]), highs(f[r + 2], f[r + 3]), highs(f[r + 4], f[r + 5]), highs(f[r + 6], f[r + 7]));
+                    }
+                    *reinterpret_cast<uint4 *>(my + band * 16 + i4 * 4) = hv;
+                    *reinterpret_cast<uint4 *>(my + band * 16 + 8 + i4 * 4) = fv;
+                }
+            }
+            stage_flush(stage, ckrec, lane);
+            ckrec += 512;
         }
-        ckp += (R / 2) * 64;
     };
     int j = 1;
     for (; j + 3 <= ql; j += 4) {
         if (((j - 1) & (CK - 1)) == 0) save();
-        const uint2 top0 = ip[0], top1 = ip[64], top2 = ip[128], top3 = ip[192];
-        ip += 256;
+        const uint2 top0 = bp[0], top1 = bp[64], top2 = bp[128], top3 = bp[192];
         const unsigned qa = qst[0], qb = qst[64];
         qst += 128;
-        one_column(top0, __builtin_amdgcn_perm(qb, qa, 0x0c040c00u));
-        one_column(top1, __builtin_amdgcn_perm(qb, qa, 0x0c050c01u));
-        one_column(top2, __builtin_amdgcn_perm(qb, qa, 0x0c060c02u));
-        one_column(top3, __builtin_amdgcn_perm(qb, qa, 0x0c070c03u));
+        const int c0 = (j - 1) & 4;
+        one_column(top0, __builtin_amdgcn_perm(qb, qa, 0x0c040c00u), c0);
+        one_column(top1, __builtin_amdgcn_perm(qb, qa, 0x0c050c01u), c0 + 1);
+        one_column(top2, __builtin_amdgcn_perm(qb, qa, 0x0c060c02u), c0 + 2);
+        one_column(top3, __builtin_amdgcn_perm(qb, qa, 0x0c070c03u), c0 + 3);
+        if (c0) { // columns 8 g + 1 .. 8 g + 8 are staged
+            stage_flush(stage, rowrec, lane);
+            rowrec += 512;
+        }
     }
     if (j <= ql) { // the last one to three columns (j - 1 is a multiple of four here)
         if (((j - 1) & (CK - 1)) == 0) save();
         const unsigned qa = qst[0], qb = qst[64];
         unsigned sel = 0x0c040c00u;
         for (; j <= ql; ++j) {
-            const uint2 top = ip[0];
-            ip += 64;
-            one_column(top, __builtin_amdgcn_perm(qb, qa, sel));
+            const uint2 top = bp[0];
+            one_column(top, __builtin_amdgcn_perm(qb, qa, sel), (j - 1) & 7);
             sel += 0x00010001u;
         }
     }
+    if (ql & 7) stage_flush(stage, rowrec, lane); // a last group of fewer than eight columns
     // last column (sw.cpp:100-104), as in sw_dp16_lane.hip
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -255,12 +302,14 @@ struct PathWalk {
             } else if (mode == 1) {
                 n += cnt;
                 pi -= cnt;
+                if (cnt == LOOK && cnt <= room) return true; // more of the run in this block than one round looks at
                 if (cnt > room && pi >= 1) return false; // every cell up to the block's edge extends the gap: goes on in the block above
                 take('D', n);
                 I -= n;
             } else {
                 n += cnt;
                 pj -= cnt;
+                if (cnt == LOOK && cnt <= room) return true;
                 if (cnt > room && pj >= 1) return false;
                 take('I', n);
                 J -= n;
@@ -310,16 +359,16 @@ struct PathWalk {
     }
 };
 
-// low half of a, high half of b
-__device__ __forceinline__ unsigned mix(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060100u); }
-
 // ---- pass 2: recompute the flags of block (sA, bA) for the low halves and of block (sB, bB) for the high halves; s = 16-row band
-// (strip s / 2, its upper or lower half), b = block of CK columns
-__device__ __forceinline__ void ck_block(const int sA, const int bA, const int sB, const int bB, const int ql, const int nb, const uint2 *rows,
-                                         const uint4 *ck, const unsigned *qst, const unsigned *tst, uint4 *blk, const LaneConsts &c)
+// (strip s / 2, its upper or lower half), b = block of CK columns.  rowrec / ckrec: the wave's records + this lane's 8 uint4.
+struct BlockGeom {
+    int ql, nb, ng8, gopen, gext, base;
+    bool indel;
+};
+__device__ __forceinline__ void ck_block(const int sA, const int bA, const int sB, const int bB, const BlockGeom &g, const uint4 *rowrec,
+                                         const uint4 *ckrec, const unsigned *qst, const unsigned *tst, uint4 *blk, const LaneConsts &c)
 {
     unsigned h[RB], f[RB], t[RB];
-    const size_t row_len = (size_t)(ql + 1) * 64;
 #pragma unroll
     for (int r4 = 0; r4 < RB / 4; ++r4) {
         const unsigned ta = tst[(size_t)(2 * (sA * (RB / 4) + r4)) * 64], tb = tst[(size_t)(2 * (sB * (RB / 4) + r4) + 1) * 64];
@@ -329,41 +378,74 @@ __device__ __forceinline__ void ck_block(const int sA, const int bA, const int s
         t[4 * r4 + 3] = __builtin_amdgcn_perm(tb, ta, 0x0c070c03u);
     }
     {
-        // the strip's checkpoint at column CK b: quads 0 .. 7 = h[0..31], 8 .. 15 = f[0..31]; this band's rows are quads (s & 1) * 4 ..
-        const uint4 *ca = ck + (((size_t)(sA >> 1) * nb + bA) * (R / 2) + (sA & 1) * (RB / 4)) * 64;
-        const uint4 *cb = ck + (((size_t)(sB >> 1) * nb + bB) * (R / 2) + (sB & 1) * (RB / 4)) * 64;
+        const uint4 *ca = ckrec + ((size_t)(((sA >> 1) * g.nb + bA) * 2 + 0) * 64) * 8 + (sA & 1) * 4;
+        const uint4 *cb = ckrec + ((size_t)(((sB >> 1) * g.nb + bB) * 2 + 1) * 64) * 8 + (sB & 1) * 4;
 #pragma unroll
-        for (int r4 = 0; r4 < RB / 4; ++r4) {
-            const uint4 ha = ca[(size_t)r4 * 64], hb = cb[(size_t)r4 * 64], fa = ca[(size_t)(R / 4 + r4) * 64], fb = cb[(size_t)(R / 4 + r4) * 64];
-            h[4 * r4 + 0] = mix(ha.x, hb.x);
-            h[4 * r4 + 1] = mix(ha.y, hb.y);
-            h[4 * r4 + 2] = mix(ha.z, hb.z);
-            h[4 * r4 + 3] = mix(ha.w, hb.w);
-            f[4 * r4 + 0] = mix(fa.x, fb.x);
-            f[4 * r4 + 1] = mix(fa.y, fb.y);
-            f[4 * r4 + 2] = mix(fa.z, fb.z);
-            f[4 * r4 + 3] = mix(fa.w, fb.w);
+        for (int i4 = 0; i4 < 2; ++i4) {
+            const uint4 ha = ca[i4], hb = cb[i4], fa = ca[2 + i4], fb = cb[2 + i4];
+            h[8 * i4 + 0] = lows(ha.x, hb.x);
+            h[8 * i4 + 1] = highs(ha.x, hb.x);
+            h[8 * i4 + 2] = lows(ha.y, hb.y);
+            h[8 * i4 + 3] = highs(ha.y, hb.y);
+            h[8 * i4 + 4] = lows(ha.z, hb.z);
+            h[8 * i4 + 5] = highs(ha.z, hb.z);
+            h[8 * i4 + 6] = lows(ha.w, hb.w);
+            h[8 * i4 + 7] = highs(ha.w, hb.w);
+            f[8 * i4 + 0] = lows(fa.x, fb.x);
+            f[8 * i4 + 1] = highs(fa.x, fb.x);
+            f[8 * i4 + 2] = lows(fa.y, fb.y);
+            f[8 * i4 + 3] = highs(fa.y, fb.y);
+            f[8 * i4 + 4] = lows(fa.z, fb.z);
+            f[8 * i4 + 5] = highs(fa.z, fb.z);
+            f[8 * i4 + 6] = lows(fa.w, fb.w);
+            f[8 * i4 + 7] = highs(fa.w, fb.w);
         }
     }
-    const uint2 *ra = rows + (size_t)sA * row_len, *rb = rows + (size_t)sB * row_len;
-    const int cA = bA * CK, cB = bB * CK;
-    unsigned hd = mix(ra[(size_t)cA * 64].x, rb[(size_t)cB * 64].x);
-    const int qmax = ((ql + 3) >> 2) - 1;
+    // the row entering the band: the middle row of its strip (odd s), or the last row of the strip above / the border (even s)
+    // (band 0: the border row, sw.cpp:14-18,31-35, by its formula -- every pair has the same)
+    const int slotA = max(((sA + 1) >> 1) - 1, 0), slotB = max(((sB + 1) >> 1) - 1, 0);
+    const bool botA = (sA & 1) == 0, botB = (sB & 1) == 0, topA = sA == 0, topB = sB == 0;
+    const int hb_k = g.indel ? g.gext - g.gopen + g.base : g.base, hb_j = g.indel ? 0 : g.gext, oe = g.gopen - g.gext; // H[0][j] = hb_k + j hb_j (j > 0)
+    const uint4 *ra = rowrec + ((size_t)slotA * g.ng8 * 64) * 8, *rb = rowrec + ((size_t)slotB * g.ng8 * 64) * 8 + 4;
+    // H[16 s][CK b]: the entry of the column before the block, or the border column (sw.cpp:24,38)
+    unsigned hdA, hdB;
+    {
+        const int rowA = sA * RB, rowB = sB * RB;
+        const unsigned fa_ = (unsigned)(border(rowA, g.gopen, g.gext, g.indel) + rowA * g.gext + g.base);
+        const unsigned fb_ = (unsigned)(border(rowB, g.gopen, g.gext, g.indel) + rowB * g.gext + g.base);
+        const unsigned *pa = reinterpret_cast<const unsigned *>(ra + ((size_t)max((CK / 8) * bA - 1, 0) * 64) * 8) + 14 + (botA ? 1 : 0);
+        const unsigned *pb = reinterpret_cast<const unsigned *>(rb + ((size_t)max((CK / 8) * bB - 1, 0) * 64) * 8) + 14 + (botB ? 1 : 0);
+        const unsigned la = *pa, lb = *pb;
+        hdA = bA > 0 ? (topA ? (unsigned)(hb_k + CK * bA * hb_j) : la) : fa_;
+        hdB = bB > 0 ? (topB ? (unsigned)(hb_k + CK * bB * hb_j) : lb) : fb_;
+    }
+    unsigned hd = lows(hdA, hdB);
+    const int qmax = ((g.ql + 3) >> 2) - 1;
 #pragma unroll 1
-    for (int g = 0; g < CK / 4; ++g) {
-        uint2 ta[4], tb[4];
+    for (int gg = 0; gg < CK / 8; ++gg) {
+        const uint4 *pa = ra + ((size_t)min((CK / 8) * bA + gg, g.ng8 - 1) * 64) * 8, *pb = rb + ((size_t)min((CK / 8) * bB + gg, g.ng8 - 1) * 64) * 8;
+        uint4 va[4], vb[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { // columns past ql: the last column again (their flags are never read)
-            ta[u] = ra[(size_t)min(cA + 4 * g + u + 1, ql) * 64];
-            tb[u] = rb[(size_t)min(cB + 4 * g + u + 1, ql) * 64];
+        for (int u = 0; u < 4; ++u) { // (a group past ql: the last group again -- flags of columns past ql are never read)
+            va[u] = pa[u];
+            vb[u] = pb[u];
         }
-        const unsigned qa = qst[(size_t)(2 * min((cA >> 2) + g, qmax)) * 64], qb = qst[(size_t)(2 * min((cB >> 2) + g, qmax) + 1) * 64];
+        unsigned qa[2], qb[2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            unsigned e = mix(ta[u].y, tb[u].y);
-            const unsigned q = __builtin_amdgcn_perm(qb, qa, 0x0c040c00u + 0x00010001u * u);
-            column<RB, false>(h, f, t, q, hd, e, c, blk + (size_t)(4 * g + u) * 64);
-            hd = mix(ta[u].x, tb[u].x);
+        for (int u = 0; u < 2; ++u) {
+            qa[u] = qst[(size_t)(2 * min(bA * (CK / 4) + 2 * gg + u, qmax)) * 64];
+            qb[u] = qst[(size_t)(2 * min(bB * (CK / 4) + 2 * gg + u, qmax) + 1) * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned ma = (u & 1) ? va[u >> 1].z : va[u >> 1].x, ba = (u & 1) ? va[u >> 1].w : va[u >> 1].y;
+            const unsigned mb = (u & 1) ? vb[u >> 1].z : vb[u >> 1].x, bb = (u & 1) ? vb[u >> 1].w : vb[u >> 1].y;
+            const int ha_ = hb_k + (CK * bA + 8 * gg + u + 1) * hb_j, hb_ = hb_k + (CK * bB + 8 * gg + u + 1) * hb_j;
+            const unsigned ea = topA ? pack2(ha_, ha_ - oe) : botA ? ba : ma, eb = topB ? pack2(hb_, hb_ - oe) : botB ? bb : mb; // {H : 16, E : 16} of the row above, this column
+            unsigned e = highs(ea, eb);
+            const unsigned q = __builtin_amdgcn_perm(qb[u >> 2], qa[u >> 2], 0x0c040c00u + 0x00010001u * (u & 3));
+            column<RB, false>(h, f, t, q, hd, e, c, blk + (size_t)(8 * gg + u) * 64);
+            hd = lows(ea, eb);
         }
     }
 }
@@ -397,18 +479,20 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
         asm volatile("" : "+s"(c.k12[u]), "+s"(c.k34[u]));
     }
 
-    const int strips = lane_strips(tl, R), nb = lane_ck_blocks(ql);
-    // the wave's scratch, as in sw_dp16_lane.hip (its one carry row is not used here): both queries and both targets of every
-    // lane transposed to [4-base block][A | B][lane] dwords
+    const int strips = lane_strips(tl, R), nb = lane_ck_blocks(ql), ng8 = lane_ck_groups(ql);
+    // the wave's scratch, as in sw_dp16_lane.hip: the carry row between strips [column 0 .. ql][lane] x {H, E}, then both queries
+    // and both targets of every lane transposed to [4-base block][A | B][lane] dwords
     unsigned char *const wave_scratch = a.scratch + (size_t)gw * (size_t)lane_scratch_bytes(tl, ql, R);
+    uint2 *const bnd = reinterpret_cast<uint2 *>(wave_scratch) + lane;
     unsigned *const qst = reinterpret_cast<unsigned *>(wave_scratch + (size_t)lane_bnd_entries(ql) * 8) + lane;
     unsigned *const tst = qst + (size_t)((ql + 3) >> 2) * 128;
-    // the wave's region: rows, checkpoints, block buffer
-    uint32_t *const region = a.tb + (size_t)gw * (size_t)a.tb_stride_words;
-    const size_t row_len = (size_t)(ql + 1) * 64;
-    uint2 *const rows = reinterpret_cast<uint2 *>(region) + lane;
-    uint4 *const ck = reinterpret_cast<uint4 *>(region + (size_t)(2 * strips + 1) * row_len * 2) + lane;
-    uint4 *const blk = reinterpret_cast<uint4 *>(region + (size_t)(2 * strips + 1) * row_len * 2 + (size_t)64 * strips * nb * (R * 2)) + lane;
+    // the wave's region: row records, checkpoint records, block buffer
+    uint4 *const region = reinterpret_cast<uint4 *>(a.tb + (size_t)gw * (size_t)a.tb_stride_words);
+    uint4 *const rowrec = region;
+    uint4 *const ckrec = region + (size_t)strips * ng8 * 512;
+    uint4 *const blk = ckrec + (size_t)strips * nb * 2 * 512 + lane;
+    __shared__ unsigned stage_all[4 * 64 * STAGE_ROW];
+    unsigned *const stage = stage_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (64 * STAGE_ROW);
     {
         const int64_t pA = a.first + slotA, pB = a.first + slotB;
         SeqWords sa, sb;
@@ -431,25 +515,23 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
         for (int j = 0; j <= ql; ++j) {
             const int hb0 = border(j, gopen, gext, indel) + j * gext + base;
             const unsigned hp = pack2(hb0, hb0);
-            rows[(size_t)j * 64] = make_uint2(hp, pk_sub(hp, c.o_e));
+            bnd[(size_t)j * 64] = make_uint2(hp, pk_sub(hp, c.o_e));
         }
     }
 
     // ---- pass 1
     int bestA = NEG_INF, bestA_i = -1, bestB = NEG_INF, bestB_i = -1;
     for (int k = 0; k < strips - 1; ++k)
-        ck_strip<false>(k * R, tl, ql, rows + (size_t)(2 * k) * row_len, rows + (size_t)(2 * k + 1) * row_len, rows + (size_t)(2 * k + 2) * row_len,
-                        ck + (size_t)k * nb * (R / 2) * 64, qst, tst, c, gopen, gext, base, indel, bestA, bestA_i, bestB, bestB_i);
-    ck_strip<true>((strips - 1) * R, tl, ql, rows + (size_t)(2 * strips - 2) * row_len, rows + (size_t)(2 * strips - 1) * row_len,
-                   rows + (size_t)(2 * strips) * row_len, ck + (size_t)(strips - 1) * nb * (R / 2) * 64, qst, tst, c, gopen, gext, base, indel, bestA,
-                   bestA_i, bestB, bestB_i);
+        ck_strip<false>(k * R, tl, ql, bnd, stage, rowrec + (size_t)k * ng8 * 512, ckrec + (size_t)k * nb * 2 * 512, lane, qst, tst, c, gopen, gext,
+                        base, indel, bestA, bestA_i, bestB, bestB_i);
+    ck_strip<true>((strips - 1) * R, tl, ql, bnd, stage, rowrec + (size_t)(strips - 1) * ng8 * 512, ckrec + (size_t)(strips - 1) * nb * 2 * 512, lane, qst, tst,
+                   c, gopen, gext, base, indel, bestA, bestA_i, bestB, bestB_i);
 
     // ---- last row (sw.cpp:116-127), as in sw_dp16_lane.hip
     int rmA = NEG_INF, rdA = 0x7fffffff, rjA = 0x7fffffff, rmB = NEG_INF, rdB = 0x7fffffff, rjB = 0x7fffffff;
     {
-        const uint2 *last = rows + (size_t)(2 * strips) * row_len;
         for (int j = 1; j <= ql; ++j) {
-            const unsigned bot = last[(size_t)j * 64].x;
+            const unsigned bot = bnd[(size_t)j * 64].x;
             const int unshift = -(tl + j) * gext - base;
             const int d = abs(tl - j);
             const int sa = lo16(bot) + unshift, sb = hi16(bot) + unshift;
@@ -481,31 +563,27 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
         if (half ? validB : lvalid) a.rec[half ? slotB : slotA] = r;
     }
 
-    if (a.sps_cap & 1) return; // TIMING EXPERIMENT
     // ---- pass 2
     const int64_t pA = a.first + slotA, pB = a.first + slotB;
     const int64_t oA = walk.dest ? walk.dest[pA] : pA, oB = walk.dest ? walk.dest[pB] : pB;
     PathWalk wa, wb;
     wa.start(walk, rec[0], oA, tl, ql, lvalid);
     wb.start(walk, rec[1], oB, tl, ql, validB);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the lane's own rows and checkpoints are in memory
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the wave's records are in memory (written by other lanes of this wave)
+    BlockGeom geom;
+    geom.ql = ql;
+    geom.nb = nb;
+    geom.ng8 = ng8;
+    geom.gopen = gopen;
+    geom.gext = gext;
+    geom.base = base;
+    geom.indel = indel;
     const uint32_t *const blk_words = reinterpret_cast<const uint32_t *>(blk);
-    int iters = 0, na = 0, nb_ = 0, rounds = 0;
     while (__builtin_amdgcn_ballot_w64(!wa.done || !wb.done) != 0) {
         // (a finished walk keeps recomputing some valid block: both halves run the same instructions anyway)
-        int kA = max(wa.pi - 1, 0) >> 4, bA = max(wa.pj - 1, 0) / CK, kB = max(wb.pi - 1, 0) >> 4, bB = max(wb.pj - 1, 0) / CK;
-        if (a.sps_cap & 64) { // EXPERIMENT: scattered blocks without the walk
-            const unsigned hsh = (unsigned)(lane * 2654435761u + iters * 40503u) >> 8;
-            kA = hsh % (2 * strips); bA = (hsh >> 5) % nb; kB = (hsh >> 9) % (2 * strips); bB = (hsh >> 13) % nb;
-        }
-        ck_block(kA, bA, kB, bB, ql, nb, rows, ck, qst, tst, blk, c);
+        const int kA = max(wa.pi - 1, 0) >> 4, bA = max(wa.pj - 1, 0) / CK, kB = max(wb.pi - 1, 0) >> 4, bB = max(wb.pj - 1, 0) / CK;
+        ck_block(kA, bA, kB, bB, geom, rowrec + (size_t)lane * 8, ckrec + (size_t)lane * 8, qst, tst, blk, c);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (a.sps_cap & 2) { // TIMING EXPERIMENT: no walk, a fixed number of blocks
-            if (++iters >= 20) wa.done = wb.done = true;
-            continue;
-        }
-        if (!wa.done) ++na;
-        if (!wb.done) ++nb_;
         for (;;) {
             const bool la = wa.can_load(kA, bA), lb = wb.can_load(kB, bB);
             // (a lane with nothing to fetch still runs apply(): a run that ends at the matrix's edge needs no flags)
@@ -513,17 +591,11 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
             if (la) wa.load(blk_words, fa);
             if (lb) wb.load(blk_words, fb);
             const bool ga = wa.apply(fa, 0, kA, bA), gb = wb.apply(fb, 1, kB, bB);
-            ++rounds;
             if (!__builtin_amdgcn_ballot_w64(ga || gb)) break;
         }
-        ++iters;
     }
     if (lvalid) wa.finish(walk, rec[0], oA);
     if (validB) wb.finish(walk, rec[1], oB);
-    if ((a.sps_cap & 4) && walk.status) { // EXPERIMENT: blocks the wave computed / this pair needed
-        if (lvalid) walk.status[oA] = iters | (rounds << 16);
-        if (validB) walk.status[oB] = iters | (rounds << 16);
-    }
 }
 
 } // namespace
@@ -535,10 +607,7 @@ hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &walk, hipStream_t 
     const int waves_per_block = 4;
     const int64_t waves = ((a.count + 1) / 2 + 63) / 64;
     const dim3 grid((unsigned)((waves + waves_per_block - 1) / waves_per_block)), block(64 * waves_per_block);
-    static const int dbg = [] { const char *e = getenv("MGL_SW_CK_DEBUG"); return e ? atoi(e) : 0; }();
-    DpArgs b = a;
-    b.sps_cap = dbg;
-    hipLaunchKernelGGL(sw_dp16_lane_ck_kernel, grid, block, 0, stream, b, walk);
+    hipLaunchKernelGGL(sw_dp16_lane_ck_kernel, grid, block, 0, stream, a, walk);
     return hipGetLastError();
 }
 

@@ -149,8 +149,9 @@ int main()
         uni.add(t, q);
     }
     const Expect eu = expect(uni, MGL_SW_OS_INDEL);
-    for (int lane_mode : {2, 1}) {
-        CHECK(mgl_sw_ctx_set_lane_kernel(ctx, lane_mode) == 0 && mgl_sw_ctx_set_workspace(ctx, 24ll << 20) == 0);
+    for (int lane_mode : {2, 3, 1}) { // 2: the lane kernel in its default (checkpointed) form, 3: with stored traceback, 1: never
+        CHECK(mgl_sw_ctx_set_lane_kernel(ctx, lane_mode == 3 ? 2 : lane_mode) == 0 && mgl_sw_ctx_set_lane_checkpoint(ctx, lane_mode == 3 ? 1 : 0) == 0 &&
+              mgl_sw_ctx_set_workspace(ctx, 24ll << 20) == 0);
         const int64_t n = uni.n();
         std::vector<int32_t> off((size_t)n), len((size_t)n);
         std::vector<mgl_sw_score> sc((size_t)n);
@@ -159,7 +160,9 @@ int main()
                                  sc.data(), cg.data(), 64, len.data()) == 0);
         compare(uni, eu, off, sc, cg, 64, len, nullptr);
         mgl_sw_timing tm;
-        CHECK(mgl_sw_ctx_get_timing(ctx, &tm) == 0 && tm.fill_kernel == (lane_mode == 2 ? MGL_SW_KERNEL_LANE16 : MGL_SW_KERNEL_DP16));
+        CHECK(mgl_sw_ctx_get_timing(ctx, &tm) == 0 && tm.fill_kernel == (lane_mode == 2 ? MGL_SW_KERNEL_LANE16_CK : lane_mode == 3 ? MGL_SW_KERNEL_LANE16 : MGL_SW_KERNEL_DP16));
+        int32_t btr_probe[4];
+        if (lane_mode == 2) CHECK(mgl_sw_ctx_expand_slot(ctx, 0, 1, 1, btr_probe) == MGL_SW_ERR_UNSUPPORTED); // no stored traceback to expand
     }
     mgl_sw_ctx_destroy(ctx);
 

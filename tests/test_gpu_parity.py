@@ -966,7 +966,7 @@ def test_lane_kernel_goldens_unaligned_chunked_score_only(lane_aligner):
         assert b.uniform
         small = sw.MicrosoftSmithWaterman(0)
         small.set_lane_kernel(2)
-        small.set_workspace(12 << 20)    # a few waves per chunk (one buffer: the lanes walk their own paths, nothing overlaps)
+        small.set_workspace(7 << 20)     # a few waves per chunk (one buffer: the lanes walk their own paths, nothing overlaps)
         b.run(small)
         torch.cuda.synchronize()
         tm = small.timing()
