@@ -448,7 +448,7 @@ def main():
         },
         "reads_per_s": round(n_total * args.steps / elapsed, 1),
         "kernel_ms": ({fill_kernel: round(tm.dp_ms, 3), "path_walk": "inside the fill kernel (every lane walks its own two pairs)",
-                       "launches_each": tm.dp_launches} if fill_kernel == "sw_dp16_lane_kernel" else
+                       "launches_each": tm.dp_launches} if fill_kernel in ("sw_dp16_lane_kernel", "sw_dp16_lane_ck_kernel") else
                       {fill_kernel: round(tm.dp_ms, 3), "sw_traceback_kernel": round(tm.tb_ms, 3), "launches_each": tm.dp_launches}),
         "cigar_overflows": status_bad,
         "roofline": {
@@ -460,7 +460,10 @@ def main():
             "pairs_per_launch": round(pairs_per_launch, 1),
             "avg_launch_ms": round(tm.dp_ms / max(1, tm.dp_launches), 4),
             "kernel_gcups": round(cells / dp_s / 1e9, 2),
-            "note": "integer DP: the kernel is VALU-issue bound, the HBM fraction is small by construction",
+            "note": ("integer DP: the kernel is VALU-issue bound, the HBM fraction is small by construction"
+                     + ("; sw_dp16_lane_ck_kernel spills no traceback at all (carry rows and checkpoints instead, ~24 KB per pair, `traffic`): "
+                        "`achieved` keeps SURVEY 8d's per-pair figure with the traceback so that the fraction compares with earlier lines"
+                        if fill_kernel == "sw_dp16_lane_ck_kernel" else "")),
             "valu": valu_obj,
         },
     }

@@ -943,6 +943,48 @@ def test_lane_kernel_uniform_batches(lane_aligner, tl, ql):
                 assert (btr[1:, 1:] == o["btr"][1:, 1:]).all(), (params, strategy, slot)
 
 
+@pytest.mark.parametrize("tl,ql", [(256, 150), (300, 200), (120, 260), (64, 33), (1000, 150), (513, 31), (60, 300)])
+def test_lane_checkpointed_long_gaps(tl, ql):
+    """sw_dp16_lane_ck_kernel: paths with long gaps -- runs that cross the 16-row bands and 32-column blocks its walk recomputes, and
+    horizontal runs longer than one look-ahead round inside a block -- plus unrelated pairs (many short gaps), every strategy."""
+    rng = np.random.default_rng(tl * 7 + ql)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    n = 150
+    ts, qs = [], []
+    for k in range(n):
+        t = alpha[rng.integers(0, 4, tl)]
+        if k % 5 == 4:
+            q = alpha[rng.integers(0, 4, ql)]
+        else:
+            src = np.resize(t[int(rng.integers(0, max(1, tl // 3))):], ql + 200).copy()
+            gap = int(rng.integers(17, 70))
+            at = int(rng.integers(1, max(2, ql - 1)))
+            if k % 5 in (0, 1):   # the read lacks `gap` bases of the target: a long vertical run
+                src = np.concatenate([src[:at], src[at + gap:]])
+            elif k % 5 == 2:      # the read has `gap` extra bases: a long horizontal run
+                src = np.concatenate([src[:at], alpha[rng.integers(0, 4, gap)], src[at:]])
+            sub = rng.random(len(src)) < 0.03
+            src[sub] = alpha[rng.integers(0, 4, int(sub.sum()))]
+            q = src[:ql]
+        ts.append(t.tobytes())
+        qs.append(q.tobytes())
+    a = sw.MicrosoftSmithWaterman(0)
+    a.set_lane_kernel(2)
+    ran_ck = 0
+    try:
+        for params in [(200, -150, 260, 11), (25, -50, 110, 6), (1, -1, 1, 1), (5, -4, 10, 1), (10, -30, 40, 1)]:
+            for strategy in ol.STRATEGIES:
+                res = a.align_batch(ts, qs, params, strategy)
+                ran_ck += a.timing().fill_kernel == 7  # (scores of some of these parameter sets leave 16 bits at the larger geometries)
+                off, sc, cg = ol.oracle_align_batch(ts, qs, params, strategy, nthreads=4)
+                assert (res.offsets == off).all(), (params, strategy)
+                assert (res.scores == sc).all(), (params, strategy)
+                assert res.cigars == cg, (params, strategy)
+        assert ran_ck >= 8, "32-row strips: most of these runs should take the checkpointed lane kernel"
+    finally:
+        a.close()
+
+
 def test_lane_kernel_goldens_unaligned_chunked_score_only(lane_aligner):
     """The window goldens (one geometry) through the lane kernel: sequences at odd byte offsets (the kernel reads aligned
     dwords and shifts), several chunks, and the score-only hint."""
