@@ -125,11 +125,12 @@ int mgl_sw_ctx_set_strip_kernel(mgl_sw_ctx *ctx, int mode);
  * two-pairs-per-lane-of-a-16-lane-group kernel (sw_dp16.hip: eight pairs per wave); 1 = never the lane kernel;
  * 2 = the lane kernel whenever the batch is eligible (tests; results are identical) */
 int mgl_sw_ctx_set_lane_kernel(mgl_sw_ctx *ctx, int mode);
-/* the lane kernel stores no traceback by default (sw_dp16_lane_ck.hip): its fill keeps the carry row of every 32-row strip and the
- * lanes' state every 16 query columns, and the path walk recomputes the 32 x 16 blocks it crosses (same flags, same results, about a
- * fifth of the matrix twice instead of eight flag instructions for every cell).  0 (default) = that form whenever the lane kernel
- * runs with 32-row strips and writes CIGARs; 1 = never (the flags of every cell are stored: needed before mgl_sw_ctx_expand_slot);
- * 2 = same as 0 (tests) */
+/* the lane kernel stores no traceback by default (sw_dp16_lane_ck.hip): its fill keeps the carry row leaving every 16 target rows and
+ * the lanes' state every 32 query columns, and the path walk recomputes the 16 x 32 blocks it crosses (same flags, same results, about
+ * a fifth of the matrix twice instead of eight flag instructions for every cell).  0 (default) = that form whenever the lane kernel
+ * runs with 32-row strips and writes CIGARs, and for the geometries of a batch of mixed lengths that fill whole waves of 128 pairs
+ * (chunks sorted by geometry, from two rounds of the chip on); 1 = never (the flags of every cell are stored: needed before
+ * mgl_sw_ctx_expand_slot); 2 = same as 0 (tests) */
 int mgl_sw_ctx_set_lane_checkpoint(mgl_sw_ctx *ctx, int mode);
 /* 1 = HIP events around every kernel launch of a call, on the streams the kernels run on, read back by
  * mgl_sw_ctx_get_timing (the call itself stays asynchronous); 2 = additionally stamp the shader clock

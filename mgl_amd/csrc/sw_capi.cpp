@@ -200,6 +200,8 @@ struct Regroup {
     const int64_t *d_t_start = nullptr, *d_q_start = nullptr, *d_dest = nullptr;
     const int32_t *d_t_len = nullptr, *d_q_len = nullptr;
     int64_t n_grouped = 0;
+    bool lane_blocks = false; // in: a geometry's full blocks of 128 pairs first (whole waves of the checkpointed lane kernel) ...
+    int64_t n_lane = 0;       // out: ... slots [0, n_lane)
 };
 struct ChunkHooks {
     std::function<int(int64_t first, int64_t count, hipStream_t fill_stream)> before_fill;
@@ -286,6 +288,11 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                             !ctx->stripe_rows && ctx->cooperative < 2 && ctx->carry_memory == 0 && max_ql < kRows64MinQuery &&
                             dp16_lds_bytes(sps_for(max_ql), wpb16) <= 64 * 1024 && pick_waves_per_block(sps_for_rows(max_ql, 16), 16) > 0 &&
                             dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
+    // ... of which the geometries with 128 pairs and more go, whole waves of one geometry each, through the checkpointed lane kernel
+    static const bool lane_group_on = [] { const char *e = getenv("MGL_SW_LANE_GROUP"); return !e || atoi(e) != 0; }();
+    static const bool lane_ck_on = [] { const char *e = getenv("MGL_SW_LANE_CK"); return !e || atoi(e) != 0; }();
+    const bool lane_group = auto_group && lane_group_on && lane_ck_on && ctx->lane_checkpoint != 1 && ctx->lane_kernel != 1 && lane16_supported(tset, qset);
+    const int64_t lane_group_stride = lane_group ? lane_ck_words(max_tl, max_ql) : 0; // words per wave
     const bool use16 = (use16_eligible && !use_lane) || auto_group;
     // MGL_SW_FLAG_SCORE_ONLY is honoured by the packed kernels only; elsewhere the full path runs (a superset of the result)
     const bool score_only = score_only_hint && (use16 || use_lane) && d_score != nullptr && !hooks;
@@ -388,7 +395,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const int sps32 = sps_for_rows(max_ql, 16);
     const int64_t stride32_words = tb_words_for(max_tl, sps32, 16);
     const int64_t per_pair = use_lane ? ((score_only ? 0 : stride_words * 4) + lane_scratch_bytes(max_tl, max_ql, rows)) / 128 + 1 + (int64_t)sizeof(DpRecord)
-                             : auto_group ? std::max(stride_words * 2, stride32_words * 4) + (int64_t)sizeof(DpRecord)
+                             : auto_group ? std::max(std::max(stride_words * 2, stride32_words * 4), lane_group ? (lane_group_stride * 4 + lane_scratch_bytes(max_tl, max_ql, 32)) / 128 + 1 : 0) + (int64_t)sizeof(DpRecord)
                                           : (score_only ? 0 : stride_words * 4 / (use16 ? 2 : 1)) + (int64_t)sizeof(DpRecord);
     // the workspace is split in two halves so that the traceback of one chunk can run (on ctx->aux)
     // while the next chunk is being filled; a batch that fits one half is a single chunk
@@ -442,6 +449,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         else if (!score_only)
             HIP_TRY(ctx, ctx->tb[h].reserve(regions * (size_t)stride_words * 4));
         if (use_lane) HIP_TRY(ctx, ctx->bnd[h].reserve(regions * (size_t)lane_scratch_bytes(max_tl, max_ql, rows)));
+        if (lane_group) HIP_TRY(ctx, ctx->bnd[h].reserve((size_t)(chunk / 128 + 1) * (size_t)lane_scratch_bytes(max_tl, max_ql, 32)));
         HIP_TRY(ctx, ctx->rec[h].reserve((size_t)chunk * sizeof(DpRecord)));
     }
 
@@ -469,6 +477,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     int64_t k = 0;
     // result copies trail the launches by two chunks: the traceback of chunk k-2 is what the fill of chunk k waits
     // for anyway, so the (blocking) copy of its results never stalls behind the low-priority traceback stream
+    int64_t lane_pairs_last = 0; // sorted chunks: pairs of the last chunk that went through the lane kernel
     struct Pending { int64_t first, count; hipEvent_t ready; } pending[2];
     int n_pending = 0;
     for (int64_t first = 0; first < n; first += chunk, ++k) {
@@ -490,7 +499,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             DpRecord *rec;
             const int64_t *dest;
             int rows, wpb, sps_cap;
-        } parts[2];
+        } parts[3];
         int n_parts = 0;
         uint32_t *const tb_base = static_cast<uint32_t *>(ctx->tb[h].p);
         DpRecord *const rec_base = static_cast<DpRecord *>(ctx->rec[h].p);
@@ -500,6 +509,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             // the index arrays of this half were last read by the kernels of chunk k-2
             if (overlap && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->h2d, ctx->tb_done[h], 0));
             Regroup rg;
+            rg.lane_blocks = lane_group;
             if (hooks) {
                 const int hrc = hooks->regroup(first, count, h, fs, &rg);
                 if (hrc != MGL_SW_OK) return hrc;
@@ -521,7 +531,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                     ra.nfull = g + cells_n;
                     ra.full_start = g + 2 * cells_n;
                     ra.rest_start = g + 3 * cells_n;
-                    ra.total = reinterpret_cast<int64_t *>(g + 4 * cells_n) + hh;
+                    ra.nlane = g + 4 * cells_n;
+                    ra.lane_start = g + 5 * cells_n;
+                    ra.lane_blocks = lane_group ? 1 : 0;
+                    ra.total = reinterpret_cast<int64_t *>(g + 6 * cells_n) + 2 * hh;
                     ra.t_start = d;
                     ra.q_start = d + c;
                     ra.dest = d + 2 * c;
@@ -534,7 +547,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                     // these index arrays were last read by the kernels of the chunk four before this one
                     if (srt_used[hh]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->h2d, ctx->srt_free[hh], 0));
                     HIP_TRY(ctx, launch_regroup(ra, ctx->h2d));
-                    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_total + hh, ra.total, 8, hipMemcpyDeviceToHost, ctx->h2d));
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_total + 2 * hh, ra.total, 16, hipMemcpyDeviceToHost, ctx->h2d));
                     HIP_TRY(ctx, hipEventRecord(ctx->srt_done[hh], ctx->h2d));
                     return MGL_SW_OK;
                 };
@@ -551,7 +564,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                         if (!ctx->srt_free[b]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->srt_free[b], hipEventDisableTiming));
                         if (!ctx->srt_done[b]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->srt_done[b], hipEventDisableTiming));
                     }
-                    HIP_TRY(ctx, ctx->d_grid.reserve(cells_n * 16 + 64));
+                    HIP_TRY(ctx, ctx->d_grid.reserve(cells_n * 24 + 128));
                     if (!ctx->pin_total) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->pin_total), 64, hipHostMallocDefault));
                     // (the caller's stream may still be producing the inputs)
                     HIP_TRY(ctx, hipEventRecord(ctx->fill_done[0], stream));
@@ -569,8 +582,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                 rg.d_dest = ra.dest;
                 rg.d_t_len = ra.t_len;
                 rg.d_q_len = ra.q_len;
-                rg.n_grouped = ctx->pin_total[k & 3];
-                if (rg.n_grouped < 0 || rg.n_grouped > count || (rg.n_grouped & 7)) return fail(ctx, MGL_SW_ERR_DEVICE, "sorting a chunk by geometry failed");
+                rg.n_grouped = ctx->pin_total[2 * (k & 3)];
+                rg.n_lane = ctx->pin_total[2 * (k & 3) + 1];
+                if (rg.n_grouped < 0 || rg.n_grouped > count || (rg.n_grouped & 7) || rg.n_lane < 0 || rg.n_lane > rg.n_grouped || (rg.n_lane & 127))
+                    return fail(ctx, MGL_SW_ERR_DEVICE, "sorting a chunk by geometry failed");
                 {
                     const int src = sort_ahead(k + 2);
                     if (src != MGL_SW_OK) return src;
@@ -578,13 +593,23 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             }
             const SeqSet ts{tset.data, rg.d_t_start, rg.d_t_len, max_tl, tset.packed2}, qs{qset.data, rg.d_q_start, rg.d_q_len, max_ql, qset.packed2};
             const int64_t ng = rg.n_grouped;
-            if (ng > 0) parts[n_parts++] = Part{false, true, 0, ng, ts, qs, tb_base, stride_words, rec_base, rg.d_dest, 16, wpb16, sps_for(max_ql)};
+            // whole waves of one geometry: worth a launch of the lane kernel from two rounds of the chip on (a wave takes as long as 128
+            // pairs one after the other however few waves there are: 4 M reads of 100-150 bases in chunks of 1.3 M pairs 2 963 GCUPS
+            // against 2 790 without, but the host entry's chunks of 256 k pairs 2 131 against 2 397); fewer go with the blocks of
+            // eight, which they also are
+            const char *const lgm = getenv("MGL_SW_LANE_GROUP_MIN"); // (tests: read per chunk)
+            const int64_t lane_group_min = lgm ? (int64_t)atoll(lgm) : (int64_t)ctx->n_cus * 24 * 128;
+            const int64_t nl = lane_group && rg.n_lane >= std::max<int64_t>(lane_group_min, 128) ? rg.n_lane : 0;
+            uint32_t *const tb16 = tb_base + (size_t)(nl / 128) * (size_t)lane_group_stride;
+            lane_pairs_last = nl;
+            if (nl > 0) parts[n_parts++] = Part{true, false, 0, nl, ts, qs, tb_base, lane_group_stride, rec_base, rg.d_dest, 32, 4, max_ql};
+            if (ng > nl) parts[n_parts++] = Part{false, true, nl, ng - nl, ts, qs, tb16, stride_words, rec_base + nl, rg.d_dest, 16, wpb16, sps_for(max_ql)};
             if (count > ng)
-                parts[n_parts++] = Part{false, false, ng, count - ng, ts, qs, tb_base + (size_t)(ng / 2) * (size_t)stride_words, stride32_words,
+                parts[n_parts++] = Part{false, false, ng, count - ng, ts, qs, tb16 + (size_t)((ng - nl) / 2) * (size_t)stride_words, stride32_words,
                                         rec_base + ng, rg.d_dest, 16, pick_waves_per_block(sps32, 16), sps32};
         }
-        DpArgs das[2];
-        TbArgs tas[2];
+        DpArgs das[3];
+        TbArgs tas[3];
         int64_t n_blocks = 0;
         for (int i = 0; i < n_parts; ++i) {
             const Part &pt = parts[i];
@@ -610,6 +635,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             da.code = d_code;
             da.matrix_lds_offset = 0;
             da.score_only = score_only ? 1 : 0;
+            da.grouped = pt.lane && auto_group ? 1 : 0;
             const int per_block = pt.lane ? pt.wpb * 128 : pt.packed ? pt.wpb * 8 : strip16 ? 1 : pt.wpb * (64 / pt.rows);
             if (i == 0) n_blocks = (pt.count + per_block - 1) / per_block;
             if (ctx->profiling >= 2 && i == 0) {
@@ -657,8 +683,8 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         for (int i = 0; i < n_parts; ++i) {
             const Part &pt = parts[i];
             TbArgs walk = tas[i];
-            if (!fused_walk) walk.cigar = nullptr;
-            HIP_TRY(ctx, pt.lane ? (lane_ck ? launch_dp16_lane_ck(das[i], walk, fs) : launch_dp16_lane(das[i], walk, pt.rows, fs))
+            if (!fused_walk && !das[i].grouped) walk.cigar = nullptr; // (the waves of a sorted chunk's lane part walk their own paths too)
+            HIP_TRY(ctx, pt.lane ? (lane_ck || das[i].grouped ? launch_dp16_lane_ck(das[i], walk, fs) : launch_dp16_lane(das[i], walk, pt.rows, fs))
                          : pt.packed ? launch_dp16(das[i], pt.wpb, fs)
                          : strip16 ? launch_dp16_strip(das[i], strip_waves, pt.rows, fs)
                          : coop16 ? launch_dp_coop16(das[i], coop_waves, fs) : coop_waves ? launch_dp_coop(das[i], coop_waves, fs) : launch_dp(das[i], pt.wpb, pt.rows, fs));
@@ -669,8 +695,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->fill_done[h], 0));
         }
         if (pe[2]) HIP_TRY(ctx, hipEventRecord(pe[2], tb_stream));
-        for (int i = 0; i < n_parts && !fused_walk; ++i)
+        for (int i = 0; i < n_parts && !fused_walk; ++i) {
+            if (das[i].grouped) continue; // walked inside its fill kernel
             HIP_TRY(ctx, score_only ? launch_scores_only(tas[i], tb_stream) : launch_traceback(tas[i], tb_stream));
+        }
         if (pe[3]) HIP_TRY(ctx, hipEventRecord(pe[3], tb_stream));
         if (overlap) {
             HIP_TRY(ctx, hipEventRecord(ctx->tb_done[h], ctx->aux));
@@ -700,7 +728,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         ctx->timing.tb_launches++;
         ctx->timing.tb_bytes += (use_lane ? (count + 127) / 128 : use16 ? (count + 1) / 2 : count) * stride_words * 4;
         ctx->timing.packed16 = (use16 || use_lane) ? 1 : 0;
-        ctx->timing.fill_kernel = lane_ck ? MGL_SW_KERNEL_LANE16_CK : use_lane ? MGL_SW_KERNEL_LANE16 : use16 ? MGL_SW_KERNEL_DP16 : strip16 ? MGL_SW_KERNEL_STRIP16 : coop16 ? MGL_SW_KERNEL_COOP16 : coop_waves ? MGL_SW_KERNEL_COOP : rows == 64 ? MGL_SW_KERNEL_DP32_64 : MGL_SW_KERNEL_DP32;
+        ctx->timing.fill_kernel = lane_ck || lane_pairs_last > 0 ? MGL_SW_KERNEL_LANE16_CK : use_lane ? MGL_SW_KERNEL_LANE16 : use16 ? MGL_SW_KERNEL_DP16 : strip16 ? MGL_SW_KERNEL_STRIP16 : coop16 ? MGL_SW_KERNEL_COOP16 : coop_waves ? MGL_SW_KERNEL_COOP : rows == 64 ? MGL_SW_KERNEL_DP32_64 : MGL_SW_KERNEL_DP32;
     }
     for (int i = 0; hooks && i < n_pending; ++i) {
         const int hrc = hooks->after_traceback(pending[i].first, pending[i].count, pending[i].ready);
@@ -1227,7 +1255,8 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     // first (packed kernel), the left-over pairs behind them (int32 kernel); run_device decides whether it applies
     const int64_t range_t = hi_t - lo_t + 1, range_q = hi_q - lo_q + 1;
     static const bool auto_group_on = [] { const char *e = getenv("MGL_SW_AUTO_GROUP"); return !e || atoi(e) != 0; }();
-    std::vector<int32_t> grid_pos, grid_nfull, grid_full, grid_rest;
+    std::vector<int32_t> grid_pos, grid_nfull, grid_full, grid_rest, grid_nlane, grid_lane;
+    int64_t lane_total[2] = {0, 0};  // per half: pairs in the leading blocks of 128 (written by build, read after the job is joined)
     std::future<int64_t> next_job;   // the sort of the NEXT chunk runs on a helper thread while this thread is inside the
     int64_t next_first = -1;         // (blocking) pageable copies of the current one
     if (uniform == GEOM_MIXED && auto_group_on && n >= 1024 && range_t * range_q <= (1ll << 20)) {
@@ -1236,8 +1265,10 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
         grid_nfull.resize(cells_n);
         grid_full.resize(cells_n);
         grid_rest.resize(cells_n);
+        grid_nlane.resize(cells_n);
+        grid_lane.resize(cells_n);
         // slot arrays of a chunk in pinned memory: int64 t_start | int64 q_start | int64 dest | int32 t_len | int32 q_len
-        auto build = [&, cells_n](int64_t first, int64_t count, int h) -> int64_t {
+        auto build = [&, cells_n](int64_t first, int64_t count, int h, bool lane_blocks) -> int64_t {
             if (hipSetDevice(ctx->device) != hipSuccess) return -1;
             if (hipEventSynchronize(ctx->grp_copied[h]) != hipSuccess) return -1; // the copy of chunk k-2 has left the pinned buffer
             int64_t *ts_ = static_cast<int64_t *>(ctx->pin_grp[h]), *qs_ = ts_ + count, *dest_ = qs_ + count;
@@ -1247,12 +1278,20 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
             // cells in grid order), the others its left-over pairs (behind all the full blocks, in grid order too)
             std::fill(grid_pos.begin(), grid_pos.end(), 0);
             for (int64_t k = first; k < first + count; ++k) ++grid_pos[cell(k)];
-            int64_t full_total = 0, rest_total = 0;
+            // (lane_blocks: a cell's full blocks of 128 pairs before everything else -- whole waves of the checkpointed lane kernel)
+            int64_t full_total = 0, rest_total = 0, lane_sum = 0;
+            for (size_t c = 0; c < cells_n; ++c) {
+                grid_nlane[c] = lane_blocks ? grid_pos[c] & ~127 : 0;
+                grid_lane[c] = (int32_t)lane_sum;
+                lane_sum += grid_nlane[c];
+            }
+            full_total = lane_sum;
             for (size_t c = 0; c < cells_n; ++c) {
                 grid_nfull[c] = grid_pos[c] & ~7;
                 grid_full[c] = (int32_t)full_total;
-                full_total += grid_nfull[c];
+                full_total += grid_nfull[c] - grid_nlane[c];
             }
+            lane_total[h] = lane_sum;
             for (size_t c = 0; c < cells_n; ++c) {
                 grid_rest[c] = (int32_t)(full_total + rest_total);
                 rest_total += grid_pos[c] & 7;
@@ -1261,7 +1300,9 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
             for (int64_t k = first; k < first + count; ++k) {
                 const size_t c = cell(k);
                 const int32_t p = grid_pos[c]++;
-                const int64_t slot = p < grid_nfull[c] ? (int64_t)grid_full[c] + p : (int64_t)grid_rest[c] + (p - grid_nfull[c]);
+                const int64_t slot = p < grid_nlane[c]   ? (int64_t)grid_lane[c] + p
+                                     : p < grid_nfull[c] ? (int64_t)grid_full[c] + (p - grid_nlane[c])
+                                                         : (int64_t)grid_rest[c] + (p - grid_nfull[c]);
                 ts_[slot] = t_off[k];
                 qs_[slot] = q_off[k];
                 dest_[slot] = k;
@@ -1293,7 +1334,7 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
                 ng = next_job.get();
             } else {
                 if (next_job.valid()) next_job.wait();
-                ng = build(first, count, h);
+                ng = build(first, count, h, out->lane_blocks);
             }
             if (ng < 0) return fail(ctx, MGL_SW_ERR_DEVICE, "mgl_sw_align_batch: sorting a chunk by geometry failed");
             HIP_TRY(ctx, hipMemcpyAsync(ctx->d_grp[h].p, ctx->pin_grp[h], bytes, hipMemcpyHostToDevice, ctx->h2d));
@@ -1301,7 +1342,7 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
             HIP_TRY(ctx, hipStreamWaitEvent(fill_stream, ctx->grp_copied[h], 0));
             // the next chunk (the other half's buffers) is sorted while this thread copies and launches
             next_first = first + count;
-            if (next_first < n) next_job = std::async(std::launch::async, build, next_first, std::min(count, n - next_first), h ^ 1);
+            if (next_first < n) next_job = std::async(std::launch::async, build, next_first, std::min(count, n - next_first), h ^ 1, out->lane_blocks);
             const int64_t *d = static_cast<const int64_t *>(ctx->d_grp[h].p);
             out->d_t_start = d;
             out->d_q_start = d + count;
@@ -1309,6 +1350,7 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
             out->d_t_len = reinterpret_cast<const int32_t *>(d + 3 * count);
             out->d_q_len = out->d_t_len + count;
             out->n_grouped = ng;
+            out->n_lane = lane_total[h];
             return MGL_SW_OK;
         };
     }

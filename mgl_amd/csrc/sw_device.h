@@ -65,6 +65,7 @@ struct DpArgs {
     const uint8_t *code;      // byte -> 0 .. MATRIX_DIM-1
     int matrix_lds_offset;    // set by the launcher
     int score_only;           // packed kernel: no traceback flags (MGL_SW_FLAG_SCORE_ONLY)
+    int grouped;              // sw_dp16_lane_ck_kernel: every wave of 128 pairs has its own geometry (a chunk sorted by geometry)
 };
 
 struct TbArgs {
@@ -190,13 +191,15 @@ hipError_t launch_traceback(const TbArgs &a, hipStream_t stream);
 
 // Device-side sort of a chunk by geometry (sw_kernels.hip): a counting sort over the (tl, ql) grid [1, max_tl] x [1, max_ql].
 // Slots [0, total[0]) hold the full blocks of eight pairs of one geometry, cell after cell; the left-over pairs (fewer than
-// eight per cell) follow.  Slot arrays are in the indexed form of SeqSet (start, length) plus dest = the pair's index in the batch.
+// eight per cell) follow.  With lane_blocks, the full blocks of 128 pairs of every cell come first (slots [0, total[1])): whole
+// waves of sw_dp16_lane_ck_kernel.  Slot arrays are in the indexed form of SeqSet (start, length) plus dest = the pair's index in the batch.
 struct RegroupArgs {
     SeqSet t, q;
     int64_t first, count; // pairs [first, first + count) of the batch
     int max_tl, max_ql;
-    int32_t *cnt, *nfull, *full_start, *rest_start; // max_tl * max_ql each
-    int64_t *total;                                 // [0] = number of pairs in full blocks
+    int32_t *cnt, *nfull, *full_start, *rest_start, *nlane, *lane_start; // max_tl * max_ql each
+    int64_t *total;                                 // [0] = number of pairs in full blocks, [1] = of those, in the leading blocks of 128
+    int lane_blocks;                                // a cell's full blocks of 128 pairs come first of all (slots [0, total[1]))
     int64_t *t_start, *q_start, *dest;              // count each
     int32_t *t_len, *q_len;
 };

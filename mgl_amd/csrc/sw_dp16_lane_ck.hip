@@ -462,7 +462,11 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
     const bool validB = lvalid && (2 * ls + 1 < a.count);
     const int64_t slotB = validB ? 2 * ls + 1 : slotA;
 
-    const int tl = a.uni_tl, ql = a.uni_ql;
+    // one geometry per launch (a.uni_tl x a.uni_ql), or -- a.grouped: a chunk sorted by geometry, whole waves of 128 pairs --
+    // one per wave, read from its first pair; a.uni_tl / a.uni_ql are then the maxima that size the wave's regions
+    const bool grouped = a.grouped != 0;
+    const int tl = grouped ? __builtin_amdgcn_readfirstlane(a.t.length(a.first + gw * 128)) : a.uni_tl;
+    const int ql = grouped ? __builtin_amdgcn_readfirstlane(a.q.length(a.first + gw * 128)) : a.uni_ql;
     const int match = a.match, gopen = a.gopen, gext = a.gext;
     const bool indel = (a.strategy & (OS_INDEL | OS_LEAD_ID)) != 0;
     const int base = dp16_base(tl, ql, match, gext);
@@ -482,7 +486,7 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
     const int strips = lane_strips(tl, R), nb = lane_ck_blocks(ql), ng8 = lane_ck_groups(ql);
     // the wave's scratch, as in sw_dp16_lane.hip: the carry row between strips [column 0 .. ql][lane] x {H, E}, then both queries
     // and both targets of every lane transposed to [4-base block][A | B][lane] dwords
-    unsigned char *const wave_scratch = a.scratch + (size_t)gw * (size_t)lane_scratch_bytes(tl, ql, R);
+    unsigned char *const wave_scratch = a.scratch + (size_t)gw * (size_t)lane_scratch_bytes(a.uni_tl, a.uni_ql, R);
     uint2 *const bnd = reinterpret_cast<uint2 *>(wave_scratch) + lane;
     unsigned *const qst = reinterpret_cast<unsigned *>(wave_scratch + (size_t)lane_bnd_entries(ql) * 8) + lane;
     unsigned *const tst = qst + (size_t)((ql + 3) >> 2) * 128;

@@ -1024,42 +1024,67 @@ __global__ __launch_bounds__(RG_BLOCK) void sw_regroup_count_kernel(const Regrou
     const bool valid = k < a.count;
     (void)regroup_take(a.cnt, valid ? regroup_cell(a, a.first + k) : 0, valid, tab, false);
 }
-// one workgroup: exclusive prefix sums over the grid, of the pairs in full blocks (high word) and of the left-over pairs (low
-// word), 1024 cells at a time; rest_start is relative to the end of the full blocks (total[0], added by the scatter)
+// one workgroup: exclusive prefix sums over the grid, 1024 cells at a time, of the pairs in blocks of 128 (lane_blocks only), of
+// the pairs in the remaining full blocks of eight, and of the left-over pairs; full_start is relative to the end of the blocks
+// of 128 (total[1]), rest_start to the end of all full blocks (total[0]): both added by the scatter
 __global__ __launch_bounds__(1024) void sw_regroup_scan_kernel(const RegroupArgs a)
 {
     __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned s_rest[16];
     const int cells = a.max_tl * a.max_ql, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long run = 0; // totals of the tiles before this one
+    unsigned long long run = 0; // totals of the tiles before this one: blocks of 128 (high word), of eight (low word)
+    unsigned run_rest = 0;
     for (int c0 = 0; c0 < cells; c0 += 1024) {
         const int c = c0 + (int)threadIdx.x;
         const int n = c < cells ? a.cnt[c] : 0;
-        const unsigned long long mine = ((unsigned long long)(unsigned)(n & ~7) << 32) | (unsigned)(n & 7);
+        const int nl = a.lane_blocks ? n & ~127 : 0, n8 = (n - nl) & ~7;
+        const unsigned long long mine = ((unsigned long long)(unsigned)nl << 32) | (unsigned)n8;
+        const unsigned mine_rest = (unsigned)(n & 7);
         unsigned long long incl = mine;
+        unsigned incl_rest = mine_rest;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const unsigned long long up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
+            const unsigned up_rest = __shfl_up(incl_rest, d);
+            if (lane >= d) {
+                incl += up;
+                incl_rest += up_rest;
+            }
         }
-        if (lane == 63) s_wave[wave] = incl;
+        if (lane == 63) {
+            s_wave[wave] = incl;
+            s_rest[wave] = incl_rest;
+        }
         __syncthreads();
         unsigned long long before = 0, tile = 0;
+        unsigned before_rest = 0, tile_rest = 0;
         for (int w = 0; w < 16; ++w) {
             const unsigned long long v = s_wave[w];
-            if (w < wave) before += v;
+            const unsigned vr = s_rest[w];
+            if (w < wave) {
+                before += v;
+                before_rest += vr;
+            }
             tile += v;
+            tile_rest += vr;
         }
         const unsigned long long excl = run + before + incl - mine;
         if (c < cells) {
-            a.nfull[c] = n & ~7;
-            a.full_start[c] = (int)(excl >> 32);
-            a.rest_start[c] = (int)(excl & 0xffffffffu);
+            a.nlane[c] = nl;
+            a.nfull[c] = nl + n8;
+            a.lane_start[c] = (int)(excl >> 32);
+            a.full_start[c] = (int)(excl & 0xffffffffu);
+            a.rest_start[c] = (int)(run_rest + before_rest + incl_rest - mine_rest);
             a.cnt[c] = 0; // the scatter counts again
         }
         run += tile;
+        run_rest += tile_rest;
         __syncthreads();
     }
-    if (threadIdx.x == 0) a.total[0] = (int64_t)(run >> 32);
+    if (threadIdx.x == 0) {
+        a.total[1] = (int64_t)(run >> 32);
+        a.total[0] = (int64_t)(run >> 32) + (int64_t)(run & 0xffffffffu);
+    }
 }
 __global__ __launch_bounds__(RG_BLOCK) void sw_regroup_scatter_kernel(const RegroupArgs a)
 {
@@ -1070,8 +1095,9 @@ __global__ __launch_bounds__(RG_BLOCK) void sw_regroup_scatter_kernel(const Regr
     const int c = regroup_cell(a, p);
     const int pos = regroup_take(a.cnt, c, valid, tab, true);
     if (!valid) return;
-    const int nf = a.nfull[c];
-    const int64_t slot = pos < nf ? (int64_t)a.full_start[c] + pos : a.total[0] + a.rest_start[c] + (pos - nf);
+    const int nl = a.nlane[c], nf = a.nfull[c];
+    const int64_t slot = pos < nl ? (int64_t)a.lane_start[c] + pos
+                         : pos < nf ? a.total[1] + a.full_start[c] + (pos - nl) : a.total[0] + a.rest_start[c] + (pos - nf);
     a.t_start[slot] = a.t.off[p];
     a.q_start[slot] = a.q.off[p];
     a.dest[slot] = p;

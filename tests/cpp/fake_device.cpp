@@ -125,11 +125,17 @@ hipError_t launch_regroup(const RegroupArgs &a, hipStream_t)
     };
     for (int c = 0; c < cells; ++c) a.cnt[c] = 0;
     for (int64_t k = 0; k < a.count; ++k) ++a.cnt[cell(a.first + k)];
-    int full = 0, rest = 0;
+    int lane = 0, full = 0, rest = 0;
+    for (int c = 0; c < cells; ++c) {
+        a.nlane[c] = a.lane_blocks ? a.cnt[c] & ~127 : 0;
+        a.lane_start[c] = lane;
+        lane += a.nlane[c];
+    }
+    full = lane;
     for (int c = 0; c < cells; ++c) {
         a.nfull[c] = a.cnt[c] & ~7;
         a.full_start[c] = full;
-        full += a.nfull[c];
+        full += a.nfull[c] - a.nlane[c];
     }
     for (int c = 0; c < cells; ++c) {
         a.rest_start[c] = full + rest;
@@ -137,10 +143,13 @@ hipError_t launch_regroup(const RegroupArgs &a, hipStream_t)
         a.cnt[c] = 0;
     }
     a.total[0] = full;
+    a.total[1] = lane;
     for (int64_t k = 0; k < a.count; ++k) {
         const int64_t p = a.first + k;
         const int c = cell(p), pos = a.cnt[c]++;
-        const int64_t slot = pos < a.nfull[c] ? (int64_t)a.full_start[c] + pos : (int64_t)a.rest_start[c] + (pos - a.nfull[c]);
+        const int64_t slot = pos < a.nlane[c]   ? (int64_t)a.lane_start[c] + pos
+                             : pos < a.nfull[c] ? (int64_t)a.full_start[c] + (pos - a.nlane[c])
+                                                : (int64_t)a.rest_start[c] + (pos - a.nfull[c]);
         a.t_start[slot] = a.t.off[p];
         a.q_start[slot] = a.q.off[p];
         a.dest[slot] = p;

@@ -164,6 +164,36 @@ int main()
         int32_t btr_probe[4];
         if (lane_mode == 2) CHECK(mgl_sw_ctx_expand_slot(ctx, 0, 1, 1, btr_probe) == MGL_SW_ERR_UNSUPPORTED); // no stored traceback to expand
     }
+    // ---- a mixed batch with one dominant geometry: the sorted chunks' whole waves of 128 go through the (fake) lane kernel, the rest
+    // through the packed and int32 parts -- both entries, several chunks (threshold lowered: MGL_SW_LANE_GROUP_MIN)
+    {
+        Batch most;
+        for (int k = 0; k < 2600; ++k) {
+            const bool odd = k % 9 == 0;
+            std::string t = rnd(g, odd ? 200 + (int)(g() % 57) : 256), q = t.substr(g() % 40, odd ? 100 + g() % 51 : 150);
+            q[g() % q.size()] = 'T';
+            most.add(t, q);
+        }
+        const Expect eo = expect(most, MGL_SW_OS_SOFTCLIP);
+        setenv("MGL_SW_LANE_GROUP_MIN", "128", 1);
+        CHECK(mgl_sw_ctx_set_lane_kernel(ctx, 0) == 0 && mgl_sw_ctx_set_lane_checkpoint(ctx, 0) == 0 && mgl_sw_ctx_set_workspace(ctx, 64ll << 20) == 0);
+        const int64_t n = most.n();
+        for (int entry = 0; entry < 2; ++entry) {
+            std::vector<int32_t> off((size_t)n), len((size_t)n), st((size_t)n);
+            std::vector<mgl_sw_score> sc((size_t)n);
+            std::vector<char> cg((size_t)n * 64, 1);
+            if (entry == 0)
+                CHECK(mgl_sw_align_batch_status(ctx, n, most.t.data(), most.toff.data(), most.q.data(), most.qoff.data(), 200, -150, 260, 11, MGL_SW_OS_SOFTCLIP,
+                                                off.data(), sc.data(), cg.data(), 64, len.data(), st.data()) == 0);
+            else
+                CHECK(mgl_sw_align_batch_device(ctx, nullptr, n, most.t.data(), most.toff.data(), most.q.data(), most.qoff.data(), 256, 150, 200, -150, 260, 11,
+                                                MGL_SW_OS_SOFTCLIP, off.data(), sc.data(), cg.data(), 64, len.data(), st.data(), 0) == 0);
+            mgl_sw_timing tm;
+            CHECK(mgl_sw_ctx_get_timing(ctx, &tm) == 0 && tm.dp_launches >= 2 && tm.fill_kernel == MGL_SW_KERNEL_LANE16_CK);
+            compare(most, eo, off, sc, cg, 64, len, &st);
+        }
+        unsetenv("MGL_SW_LANE_GROUP_MIN");
+    }
     mgl_sw_ctx_destroy(ctx);
 
     // ---- several devices from one process

@@ -703,6 +703,47 @@ def test_host_entry_sorts_mixed_batches_by_geometry_itself():
     b.close()
 
 
+@pytest.mark.parametrize("resident", [True, False])
+def test_sorted_chunks_run_big_geometries_on_the_lane_kernel(monkeypatch, resident):
+    """A chunk sorted by geometry (either entry) hands the geometries that fill whole waves of 128 pairs to the checkpointed lane
+    kernel -- one geometry per wave -- the remaining full blocks of eight to the packed kernel and the left-over pairs to the int32
+    kernel.  The threshold (half a round of the chip) is lowered so that a test-sized batch takes all three."""
+    import torch
+    from mgl_amd import device_batch, synth
+
+    monkeypatch.setenv("MGL_SW_LANE_GROUP_MIN", "128")
+    rng = synth.rng_for(91)
+    n = 36_000
+    genome = synth.random_genome(rng, 1 << 18)
+    starts = rng.integers(0, len(genome) - 300, size=n)
+    tls = rng.choice([256, 256, 256, 200], size=n)
+    qls = rng.choice([150, 150, 125, 101, 64], size=n)
+    qls[::53] = rng.integers(1, 151, size=len(qls[::53]))   # odd geometries: blocks of eight and left-over pairs
+    reads = synth.illumina_reads(rng, genome, starts + 30, read_len=150, sub=0.02, ins=0.004, dele=0.004)
+    tseqs = [genome[s: s + tl].tobytes() for s, tl in zip(starts, tls)]
+    qseqs = [r[:q].tobytes() for r, q in zip(reads, qls)]
+    a = sw.MicrosoftSmithWaterman(0)
+    a.set_workspace(256 << 20)  # a few chunks
+    for strategy in (ol.SOFTCLIP, ol.INDEL):
+        woff, wsc, wcg = ol.oracle_align_batch(tseqs, qseqs, (200, -150, 260, 11), strategy, nthreads=8)
+        if resident:
+            td, toff = sw.concat(tseqs)
+            qd, qoff = sw.concat(qseqs)
+            b = device_batch.from_host(td, toff, qd, qoff, "cuda:0", cigar_stride=128)
+            b.run(a, overhang_strategy=strategy)
+            torch.cuda.synchronize()
+            off, sc, cg = b.offsets.cpu().numpy(), b.scores.cpu().numpy(), b.cigar_strings()
+            assert int((b.status != 0).sum()) == 0
+        else:
+            res = a.align_batch(tseqs, qseqs, (200, -150, 260, 11), strategy, cigar_stride=128)
+            off, sc, cg = res.offsets, res.scores, list(res.cigars)
+        tm = a.timing()
+        assert tm.dp_launches >= 2 and tm.fill_kernel == 7, "the sorted chunks' big geometries should take the lane kernel"
+        assert (off == woff).all() and (sc == wsc).all()
+        assert all(cg[k] == wcg[k] for k in range(n))
+    a.close()
+
+
 def test_grouping_helper_feeds_the_indexed_entry(aligner):
     """What a C caller does with variable-length reads: mgl_sw_group_by_geometry on the host, then the grouped part through
     mgl_sw_align_batch_device_indexed with MGL_SW_FLAG_GROUPED_GEOMETRY (packed kernel) and the rest without the flag."""
