@@ -3,10 +3,10 @@
 // sw_lane_cell.h -- for 38 400 cells of a 256 x 150 pair of which the path visits ~300.  Here
 //
 //   pass 1  runs the score-only column code (9 instructions per two cells) over the whole matrix and keeps what is needed
-//           to START AGAIN anywhere on a coarse grid: the carry row entering every strip of 32 target rows (H and E per
-//           column -- the reference's score[] / step[], sw_avx.cpp:36-47,196-197; the fill writes these anyway, here they
-//           are kept instead of overwritten) and, every LANE_CK_COLS query columns, the lane's register state (H of the
-//           previous column and the horizontal-gap value of its 32 rows);
+//           to START AGAIN anywhere on a coarse grid: the carry row leaving every 16 target rows -- the last row of every 32-row
+//           strip (H and E per column: the reference's score[] / step[], sw_avx.cpp:36-47,196-197) and the row in its middle --
+//           and, every LANE_CK_COLS query columns, the lane's register state (H of the previous column and the horizontal-gap
+//           value of its 32 rows);
 //   pass 2  walks the path (sw.cpp:149-255) block by block: the lane recomputes the 16 x LANE_CK_COLS block its walk stands
 //           in -- the SAME column code with the flags switched on, started from the two checkpoints of the block, so every
 //           flag is bit for bit the one the full fill would have stored -- into a small private buffer, walks as far as the
@@ -16,20 +16,20 @@
 //           columns wide -- a path of a 256 x 150 pair crosses ~14 of them, 7 000 of 38 400 cells -- and a 16-row column needs
 //           48 registers of state where a 32-row one needs 96 (with 32-row blocks the compiler spilled the target bases into
 //           the column loop).  Measured on 2 M pairs of 256 x 150: blocks of 16 columns 22.6 ms, of 32 columns 21.7 (half the
-//           checkpoint bytes weigh more than the larger blocks: pass 1 pays ~0.3 ms per KB it writes per pair).
+//           checkpoint bytes weigh more than the larger blocks: the record stores cost pass 1 2.7 ms of its 13.9).
 //
 // Same arithmetic, same range guard (dp16_range_ok), same results as sw_dp16_lane_kernel.
 //
 // What pass 2 fetches is scattered -- every lane is somewhere else on its path -- so it is laid out PER PAIR: a fetch then uses
-// the 64-byte sectors it touches (time-major [column][lane] arrays cost a sector per 8 bytes: 33 sectors per block and pair,
-// more traffic than the flags this kernel saves).  Pass 1 produces its values lane by lane and column by column, so it stages
+// the 64-byte sectors it touches (time-major [column][lane] arrays cost a sector per 8 bytes: 33 sectors per 16-column block and
+// pair).  Pass 1 produces its values lane by lane and column by column, so it stages
 // them in LDS (128 bytes per lane) and writes them out transposed, whole lines per store instruction.
 //
 // Per-wave region (a.tb + wave * a.tb_stride_words, lane_ck_words()), in RECORDS of [lane][32 dwords] (8 KB):
 //   rows   record (slot * groups + g): columns 8 g + 1 .. 8 g + 8 of two carry rows, per lane [pair A | pair B][column][mid | bot]
 //          dwords {H : 16, E : 16}: slot k = strip k's middle row (what enters its lower 16 rows) and its last row (what enters
 //          the strip below)
-//   ckpt   record ((strip * blocks + b) * 2 + pair): the pair's state at column 16 b, [upper | lower 16 rows][h x 8 | f x 8]
+//   ckpt   record ((strip * blocks + b) * 2 + pair): the pair's state at column LANE_CK_COLS b, [upper | lower 16 rows][h x 8 | f x 8]
 //          dwords of two rows each
 //   block  [column of the block][lane] uint4: the recomputed flags of 16 rows, bytes as in sw_dp16_lane.hip
 // The carry row between strips that pass 1 itself reads (time-major, updated in place) lives in the wave's scratch as in
