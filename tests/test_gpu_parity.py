@@ -1026,6 +1026,53 @@ def test_lane_checkpointed_long_gaps(tl, ql):
         a.close()
 
 
+def test_lane_kernels_alphabets_binary_cigar_and_overflow(lane_aligner):
+    """Both lane kernels on what their other tests leave out: arbitrary byte alphabets and unusual scoring parameters (bytes compared
+    raw, sw.cpp:55; zero gap costs, many ties), BAM-style binary CIGARs, and CIGAR slots too small for some pairs (per-pair overflow
+    status and needed length, the other pairs unaffected) -- against the oracle and against the default aligner's bytes."""
+    import torch
+    from mgl_amd import device_batch as db
+
+    rng = np.random.default_rng(2718)
+    psets = [(200, -150, 260, 11), (1, 0, 0, 0), (5, -3, 0, 1), (5, -3, 7, 0), (2, -7, 1, 1), (127, -128, 255, 1), (9, -9, 9, 9), (1, -1, 50, 50)]
+    ran = 0
+    for it, params in enumerate(psets):
+        tl, ql = [(256, 150), (64, 65), (96, 40), (130, 33)][it % 4]
+        hi = 256 if it % 2 else 3
+        ts, qs = [], []
+        for k in range(131):
+            t = rng.integers(0, hi, tl, dtype=np.uint8)
+            q = np.resize(t[int(rng.integers(0, max(1, tl - ql + 1))):], ql).copy() if k % 3 else rng.integers(0, hi, ql, dtype=np.uint8)
+            if k % 3 == 1:
+                q[rng.integers(0, ql, 3)] ^= 1
+            ts.append(t.tobytes())
+            qs.append(q.tobytes())
+        for strategy in ol.STRATEGIES:
+            res = lane_aligner.align_batch(ts, qs, params, strategy)
+            ran += lane_aligner.timing().fill_kernel in lane_aligner.lane_kernels  # (gap open below gap extend: outside the 16-bit guard)
+            off, sc, cg = ol.oracle_align_batch(ts, qs, params, strategy, nthreads=4)
+            assert (res.offsets == off).all() and (res.scores == sc).all() and list(res.cigars) == cg, (params, strategy)
+    assert ran >= 16, "most of these parameter sets fit the lane kernels"
+    # binary CIGARs and small slots: reads with an indel each, so that the text needs more than eight bytes for some pairs only
+    rows = [g for g in golden_io.load("window") if g.strategy == ol.SOFTCLIP][:300]
+    td, toff = sw.concat([g.t for g in rows])
+    qd, qoff = sw.concat([g.q for g in rows])
+    b = db.from_host(td, toff, qd, qoff, "cuda:0", cigar_stride=4 * 64)
+    b.run(lane_aligner, rows[0].params, ol.SOFTCLIP, binary_cigar=True)
+    torch.cuda.synchronize()
+    assert lane_aligner.timing().fill_kernel in lane_aligner.lane_kernels and int((b.status != 0).sum()) == 0
+    assert b.cigar_elements() == [g.cigar for g in rows]
+    small = db.from_host(td, toff, qd, qoff, "cuda:0", cigar_stride=8)
+    small.run(lane_aligner, rows[0].params, ol.SOFTCLIP)
+    torch.cuda.synchronize()
+    st, need = small.status.cpu().numpy(), small.cigar_len.cpu().numpy()
+    cgs = small.cigar_strings()
+    assert 0 < int((st != 0).sum()) < len(rows)
+    for k, g in enumerate(rows):
+        assert need[k] == len(g.cigar) and int(small.offsets[k]) == g.offset
+        assert (st[k] == 2 and len(g.cigar) > 8) or (st[k] == 0 and cgs[k] == g.cigar), (k, st[k], g.cigar)
+
+
 def test_lane_kernel_goldens_unaligned_chunked_score_only(lane_aligner):
     """The window goldens (one geometry) through the lane kernel: sequences at odd byte offsets (the kernel reads aligned
     dwords and shifts), several chunks, and the score-only hint."""
