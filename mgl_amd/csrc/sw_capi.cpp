@@ -1280,7 +1280,7 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
             for (int64_t k = first; k < first + count; ++k) ++grid_pos[cell(k)];
             // (lane_blocks: a cell's full blocks of 128 pairs before everything else -- whole waves of the checkpointed lane kernel)
             int64_t full_total = 0, rest_total = 0, lane_sum = 0;
-            for (size_t c = 0; c < cells_n; ++c) {
+            for (size_t c = cells_n; c-- > 0;) { // (in reverse grid order: the waves with the longest queries first, they take longest)
                 grid_nlane[c] = lane_blocks ? grid_pos[c] & ~127 : 0;
                 grid_lane[c] = (int32_t)lane_sum;
                 lane_sum += grid_nlane[c];

@@ -1072,7 +1072,8 @@ __global__ __launch_bounds__(1024) void sw_regroup_scan_kernel(const RegroupArgs
         if (c < cells) {
             a.nlane[c] = nl;
             a.nfull[c] = nl + n8;
-            a.lane_start[c] = (int)(excl >> 32);
+            a.lane_start[c] = -(int)(excl >> 32) - nl; // from the END of the lane part (total[1], added by the scatter): the cells with
+                                                       // the longest queries first -- the waves that take longest should not start last
             a.full_start[c] = (int)(excl & 0xffffffffu);
             a.rest_start[c] = (int)(run_rest + before_rest + incl_rest - mine_rest);
             a.cnt[c] = 0; // the scatter counts again
@@ -1096,7 +1097,7 @@ __global__ __launch_bounds__(RG_BLOCK) void sw_regroup_scatter_kernel(const Regr
     const int pos = regroup_take(a.cnt, c, valid, tab, true);
     if (!valid) return;
     const int nl = a.nlane[c], nf = a.nfull[c];
-    const int64_t slot = pos < nl ? (int64_t)a.lane_start[c] + pos
+    const int64_t slot = pos < nl ? a.total[1] + a.lane_start[c] + pos
                          : pos < nf ? a.total[1] + a.full_start[c] + (pos - nl) : a.total[0] + a.rest_start[c] + (pos - nf);
     a.t_start[slot] = a.t.off[p];
     a.q_start[slot] = a.q.off[p];

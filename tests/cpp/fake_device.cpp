@@ -126,7 +126,7 @@ hipError_t launch_regroup(const RegroupArgs &a, hipStream_t)
     for (int c = 0; c < cells; ++c) a.cnt[c] = 0;
     for (int64_t k = 0; k < a.count; ++k) ++a.cnt[cell(a.first + k)];
     int lane = 0, full = 0, rest = 0;
-    for (int c = 0; c < cells; ++c) {
+    for (int c = cells - 1; c >= 0; --c) { // (reverse grid order, as on the device: long queries first)
         a.nlane[c] = a.lane_blocks ? a.cnt[c] & ~127 : 0;
         a.lane_start[c] = lane;
         lane += a.nlane[c];
@@ -147,7 +147,7 @@ hipError_t launch_regroup(const RegroupArgs &a, hipStream_t)
     for (int64_t k = 0; k < a.count; ++k) {
         const int64_t p = a.first + k;
         const int c = cell(p), pos = a.cnt[c]++;
-        const int64_t slot = pos < a.nlane[c]   ? (int64_t)a.lane_start[c] + pos
+        const int64_t slot = pos < a.nlane[c]   ? (int64_t)a.lane_start[c] + pos // (the fake stores the start itself, not the device's offset from the end)
                              : pos < a.nfull[c] ? (int64_t)a.full_start[c] + (pos - a.nlane[c])
                                                 : (int64_t)a.rest_start[c] + (pos - a.nfull[c]);
         a.t_start[slot] = a.t.off[p];
