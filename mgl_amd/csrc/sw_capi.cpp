@@ -73,6 +73,11 @@ struct mgl_sw_ctx {
     DevBuf stage_in, stage_out;
     // host entry, batches of mixed geometries: per workspace half the chunk's index arrays (start / length / caller index per
     // slot, sorted by geometry), built in pinned memory and mirrored on the device
+    // host-buffer entry: results travel device -> pinned ring (asynchronous, own stream) -> the caller's arrays (helper jobs)
+    void *pin_res[3] = {nullptr, nullptr, nullptr};
+    size_t pin_res_cap[3] = {0, 0, 0};
+    hipEvent_t res_copied[3] = {nullptr, nullptr, nullptr};
+    hipStream_t d2h = nullptr;
     void *pin_grp[2] = {nullptr, nullptr};
     size_t pin_grp_cap[2] = {0, 0};
     DevBuf d_grp[2];
@@ -850,6 +855,11 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     if (ctx->pin_matrix) (void)hipHostFree(ctx->pin_matrix);
     if (ctx->matrix_copied) (void)hipEventDestroy(ctx->matrix_copied);
     if (ctx->ws_idle) (void)hipEventDestroy(ctx->ws_idle);
+    for (int r = 0; r < 3; ++r) {
+        if (ctx->pin_res[r]) (void)hipHostFree(ctx->pin_res[r]);
+        if (ctx->res_copied[r]) (void)hipEventDestroy(ctx->res_copied[r]);
+    }
+    if (ctx->d2h) (void)hipStreamDestroy(ctx->d2h);
     for (int h = 0; h < 2; ++h) {
         if (ctx->pin_grp[h]) (void)hipHostFree(ctx->pin_grp[h]);
         if (ctx->grp_copied[h]) (void)hipEventDestroy(ctx->grp_copied[h]);
@@ -1212,6 +1222,10 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     double t_in = 0, t_out = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
+    // (Inputs stay blocking pageable copies on this thread.  Staging them through a pinned ring by helper jobs, a chunk ahead, was
+    // measured: the thread then waits 11 ms instead of 43 per 4 M mixed pairs, but the chunk sort it used to hide behind those
+    // copies becomes the critical path and the helpers compete with it for the box's cores -- 64 ms per call against 54; uniform
+    // batches, kernel bound, gain nothing: 3 505 against 3 477 GCUPS.)
     hooks.before_fill = [&](int64_t first, int64_t count, hipStream_t fill_stream) -> int {
         const double t0 = now();
         const int64_t ta = t_off[first], tb = t_off[first + count], qa = q_off[first], qb = q_off[first + count];
@@ -1226,13 +1240,64 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
         t_in += now() - t0;
         return MGL_SW_OK;
     };
-    // (Result copies from a helper thread with a stream of its own, so that both directions of the link run at once, were
-    // tried: 138-151 ms against 136 -- two threads inside the runtime's pageable-copy path slow each other down.)
+    // Results: a blocking copy into the caller's pageable arrays keeps this thread from the next chunk's input copies for a third of
+    // the call (10 M pairs: 17 ms out, 29 ms in), and a second thread inside the runtime's pageable-copy path makes both slower.  So
+    // the results of a chunk go to a pinned buffer by an asynchronous copy on a stream of their own (the link's other direction),
+    // and a helper job moves them on into the caller's arrays once they have landed; three buffers in rotation.
+    static const bool staged_out = [] { const char *e = getenv("MGL_SW_OUT_STAGED"); return !e || atoi(e) != 0; }();
+    std::future<int> res_job[3];
+    int64_t res_seq = 0;
+    auto join_results = [&]() -> int {
+        int worst = MGL_SW_OK;
+        for (auto &j : res_job)
+            if (j.valid()) {
+                const int r = j.get();
+                if (r != MGL_SW_OK) worst = r;
+            }
+        return worst;
+    };
     hooks.after_traceback = [&](int64_t first, int64_t count, hipEvent_t results_ready) -> int {
         const double t0 = now();
+        const size_t f = (size_t)first, c = (size_t)count;
+        if (staged_out) {
+            const int r = (int)(res_seq++ % 3);
+            if (res_job[r].valid() && res_job[r].get() != MGL_SW_OK) return fail(ctx, MGL_SW_ERR_DEVICE, "mgl_sw_align_batch: copying results out failed");
+            // sections of the pinned buffer, 16-byte aligned: offsets | scores | cigars | lengths | statuses
+            const size_t o_off = 0, o_sc = o_off + ((c * 4 + 15) & ~(size_t)15), o_cg = o_sc + ((c * sizeof(Score) + 15) & ~(size_t)15),
+                         o_len = o_cg + ((c * (size_t)cigar_stride + 15) & ~(size_t)15), o_st = o_len + ((c * 4 + 15) & ~(size_t)15), bytes = o_st + c * 4 + 16;
+            if (!ctx->d2h) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->d2h, hipStreamNonBlocking));
+            if (!ctx->res_copied[r]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->res_copied[r], hipEventDisableTiming));
+            if (bytes > ctx->pin_res_cap[r]) {
+                if (ctx->pin_res[r]) (void)hipHostFree(ctx->pin_res[r]);
+                ctx->pin_res[r] = nullptr;
+                ctx->pin_res_cap[r] = 0;
+                HIP_TRY(ctx, hipHostMalloc(&ctx->pin_res[r], bytes + bytes / 8, hipHostMallocDefault));
+                ctx->pin_res_cap[r] = bytes + bytes / 8;
+            }
+            char *const pin = static_cast<char *>(ctx->pin_res[r]);
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, results_ready, 0));
+            HIP_TRY(ctx, hipMemcpyAsync(pin + o_off, static_cast<int32_t *>(ctx->d_off.p) + f, c * 4, hipMemcpyDeviceToHost, ctx->d2h));
+            if (score_out) HIP_TRY(ctx, hipMemcpyAsync(pin + o_sc, static_cast<Score *>(ctx->d_score.p) + f, c * sizeof(Score), hipMemcpyDeviceToHost, ctx->d2h));
+            HIP_TRY(ctx, hipMemcpyAsync(pin + o_cg, static_cast<char *>(ctx->d_cig.p) + f * cigar_stride, c * (size_t)cigar_stride, hipMemcpyDeviceToHost, ctx->d2h));
+            if (cigar_len_out) HIP_TRY(ctx, hipMemcpyAsync(pin + o_len, static_cast<int32_t *>(ctx->d_len.p) + f, c * 4, hipMemcpyDeviceToHost, ctx->d2h));
+            if (status_out) HIP_TRY(ctx, hipMemcpyAsync(pin + o_st, static_cast<int32_t *>(ctx->d_status.p) + f, c * 4, hipMemcpyDeviceToHost, ctx->d2h));
+            HIP_TRY(ctx, hipEventRecord(ctx->res_copied[r], ctx->d2h));
+            hipEvent_t landed = ctx->res_copied[r];
+            const int device = ctx->device;
+            res_job[r] = std::async(std::launch::async, [=]() -> int {
+                if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(landed) != hipSuccess) return MGL_SW_ERR_DEVICE;
+                memcpy(offset_out + f, pin + o_off, c * 4);
+                if (score_out) memcpy(score_out + f, pin + o_sc, c * sizeof(Score));
+                memcpy(cigar_out + f * cigar_stride, pin + o_cg, c * (size_t)cigar_stride);
+                if (cigar_len_out) memcpy(cigar_len_out + f, pin + o_len, c * 4);
+                if (status_out) memcpy(status_out + f, pin + o_st, c * 4);
+                return MGL_SW_OK;
+            });
+            t_out += now() - t0;
+            return MGL_SW_OK;
+        }
         hipStream_t tb_stream = ctx->h2d;   // the copy stream: never queued behind a later chunk's kernels
         HIP_TRY(ctx, hipStreamWaitEvent(tb_stream, results_ready, 0));
-        const size_t f = (size_t)first, c = (size_t)count;
         HIP_TRY(ctx, hipMemcpyAsync(offset_out + f, static_cast<int32_t *>(ctx->d_off.p) + f, c * 4, hipMemcpyDeviceToHost,
                                     tb_stream));
         if (score_out)
@@ -1259,6 +1324,9 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     int64_t lane_total[2] = {0, 0};  // per half: pairs in the leading blocks of 128 (written by build, read after the job is joined)
     std::future<int64_t> next_job;   // the sort of the NEXT chunk runs on a helper thread while this thread is inside the
     int64_t next_first = -1;         // (blocking) pageable copies of the current one
+    // (Sorting on the DEVICE instead, like a device-resident batch's chunks -- all offsets first, launch_regroup on a stream of its
+    // own two chunks ahead -- was measured and is no faster: 53.5 ms per 4 M mixed pairs against 53.7.  Either way the calling
+    // thread spends 42 of them inside its blocking input copies, 1.6 GB at 38 GB/s beside the result traffic.)
     if (uniform == GEOM_MIXED && auto_group_on && n >= 1024 && range_t * range_q <= (1ll << 20)) {
         const size_t cells_n = (size_t)(range_t * range_q);
         grid_pos.resize(cells_n);
@@ -1362,7 +1430,10 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
                         static_cast<char *>(ctx->d_cig.p), cigar_stride, static_cast<int32_t *>(ctx->d_len.p),
                         static_cast<int32_t *>(ctx->d_status.p), cells, uniform, false, &hooks);
     if (next_job.valid()) next_job.wait();
+    const int res_rc = join_results(); // (the helper jobs hold references to nothing of this frame, but their copies must have landed)
+    if (rc == MGL_SW_OK && res_rc != MGL_SW_OK) rc = fail(ctx, MGL_SW_ERR_DEVICE, "mgl_sw_align_batch: copying results out failed");
     if (rc != MGL_SW_OK) {
+        if (ctx->d2h) (void)hipStreamSynchronize(ctx->d2h);
         (void)hipStreamSynchronize(ctx->h2d);
         (void)hipStreamSynchronize(ctx->aux);
         (void)hipStreamSynchronize(st);
