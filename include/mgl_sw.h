@@ -120,7 +120,7 @@ int mgl_sw_ctx_set_cooperative(mgl_sw_ctx *ctx, int mode);
  * scoring parameters fit its static 16-bit window and enough of its strip slots would be busy; 1 = never; 2 = whenever
  * eligible, whatever the lengths (tests; identical results) */
 int mgl_sw_ctx_set_strip_kernel(mgl_sw_ctx *ctx, int mode);
-/* uniform batches whose scores fit 16 bits: which packed kernel runs.  0 (default) = by launch size: from 524 288 pairs on
+/* uniform batches whose scores fit 16 bits: which packed kernel runs.  0 (default) = by launch size: from 262 144 pairs on
  * the two-pairs-per-LANE kernel (sw_dp16_lane.hip: 128 pairs per wave, nothing shared between lanes), below that the
  * two-pairs-per-lane-of-a-16-lane-group kernel (sw_dp16.hip: eight pairs per wave); 1 = never the lane kernel;
  * 2 = the lane kernel whenever the batch is eligible (tests; results are identical) */

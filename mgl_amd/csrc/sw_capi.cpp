@@ -177,9 +177,10 @@ int pick_waves_per_block(int sps_cap, int rows, int extra = 0)
 // queries from this length on run one pair per wave (64-row stripes): the pipeline fill/drain is then
 // 63/(ql+64) <= 6 %, and a batch needs four times fewer pairs to occupy the machine
 constexpr int kRows64MinQuery = 1024;
-// uniform batches (launches) from this size on take the two-pairs-per-lane kernel: 4 096 waves of 128 pairs, a good round
-// of the chip (measured crossover with the eight-pairs-per-wave kernel at 256 x 150: scripts/kernel_crossover.py)
-constexpr int64_t kLaneMinPairs = 128 * 4096;
+// uniform batches (launches) from this size on take the two-pairs-per-lane kernel: 2 048 waves of 128 pairs (measured crossover
+// with the eight-pairs-per-wave kernel at 256 x 150, scripts/kernel_crossover.py: 131 072 pairs 2 424 against 2 751 GCUPS,
+// 262 144 pairs 3 057 against 2 942, 524 288 pairs 3 092 against 2 824; with the flags of every cell stored it crossed at 524 288)
+constexpr int64_t kLaneMinPairs = 128 * 2048;
 
 int max_lds_query_len()
 {
@@ -279,7 +280,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const int64_t lane_launch = std::min<int64_t>(lane_rounds ? n : hooks ? std::max<int64_t>(n / host_chunks_l, (int64_t)256 * 1024) : n,
                                                   std::min<int64_t>(n, ctx->ws_limit / (lane_tb_words(max_tl, max_ql, lane_rows) * 4 / 128 + 1)));
     const bool use_lane = geom == GEOM_UNIFORM && ctx->precision != 32 && !d_matrix && match > 0 && ctx->lane_kernel != 1 &&
-                          (ctx->lane_kernel == 2 || lane_launch >= kLaneMinPairs) && lane16_supported(tset, qset) &&
+                          (ctx->lane_kernel == 2 || lane_launch >= (hooks ? 2 * kLaneMinPairs : kLaneMinPairs)) && lane16_supported(tset, qset) && // (the host entry's chunks: as measured before)
                           dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
     // a batch of mixed geometries whose chunks the host entry sorts by geometry (hooks->regroup): full blocks of eight pairs
     // with one geometry go through the packed kernel, the few left over through the int32 kernel, results land in the
