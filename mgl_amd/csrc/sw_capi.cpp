@@ -690,7 +690,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             const Part &pt = parts[i];
             TbArgs walk = tas[i];
             if (!fused_walk && !das[i].grouped) walk.cigar = nullptr; // (the waves of a sorted chunk's lane part walk their own paths too)
-            HIP_TRY(ctx, pt.lane ? (lane_ck || das[i].grouped ? launch_dp16_lane_ck(das[i], walk, fs) : launch_dp16_lane(das[i], walk, pt.rows, fs))
+            HIP_TRY(ctx, pt.lane ? (lane_ck || das[i].grouped ? launch_dp16_lane_ck(das[i], walk, fs, ctx->n_cus) : launch_dp16_lane(das[i], walk, pt.rows, fs))
                          : pt.packed ? launch_dp16(das[i], pt.wpb, fs)
                          : strip16 ? launch_dp16_strip(das[i], strip_waves, pt.rows, fs)
                          : coop16 ? launch_dp_coop16(das[i], coop_waves, fs) : coop_waves ? launch_dp_coop(das[i], coop_waves, fs) : launch_dp(das[i], pt.wpb, pt.rows, fs));
