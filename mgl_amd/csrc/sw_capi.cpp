@@ -383,10 +383,9 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "scores of this geometry and these parameters leave the 32-bit range");
     // the lane kernel without stored flags (sw_dp16_lane_ck.hip): its walk recomputes the blocks the path crosses; strips of 32 rows,
     // fused walk only (a caller who wants the matrix itself -- mgl_sw_ctx_expand_slot -- switches it off)
-    static const int lane_ck_env = [] { const char *e = getenv("MGL_SW_LANE_CK"); return e ? atoi(e) : -1; }();
-    static const bool lane_fuse_on = [] { const char *e = getenv("MGL_SW_LANE_FUSE"); return !e || atoi(e) != 0; }();
-    const bool lane_ck = use_lane && rows == 32 && !score_only && lane_fuse_on && d_cigar != nullptr && ctx->lane_checkpoint != 1 &&
-                         (ctx->lane_checkpoint == 2 || lane_ck_env != 0);
+    static const bool lane_fuse = [] { const char *e = getenv("MGL_SW_LANE_FUSE"); return !e || atoi(e) != 0; }();
+    const bool lane_ck = use_lane && rows == 32 && !score_only && lane_fuse && d_cigar != nullptr && ctx->lane_checkpoint != 1 &&
+                         (ctx->lane_checkpoint == 2 || lane_ck_on);
     // traceback words per pair (int32 layout) or per group of two pairs (packed16 layout)
     // (packed layout: the step count of a pair is not monotone in tl or ql -- a partial last stripe runs stand-alone, short
     // queries are not chained -- so a grouped batch, whose waves each run their own geometry, is sized by a bound that is)
@@ -410,7 +409,6 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const int64_t gran = use_lane ? 128 : use16 ? 8 : (rows == 64 || strip16) ? 1 : 4;
     // lane kernel: every lane walks the paths of its own two pairs at the end of its fill -- no traceback kernel, nothing
     // to overlap, so the whole workspace is one buffer and the chunks are twice as large
-    static const bool lane_fuse = [] { const char *e = getenv("MGL_SW_LANE_FUSE"); return !e || atoi(e) != 0; }();
     const bool fused_walk = use_lane && !score_only && lane_fuse;
     // ... except behind the host-buffer entry, whose chunks are the units of its copy pipeline anyway: there consecutive chunks
     // alternate between two streams and two halves, so that the last waves of one launch (the launch's tail, 1-2 ms of a
@@ -690,7 +688,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             const Part &pt = parts[i];
             TbArgs walk = tas[i];
             if (!fused_walk && !das[i].grouped) walk.cigar = nullptr; // (the waves of a sorted chunk's lane part walk their own paths too)
-            HIP_TRY(ctx, pt.lane ? (lane_ck || das[i].grouped ? launch_dp16_lane_ck(das[i], walk, fs, ctx->n_cus) : launch_dp16_lane(das[i], walk, pt.rows, fs))
+            HIP_TRY(ctx, pt.lane ? (lane_ck || das[i].grouped ? launch_dp16_lane_ck(das[i], walk, fs) : launch_dp16_lane(das[i], walk, pt.rows, fs))
                          : pt.packed ? launch_dp16(das[i], pt.wpb, fs)
                          : strip16 ? launch_dp16_strip(das[i], strip_waves, pt.rows, fs)
                          : coop16 ? launch_dp_coop16(das[i], coop_waves, fs) : coop_waves ? launch_dp_coop(das[i], coop_waves, fs) : launch_dp(das[i], pt.wpb, pt.rows, fs));

@@ -169,7 +169,7 @@ bool lane16_supported(const SeqSet &t, const SeqSet &q);
 struct TbArgs;
 // a.scratch = per-wave scratch, a.tb_stride_words per wave; walk.cigar != null: every lane also walks the paths of its two pairs
 hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &walk, int rows, hipStream_t stream);
-hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &walk, hipStream_t stream, int n_cus); // a.tb_stride_words = lane_ck_words per wave; walk.cigar != null
+hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &walk, hipStream_t stream); // a.tb_stride_words = lane_ck_words per wave; walk.cigar != null
 hipError_t launch_dp(const DpArgs &a, int waves_per_block, int rows, hipStream_t stream);
 int coop_lds_bytes(int sps_cap, int waves_per_block);
 hipError_t launch_dp_coop(const DpArgs &a, int waves_per_block, hipStream_t stream);

@@ -611,13 +611,12 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
 __global__ __launch_bounds__(256, 3) void sw_dp16_lane_ck_kernel_w3(const DpArgs a, const TbArgs walk) { sw_dp16_lane_ck_body(a, walk); }
 __global__ __launch_bounds__(256, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, const TbArgs walk) { sw_dp16_lane_ck_body(a, walk); }
 
-hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &walk, hipStream_t stream, int n_cus)
+hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &walk, hipStream_t stream)
 {
     const int waves_per_block = 4;
     const int64_t waves = ((a.count + 1) / 2 + 63) / 64;
     const dim3 grid((unsigned)((waves + waves_per_block - 1) / waves_per_block)), block(64 * waves_per_block);
     static const int wps_env = [] { const char *e = getenv("MGL_SW_LANE_CK_WPS"); return e ? atoi(e) : 0; }();
-    (void)n_cus;
     // (long targets -- many strips per wave, the walk a small share -- run 2 % faster with three: 1000 x 150, 2.56 M pairs, 77.8 ms
     // against 79.4)
     const bool two = wps_env ? wps_env == 2 : a.uni_tl < 512;

@@ -108,7 +108,7 @@ hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &w, int, hipStream_t)
     if (w.cigar) walk(w, false);
     return hipSuccess;
 }
-hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &w, hipStream_t, int)
+hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &w, hipStream_t)
 {
     remember(a);
     if (w.cigar) walk(w, false);
