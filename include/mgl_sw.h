@@ -352,7 +352,9 @@ int mgl_sw_band_fill(const int32_t *target, int target_length, const int32_t *qu
  * Same expansion for pair `slot` of the LAST chunk a batch call processed on ctx
  * (slot = pair index when the whole batch fitted one chunk).  The traceback
  * workspace is only valid until the next call on ctx.  tl / ql must be that
- * pair's lengths.  Parity / debugging entry.
+ * pair's lengths.  Parity / debugging entry.  MGL_SW_ERR_UNSUPPORTED when the last call ran the
+ * checkpointed lane kernel, which stores no traceback (large uniform batches by default:
+ * mgl_sw_ctx_set_lane_checkpoint(ctx, 1) before the batch call keeps the flags of every cell).
  */
 int mgl_sw_ctx_expand_slot(mgl_sw_ctx *ctx, int64_t slot, int tl, int ql, int32_t *btr);
 /* Traceback layout pair `slot` of the last chunk was filled in: 0 = an int32 kernel, 1 = sw_dp16_kernel, 2 =
