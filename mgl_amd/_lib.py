@@ -57,7 +57,7 @@ def _sources_newer():
 def build(force=False):
     """Compile csrc/ for gfx950 into mgl_amd/libmgl_sw_hip.so (hipcc cross-compiles without a GPU)."""
     if force or _sources_newer():
-        subprocess.check_call(["make", "-s", "-C", CSRC] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-s", "-j8", "-C", CSRC] + (["-B"] if force else []))
     return LIB_PATH
 
 

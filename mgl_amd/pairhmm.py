@@ -47,7 +47,7 @@ def lib():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        subprocess.check_call(["make", "-s", "-C", CSRC])
+        subprocess.check_call(["make", "-s", "-j8", "-C", CSRC])
     L = C.CDLL(LIB_PATH, mode=os.RTLD_NOW)
     vp = C.c_void_p
     L.mgl_pairhmm_strerror.restype = C.c_char_p
