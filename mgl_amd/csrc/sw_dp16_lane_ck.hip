@@ -139,12 +139,25 @@ __device__ __forceinline__ void ck_strip(const int i0, const int tl, const int q
             ckrec += 512;
         }
     };
+    // The carry row and the query are read ONE GROUP OF FOUR COLUMNS AHEAD: what a group needs was requested at the top of the
+    // group before it, so its latency -- and the acknowledgements of the stores issued in between, which s_waitcnt vmcnt counts
+    // in the same queue -- hides behind 1 150 instructions of arithmetic instead of stalling the wave at every group (measured
+    // before: a third of the waves' lifetime in s_waitcnt at two waves per SIMD).  Reads past column ql stay inside the wave's own
+    // scratch (the staged sequences follow the carry row) and are never used.
     int j = 1;
+    uint2 n0 = bp[0], n1 = bp[64], n2 = bp[128], n3 = bp[192];
+    unsigned nqa = qst[0], nqb = qst[64];
     for (; j + 3 <= ql; j += 4) {
         if (((j - 1) & (CK - 1)) == 0) save();
-        const uint2 top0 = bp[0], top1 = bp[64], top2 = bp[128], top3 = bp[192];
-        const unsigned qa = qst[0], qb = qst[64];
+        const uint2 top0 = n0, top1 = n1, top2 = n2, top3 = n3;
+        const unsigned qa = nqa, qb = nqb;
         qst += 128;
+        n0 = bp[256];
+        n1 = bp[320];
+        n2 = bp[384];
+        n3 = bp[448];
+        nqa = qst[0];
+        nqb = qst[64];
         const int c0 = (j - 1) & 4;
         one_column(top0, __builtin_amdgcn_perm(qb, qa, 0x0c040c00u), c0);
         one_column(top1, __builtin_amdgcn_perm(qb, qa, 0x0c050c01u), c0 + 1);
@@ -157,13 +170,10 @@ __device__ __forceinline__ void ck_strip(const int i0, const int tl, const int q
     }
     if (j <= ql) { // the last one to three columns (j - 1 is a multiple of four here)
         if (((j - 1) & (CK - 1)) == 0) save();
-        const unsigned qa = qst[0], qb = qst[64];
-        unsigned sel = 0x0c040c00u;
-        for (; j <= ql; ++j) {
-            const uint2 top = bp[0];
-            one_column(top, __builtin_amdgcn_perm(qb, qa, sel), (j - 1) & 7);
-            sel += 0x00010001u;
-        }
+        const int c0 = (j - 1) & 4;
+        one_column(n0, __builtin_amdgcn_perm(nqb, nqa, 0x0c040c00u), c0);
+        if (j + 1 <= ql) one_column(n1, __builtin_amdgcn_perm(nqb, nqa, 0x0c050c01u), c0 + 1);
+        if (j + 2 <= ql) one_column(n2, __builtin_amdgcn_perm(nqb, nqa, 0x0c060c02u), c0 + 2);
     }
     if (ql & 7) stage_flush(stage, rowrec, lane); // a last group of fewer than eight columns
     // last column (sw.cpp:100-104), as in sw_dp16_lane.hip
@@ -320,6 +330,51 @@ struct PathWalk {
         pj = J;
         done = !(I > 0 && J > 0); // sw.cpp:214
         return !done && ((pi - 1) >> 4) == k && (pj - 1) / CK == b;
+    }
+    // ---- cells that need no flags.  H[i][j] <= H[i-1][j-1] + match holds in every cell (by induction over the recurrence of
+    // sw.cpp:51-93: the diagonal candidate adds at most match; a vertical gap of length k into (i, j) starts from H[i-k][j] <=
+    // H[i-k-1][j-1] + match, and the same gap from (i-k-1, j-1) into (i-1, j-1) bounds H[i-1][j-1] from below by H[i-k-1][j-1] - o -
+    // (k-1) e; likewise horizontally; the border rows and columns of sw.cpp:29-40 satisfy it when gap open >= gap extend, which the
+    // caller checks).  So wherever the two bases are EQUAL the diagonal candidate reaches the bound, nothing beats it, and sw.cpp:60-62
+    // records btr = 0: the walk takes a diagonal step there whatever the scores are.  A walk standing at a cell (mode 0) therefore
+    // runs up its diagonal by comparing bases alone and needs a block's flags only at the first cell whose bases differ.
+    // One round looks at SCAN bases of both sequences (their staged copies: [4-base block][A | B][lane] dwords).
+    static constexpr int SCAN = 32;
+    __device__ __forceinline__ bool can_scan() const { return !done && mode == 0; }
+    __device__ __forceinline__ void scan_load(const unsigned *tst, const unsigned *qst, int half, int tblocks, int qblocks, unsigned (&tw)[SCAN / 4 + 1],
+                                              unsigned (&qw)[SCAN / 4 + 1]) const
+    {
+        const int dt = (I - SCAN) >> 2, dq = (J - SCAN) >> 2; // bases I - SCAN .. I - 1 (0-based) of the target, J - SCAN .. J - 1 of the query
+#pragma unroll
+        for (int k = 0; k <= SCAN / 4; ++k) { // (blocks before the sequence: block 0 again, masked by min(I, J) in scan_apply)
+            tw[k] = tst[(size_t)(2 * min(max(dt + k, 0), tblocks - 1) + half) * 64];
+            qw[k] = qst[(size_t)(2 * min(max(dq + k, 0), qblocks - 1) + half) * 64];
+        }
+    }
+    // returns true when all SCAN bases were equal and the walk goes on: another round
+    __device__ __forceinline__ bool scan_apply(const unsigned (&tw)[SCAN / 4 + 1], const unsigned (&qw)[SCAN / 4 + 1])
+    {
+        if (!can_scan()) return false;
+        const unsigned st = (unsigned)(I - SCAN) & 3u, sq = (unsigned)(J - SCAN) & 3u;
+        int cnt = 0;
+        bool run = true;
+#pragma unroll
+        for (int k = SCAN / 4 - 1; k >= 0; --k) {
+            const unsigned x = __builtin_amdgcn_alignbyte(tw[k + 1], tw[k], st) ^ __builtin_amdgcn_alignbyte(qw[k + 1], qw[k], sq);
+            const int z = __clz((int)x) >> 3; // equal bases from the top of the dword: 4 when all are
+            cnt += run ? z : 0;
+            run = run && z == 4;
+        }
+        cnt = min(cnt, min(I, J));
+        if (cnt > 0) {
+            take('M', cnt);
+            I -= cnt;
+            J -= cnt;
+        }
+        pi = I;
+        pj = J;
+        done = !(I > 0 && J > 0); // sw.cpp:214
+        return cnt == SCAN && !done;
     }
     // overhangs, text, per-pair results (walk_and_write's tail + traceback_one_pair)
     __device__ __forceinline__ void finish(const TbArgs &a, const DpRecord &r, int64_t o)
@@ -583,7 +638,20 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
     geom.base = base;
     geom.indel = indel;
     const uint32_t *const blk_words = reinterpret_cast<const uint32_t *>(blk);
+    // (gap open < gap extend: the border column can break the bound PathWalk's base comparison rests on -- flags for every cell then)
+    const bool by_bases = gopen >= gext;
+    const int tblocks = strips * (R / 4), qblocks = (ql + 3) >> 2;
     while (__builtin_amdgcn_ballot_w64(!wa.done || !wb.done) != 0) {
+        if (by_bases) {
+            for (;;) { // every walk standing at a cell runs up its diagonal as far as the bases are equal
+                unsigned ta[PathWalk::SCAN / 4 + 1], qa[PathWalk::SCAN / 4 + 1], tb[PathWalk::SCAN / 4 + 1], qb[PathWalk::SCAN / 4 + 1];
+                if (wa.can_scan()) wa.scan_load(tst, qst, 0, tblocks, qblocks, ta, qa);
+                if (wb.can_scan()) wb.scan_load(tst, qst, 1, tblocks, qblocks, tb, qb);
+                const bool ma = wa.scan_apply(ta, qa), mb = wb.scan_apply(tb, qb);
+                if (!__builtin_amdgcn_ballot_w64(ma || mb)) break;
+            }
+            if (__builtin_amdgcn_ballot_w64(!wa.done || !wb.done) == 0) break;
+        }
         // (a finished walk keeps recomputing some valid block: both halves run the same instructions anyway)
         const int kA = max(wa.pi - 1, 0) >> 4, bA = max(wa.pj - 1, 0) / CK, kB = max(wb.pi - 1, 0) >> 4, bB = max(wb.pj - 1, 0) / CK;
         ck_block(kA, bA, kB, bB, geom, rowrec + (size_t)lane * 8, ckrec + (size_t)lane * 8, qst, tst, blk, c);
