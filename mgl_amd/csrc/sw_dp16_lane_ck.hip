@@ -36,11 +36,32 @@
 // sw_dp16_lane.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "sw_device.h"
 #include "sw_lane_cell.h"
 #include "sw_traceback.h"
+
+// Timing-only experiment builds (scripts/build_variant.sh; results are WRONG with bits 1, 2, 4 or 16): parts of the kernel switched off
+#ifndef MGL_CK_ABLATE
+#define MGL_CK_ABLATE 0
+#endif
+
+// -DMGL_CK_PHASES (scripts/build_variant.sh): every wave adds the shader-clock ticks it spent in each part of the kernel to a
+// device array; mgl_ck_phases_dump() (exported by that build only) prints and clears it
+#ifdef MGL_CK_PHASES
+__device__ unsigned long long mgl_ck_phase_ticks[16];
+#define CK_PHASE(k)                                                                                    \
+    do {                                                                                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                  \
+        if (lane == 0) atomicAdd(&mgl_ck_phase_ticks[k], now_ - phase_t0);                             \
+        phase_t0 = __builtin_amdgcn_s_memtime();                                                       \
+    } while (0)
+#else
+#define CK_PHASE(k) do { } while (0)
+#endif
 
 namespace mgl_sw_dev {
 
@@ -148,7 +169,7 @@ __device__ __forceinline__ void ck_strip(const int i0, const int tl, const int q
     uint2 n0 = bp[0], n1 = bp[64], n2 = bp[128], n3 = bp[192];
     unsigned nqa = qst[0], nqb = qst[64];
     for (; j + 3 <= ql; j += 4) {
-        if (((j - 1) & (CK - 1)) == 0) save();
+        if (!(MGL_CK_ABLATE & 2) && ((j - 1) & (CK - 1)) == 0) save();
         const uint2 top0 = n0, top1 = n1, top2 = n2, top3 = n3;
         const unsigned qa = nqa, qb = nqb;
         qst += 128;
@@ -163,7 +184,7 @@ __device__ __forceinline__ void ck_strip(const int i0, const int tl, const int q
         one_column(top1, __builtin_amdgcn_perm(qb, qa, 0x0c050c01u), c0 + 1);
         one_column(top2, __builtin_amdgcn_perm(qb, qa, 0x0c060c02u), c0 + 2);
         one_column(top3, __builtin_amdgcn_perm(qb, qa, 0x0c070c03u), c0 + 3);
-        if (c0) { // columns 8 g + 1 .. 8 g + 8 are staged
+        if (!(MGL_CK_ABLATE & 4) && c0) { // columns 8 g + 1 .. 8 g + 8 are staged
             stage_flush(stage, rowrec, lane);
             rowrec += 512;
         }
@@ -195,14 +216,22 @@ __device__ __forceinline__ void ck_strip(const int i0, const int tl, const int q
     }
 }
 
+// what pass 2 needs to know about the wave's geometry and scoring
+struct BlockGeom {
+    int ql, nb, ng8, match, mismatch, gopen, gext, base;
+    bool indel;
+};
+
 // ---- pass 2: the walk of one pair (calculateCigar, sw.cpp:149-255) as a machine that can stop at a block's edge and go on in
 // the next block.  (pi, pj) is the cell whose flags it needs next: the current cell, or the cell a gap run is counting through
 // (TbView::vrun / hrun taken apart).
 struct PathWalk {
     int I, J, pi, pj, n, seg;
+    int hc;     // mode 0: H[I][J], the score of the cell the walk stands at
     int mode;   // 0: at a cell; 1: counting a vertical run (sw.cpp:73-82); 2: a horizontal one (sw.cpp:84-93)
     char state;
     bool done;
+    bool stuck; // the stretch above (I, J) does not add up: the walk needs this block's flags
     CigarWriter cw;
 
     __device__ __forceinline__ void take(char next, int step)
@@ -215,7 +244,8 @@ struct PathWalk {
             state = next;
         }
     }
-    __device__ __forceinline__ void start(const TbArgs &a, const DpRecord &r, int64_t o, int tl, int ql, bool ok)
+    // h_corner: H[tl][ql], where the walk of SW_OS_INDEL starts
+    __device__ __forceinline__ void start(const TbArgs &a, const DpRecord &r, int64_t o, int tl, int ql, bool ok, int h_corner)
     {
         cw.slot = a.cigar + (size_t)o * a.cigar_stride;
         cw.binary = a.binary_cigar;
@@ -226,15 +256,19 @@ struct PathWalk {
         if (a.strategy == OS_INDEL) { // sw.cpp:155-170
             I = tl;
             J = ql;
+            hc = h_corner;
         } else if (a.strategy != OS_LEAD_ID) {
             I = r.max_t;
             J = r.max_q;
             seg = r.seg;
+            hc = r.max;
         } else {
             I = r.mqe_t;
             J = ql;
+            hc = r.mqe;
         }
         done = !ok;
+        stuck = false;
         if (ok && seg > 0 && a.strategy == OS_SOFTCLIP) { // sw.cpp:173-176
             cw.push_front('S', seg);
             seg = 0;
@@ -267,7 +301,9 @@ struct PathWalk {
         }
     }
     // returns false when the walk cannot go on inside this block (finished, or the cell it needs next is in another block)
-    __device__ __forceinline__ bool apply(const unsigned (&w)[LOOK], int half, int k, int b)
+    // (tw, qw: win_load() of the cell the walk stands at -- mode 0 only: the scores of the diagonal steps it takes)
+    __device__ __forceinline__ bool apply(const unsigned (&w)[LOOK], const unsigned (&tw)[5], const unsigned (&qw)[5], int half, int k, int b,
+                                          const BlockGeom &g)
     {
         if (done) return false;
         if (mode == 1 && pi < 1) { // the run reached the matrix's top (TbView::vrun: r >= 1)
@@ -297,6 +333,7 @@ struct PathWalk {
             }
             if (mode == 0) {
                 if (cnt > 0) {
+                    hc -= cnt * g.match + mismatches(tw, qw, cnt) * (g.mismatch - g.match);
                     take('M', cnt);
                     I -= cnt;
                     J -= cnt;
@@ -314,6 +351,7 @@ struct PathWalk {
                 pi -= cnt;
                 if (cnt == LOOK && cnt <= room) return true; // more of the run in this block than one round looks at
                 if (cnt > room && pi >= 1) return false; // every cell up to the block's edge extends the gap: goes on in the block above
+                hc += g.gopen + (n - 1) * g.gext; // H[I][J] = E = H[I - n][J] - o - (n - 1) e (sw.cpp:73-82)
                 take('D', n);
                 I -= n;
             } else {
@@ -321,6 +359,7 @@ struct PathWalk {
                 pj -= cnt;
                 if (cnt == LOOK && cnt <= room) return true;
                 if (cnt > room && pj >= 1) return false;
+                hc += g.gopen + (n - 1) * g.gext; // sw.cpp:84-93
                 take('I', n);
                 J -= n;
             }
@@ -331,50 +370,73 @@ struct PathWalk {
         done = !(I > 0 && J > 0); // sw.cpp:214
         return !done && ((pi - 1) >> 4) == k && (pj - 1) / CK == b;
     }
-    // ---- cells that need no flags.  H[i][j] <= H[i-1][j-1] + match holds in every cell (by induction over the recurrence of
-    // sw.cpp:51-93: the diagonal candidate adds at most match; a vertical gap of length k into (i, j) starts from H[i-k][j] <=
-    // H[i-k-1][j-1] + match, and the same gap from (i-k-1, j-1) into (i-1, j-1) bounds H[i-1][j-1] from below by H[i-k-1][j-1] - o -
-    // (k-1) e; likewise horizontally; the border rows and columns of sw.cpp:29-40 satisfy it when gap open >= gap extend, which the
-    // caller checks).  So wherever the two bases are EQUAL the diagonal candidate reaches the bound, nothing beats it, and sw.cpp:60-62
-    // records btr = 0: the walk takes a diagonal step there whatever the scores are.  A walk standing at a cell (mode 0) therefore
-    // runs up its diagonal by comparing bases alone and needs a block's flags only at the first cell whose bases differ.
-    // One round looks at SCAN bases of both sequences (their staged copies: [4-base block][A | B][lane] dwords).
-    static constexpr int SCAN = 32;
-    __device__ __forceinline__ bool can_scan() const { return !done && mode == 0; }
-    __device__ __forceinline__ void scan_load(const unsigned *tst, const unsigned *qst, int half, int tblocks, int qblocks, unsigned (&tw)[SCAN / 4 + 1],
-                                              unsigned (&qw)[SCAN / 4 + 1]) const
+    // ---- cells that need no flags: a diagonal stretch whose scores add up.  Along any diagonal stretch c0, c1 .. cL the diagonal
+    // candidate of sw.cpp:51-55 gives H[ck] >= H[ck-1] + s(ck) (s = match or mismatch by the two bases); if H[cL] - H[c0] EQUALS
+    // the sum of the L substitution scores, every one of these inequalities is tight, so in every cell of the stretch the diagonal
+    // candidate is the maximum, sw.cpp:60-62 records btr = 0 (the diagonal wins ties), and the walk of sw.cpp:182-214 takes L
+    // diagonal steps -- whatever the stretch contains (substitutions included) and whatever the penalties are.  The walk knows H of
+    // the cell it stands at (hc: the start cell's score is in the record, a diagonal step subtracts s, a gap run of n adds
+    // o + (n-1) e: sw.cpp:73-93), pass 1 kept H of every 16th row (the carry-row records) and the borders are formulas, so one round
+    // checks the stretch from the walk's cell up to the next recorded row (or the matrix's edge) with one look at that row's H and
+    // at most 16 bases of both sequences (their staged copies: [4-base block][A | B][lane] dwords).  Only where the sum does NOT
+    // fit -- a gap, or a tie taken elsewhere -- does the walk need the flags of the block.
+    __device__ __forceinline__ bool can_verify() const { return !done && mode == 0 && !stuck; }
+    // bases I - 16 .. I - 1 (0-based) of the target and J - 16 .. J - 1 of the query: byte 15 of the window belongs to cell (I, J)
+    __device__ __forceinline__ void win_load(const unsigned *tst, const unsigned *qst, int half, int tblocks, int qblocks, unsigned (&tw)[5],
+                                             unsigned (&qw)[5]) const
     {
-        const int dt = (I - SCAN) >> 2, dq = (J - SCAN) >> 2; // bases I - SCAN .. I - 1 (0-based) of the target, J - SCAN .. J - 1 of the query
+        const int dt = (I - 16) >> 2, dq = (J - 16) >> 2;
 #pragma unroll
-        for (int k = 0; k <= SCAN / 4; ++k) { // (blocks before the sequence: block 0 again, masked by min(I, J) in scan_apply)
+        for (int k = 0; k < 5; ++k) { // (blocks before the sequence: block 0 again -- those bytes are never counted)
             tw[k] = tst[(size_t)(2 * min(max(dt + k, 0), tblocks - 1) + half) * 64];
             qw[k] = qst[(size_t)(2 * min(max(dq + k, 0), qblocks - 1) + half) * 64];
         }
     }
-    // returns true when all SCAN bases were equal and the walk goes on: another round
-    __device__ __forceinline__ bool scan_apply(const unsigned (&tw)[SCAN / 4 + 1], const unsigned (&qw)[SCAN / 4 + 1])
+    // how many of the cells (I, J), (I-1, J-1) .. (I-L+1, J-L+1) hold different bases (raw byte compare, sw.cpp:55); L <= 16, I, J
+    __device__ __forceinline__ int mismatches(const unsigned (&tw)[5], const unsigned (&qw)[5], int L) const
     {
-        if (!can_scan()) return false;
-        const unsigned st = (unsigned)(I - SCAN) & 3u, sq = (unsigned)(J - SCAN) & 3u;
-        int cnt = 0;
-        bool run = true;
+        const unsigned st = (unsigned)(I - 16) & 3u, sq = (unsigned)(J - 16) & 3u;
+        const int drop = 16 - L, dq = drop >> 2, sh = (drop & 3) * 8; // the window's low `drop` bytes are not part of the stretch
+        int n = 0;
 #pragma unroll
-        for (int k = SCAN / 4 - 1; k >= 0; --k) {
+        for (int k = 0; k < 4; ++k) {
             const unsigned x = __builtin_amdgcn_alignbyte(tw[k + 1], tw[k], st) ^ __builtin_amdgcn_alignbyte(qw[k + 1], qw[k], sq);
-            const int z = __clz((int)x) >> 3; // equal bases from the top of the dword: 4 when all are
-            cnt += run ? z : 0;
-            run = run && z == 4;
+            const unsigned nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; // bit 7 of every byte that is not zero
+            n += __popc(k > dq ? nz : k == dq ? nz >> sh : 0u);
         }
-        cnt = min(cnt, min(I, J));
-        if (cnt > 0) {
-            take('M', cnt);
-            I -= cnt;
-            J -= cnt;
+        return n;
+    }
+    // the end of the stretch: the next recorded row above (I - 1) / 16 * 16, or where the diagonal leaves the matrix
+    __device__ __forceinline__ int stretch() const { return min(I - (((I - 1) >> 4) << 4), J); }
+    // H of that row in stored form: strip s keeps row 32 s + 16 (mid) and row 32 s + 32 (bot); this lane's 32 dwords of a record are
+    // [pair][column of the group of eight][mid | bot] x {H : 16, E : 16}
+    __device__ __forceinline__ void grid_load(const uint4 *rowrec_lane, int half, int ng8, unsigned &w) const
+    {
+        const int L = stretch(), ie = I - L, je = J - L;
+        const int m = max(ie >> 4, 1), slot = (m - 1) >> 1, c = max(je - 1, 0); // (a stretch that ends on a border: some valid dword, not used)
+        w = reinterpret_cast<const unsigned *>(rowrec_lane + ((size_t)slot * ng8 + (c >> 3)) * 512)[half * 16 + (c & 7) * 2 + ((m & 1) ^ 1)];
+    }
+    // returns true when the stretch was taken and the walk can try the next one
+    __device__ __forceinline__ bool verify_apply(const unsigned (&tw)[5], const unsigned (&qw)[5], unsigned w, const BlockGeom &g)
+    {
+        if (!can_verify()) return false;
+        const int L = stretch(), ie = I - L, je = J - L;
+        const int he = ie == 0 ? border(je, g.gopen, g.gext, g.indel)
+                     : je == 0 ? border(ie, g.gopen, g.gext, g.indel)
+                               : lo16(w) - (ie + je) * g.gext - g.base;
+        const int sum = L * g.match + mismatches(tw, qw, L) * (g.mismatch - g.match);
+        if (hc - he != sum) {
+            stuck = true; // this block's flags, then
+            return false;
         }
+        take('M', L);
+        I = ie;
+        J = je;
+        hc = he;
         pi = I;
         pj = J;
         done = !(I > 0 && J > 0); // sw.cpp:214
-        return cnt == SCAN && !done;
+        return !done;
     }
     // overhangs, text, per-pair results (walk_and_write's tail + traceback_one_pair)
     __device__ __forceinline__ void finish(const TbArgs &a, const DpRecord &r, int64_t o)
@@ -416,10 +478,6 @@ struct PathWalk {
 
 // ---- pass 2: recompute the flags of block (sA, bA) for the low halves and of block (sB, bB) for the high halves; s = 16-row band
 // (strip s / 2, its upper or lower half), b = block of CK columns.  rowrec / ckrec: the wave's records + this lane's 8 uint4.
-struct BlockGeom {
-    int ql, nb, ng8, gopen, gext, base;
-    bool indel;
-};
 __device__ __forceinline__ void ck_block(const int sA, const int bA, const int sB, const int bB, const BlockGeom &g, const uint4 *rowrec,
                                          const uint4 *ckrec, const unsigned *qst, const unsigned *tst, uint4 *blk, const LaneConsts &c)
 {
@@ -511,6 +569,9 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t n_ls = (a.count + 1) >> 1;
     if (gw * 64 >= n_ls) return;
+#ifdef MGL_CK_PHASES
+    unsigned long long phase_t0 = __builtin_amdgcn_s_memtime();
+#endif
     const int64_t ls = gw * 64 + lane;
     const bool lvalid = ls < n_ls;
     const int64_t slotA = lvalid ? 2 * ls : a.count - 1;
@@ -554,22 +615,30 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
     unsigned *const stage = stage_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (64 * STAGE_ROW);
     {
         const int64_t pA = a.first + slotA, pB = a.first + slotB;
-        SeqWords sa, sb;
-        sa.init(a.q.data + a.q.off[pA], ql);
-        sb.init(a.q.data + a.q.off[pB], ql);
-        unsigned loA = sa.word(0), loB = sb.word(0);
-        for (int cb = 0; cb < (ql + 3) >> 2; ++cb) {
-            qst[(size_t)(2 * cb) * 64] = sa.next_block(cb, loA);
-            qst[(size_t)(2 * cb + 1) * 64] = sb.next_block(cb, loB);
-        }
-        sa.init(a.t.data + a.t.off[pA], tl);
-        sb.init(a.t.data + a.t.off[pB], tl);
-        loA = sa.word(0);
-        loB = sb.word(0);
-        for (int cb = 0; cb < strips * (R / 4); ++cb) {
-            tst[(size_t)(2 * cb) * 64] = sa.next_block(cb, loA);
-            tst[(size_t)(2 * cb + 1) * 64] = sb.next_block(cb, loB);
-        }
+        // eight blocks of both pairs per round: 18 loads in flight, then the stores (one block per round would expose a memory
+        // latency per block: a tenth of the wave's lifetime, measured)
+        auto stage = [&](const uint8_t *seqA, const uint8_t *seqB, int len, int nblocks, unsigned *dst) {
+            SeqWords sa, sb;
+            sa.init(seqA, len);
+            sb.init(seqB, len);
+            for (int cb = 0; cb < nblocks; cb += 8) {
+                unsigned wa[9], wb[9];
+#pragma unroll
+                for (int u = 0; u < 9; ++u) {
+                    wa[u] = sa.word(cb + u);
+                    wb[u] = sb.word(cb + u);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (cb + u < nblocks) { // (blocks past the end of a target repeat its last dword: rows > tl, never read)
+                        dst[(size_t)(2 * (cb + u)) * 64] = __builtin_amdgcn_alignbyte(wa[u + 1], wa[u], sa.shift);
+                        dst[(size_t)(2 * (cb + u) + 1) * 64] = __builtin_amdgcn_alignbyte(wb[u + 1], wb[u], sb.shift);
+                    }
+                }
+            }
+        };
+        stage(a.q.data + a.q.off[pA], a.q.data + a.q.off[pB], ql, (ql + 3) >> 2, qst);
+        stage(a.t.data + a.t.off[pA], a.t.data + a.t.off[pB], tl, strips * (R / 4), tst);
         // row 0 (the border row, sw.cpp:14-18,31-35) in stored form: H[0][j], E[1][j] = H[0][j] - o
         for (int j = 0; j <= ql; ++j) {
             const int hb0 = border(j, gopen, gext, indel) + j * gext + base;
@@ -578,6 +647,7 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
         }
     }
 
+    CK_PHASE(0); // staging
     // ---- pass 1
     int bestA = NEG_INF, bestA_i = -1, bestB = NEG_INF, bestB_i = -1;
     for (int k = 0; k < strips - 1; ++k)
@@ -586,22 +656,35 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
     ck_strip<true>((strips - 1) * R, tl, ql, bnd, stage, rowrec + (size_t)(strips - 1) * ng8 * 512, ckrec + (size_t)(strips - 1) * nb * 2 * 512, lane, qst, tst,
                    c, gopen, gext, base, indel, bestA, bestA_i, bestB, bestB_i);
 
+    CK_PHASE(1); // pass 1
     // ---- last row (sw.cpp:116-127), as in sw_dp16_lane.hip
     int rmA = NEG_INF, rdA = 0x7fffffff, rjA = 0x7fffffff, rmB = NEG_INF, rdB = 0x7fffffff, rjB = 0x7fffffff;
+    int cornerA = 0, cornerB = 0; // H[tl][ql]
     {
-        for (int j = 1; j <= ql; ++j) {
-            const unsigned bot = bnd[(size_t)j * 64].x;
-            const int unshift = -(tl + j) * gext - base;
-            const int d = abs(tl - j);
-            const int sa = lo16(bot) + unshift, sb = hi16(bot) + unshift;
-            const bool ta_ = sa > rmA || (sa == rmA && d < rdA);
-            rmA = ta_ ? sa : rmA;
-            rdA = ta_ ? d : rdA;
-            rjA = ta_ ? j : rjA;
-            const bool tb_ = sb > rmB || (sb == rmB && d < rdB);
-            rmB = tb_ ? sb : rmB;
-            rdB = tb_ ? d : rdB;
-            rjB = tb_ ? j : rjB;
+        for (int j0 = 1; j0 <= ql; j0 += 8) { // eight columns' loads at once
+            unsigned bots[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bots[u] = bnd[(size_t)min(j0 + u, ql) * 64].x;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                if (j <= ql) {
+                    const unsigned bot = bots[u];
+                    const int unshift = -(tl + j) * gext - base;
+                    const int d = abs(tl - j);
+                    const int sa = lo16(bot) + unshift, sb = hi16(bot) + unshift;
+                    const bool ta_ = sa > rmA || (sa == rmA && d < rdA);
+                    rmA = ta_ ? sa : rmA;
+                    rdA = ta_ ? d : rdA;
+                    rjA = ta_ ? j : rjA;
+                    const bool tb_ = sb > rmB || (sb == rmB && d < rdB);
+                    rmB = tb_ ? sb : rmB;
+                    rdB = tb_ ? d : rdB;
+                    rjB = tb_ ? j : rjB;
+                    cornerA = sa; // (the last one stays: H[tl][ql])
+                    cornerB = sb;
+                }
+            }
         }
     }
     DpRecord rec[2];
@@ -622,52 +705,79 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
         if (half ? validB : lvalid) a.rec[half ? slotB : slotA] = r;
     }
 
+    CK_PHASE(2); // last row, records
     // ---- pass 2
     const int64_t pA = a.first + slotA, pB = a.first + slotB;
     const int64_t oA = walk.dest ? walk.dest[pA] : pA, oB = walk.dest ? walk.dest[pB] : pB;
     PathWalk wa, wb;
-    wa.start(walk, rec[0], oA, tl, ql, lvalid);
-    wb.start(walk, rec[1], oB, tl, ql, validB);
+    wa.start(walk, rec[0], oA, tl, ql, lvalid, cornerA);
+    wb.start(walk, rec[1], oB, tl, ql, validB, cornerB);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the wave's records are in memory (written by other lanes of this wave)
     BlockGeom geom;
     geom.ql = ql;
     geom.nb = nb;
     geom.ng8 = ng8;
+    geom.match = match;
+    geom.mismatch = a.mismatch;
     geom.gopen = gopen;
     geom.gext = gext;
     geom.base = base;
     geom.indel = indel;
     const uint32_t *const blk_words = reinterpret_cast<const uint32_t *>(blk);
-    // (gap open < gap extend: the border column can break the bound PathWalk's base comparison rests on -- flags for every cell then)
-    const bool by_bases = gopen >= gext;
+    const bool by_score = !(MGL_CK_ABLATE & 8);
     const int tblocks = strips * (R / 4), qblocks = (ql + 3) >> 2;
-    while (__builtin_amdgcn_ballot_w64(!wa.done || !wb.done) != 0) {
-        if (by_bases) {
-            for (;;) { // every walk standing at a cell runs up its diagonal as far as the bases are equal
-                unsigned ta[PathWalk::SCAN / 4 + 1], qa[PathWalk::SCAN / 4 + 1], tb[PathWalk::SCAN / 4 + 1], qb[PathWalk::SCAN / 4 + 1];
-                if (wa.can_scan()) wa.scan_load(tst, qst, 0, tblocks, qblocks, ta, qa);
-                if (wb.can_scan()) wb.scan_load(tst, qst, 1, tblocks, qblocks, tb, qb);
-                const bool ma = wa.scan_apply(ta, qa), mb = wb.scan_apply(tb, qb);
+    const uint4 *const rowrec_lane = rowrec + (size_t)lane * 8, *const ckrec_lane = ckrec + (size_t)lane * 8;
+    while (!(MGL_CK_ABLATE & 1) && __builtin_amdgcn_ballot_w64(!wa.done || !wb.done) != 0) {
+        if (by_score) {
+            for (;;) { // every walk standing at a cell takes the diagonal stretches whose scores add up (PathWalk::verify_apply)
+                unsigned ta[5], qa[5], tb[5], qb[5], ga = 0, gb = 0;
+                if (wa.can_verify()) {
+                    wa.win_load(tst, qst, 0, tblocks, qblocks, ta, qa);
+                    wa.grid_load(rowrec_lane, 0, ng8, ga);
+                }
+                if (wb.can_verify()) {
+                    wb.win_load(tst, qst, 1, tblocks, qblocks, tb, qb);
+                    wb.grid_load(rowrec_lane, 1, ng8, gb);
+                }
+                const bool ma = wa.verify_apply(ta, qa, ga, geom), mb = wb.verify_apply(tb, qb, gb, geom);
                 if (!__builtin_amdgcn_ballot_w64(ma || mb)) break;
             }
+            CK_PHASE(3); // stretches that add up
             if (__builtin_amdgcn_ballot_w64(!wa.done || !wb.done) == 0) break;
         }
         // (a finished walk keeps recomputing some valid block: both halves run the same instructions anyway)
         const int kA = max(wa.pi - 1, 0) >> 4, bA = max(wa.pj - 1, 0) / CK, kB = max(wb.pi - 1, 0) >> 4, bB = max(wb.pj - 1, 0) / CK;
-        ck_block(kA, bA, kB, bB, geom, rowrec + (size_t)lane * 8, ckrec + (size_t)lane * 8, qst, tst, blk, c);
+        ck_block(kA, bA, kB, bB, geom, rowrec_lane, ckrec_lane, qst, tst, blk, c);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CK_PHASE(4); // a block's flags
+#ifdef MGL_CK_PHASES
+        if (lane == 0) atomicAdd(&mgl_ck_phase_ticks[8], 1ull);
+#endif
         for (;;) {
             const bool la = wa.can_load(kA, bA), lb = wb.can_load(kB, bB);
             // (a lane with nothing to fetch still runs apply(): a run that ends at the matrix's edge needs no flags)
-            unsigned fa[PathWalk::LOOK], fb[PathWalk::LOOK];
-            if (la) wa.load(blk_words, fa);
-            if (lb) wb.load(blk_words, fb);
-            const bool ga = wa.apply(fa, 0, kA, bA), gb = wb.apply(fb, 1, kB, bB);
+            unsigned fa[PathWalk::LOOK], fb[PathWalk::LOOK], ta[5], qa[5], tb[5], qb[5];
+            if (la) {
+                wa.load(blk_words, fa);
+                if (wa.mode == 0) wa.win_load(tst, qst, 0, tblocks, qblocks, ta, qa);
+            }
+            if (lb) {
+                wb.load(blk_words, fb);
+                if (wb.mode == 0) wb.win_load(tst, qst, 1, tblocks, qblocks, tb, qb);
+            }
+            const bool ga = wa.apply(fa, ta, qa, 0, kA, bA, geom), gb = wb.apply(fb, tb, qb, 1, kB, bB, geom);
             if (!__builtin_amdgcn_ballot_w64(ga || gb)) break;
         }
+        wa.stuck = wb.stuck = false; // either walk has moved on
+        CK_PHASE(5); // the walk inside the block
     }
+    CK_PHASE(6);
     if (lvalid) wa.finish(walk, rec[0], oA);
     if (validB) wb.finish(walk, rec[1], oB);
+    CK_PHASE(7); // overhangs, text, results
+#ifdef MGL_CK_PHASES
+    if (lane == 0) atomicAdd(&mgl_ck_phase_ticks[9], 1ull);
+#endif
 }
 
 } // namespace
@@ -696,3 +806,19 @@ hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &walk, hipStream_t 
 }
 
 } // namespace mgl_sw_dev
+
+#ifdef MGL_CK_PHASES
+extern "C" void mgl_ck_phases_dump()
+{
+    unsigned long long h[16] = {0};
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(mgl_ck_phase_ticks), sizeof h);
+    static const char *names[8] = {"staging", "pass 1", "last row + records", "stretches", "block flags", "walk in block", "(loop exit)", "finish"};
+    unsigned long long tot = 0;
+    for (int k = 0; k < 8; ++k) tot += h[k];
+    for (int k = 0; k < 8; ++k) fprintf(stderr, "phase %-20s %6.2f %%  %10.1f ticks per wave\n", names[k], 100.0 * h[k] / (double)tot, (double)h[k] / (double)h[9]);
+    fprintf(stderr, "waves %llu, block rounds per wave %.2f\n", h[9], (double)h[8] / (double)h[9]);
+    memset(h, 0, sizeof h);
+    hipMemcpyToSymbol(HIP_SYMBOL(mgl_ck_phase_ticks), h, sizeof h);
+}
+#endif
