@@ -279,8 +279,14 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const bool lane_rounds = hooks && n >= 4 * lane_round;
     const int64_t lane_launch = std::min<int64_t>(lane_rounds ? n : hooks ? std::max<int64_t>(n / host_chunks_l, (int64_t)256 * 1024) : n,
                                                   std::min<int64_t>(n, ctx->ws_limit / (lane_tb_words(max_tl, max_ql, lane_rows) * 4 / 128 + 1)));
+    // (its checkpointed form stages base codes and takes either wire format; the form that stores every flag reads ASCII only)
+    static const bool lane_fuse = [] { const char *e = getenv("MGL_SW_LANE_FUSE"); return !e || atoi(e) != 0; }();
+    static const bool lane_ck_on = [] { const char *e = getenv("MGL_SW_LANE_CK"); return !e || atoi(e) != 0; }();
+    const bool lane_ck_ok = lane_rows == 32 && lane_fuse && d_cigar != nullptr && ctx->lane_checkpoint != 1 && (ctx->lane_checkpoint == 2 || lane_ck_on);
+    const bool lane_ck_wanted = lane_ck_ok && !score_only_hint; // (a 2-bit batch gets the lane kernel only in this form)
     const bool use_lane = geom == GEOM_UNIFORM && ctx->precision != 32 && !d_matrix && match > 0 && ctx->lane_kernel != 1 &&
-                          (ctx->lane_kernel == 2 || lane_launch >= (hooks ? 2 * kLaneMinPairs : kLaneMinPairs)) && lane16_supported(tset, qset) && // (the host entry's chunks: as measured before)
+                          (ctx->lane_kernel == 2 || lane_launch >= (hooks ? 2 * kLaneMinPairs : kLaneMinPairs)) && // (the host entry's chunks: as measured before)
+                          (lane16_supported(tset, qset) || (lane_ck_wanted && lane16_ck_supported(tset, qset))) &&
                           dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
     // a batch of mixed geometries whose chunks the host entry sorts by geometry (hooks->regroup): full blocks of eight pairs
     // with one geometry go through the packed kernel, the few left over through the int32 kernel, results land in the
@@ -296,8 +302,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                             dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
     // ... of which the geometries with 128 pairs and more go, whole waves of one geometry each, through the checkpointed lane kernel
     static const bool lane_group_on = [] { const char *e = getenv("MGL_SW_LANE_GROUP"); return !e || atoi(e) != 0; }();
-    static const bool lane_ck_on = [] { const char *e = getenv("MGL_SW_LANE_CK"); return !e || atoi(e) != 0; }();
-    const bool lane_group = auto_group && lane_group_on && lane_ck_on && ctx->lane_checkpoint != 1 && ctx->lane_kernel != 1 && lane16_supported(tset, qset);
+    const bool lane_group = auto_group && lane_group_on && lane_ck_on && ctx->lane_checkpoint != 1 && ctx->lane_kernel != 1 && lane16_ck_supported(tset, qset);
     const int64_t lane_group_stride = lane_group ? lane_ck_words(max_tl, max_ql) : 0; // words per wave
     const bool use16 = (use16_eligible && !use_lane) || auto_group;
     // MGL_SW_FLAG_SCORE_ONLY is honoured by the packed kernels only; elsewhere the full path runs (a superset of the result)
@@ -383,9 +388,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "scores of this geometry and these parameters leave the 32-bit range");
     // the lane kernel without stored flags (sw_dp16_lane_ck.hip): its walk recomputes the blocks the path crosses; strips of 32 rows,
     // fused walk only (a caller who wants the matrix itself -- mgl_sw_ctx_expand_slot -- switches it off)
-    static const bool lane_fuse = [] { const char *e = getenv("MGL_SW_LANE_FUSE"); return !e || atoi(e) != 0; }();
-    const bool lane_ck = use_lane && rows == 32 && !score_only && lane_fuse && d_cigar != nullptr && ctx->lane_checkpoint != 1 &&
-                         (ctx->lane_checkpoint == 2 || lane_ck_on);
+    const bool lane_ck = use_lane && !score_only && lane_ck_ok;
     // traceback words per pair (int32 layout) or per group of two pairs (packed16 layout)
     // (packed layout: the step count of a pair is not monotone in tl or ql -- a partial last stripe runs stand-alone, short
     // queries are not chained -- so a grouped batch, whose waves each run their own geometry, is sized by a bound that is)

@@ -165,7 +165,8 @@ int dp_lds_bytes(int sps_cap, int waves_per_block, int rows);
 int dp16_lds_bytes(int sps, int waves_per_block);
 bool dp16_range_ok(int tl, int ql, int match, int mismatch, int gopen, int gext, int strategy);
 hipError_t launch_dp16(const DpArgs &a, int waves_per_block, hipStream_t stream);
-bool lane16_supported(const SeqSet &t, const SeqSet &q);
+bool lane16_supported(const SeqSet &t, const SeqSet &q);    // sw_dp16_lane_kernel (every flag stored): ASCII
+bool lane16_ck_supported(const SeqSet &t, const SeqSet &q); // sw_dp16_lane_ck_kernel: ASCII, or both sequence sets 2-bit packed
 struct TbArgs;
 // a.scratch = per-wave scratch, a.tb_stride_words per wave; walk.cigar != null: every lane also walks the paths of its two pairs
 hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &walk, int rows, hipStream_t stream);

@@ -89,7 +89,7 @@ __device__ __forceinline__ void stage_flush(const unsigned *stage, uint4 *rec, c
 }
 
 // ---- pass 1: one strip, score only, keeping the carry rows and the column checkpoints
-template <bool LAST>
+template <bool LAST, bool CODES>
 __device__ __forceinline__ void ck_strip(const int i0, const int tl, const int ql, uint2 *bnd, unsigned *stage, uint4 *rowrec, uint4 *ckrec,
                                          const int lane, const unsigned *qst, const unsigned *tst, const LaneConsts &c, const int gopen,
                                          const int gext, const int base, const bool indel, int &bestA, int &bestA_i, int &bestB, int &bestB_i)
@@ -98,10 +98,10 @@ __device__ __forceinline__ void ck_strip(const int i0, const int tl, const int q
 #pragma unroll
     for (int r4 = 0; r4 < R / 4; ++r4) {
         const unsigned ta = tst[(size_t)(2 * ((i0 >> 2) + r4)) * 64], tb = tst[(size_t)(2 * ((i0 >> 2) + r4) + 1) * 64];
-        t[4 * r4 + 0] = __builtin_amdgcn_perm(tb, ta, 0x0c040c00u);
-        t[4 * r4 + 1] = __builtin_amdgcn_perm(tb, ta, 0x0c050c01u);
-        t[4 * r4 + 2] = __builtin_amdgcn_perm(tb, ta, 0x0c060c02u);
-        t[4 * r4 + 3] = __builtin_amdgcn_perm(tb, ta, 0x0c070c03u);
+        t[4 * r4 + 0] = __builtin_amdgcn_perm(tb, ta, 0x0c040c00u) | (CODES ? CODE_SEL : 0u);
+        t[4 * r4 + 1] = __builtin_amdgcn_perm(tb, ta, 0x0c050c01u) | (CODES ? CODE_SEL : 0u);
+        t[4 * r4 + 2] = __builtin_amdgcn_perm(tb, ta, 0x0c060c02u) | (CODES ? CODE_SEL : 0u);
+        t[4 * r4 + 3] = __builtin_amdgcn_perm(tb, ta, 0x0c070c03u) | (CODES ? CODE_SEL : 0u);
     }
     // column 0 (sw.cpp:24,38,47-49), as in sw_dp16_lane.hip
 #pragma unroll
@@ -117,10 +117,14 @@ __device__ __forceinline__ void ck_strip(const int i0, const int tl, const int q
 
     unsigned *const my = stage + lane * STAGE_ROW; // this lane's 32 dwords: [A | B][column of the group of eight][mid | bot]
     uint2 *bp = bnd + 64;                          // column j of the time-major carry row
-    auto one_column = [&](const uint2 top, const unsigned q, const int cidx) {
+    // column u (0 .. 3) of the group whose query dwords are qa / qb
+    auto one_column = [&](const uint2 top, const unsigned qa, const unsigned qb, const int u, const int cidx) {
         unsigned e = top.y;
         uint2 mid;
-        column<R, true, true>(h, f, t, q, hd, e, c, nullptr, &mid);
+        if (CODES)
+            column<R, true, true, true>(h, f, t, code_table((qa >> (8 * u)) & 0xffu), hd, e, c, nullptr, &mid, code_table((qb >> (8 * u)) & 0xffu));
+        else
+            column<R, true, true, false>(h, f, t, __builtin_amdgcn_perm(qb, qa, 0x0c040c00u + 0x00010001u * u), hd, e, c, nullptr, &mid);
         hd = top.x;
         *reinterpret_cast<uint2 *>(my + 2 * cidx) = make_uint2(lows(mid.x, mid.y), lows(h[R - 1], e));
         *reinterpret_cast<uint2 *>(my + 16 + 2 * cidx) = make_uint2(highs(mid.x, mid.y), highs(h[R - 1], e));
@@ -180,10 +184,10 @@ __device__ __forceinline__ void ck_strip(const int i0, const int tl, const int q
         nqa = qst[0];
         nqb = qst[64];
         const int c0 = (j - 1) & 4;
-        one_column(top0, __builtin_amdgcn_perm(qb, qa, 0x0c040c00u), c0);
-        one_column(top1, __builtin_amdgcn_perm(qb, qa, 0x0c050c01u), c0 + 1);
-        one_column(top2, __builtin_amdgcn_perm(qb, qa, 0x0c060c02u), c0 + 2);
-        one_column(top3, __builtin_amdgcn_perm(qb, qa, 0x0c070c03u), c0 + 3);
+        one_column(top0, qa, qb, 0, c0);
+        one_column(top1, qa, qb, 1, c0 + 1);
+        one_column(top2, qa, qb, 2, c0 + 2);
+        one_column(top3, qa, qb, 3, c0 + 3);
         if (!(MGL_CK_ABLATE & 4) && c0) { // columns 8 g + 1 .. 8 g + 8 are staged
             stage_flush(stage, rowrec, lane);
             rowrec += 512;
@@ -192,9 +196,9 @@ __device__ __forceinline__ void ck_strip(const int i0, const int tl, const int q
     if (j <= ql) { // the last one to three columns (j - 1 is a multiple of four here)
         if (((j - 1) & (CK - 1)) == 0) save();
         const int c0 = (j - 1) & 4;
-        one_column(n0, __builtin_amdgcn_perm(nqb, nqa, 0x0c040c00u), c0);
-        if (j + 1 <= ql) one_column(n1, __builtin_amdgcn_perm(nqb, nqa, 0x0c050c01u), c0 + 1);
-        if (j + 2 <= ql) one_column(n2, __builtin_amdgcn_perm(nqb, nqa, 0x0c060c02u), c0 + 2);
+        one_column(n0, nqa, nqb, 0, c0);
+        if (j + 1 <= ql) one_column(n1, nqa, nqb, 1, c0 + 1);
+        if (j + 2 <= ql) one_column(n2, nqa, nqb, 2, c0 + 2);
     }
     if (ql & 7) stage_flush(stage, rowrec, lane); // a last group of fewer than eight columns
     // last column (sw.cpp:100-104), as in sw_dp16_lane.hip
@@ -220,6 +224,7 @@ __device__ __forceinline__ void ck_strip(const int i0, const int tl, const int q
 struct BlockGeom {
     int ql, nb, ng8, match, mismatch, gopen, gext, base;
     bool indel;
+    bool codes; // the staged sequences hold base codes
 };
 
 // ---- pass 2: the walk of one pair (calculateCigar, sw.cpp:149-255) as a machine that can stop at a block's edge and go on in
@@ -333,7 +338,7 @@ struct PathWalk {
             }
             if (mode == 0) {
                 if (cnt > 0) {
-                    hc -= cnt * g.match + mismatches(tw, qw, cnt) * (g.mismatch - g.match);
+                    hc -= cnt * g.match + mismatches(tw, qw, cnt, g.codes) * (g.mismatch - g.match);
                     take('M', cnt);
                     I -= cnt;
                     J -= cnt;
@@ -393,15 +398,16 @@ struct PathWalk {
         }
     }
     // how many of the cells (I, J), (I-1, J-1) .. (I-L+1, J-L+1) hold different bases (raw byte compare, sw.cpp:55); L <= 16, I, J
-    __device__ __forceinline__ int mismatches(const unsigned (&tw)[5], const unsigned (&qw)[5], int L) const
+    // (codes: the staged target holds codes 0 .. 3, the staged query 8 x code or 32 -- sw_lane_cell.h)
+    __device__ __forceinline__ int mismatches(const unsigned (&tw)[5], const unsigned (&qw)[5], int L, bool codes) const
     {
         const unsigned st = (unsigned)(I - 16) & 3u, sq = (unsigned)(J - 16) & 3u;
         const int drop = 16 - L, dq = drop >> 2, sh = (drop & 3) * 8; // the window's low `drop` bytes are not part of the stretch
         int n = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const unsigned x = __builtin_amdgcn_alignbyte(tw[k + 1], tw[k], st) ^ __builtin_amdgcn_alignbyte(qw[k + 1], qw[k], sq);
-            const unsigned nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; // bit 7 of every byte that is not zero
+            const unsigned tt = __builtin_amdgcn_alignbyte(tw[k + 1], tw[k], st);
+            const unsigned nz = nonzero_bytes((codes ? tt << 3 : tt) ^ __builtin_amdgcn_alignbyte(qw[k + 1], qw[k], sq));
             n += __popc(k > dq ? nz : k == dq ? nz >> sh : 0u);
         }
         return n;
@@ -424,7 +430,7 @@ struct PathWalk {
         const int he = ie == 0 ? border(je, g.gopen, g.gext, g.indel)
                      : je == 0 ? border(ie, g.gopen, g.gext, g.indel)
                                : lo16(w) - (ie + je) * g.gext - g.base;
-        const int sum = L * g.match + mismatches(tw, qw, L) * (g.mismatch - g.match);
+        const int sum = L * g.match + mismatches(tw, qw, L, g.codes) * (g.mismatch - g.match);
         if (hc - he != sum) {
             stuck = true; // this block's flags, then
             return false;
@@ -478,6 +484,7 @@ struct PathWalk {
 
 // ---- pass 2: recompute the flags of block (sA, bA) for the low halves and of block (sB, bB) for the high halves; s = 16-row band
 // (strip s / 2, its upper or lower half), b = block of CK columns.  rowrec / ckrec: the wave's records + this lane's 8 uint4.
+template <bool CODES>
 __device__ __forceinline__ void ck_block(const int sA, const int bA, const int sB, const int bB, const BlockGeom &g, const uint4 *rowrec,
                                          const uint4 *ckrec, const unsigned *qst, const unsigned *tst, uint4 *blk, const LaneConsts &c)
 {
@@ -485,10 +492,10 @@ __device__ __forceinline__ void ck_block(const int sA, const int bA, const int s
 #pragma unroll
     for (int r4 = 0; r4 < RB / 4; ++r4) {
         const unsigned ta = tst[(size_t)(2 * (sA * (RB / 4) + r4)) * 64], tb = tst[(size_t)(2 * (sB * (RB / 4) + r4) + 1) * 64];
-        t[4 * r4 + 0] = __builtin_amdgcn_perm(tb, ta, 0x0c040c00u);
-        t[4 * r4 + 1] = __builtin_amdgcn_perm(tb, ta, 0x0c050c01u);
-        t[4 * r4 + 2] = __builtin_amdgcn_perm(tb, ta, 0x0c060c02u);
-        t[4 * r4 + 3] = __builtin_amdgcn_perm(tb, ta, 0x0c070c03u);
+        t[4 * r4 + 0] = __builtin_amdgcn_perm(tb, ta, 0x0c040c00u) | (CODES ? CODE_SEL : 0u);
+        t[4 * r4 + 1] = __builtin_amdgcn_perm(tb, ta, 0x0c050c01u) | (CODES ? CODE_SEL : 0u);
+        t[4 * r4 + 2] = __builtin_amdgcn_perm(tb, ta, 0x0c060c02u) | (CODES ? CODE_SEL : 0u);
+        t[4 * r4 + 3] = __builtin_amdgcn_perm(tb, ta, 0x0c070c03u) | (CODES ? CODE_SEL : 0u);
     }
     {
         const uint4 *ca = ckrec + ((size_t)(((sA >> 1) * g.nb + bA) * 2 + 0) * 64) * 8 + (sA & 1) * 4;
@@ -556,9 +563,101 @@ __device__ __forceinline__ void ck_block(const int sA, const int bA, const int s
             const int ha_ = hb_k + (CK * bA + 8 * gg + u + 1) * hb_j, hb_ = hb_k + (CK * bB + 8 * gg + u + 1) * hb_j;
             const unsigned ea = topA ? pack2(ha_, ha_ - oe) : botA ? ba : ma, eb = topB ? pack2(hb_, hb_ - oe) : botB ? bb : mb; // {H : 16, E : 16} of the row above, this column
             unsigned e = highs(ea, eb);
-            const unsigned q = __builtin_amdgcn_perm(qb[u >> 2], qa[u >> 2], 0x0c040c00u + 0x00010001u * (u & 3));
-            column<RB, false>(h, f, t, q, hd, e, c, blk + (size_t)(8 * gg + u) * 64);
+            if (CODES)
+                column<RB, false, false, true>(h, f, t, code_table((qa[u >> 2] >> (8 * (u & 3))) & 0xffu), hd, e, c, blk + (size_t)(8 * gg + u) * 64, nullptr,
+                                               code_table((qb[u >> 2] >> (8 * (u & 3))) & 0xffu));
+            else
+                column<RB, false, false, false>(h, f, t, __builtin_amdgcn_perm(qb[u >> 2], qa[u >> 2], 0x0c040c00u + 0x00010001u * (u & 3)), hd, e, c,
+                                                blk + (size_t)(8 * gg + u) * 64);
             hd = lows(ea, eb);
+        }
+    }
+}
+
+// ---- staging.  Eight 4-base blocks of both pairs per round: all loads of a round in flight, then the stores (one block per round
+// exposes a memory latency per block: a tenth of the wave's lifetime, measured).  dst: the wave's [block][A | B][lane] dwords + lane.
+// ASCII sequences (sw.cpp:55 compares raw bytes).  CODES: store base codes -- a target as the code per byte, a QUERY as 8 x code, or 32
+// for a byte that is not one of ACGT (sw_lane_cell.h) -- and return nonzero if a byte of the first `len` is not one of ACGT.
+template <bool CODES, bool QUERY>
+__device__ __forceinline__ unsigned stage_ascii(const uint8_t *seqA, const uint8_t *seqB, const int len, const int nblocks, unsigned *dst)
+{
+    SeqWords sa, sb;
+    sa.init(seqA, len);
+    sb.init(seqB, len);
+    unsigned bad = 0;
+    for (int cb = 0; cb < nblocks; cb += 8) {
+        unsigned wa[9], wb[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            wa[u] = sa.word(cb + u);
+            wb[u] = sb.word(cb + u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (cb + u < nblocks) { // (blocks past the end of a target repeat its last dword: rows > tl, never read)
+                unsigned va = __builtin_amdgcn_alignbyte(wa[u + 1], wa[u], sa.shift), vb = __builtin_amdgcn_alignbyte(wb[u + 1], wb[u], sb.shift);
+                if (CODES) {
+                    unsigned da, db;
+                    va = ascii_codes(va, da);
+                    vb = ascii_codes(vb, db);
+                    if (QUERY) {
+                        const unsigned na = nonzero_bytes(da), nb = nonzero_bytes(db); // 0x80 in the bytes that are no ACGT: those become 32
+                        va = ((va << 3) & ~((na >> 2) - (na >> 7))) | (na >> 2);
+                        vb = ((vb << 3) & ~((nb >> 2) - (nb >> 7))) | (nb >> 2);
+                    } else {
+                        const int nv = len - 4 * (cb + u); // bytes of this block that belong to the sequence
+                        const unsigned keep = nv >= 4 ? 0xffffffffu : nv <= 0 ? 0u : (1u << (8 * nv)) - 1u;
+                        bad |= (da | db) & keep;
+                    }
+                }
+                dst[(size_t)(2 * (cb + u)) * 64] = va;
+                dst[(size_t)(2 * (cb + u) + 1) * 64] = vb;
+            }
+        }
+    }
+    return bad;
+}
+
+// 2-bit packed sequences (SeqSet::packed2: base k of the array in bits 2 (k & 3) of byte k >> 2; a pair's bases start at BASE index
+// `start`, any alignment): read as aligned dwords of 16 bases, clamped to the last dword that holds a base of the sequence.
+struct Seq2Words {
+    const uint32_t *base;
+    unsigned shift; // bits
+    int kmax;
+    __device__ __forceinline__ void init(const uint8_t *data, int64_t start, int len)
+    {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(data) + (uintptr_t)(start >> 2), e = reinterpret_cast<uintptr_t>(data) + (uintptr_t)((start + len - 1) >> 2);
+        base = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+        shift = (unsigned)(a & 3) * 8u + 2u * (unsigned)(start & 3);
+        kmax = (int)(((e & ~(uintptr_t)3) - (a & ~(uintptr_t)3)) >> 2);
+    }
+    __device__ __forceinline__ unsigned word(int k) const { return base[k < kmax ? k : kmax]; }
+};
+template <bool QUERY>
+__device__ __forceinline__ void stage_2bit(const uint8_t *data, const int64_t startA, const int64_t startB, const int len, const int nblocks, unsigned *dst)
+{
+    Seq2Words sa, sb;
+    sa.init(data, startA, len);
+    sb.init(data, startB, len);
+    for (int cb = 0; cb < nblocks; cb += 16) { // four dwords of 16 bases = sixteen blocks of both pairs per round
+        unsigned wa[5], wb[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            wa[u] = sa.word((cb >> 2) + u);
+            wb[u] = sb.word((cb >> 2) + u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned va = __builtin_amdgcn_alignbit(wa[u + 1], wa[u], sa.shift), vb = __builtin_amdgcn_alignbit(wb[u + 1], wb[u], sb.shift);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int blk = cb + 4 * u + x;
+                if (blk < nblocks) {
+                    const unsigned ca = spread_2bit((va >> (8 * x)) & 0xffu), cb2 = spread_2bit((vb >> (8 * x)) & 0xffu);
+                    dst[(size_t)(2 * blk) * 64] = QUERY ? ca << 3 : ca;
+                    dst[(size_t)(2 * blk + 1) * 64] = QUERY ? cb2 << 3 : cb2;
+                }
+            }
         }
     }
 }
@@ -613,32 +712,27 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
     uint4 *const blk = ckrec + (size_t)strips * nb * 2 * 512 + lane;
     __shared__ unsigned stage_all[4 * 64 * STAGE_ROW];
     unsigned *const stage = stage_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (64 * STAGE_ROW);
+    // ---- staging: both sequences of every lane, transposed to [4-base block][A | B][lane] dwords in the wave's scratch -- as BASE
+    // CODES where the wave's targets allow it (sw_lane_cell.h: 2-bit packed inputs always do; ASCII targets when every byte is one of
+    // ACGT -- the queries may hold anything), else as the raw bytes.
+    bool codes;
     {
         const int64_t pA = a.first + slotA, pB = a.first + slotB;
-        // eight blocks of both pairs per round: 18 loads in flight, then the stores (one block per round would expose a memory
-        // latency per block: a tenth of the wave's lifetime, measured)
-        auto stage = [&](const uint8_t *seqA, const uint8_t *seqB, int len, int nblocks, unsigned *dst) {
-            SeqWords sa, sb;
-            sa.init(seqA, len);
-            sb.init(seqB, len);
-            for (int cb = 0; cb < nblocks; cb += 8) {
-                unsigned wa[9], wb[9];
-#pragma unroll
-                for (int u = 0; u < 9; ++u) {
-                    wa[u] = sa.word(cb + u);
-                    wb[u] = sb.word(cb + u);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (cb + u < nblocks) { // (blocks past the end of a target repeat its last dword: rows > tl, never read)
-                        dst[(size_t)(2 * (cb + u)) * 64] = __builtin_amdgcn_alignbyte(wa[u + 1], wa[u], sa.shift);
-                        dst[(size_t)(2 * (cb + u) + 1) * 64] = __builtin_amdgcn_alignbyte(wb[u + 1], wb[u], sb.shift);
-                    }
-                }
+        const int qblocks = (ql + 3) >> 2, tblocks = strips * (R / 4);
+        if (a.t.packed2) {
+            stage_2bit<false>(a.t.data, a.t.off[pA], a.t.off[pB], tl, tblocks, tst);
+            stage_2bit<true>(a.q.data, a.q.off[pA], a.q.off[pB], ql, qblocks, qst);
+            codes = true;
+        } else {
+            const unsigned bad = stage_ascii<true, false>(a.t.data + a.t.off[pA], a.t.data + a.t.off[pB], tl, tblocks, tst);
+            codes = __builtin_amdgcn_ballot_w64(bad != 0u) == 0;
+            if (codes) {
+                stage_ascii<true, true>(a.q.data + a.q.off[pA], a.q.data + a.q.off[pB], ql, qblocks, qst);
+            } else { // a target byte outside ACGT somewhere in the wave: raw bytes for all of it
+                stage_ascii<false, false>(a.t.data + a.t.off[pA], a.t.data + a.t.off[pB], tl, tblocks, tst);
+                stage_ascii<false, true>(a.q.data + a.q.off[pA], a.q.data + a.q.off[pB], ql, qblocks, qst);
             }
-        };
-        stage(a.q.data + a.q.off[pA], a.q.data + a.q.off[pB], ql, (ql + 3) >> 2, qst);
-        stage(a.t.data + a.t.off[pA], a.t.data + a.t.off[pB], tl, strips * (R / 4), tst);
+        }
         // row 0 (the border row, sw.cpp:14-18,31-35) in stored form: H[0][j], E[1][j] = H[0][j] - o
         for (int j = 0; j <= ql; ++j) {
             const int hb0 = border(j, gopen, gext, indel) + j * gext + base;
@@ -650,11 +744,19 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
     CK_PHASE(0); // staging
     // ---- pass 1
     int bestA = NEG_INF, bestA_i = -1, bestB = NEG_INF, bestB_i = -1;
-    for (int k = 0; k < strips - 1; ++k)
-        ck_strip<false>(k * R, tl, ql, bnd, stage, rowrec + (size_t)k * ng8 * 512, ckrec + (size_t)k * nb * 2 * 512, lane, qst, tst, c, gopen, gext,
-                        base, indel, bestA, bestA_i, bestB, bestB_i);
-    ck_strip<true>((strips - 1) * R, tl, ql, bnd, stage, rowrec + (size_t)(strips - 1) * ng8 * 512, ckrec + (size_t)(strips - 1) * nb * 2 * 512, lane, qst, tst,
-                   c, gopen, gext, base, indel, bestA, bestA_i, bestB, bestB_i);
+    if (codes) {
+        for (int k = 0; k < strips - 1; ++k)
+            ck_strip<false, true>(k * R, tl, ql, bnd, stage, rowrec + (size_t)k * ng8 * 512, ckrec + (size_t)k * nb * 2 * 512, lane, qst, tst, c, gopen,
+                                  gext, base, indel, bestA, bestA_i, bestB, bestB_i);
+        ck_strip<true, true>((strips - 1) * R, tl, ql, bnd, stage, rowrec + (size_t)(strips - 1) * ng8 * 512, ckrec + (size_t)(strips - 1) * nb * 2 * 512,
+                             lane, qst, tst, c, gopen, gext, base, indel, bestA, bestA_i, bestB, bestB_i);
+    } else {
+        for (int k = 0; k < strips - 1; ++k)
+            ck_strip<false, false>(k * R, tl, ql, bnd, stage, rowrec + (size_t)k * ng8 * 512, ckrec + (size_t)k * nb * 2 * 512, lane, qst, tst, c, gopen,
+                                   gext, base, indel, bestA, bestA_i, bestB, bestB_i);
+        ck_strip<true, false>((strips - 1) * R, tl, ql, bnd, stage, rowrec + (size_t)(strips - 1) * ng8 * 512, ckrec + (size_t)(strips - 1) * nb * 2 * 512,
+                              lane, qst, tst, c, gopen, gext, base, indel, bestA, bestA_i, bestB, bestB_i);
+    }
 
     CK_PHASE(1); // pass 1
     // ---- last row (sw.cpp:116-127), as in sw_dp16_lane.hip
@@ -723,6 +825,7 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
     geom.gext = gext;
     geom.base = base;
     geom.indel = indel;
+    geom.codes = codes;
     const uint32_t *const blk_words = reinterpret_cast<const uint32_t *>(blk);
     const bool by_score = !(MGL_CK_ABLATE & 8);
     const int tblocks = strips * (R / 4), qblocks = (ql + 3) >> 2;
@@ -747,7 +850,10 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
         }
         // (a finished walk keeps recomputing some valid block: both halves run the same instructions anyway)
         const int kA = max(wa.pi - 1, 0) >> 4, bA = max(wa.pj - 1, 0) / CK, kB = max(wb.pi - 1, 0) >> 4, bB = max(wb.pj - 1, 0) / CK;
-        ck_block(kA, bA, kB, bB, geom, rowrec_lane, ckrec_lane, qst, tst, blk, c);
+        if (codes)
+            ck_block<true>(kA, bA, kB, bB, geom, rowrec_lane, ckrec_lane, qst, tst, blk, c);
+        else
+            ck_block<false>(kA, bA, kB, bB, geom, rowrec_lane, ckrec_lane, qst, tst, blk, c);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         CK_PHASE(4); // a block's flags
 #ifdef MGL_CK_PHASES
@@ -788,6 +894,9 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
 // 3 812 / 3 734 (scripts/wps_probe.sh) -- a round of the chip is 8 waves per CU instead of 12, and the last round of a launch fuller.
 __global__ __launch_bounds__(256, 3) void sw_dp16_lane_ck_kernel_w3(const DpArgs a, const TbArgs walk) { sw_dp16_lane_ck_body(a, walk); }
 __global__ __launch_bounds__(256, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, const TbArgs walk) { sw_dp16_lane_ck_body(a, walk); }
+
+// either wire format, the same for both sequence sets (the kernel stages base codes, sw_lane_cell.h)
+bool lane16_ck_supported(const SeqSet &t, const SeqSet &q) { return (t.packed2 != 0) == (q.packed2 != 0); }
 
 hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &walk, hipStream_t stream)
 {

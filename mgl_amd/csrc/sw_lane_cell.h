@@ -67,6 +67,27 @@ struct SeqWords {
     }
 };
 
+// ---- base codes (sw_dp16_lane_ck.hip).  Staged targets hold one code 0 .. 3 per byte, staged queries 8 x code, or 32 for a base
+// outside the target alphabet.
+constexpr unsigned CODE_SEL = 0x0c040c00u; // a row's selector: or-ed onto {0, code B, 0, code A}
+// the column's table of one pair from its staged query byte
+__device__ __forceinline__ unsigned code_table(unsigned q8) { return 0x01010101u ^ (unsigned)(1ull << q8); }
+// four ASCII bases -> four codes (A 0, C 1, T 2, G 3: bits 1 and 2 of the byte); `bad` collects the bytes that are not one of
+// these four upper-case letters (nonzero = such a byte exists among the dword's first `valid` bytes)
+__device__ __forceinline__ unsigned ascii_codes(unsigned w, unsigned &diff)
+{
+    const unsigned code = (w >> 1) & 0x03030303u;
+    diff = __builtin_amdgcn_perm(0u, 0x47544341u, code) ^ w; // the letter each code stands for, against the byte itself
+    return code;
+}
+__device__ __forceinline__ unsigned nonzero_bytes(unsigned x) { return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; } // bit 7 of each
+// four 2-bit bases (the low byte of x) -> four codes
+__device__ __forceinline__ unsigned spread_2bit(unsigned x)
+{
+    const unsigned y = (x | (x << 12)) & 0x000f000fu;
+    return (y | (y << 6)) & 0x03030303u;
+}
+
 // (a & k) | b in one VOP3 instruction, k in an SGPR (left to the compiler this becomes v_and_b32 + v_or_b32)
 __device__ __forceinline__ unsigned and_or(unsigned a, unsigned k, unsigned b)
 {
@@ -86,26 +107,36 @@ struct LaneConsts {
 // hd: H[row -1][j-1] (the strip's top row, previous column); hup / e: H and E coming down from the strip above.
 // On exit e = E leaving the strip's last row, h[R-1] = H of its last row.  w: the R/4 traceback dwords of the column.
 // MID: {H, E} leaving row 15 also go to *mid (sw_dp16_lane_ck.hip: the carry row of the strip's lower half).
-template <int R, bool NOTB, bool MID = false>
+// How a cell learns whether its two bases differ (m = 1 where they do, per half; raw byte compare, sw.cpp:55):
+//   bytes (CODES = false)  t[r] = {target byte A, target byte B} in the low bytes of the halves, q likewise: xor, then min(., 1)
+//   codes (CODES = true)   one v_perm_b32: q / q2 are the COLUMN's tables for pair A / B -- byte c = 0 if the query base has code c,
+//                          else 1 -- and t[r] is the ROW's selector 0x0c, 4 + code B, 0x0c, code A (0x0c selects a zero byte), so
+//                          the lookup lands m in both halves at once.  Codes 0 .. 3 are the target's alphabet; a query base outside
+//                          it has the all-ones table.  One instruction less per two cells.
+template <int R, bool NOTB, bool MID = false, bool CODES = false>
 __device__ __forceinline__ void column(unsigned (&h)[R], unsigned (&f)[R], const unsigned (&t)[R], const unsigned q, unsigned hd,
-                                       unsigned &e, const LaneConsts &c, uint4 *tbp, uint2 *mid = nullptr)
+                                       unsigned &e, const LaneConsts &c, uint4 *tbp, uint2 *mid = nullptr, const unsigned q2 = 0u)
 {
     unsigned w[4];
+    auto differ = [&](const int r) { return CODES ? __builtin_amdgcn_perm(q2, q, t[r]) : pk_min_u(q ^ t[r], c.one); };
     // the diagonal of row r + 1 is taken from H[r][j-1] BEFORE row r overwrites it with H[r][j] (so that H stays in place,
     // no copy per row), one row ahead of the recurrence
-    unsigned dg = pk_add(hd, pk_mad(pk_min_u(q ^ t[0], c.one), c.delta, c.k2));
+    unsigned dg = pk_add(hd, pk_mad(differ(0), c.delta, c.k2));
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const unsigned diag = dg;
         if (r + 1 < R) {
-            const unsigned m = pk_min_u(q ^ t[r + 1], c.one);   // 1 where the bases differ (raw byte compare, sw.cpp:55)
-            const unsigned s = pk_mad(m, c.delta, c.k2);        // match + 2e or mismatch + 2e
+            const unsigned s = pk_mad(differ(r + 1), c.delta, c.k2); // match + 2e or mismatch + 2e
             dg = pk_add(h[r], s);
         }
         const unsigned fr = f[r];
         const unsigned sm = pk_max(diag, fr);
         const unsigned hn = pk_max(sm, e);              // sw.cpp:60-71: diag >= F >= E priority via the two strict flags below
+#if defined(MGL_CK_ABLATE) && (MGL_CK_ABLATE & 32)
+        const unsigned open = hn - c.o_e;               // (timing experiment: a full-rate 32-bit subtract; wrong results)
+#else
         const unsigned open = pk_sub(hn, c.o_e);        // a new gap, either direction
+#endif
         const unsigned eo = pk_max(open, e);            // extension is free in this representation (sw.cpp:73-93)
         const unsigned fo = pk_max(open, fr);
         if (!NOTB) {
