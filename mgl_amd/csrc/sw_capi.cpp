@@ -402,8 +402,8 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // (auto-grouped chunks: the packed regions first, the int32 regions of the left-over pairs behind them)
     const int sps32 = sps_for_rows(max_ql, 16);
     const int64_t stride32_words = tb_words_for(max_tl, sps32, 16);
-    const int64_t per_pair = use_lane ? ((score_only ? 0 : stride_words * 4) + lane_scratch_bytes(max_tl, max_ql, rows)) / 128 + 1 + (int64_t)sizeof(DpRecord)
-                             : auto_group ? std::max(std::max(stride_words * 2, stride32_words * 4), lane_group ? (lane_group_stride * 4 + lane_scratch_bytes(max_tl, max_ql, 32)) / 128 + 1 : 0) + (int64_t)sizeof(DpRecord)
+    const int64_t per_pair = use_lane ? ((score_only ? 0 : stride_words * 4) + (lane_ck ? lane_ck_scratch_bytes(max_tl, max_ql) : lane_scratch_bytes(max_tl, max_ql, rows))) / 128 + 1 + (int64_t)sizeof(DpRecord)
+                             : auto_group ? std::max(std::max(stride_words * 2, stride32_words * 4), lane_group ? (lane_group_stride * 4 + lane_ck_scratch_bytes(max_tl, max_ql)) / 128 + 1 : 0) + (int64_t)sizeof(DpRecord)
                                           : (score_only ? 0 : stride_words * 4 / (use16 ? 2 : 1)) + (int64_t)sizeof(DpRecord);
     // the workspace is split in two halves so that the traceback of one chunk can run (on ctx->aux)
     // while the next chunk is being filled; a batch that fits one half is a single chunk
@@ -455,8 +455,8 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             HIP_TRY(ctx, ctx->tb[h].reserve((size_t)chunk * (size_t)(per_pair - (int64_t)sizeof(DpRecord)) + 64));
         else if (!score_only)
             HIP_TRY(ctx, ctx->tb[h].reserve(regions * (size_t)stride_words * 4));
-        if (use_lane) HIP_TRY(ctx, ctx->bnd[h].reserve(regions * (size_t)lane_scratch_bytes(max_tl, max_ql, rows)));
-        if (lane_group) HIP_TRY(ctx, ctx->bnd[h].reserve((size_t)(chunk / 128 + 1) * (size_t)lane_scratch_bytes(max_tl, max_ql, 32)));
+        if (use_lane) HIP_TRY(ctx, ctx->bnd[h].reserve(regions * (size_t)(lane_ck ? lane_ck_scratch_bytes(max_tl, max_ql) : lane_scratch_bytes(max_tl, max_ql, rows))));
+        if (lane_group) HIP_TRY(ctx, ctx->bnd[h].reserve((size_t)(chunk / 128 + 1) * (size_t)lane_ck_scratch_bytes(max_tl, max_ql)));
         HIP_TRY(ctx, ctx->rec[h].reserve((size_t)chunk * sizeof(DpRecord)));
     }
 

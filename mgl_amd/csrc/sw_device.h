@@ -147,18 +147,19 @@ __host__ __device__ inline int64_t tb_words_coop16(int tl, int ql) { return (int
 __host__ __device__ inline int coop_query_bytes(int sps_cap) { return (sps_cap + 192 + 15) & ~15; } // 64 + ql + slack
 __host__ __device__ inline int coop_wrap_cols(int sps_cap) { return sps_cap + 192; }                // 8 bytes each, per pair
 
-// ---- sw_dp16_lane_ck_kernel (sw_dp16_lane_ck.hip): the same kernel without stored flags -- carry rows of every 32-row strip and
-// the lanes' register state every LANE_CK_COLS columns are kept, the walk recomputes the blocks its path crosses
+// ---- sw_dp16_lane_ck_kernel (sw_dp16_lane_ck.hip): the same kernel without stored flags -- {H, E} of every 16th target row and
+// the lanes' register state every LANE_CK_COLS columns are kept, the walk recomputes the few blocks it cannot check by score
 constexpr int LANE_CK_COLS = 32;
 __host__ __device__ inline int lane_ck_blocks(int ql) { return (ql + LANE_CK_COLS - 1) / LANE_CK_COLS; }
-__host__ __device__ inline int lane_ck_groups(int ql) { return (ql + 7) / 8; } // groups of eight columns
-// dwords per WAVE: records of [lane][32 dwords] -- strips x groups of carry rows, strips x blocks x 2 checkpoints -- and one
-// block of flags [column][lane] uint4
+// dwords per WAVE, all [..][lane]: strips + 1 carry rows and strips middle rows of uint2 {H, E} per column, strips x (blocks - 1)
+// checkpoints of 64 registers, one block of flags [column][lane] uint4
 __host__ __device__ inline int64_t lane_ck_words(int tl, int ql)
 {
     const int64_t strips = lane_strips(tl, 32);
-    return (strips * lane_ck_groups(ql) + strips * lane_ck_blocks(ql) * 2) * 64 * 32 + (int64_t)LANE_CK_COLS * 64 * 4;
+    return ((strips + 1) * (ql + 1) * 2 + strips * ql * 2 + strips * (lane_ck_blocks(ql) - 1) * 64 + (int64_t)LANE_CK_COLS * 4) * 64;
 }
+// per-wave scratch: both queries and both targets of every lane transposed to [4-base block][A | B][lane] dwords
+__host__ __device__ inline int64_t lane_ck_scratch_bytes(int tl, int ql) { return ((int64_t)((ql + 3) / 4) + (int64_t)lane_strips(tl, 32) * 8) * 2 * 64 * 4; }
 
 int64_t dp_group_bytes(int sps_cap, int rows); // carry ring + query copies of one pair (LDS, or HBM scratch)
 int dp_lds_bytes(int sps_cap, int waves_per_block, int rows);

@@ -1,39 +1,26 @@
-// sw_dp16_lane_ck.hip -- the two-pairs-per-lane kernel (sw_dp16_lane.hip) in its CHECKPOINTED form: the fill keeps no
-// traceback flags at all.  Of the 17 VALU instructions the fill spends per two cells, 8 build the four flags of
-// sw_lane_cell.h -- for 38 400 cells of a 256 x 150 pair of which the path visits ~300.  Here
+// sw_dp16_lane_ck.hip -- the two-pairs-per-lane kernel (sw_dp16_lane.hip) in its CHECKPOINTED form: the fill keeps no traceback
+// flags at all.  Of the 17 VALU instructions the full fill spends per two cells, 8 build the four flags of sw_lane_cell.h -- for
+// 38 400 cells of a 256 x 150 pair of which the path visits ~300, nearly all of them in a way that needs no flag to be known.
 //
-//   pass 1  runs the score-only column code (9 instructions per two cells) over the whole matrix and keeps what is needed
-//           to START AGAIN anywhere on a coarse grid: the carry row leaving every 16 target rows -- the last row of every 32-row
-//           strip (H and E per column: the reference's score[] / step[], sw_avx.cpp:36-47,196-197) and the row in its middle --
-//           and, every LANE_CK_COLS query columns, the lane's register state (H of the previous column and the horizontal-gap
-//           value of its 32 rows);
-//   pass 2  walks the path (sw.cpp:149-255) block by block: the lane recomputes the 16 x LANE_CK_COLS block its walk stands
-//           in -- the SAME column code with the flags switched on, started from the two checkpoints of the block, so every
-//           flag is bit for bit the one the full fill would have stored -- into a small private buffer, walks as far as the
-//           block reaches, and goes on with the block the path leaves into.  Both pairs of the lane do this in lock step
-//           (one packed recomputation serves pair A's block and pair B's block, which are different blocks in general).
-//           Blocks are 16 rows high (half a strip: pass 1 also keeps the row in the middle of every strip) and LANE_CK_COLS = 32
-//           columns wide -- a path of a 256 x 150 pair crosses ~14 of them, 7 000 of 38 400 cells -- and a 16-row column needs
-//           48 registers of state where a 32-row one needs 96 (with 32-row blocks the compiler spilled the target bases into
-//           the column loop).  Measured on 2 M pairs of 256 x 150: blocks of 16 columns 22.6 ms, of 32 columns 21.7 (half the
-//           checkpoint bytes weigh more than the larger blocks: the record stores cost pass 1 2.7 ms of its 13.9).
+//   pass 1  runs the score-only column code (8 instructions per two cells with base codes, sw_lane_cell.h) over the whole matrix
+//           and keeps what is needed to START AGAIN anywhere on a coarse grid: {H, E} of every 16th target row per column -- the
+//           carry row entering every 32-row strip (the reference's score[] / step[], sw_avx.cpp:36-47,196-197; kept for all strips
+//           instead of being updated in place) and the row in a strip's middle -- and, every LANE_CK_COLS query columns, the lane's
+//           register state (H of the previous column and the horizontal-gap value of its 32 rows).  All of it time-major,
+//           [..][lane], stored straight from the registers in whole 256- / 512-byte rows: a lane only ever reads back its own.
+//   pass 2  walks the path (sw.cpp:149-255).  The walk knows H of the cell it stands at, so a diagonal stretch up to the next
+//           kept row is CHECKED instead of recomputed: if H drops by exactly the sum of the stretch's substitution scores, every
+//           cell of it took the diagonal (PathWalk::verify_apply: the proof).  Only where that fails -- a gap, or a tie taken
+//           elsewhere: 0.4 blocks per pair on Illumina-style reads, 3.5 rounds per wave -- the lane recomputes the 16 x LANE_CK_COLS
+//           block the walk stands in: the SAME column code with the flags switched on, started from the block's kept row and
+//           checkpoint, so every flag is bit for bit the one the full fill would have stored, into a small private buffer; it walks
+//           as far as the block reaches and goes on.  Both pairs of a lane do this in lock step (one packed recomputation serves
+//           pair A's block and pair B's, different blocks in general).
 //
 // Same arithmetic, same range guard (dp16_range_ok), same results as sw_dp16_lane_kernel.
 //
-// What pass 2 fetches is scattered -- every lane is somewhere else on its path -- so it is laid out PER PAIR: a fetch then uses
-// the 64-byte sectors it touches (time-major [column][lane] arrays cost a sector per 8 bytes: 33 sectors per 16-column block and
-// pair).  Pass 1 produces its values lane by lane and column by column, so it stages
-// them in LDS (128 bytes per lane) and writes them out transposed, whole lines per store instruction.
-//
-// Per-wave region (a.tb + wave * a.tb_stride_words, lane_ck_words()), in RECORDS of [lane][32 dwords] (8 KB):
-//   rows   record (slot * groups + g): columns 8 g + 1 .. 8 g + 8 of two carry rows, per lane [pair A | pair B][column][mid | bot]
-//          dwords {H : 16, E : 16}: slot k = strip k's middle row (what enters its lower 16 rows) and its last row (what enters
-//          the strip below)
-//   ckpt   record ((strip * blocks + b) * 2 + pair): the pair's state at column LANE_CK_COLS b, [upper | lower 16 rows][h x 8 | f x 8]
-//          dwords of two rows each
-//   block  [column of the block][lane] uint4: the recomputed flags of 16 rows, bytes as in sw_dp16_lane.hip
-// The carry row between strips that pass 1 itself reads (time-major, updated in place) lives in the wave's scratch as in
-// sw_dp16_lane.hip.
+// Per-wave region (a.tb + wave * a.tb_stride_words, lane_ck_words()): WaveMem below.  The wave's scratch (a.scratch,
+// lane_ck_scratch_bytes()) holds both sequences of every lane, staged once as [4-base block][A | B][lane] dwords.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -71,160 +58,26 @@ constexpr int R = 32;            // target rows per strip
 constexpr int RB = 16;           // rows per recomputed block
 constexpr int CK = LANE_CK_COLS; // query columns per block
 
-// rows of the LDS staging buffer: 32 dwords per lane, padded to 36 (16-byte aligned rows, lanes spread over the banks)
-constexpr int STAGE_ROW = 36;
-
-// two rows of one pair side by side: {row 2i : 16, row 2i + 1 : 16} from the packed A|B registers of both rows
-__device__ __forceinline__ unsigned lows(unsigned r0, unsigned r1) { return __builtin_amdgcn_perm(r1, r0, 0x05040100u); }
-__device__ __forceinline__ unsigned highs(unsigned r0, unsigned r1) { return __builtin_amdgcn_perm(r1, r0, 0x07060302u); }
-
-// the wave writes its staging buffer out as one record: store instruction i covers lanes 8 i .. 8 i + 7, 128 bytes each
-__device__ __forceinline__ void stage_flush(const unsigned *stage, uint4 *rec, const int lane)
-{
-    asm volatile("" ::: "memory"); // LDS instructions of a wave execute in order: all it takes is that the compiler keeps them so
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        rec[i * 64 + lane] = *reinterpret_cast<const uint4 *>(stage + (i * 8 + (lane >> 3)) * STAGE_ROW + (lane & 7) * 4);
-    asm volatile("" ::: "memory");
-}
-
-// ---- pass 1: one strip, score only, keeping the carry rows and the column checkpoints
-template <bool LAST, bool CODES>
-__device__ __forceinline__ void ck_strip(const int i0, const int tl, const int ql, uint2 *bnd, unsigned *stage, uint4 *rowrec, uint4 *ckrec,
-                                         const int lane, const unsigned *qst, const unsigned *tst, const LaneConsts &c, const int gopen,
-                                         const int gext, const int base, const bool indel, int &bestA, int &bestA_i, int &bestB, int &bestB_i)
-{
-    unsigned h[R], f[R], t[R];
-#pragma unroll
-    for (int r4 = 0; r4 < R / 4; ++r4) {
-        const unsigned ta = tst[(size_t)(2 * ((i0 >> 2) + r4)) * 64], tb = tst[(size_t)(2 * ((i0 >> 2) + r4) + 1) * 64];
-        t[4 * r4 + 0] = __builtin_amdgcn_perm(tb, ta, 0x0c040c00u) | (CODES ? CODE_SEL : 0u);
-        t[4 * r4 + 1] = __builtin_amdgcn_perm(tb, ta, 0x0c050c01u) | (CODES ? CODE_SEL : 0u);
-        t[4 * r4 + 2] = __builtin_amdgcn_perm(tb, ta, 0x0c060c02u) | (CODES ? CODE_SEL : 0u);
-        t[4 * r4 + 3] = __builtin_amdgcn_perm(tb, ta, 0x0c070c03u) | (CODES ? CODE_SEL : 0u);
-    }
-    // column 0 (sw.cpp:24,38,47-49), as in sw_dp16_lane.hip
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int row = i0 + r + 1;
-        const int hb = border(row, gopen, gext, indel) + row * gext + base;
-        h[r] = pack2(hb, hb);
-        f[r] = pk_sub(h[r], c.o_e);
-    }
-    const int hd0 = border(i0, gopen, gext, indel) + i0 * gext + base; // H[i0][0]
-    unsigned hd = pack2(hd0, hd0);
-    const int rl = tl - 1 - i0;
-
-    unsigned *const my = stage + lane * STAGE_ROW; // this lane's 32 dwords: [A | B][column of the group of eight][mid | bot]
-    uint2 *bp = bnd + 64;                          // column j of the time-major carry row
-    // column u (0 .. 3) of the group whose query dwords are qa / qb
-    auto one_column = [&](const uint2 top, const unsigned qa, const unsigned qb, const int u, const int cidx) {
-        unsigned e = top.y;
-        uint2 mid;
-        if (CODES)
-            column<R, true, true, true>(h, f, t, code_table((qa >> (8 * u)) & 0xffu), hd, e, c, nullptr, &mid, code_table((qb >> (8 * u)) & 0xffu));
-        else
-            column<R, true, true, false>(h, f, t, __builtin_amdgcn_perm(qb, qa, 0x0c040c00u + 0x00010001u * u), hd, e, c, nullptr, &mid);
-        hd = top.x;
-        *reinterpret_cast<uint2 *>(my + 2 * cidx) = make_uint2(lows(mid.x, mid.y), lows(h[R - 1], e));
-        *reinterpret_cast<uint2 *>(my + 16 + 2 * cidx) = make_uint2(highs(mid.x, mid.y), highs(h[R - 1], e));
-        if (!LAST) {
-            bp[0] = make_uint2(h[R - 1], e);
-        } else {
-            unsigned bot = h[R - 1];
-            if (rl != R - 1) {
-#pragma unroll
-                for (int r = 0; r < R - 1; ++r) bot = (r == rl) ? h[r] : bot;
-            }
-            bp[0] = make_uint2(bot, 0u);
-        }
-        bp += 64;
-    };
-    auto save = [&]() { // the state BEFORE column j: H[.][j-1] and the horizontal-gap values entering column j; pair A, then pair B
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-#pragma unroll
-            for (int band = 0; band < 2; ++band) {
-#pragma unroll
-                for (int i4 = 0; i4 < 2; ++i4) {
-                    const int r = band * RB + i4 * 8;
-                    uint4 hv, fv;
-                    if (x == 0) {
-                        hv = make_uint4(lows(h[r], h[r + 1]), lows(h[r + 2], h[r + 3]), lows(h[r + 4], h[r + 5]), lows(h[r + 6], h[r + 7]));
-                        fv = make_uint4(lows(f[r], f[r + 1]), lows(f[r + 2], f[r + 3]), lows(f[r + 4], f[r + 5]), lows(f[r + 6], f[r + 7]));
-                    } else {
-                        hv = make_uint4(highs(h[r], h[r + 1]), highs(h[r + 2], h[r + 3]), highs(h[r + 4], h[r + 5]), highs(h[r + 6], h[r + 7]));
-                        fv = make_uint4(highs(f[r], f[r + 1]), highs(f[r + 2], f[r + 3]), highs(f[r + 4], f[r + 5]), highs(f[r + 6], f[r + 7]));
-                    }
-                    *reinterpret_cast<uint4 *>(my + band * 16 + i4 * 4) = hv;
-                    *reinterpret_cast<uint4 *>(my + band * 16 + 8 + i4 * 4) = fv;
-                }
-            }
-            stage_flush(stage, ckrec, lane);
-            ckrec += 512;
-        }
-    };
-    // The carry row and the query are read ONE GROUP OF FOUR COLUMNS AHEAD: what a group needs was requested at the top of the
-    // group before it, so its latency -- and the acknowledgements of the stores issued in between, which s_waitcnt vmcnt counts
-    // in the same queue -- hides behind 1 150 instructions of arithmetic instead of stalling the wave at every group (measured
-    // before: a third of the waves' lifetime in s_waitcnt at two waves per SIMD).  Reads past column ql stay inside the wave's own
-    // scratch (the staged sequences follow the carry row) and are never used.
-    int j = 1;
-    uint2 n0 = bp[0], n1 = bp[64], n2 = bp[128], n3 = bp[192];
-    unsigned nqa = qst[0], nqb = qst[64];
-    for (; j + 3 <= ql; j += 4) {
-        if (!(MGL_CK_ABLATE & 2) && ((j - 1) & (CK - 1)) == 0) save();
-        const uint2 top0 = n0, top1 = n1, top2 = n2, top3 = n3;
-        const unsigned qa = nqa, qb = nqb;
-        qst += 128;
-        n0 = bp[256];
-        n1 = bp[320];
-        n2 = bp[384];
-        n3 = bp[448];
-        nqa = qst[0];
-        nqb = qst[64];
-        const int c0 = (j - 1) & 4;
-        one_column(top0, qa, qb, 0, c0);
-        one_column(top1, qa, qb, 1, c0 + 1);
-        one_column(top2, qa, qb, 2, c0 + 2);
-        one_column(top3, qa, qb, 3, c0 + 3);
-        if (!(MGL_CK_ABLATE & 4) && c0) { // columns 8 g + 1 .. 8 g + 8 are staged
-            stage_flush(stage, rowrec, lane);
-            rowrec += 512;
-        }
-    }
-    if (j <= ql) { // the last one to three columns (j - 1 is a multiple of four here)
-        if (((j - 1) & (CK - 1)) == 0) save();
-        const int c0 = (j - 1) & 4;
-        one_column(n0, nqa, nqb, 0, c0);
-        if (j + 1 <= ql) one_column(n1, nqa, nqb, 1, c0 + 1);
-        if (j + 2 <= ql) one_column(n2, nqa, nqb, 2, c0 + 2);
-    }
-    if (ql & 7) stage_flush(stage, rowrec, lane); // a last group of fewer than eight columns
-    // last column (sw.cpp:100-104), as in sw_dp16_lane.hip
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int row = i0 + r + 1;
-        if (row <= tl) {
-            const int unshift = -(row + ql) * gext - base;
-            const int ca = lo16(h[r]) + unshift, cb = hi16(h[r]) + unshift;
-            if (ca >= bestA) {
-                bestA = ca;
-                bestA_i = row;
-            }
-            if (cb >= bestB) {
-                bestB = cb;
-                bestB_i = row;
-            }
-        }
-    }
-}
+// the halves of two packed registers: {a.low, b.high}
+__device__ __forceinline__ unsigned lo_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060100u); }
 
 // what pass 2 needs to know about the wave's geometry and scoring
 struct BlockGeom {
-    int ql, nb, ng8, match, mismatch, gopen, gext, base;
+    int ql, nb, match, mismatch, gopen, gext, base;
     bool indel;
     bool codes; // the staged sequences hold base codes
+};
+
+// the wave's arrays (every pointer includes the lane): what pass 1 keeps, time-major -- a lane only ever reads what it wrote itself
+struct WaveMem {
+    uint2 *bnd;    // [row 32 k, k = 0 .. strips][column 0 .. ql][lane] {H, E} packed A | B: the carry row entering strip k (row 0: the border)
+    uint2 *mid;    // [strip][column 1 .. ql][lane]: the row in the strip's middle (row 32 k + 16)
+    unsigned *ck;  // [strip][block 1 .. nb - 1][2 r | 2 r + 1][lane]: H[.][32 b] and the horizontal-gap value of the strip's row r entering column 32 b + 1
+    uint4 *blk;    // [column of the block][lane]: the recomputed flags of 16 rows
+    __device__ __forceinline__ const uint2 *row16(int m, int ql) const // row 16 m (m >= 0), indexed [column * 64]
+    {
+        return (m & 1) ? mid + ((size_t)(m >> 1) * ql - 1) * 64 : bnd + (size_t)(m >> 1) * (ql + 1) * 64;
+    }
 };
 
 // ---- pass 2: the walk of one pair (calculateCigar, sw.cpp:149-255) as a machine that can stop at a block's edge and go on in
@@ -381,7 +234,7 @@ struct PathWalk {
     // candidate is the maximum, sw.cpp:60-62 records btr = 0 (the diagonal wins ties), and the walk of sw.cpp:182-214 takes L
     // diagonal steps -- whatever the stretch contains (substitutions included) and whatever the penalties are.  The walk knows H of
     // the cell it stands at (hc: the start cell's score is in the record, a diagonal step subtracts s, a gap run of n adds
-    // o + (n-1) e: sw.cpp:73-93), pass 1 kept H of every 16th row (the carry-row records) and the borders are formulas, so one round
+    // o + (n-1) e: sw.cpp:73-93), pass 1 kept H of every 16th row (WaveMem) and the borders are formulas, so one round
     // checks the stretch from the walk's cell up to the next recorded row (or the matrix's edge) with one look at that row's H and
     // at most 16 bases of both sequences (their staged copies: [4-base block][A | B][lane] dwords).  Only where the sum does NOT
     // fit -- a gap, or a tie taken elsewhere -- does the walk need the flags of the block.
@@ -414,22 +267,20 @@ struct PathWalk {
     }
     // the end of the stretch: the next recorded row above (I - 1) / 16 * 16, or where the diagonal leaves the matrix
     __device__ __forceinline__ int stretch() const { return min(I - (((I - 1) >> 4) << 4), J); }
-    // H of that row in stored form: strip s keeps row 32 s + 16 (mid) and row 32 s + 32 (bot); this lane's 32 dwords of a record are
-    // [pair][column of the group of eight][mid | bot] x {H : 16, E : 16}
-    __device__ __forceinline__ void grid_load(const uint4 *rowrec_lane, int half, int ng8, unsigned &w) const
+    // H of that row in stored form (both pairs of the lane, this pair's in half `half`)
+    __device__ __forceinline__ void grid_load(const WaveMem &wm, int ql, unsigned &w) const
     {
         const int L = stretch(), ie = I - L, je = J - L;
-        const int m = max(ie >> 4, 1), slot = (m - 1) >> 1, c = max(je - 1, 0); // (a stretch that ends on a border: some valid dword, not used)
-        w = reinterpret_cast<const unsigned *>(rowrec_lane + ((size_t)slot * ng8 + (c >> 3)) * 512)[half * 16 + (c & 7) * 2 + ((m & 1) ^ 1)];
+        w = wm.row16(ie >> 4, ql)[(size_t)max(je, 1) * 64].x; // (a stretch that ends on a border: some valid entry, not used)
     }
     // returns true when the stretch was taken and the walk can try the next one
-    __device__ __forceinline__ bool verify_apply(const unsigned (&tw)[5], const unsigned (&qw)[5], unsigned w, const BlockGeom &g)
+    __device__ __forceinline__ bool verify_apply(const unsigned (&tw)[5], const unsigned (&qw)[5], unsigned w, int half, const BlockGeom &g)
     {
         if (!can_verify()) return false;
         const int L = stretch(), ie = I - L, je = J - L;
         const int he = ie == 0 ? border(je, g.gopen, g.gext, g.indel)
                      : je == 0 ? border(ie, g.gopen, g.gext, g.indel)
-                               : lo16(w) - (ie + je) * g.gext - g.base;
+                               : (half ? hi16(w) : lo16(w)) - (ie + je) * g.gext - g.base;
         const int sum = L * g.match + mismatches(tw, qw, L, g.codes) * (g.mismatch - g.match);
         if (hc - he != sum) {
             stuck = true; // this block's flags, then
@@ -482,11 +333,124 @@ struct PathWalk {
     }
 };
 
+// ---- pass 1: strip k, score only, keeping the rows and the column checkpoints
+template <bool LAST, bool CODES>
+__device__ __forceinline__ void ck_strip(const int k, const int tl, const int ql, const int nb, const WaveMem &wm, const unsigned *qst, const unsigned *tst,
+                                         const LaneConsts &c, const int gopen, const int gext, const int base, const bool indel, int &bestA,
+                                         int &bestA_i, int &bestB, int &bestB_i)
+{
+    const int i0 = k * R;
+    unsigned h[R], f[R], t[R];
+#pragma unroll
+    for (int r4 = 0; r4 < R / 4; ++r4) {
+        const unsigned ta = tst[(size_t)(2 * ((i0 >> 2) + r4)) * 64], tb = tst[(size_t)(2 * ((i0 >> 2) + r4) + 1) * 64];
+        t[4 * r4 + 0] = __builtin_amdgcn_perm(tb, ta, 0x0c040c00u) | (CODES ? CODE_SEL : 0u);
+        t[4 * r4 + 1] = __builtin_amdgcn_perm(tb, ta, 0x0c050c01u) | (CODES ? CODE_SEL : 0u);
+        t[4 * r4 + 2] = __builtin_amdgcn_perm(tb, ta, 0x0c060c02u) | (CODES ? CODE_SEL : 0u);
+        t[4 * r4 + 3] = __builtin_amdgcn_perm(tb, ta, 0x0c070c03u) | (CODES ? CODE_SEL : 0u);
+    }
+    // column 0 (sw.cpp:24,38,47-49), as in sw_dp16_lane.hip
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = i0 + r + 1;
+        const int hb = border(row, gopen, gext, indel) + row * gext + base;
+        h[r] = pack2(hb, hb);
+        f[r] = pk_sub(h[r], c.o_e);
+    }
+    const int rl = tl - 1 - i0;
+
+    const uint2 *bp = wm.bnd + ((size_t)k * (ql + 1) + 1) * 64; // column j of the row entering this strip
+    uint2 *bo = wm.bnd + ((size_t)(k + 1) * (ql + 1) + 1) * 64; // ... of the row leaving it
+    uint2 *mp = wm.mid + (size_t)k * ql * 64;
+    unsigned *ckp = wm.ck + (size_t)k * (nb - 1) * 64 * 64;
+    unsigned hd = bp[-64].x; // H[32 k][0]
+    // column u (0 .. 3) of the group whose query dwords are qa / qb
+    auto one_column = [&](const uint2 top, const unsigned qa, const unsigned qb, const int u) {
+        unsigned e = top.y;
+        uint2 mid;
+        if (CODES)
+            column<R, true, true, true>(h, f, t, code_table((qa >> (8 * u)) & 0xffu), hd, e, c, nullptr, &mid, code_table((qb >> (8 * u)) & 0xffu));
+        else
+            column<R, true, true, false>(h, f, t, __builtin_amdgcn_perm(qb, qa, 0x0c040c00u + 0x00010001u * u), hd, e, c, nullptr, &mid);
+        hd = top.x;
+        if (!(MGL_CK_ABLATE & 4)) mp[0] = mid;
+        mp += 64;
+        if (!LAST) {
+            bo[0] = make_uint2(h[R - 1], e);
+        } else { // the row the last-row scan reads: H[tl][j]
+            unsigned bot = h[R - 1];
+            if (rl != R - 1) {
+#pragma unroll
+                for (int r = 0; r < R - 1; ++r) bot = (r == rl) ? h[r] : bot;
+            }
+            bo[0] = make_uint2(bot, 0u);
+        }
+        bo += 64;
+    };
+    auto save = [&]() { // the state BEFORE column j: H[.][j-1] and the horizontal-gap values entering column j
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            ckp[(size_t)(2 * r) * 64] = h[r];
+            ckp[(size_t)(2 * r + 1) * 64] = f[r];
+        }
+        ckp += 64 * 64;
+    };
+    // The carry row and the query are read ONE GROUP OF FOUR COLUMNS AHEAD: what a group needs was requested at the top of the
+    // group before it, so its latency -- and the acknowledgements of the stores issued in between, which s_waitcnt vmcnt counts
+    // in the same queue -- hides behind a thousand instructions of arithmetic instead of stalling the wave at every group (measured
+    // before: a third of the waves' lifetime in s_waitcnt at two waves per SIMD).  Reads past column ql stay inside the wave's own
+    // region (the next kept row follows) and are never used.
+    int j = 1;
+    uint2 n0 = bp[0], n1 = bp[64], n2 = bp[128], n3 = bp[192];
+    unsigned nqa = qst[0], nqb = qst[64];
+    for (; j + 3 <= ql; j += 4) {
+        if (!(MGL_CK_ABLATE & 2) && j > 1 && ((j - 1) & (CK - 1)) == 0) save(); // (column 0 is a formula: no checkpoint)
+        const uint2 top0 = n0, top1 = n1, top2 = n2, top3 = n3;
+        const unsigned qa = nqa, qb = nqb;
+        qst += 128;
+        bp += 256;
+        n0 = bp[0];
+        n1 = bp[64];
+        n2 = bp[128];
+        n3 = bp[192];
+        nqa = qst[0];
+        nqb = qst[64];
+        one_column(top0, qa, qb, 0);
+        one_column(top1, qa, qb, 1);
+        one_column(top2, qa, qb, 2);
+        one_column(top3, qa, qb, 3);
+    }
+    if (j <= ql) { // the last one to three columns (j - 1 is a multiple of four here)
+        if (j > 1 && ((j - 1) & (CK - 1)) == 0) save();
+        one_column(n0, nqa, nqb, 0);
+        if (j + 1 <= ql) one_column(n1, nqa, nqb, 1);
+        if (j + 2 <= ql) one_column(n2, nqa, nqb, 2);
+    }
+    // last column (sw.cpp:100-104), as in sw_dp16_lane.hip
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = i0 + r + 1;
+        if (row <= tl) {
+            const int unshift = -(row + ql) * gext - base;
+            const int ca = lo16(h[r]) + unshift, cb = hi16(h[r]) + unshift;
+            if (ca >= bestA) {
+                bestA = ca;
+                bestA_i = row;
+            }
+            if (cb >= bestB) {
+                bestB = cb;
+                bestB_i = row;
+            }
+        }
+    }
+}
+
 // ---- pass 2: recompute the flags of block (sA, bA) for the low halves and of block (sB, bB) for the high halves; s = 16-row band
-// (strip s / 2, its upper or lower half), b = block of CK columns.  rowrec / ckrec: the wave's records + this lane's 8 uint4.
+// (strip s / 2, its upper or lower half), b = block of CK columns.  needA / needB: the pair's walk waits for this block (a pair
+// that does not fetches nothing; its half computes garbage nobody reads).
 template <bool CODES>
-__device__ __forceinline__ void ck_block(const int sA, const int bA, const int sB, const int bB, const BlockGeom &g, const uint4 *rowrec,
-                                         const uint4 *ckrec, const unsigned *qst, const unsigned *tst, uint4 *blk, const LaneConsts &c)
+__device__ __forceinline__ void ck_block(const int sA, const int bA, const int sB, const int bB, const bool needA, const bool needB, const BlockGeom &g,
+                                         const WaveMem &wm, const unsigned *qst, const unsigned *tst, const LaneConsts &c)
 {
     unsigned h[RB], f[RB], t[RB];
 #pragma unroll
@@ -497,58 +461,63 @@ __device__ __forceinline__ void ck_block(const int sA, const int bA, const int s
         t[4 * r4 + 2] = __builtin_amdgcn_perm(tb, ta, 0x0c060c02u) | (CODES ? CODE_SEL : 0u);
         t[4 * r4 + 3] = __builtin_amdgcn_perm(tb, ta, 0x0c070c03u) | (CODES ? CODE_SEL : 0u);
     }
+    // the state entering the block's first column: the checkpoint of column CK b, or column 0 by its formula (sw.cpp:24,38,47-49)
     {
-        const uint4 *ca = ckrec + ((size_t)(((sA >> 1) * g.nb + bA) * 2 + 0) * 64) * 8 + (sA & 1) * 4;
-        const uint4 *cb = ckrec + ((size_t)(((sB >> 1) * g.nb + bB) * 2 + 1) * 64) * 8 + (sB & 1) * 4;
+        const unsigned *ca = wm.ck + ((size_t)((sA >> 1) * (g.nb - 1) + max(bA - 1, 0)) * 64 + (sA & 1) * 2 * RB) * 64;
+        const unsigned *cb = wm.ck + ((size_t)((sB >> 1) * (g.nb - 1) + max(bB - 1, 0)) * 64 + (sB & 1) * 2 * RB) * 64;
+        unsigned va[2 * RB], vb[2 * RB];
 #pragma unroll
-        for (int i4 = 0; i4 < 2; ++i4) {
-            const uint4 ha = ca[i4], hb = cb[i4], fa = ca[2 + i4], fb = cb[2 + i4];
-            h[8 * i4 + 0] = lows(ha.x, hb.x);
-            h[8 * i4 + 1] = highs(ha.x, hb.x);
-            h[8 * i4 + 2] = lows(ha.y, hb.y);
-            h[8 * i4 + 3] = highs(ha.y, hb.y);
-            h[8 * i4 + 4] = lows(ha.z, hb.z);
-            h[8 * i4 + 5] = highs(ha.z, hb.z);
-            h[8 * i4 + 6] = lows(ha.w, hb.w);
-            h[8 * i4 + 7] = highs(ha.w, hb.w);
-            f[8 * i4 + 0] = lows(fa.x, fb.x);
-            f[8 * i4 + 1] = highs(fa.x, fb.x);
-            f[8 * i4 + 2] = lows(fa.y, fb.y);
-            f[8 * i4 + 3] = highs(fa.y, fb.y);
-            f[8 * i4 + 4] = lows(fa.z, fb.z);
-            f[8 * i4 + 5] = highs(fa.z, fb.z);
-            f[8 * i4 + 6] = lows(fa.w, fb.w);
-            f[8 * i4 + 7] = highs(fa.w, fb.w);
+        for (int x = 0; x < 2 * RB; ++x) va[x] = vb[x] = 0u;
+        if (needA && bA > 0) {
+#pragma unroll
+            for (int x = 0; x < 2 * RB; ++x) va[x] = ca[(size_t)x * 64];
+        }
+        if (needB && bB > 0) {
+#pragma unroll
+            for (int x = 0; x < 2 * RB; ++x) vb[x] = cb[(size_t)x * 64];
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int rowA = sA * RB + r + 1, rowB = sB * RB + r + 1;
+            const int fa_ = border(rowA, g.gopen, g.gext, g.indel) + rowA * g.gext + g.base, fb_ = border(rowB, g.gopen, g.gext, g.indel) + rowB * g.gext + g.base;
+            const unsigned ha = bA > 0 ? va[2 * r] : (unsigned)fa_, hb = bB > 0 ? vb[2 * r] : (unsigned)fb_ << 16;
+            const unsigned ga = bA > 0 ? va[2 * r + 1] : (unsigned)(fa_ - (g.gopen - g.gext)), gb = bB > 0 ? vb[2 * r + 1] : (unsigned)(fb_ - (g.gopen - g.gext)) << 16;
+            h[r] = lo_hi(ha, hb);
+            f[r] = lo_hi(ga, gb);
         }
     }
-    // the row entering the band: the middle row of its strip (odd s), or the last row of the strip above / the border (even s)
-    // (band 0: the border row, sw.cpp:14-18,31-35, by its formula -- every pair has the same)
-    const int slotA = max(((sA + 1) >> 1) - 1, 0), slotB = max(((sB + 1) >> 1) - 1, 0);
-    const bool botA = (sA & 1) == 0, botB = (sB & 1) == 0, topA = sA == 0, topB = sB == 0;
-    const int hb_k = g.indel ? g.gext - g.gopen + g.base : g.base, hb_j = g.indel ? 0 : g.gext, oe = g.gopen - g.gext; // H[0][j] = hb_k + j hb_j (j > 0)
-    const uint4 *ra = rowrec + ((size_t)slotA * g.ng8 * 64) * 8, *rb = rowrec + ((size_t)slotB * g.ng8 * 64) * 8 + 4;
-    // H[16 s][CK b]: the entry of the column before the block, or the border column (sw.cpp:24,38)
-    unsigned hdA, hdB;
+    // the row entering the band, per column: row 16 s of the pair (WaveMem::row16; row 0 is the border row, kept like any other)
+    const uint2 *ra = wm.row16(sA, g.ql), *rb = wm.row16(sB, g.ql);
+    unsigned hd;
     {
-        const int rowA = sA * RB, rowB = sB * RB;
-        const unsigned fa_ = (unsigned)(border(rowA, g.gopen, g.gext, g.indel) + rowA * g.gext + g.base);
-        const unsigned fb_ = (unsigned)(border(rowB, g.gopen, g.gext, g.indel) + rowB * g.gext + g.base);
-        const unsigned *pa = reinterpret_cast<const unsigned *>(ra + ((size_t)max((CK / 8) * bA - 1, 0) * 64) * 8) + 14 + (botA ? 1 : 0);
-        const unsigned *pb = reinterpret_cast<const unsigned *>(rb + ((size_t)max((CK / 8) * bB - 1, 0) * 64) * 8) + 14 + (botB ? 1 : 0);
-        const unsigned la = *pa, lb = *pb;
-        hdA = bA > 0 ? (topA ? (unsigned)(hb_k + CK * bA * hb_j) : la) : fa_;
-        hdB = bB > 0 ? (topB ? (unsigned)(hb_k + CK * bB * hb_j) : lb) : fb_;
+        unsigned a0 = 0u, b0 = 0u; // H[16 s][CK b]
+        if (needA) a0 = ra[(size_t)(CK * bA) * 64].x;
+        if (needB) b0 = rb[(size_t)(CK * bB) * 64].x;
+        if (sA & 1) { // (the middle rows start at column 1: column 0 by its formula)
+            const int row = sA * RB;
+            const int v = border(row, g.gopen, g.gext, g.indel) + row * g.gext + g.base;
+            a0 = bA > 0 ? a0 : (unsigned)v;
+        }
+        if (sB & 1) {
+            const int row = sB * RB;
+            const int v = border(row, g.gopen, g.gext, g.indel) + row * g.gext + g.base;
+            b0 = bB > 0 ? b0 : (unsigned)v << 16;
+        }
+        hd = lo_hi(a0, b0);
     }
-    unsigned hd = lows(hdA, hdB);
     const int qmax = ((g.ql + 3) >> 2) - 1;
 #pragma unroll 1
     for (int gg = 0; gg < CK / 8; ++gg) {
-        const uint4 *pa = ra + ((size_t)min((CK / 8) * bA + gg, g.ng8 - 1) * 64) * 8, *pb = rb + ((size_t)min((CK / 8) * bB + gg, g.ng8 - 1) * 64) * 8;
-        uint4 va[4], vb[4];
+        uint2 va[8], vb[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { // (a group past ql: the last group again -- flags of columns past ql are never read)
-            va[u] = pa[u];
-            vb[u] = pb[u];
+        for (int u = 0; u < 8; ++u) va[u] = vb[u] = make_uint2(0u, 0u);
+        if (needA) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) va[u] = ra[(size_t)min(CK * bA + 8 * gg + u + 1, g.ql) * 64]; // (past ql: the last column again -- flags never read)
+        }
+        if (needB) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vb[u] = rb[(size_t)min(CK * bB + 8 * gg + u + 1, g.ql) * 64];
         }
         unsigned qa[2], qb[2];
 #pragma unroll
@@ -558,18 +527,14 @@ __device__ __forceinline__ void ck_block(const int sA, const int bA, const int s
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const unsigned ma = (u & 1) ? va[u >> 1].z : va[u >> 1].x, ba = (u & 1) ? va[u >> 1].w : va[u >> 1].y;
-            const unsigned mb = (u & 1) ? vb[u >> 1].z : vb[u >> 1].x, bb = (u & 1) ? vb[u >> 1].w : vb[u >> 1].y;
-            const int ha_ = hb_k + (CK * bA + 8 * gg + u + 1) * hb_j, hb_ = hb_k + (CK * bB + 8 * gg + u + 1) * hb_j;
-            const unsigned ea = topA ? pack2(ha_, ha_ - oe) : botA ? ba : ma, eb = topB ? pack2(hb_, hb_ - oe) : botB ? bb : mb; // {H : 16, E : 16} of the row above, this column
-            unsigned e = highs(ea, eb);
+            unsigned e = lo_hi(va[u].y, vb[u].y);
+            uint4 *const out = wm.blk + (size_t)(8 * gg + u) * 64;
             if (CODES)
-                column<RB, false, false, true>(h, f, t, code_table((qa[u >> 2] >> (8 * (u & 3))) & 0xffu), hd, e, c, blk + (size_t)(8 * gg + u) * 64, nullptr,
+                column<RB, false, false, true>(h, f, t, code_table((qa[u >> 2] >> (8 * (u & 3))) & 0xffu), hd, e, c, out, nullptr,
                                                code_table((qb[u >> 2] >> (8 * (u & 3))) & 0xffu));
             else
-                column<RB, false, false, false>(h, f, t, __builtin_amdgcn_perm(qb[u >> 2], qa[u >> 2], 0x0c040c00u + 0x00010001u * (u & 3)), hd, e, c,
-                                                blk + (size_t)(8 * gg + u) * 64);
-            hd = lows(ea, eb);
+                column<RB, false, false, false>(h, f, t, __builtin_amdgcn_perm(qb[u >> 2], qa[u >> 2], 0x0c040c00u + 0x00010001u * (u & 3)), hd, e, c, out);
+            hd = lo_hi(va[u].x, vb[u].x);
         }
     }
 }
@@ -698,20 +663,18 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
         asm volatile("" : "+s"(c.k12[u]), "+s"(c.k34[u]));
     }
 
-    const int strips = lane_strips(tl, R), nb = lane_ck_blocks(ql), ng8 = lane_ck_groups(ql);
-    // the wave's scratch, as in sw_dp16_lane.hip: the carry row between strips [column 0 .. ql][lane] x {H, E}, then both queries
-    // and both targets of every lane transposed to [4-base block][A | B][lane] dwords
-    unsigned char *const wave_scratch = a.scratch + (size_t)gw * (size_t)lane_scratch_bytes(a.uni_tl, a.uni_ql, R);
-    uint2 *const bnd = reinterpret_cast<uint2 *>(wave_scratch) + lane;
-    unsigned *const qst = reinterpret_cast<unsigned *>(wave_scratch + (size_t)lane_bnd_entries(ql) * 8) + lane;
+    const int strips = lane_strips(tl, R), nb = lane_ck_blocks(ql);
+    // the wave's scratch: both queries and both targets of every lane transposed to [4-base block][A | B][lane] dwords
+    unsigned *const qst = reinterpret_cast<unsigned *>(a.scratch + (size_t)gw * (size_t)lane_ck_scratch_bytes(a.uni_tl, a.uni_ql)) + lane;
     unsigned *const tst = qst + (size_t)((ql + 3) >> 2) * 128;
-    // the wave's region: row records, checkpoint records, block buffer
-    uint4 *const region = reinterpret_cast<uint4 *>(a.tb + (size_t)gw * (size_t)a.tb_stride_words);
-    uint4 *const rowrec = region;
-    uint4 *const ckrec = region + (size_t)strips * ng8 * 512;
-    uint4 *const blk = ckrec + (size_t)strips * nb * 2 * 512 + lane;
-    __shared__ unsigned stage_all[4 * 64 * STAGE_ROW];
-    unsigned *const stage = stage_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (64 * STAGE_ROW);
+    WaveMem wm;
+    {
+        uint2 *const region = reinterpret_cast<uint2 *>(a.tb + (size_t)gw * (size_t)a.tb_stride_words);
+        wm.bnd = region + lane;
+        wm.mid = wm.bnd + (size_t)(strips + 1) * (ql + 1) * 64;
+        wm.ck = reinterpret_cast<unsigned *>(region + ((size_t)(strips + 1) * (ql + 1) + (size_t)strips * ql) * 64) + lane;
+        wm.blk = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned *>(region) + ((size_t)(strips + 1) * (ql + 1) * 2 + (size_t)strips * ql * 2 + (size_t)strips * (nb - 1) * 64) * 64) + lane;
+    }
     // ---- staging: both sequences of every lane, transposed to [4-base block][A | B][lane] dwords in the wave's scratch -- as BASE
     // CODES where the wave's targets allow it (sw_lane_cell.h: 2-bit packed inputs always do; ASCII targets when every byte is one of
     // ACGT -- the queries may hold anything), else as the raw bytes.
@@ -737,7 +700,12 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
         for (int j = 0; j <= ql; ++j) {
             const int hb0 = border(j, gopen, gext, indel) + j * gext + base;
             const unsigned hp = pack2(hb0, hb0);
-            bnd[(size_t)j * 64] = make_uint2(hp, pk_sub(hp, c.o_e));
+            wm.bnd[(size_t)j * 64] = make_uint2(hp, pk_sub(hp, c.o_e));
+        }
+        // column 0 of the rows entering the other strips: H[32 k][0] (what a strip's first diagonal starts from)
+        for (int k = 1; k <= strips; ++k) {
+            const int hb0 = border(k * R, gopen, gext, indel) + k * R * gext + base;
+            wm.bnd[(size_t)k * (ql + 1) * 64] = make_uint2(pack2(hb0, hb0), 0u);
         }
     }
 
@@ -745,28 +713,23 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
     // ---- pass 1
     int bestA = NEG_INF, bestA_i = -1, bestB = NEG_INF, bestB_i = -1;
     if (codes) {
-        for (int k = 0; k < strips - 1; ++k)
-            ck_strip<false, true>(k * R, tl, ql, bnd, stage, rowrec + (size_t)k * ng8 * 512, ckrec + (size_t)k * nb * 2 * 512, lane, qst, tst, c, gopen,
-                                  gext, base, indel, bestA, bestA_i, bestB, bestB_i);
-        ck_strip<true, true>((strips - 1) * R, tl, ql, bnd, stage, rowrec + (size_t)(strips - 1) * ng8 * 512, ckrec + (size_t)(strips - 1) * nb * 2 * 512,
-                             lane, qst, tst, c, gopen, gext, base, indel, bestA, bestA_i, bestB, bestB_i);
+        for (int k = 0; k < strips - 1; ++k) ck_strip<false, true>(k, tl, ql, nb, wm, qst, tst, c, gopen, gext, base, indel, bestA, bestA_i, bestB, bestB_i);
+        ck_strip<true, true>(strips - 1, tl, ql, nb, wm, qst, tst, c, gopen, gext, base, indel, bestA, bestA_i, bestB, bestB_i);
     } else {
-        for (int k = 0; k < strips - 1; ++k)
-            ck_strip<false, false>(k * R, tl, ql, bnd, stage, rowrec + (size_t)k * ng8 * 512, ckrec + (size_t)k * nb * 2 * 512, lane, qst, tst, c, gopen,
-                                   gext, base, indel, bestA, bestA_i, bestB, bestB_i);
-        ck_strip<true, false>((strips - 1) * R, tl, ql, bnd, stage, rowrec + (size_t)(strips - 1) * ng8 * 512, ckrec + (size_t)(strips - 1) * nb * 2 * 512,
-                              lane, qst, tst, c, gopen, gext, base, indel, bestA, bestA_i, bestB, bestB_i);
+        for (int k = 0; k < strips - 1; ++k) ck_strip<false, false>(k, tl, ql, nb, wm, qst, tst, c, gopen, gext, base, indel, bestA, bestA_i, bestB, bestB_i);
+        ck_strip<true, false>(strips - 1, tl, ql, nb, wm, qst, tst, c, gopen, gext, base, indel, bestA, bestA_i, bestB, bestB_i);
     }
 
     CK_PHASE(1); // pass 1
-    // ---- last row (sw.cpp:116-127), as in sw_dp16_lane.hip
+    // ---- last row (sw.cpp:116-127), as in sw_dp16_lane.hip: the last strip left H[tl][j] in the row "entering strip `strips`"
     int rmA = NEG_INF, rdA = 0x7fffffff, rjA = 0x7fffffff, rmB = NEG_INF, rdB = 0x7fffffff, rjB = 0x7fffffff;
     int cornerA = 0, cornerB = 0; // H[tl][ql]
     {
+        const uint2 *const last = wm.bnd + (size_t)strips * (ql + 1) * 64;
         for (int j0 = 1; j0 <= ql; j0 += 8) { // eight columns' loads at once
             unsigned bots[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) bots[u] = bnd[(size_t)min(j0 + u, ql) * 64].x;
+            for (int u = 0; u < 8; ++u) bots[u] = last[(size_t)min(j0 + u, ql) * 64].x;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int j = j0 + u;
@@ -814,11 +777,9 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
     PathWalk wa, wb;
     wa.start(walk, rec[0], oA, tl, ql, lvalid, cornerA);
     wb.start(walk, rec[1], oB, tl, ql, validB, cornerB);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the wave's records are in memory (written by other lanes of this wave)
     BlockGeom geom;
     geom.ql = ql;
     geom.nb = nb;
-    geom.ng8 = ng8;
     geom.match = match;
     geom.mismatch = a.mismatch;
     geom.gopen = gopen;
@@ -826,35 +787,34 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
     geom.base = base;
     geom.indel = indel;
     geom.codes = codes;
-    const uint32_t *const blk_words = reinterpret_cast<const uint32_t *>(blk);
+    const uint32_t *const blk_words = reinterpret_cast<const uint32_t *>(wm.blk);
     const bool by_score = !(MGL_CK_ABLATE & 8);
     const int tblocks = strips * (R / 4), qblocks = (ql + 3) >> 2;
-    const uint4 *const rowrec_lane = rowrec + (size_t)lane * 8, *const ckrec_lane = ckrec + (size_t)lane * 8;
     while (!(MGL_CK_ABLATE & 1) && __builtin_amdgcn_ballot_w64(!wa.done || !wb.done) != 0) {
         if (by_score) {
             for (;;) { // every walk standing at a cell takes the diagonal stretches whose scores add up (PathWalk::verify_apply)
                 unsigned ta[5], qa[5], tb[5], qb[5], ga = 0, gb = 0;
                 if (wa.can_verify()) {
                     wa.win_load(tst, qst, 0, tblocks, qblocks, ta, qa);
-                    wa.grid_load(rowrec_lane, 0, ng8, ga);
+                    wa.grid_load(wm, ql, ga);
                 }
                 if (wb.can_verify()) {
                     wb.win_load(tst, qst, 1, tblocks, qblocks, tb, qb);
-                    wb.grid_load(rowrec_lane, 1, ng8, gb);
+                    wb.grid_load(wm, ql, gb);
                 }
-                const bool ma = wa.verify_apply(ta, qa, ga, geom), mb = wb.verify_apply(tb, qb, gb, geom);
+                const bool ma = wa.verify_apply(ta, qa, ga, 0, geom), mb = wb.verify_apply(tb, qb, gb, 1, geom);
                 if (!__builtin_amdgcn_ballot_w64(ma || mb)) break;
             }
             CK_PHASE(3); // stretches that add up
             if (__builtin_amdgcn_ballot_w64(!wa.done || !wb.done) == 0) break;
         }
-        // (a finished walk keeps recomputing some valid block: both halves run the same instructions anyway)
+        // (a finished walk's half recomputes some valid block's worth of garbage: both halves run the same instructions anyway)
         const int kA = max(wa.pi - 1, 0) >> 4, bA = max(wa.pj - 1, 0) / CK, kB = max(wb.pi - 1, 0) >> 4, bB = max(wb.pj - 1, 0) / CK;
         if (codes)
-            ck_block<true>(kA, bA, kB, bB, geom, rowrec_lane, ckrec_lane, qst, tst, blk, c);
+            ck_block<true>(kA, bA, kB, bB, !wa.done, !wb.done, geom, wm, qst, tst, c);
         else
-            ck_block<false>(kA, bA, kB, bB, geom, rowrec_lane, ckrec_lane, qst, tst, blk, c);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ck_block<false>(kA, bA, kB, bB, !wa.done, !wb.done, geom, wm, qst, tst, c);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the block's flags are in memory
         CK_PHASE(4); // a block's flags
 #ifdef MGL_CK_PHASES
         if (lane == 0) atomicAdd(&mgl_ck_phase_ticks[8], 1ull);
