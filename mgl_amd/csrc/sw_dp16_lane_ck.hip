@@ -74,10 +74,19 @@ struct WaveMem {
     uint2 *mid;    // [strip][column 1 .. ql][lane]: the row in the strip's middle (row 32 k + 16)
     unsigned *ck;  // [strip][block 1 .. nb - 1][2 r | 2 r + 1][lane]: H[.][32 b] and the horizontal-gap value of the strip's row r entering column 32 b + 1
     uint4 *blk;    // [column of the block][lane]: the recomputed flags of 16 rows
-    __device__ __forceinline__ const uint2 *row16(int m, int ql) const // row 16 m (m >= 0), indexed [column * 64]
+    // the same arrays as pass 2 addresses them: wave-uniform bases (SGPRs) and 32-bit indices that include the lane -- one address
+    // register per load instead of two, no 64-bit arithmetic in the walk
+    const uint2 *rows;     // the region: bnd at 0, mid at mid_off (entries)
+    const unsigned *cku;   // ck without the lane
+    const uint32_t *blku;  // blk without the lane, as dwords
+    const unsigned *seq;   // the wave's staged sequences: the queries' blocks at 0, the targets' at t_off (dwords)
+    unsigned mid_off, t_off, lane;
+    __device__ __forceinline__ uint2 row16(int m, int ql, int j) const // {H, E} of row 16 m (m >= 0) at column j
     {
-        return (m & 1) ? mid + ((size_t)(m >> 1) * ql - 1) * 64 : bnd + (size_t)(m >> 1) * (ql + 1) * 64;
+        return rows[(m & 1) ? mid_off + (unsigned)(((m >> 1) * ql + j - 1) * 64) + lane : (unsigned)(((m >> 1) * (ql + 1) + j) * 64) + lane];
     }
+    __device__ __forceinline__ unsigned qblock(int blk4, int half) const { return seq[(unsigned)((2 * blk4 + half) * 64) + lane]; }
+    __device__ __forceinline__ unsigned tblock(int blk4, int half) const { return seq[t_off + (unsigned)((2 * blk4 + half) * 64) + lane]; }
 };
 
 // ---- pass 2: the walk of one pair (calculateCigar, sw.cpp:149-255) as a machine that can stop at a block's edge and go on in
@@ -148,14 +157,14 @@ struct PathWalk {
     {
         return !done && pi >= 1 && pj >= 1 && ((pi - 1) >> 4) == k && (pj - 1) / CK == b;
     }
-    __device__ __forceinline__ void load(const uint32_t *blk, unsigned (&w)[LOOK]) const
+    __device__ __forceinline__ void load(const WaveMem &wm, unsigned (&w)[LOOK]) const
     {
         const int rr = (pi - 1) & (RB - 1), cl = (pj - 1) & (CK - 1);
         const int di = mode != 2, dj = mode != 1;
 #pragma unroll
         for (int u = 0; u < LOOK; ++u) { // (cells past the block's edge: some valid address, masked in apply())
             const int r = max(rr - u * di, 0), cc = max(cl - u * dj, 0);
-            w[u] = blk[(size_t)cc * 256 + (r >> 2)];
+            w[u] = wm.blku[(unsigned)(cc * 256 + (r >> 2)) + 4u * wm.lane];
         }
     }
     // returns false when the walk cannot go on inside this block (finished, or the cell it needs next is in another block)
@@ -163,12 +172,23 @@ struct PathWalk {
     __device__ __forceinline__ bool apply(const unsigned (&w)[LOOK], const unsigned (&tw)[5], const unsigned (&qw)[5], int half, int k, int b,
                                           const BlockGeom &g)
     {
+        char op = 0; // the CIGAR element this round completes, if any: taken in ONE place (take() is a large piece of code)
+        int len = 0;
+        const bool more = moves(w, tw, qw, half, k, b, g, op, len);
+        if (len > 0) take(op, len);
+        return more;
+    }
+    __device__ __forceinline__ bool moves(const unsigned (&w)[LOOK], const unsigned (&tw)[5], const unsigned (&qw)[5], int half, int k, int b,
+                                          const BlockGeom &g, char &op, int &len)
+    {
         if (done) return false;
         if (mode == 1 && pi < 1) { // the run reached the matrix's top (TbView::vrun: r >= 1)
-            take('D', n);
+            op = 'D';
+            len = n;
             I -= n;
         } else if (mode == 2 && pj < 1) {
-            take('I', n);
+            op = 'I';
+            len = n;
             J -= n;
         } else {
             if (((pi - 1) >> 4) != k || (pj - 1) / CK != b) return false;
@@ -192,7 +212,8 @@ struct PathWalk {
             if (mode == 0) {
                 if (cnt > 0) {
                     hc -= cnt * g.match + mismatches(tw, qw, cnt, g.codes) * (g.mismatch - g.match);
-                    take('M', cnt);
+                    op = 'M';
+                    len = cnt;
                     I -= cnt;
                     J -= cnt;
                 }
@@ -210,7 +231,8 @@ struct PathWalk {
                 if (cnt == LOOK && cnt <= room) return true; // more of the run in this block than one round looks at
                 if (cnt > room && pi >= 1) return false; // every cell up to the block's edge extends the gap: goes on in the block above
                 hc += g.gopen + (n - 1) * g.gext; // H[I][J] = E = H[I - n][J] - o - (n - 1) e (sw.cpp:73-82)
-                take('D', n);
+                op = 'D';
+                len = n;
                 I -= n;
             } else {
                 n += cnt;
@@ -218,7 +240,8 @@ struct PathWalk {
                 if (cnt == LOOK && cnt <= room) return true;
                 if (cnt > room && pj >= 1) return false;
                 hc += g.gopen + (n - 1) * g.gext; // sw.cpp:84-93
-                take('I', n);
+                op = 'I';
+                len = n;
                 J -= n;
             }
         }
@@ -240,14 +263,13 @@ struct PathWalk {
     // fit -- a gap, or a tie taken elsewhere -- does the walk need the flags of the block.
     __device__ __forceinline__ bool can_verify() const { return !done && mode == 0 && !stuck; }
     // bases I - 16 .. I - 1 (0-based) of the target and J - 16 .. J - 1 of the query: byte 15 of the window belongs to cell (I, J)
-    __device__ __forceinline__ void win_load(const unsigned *tst, const unsigned *qst, int half, int tblocks, int qblocks, unsigned (&tw)[5],
-                                             unsigned (&qw)[5]) const
+    __device__ __forceinline__ void win_load(const WaveMem &wm, int half, int tblocks, int qblocks, unsigned (&tw)[5], unsigned (&qw)[5]) const
     {
         const int dt = (I - 16) >> 2, dq = (J - 16) >> 2;
 #pragma unroll
         for (int k = 0; k < 5; ++k) { // (blocks before the sequence: block 0 again -- those bytes are never counted)
-            tw[k] = tst[(size_t)(2 * min(max(dt + k, 0), tblocks - 1) + half) * 64];
-            qw[k] = qst[(size_t)(2 * min(max(dq + k, 0), qblocks - 1) + half) * 64];
+            tw[k] = wm.tblock(min(max(dt + k, 0), tblocks - 1), half);
+            qw[k] = wm.qblock(min(max(dq + k, 0), qblocks - 1), half);
         }
     }
     // how many of the cells (I, J), (I-1, J-1) .. (I-L+1, J-L+1) hold different bases (raw byte compare, sw.cpp:55); L <= 16, I, J
@@ -265,35 +287,69 @@ struct PathWalk {
         }
         return n;
     }
-    // the end of the stretch: the next recorded row above (I - 1) / 16 * 16, or where the diagonal leaves the matrix
-    __device__ __forceinline__ int stretch() const { return min(I - (((I - 1) >> 4) << 4), J); }
-    // H of that row in stored form (both pairs of the lane, this pair's in half `half`)
-    __device__ __forceinline__ void grid_load(const WaveMem &wm, int ql, unsigned &w) const
+    // One round checks up to VB stretches at once -- from the walk's cell to each of the next VB kept rows: 64 bases of both
+    // sequences and the VB rows' H are fetched together, their addresses depend on nothing the round computes -- and takes the
+    // longest one that adds up (if the stretch to a row adds up, so does the stretch to every row before it).
+    static constexpr int VB = 4;
+    __device__ __forceinline__ void win64_load(const WaveMem &wm, int half, int tblocks, int qblocks, unsigned (&tw)[17], unsigned (&qw)[17]) const
     {
-        const int L = stretch(), ie = I - L, je = J - L;
-        w = wm.row16(ie >> 4, ql)[(size_t)max(je, 1) * 64].x; // (a stretch that ends on a border: some valid entry, not used)
+        const int dt = (I - 64) >> 2, dq = (J - 64) >> 2;
+#pragma unroll
+        for (int k = 0; k < 17; ++k) {
+            tw[k] = wm.tblock(min(max(dt + k, 0), tblocks - 1), half);
+            qw[k] = wm.qblock(min(max(dq + k, 0), qblocks - 1), half);
+        }
     }
-    // returns true when the stretch was taken and the walk can try the next one
-    __device__ __forceinline__ bool verify_apply(const unsigned (&tw)[5], const unsigned (&qw)[5], unsigned w, int half, const BlockGeom &g)
+    // the stretch to the m-th kept row above the walk's cell (m = 0: the next one), cut where the diagonal leaves the matrix
+    __device__ __forceinline__ int stretch_to(int m) const { return min(I - max((((I - 1) >> 4) - m) << 4, 0), J); }
+    // H of those rows in stored form (both pairs of the lane)
+    __device__ __forceinline__ void grid_load(const WaveMem &wm, int ql, unsigned (&w)[VB]) const
+    {
+#pragma unroll
+        for (int m = 0; m < VB; ++m) {
+            const int L = stretch_to(m), ie = I - L, je = J - L;
+            w[m] = wm.row16(ie >> 4, ql, max(je, 1)).x; // (a stretch that ends on a border: some valid entry, not used)
+        }
+    }
+    // returns true when all VB stretches were taken and the walk can try the next ones
+    __device__ __forceinline__ bool verify_apply(const unsigned (&tw)[17], const unsigned (&qw)[17], const unsigned (&w)[VB], int half, const BlockGeom &g)
     {
         if (!can_verify()) return false;
-        const int L = stretch(), ie = I - L, je = J - L;
-        const int he = ie == 0 ? border(je, g.gopen, g.gext, g.indel)
-                     : je == 0 ? border(ie, g.gopen, g.gext, g.indel)
-                               : (half ? hi16(w) : lo16(w)) - (ie + je) * g.gext - g.base;
-        const int sum = L * g.match + mismatches(tw, qw, L, g.codes) * (g.mismatch - g.match);
-        if (hc - he != sum) {
-            stuck = true; // this block's flags, then
-            return false;
+        // bit u of `differ`: the bases of cell (I - u, J - u) differ (byte 63 - u of the window)
+        const unsigned st = (unsigned)(I - 64) & 3u, sq = (unsigned)(J - 64) & 3u;
+        unsigned long long differ = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const unsigned tt = __builtin_amdgcn_alignbyte(tw[k + 1], tw[k], st);
+            const unsigned nz = nonzero_bytes((g.codes ? tt << 3 : tt) ^ __builtin_amdgcn_alignbyte(qw[k + 1], qw[k], sq)) >> 7;
+            const unsigned nib = ((nz * 0x08040201u) >> 24) & 0xfu; // byte 3 -> bit 0 .. byte 0 -> bit 3
+            differ |= (unsigned long long)nib << (4 * (15 - k));
         }
-        take('M', L);
-        I = ie;
-        J = je;
-        hc = he;
-        pi = I;
-        pj = J;
-        done = !(I > 0 && J > 0); // sw.cpp:214
-        return !done;
+        int took = 0, h_at = hc;
+        bool all = true;
+#pragma unroll
+        for (int m = 0; m < VB; ++m) {
+            const int L = stretch_to(m), ie = I - L, je = J - L;
+            const int he = ie == 0 ? border(je, g.gopen, g.gext, g.indel)
+                         : je == 0 ? border(ie, g.gopen, g.gext, g.indel)
+                                   : (half ? hi16(w[m]) : lo16(w[m])) - (ie + je) * g.gext - g.base;
+            const unsigned long long in = L >= 64 ? ~0ull : (1ull << L) - 1ull;
+            const bool ok = hc - he == L * g.match + __popcll(differ & in) * (g.mismatch - g.match);
+            took = ok ? L : took; // (the stretches that add up are the first ones: each contains the one before)
+            h_at = ok ? he : h_at;
+            all = all && ok;
+        }
+        stuck = !all; // the first stretch that does not add up holds a gap (or a tie taken elsewhere): this block's flags, then
+        if (took > 0) {
+            take('M', took);
+            I -= took;
+            J -= took;
+            hc = h_at;
+            pi = I;
+            pj = J;
+            done = !(I > 0 && J > 0); // sw.cpp:214
+        }
+        return all && !done;
     }
     // overhangs, text, per-pair results (walk_and_write's tail + traceback_one_pair)
     __device__ __forceinline__ void finish(const TbArgs &a, const DpRecord &r, int64_t o)
@@ -450,12 +506,12 @@ __device__ __forceinline__ void ck_strip(const int k, const int tl, const int ql
 // that does not fetches nothing; its half computes garbage nobody reads).
 template <bool CODES>
 __device__ __forceinline__ void ck_block(const int sA, const int bA, const int sB, const int bB, const bool needA, const bool needB, const BlockGeom &g,
-                                         const WaveMem &wm, const unsigned *qst, const unsigned *tst, const LaneConsts &c)
+                                         const WaveMem &wm, const LaneConsts &c)
 {
     unsigned h[RB], f[RB], t[RB];
 #pragma unroll
     for (int r4 = 0; r4 < RB / 4; ++r4) {
-        const unsigned ta = tst[(size_t)(2 * (sA * (RB / 4) + r4)) * 64], tb = tst[(size_t)(2 * (sB * (RB / 4) + r4) + 1) * 64];
+        const unsigned ta = wm.tblock(sA * (RB / 4) + r4, 0), tb = wm.tblock(sB * (RB / 4) + r4, 1);
         t[4 * r4 + 0] = __builtin_amdgcn_perm(tb, ta, 0x0c040c00u) | (CODES ? CODE_SEL : 0u);
         t[4 * r4 + 1] = __builtin_amdgcn_perm(tb, ta, 0x0c050c01u) | (CODES ? CODE_SEL : 0u);
         t[4 * r4 + 2] = __builtin_amdgcn_perm(tb, ta, 0x0c060c02u) | (CODES ? CODE_SEL : 0u);
@@ -463,18 +519,18 @@ __device__ __forceinline__ void ck_block(const int sA, const int bA, const int s
     }
     // the state entering the block's first column: the checkpoint of column CK b, or column 0 by its formula (sw.cpp:24,38,47-49)
     {
-        const unsigned *ca = wm.ck + ((size_t)((sA >> 1) * (g.nb - 1) + max(bA - 1, 0)) * 64 + (sA & 1) * 2 * RB) * 64;
-        const unsigned *cb = wm.ck + ((size_t)((sB >> 1) * (g.nb - 1) + max(bB - 1, 0)) * 64 + (sB & 1) * 2 * RB) * 64;
+        const unsigned ia = (unsigned)((((sA >> 1) * (g.nb - 1) + max(bA - 1, 0)) * 64 + (sA & 1) * 2 * RB) * 64) + wm.lane;
+        const unsigned ib = (unsigned)((((sB >> 1) * (g.nb - 1) + max(bB - 1, 0)) * 64 + (sB & 1) * 2 * RB) * 64) + wm.lane;
         unsigned va[2 * RB], vb[2 * RB];
 #pragma unroll
         for (int x = 0; x < 2 * RB; ++x) va[x] = vb[x] = 0u;
         if (needA && bA > 0) {
 #pragma unroll
-            for (int x = 0; x < 2 * RB; ++x) va[x] = ca[(size_t)x * 64];
+            for (int x = 0; x < 2 * RB; ++x) va[x] = wm.cku[ia + (unsigned)(x * 64)];
         }
         if (needB && bB > 0) {
 #pragma unroll
-            for (int x = 0; x < 2 * RB; ++x) vb[x] = cb[(size_t)x * 64];
+            for (int x = 0; x < 2 * RB; ++x) vb[x] = wm.cku[ib + (unsigned)(x * 64)];
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
@@ -487,12 +543,11 @@ __device__ __forceinline__ void ck_block(const int sA, const int bA, const int s
         }
     }
     // the row entering the band, per column: row 16 s of the pair (WaveMem::row16; row 0 is the border row, kept like any other)
-    const uint2 *ra = wm.row16(sA, g.ql), *rb = wm.row16(sB, g.ql);
     unsigned hd;
     {
         unsigned a0 = 0u, b0 = 0u; // H[16 s][CK b]
-        if (needA) a0 = ra[(size_t)(CK * bA) * 64].x;
-        if (needB) b0 = rb[(size_t)(CK * bB) * 64].x;
+        if (needA) a0 = wm.row16(sA, g.ql, CK * bA).x;
+        if (needB) b0 = wm.row16(sB, g.ql, CK * bB).x;
         if (sA & 1) { // (the middle rows start at column 1: column 0 by its formula)
             const int row = sA * RB;
             const int v = border(row, g.gopen, g.gext, g.indel) + row * g.gext + g.base;
@@ -513,17 +568,17 @@ __device__ __forceinline__ void ck_block(const int sA, const int bA, const int s
         for (int u = 0; u < 8; ++u) va[u] = vb[u] = make_uint2(0u, 0u);
         if (needA) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) va[u] = ra[(size_t)min(CK * bA + 8 * gg + u + 1, g.ql) * 64]; // (past ql: the last column again -- flags never read)
+            for (int u = 0; u < 8; ++u) va[u] = wm.row16(sA, g.ql, min(CK * bA + 8 * gg + u + 1, g.ql)); // (past ql: the last column again -- flags never read)
         }
         if (needB) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) vb[u] = rb[(size_t)min(CK * bB + 8 * gg + u + 1, g.ql) * 64];
+            for (int u = 0; u < 8; ++u) vb[u] = wm.row16(sB, g.ql, min(CK * bB + 8 * gg + u + 1, g.ql));
         }
         unsigned qa[2], qb[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            qa[u] = qst[(size_t)(2 * min(bA * (CK / 4) + 2 * gg + u, qmax)) * 64];
-            qb[u] = qst[(size_t)(2 * min(bB * (CK / 4) + 2 * gg + u, qmax) + 1) * 64];
+            qa[u] = wm.qblock(min(bA * (CK / 4) + 2 * gg + u, qmax), 0);
+            qb[u] = wm.qblock(min(bB * (CK / 4) + 2 * gg + u, qmax), 1);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -674,6 +729,13 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
         wm.mid = wm.bnd + (size_t)(strips + 1) * (ql + 1) * 64;
         wm.ck = reinterpret_cast<unsigned *>(region + ((size_t)(strips + 1) * (ql + 1) + (size_t)strips * ql) * 64) + lane;
         wm.blk = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned *>(region) + ((size_t)(strips + 1) * (ql + 1) * 2 + (size_t)strips * ql * 2 + (size_t)strips * (nb - 1) * 64) * 64) + lane;
+        wm.rows = region;
+        wm.mid_off = (unsigned)((strips + 1) * (ql + 1) * 64);
+        wm.cku = reinterpret_cast<const unsigned *>(region + ((size_t)(strips + 1) * (ql + 1) + (size_t)strips * ql) * 64);
+        wm.blku = reinterpret_cast<const uint32_t *>(region) + ((size_t)(strips + 1) * (ql + 1) * 2 + (size_t)strips * ql * 2 + (size_t)strips * (nb - 1) * 64) * 64;
+        wm.seq = reinterpret_cast<const unsigned *>(a.scratch + (size_t)gw * (size_t)lane_ck_scratch_bytes(a.uni_tl, a.uni_ql));
+        wm.t_off = (unsigned)(((ql + 3) >> 2) * 128);
+        wm.lane = (unsigned)lane;
     }
     // ---- staging: both sequences of every lane, transposed to [4-base block][A | B][lane] dwords in the wave's scratch -- as BASE
     // CODES where the wave's targets allow it (sw_lane_cell.h: 2-bit packed inputs always do; ASCII targets when every byte is one of
@@ -787,19 +849,18 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
     geom.base = base;
     geom.indel = indel;
     geom.codes = codes;
-    const uint32_t *const blk_words = reinterpret_cast<const uint32_t *>(wm.blk);
     const bool by_score = !(MGL_CK_ABLATE & 8);
     const int tblocks = strips * (R / 4), qblocks = (ql + 3) >> 2;
     while (!(MGL_CK_ABLATE & 1) && __builtin_amdgcn_ballot_w64(!wa.done || !wb.done) != 0) {
         if (by_score) {
             for (;;) { // every walk standing at a cell takes the diagonal stretches whose scores add up (PathWalk::verify_apply)
-                unsigned ta[5], qa[5], tb[5], qb[5], ga = 0, gb = 0;
+                unsigned ta[17], qa[17], tb[17], qb[17], ga[PathWalk::VB], gb[PathWalk::VB];
                 if (wa.can_verify()) {
-                    wa.win_load(tst, qst, 0, tblocks, qblocks, ta, qa);
+                    wa.win64_load(wm, 0, tblocks, qblocks, ta, qa);
                     wa.grid_load(wm, ql, ga);
                 }
                 if (wb.can_verify()) {
-                    wb.win_load(tst, qst, 1, tblocks, qblocks, tb, qb);
+                    wb.win64_load(wm, 1, tblocks, qblocks, tb, qb);
                     wb.grid_load(wm, ql, gb);
                 }
                 const bool ma = wa.verify_apply(ta, qa, ga, 0, geom), mb = wb.verify_apply(tb, qb, gb, 1, geom);
@@ -811,9 +872,9 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
         // (a finished walk's half recomputes some valid block's worth of garbage: both halves run the same instructions anyway)
         const int kA = max(wa.pi - 1, 0) >> 4, bA = max(wa.pj - 1, 0) / CK, kB = max(wb.pi - 1, 0) >> 4, bB = max(wb.pj - 1, 0) / CK;
         if (codes)
-            ck_block<true>(kA, bA, kB, bB, !wa.done, !wb.done, geom, wm, qst, tst, c);
+            ck_block<true>(kA, bA, kB, bB, !wa.done, !wb.done, geom, wm, c);
         else
-            ck_block<false>(kA, bA, kB, bB, !wa.done, !wb.done, geom, wm, qst, tst, c);
+            ck_block<false>(kA, bA, kB, bB, !wa.done, !wb.done, geom, wm, c);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the block's flags are in memory
         CK_PHASE(4); // a block's flags
 #ifdef MGL_CK_PHASES
@@ -824,12 +885,12 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
             // (a lane with nothing to fetch still runs apply(): a run that ends at the matrix's edge needs no flags)
             unsigned fa[PathWalk::LOOK], fb[PathWalk::LOOK], ta[5], qa[5], tb[5], qb[5];
             if (la) {
-                wa.load(blk_words, fa);
-                if (wa.mode == 0) wa.win_load(tst, qst, 0, tblocks, qblocks, ta, qa);
+                wa.load(wm, fa);
+                if (wa.mode == 0) wa.win_load(wm, 0, tblocks, qblocks, ta, qa);
             }
             if (lb) {
-                wb.load(blk_words, fb);
-                if (wb.mode == 0) wb.win_load(tst, qst, 1, tblocks, qblocks, tb, qb);
+                wb.load(wm, fb);
+                if (wb.mode == 0) wb.win_load(wm, 1, tblocks, qblocks, tb, qb);
             }
             const bool ga = wa.apply(fa, ta, qa, 0, kA, bA, geom), gb = wb.apply(fb, tb, qb, 1, kB, bB, geom);
             if (!__builtin_amdgcn_ballot_w64(ga || gb)) break;
