@@ -598,6 +598,21 @@ __device__ __forceinline__ void ck_block(const int sA, const int bA, const int s
 // exposes a memory latency per block: a tenth of the wave's lifetime, measured).  dst: the wave's [block][A | B][lane] dwords + lane.
 // ASCII sequences (sw.cpp:55 compares raw bytes).  CODES: store base codes -- a target as the code per byte, a QUERY as 8 x code, or 32
 // for a byte that is not one of ACGT (sw_lane_cell.h) -- and return nonzero if a byte of the first `len` is not one of ACGT.
+typedef uint32_t dwords4 __attribute__((ext_vector_type(4), aligned(4))); // four consecutive dwords at a dword-aligned address
+// dwords k0 .. k0 + 3 of a sequence: one 16-byte load where all four hold bytes of it, else dword by dword, clamped (SeqWords::word)
+__device__ __forceinline__ void seq_words4(const SeqWords &s, const int k0, unsigned (&w)[4])
+{
+    if (k0 + 3 <= s.kmax) {
+        const dwords4 v = *reinterpret_cast<const dwords4 *>(s.base + k0);
+        w[0] = v.x;
+        w[1] = v.y;
+        w[2] = v.z;
+        w[3] = v.w;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = s.word(k0 + u);
+    }
+}
 template <bool CODES, bool QUERY>
 __device__ __forceinline__ unsigned stage_ascii(const uint8_t *seqA, const uint8_t *seqB, const int len, const int nblocks, unsigned *dst)
 {
@@ -605,15 +620,23 @@ __device__ __forceinline__ unsigned stage_ascii(const uint8_t *seqA, const uint8
     sa.init(seqA, len);
     sb.init(seqB, len);
     unsigned bad = 0;
-    for (int cb = 0; cb < nblocks; cb += 8) {
-        unsigned wa[9], wb[9];
+    for (int cb = 0; cb < nblocks; cb += 16) { // sixteen blocks of both pairs per round: 17 dwords of each sequence, in 16-byte loads
+        unsigned wa[20], wb[20];
 #pragma unroll
-        for (int u = 0; u < 9; ++u) {
-            wa[u] = sa.word(cb + u);
-            wb[u] = sb.word(cb + u);
+        for (int u = 0; u < 4; ++u) {
+            unsigned xa[4], xb[4];
+            seq_words4(sa, cb + 4 * u, xa);
+            seq_words4(sb, cb + 4 * u, xb);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                wa[4 * u + x] = xa[x];
+                wb[4 * u + x] = xb[x];
+            }
         }
+        wa[16] = sa.word(cb + 16);
+        wb[16] = sb.word(cb + 16);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
             if (cb + u < nblocks) { // (blocks past the end of a target repeat its last dword: rows > tl, never read)
                 unsigned va = __builtin_amdgcn_alignbyte(wa[u + 1], wa[u], sa.shift), vb = __builtin_amdgcn_alignbyte(wb[u + 1], wb[u], sb.shift);
                 if (CODES) {
