@@ -36,16 +36,17 @@ from mgl_amd import device_batch, dist  # noqa: E402
 from mgl_amd.smithwaterman import GATK_PARAMETERS, MicrosoftSmithWaterman, SWOverhangStrategy  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+DEFAULT_WORKSPACE_GIB = 208.0  # the 10 M-pair batch of configs[1] is ONE launch of the lane kernel (the card has 288 GB)
 
 
-def algorithmic_bytes_per_pair(tl, ql, packed2=False):
-    """DESIGN.md "algorithmic bytes": what the fill kernel must move per pair whatever the schedule:
-    the two sequences as shipped (ASCII like the reference's ByteBuffer, or 2-bit packed), two int64
-    offsets each (amortised 16 B), the 4-bit-per-cell traceback spilled to HBM, and the 32-byte fill record.
-    (What a particular schedule moves on top -- the lane kernel's strip carries and its path walk's re-reads --
-    shows in `traffic`, not here.)"""
+def algorithmic_bytes_per_pair(tl, ql, packed2=False, traceback_spilled=False, cigar_bytes=0.0):
+    """SURVEY.md 8d "algorithmic bytes per unit of work", per pair, for what the kernel in question does: in = the two
+    sequences as shipped (ASCII like the reference's ByteBuffer, or 2-bit packed) + the two int64 descriptors this ABI
+    takes per pair (16 B); out = offset (4 B) + the six ScoreMax fields (24 B) + CIGAR length and status (8 B) + the
+    CIGAR bytes actually written; traceback = tl*ql/2 bytes + the 32-byte fill record ONLY for a kernel that spills it
+    to HBM (sw_dp16_lane_ck_kernel keeps none: what it writes on top is schedule and shows in `traffic`)."""
     seq = (tl + 3) // 4 + (ql + 3) // 4 if packed2 else tl + ql
-    return seq + 16 + (tl * ql) // 2 + 32
+    return seq + 16 + 36 + cigar_bytes + ((tl * ql) // 2 + 32 if traceback_spilled else 0)
 
 
 def host_cores():
@@ -311,7 +312,7 @@ def main():
                          "shard dist.shard_range(pairs, r, N) of it; weak: every rank its own --pairs pairs")
     ap.add_argument("--tl", type=int, default=256, help="reference window length")
     ap.add_argument("--ql", type=int, default=150, help="read length")
-    ap.add_argument("--workspace-gib", type=float, default=208.0,
+    ap.add_argument("--workspace-gib", type=float, default=DEFAULT_WORKSPACE_GIB,
                     help="traceback workspace per GPU (208 GiB: the 10 M-pair batch is one launch; the card has 288 GB)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (long reads, PairHMM, protein)")
@@ -378,8 +379,8 @@ def main():
     for _ in range(args.warmup):
         step()
     # HIP events around every kernel launch, on the streams the kernels run on (asynchronous: they are
-    # read back after the timed region) -> per-launch durations of the LAST timed step for the roofline
-    aligner.set_profiling(1)
+    # read back after the timed region) -> the MEAN launch duration over the timed steps for the roofline
+    aligner.set_profiling(3)  # summed over the timed steps, read once afterwards
     dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -391,7 +392,7 @@ def main():
 
     status_bad = int((batch.status != 0).sum().item())
 
-    tm = aligner.timing()  # kernel durations of the last timed step (HIP events recorded in the timed region)
+    tm = aligner.timing()  # kernel durations summed over the timed steps (HIP events recorded in the timed region)
     aligner.set_profiling(0)
 
     if rank != 0:
@@ -402,10 +403,14 @@ def main():
         np.save(args.dump_scores, gathered.cpu().numpy().astype(np.int32))
     fill_kernel = aligner.fill_kernel_name(tm)
     total_cells = n_total * args.tl * args.ql * args.steps
-    per_pair = algorithmic_bytes_per_pair(args.tl, args.ql, args.input == "2bit")
-    dp_s = tm.dp_ms / 1e3
-    achieved = n_local * per_pair / dp_s / 1e9
-    pairs_per_launch = n_local / max(1, tm.dp_launches)
+    # (tm sums the HIP events of every launch of the timed loop: mgl_sw_ctx_set_profiling(ctx, 3))
+    launches = max(1, tm.dp_launches)
+    avg_launch_s = tm.dp_ms / 1e3 / launches
+    pairs_per_launch = n_local * args.steps / launches
+    spills = fill_kernel not in ("sw_dp16_lane_ck_kernel",)  # every other fill kernel writes the 4-bit traceback to HBM
+    cigar_bytes = float(batch.cigar_len.float().mean().item())
+    per_pair = algorithmic_bytes_per_pair(args.tl, args.ql, args.input == "2bit", spills, cigar_bytes)
+    achieved = pairs_per_launch * per_pair / avg_launch_s / 1e9
     tpp = pmc_traffic_per_pair(args.tl, args.ql, fill_kernel)
     traffic = None if tpp is None else round(tpp * pairs_per_launch)  # HBM bytes per launch (PMC)
     valu = pmc_valu(args.tl, args.ql, fill_kernel)
@@ -415,7 +420,7 @@ def main():
         # measured per-class issue costs / SIMD-cycles available in the measured launch duration (1024 SIMDs x clock)
         clock_hz = (tm.clock_mhz or 2400) * 1e6
         need = valu["wave_insts_per_pair"] * pairs_per_launch * valu["avg_cycles_per_inst"]
-        have = (tm.dp_ms / max(1, tm.dp_launches)) * 1e-3 * clock_hz * 1024
+        have = avg_launch_s * clock_hz * 1024
         valu_obj = {"issue_frac": round(need / have, 3), "wave_insts_per_pair": valu["wave_insts_per_pair"],
                     "avg_cycles_per_inst": valu["avg_cycles_per_inst"], "lds_bank_conflict_rate": valu["lds_bank_conflict_rate"],
                     "clock_mhz": int(clock_hz / 1e6), "source": valu.get("source", "profiles/pmc_traffic.json (rocprofv3 --pmc)")}
@@ -447,22 +452,30 @@ def main():
                             if world > 1 else "1 GPU"),
         },
         "reads_per_s": round(n_total * args.steps / elapsed, 1),
-        "kernel_ms": ({fill_kernel: round(tm.dp_ms, 3), "path_walk": "inside the fill kernel (every lane walks its own two pairs)",
-                       "launches_each": tm.dp_launches} if fill_kernel in ("sw_dp16_lane_kernel", "sw_dp16_lane_ck_kernel") else
-                      {fill_kernel: round(tm.dp_ms, 3), "sw_traceback_kernel": round(tm.tb_ms, 3), "launches_each": tm.dp_launches}),
+        "kernel_ms": ({fill_kernel: round(tm.dp_ms / args.steps, 3), "path_walk": "inside the fill kernel (every lane walks its own two pairs)",
+                       "launches_per_step": launches / args.steps, "averaged_over_steps": args.steps}
+                      if fill_kernel in ("sw_dp16_lane_kernel", "sw_dp16_lane_ck_kernel") else
+                      {fill_kernel: round(tm.dp_ms / args.steps, 3), "sw_traceback_kernel": round(tm.tb_ms / args.steps, 3),
+                       "launches_per_step": launches / args.steps, "averaged_over_steps": args.steps}),
         "cigar_overflows": status_bad,
         "roofline": {
             "bound": "hbm", "kernel": fill_kernel,
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic,
-            "algorithmic_bytes_per_pair": per_pair,
+            "algorithmic_bytes_per_pair": round(per_pair, 1),
             "pairs_per_launch": round(pairs_per_launch, 1),
-            "avg_launch_ms": round(tm.dp_ms / max(1, tm.dp_launches), 4),
-            "kernel_gcups": round(cells / dp_s / 1e9, 2),
-            "note": ("integer DP: the kernel is VALU-issue bound, the HBM fraction is small by construction"
-                     + ("; sw_dp16_lane_ck_kernel spills no traceback at all (carry rows and checkpoints instead, ~24 KB per pair, `traffic`): "
-                        "`achieved` keeps SURVEY 8d's per-pair figure with the traceback so that the fraction compares with earlier lines"
+            "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+            "kernel_gcups": round(pairs_per_launch * args.tl * args.ql / avg_launch_s / 1e9, 2),
+            # what the counters say the kernel really moves, against the same peak (null without a PMC pass for this geometry)
+            "traffic_frac_of_peak": None if traffic is None else round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4),
+            # the figure earlier rounds' lines quoted: SURVEY 8d's per-pair bytes WITH a spilled 4-bit traceback, which this kernel does not write
+            "if_traceback_were_spilled": {"bytes_per_pair": algorithmic_bytes_per_pair(args.tl, args.ql, args.input == "2bit", True, cigar_bytes),
+                                          "frac": round(pairs_per_launch * algorithmic_bytes_per_pair(args.tl, args.ql, args.input == "2bit", True, cigar_bytes)
+                                                        / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4)},
+            "note": ("integer DP: the kernel is VALU-issue bound (`valu`), the HBM fraction of SURVEY 8d's algorithmic bytes is small by construction"
+                     + ("; sw_dp16_lane_ck_kernel spills no traceback: `algorithmic_bytes_per_pair` = inputs + descriptors + results, and the rows and "
+                        "checkpoints it keeps to restart from are schedule -- they show in `traffic` (rocprofv3 PMC), not here"
                         if fill_kernel == "sw_dp16_lane_ck_kernel" else "")),
             "valu": valu_obj,
         },

@@ -134,7 +134,8 @@ int mgl_sw_ctx_set_lane_kernel(mgl_sw_ctx *ctx, int mode);
 int mgl_sw_ctx_set_lane_checkpoint(mgl_sw_ctx *ctx, int mode);
 /* 1 = HIP events around every kernel launch of a call, on the streams the kernels run on, read back by
  * mgl_sw_ctx_get_timing (the call itself stays asynchronous); 2 = additionally stamp the shader clock
- * inside the fill kernel (diagnostic; a few extra instructions per workgroup); 0 = off */
+ * inside the fill kernel (diagnostic; a few extra instructions per workgroup); 3 = as 1, summed over every call until
+ * mgl_sw_ctx_get_timing reads and clears it (dp_ms / dp_launches = the mean launch duration over a timed loop); 0 = off */
 int mgl_sw_ctx_set_profiling(mgl_sw_ctx *ctx, int enable);
 int mgl_sw_ctx_get_timing(mgl_sw_ctx *ctx, mgl_sw_timing *out); /* waits for the last call's kernels */
 

@@ -475,9 +475,13 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->fill2, ctx->fill_done[0], 0));
     }
 
-    ctx->timing = mgl_sw_timing{};
-    ctx->timing.cells = cells_hint;
-    ctx->pool_used = 0;
+    if (ctx->profiling == 3) { // accumulate over calls until mgl_sw_ctx_get_timing reads and clears
+        ctx->timing.cells += cells_hint;
+    } else {
+        ctx->timing = mgl_sw_timing{};
+        ctx->timing.cells = cells_hint;
+        ctx->pool_used = 0;
+    }
 
     bool tb_pending[2] = {false, false};
     bool srt_used[4] = {false, false, false, false};
@@ -645,7 +649,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             da.grouped = pt.lane && auto_group ? 1 : 0;
             const int per_block = pt.lane ? pt.wpb * 128 : pt.packed ? pt.wpb * 8 : strip16 ? 1 : pt.wpb * (64 / pt.rows);
             if (i == 0) n_blocks = (pt.count + per_block - 1) / per_block;
-            if (ctx->profiling >= 2 && i == 0) {
+            if (ctx->profiling == 2 && i == 0) {
                 HIP_TRY(ctx, ctx->diag.reserve((size_t)n_blocks * 16));
                 da.diag = static_cast<unsigned long long *>(ctx->diag.p);
             }
@@ -962,6 +966,10 @@ int mgl_sw_ctx_set_profiling(mgl_sw_ctx *ctx, int enable)
     if (!ctx) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->profiling = enable < 0 ? 0 : enable;
+    if (ctx->profiling == 3) { // a new sum starts here
+        ctx->timing = mgl_sw_timing{};
+        ctx->pool_used = 0;
+    }
     return MGL_SW_OK;
 }
 
@@ -982,7 +990,7 @@ int mgl_sw_ctx_get_timing(mgl_sw_ctx *ctx, mgl_sw_timing *out)
         }
         ctx->timing.dp_ms = dp;
         ctx->timing.tb_ms = tb;
-        if (ctx->profiling >= 2 && ctx->diag.p && ctx->diag_blocks > 0) {
+        if (ctx->profiling == 2 && ctx->diag.p && ctx->diag_blocks > 0) {
             // in-kernel clock of the last chunk's fill launch
             std::vector<unsigned long long> h((size_t)ctx->diag_blocks * 2);
             HIP_TRY(ctx, hipMemcpy(h.data(), ctx->diag.p, h.size() * 8, hipMemcpyDeviceToHost));
@@ -996,6 +1004,7 @@ int mgl_sw_ctx_get_timing(mgl_sw_ctx *ctx, mgl_sw_timing *out)
         ctx->pool_used = 0;
     }
     *out = ctx->timing;
+    if (ctx->profiling == 3) ctx->timing = mgl_sw_timing{}; // the next calls start a new sum
     return MGL_SW_OK;
 }
 

@@ -932,11 +932,9 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
 
 } // namespace
 
-// Two register budgets, the same code: two waves per SIMD (no spills; the default for targets below 512 rows) or three (168 VGPRs, a
-// few spills outside the loops; MGL_SW_LANE_CK_WPS=2 / 3 force one).  Launches of 10 M pairs run equally fast on both (3 838-3 855 GCUPS); shorter ones are 2-7 % faster
-// with two -- 393 216 pairs 3 154 against 2 991 GCUPS, 786 432: 3 542 / 3 321, 1.25 M: 3 535 / 3 401, 2.5 M: 3 654 / 3 466, 5 M:
-// 3 812 / 3 734 (scripts/wps_probe.sh) -- a round of the chip is 8 waves per CU instead of 12, and the last round of a launch fuller.
-__global__ __launch_bounds__(256, 3) void sw_dp16_lane_ck_kernel_w3(const DpArgs a, const TbArgs walk) { sw_dp16_lane_ck_body(a, walk); }
+// Two waves per SIMD (256 registers: no spills in pass 1's loops).  A three-wave build of the same code (168 registers, spills)
+// ran launches of 10 M pairs equally fast in round 2 and shorter ones 2-7 % slower; with pass 2 as it is now it is slower
+// everywhere (1000 x 150, 2.56 M pairs: 62.9 ms against 61.4) and was dropped.
 __global__ __launch_bounds__(256, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, const TbArgs walk) { sw_dp16_lane_ck_body(a, walk); }
 
 // either wire format, the same for both sequence sets (the kernel stages base codes, sw_lane_cell.h)
@@ -947,14 +945,7 @@ hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &walk, hipStream_t 
     const int waves_per_block = 4;
     const int64_t waves = ((a.count + 1) / 2 + 63) / 64;
     const dim3 grid((unsigned)((waves + waves_per_block - 1) / waves_per_block)), block(64 * waves_per_block);
-    static const int wps_env = [] { const char *e = getenv("MGL_SW_LANE_CK_WPS"); return e ? atoi(e) : 0; }();
-    // (long targets -- many strips per wave, the walk a small share -- run 2 % faster with three: 1000 x 150, 2.56 M pairs, 77.8 ms
-    // against 79.4)
-    const bool two = wps_env ? wps_env == 2 : a.uni_tl < 512;
-    if (two)
-        hipLaunchKernelGGL(sw_dp16_lane_ck_kernel, grid, block, 0, stream, a, walk);
-    else
-        hipLaunchKernelGGL(sw_dp16_lane_ck_kernel_w3, grid, block, 0, stream, a, walk);
+    hipLaunchKernelGGL(sw_dp16_lane_ck_kernel, grid, block, 0, stream, a, walk);
     return hipGetLastError();
 }
 

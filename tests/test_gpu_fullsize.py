@@ -76,6 +76,7 @@ def full():
 def test_fullsize_global_invariants(full):
     a, b = full
     assert a.timing().packed16 == 1
+    assert a.timing().fill_kernel == 7, "configs[1] at full size is the checkpointed lane kernel's batch (sw_dp16_lane_ck_kernel)"
     assert int((b.status != 0).sum()) == 0
     ln = b.cigar_len
     assert int(ln.min()) >= 2 and int(ln.max()) <= b.cigar_stride
@@ -113,7 +114,7 @@ def test_fullsize_int16_equals_int32_on_a_slice(full):
                                   b.cigar_stride, uniform=True)
     sl.run(a)
     torch.cuda.synchronize()
-    assert a.timing().packed16 == 1
+    assert a.timing().packed16 == 1 and a.timing().fill_kernel == 7
     d16 = digest(sl)
     forced = sw.MicrosoftSmithWaterman(0)
     forced.set_precision(32)
@@ -145,3 +146,34 @@ def test_fullsize_sample_rescoring_and_oracle(full):
     sub = slice(0, 2000)
     o_off, o_sc, o_cg = ol.oracle_align_batch(ts[sub], qs[sub], (M, X, O, E), ol.SOFTCLIP, nthreads=8)
     assert (o_off == off[sub]).all() and (o_sc == sc[sub]).all() and o_cg == cig[sub]
+
+
+def test_fullsize_one_launch_as_the_bench_runs_it(full):
+    """The exact configuration the headline is quoted on: bench.py's workspace, so that the 10 M pairs are ONE launch of
+    sw_dp16_lane_ck_kernel (78 125 waves) -- identical to the chunked run of the fixture, and a 20 000-pair sample spread
+    over the whole launch against the CPU checker."""
+    import bench
+
+    a, b = full
+    d0 = digest(b)
+    free, _total = torch.cuda.mem_get_info()
+    ws = int(bench.DEFAULT_WORKSPACE_GIB * (1 << 30))
+    if free < ws + (8 << 30):
+        pytest.skip(f"{free >> 30} GiB free: the one-launch workspace of bench.py ({bench.DEFAULT_WORKSPACE_GIB} GiB) does not fit this card")
+    big = sw.MicrosoftSmithWaterman(0)
+    try:
+        big.set_workspace(ws)
+        big.set_profiling(1)
+        b.run(big)
+        torch.cuda.synchronize()
+        tm = big.timing()
+        assert tm.fill_kernel == 7 and tm.packed16 == 1 and tm.dp_launches == 1, (tm.fill_kernel, tm.dp_launches)
+        assert int((b.status != 0).sum()) == 0
+        assert digest(b) == d0, "one launch and the chunked run differ"
+        idx = np.sort(np.random.default_rng(11).choice(N_FULL, size=20_000, replace=False))
+        ts, qs = b.host_pairs(idx)
+        o_off, o_sc, o_cg = ol.oracle_align_batch(ts, qs, (M, X, O, E), ol.SOFTCLIP, nthreads=16)
+        assert (o_off == b.offsets[idx].cpu().numpy()).all() and (o_sc == b.scores[idx].cpu().numpy()).all()
+        assert o_cg == b.cigar_strings(idx)
+    finally:
+        big.close()

@@ -17,12 +17,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PAIRS = 200_000
 
 
-def _bench(nproc, extra, tmp_path, tag):
+def _bench(nproc, extra, tmp_path, tag, backend="gloo"):
     dump = str(tmp_path / f"scores_{tag}.npy")
     with socket.socket() as sk:  # a free rendezvous port
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, MGL_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MGL_DIST_BACKEND=backend, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--pairs", str(PAIRS), "--steps", "2",
            "--warmup", "1", "--no-secondary", "--no-extra", "--no-cpu", "--dump-scores", dump] + extra
@@ -62,6 +62,22 @@ def test_two_ranks_share_the_gpu_over_gloo(tmp_path):
     dw, sw_ = _bench(2, ["--scaling", "weak"], tmp_path, "weak")
     assert dw["scaling"] == "weak" and dw["config"]["pairs_total"] == 2 * PAIRS and sw_.shape == (2 * PAIRS,)
     assert (sw_[:PAIRS] == s1).all()              # rank 0's batch is the seed-42 workload
+
+
+@pytest.mark.gpu
+def test_one_rank_over_rccl(tmp_path):
+    """The `nccl` branch of mgl_amd/dist.py (RCCL: init_process_group(device_id=...), the gather, barrier(device_ids=...), the
+    max-over-ranks all-reduce) executed once on the one GPU of this box: torchrun with ONE rank and the backend the 8-GPU run
+    uses.  Its gathered score vector must be the vector of a plain one-process run of the same workload."""
+    d, s_rccl = _bench(1, [], tmp_path, "rccl", backend="nccl")
+    assert d["n_gpus"] == 1 and d["config"]["pairs_total"] == PAIRS and d["cigar_overflows"] == 0
+    dump = str(tmp_path / "scores_plain.npy")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--pairs", str(PAIRS), "--steps", "1", "--warmup", "0",
+                        "--no-secondary", "--no-extra", "--no-cpu", "--dump-scores", dump], capture_output=True, text=True, timeout=900,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s_plain = np.load(dump)
+    assert s_rccl.shape == s_plain.shape == (PAIRS,) and (s_rccl == s_plain).all()
 
 
 @pytest.mark.gpu
