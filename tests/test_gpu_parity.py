@@ -1288,6 +1288,99 @@ def test_2bit_window_batch_equals_ascii(aligner):
     assert torch.equal(pb.cigars, ab.cigars) and torch.equal(pb.cigar_len, ab.cigar_len)
 
 
+@pytest.mark.parametrize("tl,ql", [(256, 150), (1000, 150), (64, 65), (250, 150), (33, 8), (96, 131)])
+def test_2bit_inputs_on_the_lane_kernel(tl, ql):
+    """The 2-bit wire format on sw_dp16_lane_ck_kernel (forced onto a small batch): uniform pairs packed at unaligned base
+    offsets -- target windows overlapping inside one packed array -- every strategy, against the oracle; and byte-identical
+    to the ASCII batch of the same bases on the same kernel."""
+    import torch
+    from mgl_amd import device_batch as db
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(tl * 31 + ql)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    n = 259
+    genome = alpha[rng.integers(0, 4, 3 * tl + 2 * n + 64)]
+    t_start = rng.integers(0, len(genome) - tl, n)            # overlapping windows, any alignment
+    ts, qs = [], []
+    for k in range(n):
+        t = genome[t_start[k]: t_start[k] + tl]
+        q = np.resize(t[int(rng.integers(0, max(1, tl // 2))):], ql + 8).copy()
+        if k % 3 == 1 and ql > 12:
+            at = int(rng.integers(2, ql - 4))
+            q = np.concatenate([q[:at], q[at + 3:]])
+        elif k % 3 == 2 and ql > 12:
+            at = int(rng.integers(2, ql - 4))
+            q = np.concatenate([q[:at], alpha[rng.integers(0, 4, 2)], q[at:]])
+        sub = rng.random(len(q)) < 0.03
+        q[sub] = alpha[rng.integers(0, 4, int(sub.sum()))]
+        ts.append(t.tobytes())
+        qs.append(q[:ql].tobytes())
+    lead = 3                                                   # reads packed back to back behind three bases of padding
+    G = torch.from_numpy(db.pack2bit(genome.tobytes() + b"A" * ((-len(genome)) % 4))).to(dev)
+    qcat = b"C" * lead + b"".join(qs)
+    Q = torch.from_numpy(db.pack2bit(qcat + b"A" * ((-len(qcat)) % 4))).to(dev)
+    i64 = lambda v: torch.tensor(np.asarray(v), dtype=torch.int64, device=dev)
+    pb = db.PackedBatch(G, i64(t_start), None, Q, i64(lead + np.arange(n) * ql), None, tl, ql, cigar_stride=2 * max(tl, ql) + 16)
+    td, toff = sw.concat(ts)
+    qd, qoff = sw.concat(qs)
+    ab = db.from_host(td, toff, qd, qoff, "cuda:0", cigar_stride=pb.cigar_stride)
+    ab.uniform = True
+    a = sw.MicrosoftSmithWaterman(0)
+    a.set_lane_kernel(2)
+    try:
+        for params in [(200, -150, 260, 11), (25, -50, 110, 6), (1, -1, 1, 1)]:
+            for strategy in ol.STRATEGIES:
+                pb.run(a, params, strategy)
+                torch.cuda.synchronize()
+                # (33 rows: the planner prefers 16-row strips there, which only the kernels that store every flag have -- sw_dp16_kernel for 2-bit)
+                assert a.timing().fill_kernel == (1 if tl == 33 else 7), "a uniform 2-bit batch takes the checkpointed lane kernel"
+                assert int((pb.status != 0).sum()) == 0
+                off, sc, cg = ol.oracle_align_batch(ts, qs, params, strategy, nthreads=4)
+                assert (pb.offsets.cpu().numpy() == off).all() and (pb.scores.cpu().numpy() == sc).all(), (params, strategy)
+                assert pb.cigar_strings() == cg, (params, strategy)
+                ab.run(a, params, strategy)
+                torch.cuda.synchronize()
+                assert a.timing().fill_kernel in ((4, 7) if tl == 33 else (7,))
+                assert torch.equal(pb.cigars, ab.cigars) and torch.equal(pb.offsets, ab.offsets) and torch.equal(pb.scores, ab.scores)
+    finally:
+        a.close()
+
+
+def test_lane_kernel_bases_outside_acgt():
+    """sw_dp16_lane_ck_kernel stages base codes when every TARGET byte of a wave is one of ACGT and raw bytes otherwise
+    (sw.cpp:55 compares bytes): reads with N, lower case and arbitrary bytes against clean targets (codes, the query byte
+    becomes "no target base"), targets with N (that wave falls back to bytes), N against N (equal bytes match)."""
+    rng = np.random.default_rng(99)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    tl, ql, n = 256, 150, 300                  # three waves: clean / N in some reads / N in some targets
+    ts, qs = [], []
+    for k in range(n):
+        t = alpha[rng.integers(0, 4, tl)].copy()
+        a0 = int(rng.integers(0, tl - ql))
+        q = t[a0:a0 + ql].copy()
+        if k >= 128 and k % 3 == 0:            # reads with N / lower case / junk
+            pos = rng.integers(0, ql, 4)
+            q[pos] = np.frombuffer(b"NnaX", np.uint8)[rng.integers(0, 4, 4)]
+        if k >= 256 and k % 4 == 1:            # targets with N, some aligned with an N of the read
+            pos = rng.integers(a0, a0 + ql, 3)
+            t[pos] = ord("N")
+            if k % 8 == 1:
+                q[pos - a0] = ord("N")
+        ts.append(t.tobytes())
+        qs.append(q.tobytes())
+    a = sw.MicrosoftSmithWaterman(0)
+    a.set_lane_kernel(2)
+    try:
+        for strategy in ol.STRATEGIES:
+            res = a.align_batch(ts, qs, (200, -150, 260, 11), strategy)
+            assert a.timing().fill_kernel == 7
+            off, sc, cg = ol.oracle_align_batch(ts, qs, (200, -150, 260, 11), strategy, nthreads=4)
+            assert (res.offsets == off).all() and (res.scores == sc).all() and list(res.cigars) == cg, strategy
+    finally:
+        a.close()
+
+
 def test_binary_cigar_output(aligner):
     """MGL_SW_FLAG_BINARY_CIGAR: BAM-style uint32 elements carry the same elements in the same order as the text."""
     import torch
