@@ -237,12 +237,12 @@ def secondary_workloads():
 
 
 def pcie_inclusive_leg(aligner, batch, args):
-    """SURVEY.md 8d's wall-time definition: the same pairs through the host-buffer entry mgl_sw_align_batch -- inputs in
-    pageable host memory (the reference is always called with host buffers, MicrosoftSmithWaterman.java:66-86), H2D of
-    the ASCII bases, kernels, D2H of every result -- timed around the one blocking call and cross-checked against the
-    arrays the device-resident headline run left in HBM.  Never `value`."""
-    import ctypes as C
-
+    """SURVEY.md 8d's wall-time definition: the same pairs through the host-buffer entries -- inputs in host memory (the
+    reference is always called with host buffers, MicrosoftSmithWaterman.java:66-86), H2D, kernels, D2H of every result --
+    timed around the one blocking call and cross-checked against the arrays the device-resident headline run left in HBM.
+    Three forms: ASCII bases in pageable memory (the reference's own contract: 4.2 GB in), the same arrays REGISTERED
+    (mgl_sw_register_host_buffer), and 2-bit packed bases with windows into one packed genome (SURVEY 8d config 2's wire format:
+    0.54 GB in), registered.  Never `value`."""
     from mgl_amd import _lib
 
     n, tl, ql, stride = batch.n, batch.max_tl, batch.max_ql, batch.cigar_stride
@@ -252,25 +252,73 @@ def pcie_inclusive_leg(aligner, batch, args):
     cg, ln = np.zeros(n * stride, np.uint8), np.zeros(n, np.int32)
     m, x, o, e = GATK_PARAMETERS
     L = _lib.lib()
+    want = (batch.offsets.cpu().numpy(), batch.cigars.cpu().numpy(), batch.scores.cpu().numpy())
 
-    def call(k):
-        t0 = time.perf_counter()
-        rc = L.mgl_sw_align_batch(aligner.ctx, k, t.ctypes.data, toff.ctypes.data, q.ctypes.data, qoff.ctypes.data, m, x, o, e,
+    def mismatches():
+        return int((want[0] != off).sum() + (want[1] != cg.reshape(n, stride)).any(axis=1).sum() + (want[2] != sc).any(axis=1).sum())
+
+    def timed(call):
+        call()                                 # untimed: the context's staging buffers exist from here on
+        off[:] = -1
+        times = []
+        for _ in range(max(1, args.steps)):
+            t0 = time.perf_counter()
+            call()
+            times.append(time.perf_counter() - t0)
+        dt = sum(times) / len(times)
+        return {"ms_per_step": round(dt * 1e3, 3), "gcups": round(n * tl * ql / dt / 1e9, 2), "reads_per_s": round(n / dt, 1),
+                "calls": len(times), "mismatches_vs_headline": mismatches()}
+
+    def ascii_call():
+        rc = L.mgl_sw_align_batch(aligner.ctx, n, t.ctypes.data, toff.ctypes.data, q.ctypes.data, qoff.ctypes.data, m, x, o, e,
                                   int(SWOverhangStrategy.SOFTCLIP), off.ctypes.data, sc.ctypes.data, cg.ctypes.data, stride,
                                   ln.ctypes.data)
         assert rc == 0, rc
-        return time.perf_counter() - t0
 
-    call(n)                                   # untimed: the context's staging buffers (4 GB of inputs, 1 GB of results) exist from here on
-    times = [call(n) for _ in range(max(1, args.steps))]
-    dt = sum(times) / len(times)
-    mism = int((batch.offsets.cpu().numpy() != off).sum()
-               + (batch.cigars.cpu().numpy() != cg.reshape(n, stride)).any(axis=1).sum()
-               + (batch.scores.cpu().numpy() != sc).any(axis=1).sum())
-    return {"ms_per_step": round(dt * 1e3, 3), "gcups": round(n * tl * ql / dt / 1e9, 2), "reads_per_s": round(n / dt, 1),
-            "calls": len(times), "bytes_in": int(t.nbytes + q.nbytes + toff.nbytes + qoff.nbytes),
-            "bytes_out": int(off.nbytes + sc.nbytes + cg.nbytes + ln.nbytes), "host_memory": "pageable",
-            "mismatches_vs_headline": mism}
+    out = timed(ascii_call)
+    out.update({"bytes_in": int(t.nbytes + q.nbytes + toff.nbytes + qoff.nbytes),
+                "bytes_out": int(off.nbytes + sc.nbytes + cg.nbytes + ln.nbytes), "host_memory": "pageable", "input": "ascii"})
+    regs = [t, toff, q, qoff, off, sc, cg, ln]
+    try:
+        for a_ in regs:
+            aligner.register_host_buffer(a_)
+        r = timed(ascii_call)
+        r.update({"host_memory": "registered by the caller (mgl_sw_register_host_buffer)", "input": "ascii", "bytes_in": out["bytes_in"]})
+        out["registered"] = r
+        for a_ in regs[:4]:
+            aligner.unregister_host_buffer(a_)
+        # 2-bit packed: the genome once, windows by base offset, reads packed back to back
+        if getattr(batch, "win", None) is not None:
+            g = torch.Generator(device=batch.targets.device)
+            g.manual_seed(int(args.seed))
+            genome = torch.randint(0, 4, (1 << 24,), generator=g, device=batch.targets.device, dtype=torch.uint8)
+            lut = torch.zeros(256, dtype=torch.uint8, device=batch.targets.device)
+            for k, ch in enumerate(b"ACGT"):
+                lut[ch] = k
+            G = device_batch._pack2bit_torch(genome).cpu().numpy()
+            Q = device_batch._pack2bit_torch(lut[batch.queries.long()]).cpu().numpy() if (n * ql) % 4 == 0 else None
+            if Q is not None:
+                win = batch.win.cpu().numpy().astype(np.int64)
+                qst = (np.arange(n, dtype=np.int64) * ql)
+                packed = [G, win, Q, qst]
+                for a_ in packed:
+                    aligner.register_host_buffer(a_)
+
+                def packed_call():
+                    aligner.align_packed_2bit(G, 1 << 24, win, None, Q, n * ql, qst, None, tl, ql, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP,
+                                              stride, out=(off, sc, cg, ln))
+
+                r = timed(packed_call)
+                r.update({"host_memory": "registered", "input": "2bit (one packed genome + window offsets, packed reads)",
+                          "bytes_in": int(G.nbytes + win.nbytes + Q.nbytes + qst.nbytes), "bytes_out": out["bytes_out"]})
+                out["packed_2bit"] = r
+                for a_ in packed:
+                    aligner.unregister_host_buffer(a_)
+        for a_ in regs[4:]:
+            aligner.unregister_host_buffer(a_)
+    except Exception as e_:  # noqa: BLE001 -- the extra forms must not take the pageable line down
+        out["registered_error"] = repr(e_)[:200]
+    return out
 
 
 def tl1000_leg(aligner, args, dev):

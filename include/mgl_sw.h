@@ -22,6 +22,7 @@
 #ifndef MGL_SW_H
 #define MGL_SW_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -277,6 +278,30 @@ int mgl_sw_align_batch_device_2bit(mgl_sw_ctx *ctx, void *stream, int64_t n, con
                                    int gopen, int gext, int strategy, int32_t *d_offset_out,
                                    mgl_sw_score *d_score_out, char *d_cigar_out, int cigar_stride,
                                    int32_t *d_cigar_len_out, int32_t *d_status_out, int flags);
+
+/*
+ * The same wire format from HOST memory (replaces the ASCII-in-ByteBuffer contract of MicrosoftSmithWaterman.java:73-75 for callers
+ * that hold packed bases): target_base_count / query_base_count are the numbers of bases the two packed arrays hold.  The packed
+ * arrays travel chunk by chunk beside the kernels when the pairs' start positions ascend (reads packed back to back), or whole
+ * before the first chunk (windows into one genome, in any order); results leave as in mgl_sw_align_batch_status (status_out may
+ * be NULL: then a CIGAR that does not fit fails the call).  Everything else as mgl_sw_align_batch_device_2bit.
+ */
+int mgl_sw_align_batch_2bit(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_bases, int64_t target_base_count,
+                            const int64_t *t_start, const int32_t *t_len, const uint8_t *query_bases,
+                            int64_t query_base_count, const int64_t *q_start, const int32_t *q_len, int max_tl, int max_ql,
+                            int match, int mismatch, int gopen, int gext, int strategy, int32_t *offset_out,
+                            mgl_sw_score *score_out, char *cigar_out, int cigar_stride, int32_t *cigar_len_out,
+                            int32_t *status_out, int flags);
+
+/*
+ * Page-lock arrays the caller passes to the host-buffer entries (mgl_sw_align_batch, _status, _2bit) again and again --
+ * hipHostRegister: the direct ByteBuffers of a JVM are a natural fit.  Copies from registered input arrays are asynchronous DMA
+ * (the entry no longer blocks inside pageable copies), and when EVERY output array of a call lies in registered memory the
+ * results are copied straight into it instead of through the context's own pinned ring.  Registration costs milliseconds per
+ * gigabyte: do it once, not per call.  Unregister before freeing the memory (waits for the context's copies to finish).
+ */
+int mgl_sw_register_host_buffer(mgl_sw_ctx *ctx, void *ptr, size_t bytes);
+int mgl_sw_unregister_host_buffer(mgl_sw_ctx *ctx, void *ptr);
 
 /*
  * ASCII bases addressed by (start, length) per pair instead of consecutive offsets: pair k =

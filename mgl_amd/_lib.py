@@ -28,6 +28,7 @@ SYMBOLS = (
     "mgl_sw_cigar_from_backtrack", "mgl_sw_band_fill", "mgl_sw_set_coalescing", "mgl_sw_coalescing_stats", "mgl_sw_group_by_geometry",
     "mgl_sw_multi_create", "mgl_sw_multi_destroy", "mgl_sw_multi_device_count", "mgl_sw_multi_ctx", "mgl_sw_multi_set_workspace",
     "mgl_sw_multi_last_error", "mgl_sw_align_batch_multi", "mgl_sw_multi_last_shards", "mgl_sw_shard_by_cells",
+    "mgl_sw_align_batch_2bit", "mgl_sw_register_host_buffer", "mgl_sw_unregister_host_buffer",
 )
 
 
@@ -129,6 +130,10 @@ def lib():
     L.mgl_sw_align_batch_multi.argtypes = [vp, C.c_int64, vp, vp, vp, vp] + [C.c_int] * 5 + [vp, vp, vp, C.c_int, vp, vp]
     L.mgl_sw_multi_last_shards.argtypes = [vp, vp]
     L.mgl_sw_shard_by_cells.argtypes = [C.c_int64, vp, vp, C.c_int, C.c_int64, vp]
+    L.mgl_sw_align_batch_2bit.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int] + [C.c_int] * 5 + [
+        vp, vp, vp, C.c_int, vp, vp, C.c_int]
+    L.mgl_sw_register_host_buffer.argtypes = [vp, vp, C.c_size_t]
+    L.mgl_sw_unregister_host_buffer.argtypes = [vp, vp]
     _lib = L
     return L
 

@@ -112,13 +112,23 @@ struct mgl_sw_ctx {
     std::vector<hipEvent_t> pool;
     int pool_used = 0;
     int64_t diag_blocks = 0;
-    DevBuf d_t, d_toff, d_q, d_qoff, d_off, d_score, d_cig, d_len, d_status, d_btr, d_any, d_matrix; // host-API staging
+    DevBuf d_t, d_toff, d_q, d_qoff, d_off, d_score, d_cig, d_len, d_status, d_btr, d_any, d_matrix, d_tlen, d_qlen; // host-API staging
     int64_t last_stride_words = 0, last_chunk_count = 0; // geometry of the last chunk (for expand_slot)
     int last_packed16 = 0;
     int precision = 0; // 0 = choose per batch, 32 = always the int32 kernels, 16 = try the self-checking 16-bit long-read kernel whenever its constants fit
     int profiling = 0; // 0 off, 1 per-kernel HIP events, 2 also the in-kernel clock probe
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     mgl_sw_timing timing{};
+    // host arrays the caller has page-locked for this context (mgl_sw_register_host_buffer): copies from / into them are true
+    // asynchronous DMA, so the host entry neither blocks in them nor stages results through its own pinned ring
+    std::vector<std::pair<const char *, size_t>> registered;
+    bool is_registered(const void *p, size_t bytes) const
+    {
+        const char *c = static_cast<const char *>(p);
+        for (const auto &r : registered)
+            if (c >= r.first && c + bytes <= r.first + r.second) return true;
+        return false;
+    }
     std::string err;
     std::mutex mu;
 };
@@ -274,15 +284,18 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // (what counts is the size of a launch: a batch that the workspace cuts into small chunks is no better than a small batch.
     // Behind the host-buffer entry the chunks are the units of the copy pipeline: there a large batch goes one ROUND of the
     // chip at a time -- 128 pairs per wave, three (32-row strips) or four waves per SIMD -- on two alternating streams)
-    const int64_t lane_round = (int64_t)ctx->n_cus * (lane_rows == 16 ? 16 : 12) * 128;
+    // (the checkpointed form runs two waves per SIMD, the forms that store every flag three (32-row strips) or four)
+    static const bool lane_fuse = [] { const char *e = getenv("MGL_SW_LANE_FUSE"); return !e || atoi(e) != 0; }();
+    static const bool lane_ck_on = [] { const char *e = getenv("MGL_SW_LANE_CK"); return !e || atoi(e) != 0; }();
+    const bool lane_ck_ok = lane_rows == 32 && lane_fuse && d_cigar != nullptr && ctx->lane_checkpoint != 1 && (ctx->lane_checkpoint == 2 || lane_ck_on);
+    // (a host entry's chunk: one round where the inputs are ASCII -- 0.1 GB per round over the link before the first kernel can
+    // start -- two where they are 2-bit packed: 10 M pairs 69.1 ms against 72.4 with one, 72.3 with four; ASCII: 83.1 / 84.5 / 87.2)
+    const int64_t lane_round = (int64_t)ctx->n_cus * (lane_ck_ok ? 8 : lane_rows == 16 ? 16 : 12) * 128 * (hooks && tset.packed2 ? 2 : 1);
     static const int host_chunks_l = [] { const char *e = getenv("MGL_SW_HOST_CHUNKS"); return e ? std::max(1, atoi(e)) : 32; }();
     const bool lane_rounds = hooks && n >= 4 * lane_round;
     const int64_t lane_launch = std::min<int64_t>(lane_rounds ? n : hooks ? std::max<int64_t>(n / host_chunks_l, (int64_t)256 * 1024) : n,
                                                   std::min<int64_t>(n, ctx->ws_limit / (lane_tb_words(max_tl, max_ql, lane_rows) * 4 / 128 + 1)));
     // (its checkpointed form stages base codes and takes either wire format; the form that stores every flag reads ASCII only)
-    static const bool lane_fuse = [] { const char *e = getenv("MGL_SW_LANE_FUSE"); return !e || atoi(e) != 0; }();
-    static const bool lane_ck_on = [] { const char *e = getenv("MGL_SW_LANE_CK"); return !e || atoi(e) != 0; }();
-    const bool lane_ck_ok = lane_rows == 32 && lane_fuse && d_cigar != nullptr && ctx->lane_checkpoint != 1 && (ctx->lane_checkpoint == 2 || lane_ck_on);
     const bool lane_ck_wanted = lane_ck_ok && !score_only_hint; // (a 2-bit batch gets the lane kernel only in this form)
     const bool use_lane = geom == GEOM_UNIFORM && ctx->precision != 32 && !d_matrix && match > 0 && ctx->lane_kernel != 1 &&
                           (ctx->lane_kernel == 2 || lane_launch >= (hooks ? 2 * kLaneMinPairs : kLaneMinPairs)) && // (the host entry's chunks: as measured before)
@@ -848,7 +861,7 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
-    for (DevBuf *b : {&ctx->tb[0], &ctx->tb[1], &ctx->rec[0], &ctx->rec[1], &ctx->bnd[0], &ctx->bnd[1], &ctx->diag, &ctx->scratch, &ctx->d_t, &ctx->d_toff, &ctx->d_q, &ctx->d_qoff, &ctx->d_off, &ctx->d_score,
+    for (DevBuf *b : {&ctx->tb[0], &ctx->tb[1], &ctx->rec[0], &ctx->rec[1], &ctx->bnd[0], &ctx->bnd[1], &ctx->diag, &ctx->scratch, &ctx->d_t, &ctx->d_toff, &ctx->d_q, &ctx->d_qoff, &ctx->d_tlen, &ctx->d_qlen, &ctx->d_off, &ctx->d_score,
                       &ctx->d_cig, &ctx->d_len, &ctx->d_status, &ctx->d_btr, &ctx->d_any, &ctx->d_matrix})
         b->release();
     for (auto &e : ctx->ev)
@@ -1108,6 +1121,108 @@ static int align_batch_staged_nolock(mgl_sw_ctx *ctx, int n, size_t in_bytes, si
                                      int mismatch, int gopen, int gext, int strategy, int cigar_stride, size_t out_bytes, int uniform,
                                      int64_t cells_hint);
 
+namespace {
+
+// every stream a host entry may have put work on (the error paths: nothing of the failed call may still use the context's
+// buffers when the next call reuses them)
+void drain_streams(mgl_sw_ctx *ctx, hipStream_t st)
+{
+    if (ctx->d2h) (void)hipStreamSynchronize(ctx->d2h);
+    if (ctx->fill2) (void)hipStreamSynchronize(ctx->fill2);
+    (void)hipStreamSynchronize(ctx->h2d);
+    (void)hipStreamSynchronize(ctx->aux);
+    (void)hipStreamSynchronize(st);
+}
+
+// How a host entry's results leave the device, chunk by chunk (ChunkHooks::after_traceback).  Pageable arrays: a blocking copy
+// into them keeps the calling thread from the next chunk's input copies for a third of the call (10 M pairs: 17 ms out, 29 ms
+// in), and a second thread inside the runtime's pageable-copy path makes both slower -- so a chunk's results go to a pinned
+// buffer by an asynchronous copy on a stream of their own (the link's other direction) and a helper job moves them on into the
+// caller's arrays once they have landed; three buffers in rotation.  Arrays the caller has REGISTERED
+// (mgl_sw_register_host_buffer) take the asynchronous copies directly.
+struct ResultPump {
+    mgl_sw_ctx *ctx;
+    int32_t *offset_out;
+    mgl_sw_score *score_out;
+    char *cigar_out;
+    int cigar_stride;
+    int32_t *cigar_len_out, *status_out;
+    bool direct;
+    std::future<int> res_job[3];
+    int64_t res_seq = 0;
+    ResultPump(mgl_sw_ctx *c, int32_t *off, mgl_sw_score *sc, char *cg, int stride, int32_t *len, int32_t *st, int64_t n)
+        : ctx(c), offset_out(off), score_out(sc), cigar_out(cg), cigar_stride(stride), cigar_len_out(len), status_out(st)
+    {
+        const size_t nn = (size_t)n;
+        direct = (c->is_registered(off, nn * 4) && (!sc || c->is_registered(sc, nn * sizeof(mgl_sw_score))) &&
+                                 c->is_registered(cg, nn * (size_t)stride) && (!len || c->is_registered(len, nn * 4)) &&
+                                 (!st || c->is_registered(st, nn * 4)));
+    }
+    int join()
+    {
+        int worst = MGL_SW_OK;
+        for (auto &j : res_job)
+            if (j.valid()) {
+                const int r = j.get();
+                if (r != MGL_SW_OK) worst = r;
+            }
+        return worst;
+    }
+    int after_traceback(int64_t first, int64_t count, hipEvent_t results_ready)
+    {
+        const size_t f = (size_t)first, c = (size_t)count;
+        if (!ctx->d2h) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->d2h, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, results_ready, 0));
+        if (direct) {
+            hipStream_t s = ctx->d2h;
+            HIP_TRY(ctx, hipMemcpyAsync(offset_out + f, static_cast<int32_t *>(ctx->d_off.p) + f, c * 4, hipMemcpyDeviceToHost, s));
+            if (score_out) HIP_TRY(ctx, hipMemcpyAsync(score_out + f, static_cast<Score *>(ctx->d_score.p) + f, c * sizeof(Score), hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipMemcpyAsync(cigar_out + f * cigar_stride, static_cast<char *>(ctx->d_cig.p) + f * cigar_stride, c * (size_t)cigar_stride, hipMemcpyDeviceToHost, s));
+            if (cigar_len_out) HIP_TRY(ctx, hipMemcpyAsync(cigar_len_out + f, static_cast<int32_t *>(ctx->d_len.p) + f, c * 4, hipMemcpyDeviceToHost, s));
+            if (status_out) HIP_TRY(ctx, hipMemcpyAsync(status_out + f, static_cast<int32_t *>(ctx->d_status.p) + f, c * 4, hipMemcpyDeviceToHost, s));
+            return MGL_SW_OK;
+        }
+        const int r = (int)(res_seq++ % 3);
+        if (res_job[r].valid() && res_job[r].get() != MGL_SW_OK) return fail(ctx, MGL_SW_ERR_DEVICE, "mgl_sw_align_batch: copying results out failed");
+        // sections of the pinned buffer, 16-byte aligned: offsets | scores | cigars | lengths | statuses
+        const size_t o_off = 0, o_sc = o_off + ((c * 4 + 15) & ~(size_t)15), o_cg = o_sc + ((c * sizeof(Score) + 15) & ~(size_t)15),
+                     o_len = o_cg + ((c * (size_t)cigar_stride + 15) & ~(size_t)15), o_st = o_len + ((c * 4 + 15) & ~(size_t)15), bytes = o_st + c * 4 + 16;
+        if (!ctx->res_copied[r]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->res_copied[r], hipEventDisableTiming));
+        if (bytes > ctx->pin_res_cap[r]) {
+            if (ctx->pin_res[r]) (void)hipHostFree(ctx->pin_res[r]);
+            ctx->pin_res[r] = nullptr;
+            ctx->pin_res_cap[r] = 0;
+            HIP_TRY(ctx, hipHostMalloc(&ctx->pin_res[r], bytes + bytes / 8, hipHostMallocDefault));
+            ctx->pin_res_cap[r] = bytes + bytes / 8;
+        }
+        char *const pin = static_cast<char *>(ctx->pin_res[r]);
+        HIP_TRY(ctx, hipMemcpyAsync(pin + o_off, static_cast<int32_t *>(ctx->d_off.p) + f, c * 4, hipMemcpyDeviceToHost, ctx->d2h));
+        if (score_out) HIP_TRY(ctx, hipMemcpyAsync(pin + o_sc, static_cast<Score *>(ctx->d_score.p) + f, c * sizeof(Score), hipMemcpyDeviceToHost, ctx->d2h));
+        HIP_TRY(ctx, hipMemcpyAsync(pin + o_cg, static_cast<char *>(ctx->d_cig.p) + f * cigar_stride, c * (size_t)cigar_stride, hipMemcpyDeviceToHost, ctx->d2h));
+        if (cigar_len_out) HIP_TRY(ctx, hipMemcpyAsync(pin + o_len, static_cast<int32_t *>(ctx->d_len.p) + f, c * 4, hipMemcpyDeviceToHost, ctx->d2h));
+        if (status_out) HIP_TRY(ctx, hipMemcpyAsync(pin + o_st, static_cast<int32_t *>(ctx->d_status.p) + f, c * 4, hipMemcpyDeviceToHost, ctx->d2h));
+        HIP_TRY(ctx, hipEventRecord(ctx->res_copied[r], ctx->d2h));
+        hipEvent_t landed = ctx->res_copied[r];
+        const int device = ctx->device;
+        int32_t *const off_ = offset_out, *const len_ = cigar_len_out, *const st_ = status_out;
+        mgl_sw_score *const sc_ = score_out;
+        char *const cg_ = cigar_out;
+        const int stride = cigar_stride;
+        res_job[r] = std::async(std::launch::async, [=]() -> int {
+            if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(landed) != hipSuccess) return MGL_SW_ERR_DEVICE;
+            memcpy(off_ + f, pin + o_off, c * 4);
+            if (sc_) memcpy(sc_ + f, pin + o_sc, c * sizeof(Score));
+            memcpy(cg_ + f * stride, pin + o_cg, c * (size_t)stride);
+            if (len_) memcpy(len_ + f, pin + o_len, c * 4);
+            if (st_) memcpy(st_ + f, pin + o_st, c * 4);
+            return MGL_SW_OK;
+        });
+        return MGL_SW_OK;
+    }
+};
+
+} // namespace
+
 int mgl_sw_align_batch(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const int64_t *t_off,
                        const uint8_t *queries, const int64_t *q_off, int match, int mismatch, int gopen, int gext,
                        int strategy, int32_t *offset_out, mgl_sw_score *score_out, char *cigar_out, int cigar_stride,
@@ -1251,79 +1366,12 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
         t_in += now() - t0;
         return MGL_SW_OK;
     };
-    // Results: a blocking copy into the caller's pageable arrays keeps this thread from the next chunk's input copies for a third of
-    // the call (10 M pairs: 17 ms out, 29 ms in), and a second thread inside the runtime's pageable-copy path makes both slower.  So
-    // the results of a chunk go to a pinned buffer by an asynchronous copy on a stream of their own (the link's other direction),
-    // and a helper job moves them on into the caller's arrays once they have landed; three buffers in rotation.
-    static const bool staged_out = [] { const char *e = getenv("MGL_SW_OUT_STAGED"); return !e || atoi(e) != 0; }();
-    std::future<int> res_job[3];
-    int64_t res_seq = 0;
-    auto join_results = [&]() -> int {
-        int worst = MGL_SW_OK;
-        for (auto &j : res_job)
-            if (j.valid()) {
-                const int r = j.get();
-                if (r != MGL_SW_OK) worst = r;
-            }
-        return worst;
-    };
+    ResultPump pump(ctx, offset_out, score_out, cigar_out, cigar_stride, cigar_len_out, status_out, n);
     hooks.after_traceback = [&](int64_t first, int64_t count, hipEvent_t results_ready) -> int {
         const double t0 = now();
-        const size_t f = (size_t)first, c = (size_t)count;
-        if (staged_out) {
-            const int r = (int)(res_seq++ % 3);
-            if (res_job[r].valid() && res_job[r].get() != MGL_SW_OK) return fail(ctx, MGL_SW_ERR_DEVICE, "mgl_sw_align_batch: copying results out failed");
-            // sections of the pinned buffer, 16-byte aligned: offsets | scores | cigars | lengths | statuses
-            const size_t o_off = 0, o_sc = o_off + ((c * 4 + 15) & ~(size_t)15), o_cg = o_sc + ((c * sizeof(Score) + 15) & ~(size_t)15),
-                         o_len = o_cg + ((c * (size_t)cigar_stride + 15) & ~(size_t)15), o_st = o_len + ((c * 4 + 15) & ~(size_t)15), bytes = o_st + c * 4 + 16;
-            if (!ctx->d2h) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->d2h, hipStreamNonBlocking));
-            if (!ctx->res_copied[r]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->res_copied[r], hipEventDisableTiming));
-            if (bytes > ctx->pin_res_cap[r]) {
-                if (ctx->pin_res[r]) (void)hipHostFree(ctx->pin_res[r]);
-                ctx->pin_res[r] = nullptr;
-                ctx->pin_res_cap[r] = 0;
-                HIP_TRY(ctx, hipHostMalloc(&ctx->pin_res[r], bytes + bytes / 8, hipHostMallocDefault));
-                ctx->pin_res_cap[r] = bytes + bytes / 8;
-            }
-            char *const pin = static_cast<char *>(ctx->pin_res[r]);
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, results_ready, 0));
-            HIP_TRY(ctx, hipMemcpyAsync(pin + o_off, static_cast<int32_t *>(ctx->d_off.p) + f, c * 4, hipMemcpyDeviceToHost, ctx->d2h));
-            if (score_out) HIP_TRY(ctx, hipMemcpyAsync(pin + o_sc, static_cast<Score *>(ctx->d_score.p) + f, c * sizeof(Score), hipMemcpyDeviceToHost, ctx->d2h));
-            HIP_TRY(ctx, hipMemcpyAsync(pin + o_cg, static_cast<char *>(ctx->d_cig.p) + f * cigar_stride, c * (size_t)cigar_stride, hipMemcpyDeviceToHost, ctx->d2h));
-            if (cigar_len_out) HIP_TRY(ctx, hipMemcpyAsync(pin + o_len, static_cast<int32_t *>(ctx->d_len.p) + f, c * 4, hipMemcpyDeviceToHost, ctx->d2h));
-            if (status_out) HIP_TRY(ctx, hipMemcpyAsync(pin + o_st, static_cast<int32_t *>(ctx->d_status.p) + f, c * 4, hipMemcpyDeviceToHost, ctx->d2h));
-            HIP_TRY(ctx, hipEventRecord(ctx->res_copied[r], ctx->d2h));
-            hipEvent_t landed = ctx->res_copied[r];
-            const int device = ctx->device;
-            res_job[r] = std::async(std::launch::async, [=]() -> int {
-                if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(landed) != hipSuccess) return MGL_SW_ERR_DEVICE;
-                memcpy(offset_out + f, pin + o_off, c * 4);
-                if (score_out) memcpy(score_out + f, pin + o_sc, c * sizeof(Score));
-                memcpy(cigar_out + f * cigar_stride, pin + o_cg, c * (size_t)cigar_stride);
-                if (cigar_len_out) memcpy(cigar_len_out + f, pin + o_len, c * 4);
-                if (status_out) memcpy(status_out + f, pin + o_st, c * 4);
-                return MGL_SW_OK;
-            });
-            t_out += now() - t0;
-            return MGL_SW_OK;
-        }
-        hipStream_t tb_stream = ctx->h2d;   // the copy stream: never queued behind a later chunk's kernels
-        HIP_TRY(ctx, hipStreamWaitEvent(tb_stream, results_ready, 0));
-        HIP_TRY(ctx, hipMemcpyAsync(offset_out + f, static_cast<int32_t *>(ctx->d_off.p) + f, c * 4, hipMemcpyDeviceToHost,
-                                    tb_stream));
-        if (score_out)
-            HIP_TRY(ctx, hipMemcpyAsync(score_out + f, static_cast<Score *>(ctx->d_score.p) + f, c * sizeof(Score),
-                                        hipMemcpyDeviceToHost, tb_stream));
-        HIP_TRY(ctx, hipMemcpyAsync(cigar_out + f * cigar_stride, static_cast<char *>(ctx->d_cig.p) + f * cigar_stride,
-                                    c * cigar_stride, hipMemcpyDeviceToHost, tb_stream));
-        if (cigar_len_out)
-            HIP_TRY(ctx, hipMemcpyAsync(cigar_len_out + f, static_cast<int32_t *>(ctx->d_len.p) + f, c * 4,
-                                        hipMemcpyDeviceToHost, tb_stream));
-        if (status_out)
-            HIP_TRY(ctx, hipMemcpyAsync(status_out + f, static_cast<int32_t *>(ctx->d_status.p) + f, c * 4,
-                                        hipMemcpyDeviceToHost, tb_stream));
+        const int r = pump.after_traceback(first, count, results_ready);
         t_out += now() - t0;
-        return MGL_SW_OK;
+        return r;
     };
 
     // ---- a batch of mixed geometries: every chunk is sorted by (tl, ql) here, on the host, while the GPU works on the
@@ -1441,22 +1489,188 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
                         static_cast<char *>(ctx->d_cig.p), cigar_stride, static_cast<int32_t *>(ctx->d_len.p),
                         static_cast<int32_t *>(ctx->d_status.p), cells, uniform, false, &hooks);
     if (next_job.valid()) next_job.wait();
-    const int res_rc = join_results(); // (the helper jobs hold references to nothing of this frame, but their copies must have landed)
+    const int res_rc = pump.join(); // (the helper jobs hold references to nothing of this frame, but their copies must have landed)
     if (rc == MGL_SW_OK && res_rc != MGL_SW_OK) rc = fail(ctx, MGL_SW_ERR_DEVICE, "mgl_sw_align_batch: copying results out failed");
     if (rc != MGL_SW_OK) {
-        if (ctx->d2h) (void)hipStreamSynchronize(ctx->d2h);
-        (void)hipStreamSynchronize(ctx->h2d);
-        (void)hipStreamSynchronize(ctx->aux);
-        (void)hipStreamSynchronize(st);
+        drain_streams(ctx, st); // nothing of this call may still be using the workspace when the next call reuses it
         return rc;
     }
     const double t_enq = now();
     HIP_TRY(ctx, hipStreamSynchronize(ctx->h2d));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (ctx->d2h) HIP_TRY(ctx, hipStreamSynchronize(ctx->d2h)); // (results copied straight into registered arrays)
     if (host_timing)
         fprintf(stderr, "[mgl_sw] host entry: %.1f ms enqueue (%.1f ms in input copies, %.1f ms in result copies), %.1f ms drain\n",
                 (t_enq - t_begin) * 1e3, t_in * 1e3, t_out * 1e3, (now() - t_enq) * 1e3);
+    if (status_out) return MGL_SW_OK;
+    int32_t any = 0;
+    HIP_TRY(ctx, hipMemcpy(&any, ctx->d_any.p, 4, hipMemcpyDeviceToHost));
+    if (any != 0) return fail(ctx, any, "a CIGAR did not fit cigar_stride");
+    return MGL_SW_OK;
+}
+
+// ---- the caller's arrays, page-locked (hipHostRegister): copies from and into them are true asynchronous DMA
+int mgl_sw_register_host_buffer(mgl_sw_ctx *ctx, void *ptr, size_t bytes)
+{
+    if (!ctx || !ptr || bytes == 0) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->is_registered(ptr, bytes)) return MGL_SW_OK;
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? MGL_SW_ERR_NOMEM : MGL_SW_ERR_DEVICE, std::string("hipHostRegister: ") + hipGetErrorString(e));
+    ctx->registered.emplace_back(static_cast<const char *>(ptr), bytes);
+    return MGL_SW_OK;
+}
+
+int mgl_sw_unregister_host_buffer(mgl_sw_ctx *ctx, void *ptr)
+{
+    if (!ctx || !ptr) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (size_t i = 0; i < ctx->registered.size(); ++i)
+        if (ctx->registered[i].first == static_cast<const char *>(ptr)) {
+            HIP_TRY(ctx, hipSetDevice(ctx->device));
+            drain_streams(ctx, ctx->stream); // no copy of a finished call may still be in flight
+            (void)hipHostUnregister(ptr);
+            ctx->registered.erase(ctx->registered.begin() + (long)i);
+            return MGL_SW_OK;
+        }
+    return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_unregister_host_buffer: not a registered buffer");
+}
+
+// ---- host buffers, 2-bit packed bases (the wire format of mgl_sw_align_batch_device_2bit from host memory).  The packed arrays move
+// chunk by chunk with the index arrays when the pairs' start positions ascend (reads packed back to back), or whole before the
+// first chunk (windows into a genome, in any order); results leave as in mgl_sw_align_batch_status.
+int mgl_sw_align_batch_2bit(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_bases, int64_t target_base_count, const int64_t *t_start,
+                            const int32_t *t_len, const uint8_t *query_bases, int64_t query_base_count, const int64_t *q_start,
+                            const int32_t *q_len, int max_tl, int max_ql, int match, int mismatch, int gopen, int gext, int strategy,
+                            int32_t *offset_out, mgl_sw_score *score_out, char *cigar_out, int cigar_stride, int32_t *cigar_len_out,
+                            int32_t *status_out, int flags)
+{
+    if (!ctx) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (n == 0) return MGL_SW_OK;
+    const bool uniform = (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) != 0, grouped = (flags & MGL_SW_FLAG_GROUPED_GEOMETRY) != 0;
+    if (n < 0 || !target_bases || !t_start || !query_bases || !q_start || !offset_out || !cigar_out || cigar_stride < 1 || max_tl < 1 || max_ql < 1 ||
+        target_base_count < 1 || query_base_count < 1 || !strategy_ok(strategy) || ((!t_len || !q_len) && !uniform))
+        return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch_2bit: bad argument (length arrays are required unless the geometry is uniform)");
+    // one pass over the index arrays: every pair inside its array, lengths within the stated maxima, do the starts ascend?
+    struct Scan {
+        bool bad = false, t_sorted = true, q_sorted = true;
+        int64_t cells = 0;
+    };
+    auto scan_range = [&](int64_t a, int64_t b) {
+        Scan r;
+        for (int64_t k = a; k < b; ++k) {
+            const int64_t tl = uniform ? max_tl : t_len[k], ql = uniform ? max_ql : q_len[k];
+            r.bad |= tl < 1 || ql < 1 || tl > max_tl || ql > max_ql || t_start[k] < 0 || q_start[k] < 0 || t_start[k] + tl > target_base_count ||
+                     q_start[k] + ql > query_base_count;
+            r.cells += tl * ql;
+            if (k > 0) {
+                r.t_sorted &= t_start[k] >= t_start[k - 1];
+                r.q_sorted &= q_start[k] >= q_start[k - 1];
+            }
+        }
+        return r;
+    };
+    Scan sc;
+    try {
+        constexpr int kParts = 8;
+        if (n >= (1 << 21)) {
+            std::future<Scan> part[kParts];
+            for (int p = 0; p < kParts; ++p) part[p] = std::async(std::launch::async, scan_range, n * p / kParts, n * (p + 1) / kParts + (p + 1 < kParts ? 1 : 0));
+            for (int p = 0; p < kParts; ++p) {
+                const Scan r = part[p].get();
+                sc.bad |= r.bad;
+                sc.t_sorted &= r.t_sorted;
+                sc.q_sorted &= r.q_sorted;
+                sc.cells += r.cells;
+            }
+        } else {
+            sc = scan_range(0, n);
+        }
+    } catch (const std::exception &) {
+        return fail(ctx, MGL_SW_ERR_NOMEM, "mgl_sw_align_batch_2bit: out of host resources");
+    }
+    if (sc.bad) return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch_2bit: a pair lies outside its packed array or its length outside [1, max]");
+    const size_t t_bytes = (size_t)((target_base_count + 3) >> 2), q_bytes = (size_t)((query_base_count + 3) >> 2), nn = (size_t)n;
+
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, ctx->d_t.reserve(t_bytes + 8));
+    HIP_TRY(ctx, ctx->d_q.reserve(q_bytes + 8));
+    HIP_TRY(ctx, ctx->d_toff.reserve(nn * 8));
+    HIP_TRY(ctx, ctx->d_qoff.reserve(nn * 8));
+    if (!uniform) {
+        HIP_TRY(ctx, ctx->d_tlen.reserve(nn * 4));
+        HIP_TRY(ctx, ctx->d_qlen.reserve(nn * 4));
+    }
+    HIP_TRY(ctx, ctx->d_off.reserve(nn * 4));
+    HIP_TRY(ctx, ctx->d_score.reserve(nn * sizeof(Score)));
+    HIP_TRY(ctx, ctx->d_cig.reserve(nn * (size_t)cigar_stride));
+    HIP_TRY(ctx, ctx->d_len.reserve(nn * 4));
+    HIP_TRY(ctx, ctx->d_status.reserve(nn * 4));
+    HIP_TRY(ctx, ctx->d_any.reserve(16));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_any.p, 0, 4, st));
+
+    ChunkHooks hooks;
+    hooks.d_status_any = static_cast<int32_t *>(ctx->d_any.p);
+    // bytes [done, upto) of a packed array that the chunks so far have not brought over (ascending starts), or all of it at once
+    size_t t_done = 0, q_done = 0;
+    auto bring = [&](const uint8_t *src, DevBuf &dst, size_t total, bool sorted, const int64_t *start, const int32_t *len, int uni_len, int64_t first,
+                     int64_t count, size_t &done) -> int {
+        size_t upto = total;
+        if (sorted && first + count < n) {
+            const int64_t last = first + count - 1;
+            int64_t hi = start[last] + (len ? len[last] : uni_len);
+            for (int64_t k = first; k < last; ++k) hi = std::max(hi, start[k] + (len ? len[k] : uni_len)); // (starts ascend, ends need not)
+            upto = std::min(total, (size_t)((hi + 3) >> 2));
+        }
+        if (upto > done) {
+            HIP_TRY(ctx, hipMemcpyAsync(static_cast<uint8_t *>(dst.p) + done, src + done, upto - done, hipMemcpyHostToDevice, ctx->h2d));
+            done = upto;
+        }
+        return MGL_SW_OK;
+    };
+    hooks.before_fill = [&](int64_t first, int64_t count, hipStream_t fill_stream) -> int {
+        const size_t f = (size_t)first, c = (size_t)count;
+        HIP_TRY(ctx, hipMemcpyAsync(static_cast<int64_t *>(ctx->d_toff.p) + f, t_start + f, c * 8, hipMemcpyHostToDevice, ctx->h2d));
+        HIP_TRY(ctx, hipMemcpyAsync(static_cast<int64_t *>(ctx->d_qoff.p) + f, q_start + f, c * 8, hipMemcpyHostToDevice, ctx->h2d));
+        if (!uniform) {
+            HIP_TRY(ctx, hipMemcpyAsync(static_cast<int32_t *>(ctx->d_tlen.p) + f, t_len + f, c * 4, hipMemcpyHostToDevice, ctx->h2d));
+            HIP_TRY(ctx, hipMemcpyAsync(static_cast<int32_t *>(ctx->d_qlen.p) + f, q_len + f, c * 4, hipMemcpyHostToDevice, ctx->h2d));
+        }
+        int rc = bring(target_bases, ctx->d_t, t_bytes, sc.t_sorted, t_start, uniform ? nullptr : t_len, max_tl, first, count, t_done);
+        if (rc == MGL_SW_OK) rc = bring(query_bases, ctx->d_q, q_bytes, sc.q_sorted, q_start, uniform ? nullptr : q_len, max_ql, first, count, q_done);
+        if (rc != MGL_SW_OK) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->in_done, ctx->h2d));
+        HIP_TRY(ctx, hipStreamWaitEvent(fill_stream, ctx->in_done, 0));
+        return MGL_SW_OK;
+    };
+    ResultPump pump(ctx, offset_out, score_out, cigar_out, cigar_stride, cigar_len_out, status_out, n);
+    hooks.after_traceback = [&](int64_t first, int64_t count, hipEvent_t results_ready) -> int { return pump.after_traceback(first, count, results_ready); };
+
+    const SeqSet ts{static_cast<const uint8_t *>(ctx->d_t.p), static_cast<const int64_t *>(ctx->d_toff.p), uniform ? nullptr : static_cast<const int32_t *>(ctx->d_tlen.p), max_tl, 1},
+        qs{static_cast<const uint8_t *>(ctx->d_q.p), static_cast<const int64_t *>(ctx->d_qoff.p), uniform ? nullptr : static_cast<const int32_t *>(ctx->d_qlen.p), max_ql, 1};
+    int rc;
+    try {
+        rc = run_device(ctx, st, n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext, strategy, static_cast<int32_t *>(ctx->d_off.p),
+                        static_cast<Score *>(ctx->d_score.p), static_cast<char *>(ctx->d_cig.p), cigar_stride, static_cast<int32_t *>(ctx->d_len.p),
+                        static_cast<int32_t *>(ctx->d_status.p), sc.cells, uniform ? GEOM_UNIFORM : grouped ? GEOM_GROUPED : GEOM_MIXED,
+                        (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, &hooks);
+    } catch (const std::exception &) {
+        rc = fail(ctx, MGL_SW_ERR_NOMEM, "mgl_sw_align_batch_2bit: out of host resources");
+    }
+    const int res_rc = pump.join();
+    if (rc == MGL_SW_OK && res_rc != MGL_SW_OK) rc = fail(ctx, MGL_SW_ERR_DEVICE, "mgl_sw_align_batch_2bit: copying results out failed");
+    if (rc != MGL_SW_OK) {
+        drain_streams(ctx, st);
+        return rc;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->h2d));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (ctx->d2h) HIP_TRY(ctx, hipStreamSynchronize(ctx->d2h));
     if (status_out) return MGL_SW_OK;
     int32_t any = 0;
     HIP_TRY(ctx, hipMemcpy(&any, ctx->d_any.p, 4, hipMemcpyDeviceToHost));

@@ -133,12 +133,28 @@ int mgl_sw_align_batch_multi(mgl_sw_multi *m, int64_t n, const uint8_t *targets,
         m->err = "mgl_sw_align_batch_multi: offsets are not ascending";
         return rc;
     }
-    std::vector<int> status((size_t)parts, MGL_SW_OK);
-    auto work = [&](int p) {
+    // No C++ exception may cross the C ABI, and none may escape while worker threads are joinable (std::terminate): a shard whose
+    // vectors cannot be allocated reports MGL_SW_ERR_NOMEM like any other failure of that device, and threads that cannot be
+    // started leave their shards to the calling thread.
+    std::vector<int> status;
+    try {
+        status.assign((size_t)parts, MGL_SW_OK);
+    } catch (const std::exception &) {
+        m->err = "mgl_sw_align_batch_multi: out of memory";
+        return MGL_SW_ERR_NOMEM;
+    }
+    auto work = [&](int p) noexcept {
         const int64_t lo = m->shard_first[(size_t)p], hi = m->shard_first[(size_t)p + 1], cnt = hi - lo;
         if (cnt == 0) return;
         // the host entry wants offsets that start at 0: rebase this shard's two offset arrays (16 bytes per pair)
-        std::vector<int64_t> to((size_t)cnt + 1), qo((size_t)cnt + 1);
+        std::vector<int64_t> to, qo;
+        try {
+            to.resize((size_t)cnt + 1);
+            qo.resize((size_t)cnt + 1);
+        } catch (const std::exception &) {
+            status[(size_t)p] = MGL_SW_ERR_NOMEM;
+            return;
+        }
         const int64_t t0 = t_off[lo], q0 = q_off[lo];
         for (int64_t k = 0; k <= cnt; ++k) {
             to[(size_t)k] = t_off[lo + k] - t0;
@@ -150,8 +166,14 @@ int mgl_sw_align_batch_multi(mgl_sw_multi *m, int64_t n, const uint8_t *targets,
             cigar_len_out ? cigar_len_out + lo : nullptr, status_out ? status_out + lo : nullptr);
     };
     std::vector<std::thread> th;
-    for (int p = 1; p < parts; ++p) th.emplace_back(work, p);
+    int started = 1;
+    try {
+        th.reserve((size_t)parts);
+        for (; started < parts; ++started) th.emplace_back(work, started);
+    } catch (const std::exception &) { // (no more threads: the shards from `started` on run here, one after the other)
+    }
     work(0); // the calling thread drives the first device
+    for (int p = started; p < parts; ++p) work(p);
     for (std::thread &t : th) t.join();
     for (int p = 0; p < parts; ++p)
         if (status[(size_t)p] != MGL_SW_OK) {

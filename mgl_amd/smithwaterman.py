@@ -148,6 +148,42 @@ class MicrosoftSmithWaterman:
         _check(rc, ctx)
         return BatchResult(off, sc, CigarColumn(cg.reshape(n, cigar_stride), ln), ln)
 
+    def align_packed_2bit(self, target_bases, target_base_count, t_start, t_len, query_bases, query_base_count, q_start, q_len,
+                          max_tl, max_ql, parameters=GATK_PARAMETERS, overhang_strategy=SWOverhangStrategy.SOFTCLIP, cigar_stride=None,
+                          out=None):
+        """mgl_sw_align_batch_2bit: 2-bit packed bases in host memory (four per byte), pair k = t_len[k] bases from base index
+        t_start[k] against q_len[k] from q_start[k]; t_len = q_len = None: every pair max_tl x max_ql.  ``out``: (offsets,
+        scores, cigars, lengths) arrays to write into (e.g. registered ones) instead of fresh ones."""
+        ctx = self._ensure()
+        n = len(t_start)
+        uniform = t_len is None and q_len is None
+        t_start = np.ascontiguousarray(t_start, dtype=np.int64)
+        q_start = np.ascontiguousarray(q_start, dtype=np.int64)
+        if not uniform:
+            t_len = np.ascontiguousarray(t_len, dtype=np.int32)
+            q_len = np.ascontiguousarray(q_len, dtype=np.int32)
+        if cigar_stride is None:
+            cigar_stride = max(16, 2 * max(max_tl, max_ql))
+        if out is None:
+            out = (np.empty(n, np.int32), np.empty((n, 6), np.int32), np.empty(n * cigar_stride, np.uint8), np.empty(n, np.int32))
+        off, sc, cg, ln = out
+        p = SWParameters(*parameters)
+        rc = _lib.lib().mgl_sw_align_batch_2bit(
+            ctx, n, target_bases.ctypes.data, int(target_base_count), t_start.ctypes.data, None if uniform else t_len.ctypes.data,
+            query_bases.ctypes.data, int(query_base_count), q_start.ctypes.data, None if uniform else q_len.ctypes.data, int(max_tl),
+            int(max_ql), p.match, p.mismatch, p.gap_open, p.gap_extend, int(overhang_strategy), off.ctypes.data, sc.ctypes.data,
+            cg.ctypes.data, cigar_stride, ln.ctypes.data, None, _lib.FLAG_UNIFORM_GEOMETRY if uniform else 0)
+        _check(rc, ctx)
+        return BatchResult(off, sc, CigarColumn(cg.reshape(n, cigar_stride), ln), ln)
+
+    def register_host_buffer(self, array):
+        """Page-lock a numpy array for this context (mgl_sw_register_host_buffer): the host entries then copy from / into it
+        asynchronously.  Keep the array alive and unregister it before it is freed."""
+        _check(_lib.lib().mgl_sw_register_host_buffer(self._ensure(), array.ctypes.data, array.nbytes), self._ctx)
+
+    def unregister_host_buffer(self, array):
+        _check(_lib.lib().mgl_sw_unregister_host_buffer(self._ensure(), array.ctypes.data), self._ctx)
+
     def expand_slot(self, slot, tl, ql):
         """Logical backtrack matrix of pair ``slot`` of the last chunk of the last batch call."""
         btr = np.zeros((tl + 1, ql + 1), dtype=np.int32)

@@ -38,6 +38,17 @@ static void walk(const TbArgs &a, bool scores_only)
         const int64_t p = a.first + slot;
         const int tl = a.t.length(p), ql = a.q.length(p);
         const uint8_t *t = a.t.data + a.t.off[p], *q = a.q.data + a.q.off[p];
+        std::vector<uint8_t> tb, qb; // 2-bit packed sets: unpacked to letters for the checker (only equality matters)
+        if (a.t.packed2) {
+            tb.resize((size_t)tl);
+            for (int k = 0; k < tl; ++k) tb[(size_t)k] = (uint8_t)"ACGT"[a.t.at(a.t.off[p], k)];
+            t = tb.data();
+        }
+        if (a.q.packed2) {
+            qb.resize((size_t)ql);
+            for (int k = 0; k < ql; ++k) qb[(size_t)k] = (uint8_t)"ACGT"[a.q.at(a.q.off[p], k)];
+            q = qb.data();
+        }
         const int64_t o = a.dest ? a.dest[p] : p;
         std::vector<char> text((size_t)(tl + ql + 4) * 12);
         int len = 0, off = 0;
@@ -91,6 +102,7 @@ bool dp16_range_ok(int tl, int ql, int match, int mismatch, int gopen, int gext,
 }
 int coop_lds_bytes(int sps_cap, int waves_per_block) { return coop_query_bytes(sps_cap) + waves_per_block * 2048 + 1024; }
 bool lane16_supported(const SeqSet &t, const SeqSet &q) { return !t.packed2 && !q.packed2; }
+bool lane16_ck_supported(const SeqSet &t, const SeqSet &q) { return (t.packed2 != 0) == (q.packed2 != 0); }
 
 hipError_t launch_dp16(const DpArgs &a, int, hipStream_t) { remember(a); return hipSuccess; }
 hipError_t launch_dp(const DpArgs &a, int, int, hipStream_t) { remember(a); return hipSuccess; }

@@ -3,10 +3,13 @@
 //   * mgl_sw_align_batch_status on a batch of mixed geometries cut into several chunks: the per-chunk sort by geometry on
 //     its helper thread, both workspace halves reused, results scattered back through the dest map, per-pair overflow status
 //   * a uniform batch through the lane-kernel path (fused walk, one buffer) and through the packed path
+//   * the same entry with every array REGISTERED (mgl_sw_register_host_buffer: results copied straight into the caller's arrays,
+//     no helper jobs), and mgl_sw_align_batch_2bit (packed bases from host memory) with ascending and with shuffled starts
 //   * mgl_sw_align_batch_multi over two (fake) devices: shard boundaries, one host thread per device
 //   * 48 threads through mgl_sw_align (the coalescing front-end): parking, batching, wake-up by shard, the caller whose
 //     buffer is too small (CIGAR_OVERFLOW) and the pair whose walk fails on the "device" (status handed back verbatim)
 // Every answer is compared with the CPU checker called directly.
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -193,6 +196,78 @@ int main()
             compare(most, eo, off, sc, cg, 64, len, &st);
         }
         unsetenv("MGL_SW_LANE_GROUP_MIN");
+    }
+    // ---- registered arrays: the results of every chunk go straight into the caller's arrays (no pinned ring, no helper jobs)
+    {
+        CHECK(mgl_sw_ctx_set_lane_kernel(ctx, 0) == 0 && mgl_sw_ctx_set_workspace(ctx, 96ll << 20) == 0);
+        const int64_t n = mixed.n();
+        const int stride = 128;
+        std::vector<int32_t> off((size_t)n), len((size_t)n), st((size_t)n);
+        std::vector<mgl_sw_score> sc((size_t)n);
+        std::vector<char> cg((size_t)n * stride, 1);
+        void *regs[] = {mixed.t.data(), mixed.toff.data(), mixed.q.data(), mixed.qoff.data(), off.data(), sc.data(), cg.data(), len.data(), st.data()};
+        const size_t bytes[] = {mixed.t.size(), mixed.toff.size() * 8, mixed.q.size(), mixed.qoff.size() * 8, off.size() * 4, sc.size() * sizeof(mgl_sw_score),
+                                cg.size(), len.size() * 4, st.size() * 4};
+        for (int i = 0; i < 9; ++i) CHECK(mgl_sw_register_host_buffer(ctx, regs[i], bytes[i]) == 0);
+        CHECK(mgl_sw_register_host_buffer(ctx, regs[0], bytes[0]) == 0); // registering twice is harmless
+        CHECK(mgl_sw_align_batch_status(ctx, n, mixed.t.data(), mixed.toff.data(), mixed.q.data(), mixed.qoff.data(), 200, -150, 260, 11,
+                                        MGL_SW_OS_SOFTCLIP, off.data(), sc.data(), cg.data(), stride, len.data(), st.data()) == 0);
+        compare(mixed, em, off, sc, cg, stride, len, &st);
+        for (int i = 0; i < 9; ++i) CHECK(mgl_sw_unregister_host_buffer(ctx, regs[i]) == 0);
+        CHECK(mgl_sw_unregister_host_buffer(ctx, regs[0]) == MGL_SW_ERR_BAD_ARG);
+    }
+    // ---- 2-bit packed bases from host memory: reads packed back to back (ascending starts: the packed arrays travel chunk by
+    // chunk), then the same pairs in shuffled order (whole arrays first); mixed lengths and, on a uniform subset, no length arrays
+    {
+        auto pack = [](const std::vector<uint8_t> &bases) {
+            std::vector<uint8_t> out((bases.size() + 3) / 4 + 8, 0);
+            for (size_t k = 0; k < bases.size(); ++k) {
+                const int c = bases[k] == 'A' ? 0 : bases[k] == 'C' ? 1 : bases[k] == 'G' ? 2 : 3;
+                out[k >> 2] |= (uint8_t)(c << (2 * (k & 3)));
+            }
+            return out;
+        };
+        const std::vector<uint8_t> T = pack(mixed.t), Q = pack(mixed.q);
+        const int64_t n = mixed.n();
+        for (int order = 0; order < 2; ++order) {
+            std::vector<int64_t> idx((size_t)n);
+            for (int64_t k = 0; k < n; ++k) idx[(size_t)k] = k;
+            if (order == 1) std::shuffle(idx.begin(), idx.end(), g);
+            Batch view; // the pairs in the order of `idx`, for the expected values
+            std::vector<int64_t> ts((size_t)n), qs((size_t)n);
+            std::vector<int32_t> tl((size_t)n), ql((size_t)n);
+            for (int64_t k = 0; k < n; ++k) {
+                const int64_t s = idx[(size_t)k];
+                ts[(size_t)k] = mixed.toff[(size_t)s];
+                qs[(size_t)k] = mixed.qoff[(size_t)s];
+                tl[(size_t)k] = (int32_t)(mixed.toff[(size_t)s + 1] - mixed.toff[(size_t)s]);
+                ql[(size_t)k] = (int32_t)(mixed.qoff[(size_t)s + 1] - mixed.qoff[(size_t)s]);
+                view.add(std::string(mixed.t.begin() + mixed.toff[(size_t)s], mixed.t.begin() + mixed.toff[(size_t)s + 1]),
+                         std::string(mixed.q.begin() + mixed.qoff[(size_t)s], mixed.q.begin() + mixed.qoff[(size_t)s + 1]));
+            }
+            const Expect ev = expect(view, MGL_SW_OS_SOFTCLIP);
+            CHECK(mgl_sw_ctx_set_workspace(ctx, 96ll << 20) == 0);
+            std::vector<int32_t> off((size_t)n), len((size_t)n), st((size_t)n);
+            std::vector<mgl_sw_score> sc((size_t)n);
+            std::vector<char> cg((size_t)n * 128, 1);
+            CHECK(mgl_sw_align_batch_2bit(ctx, n, T.data(), (int64_t)mixed.t.size(), ts.data(), tl.data(), Q.data(), (int64_t)mixed.q.size(), qs.data(), ql.data(),
+                                          256, 150, 200, -150, 260, 11, MGL_SW_OS_SOFTCLIP, off.data(), sc.data(), cg.data(), 128, len.data(), st.data(), 0) == 0);
+            compare(view, ev, off, sc, cg, 128, len, &st);
+            mgl_sw_timing tm;
+            CHECK(mgl_sw_ctx_get_timing(ctx, &tm) == 0 && tm.dp_launches >= 3);
+        }
+        // a pair outside its array, a length above the stated maximum, missing length arrays without the uniform flag
+        int64_t ts1[1] = {(int64_t)mixed.t.size() - 10}, qs1[1] = {0};
+        int32_t tl1[1] = {40}, ql1[1] = {20}, off1[1], len1[1];
+        char cg1[64];
+        CHECK(mgl_sw_align_batch_2bit(ctx, 1, T.data(), (int64_t)mixed.t.size(), ts1, tl1, Q.data(), (int64_t)mixed.q.size(), qs1, ql1, 256, 150, 200, -150, 260, 11,
+                                      MGL_SW_OS_SOFTCLIP, off1, nullptr, cg1, 64, len1, nullptr, 0) == MGL_SW_ERR_BAD_ARG);
+        ts1[0] = 0;
+        tl1[0] = 300;
+        CHECK(mgl_sw_align_batch_2bit(ctx, 1, T.data(), (int64_t)mixed.t.size(), ts1, tl1, Q.data(), (int64_t)mixed.q.size(), qs1, ql1, 256, 150, 200, -150, 260, 11,
+                                      MGL_SW_OS_SOFTCLIP, off1, nullptr, cg1, 64, len1, nullptr, 0) == MGL_SW_ERR_BAD_ARG);
+        CHECK(mgl_sw_align_batch_2bit(ctx, 1, T.data(), (int64_t)mixed.t.size(), ts1, nullptr, Q.data(), (int64_t)mixed.q.size(), qs1, nullptr, 256, 150, 200, -150, 260,
+                                      11, MGL_SW_OS_SOFTCLIP, off1, nullptr, cg1, 64, len1, nullptr, 0) == MGL_SW_ERR_BAD_ARG);
     }
     mgl_sw_ctx_destroy(ctx);
 

@@ -1381,6 +1381,75 @@ def test_lane_kernel_bases_outside_acgt():
         a.close()
 
 
+def test_host_entries_packed_and_registered(aligner):
+    """mgl_sw_align_batch_2bit (packed bases in host memory: ascending starts -> the arrays travel chunk by chunk; windows in any
+    order -> whole arrays first) and mgl_sw_register_host_buffer (page-locked caller arrays: results copied straight into them),
+    a uniform batch large enough for several chunks and a ragged one, against the oracle and the ASCII host entry."""
+    from mgl_amd import device_batch as db
+
+    rng = np.random.default_rng(4242)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    genome = alpha[rng.integers(0, 4, 1 << 16)]
+    n, tl, ql = 6000, 256, 150
+    win = rng.integers(0, len(genome) - tl, n).astype(np.int64)       # windows in any order
+    ts, qs = [], []
+    for k in range(n):
+        t = genome[win[k]: win[k] + tl]
+        q = t[int(rng.integers(0, tl - ql)):][:ql].copy()
+        q[rng.integers(0, ql, 2)] = alpha[rng.integers(0, 4, 2)]
+        if k % 7 == 3:
+            q = np.concatenate([q[:60], q[63:], alpha[rng.integers(0, 4, 3)]])
+        ts.append(t.tobytes())
+        qs.append(q.tobytes())
+    G = db.pack2bit(genome.tobytes())
+    Q = db.pack2bit(b"".join(qs))
+    qst = np.arange(n, dtype=np.int64) * ql
+    params = (200, -150, 260, 11)
+    off, sc, cg = ol.oracle_align_batch(ts, qs, params, ol.SOFTCLIP, nthreads=8)
+    aligner.set_workspace(64 << 20)   # several chunks
+    try:
+        res = aligner.align_packed_2bit(G, len(genome), win, None, Q, n * ql, qst, None, tl, ql, params, ol.SOFTCLIP, 64)
+        assert (res.offsets == off).all() and (res.scores == sc).all() and list(res.cigars) == cg
+        # ragged lengths, ascending starts in both arrays, every strategy
+        rts, rqs = [], []
+        for k in range(500):
+            a, b = int(rng.integers(1, 300)), int(rng.integers(1, 200))
+            t = alpha[rng.integers(0, 4, a)]
+            rts.append(t.tobytes())
+            rqs.append((np.resize(t[a // 3:], b) if k % 2 else alpha[rng.integers(0, 4, b)]).tobytes())
+        T2, Q2 = db.pack2bit(b"".join(rts)), db.pack2bit(b"".join(rqs))
+        tl2, ql2 = np.array([len(x) for x in rts], np.int32), np.array([len(x) for x in rqs], np.int32)
+        ts2, qs2 = np.concatenate([[0], np.cumsum(tl2)[:-1]]).astype(np.int64), np.concatenate([[0], np.cumsum(ql2)[:-1]]).astype(np.int64)
+        for strategy in ol.STRATEGIES:
+            r2 = aligner.align_packed_2bit(T2, int(tl2.sum()), ts2, tl2, Q2, int(ql2.sum()), qs2, ql2, int(tl2.max()), int(ql2.max()), params, strategy)
+            o2, s2, c2 = ol.oracle_align_batch(rts, rqs, params, strategy, nthreads=8)
+            assert (r2.offsets == o2).all() and (r2.scores == s2).all() and list(r2.cigars) == c2, strategy
+        # registered arrays on the ASCII entry: same bytes out as from pageable ones
+        td, toff = sw.concat(ts)
+        qd, qoff = sw.concat(qs)
+        plain = aligner.align_packed(td, toff, qd, qoff, params, ol.SOFTCLIP, 64)
+        arrays = [np.ascontiguousarray(x) for x in (td, toff, qd, qoff)]
+        outs = (np.zeros(n, np.int32), np.zeros((n, 6), np.int32), np.zeros(n * 64, np.uint8), np.zeros(n, np.int32))
+        for a_ in arrays + list(outs):
+            aligner.register_host_buffer(a_)
+        try:
+            from mgl_amd import _lib
+            rc = _lib.lib().mgl_sw_align_batch(aligner.ctx, n, arrays[0].ctypes.data, arrays[1].ctypes.data, arrays[2].ctypes.data, arrays[3].ctypes.data,
+                                               200, -150, 260, 11, int(ol.SOFTCLIP), outs[0].ctypes.data, outs[1].ctypes.data, outs[2].ctypes.data, 64,
+                                               outs[3].ctypes.data)
+            assert rc == 0
+            assert (outs[0] == plain.offsets).all() and (outs[1] == plain.scores).all() and (outs[0] == off).all()
+            assert [outs[2].reshape(n, 64)[k, : outs[3][k]].tobytes().decode() for k in range(n)] == cg
+            # and the packed entry writing into the registered outputs
+            aligner.align_packed_2bit(G, len(genome), win, None, Q, n * ql, qst, None, tl, ql, params, ol.SOFTCLIP, 64, out=outs)
+            assert (outs[0] == off).all() and (outs[1] == sc).all()
+        finally:
+            for a_ in arrays + list(outs):
+                aligner.unregister_host_buffer(a_)
+    finally:
+        aligner.set_workspace(4 << 30)
+
+
 def test_binary_cigar_output(aligner):
     """MGL_SW_FLAG_BINARY_CIGAR: BAM-style uint32 elements carry the same elements in the same order as the text."""
     import torch
