@@ -80,6 +80,24 @@ typedef struct mgl_sw_timing {
 #define MGL_SW_KERNEL_STRIP16 6   /* sw_dp16_strip_kernel: long reads, one 32-row strip per lane-half */
 #define MGL_SW_KERNEL_LANE16_CK 7 /* sw_dp16_lane_ck_kernel: the lane kernel, checkpoints instead of stored flags */
 
+/* What the library WOULD do with a batch: the planner's decisions, without running anything (mgl_sw_explain). */
+typedef struct mgl_sw_plan {
+    int32_t fill_kernel;        /* MGL_SW_KERNEL_*: the kernel of a uniform batch, or of the bulk of a sorted mixed one */
+    int32_t precision_bits;     /* 16 (packed int16 behind the range guard) or 32 */
+    int32_t rows;               /* target rows per stripe / strip of that kernel */
+    int32_t waves_per_block;
+    int32_t waves_per_pair;     /* long-read kernels: waves that share one pair; else 0 */
+    int32_t traceback;          /* 0 = four flags per cell stored in HBM, 1 = none stored (checkpoints; the walk recomputes), 2 = score only */
+    int32_t fused_walk;         /* 1 = every lane walks its own paths inside the fill kernel, 0 = traceback kernel on an auxiliary stream */
+    int32_t sorted_by_library;  /* mixed geometries: 0 = not sorted (int32 kernel), 1 = counting sort on the device, 2 = on the host */
+    int32_t fill_streams;       /* 1, or 2 when consecutive chunks alternate between two streams (host entries, lane kernel) */
+    int32_t workspace_halves;   /* 1, or 2 when chunk k's walk overlaps chunk k+1's fill */
+    int64_t chunk_pairs;        /* pairs per launch */
+    int64_t chunks;             /* launches of the fill kernel for this batch */
+    int64_t workspace_bytes_per_pair;
+    int64_t workspace_bytes;    /* of the context's workspace that this batch would use */
+} mgl_sw_plan;
+
 typedef struct mgl_sw_ctx mgl_sw_ctx; /* opaque: one GPU, its workspace and stream */
 
 int mgl_sw_version(void);
@@ -138,6 +156,14 @@ int mgl_sw_ctx_set_lane_checkpoint(mgl_sw_ctx *ctx, int mode);
  * inside the fill kernel (diagnostic; a few extra instructions per workgroup); 3 = as 1, summed over every call until
  * mgl_sw_ctx_get_timing reads and clears it (dp_ms / dp_launches = the mean launch duration over a timed loop); 0 = off */
 int mgl_sw_ctx_set_profiling(mgl_sw_ctx *ctx, int enable);
+/* The plan for a batch of n pairs up to max_tl x max_ql with these parameters, as the entry named by `entry` would run it on this
+ * context (its workspace limit and forced modes included) -- nothing is launched, allocated or copied.  flags: MGL_SW_FLAG_*;
+ * packed2: the sequences are 2-bit packed; entry: 0 = device-resident (mgl_sw_align_batch_device*), 1 = host buffers
+ * (mgl_sw_align_batch / _status / _2bit).  ctx may be NULL: a default context on a 256-CU device (what the CPU tests pin), with
+ * workspace_limit bytes of workspace (0: the default, or the context's own limit when ctx is given).  Returns the status the call
+ * itself would return from its planning (MGL_SW_ERR_UNSUPPORTED, ...). */
+int mgl_sw_explain(mgl_sw_ctx *ctx, int64_t workspace_limit, int64_t n, int max_tl, int max_ql, int match, int mismatch, int gopen,
+                   int gext, int strategy, int flags, int packed2, int entry, mgl_sw_plan *out);
 int mgl_sw_ctx_get_timing(mgl_sw_ctx *ctx, mgl_sw_timing *out); /* waits for the last call's kernels */
 
 /* Sign normalisation of the JNI boundary

@@ -28,7 +28,7 @@ SYMBOLS = (
     "mgl_sw_cigar_from_backtrack", "mgl_sw_band_fill", "mgl_sw_set_coalescing", "mgl_sw_coalescing_stats", "mgl_sw_group_by_geometry",
     "mgl_sw_multi_create", "mgl_sw_multi_destroy", "mgl_sw_multi_device_count", "mgl_sw_multi_ctx", "mgl_sw_multi_set_workspace",
     "mgl_sw_multi_last_error", "mgl_sw_align_batch_multi", "mgl_sw_multi_last_shards", "mgl_sw_shard_by_cells",
-    "mgl_sw_align_batch_2bit", "mgl_sw_register_host_buffer", "mgl_sw_unregister_host_buffer",
+    "mgl_sw_align_batch_2bit", "mgl_sw_register_host_buffer", "mgl_sw_unregister_host_buffer", "mgl_sw_explain",
 )
 
 
@@ -41,6 +41,23 @@ class Timing(C.Structure):
     _fields_ = [("dp_ms", C.c_float), ("tb_ms", C.c_float), ("dp_launches", C.c_int32), ("tb_launches", C.c_int32),
                 ("cells", C.c_int64), ("tb_bytes", C.c_int64), ("packed16", C.c_int32), ("clock_mhz", C.c_int32),
                 ("fill_kernel", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Plan(C.Structure):
+    """mgl_sw_plan: what the library would do with a batch (mgl_sw_explain)."""
+    _fields_ = [(n, C.c_int32) for n in ("fill_kernel", "precision_bits", "rows", "waves_per_block", "waves_per_pair", "traceback", "fused_walk",
+                                         "sorted_by_library", "fill_streams", "workspace_halves")] + [
+        (n, C.c_int64) for n in ("chunk_pairs", "chunks", "workspace_bytes_per_pair", "workspace_bytes")]
+
+
+def explain(n, max_tl, max_ql, parameters=(200, -150, 260, 11), strategy=1, flags=0, packed2=False, entry=0, workspace=0, ctx=None):
+    """The planner's decisions for a batch (no GPU needed when ctx is None): a Plan."""
+    p = Plan()
+    rc = lib().mgl_sw_explain(ctx, int(workspace), int(n), int(max_tl), int(max_ql), *[int(x) for x in parameters], int(strategy), int(flags),
+                              int(bool(packed2)), int(entry), C.byref(p))
+    if rc != OK:
+        raise MglSwError(rc)
+    return p
 
 
 FILL_KERNEL_NAMES = ("sw_dp_kernel", "sw_dp16_kernel", "sw_dp64_kernel", "sw_dp_coop_kernel", "sw_dp16_lane_kernel", "sw_dp_coop16_kernel", "sw_dp16_strip_kernel", "sw_dp16_lane_ck_kernel")
@@ -132,6 +149,7 @@ def lib():
     L.mgl_sw_shard_by_cells.argtypes = [C.c_int64, vp, vp, C.c_int, C.c_int64, vp]
     L.mgl_sw_align_batch_2bit.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int] + [C.c_int] * 5 + [
         vp, vp, vp, C.c_int, vp, vp, C.c_int]
+    L.mgl_sw_explain.argtypes = [vp, C.c_int64, C.c_int64] + [C.c_int] * 10 + [C.POINTER(Plan)]
     L.mgl_sw_register_host_buffer.argtypes = [vp, vp, C.c_size_t]
     L.mgl_sw_unregister_host_buffer.argtypes = [vp, vp]
     _lib = L

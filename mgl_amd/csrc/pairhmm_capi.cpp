@@ -85,7 +85,7 @@ struct mgl_pairhmm_ctx {
     std::string err;
     int use_double = 0;
     int profiling = 0;
-    int stripe_rows = 0; // 0 = per batch, 16 / 32 / 64 = forced (mgl_pairhmm_set_stripe_rows; MGL_PAIRHMM_ROWS for the bench scripts)
+    int stripe_rows = 0; // 0 = per batch, 16 / 32 / 64 = forced (mgl_pairhmm_set_stripe_rows)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false, ran_float = false;
     mgl_pairhmm_timing timing{};
@@ -166,8 +166,6 @@ int run_device(mgl_pairhmm_ctx *ctx, hipStream_t stream, int64_t n_pairs, const 
     // haplotype base each) can leave a CU with one or two waves; 64 rows x one pair keeps the CU full
     int rows = ctx->stripe_rows;
     if (!rows) {
-        static const int rows_env = [] { const char *e = getenv("MGL_PAIRHMM_ROWS"); return e ? atoi(e) : 0; }(); // bench scripts
-        rows = rows_env;
         if (rows != 16 && rows != 21 && rows != 32 && rows != 64) {
             rows = (max_read_len >= 48 && ph_lds_bytes(max_hap_len, 16, 4) > 12 * 1024) ? 64 : 16;
             // Reads of 24 .. 160 bases, more pairs than SIMDs: several pairs per wave -- 32 lanes x up to 5 rows (two pairs) or
@@ -387,10 +385,7 @@ int mgl_pairhmm_compute_pairs(mgl_pairhmm_ctx *ctx, int64_t n_pairs, int64_t n_r
     const size_t o_roff = 0, o_hoff = o_roff + (size_t)(n_reads + 1) * 8, o_out = o_hoff + (size_t)(n_haps + 1) * 8,
                  o_pr = o_out + (size_t)n_pairs * 8, o_ph = o_pr + up8((size_t)n_pairs * 4), o_need = o_ph + up8((size_t)n_pairs * 4),
                  o_reads = o_need + up8((size_t)n_pairs * 4), o_haps = o_reads + up8(rbytes), total = o_haps + up8(hbytes);
-    static const size_t zero_copy_max = [] {
-        const char *e = getenv("MGL_PAIRHMM_ZERO_COPY_BYTES");
-        return e ? (size_t)atoll(e) : (size_t)(1u << 20);
-    }();
+    constexpr size_t zero_copy_max = (size_t)(1u << 20);
     if (total <= zero_copy_max) {
         if (total > ctx->pin_cap) {
             if (ctx->pin) (void)hipHostFree(ctx->pin);

@@ -172,7 +172,7 @@ class Coalescer {
             lk.lock();
             ++n_batches_;
             n_pairs_ += (int64_t)batch.size();
-            if (timing_) { // diagnostic (MGL_SW_COALESCE_TIMING): where a batch's round trip goes, microseconds
+            if (timing_) { // diagnostic (MGL_SW_DEBUG_COALESCE_TIMING): where a batch's round trip goes, microseconds
                 auto us = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::micro>(d).count(); };
                 t_wait_ += us(now - t_first);
                 t_process_ += us(t_b - t_a);
@@ -307,7 +307,7 @@ class Coalescer {
     std::thread worker_;
     mgl_sw_ctx *ctx_ = nullptr;
     int64_t n_batches_ = 0, n_pairs_ = 0;
-    const bool timing_ = getenv("MGL_SW_COALESCE_TIMING") != nullptr;
+    const bool timing_ = getenv("MGL_SW_DEBUG_COALESCE_TIMING") != nullptr;
     double t_wait_ = 0, t_process_ = 0, t_release_ = 0, t_layout_ = 0, t_device_ = 0, t_scatter_ = 0;
 };
 

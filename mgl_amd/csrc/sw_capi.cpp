@@ -135,6 +135,26 @@ struct mgl_sw_ctx {
 
 namespace {
 
+// The only environment switches the planner reads: DEBUG aids that turn a code path off so that tests and measurements can compare
+// against the path it replaced (INTEGRATION.md 7 lists them with the operational settings of the front-end).  Read once per process,
+// except MGL_SW_DEBUG_LANE_GROUP_MIN (per chunk: the host-sanitizer driver changes it between calls).
+struct DebugKnobs {
+    bool auto_group;  // MGL_SW_DEBUG_AUTO_GROUP=0: batches of mixed geometries are not sorted by the library (they take the int32 kernel)
+    bool lane_ck;     // MGL_SW_DEBUG_LANE_CK=0: the lane kernel keeps the flags of every cell (sw_dp16_lane_kernel) instead of checkpoints
+    bool lane_group;  // MGL_SW_DEBUG_LANE_GROUP=0: sorted chunks never launch the lane kernel for their whole waves of one geometry
+    bool host_timing; // MGL_SW_DEBUG_HOST_TIMING=1: the host entry reports where the calling thread waited (stderr)
+};
+const DebugKnobs &debug_knobs()
+{
+    static const DebugKnobs k = [] {
+        auto on = [](const char *name, bool dflt) { const char *e = getenv(name); return e ? atoi(e) != 0 : dflt; };
+        return DebugKnobs{on("MGL_SW_DEBUG_AUTO_GROUP", true), on("MGL_SW_DEBUG_LANE_CK", true), on("MGL_SW_DEBUG_LANE_GROUP", true),
+                          on("MGL_SW_DEBUG_HOST_TIMING", false)};
+    }();
+    return k;
+}
+constexpr int kHostChunks = 32; // a host entry cuts a batch into about this many chunks (the units of its copy / compute pipeline)
+
 int geom_of(int flags)
 {
     return (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) ? GEOM_UNIFORM : (flags & MGL_SW_FLAG_GROUPED_GEOMETRY) ? GEOM_GROUPED : GEOM_MIXED;
@@ -187,10 +207,13 @@ int pick_waves_per_block(int sps_cap, int rows, int extra = 0)
 // queries from this length on run one pair per wave (64-row stripes): the pipeline fill/drain is then
 // 63/(ql+64) <= 6 %, and a batch needs four times fewer pairs to occupy the machine
 constexpr int kRows64MinQuery = 1024;
-// uniform batches (launches) from this size on take the two-pairs-per-lane kernel: 2 048 waves of 128 pairs (measured crossover
-// with the eight-pairs-per-wave kernel at 256 x 150, scripts/kernel_crossover.py: 131 072 pairs 2 424 against 2 751 GCUPS,
-// 262 144 pairs 3 057 against 2 942, 524 288 pairs 3 092 against 2 824; with the flags of every cell stored it crossed at 524 288)
-constexpr int64_t kLaneMinPairs = 128 * 2048;
+// uniform batches (launches) from this size on take the two-pairs-per-lane kernel: 640 waves of 128 pairs (measured crossover with
+// the eight-pairs-per-wave kernel at 256 x 150, scripts/kernel_crossover.py, round 3: 32 768 pairs 1 243 against 1 948 GCUPS,
+// 65 536 pairs 2 442 against 2 425, 131 072 pairs 4 342 against 2 731, 262 144 pairs 4 931 against 2 930; in round 2 it crossed at
+// 262 144, with the flags of every cell stored at 524 288)
+constexpr int64_t kLaneMinPairs = 128 * 640;
+// ... and a sorted chunk's whole waves of one geometry get a launch of their own from this many pairs on
+constexpr int64_t kLaneGroupMinPairs = 128 * 1024;
 
 int max_lds_query_len()
 {
@@ -232,7 +255,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                int max_ql, int match, int mismatch, int gopen, int gext, int strategy, int32_t *d_offset, Score *d_score,
                char *d_cigar, int cigar_stride, int32_t *d_cigar_len, int32_t *d_status, int64_t cells_hint, int geom,
                bool binary_cigar = false, const ChunkHooks *hooks = nullptr, const int8_t *d_matrix = nullptr,
-               const uint8_t *d_code = nullptr, bool score_only_hint = false)
+               const uint8_t *d_code = nullptr, bool score_only_hint = false, mgl_sw_plan *explain = nullptr)
 {
     if (n == 0) return MGL_SW_OK;
     const bool uniform = geom != GEOM_MIXED;
@@ -268,8 +291,6 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             }
         }
     }
-    static const int wpb16_env = [] { const char *e = getenv("MGL_SW_WPB16"); return e ? std::max(1, std::min(4, atoi(e))) : 0; }();
-    if (wpb16_env) wpb16 = wpb16_env; // launch-shape experiments only
     while (wpb16 > 1 && dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra > 64 * 1024) --wpb16;
     const bool use16_eligible = uniform && ctx->precision != 32 && dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra <= 64 * 1024 &&
                        match > 0 && dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
@@ -278,23 +299,20 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // eight-pairs-per-wave kernel above
     // strips of 32 rows (three waves per SIMD) unless 16-row strips (four waves, twice the carry traffic) save at least a
     // tenth of the rows: strips are whole, rows past tl are computed and thrown away
-    static const int lane_rows_env = [] { const char *e = getenv("MGL_SW_LANE_ROWS"); return e ? atoi(e) : 0; }();
-    const int lane_rows = lane_rows_env == 16 || lane_rows_env == 32 ? lane_rows_env
-                          : ((max_tl + 31) / 32 * 32 - (max_tl + 15) / 16 * 16) * 10 >= max_tl ? 16 : 32;
+    const int lane_rows = ((max_tl + 31) / 32 * 32 - (max_tl + 15) / 16 * 16) * 10 >= max_tl ? 16 : 32;
     // (what counts is the size of a launch: a batch that the workspace cuts into small chunks is no better than a small batch.
     // Behind the host-buffer entry the chunks are the units of the copy pipeline: there a large batch goes one ROUND of the
     // chip at a time -- 128 pairs per wave, three (32-row strips) or four waves per SIMD -- on two alternating streams)
     // (the checkpointed form runs two waves per SIMD, the forms that store every flag three (32-row strips) or four)
-    static const bool lane_fuse = [] { const char *e = getenv("MGL_SW_LANE_FUSE"); return !e || atoi(e) != 0; }();
-    static const bool lane_ck_on = [] { const char *e = getenv("MGL_SW_LANE_CK"); return !e || atoi(e) != 0; }();
-    const bool lane_ck_ok = lane_rows == 32 && lane_fuse && d_cigar != nullptr && ctx->lane_checkpoint != 1 && (ctx->lane_checkpoint == 2 || lane_ck_on);
+    const bool lane_ck_on = debug_knobs().lane_ck;
+    const bool lane_ck_ok = lane_rows == 32 && d_cigar != nullptr && ctx->lane_checkpoint != 1 && (ctx->lane_checkpoint == 2 || lane_ck_on);
     // (a host entry's chunk: one round where the inputs are ASCII -- 0.1 GB per round over the link before the first kernel can
     // start -- two where they are 2-bit packed: 10 M pairs 69.1 ms against 72.4 with one, 72.3 with four; ASCII: 83.1 / 84.5 / 87.2)
     const int64_t lane_round = (int64_t)ctx->n_cus * (lane_ck_ok ? 8 : lane_rows == 16 ? 16 : 12) * 128 * (hooks && tset.packed2 ? 2 : 1);
-    static const int host_chunks_l = [] { const char *e = getenv("MGL_SW_HOST_CHUNKS"); return e ? std::max(1, atoi(e)) : 32; }();
+    constexpr int host_chunks_l = kHostChunks;
     const bool lane_rounds = hooks && n >= 4 * lane_round;
     const int64_t lane_launch = std::min<int64_t>(lane_rounds ? n : hooks ? std::max<int64_t>(n / host_chunks_l, (int64_t)256 * 1024) : n,
-                                                  std::min<int64_t>(n, ctx->ws_limit / (lane_tb_words(max_tl, max_ql, lane_rows) * 4 / 128 + 1)));
+                                                  std::min<int64_t>(n, ctx->ws_limit / ((lane_ck_ok ? lane_ck_words(max_tl, max_ql) + lane_ck_scratch_bytes(max_tl, max_ql) / 4 : lane_tb_words(max_tl, max_ql, lane_rows)) * 4 / 128 + 1)));
     // (its checkpointed form stages base codes and takes either wire format; the form that stores every flag reads ASCII only)
     const bool lane_ck_wanted = lane_ck_ok && !score_only_hint; // (a 2-bit batch gets the lane kernel only in this form)
     const bool use_lane = geom == GEOM_UNIFORM && ctx->precision != 32 && !d_matrix && match > 0 && ctx->lane_kernel != 1 &&
@@ -306,7 +324,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // caller's order (TbArgs.dest) -- the reference takes any pair (sw_avx.cpp:6-108), so must the fast path
     // ... and a device-resident batch is sorted on the device (launch_regroup), at the price of one short synchronisation per
     // chunk: the host has to know how many pairs landed in full blocks before it can size the two launches
-    static const bool auto_group_dev_on = [] { const char *e = getenv("MGL_SW_AUTO_GROUP"); return !e || atoi(e) != 0; }();
+    const bool auto_group_dev_on = debug_knobs().auto_group;
     const bool regroup_dev = !hooks && auto_group_dev_on && n >= 1024 && (int64_t)max_tl * max_ql <= (1ll << 20) && !score_only_hint &&
                              (tset.len != nullptr || !tset.packed2) && (qset.len != nullptr || !qset.packed2);
     const bool auto_group = geom == GEOM_MIXED && ((hooks && hooks->regroup) || regroup_dev) && ctx->precision != 32 && !d_matrix && match > 0 &&
@@ -314,7 +332,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                             dp16_lds_bytes(sps_for(max_ql), wpb16) <= 64 * 1024 && pick_waves_per_block(sps_for_rows(max_ql, 16), 16) > 0 &&
                             dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
     // ... of which the geometries with 128 pairs and more go, whole waves of one geometry each, through the checkpointed lane kernel
-    static const bool lane_group_on = [] { const char *e = getenv("MGL_SW_LANE_GROUP"); return !e || atoi(e) != 0; }();
+    const bool lane_group_on = debug_knobs().lane_group;
     const bool lane_group = auto_group && lane_group_on && lane_ck_on && ctx->lane_checkpoint != 1 && ctx->lane_kernel != 1 && lane16_ck_supported(tset, qset);
     const int64_t lane_group_stride = lane_group ? lane_ck_words(max_tl, max_ql) : 0; // words per wave
     const bool use16 = (use16_eligible && !use_lane) || auto_group;
@@ -339,8 +357,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         sps_cap = coop_sps_for(max_ql);
         // packed int16 form (sw_dp_coop16_kernel): 128 rows per wave; it checks its own score window and redoes a pair in
         // 32 bits when that fails, so what is decided here is only whether trying is worthwhile
-        static const int coop16_env = [] { const char *e = getenv("MGL_SW_COOP16"); return e ? atoi(e) : -1; }();
-        if (ctx->precision != 32 && coop16_env != 0 && (ctx->precision == 16 ? coop16_possible(match, mismatch, gopen, gext) : coop16_worthwhile(match, mismatch, gopen, gext))) {
+        if (ctx->precision != 32 && (ctx->precision == 16 ? coop16_possible(match, mismatch, gopen, gext) : coop16_worthwhile(match, mismatch, gopen, gext))) {
             const int sps16 = coop16_sps_for(max_ql), dstripes = (max_tl + 127) / 128;
             int w16 = coop_waves;
             while (w16 > 2 && (w16 > dstripes || coop16_lds_bytes(sps16, w16) > 160 * 1024)) --w16;
@@ -358,13 +375,11 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     bool strip16 = false;
     int strip_waves = 0;
     {
-        static const int strip_env = [] { const char *e = getenv("MGL_SW_STRIP16"); return e ? atoi(e) : -1; }();
         // waves per pair: as few as hold the target in strips of 32 rows -- but never three: workgroups of three waves run a
         // quarter slower than those of one, two or four (pairs of 8 / 10 / 12 kb with two or four waves: 3.09 / 2.69 / 2.99
         // TCUPS, with three: 2.40 / 2.43 / 2.58; three waves do not spread evenly over a CU's four SIMDs)
-        static const int strip_waves_env = [] { const char *e = getenv("MGL_SW_STRIP_WAVES"); return e ? atoi(e) : 0; }();
-        int sw_ = std::max(strip_waves_env, ((max_tl + 31) / 32 + 127) / 128);
-        if (sw_ == 3 && strip_waves_env != 3) sw_ = 4;
+        int sw_ = ((max_tl + 31) / 32 + 127) / 128;
+        if (sw_ == 3) sw_ = 4;
         // worth it when enough of the issued lanes are real cells: strips of the 128 W slots x useful steps of all steps
         // rows per strip: as few as still cover the longest target with these waves (fewer rows = fewer instructions per column)
         int sr_ = 32;
@@ -377,7 +392,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         // (its time-major traceback regions are larger than the workgroup kernel's -- 97 MB against 50 for a 10 kb pair: a workspace
         // that cannot hold one of them per half keeps the workgroup kernel)
         const bool fits = tb_words_strip16(max_ql, sw_) * 4 + (int64_t)sizeof(DpRecord) <= ctx->ws_limit / 2;
-        if (want && fits && strip_env != 0 && !use16 && !use_lane && !d_matrix && ctx->precision != 32 && ctx->carry_memory == 0 && !ctx->stripe_rows && sw_ <= 4 &&
+        if (want && fits && !use16 && !use_lane && !d_matrix && ctx->precision != 32 && ctx->carry_memory == 0 && !ctx->stripe_rows && sw_ <= 4 &&
             strip16_lds_bytes(max_ql, sw_) <= 64 * 1024 && strip16_range_ok(match, mismatch, gopen, gext)) {
             strip16 = true;
             strip_waves = sw_;
@@ -425,12 +440,11 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const int64_t gran = use_lane ? 128 : use16 ? 8 : (rows == 64 || strip16) ? 1 : 4;
     // lane kernel: every lane walks the paths of its own two pairs at the end of its fill -- no traceback kernel, nothing
     // to overlap, so the whole workspace is one buffer and the chunks are twice as large
-    const bool fused_walk = use_lane && !score_only && lane_fuse;
+    const bool fused_walk = use_lane && !score_only;
     // ... except behind the host-buffer entry, whose chunks are the units of its copy pipeline anyway: there consecutive chunks
     // alternate between two streams and two halves, so that the last waves of one launch (the launch's tail, 1-2 ms of a
     // 14 ms chunk with most CUs idle) run beside the first waves of the next
-    static const bool lane_dual = [] { const char *e = getenv("MGL_SW_LANE_DUAL"); return !e || atoi(e) != 0; }();
-    const bool dual_ok = fused_walk && hooks && lane_dual;
+    const bool dual_ok = fused_walk && hooks;
     const int64_t ws_part = fused_walk && !dual_ok ? ctx->ws_limit : ctx->ws_limit / 2;
     if (per_pair * gran > ws_part) {
         char msg[192];
@@ -442,7 +456,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // host-buffer entry: the chunks are also the units of the copy / compute pipeline (inputs of chunk k+1 and results of
     // chunk k-1 move while chunk k computes), so a batch is cut into ~32 even when the workspace would hold it whole
     // (10 M pairs: 133 ms in 46 chunks, 143 in 12, scripts/host_entry_probe.py)
-    static const int host_chunks = [] { const char *e = getenv("MGL_SW_HOST_CHUNKS"); return e ? std::max(1, atoi(e)) : 32; }();
+    constexpr int host_chunks = kHostChunks;
     if (hooks && !(use_lane && lane_rounds))
         chunk = std::min<int64_t>(chunk, std::max<int64_t>((n / host_chunks + gran - 1) / gran * gran, (int64_t)256 * 1024));
     // lane kernel behind the host entry: one round of the chip per chunk.  A chunk that is not a whole number of rounds leaves
@@ -460,6 +474,27 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const bool overlap = !fused_walk && n > chunk;
     const bool dual = dual_ok && n > chunk;
     const int halves = overlap || dual ? 2 : 1;
+    if (explain) { // mgl_sw_explain: everything above is pure (the context's settings and the batch's description); nothing below is
+        mgl_sw_plan &pl = *explain;
+        pl = mgl_sw_plan{};
+        const bool lane_bulk = lane_group && std::min(n, chunk) >= kLaneGroupMinPairs; // (a chunk's whole waves of one geometry get their own launch from there on)
+        pl.fill_kernel = lane_ck || (auto_group && lane_bulk) ? MGL_SW_KERNEL_LANE16_CK : use_lane ? MGL_SW_KERNEL_LANE16 : use16 ? MGL_SW_KERNEL_DP16 : strip16 ? MGL_SW_KERNEL_STRIP16
+                         : coop16 ? MGL_SW_KERNEL_COOP16 : coop_waves ? MGL_SW_KERNEL_COOP : rows == 64 ? MGL_SW_KERNEL_DP32_64 : MGL_SW_KERNEL_DP32;
+        pl.precision_bits = (use16 || use_lane || strip16 || coop16) ? 16 : 32;
+        pl.rows = rows;
+        pl.waves_per_block = wpb;
+        pl.waves_per_pair = strip16 ? strip_waves : coop_waves;
+        pl.traceback = score_only ? 2 : lane_ck ? 1 : 0;
+        pl.fused_walk = fused_walk ? 1 : 0;
+        pl.sorted_by_library = auto_group ? (hooks ? 2 : 1) : 0;
+        pl.fill_streams = dual ? 2 : 1;
+        pl.workspace_halves = halves;
+        pl.chunk_pairs = chunk;
+        pl.chunks = (n + chunk - 1) / chunk;
+        pl.workspace_bytes_per_pair = per_pair;
+        pl.workspace_bytes = per_pair * chunk * halves;
+        return MGL_SW_OK;
+    }
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int h = 0; h < halves; ++h) {
@@ -621,8 +656,8 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             // pairs one after the other however few waves there are: 4 M reads of 100-150 bases in chunks of 1.3 M pairs 2 963 GCUPS
             // against 2 790 without, but the host entry's chunks of 256 k pairs 2 131 against 2 397); fewer go with the blocks of
             // eight, which they also are
-            const char *const lgm = getenv("MGL_SW_LANE_GROUP_MIN"); // (tests: read per chunk)
-            const int64_t lane_group_min = lgm ? (int64_t)atoll(lgm) : (int64_t)ctx->n_cus * 24 * 128;
+            const char *const lgm = getenv("MGL_SW_DEBUG_LANE_GROUP_MIN"); // (tests lower the threshold between calls: read per chunk)
+            const int64_t lane_group_min = lgm ? (int64_t)atoll(lgm) : kLaneGroupMinPairs;
             const int64_t nl = lane_group && rg.n_lane >= std::max<int64_t>(lane_group_min, 128) ? rg.n_lane : 0;
             uint32_t *const tb16 = tb_base + (size_t)(nl / 128) * (size_t)lane_group_stride;
             lane_pairs_last = nl;
@@ -837,7 +872,6 @@ int mgl_sw_ctx_create(int device, mgl_sw_ctx **out)
     // the traceback stream gets the lowest priority: its waves should only take what the fill kernel leaves
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (const char *e = getenv("MGL_SW_AUX_PRIO")) prio_lo = atoi(e);
     bool ok = hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, prio_lo) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&ctx->h2d, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&ctx->fill2, hipStreamNonBlocking) == hipSuccess;
@@ -1019,6 +1053,36 @@ int mgl_sw_ctx_get_timing(mgl_sw_ctx *ctx, mgl_sw_timing *out)
     *out = ctx->timing;
     if (ctx->profiling == 3) ctx->timing = mgl_sw_timing{}; // the next calls start a new sum
     return MGL_SW_OK;
+}
+
+int mgl_sw_explain(mgl_sw_ctx *ctx, int64_t workspace_limit, int64_t n, int max_tl, int max_ql, int match, int mismatch, int gopen, int gext,
+                   int strategy, int flags, int packed2, int entry, mgl_sw_plan *out)
+{
+    if (!out || n < 1 || workspace_limit < 0) return MGL_SW_ERR_BAD_ARG;
+    mgl_sw_ctx defaults; // (no device behind it: the planner reads settings only)
+    if (!ctx && workspace_limit > 0) defaults.ws_limit = workspace_limit;
+    mgl_sw_ctx *const c = ctx ? ctx : &defaults;
+    std::unique_lock<std::mutex> lk(c->mu);
+    struct Restore { // (a given context explains with another limit for the length of this call only)
+        mgl_sw_ctx *c;
+        int64_t ws;
+        ~Restore() { c->ws_limit = ws; }
+    } restore{c, c->ws_limit};
+    if (ctx && workspace_limit > 0) c->ws_limit = workspace_limit;
+    // stand-ins for the arrays: the planner looks at which of them exist, never at what they hold
+    static const uint8_t dummy8[8] = {0};
+    static const int64_t dummy64[2] = {0, 0};
+    static const int32_t dummy32[2] = {0, 0};
+    const bool uniform = (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) != 0;
+    const SeqSet ts{dummy8, dummy64, packed2 && !uniform ? dummy32 : nullptr, max_tl, packed2 ? 1 : 0},
+        qs{dummy8, dummy64, packed2 && !uniform ? dummy32 : nullptr, max_ql, packed2 ? 1 : 0};
+    ChunkHooks hooks; // a host entry: the hooks exist (they are not called), and the ASCII one sorts mixed batches itself
+    if (entry == 1 && !packed2) hooks.regroup = [](int64_t, int64_t, int, hipStream_t, Regroup *) { return MGL_SW_OK; };
+    int32_t off_ = 0;
+    char cg_ = 0;
+    Score sc_{};
+    return run_device(c, nullptr, n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext, strategy, &off_, &sc_, &cg_, 64, nullptr, nullptr, 0, geom_of(flags),
+                      (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, entry == 1 ? &hooks : nullptr, nullptr, nullptr, (flags & MGL_SW_FLAG_SCORE_ONLY) != 0, out);
 }
 
 int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_targets,
@@ -1344,7 +1408,7 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
 
     ChunkHooks hooks;
     hooks.d_status_any = static_cast<int32_t *>(ctx->d_any.p);
-    static const bool host_timing = getenv("MGL_SW_HOST_TIMING") != nullptr;   // diagnostic: where the calling thread waits
+    const bool host_timing = debug_knobs().host_timing;   // diagnostic: where the calling thread waits
     double t_in = 0, t_out = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
@@ -1378,7 +1442,7 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     // chunk before it -- a counting sort over the (tl, ql) grid of the batch, full blocks of eight pairs of one geometry
     // first (packed kernel), the left-over pairs behind them (int32 kernel); run_device decides whether it applies
     const int64_t range_t = hi_t - lo_t + 1, range_q = hi_q - lo_q + 1;
-    static const bool auto_group_on = [] { const char *e = getenv("MGL_SW_AUTO_GROUP"); return !e || atoi(e) != 0; }();
+    const bool auto_group_on = debug_knobs().auto_group;
     std::vector<int32_t> grid_pos, grid_nfull, grid_full, grid_rest, grid_nlane, grid_lane;
     int64_t lane_total[2] = {0, 0};  // per half: pairs in the leading blocks of 128 (written by build, read after the job is joined)
     std::future<int64_t> next_job;   // the sort of the NEXT chunk runs on a helper thread while this thread is inside the
@@ -1722,10 +1786,7 @@ static int align_batch_staged_nolock(mgl_sw_ctx *ctx, int n, size_t in_bytes, si
     // small batches are latency bound: the kernels then read the pinned (device-mapped, coherent) staging buffer in place
     // and write their results straight into the pinned output buffer -- no copy commands at all (a copy costs more in
     // launch latency than the few hundred bytes per pair cost over PCIe); large batches are copied to HBM first
-    static const size_t zero_copy_max = [] {
-        const char *e = getenv("MGL_SW_ZERO_COPY_BYTES");
-        return e ? (size_t)atoll(e) : (size_t)(2u << 20);
-    }();
+    constexpr size_t zero_copy_max = (size_t)(2u << 20);
     const bool zero_copy = in_bytes + out_bytes <= zero_copy_max;
     const uint8_t *din = static_cast<const uint8_t *>(ctx->stage_in.p);
     uint8_t *dout = static_cast<uint8_t *>(ctx->stage_out.p);

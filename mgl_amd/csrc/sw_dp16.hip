@@ -697,8 +697,6 @@ hipError_t launch_dp16(const DpArgs &a, int waves_per_block, hipStream_t stream)
     const int per_block = waves_per_block * 8; // pairs per block
     const int64_t blocks = (a.count + per_block - 1) / per_block;
     int lds = dp16_lds_bytes(sps_for(a.uni_ql), waves_per_block);
-    static const int extra_lds = [] { const char *e = getenv("MGL_SW_EXTRA_LDS"); return e ? atoi(e) : 0; }();
-    lds += extra_lds; // occupancy experiments only
     if (lds > 64 * 1024) { // per device and rare (long queries): set every time rather than cache across devices / threads
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_dp16_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);

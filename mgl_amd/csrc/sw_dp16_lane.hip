@@ -262,10 +262,6 @@ MGL_LANE_KERNEL(sw_dp16_lane_kernel_r16, 16, 0, 4, 120)
 MGL_LANE_KERNEL(sw_dp16_lane_score_kernel_r16, 16, 2, 4, 120)
 MGL_LANE_KERNEL(sw_dp16_lane_kernel, 32, 0, 3, 160)          // rows = 32: the default
 MGL_LANE_KERNEL(sw_dp16_lane_score_kernel, 32, 2, 3, 160)
-MGL_LANE_KERNEL(sw_dp16_lane_kernel_r32w2, 32, 0, 2, 240)
-MGL_LANE_KERNEL(sw_dp16_lane_score_kernel_r32w2, 32, 2, 2, 240)
-MGL_LANE_KERNEL(sw_dp16_lane_kernel_r32full, 32, 0, 3, 168)   // experiments: no room left for a traceback wave
-MGL_LANE_KERNEL(sw_dp16_lane_score_kernel_r32full, 32, 2, 3, 168)
 #undef MGL_LANE_KERNEL
 
 // can this batch run on the lane kernel at all (beyond the 16-bit range guard, which is dp16_range_ok)?
@@ -279,7 +275,6 @@ hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &walk, int rows, hipSt
     const int waves_per_block = 4;
     const int64_t waves = ((a.count + 1) / 2 + 63) / 64;
     const dim3 grid((unsigned)((waves + waves_per_block - 1) / waves_per_block)), block(64 * waves_per_block);
-    static const int wps_env = [] { const char *e = getenv("MGL_SW_LANE_WPS"); return e ? atoi(e) : 0; }(); // register-budget experiments
 #define MGL_LAUNCH_LANE(K, KS)                                                                         \
     do {                                                                                               \
         if (a.score_only)                                                                              \
@@ -289,10 +284,6 @@ hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &walk, int rows, hipSt
     } while (0)
     if (rows == 16)
         MGL_LAUNCH_LANE(sw_dp16_lane_kernel_r16, sw_dp16_lane_score_kernel_r16);
-    else if (wps_env == 2)
-        MGL_LAUNCH_LANE(sw_dp16_lane_kernel_r32w2, sw_dp16_lane_score_kernel_r32w2);
-    else if (wps_env == 9)
-        MGL_LAUNCH_LANE(sw_dp16_lane_kernel_r32full, sw_dp16_lane_score_kernel_r32full);
     else
         MGL_LAUNCH_LANE(sw_dp16_lane_kernel, sw_dp16_lane_score_kernel);
 #undef MGL_LAUNCH_LANE

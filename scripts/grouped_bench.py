@@ -50,7 +50,7 @@ def run_mixed():
         gb.offsets.data_ptr(), gb.scores.data_ptr(), gb.cigars.data_ptr(), gb.cigar_stride, gb.cigar_len.data_ptr(), gb.status.data_ptr(), 0)
     assert rc == 0
 ref = (gb.offsets.clone(), gb.scores.clone(), gb.cigars.clone())
-timed(run_mixed, "same slots, no promise (sorted on the device by the library; MGL_SW_AUTO_GROUP=0: int32 kernel)")
+timed(run_mixed, "same slots, no promise (sorted on the device by the library; MGL_SW_DEBUG_AUTO_GROUP=0: int32 kernel)")
 assert torch.equal(ref[0], gb.offsets) and torch.equal(ref[1], gb.scores) and torch.equal(ref[2], gb.cigars)
 print("identical results")
 # the pairs in their original (unsorted) order, no promise: mgl_sw_align_batch_device_indexed sorts every chunk on the device
@@ -79,16 +79,16 @@ td = b.targets.cpu().numpy()
 toff = b.t_off.cpu().numpy()
 off = np.zeros(n, np.int32); sc = np.zeros((n, 6), np.int32); cg = np.zeros(n * 64, np.uint8); ln = np.zeros(n, np.int32)
 L = _lib.lib()
-for env, label in (("1", "host batch of mixed lengths, sorted per chunk by the library"), ("0", "same, MGL_SW_AUTO_GROUP=0 (int32 kernel)")):
+for env, label in (("1", "host batch of mixed lengths, sorted per chunk by the library"), ("0", "same, MGL_SW_DEBUG_AUTO_GROUP=0 (int32 kernel)")):
     if env == "0":
-        break  # (the switch is read once per process: run the script again with MGL_SW_AUTO_GROUP=0 for the other line)
+        break  # (the switch is read once per process: run the script again with MGL_SW_DEBUG_AUTO_GROUP=0 for the other line)
     for rep in range(3):
         t0 = time.perf_counter()
         rc = L.mgl_sw_align_batch(a.ctx, n, td.ctypes.data, toff.ctypes.data, qd.ctypes.data, qoff.ctypes.data, 200, -150, 260, 11, 1,
                                   off.ctypes.data, sc.ctypes.data, cg.ctypes.data, 64, ln.ctypes.data)
         dt = time.perf_counter() - t0
         assert rc == 0
-    print(f"{label} (MGL_SW_AUTO_GROUP={os.environ.get('MGL_SW_AUTO_GROUP', '1')}): {dt*1e3:.1f} ms = {cells/dt/1e9:.1f} GCUPS, "
+    print(f"{label} (MGL_SW_DEBUG_AUTO_GROUP={os.environ.get('MGL_SW_DEBUG_AUTO_GROUP', '1')}): {dt*1e3:.1f} ms = {cells/dt/1e9:.1f} GCUPS, "
           f"{n/dt/1e6:.2f} M reads/s (packed16={a.timing().packed16})", flush=True)
 # same answers as the device-resident grouped run (caller order)
 g_off, g_sc = gb.gather()[0].cpu().numpy(), gb.gather()[1].cpu().numpy()

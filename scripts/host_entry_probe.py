@@ -1,5 +1,5 @@
 """Where the host-buffer entry (mgl_sw_align_batch) spends its time on a uniform batch: PCIe inclusive, pageable memory.
-Usage: MGL_SW_HOST_TIMING=1 python scripts/host_entry_probe.py [pairs] [lane_mode 0|1|2] [workspace GiB]"""
+Usage: MGL_SW_DEBUG_HOST_TIMING=1 python scripts/host_entry_probe.py [pairs] [lane_mode 0|1|2] [workspace GiB]"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)

@@ -10,7 +10,7 @@ from mgl_amd.smithwaterman import MicrosoftSmithWaterman
 tl = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ql = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 dev = torch.device("cuda", 0)
-for n in (65536, 131072, 262144, 393216, 524288, 786432, 1048576, 2097152, 4194304):
+for n in (16384, 32768, 65536, 131072, 262144, 393216, 524288, 786432, 1048576):
     b = device_batch.window_batch(42, n, dev, window=tl, read_len=ql)
     line = f"{n:8d} pairs:"
     for mode, name in ((1, "wave8"), (2, "lane ")):

@@ -1,5 +1,5 @@
 """Timing probe of the two-pairs-per-lane kernel: full call vs score-only (no traceback flags / stores), device resident.
-Usage: python scripts/lane_probe.py [pairs] [tl] [ql]   (MGL_SW_LANE_ROWS / MGL_SW_LANE_WPS select the variant)"""
+Usage: python scripts/lane_probe.py [pairs] [tl] [ql]"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 PMC passes of the two-pairs-per-lane fill kernel (run on the GPU box from the repo root).
-# Usage: bash scripts/prof_lane.sh NAME [pairs]    (environment MGL_SW_LANE_ROWS / MGL_SW_LANE_WPS select the variant)
+# Usage: bash scripts/prof_lane.sh NAME [pairs]
 set -e
 NAME=${1:-lane}; PAIRS=${2:-2097152}
 R=$PWD; O=$R/gpurun_out/$NAME; mkdir -p $O

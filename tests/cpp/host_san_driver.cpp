@@ -168,7 +168,7 @@ int main()
         if (lane_mode == 2) CHECK(mgl_sw_ctx_expand_slot(ctx, 0, 1, 1, btr_probe) == MGL_SW_ERR_UNSUPPORTED); // no stored traceback to expand
     }
     // ---- a mixed batch with one dominant geometry: the sorted chunks' whole waves of 128 go through the (fake) lane kernel, the rest
-    // through the packed and int32 parts -- both entries, several chunks (threshold lowered: MGL_SW_LANE_GROUP_MIN)
+    // through the packed and int32 parts -- both entries, several chunks (threshold lowered: MGL_SW_DEBUG_LANE_GROUP_MIN)
     {
         Batch most;
         for (int k = 0; k < 2600; ++k) {
@@ -178,7 +178,7 @@ int main()
             most.add(t, q);
         }
         const Expect eo = expect(most, MGL_SW_OS_SOFTCLIP);
-        setenv("MGL_SW_LANE_GROUP_MIN", "128", 1);
+        setenv("MGL_SW_DEBUG_LANE_GROUP_MIN", "128", 1);
         CHECK(mgl_sw_ctx_set_lane_kernel(ctx, 0) == 0 && mgl_sw_ctx_set_lane_checkpoint(ctx, 0) == 0 && mgl_sw_ctx_set_workspace(ctx, 64ll << 20) == 0);
         const int64_t n = most.n();
         for (int entry = 0; entry < 2; ++entry) {
@@ -195,7 +195,7 @@ int main()
             CHECK(mgl_sw_ctx_get_timing(ctx, &tm) == 0 && tm.dp_launches >= 2 && tm.fill_kernel == MGL_SW_KERNEL_LANE16_CK);
             compare(most, eo, off, sc, cg, 64, len, &st);
         }
-        unsetenv("MGL_SW_LANE_GROUP_MIN");
+        unsetenv("MGL_SW_DEBUG_LANE_GROUP_MIN");
     }
     // ---- registered arrays: the results of every chunk go straight into the caller's arrays (no pinned ring, no helper jobs)
     {

@@ -711,7 +711,7 @@ def test_sorted_chunks_run_big_geometries_on_the_lane_kernel(monkeypatch, reside
     import torch
     from mgl_amd import device_batch, synth
 
-    monkeypatch.setenv("MGL_SW_LANE_GROUP_MIN", "128")
+    monkeypatch.setenv("MGL_SW_DEBUG_LANE_GROUP_MIN", "128")
     rng = synth.rng_for(91)
     n = 36_000
     genome = synth.random_genome(rng, 1 << 18)

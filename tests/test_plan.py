@@ -1,0 +1,110 @@
+"""The planner's decisions, pinned (mgl_sw_explain: no GPU needed -- a default context on a 256-CU device): the kernel, the chunking
+and the streams for every BASELINE.json config and for each kernel's crossover, so that a change of a threshold shows up here and
+not as a silent change of a bench line."""
+import pytest
+
+from mgl_amd import _lib
+
+GATK = (200, -150, 260, 11)
+UNIFORM, SCORE_ONLY = _lib.FLAG_UNIFORM_GEOMETRY, _lib.FLAG_SCORE_ONLY
+BENCH_WS = 208 << 30   # bench.py's workspace
+DP32, DP16, DP32_64, COOP, LANE16, COOP16, STRIP16, LANE16_CK = range(8)
+
+
+def plan(**kw):
+    return _lib.explain(**kw)
+
+
+def test_symbol_and_struct():
+    p = plan(n=8, max_tl=10, max_ql=10)
+    assert p.fill_kernel == DP32 and p.chunks == 1 and p.chunk_pairs == 8
+
+
+def test_configs1_headline_is_one_launch_of_the_checkpointed_lane_kernel():
+    for packed in (False, True):   # ASCII and the 2-bit wire format take the same kernel
+        p = plan(n=10_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, packed2=packed, workspace=BENCH_WS)
+        assert p.fill_kernel == LANE16_CK and p.precision_bits == 16 and p.rows == 32
+        assert p.traceback == 1 and p.fused_walk == 1, "no flags stored; every lane walks its own two pairs"
+        assert p.chunks == 1 and p.chunk_pairs == 10_000_000 and p.fill_streams == 1 and p.workspace_halves == 1
+        assert 14_000 < p.workspace_bytes_per_pair < 16_000 and p.workspace_bytes < BENCH_WS
+
+
+def test_configs2_one_rank_of_eight():
+    p = plan(n=1_250_000, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, workspace=BENCH_WS)
+    assert p.fill_kernel == LANE16_CK and p.chunks == 1 and p.chunk_pairs == 1_250_000
+
+
+def test_configs0_plumbing_case_is_the_int32_kernel():
+    p = plan(n=1000, max_tl=1000, max_ql=160, parameters=GATK)    # ragged reads, no promise, too few to sort
+    assert p.fill_kernel == DP32 and p.precision_bits == 32 and p.rows == 16 and p.traceback == 0 and p.fused_walk == 0
+
+
+def test_configs3_long_reads_take_the_strip_kernel():
+    p = plan(n=2304, max_tl=10300, max_ql=10300, parameters=GATK, workspace=BENCH_WS)
+    assert p.fill_kernel == STRIP16 and p.waves_per_pair == 4 and 20 <= p.rows <= 32 and p.precision_bits == 16
+    assert p.chunk_pairs == 768 and p.chunks == 3 and p.workspace_halves == 2, "whole rounds of the chip: 256 CUs x 3 workgroups"
+    p = plan(n=8, max_tl=31000, max_ql=30500, parameters=GATK, workspace=BENCH_WS)   # beyond the strip kernel's 16 384 rows
+    assert p.fill_kernel == COOP16 and p.waves_per_pair == 16
+
+
+def test_tl1000_variant():
+    p = plan(n=2_560_000, max_tl=1000, max_ql=150, parameters=GATK, flags=UNIFORM, workspace=BENCH_WS)
+    assert p.fill_kernel == LANE16_CK and p.chunks == 1
+
+
+def test_lane_kernel_crossover():
+    """scripts/kernel_crossover.py: the lane kernel overtakes the eight-pairs-per-wave kernel between 65 536 and 131 072 pairs."""
+    small = plan(n=65_536, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, workspace=BENCH_WS)
+    large = plan(n=131_072, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, workspace=BENCH_WS)
+    assert small.fill_kernel == DP16 and small.traceback == 0 and small.fused_walk == 0
+    assert large.fill_kernel == LANE16_CK
+    # a workspace that cuts the batch below the crossover keeps the smaller kernel
+    p = plan(n=10_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, workspace=1 << 30)
+    assert p.fill_kernel == DP16 and p.chunks > 1 and p.workspace_halves == 2
+
+
+def test_rows_that_do_not_fill_strips_of_32():
+    p = plan(n=1_000_000, max_tl=33, max_ql=8, parameters=GATK, flags=UNIFORM, workspace=BENCH_WS)
+    assert p.fill_kernel == LANE16 and p.rows == 16, "16-row strips exist only with every flag stored"
+    p = plan(n=1_000_000, max_tl=33, max_ql=8, parameters=GATK, flags=UNIFORM, packed2=True, workspace=BENCH_WS)
+    assert p.fill_kernel == DP16, "... which reads ASCII only: a 2-bit batch of that shape takes the eight-pairs-per-wave kernel"
+
+
+def test_score_only_hint():
+    p = plan(n=10_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM | SCORE_ONLY, workspace=BENCH_WS)
+    assert p.fill_kernel == LANE16 and p.traceback == 2 and p.chunks == 1
+
+
+def test_scores_beyond_16_bits_take_the_int32_kernels():
+    p = plan(n=1_000_000, max_tl=256, max_ql=150, parameters=(2000, -1500, 2600, 110), flags=UNIFORM)
+    assert p.fill_kernel == DP32 and p.precision_bits == 32
+    p = plan(n=1_000_000, max_tl=256, max_ql=2000, parameters=(2000, -1500, 2600, 110), flags=UNIFORM)
+    assert p.fill_kernel == DP32_64 and p.rows == 64
+
+
+def test_mixed_geometries_are_sorted_by_the_library():
+    ws = 72 << 30   # a context's default: a quarter of the card
+    dev = plan(n=4_000_000, max_tl=256, max_ql=150, parameters=GATK, workspace=ws)              # device resident, no promise
+    assert dev.sorted_by_library == 1 and dev.fill_kernel == LANE16_CK and dev.precision_bits == 16, "whole waves of one geometry: the lane kernel"
+    host = plan(n=4_000_000, max_tl=256, max_ql=150, parameters=GATK, entry=1, workspace=ws)     # host buffers
+    assert host.sorted_by_library == 2 and host.workspace_halves == 2 and host.fill_kernel == LANE16_CK
+    tight = plan(n=4_000_000, max_tl=256, max_ql=150, parameters=GATK)                           # 4 GiB: chunks below the lane kernel's crossover
+    assert tight.sorted_by_library == 1 and tight.fill_kernel == DP16
+    few = plan(n=500, max_tl=256, max_ql=150, parameters=GATK)
+    assert few.sorted_by_library == 0 and few.fill_kernel == DP32
+
+
+def test_host_entries_pipeline_chunks_on_two_streams():
+    a = plan(n=10_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, entry=1, workspace=BENCH_WS)
+    assert a.fill_kernel == LANE16_CK and a.fill_streams == 2 and a.workspace_halves == 2
+    assert a.chunk_pairs == 256 * 8 * 128, "ASCII inputs: one round of the chip per chunk (two waves per SIMD, 128 pairs per wave)"
+    b = plan(n=10_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, entry=1, packed2=True, workspace=BENCH_WS)
+    assert b.chunk_pairs == 2 * 256 * 8 * 128 and b.chunks == 20, "2-bit inputs: two rounds per chunk"
+
+
+def test_explain_reports_what_the_call_would_refuse():
+    with pytest.raises(_lib.MglSwError) as e:
+        plan(n=1, max_tl=1 << 20, max_ql=1 << 20, parameters=GATK)
+    assert e.value.status == _lib.ERR_UNSUPPORTED
+    with pytest.raises(_lib.MglSwError):
+        plan(n=0, max_tl=10, max_ql=10)
