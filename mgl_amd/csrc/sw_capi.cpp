@@ -373,7 +373,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // per-strip baselines (sw_dp16_strip.hip); W waves per pair hold 128 W strips, W <= 4 keeps three workgroups' worth of
     // registers per SIMD
     bool strip16 = false;
-    int strip_waves = 0;
+    int strip_waves = 0, strip_k = 0; // strip_k: strips per kept band of the form without stored flags (0: flags stored)
     {
         // waves per pair: as few as hold the target in strips of 32 rows -- but never three: workgroups of three waves run a
         // quarter slower than those of one, two or four (pairs of 8 / 10 / 12 kb with two or four waves: 3.09 / 2.69 / 2.99
@@ -391,10 +391,14 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         const bool want = ctx->strip_kernel == 2 || (ctx->strip_kernel == 0 && (coop_waves || rows == 64) && ctx->cooperative < 2 && used >= 0.4);
         // (its time-major traceback regions are larger than the workgroup kernel's -- 97 MB against 50 for a 10 kb pair: a workspace
         // that cannot hold one of them per half keeps the workgroup kernel)
-        const bool fits = tb_words_strip16(max_ql, sw_) * 4 + (int64_t)sizeof(DpRecord) <= ctx->ws_limit / 2;
+        // (without stored flags -- rows of every band of K strips and column checkpoints instead, walked by sw_strip_ck_walk_kernel --
+        // a pair takes 17 MB: that form is the default where CIGARs are written; mgl_sw_ctx_set_lane_checkpoint(ctx, 1) keeps the flags)
+        const int sk_ = (ctx->lane_checkpoint != 1 && d_cigar != nullptr && !score_only_hint) ? 64 / sr_ : 0;
+        const bool fits = (sk_ ? strip16_ck_words(max_tl, max_ql, sr_, sk_) : tb_words_strip16(max_ql, sw_)) * 4 + (int64_t)sizeof(DpRecord) <= ctx->ws_limit / 2;
         if (want && fits && !use16 && !use_lane && !d_matrix && ctx->precision != 32 && ctx->carry_memory == 0 && !ctx->stripe_rows && sw_ <= 4 &&
             strip16_lds_bytes(max_ql, sw_) <= 64 * 1024 && strip16_range_ok(match, mismatch, gopen, gext)) {
             strip16 = true;
+            strip_k = sk_;
             strip_waves = sw_;
             coop16 = false;
             coop_waves = 0;
@@ -424,7 +428,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const int64_t stride_words = lane_ck ? lane_ck_words(max_tl, max_ql)
                                  : use_lane ? lane_tb_words(max_tl, max_ql, rows)
                                  : use16 ? (geom == GEOM_UNIFORM ? tb_words16_for(max_tl, max_ql) : tb_words16_bound(max_tl, max_ql))
-                                 : strip16 ? tb_words_strip16(max_ql, strip_waves)
+                                 : strip16 ? (strip_k ? strip16_ck_words(max_tl, max_ql, rows, strip_k) : tb_words_strip16(max_ql, strip_waves))
                                  : coop16 ? std::max(tb_words_for(max_tl, coop_sps_for(max_ql), 64), tb_words_coop16(max_tl, max_ql)) // either layout
                                          : tb_words_for(max_tl, sps_cap, rows);
     // (auto-grouped chunks: the packed regions first, the int32 regions of the left-over pairs behind them)
@@ -469,6 +473,9 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     if (strip16) {
         const int64_t round = (int64_t)ctx->n_cus * (12 / strip_waves);
         if (chunk > round) chunk = chunk / round * round;
+        // (without stored flags the workspace holds 2 304 pairs of 10 kb as ONE chunk, and that is right: the walk kernel's time is a
+        // pair's serial chain of ~200 block recomputations whatever the number of pairs -- three chunks of 768 walked three times as
+        // long in total, 75.9 ms against 20.6, and hid behind nothing: 94.4 ms per pass against 72.5)
     }
     chunk = std::min<int64_t>(chunk, n);
     const bool overlap = !fused_walk && n > chunk;
@@ -484,7 +491,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         pl.rows = rows;
         pl.waves_per_block = wpb;
         pl.waves_per_pair = strip16 ? strip_waves : coop_waves;
-        pl.traceback = score_only ? 2 : lane_ck ? 1 : 0;
+        pl.traceback = score_only ? 2 : lane_ck || (strip16 && strip_k) ? 1 : 0;
         pl.fused_walk = fused_walk ? 1 : 0;
         pl.sorted_by_library = auto_group ? (hooks ? 2 : 1) : 0;
         pl.fill_streams = dual ? 2 : 1;
@@ -695,6 +702,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             da.matrix_lds_offset = 0;
             da.score_only = score_only ? 1 : 0;
             da.grouped = pt.lane && auto_group ? 1 : 0;
+            da.strip_k = strip16 ? strip_k : 0;
             const int per_block = pt.lane ? pt.wpb * 128 : pt.packed ? pt.wpb * 8 : strip16 ? 1 : pt.wpb * (64 / pt.rows);
             if (i == 0) n_blocks = (pt.count + per_block - 1) / per_block;
             if (ctx->profiling == 2 && i == 0) {
@@ -709,7 +717,13 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             ta.strategy = strategy;
             ta.tb = pt.tb;
             ta.tb_stride_words = pt.stride;
-            ta.packed16 = pt.lane ? 2 : pt.packed ? 1 : strip16 ? 4 : coop16 ? 3 : 0;
+            ta.packed16 = pt.lane ? 2 : pt.packed ? 1 : strip16 ? (strip_k ? 6 : 4) : coop16 ? 3 : 0;
+            ta.match = match;
+            ta.mismatch = mismatch;
+            ta.gopen = gopen;
+            ta.gext = gext;
+            ta.strip_rows = pt.rows;
+            ta.strip_k = strip16 ? strip_k : 0;
             ta.rows_per_stripe = pt.rows;
             ta.uni_ql = max_ql;
             ta.rec = pt.rec;
@@ -756,7 +770,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         if (pe[2]) HIP_TRY(ctx, hipEventRecord(pe[2], tb_stream));
         for (int i = 0; i < n_parts && !fused_walk; ++i) {
             if (das[i].grouped) continue; // walked inside its fill kernel
-            HIP_TRY(ctx, score_only ? launch_scores_only(tas[i], tb_stream) : launch_traceback(tas[i], tb_stream));
+            HIP_TRY(ctx, score_only ? launch_scores_only(tas[i], tb_stream) : tas[i].packed16 == 6 ? launch_strip_ck_walk(tas[i], max_tl, max_ql, tb_stream) : launch_traceback(tas[i], tb_stream));
         }
         if (pe[3]) HIP_TRY(ctx, hipEventRecord(pe[3], tb_stream));
         if (overlap) {
@@ -782,7 +796,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         ctx->last_chunk_count = auto_group ? 0 : count; // (a chunk sorted by geometry has no caller-order slots to expand)
         ctx->last_half = h;
         ctx->last_rows = rows;
-        ctx->last_packed16 = lane_ck ? 5 : use_lane ? 2 : use16 ? 1 : strip16 ? 4 : coop16 ? 3 : 0;
+        ctx->last_packed16 = lane_ck ? 5 : use_lane ? 2 : use16 ? 1 : strip16 ? (strip_k ? 6 : 4) : coop16 ? 3 : 0;
         ctx->timing.dp_launches++;
         ctx->timing.tb_launches++;
         ctx->timing.tb_bytes += (use_lane ? (count + 127) / 128 : use16 ? (count + 1) / 2 : count) * stride_words * 4;
@@ -1891,7 +1905,7 @@ int mgl_sw_ctx_expand_slot(mgl_sw_ctx *ctx, int64_t slot, int tl, int ql, int32_
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, ctx->d_btr.reserve(cells * 4));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_btr.p, 0, cells * 4, ctx->stream));
-    if (ctx->last_packed16 == 5)
+    if (ctx->last_packed16 == 5 || ctx->last_packed16 == 6)
         return fail(ctx, MGL_SW_ERR_UNSUPPORTED, "mgl_sw_ctx_expand_slot: the last call kept no traceback (checkpointed lane kernel); "
                                                   "switch it off with mgl_sw_ctx_set_lane_checkpoint(ctx, 1)");
     const int64_t region = ctx->last_packed16 == 2 ? slot >> 7 : ctx->last_packed16 == 1 ? slot >> 1 : slot;

@@ -66,6 +66,7 @@ struct DpArgs {
     int matrix_lds_offset;    // set by the launcher
     int score_only;           // packed kernel: no traceback flags (MGL_SW_FLAG_SCORE_ONLY)
     int grouped;              // sw_dp16_lane_ck_kernel: every wave of 128 pairs has its own geometry (a chunk sorted by geometry)
+    int strip_k;              // sw_dp16_strip_kernel: 0 = the flags of every cell are stored; K > 0 = none are: rows and checkpoints of bands of K strips (strip16_ck_*)
 };
 
 struct TbArgs {
@@ -86,6 +87,8 @@ struct TbArgs {
     int32_t *cigar_len; // optional
     int32_t *status;    // optional
     int32_t *status_any; // optional: max of all non-zero statuses of the call
+    int match, mismatch, gopen, gext; // sw_strip_ck_walk_kernel recomputes the blocks its path crosses
+    int strip_rows, strip_k;         // ... rows per strip and strips per kept band of the fill
     const int64_t *dest; // optional: output index of input pair p (results of pair p go to offset[dest[p]], cigar slot dest[p], ...);
 };                       // null: p itself.  (Batches the host layer has reordered by geometry hand results back in the caller's order.)
 
@@ -185,11 +188,23 @@ __host__ __device__ inline int strip16_steps(int ql, int waves) { return strip16
 __host__ __device__ inline int strip16_qwords(int ql) { return ((((ql + 3) >> 2) + 4) + 3) & ~3; }
 __host__ __device__ inline int64_t tb_words_strip16(int ql, int waves) { return (int64_t)waves * strip16_steps(ql, waves) * STRIP_CPS * 2 * 64 * 4; } // [wave][step][CPS][2][lane] uint4
 __host__ __device__ inline int64_t strip16_scratch_bytes(int ql, int waves) { return ((int64_t)(ql + 8) * 2 + 2 * 33 * 64 * waves) * 4; } // per pair
+// ... without stored flags (DpArgs::strip_k = K > 0, traceback layout 6): per pair {H, E} (int32, true scores) of the row below every band of
+// K strips, all columns -- [band 1 .. NB - 1][column 0 .. ql] -- and {H, F} of every row at the band's checkpoint columns
+// j = STRIP_CK_COLS * cc - CPS * K * band (a staircase: the strips of a band reach such a column K * band steps later than strip 0
+// does) -- [cc][row 0 .. tl]
+constexpr int STRIP_CK_COLS = 256;
+__host__ __device__ inline int strip16_ck_bands(int tl, int rows, int k) { return (tl + rows * k - 1) / (rows * k); }
+__host__ __device__ inline int strip16_ck_ccs(int tl, int ql, int rows, int k) { return (ql + STRIP_CPS * k * strip16_ck_bands(tl, rows, k)) / STRIP_CK_COLS + 2; }
+__host__ __device__ inline int64_t strip16_ck_words(int tl, int ql, int rows, int k)
+{
+    return ((int64_t)strip16_ck_bands(tl, rows, k) * (ql + 1) + (int64_t)strip16_ck_ccs(tl, ql, rows, k) * (tl + 1)) * 2;
+}
 int strip16_lds_bytes(int max_ql, int waves);
 bool strip16_range_ok(int match, int mismatch, int gopen, int gext);
 hipError_t launch_dp16_strip(const DpArgs &a, int waves, int rows, hipStream_t stream); // rows per strip: 20 / 24 / 28 / 32; a.uni_ql = max_ql sizes the regions; a.scratch: strip16_scratch_bytes per pair
 hipError_t launch_dp_coop16(const DpArgs &a, int waves_per_block, hipStream_t stream); // a.sps_cap = coop16_sps_for(max_ql)
 hipError_t launch_traceback(const TbArgs &a, hipStream_t stream);
+hipError_t launch_strip_ck_walk(const TbArgs &a, int max_tl, int max_ql, hipStream_t stream); // layout 6: one wave per pair, blocks recomputed (sw_strip_walk.hip)
 
 // Device-side sort of a chunk by geometry (sw_kernels.hip): a counting sort over the (tl, ql) grid [1, max_tl] x [1, max_ql].
 // Slots [0, total[0]) hold the full blocks of eight pairs of one geometry, cell after cell; the left-over pairs (fewer than

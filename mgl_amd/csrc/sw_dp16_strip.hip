@@ -24,6 +24,12 @@
 // [wave][step][column of the group][16-row group][lane] uint4, the byte layout of the lane kernel (low bytes = low half);
 // a wave stores 1 KB per instruction although its lanes are at different columns.  Cell (i, j): strip g = (i-1)/32,
 // lane = g mod NL, half = g / NL, step = (j-1)/4 + g.
+//
+// Without stored flags (DpArgs::strip_k = K > 0, round 3; layout 6).  A 10 kb x 10 kb pair's path visits 0.02 % of the cells the flags
+// are written for (67 MB per pair).  In this form the fill runs the score-only column code (9 instead of 17 instructions per two
+// cells) and keeps what sw_strip_ck_walk_kernel (sw_strip_walk.hip) needs to recompute the 60 x 256 blocks the path crosses: the
+// true scores {H, E} of the row below every band of K strips, per column, and {H, F} of every row at the band's checkpoint columns
+// (every STRIP_CK_COLS columns, at the step offset of the band so that all strips of a band save the SAME column): 17 MB per pair.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -114,6 +120,13 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     int best = NEG_INF, best_i = -1;            // last-column candidates of this lane (both halves merged: later row wins)
 
     uint4 *const tb_wave = reinterpret_cast<uint4 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words) + (size_t)w * steps_cap * CPS * 2 * 64 + L;
+    // NOTB: the rows and checkpoints kept instead of the flags (strip16_ck_words): int2 entries
+    const int K = NOTB ? a.strip_k : 1;
+    int2 *const rows_rec = reinterpret_cast<int2 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words);
+    int2 *const ck_rec = rows_rec + (size_t)strip16_ck_bands(a.uni_tl, SR, K) * (a.uni_ql + 1);
+    const int bandA = gA / K, bandB = gB / K;
+    // the strip whose last row is the row below a band (and not the matrix's last rows): it writes that row
+    const bool rowsA = NOTB && (gA + 1) % K == 0 && (gA + 1) * SR < tl, rowsB = NOTB && (gB + 1) % K == 0 && (gB + 1) * SR < tl;
 
     for (int s = 0; s < steps; ++s) {
         const int cgA = s - gA, cgB = s - gB;
@@ -186,6 +199,16 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                 hd = pk_sub(ih, bres);
                 out_h[u] = pk_add(h[SR - 1], bres);
                 out_e[u] = pk_add(e, bres);
+                if (NOTB) { // {H[i][j], E entering row i + 1} of the row below a band, as true scores (stored = X + (i + j) e - baseline)
+                    if (rowsA && actA) {
+                        const int i = (gA + 1) * SR, j = CPS * cgA + u + 1;
+                        if (j <= ql) rows_rec[(size_t)bandA * (a.uni_ql + 1) + j] = make_int2(lo16(h[SR - 1]) + base_a - (i + j) * gext, lo16(e) + base_a - (i + 1 + j) * gext);
+                    }
+                    if (rowsB && actB) {
+                        const int i = (gB + 1) * SR, j = CPS * cgB + u + 1;
+                        if (j <= ql) rows_rec[(size_t)bandB * (a.uni_ql + 1) + j] = make_int2(hi16(h[SR - 1]) + base_b - (i + j) * gext, hi16(e) + base_b - (i + 1 + j) * gext);
+                    }
+                }
                 if (u == ulast && ((cgA == NCG - 1 && actA) || (cgB == NCG - 1 && actB))) {
                     // column ql of this strip's rows: parked in the lane's own scratch lines with the baseline that goes with it,
                     // looked at after the last step (comparing 32 rows here, in the unrolled column code, costs the allocator
@@ -213,6 +236,29 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                         rowbuf[2 * j] = (int)v;
                         rowbuf[2 * j + 1] = own_last_b ? base_b : base_a;
                     }
+                }
+            }
+        }
+        // ---- 4b. checkpoints (NOTB): a band's strips save the column they have just finished when it is one of the band's checkpoint
+        // columns j = STRIP_CK_COLS cc - CPS K band -- strip g reaches it (g mod K) steps after the band's first strip, so the wave
+        // takes this branch on K of every 64 steps, a K-th of its lanes each time
+        if (NOTB) {
+            constexpr int PER = STRIP_CK_COLS / CPS;
+            const bool ckA = actA && ((cgA + 1 + K * bandA) % PER) == 0, ckB = actB && ((cgB + 1 + K * bandB) % PER) == 0;
+            if (__builtin_amdgcn_ballot_w64(ckA || ckB)) {
+                if (ckA) {
+                    const int j = CPS * (cgA + 1), cc = (cgA + 1 + K * bandA) / PER;
+                    int2 *const dst = ck_rec + (size_t)cc * (a.uni_tl + 1) + i0A + 1;
+#pragma unroll
+                    for (int r = 0; r < SR; ++r)
+                        if (i0A + r < tl) dst[r] = make_int2(lo16(h[r]) + base_a - (i0A + r + 1 + j) * gext, lo16(f[r]) + base_a - (i0A + r + 2 + j) * gext);
+                }
+                if (ckB) {
+                    const int j = CPS * (cgB + 1), cc = (cgB + 1 + K * bandB) / PER;
+                    int2 *const dst = ck_rec + (size_t)cc * (a.uni_tl + 1) + i0B + 1;
+#pragma unroll
+                    for (int r = 0; r < SR; ++r)
+                        if (i0B + r < tl) dst[r] = make_int2(hi16(h[r]) + base_b - (i0B + r + 1 + j) * gext, hi16(f[r]) + base_b - (i0B + r + 2 + j) * gext);
                 }
             }
         }
@@ -281,7 +327,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
             r.max_t = row_wins ? tl : mqe_t;
             r.max_q = row_wins ? rj : ql;
             r.seg = row_wins ? ql - rj : 0;
-            r.g_tail = -(100 + W);
+            r.g_tail = NOTB ? -(200 + W) : -(100 + W);
             r.sps = steps_cap;
             a.rec[slot] = r;
         }
@@ -299,6 +345,11 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     {                                                                                    \
         extern __shared__ __attribute__((aligned(16))) unsigned char smem[];             \
         sw_dp16_strip_body<ROWS, false>(a, smem);                                        \
+    }                                                                                    \
+    __global__ __launch_bounds__(256, 3) void NAME##_ck(const DpArgs a)                  \
+    {                                                                                    \
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem[];             \
+        sw_dp16_strip_body<ROWS, true>(a, smem);                                         \
     }
 MGL_STRIP_KERNEL(sw_dp16_strip_kernel, 32)
 MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r31, 31)
@@ -335,8 +386,12 @@ hipError_t launch_dp16_strip(const DpArgs &a, int waves, int rows, hipStream_t s
                                                     sw_dp16_strip_kernel_r24, sw_dp16_strip_kernel_r25, sw_dp16_strip_kernel_r26, sw_dp16_strip_kernel_r27,
                                                     sw_dp16_strip_kernel_r28, sw_dp16_strip_kernel_r29, sw_dp16_strip_kernel_r30, sw_dp16_strip_kernel_r31,
                                                     sw_dp16_strip_kernel};
+    static void (*const table_ck[13])(const DpArgs) = {sw_dp16_strip_kernel_r20_ck, sw_dp16_strip_kernel_r21_ck, sw_dp16_strip_kernel_r22_ck, sw_dp16_strip_kernel_r23_ck,
+                                                       sw_dp16_strip_kernel_r24_ck, sw_dp16_strip_kernel_r25_ck, sw_dp16_strip_kernel_r26_ck, sw_dp16_strip_kernel_r27_ck,
+                                                       sw_dp16_strip_kernel_r28_ck, sw_dp16_strip_kernel_r29_ck, sw_dp16_strip_kernel_r30_ck, sw_dp16_strip_kernel_r31_ck,
+                                                       sw_dp16_strip_kernel_ck};
     if (rows < 20 || rows > 32) return hipErrorInvalidValue;
-    void (*k)(const DpArgs) = table[rows - 20];
+    void (*k)(const DpArgs) = a.strip_k > 0 ? table_ck[rows - 20] : table[rows - 20];
     hipLaunchKernelGGL(k, dim3((unsigned)a.count), dim3(64 * waves), lds, stream, a);
     return hipGetLastError();
 }

@@ -38,6 +38,8 @@ a = MicrosoftSmithWaterman(0)
 a.set_workspace(int(args.workspace_gib * (1 << 30)))
 if os.environ.get("MGL_STRIP"):
     a.set_strip_kernel(int(os.environ["MGL_STRIP"]))   # 1 = never, 2 = whenever eligible
+if os.environ.get("MGL_STORED"):
+    a.set_lane_checkpoint(1)   # the strip kernel with the flags of every cell stored (default: none stored, the walk recomputes blocks)
 if os.environ.get("MGL_COOP_W"):
     a.set_cooperative(int(os.environ["MGL_COOP_W"]))
 cells = b.cells
@@ -59,20 +61,27 @@ if args.json:
     import json
     # HBM roofline of the fill kernel (north_star's roofline; the kernel is VALU-issue bound): algorithmic bytes per pair =
     # both sequences + offsets + the 4-bit-per-cell traceback spilled to HBM + the fill record
-    alg = sum(len(ts[k]) + len(qs[k]) + 16 + len(ts[k]) * len(qs[k]) // 2 + 32 for k in range(n))
+    # (the traceback counts only where it is spilled to HBM -- the strip kernel's default form keeps none)
+    spilled = a.slot_layout(0) != 6
+    out_bytes = float(b.cigar_len.float().mean().item()) + 36
+    alg = sum(len(ts[k]) + len(qs[k]) + 16 + out_bytes + (len(ts[k]) * len(qs[k]) // 2 + 32 if spilled else 0) for k in range(n))
     fill_s = tm.dp_ms / 1e3
+    walk_name = "sw_traceback_wave_kernel" if spilled else "sw_strip_ck_walk_kernel"
     print(json.dumps({"gcups": round(cells * reps / dt / 1e9, 1), "pairs": n, "length": length, "passes": reps, "seconds": round(dt, 1),
                       "ms_per_pass": round(dt * 1e3 / reps, 2),
-                      "kernel_ms": {a.fill_kernel_name(tm): round(tm.dp_ms, 2), "sw_traceback_wave_kernel": round(tm.tb_ms, 2), "launches": tm.dp_launches},
+                      "kernel_ms": {a.fill_kernel_name(tm): round(tm.dp_ms, 2), walk_name: round(tm.tb_ms, 2), "launches": tm.dp_launches},
+                      "traceback": "4 bits per cell in HBM" if spilled else "none stored: kept rows and checkpoints (17 MB per 10 kb pair), the walk recomputes the blocks the path crosses",
                       "roofline": {"bound": "hbm", "kernel": a.fill_kernel_name(tm), "achieved": round(alg / fill_s / 1e9, 1), "peak": 8000.0,
-                                   "unit": "GB/s", "frac": round(alg / fill_s / 1e9 / 8000.0, 4), "traffic": None,
-                                   "algorithmic_bytes_per_pass": alg, "kernel_gcups": round(cells / fill_s / 1e9, 1),
-                                   "note": ("one 32-row strip per lane-half, the lane kernel's column code with per-strip 16-bit baselines; VALU-issue "
-                                            "bound, 71 % of the issued lanes are real cells (strip slots and pipeline ramp), profiles/r02_d_strip_kernel.txt"
+                                   "unit": "GB/s", "frac": round(alg / fill_s / 1e9 / 8000.0, 5), "traffic": None,
+                                   "algorithmic_bytes_per_pass": round(alg), "kernel_gcups": round(cells / fill_s / 1e9, 1),
+                                   "if_traceback_were_spilled_frac": round(sum(len(ts[k]) * len(qs[k]) // 2 for k in range(n)) / fill_s / 1e9 / 8000.0, 4),
+                                   "note": ("one strip of 20-32 rows per lane-half, the lane kernel's column code with per-strip 16-bit baselines; VALU-issue "
+                                            "bound; " + ("no flags stored (score-only column code, 9 instructions per two cells), profiles/r03_e_long_reads.txt"
+                                                         if not spilled else "flags of every cell stored, profiles/r02_d_strip_kernel.txt")
                                             if tm.fill_kernel == 6 else
                                             "packed int16 wavefront, 128 rows per wave, VALU-issue bound (36 VALU instructions per 128-cell step = 87 % of "
                                             "the issue peak, profiles/r02_b_long_reads.txt)" if tm.fill_kernel == 5 else
-                                            "int32 wavefront, VALU-issue bound (about 22 instructions per 64-cell step)") + "; traffic: PMC pass at 1024 pairs only"}}),
+                                            "int32 wavefront, VALU-issue bound (about 22 instructions per 64-cell step)")}}),
           flush=True)
 import oracle_lib as ol
 if args.check:

@@ -127,6 +127,7 @@ hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &w, hipStream_t)
     return hipSuccess;
 }
 hipError_t launch_traceback(const TbArgs &a, hipStream_t) { walk(a, false); return hipSuccess; }
+hipError_t launch_strip_ck_walk(const TbArgs &a, int, int, hipStream_t) { walk(a, false); return hipSuccess; }
 hipError_t launch_regroup(const RegroupArgs &a, hipStream_t)
 {
     // the device's counting sort, sequentially (fake device memory is host memory)

@@ -261,14 +261,18 @@ def test_device_batch_of_mixed_lengths_is_sorted_on_the_device(two_bit):
     a.close()
 
 
-def test_strip_kernel_long_reads():
+@pytest.mark.parametrize("stored", [False, True], ids=["checkpointed", "stored"])
+def test_strip_kernel_long_reads(stored):
     """sw_dp16_strip_kernel (one pair per workgroup, one 32-row strip per lane-half, per-strip 16-bit baselines, hand-over by DPP
     and an LDS mailbox) forced onto the long goldens, onto pairs of awkward lengths under every strategy, and onto ordinary
-    short pairs (one wave, mostly idle strips): identical results, traceback included."""
+    short pairs (one wave, mostly idle strips): identical results, traceback included.  Both forms: no flags stored -- kept
+    rows and checkpoints, sw_strip_ck_walk_kernel recomputes the blocks the path crosses (layout 6, the default) -- and the
+    flags of every cell stored (layout 4, what mgl_sw_ctx_expand_slot needs)."""
     from mgl_amd import synth
 
     forced = sw.MicrosoftSmithWaterman(0)
     forced.set_strip_kernel(2)
+    forced.set_lane_checkpoint(1 if stored else 0)
     gs = [g for g in golden_io.load("long") + golden_io.load("long2") if g.params == (200, -150, 260, 11) and len(g.t) <= 16384]
     assert len(gs) >= 12
     assert run_groups(forced, gs) == len(gs)
@@ -282,7 +286,7 @@ def test_strip_kernel_long_reads():
         for k, (t, q) in enumerate(pairs):
             o = ol.oracle_align(t, q, (200, -150, 260, 11), strategy)
             assert (int(res.offsets[k]), res.cigars[k], tuple(int(x) for x in res.scores[k])) == (o["offset"], o["cigar"], o["score"]), (strategy, k)
-            assert forced.slot_layout(k) == 4
+            assert forced.slot_layout(k) == (4 if stored else 6)
     # four waves per pair (targets of 12 289 .. 16 384 rows), a short query against a long target and the reverse
     wide = [(synth.random_genome(rng, 15000).tobytes(), synth.random_genome(rng, 1800).tobytes())]
     wide.append((wide[0][0][:16384 - 3], wide[0][0][200:1500]))
@@ -308,6 +312,10 @@ def test_strip_kernel_long_reads():
     g24 = [g for g in golden_io.load("random") if g.params == (200, -150, 260, 11) and g.strategy == ol.SOFTCLIP][:24]
     forced.align_batch([g.t for g in g24], [g.q for g in g24], g24[0].params, ol.SOFTCLIP)
     for k, g in enumerate(g24):
+        if not stored:
+            with pytest.raises(RuntimeError):
+                forced.expand_slot(k, len(g.t), len(g.q))   # no stored traceback to expand
+            break
         btr = forced.expand_slot(k, len(g.t), len(g.q))
         assert zlib.crc32(np.ascontiguousarray(btr[1:, 1:]).astype("<i4").tobytes()) & 0xFFFFFFFF == g.crc
     forced.close()
@@ -813,7 +821,7 @@ def test_single_long_pair_through_the_one_pair_entry():
     assert tuple(ez) == g.score
     # a small workspace holds exactly as many pairs as fit, down to one per chunk
     a = sw.MicrosoftSmithWaterman(0)
-    a.set_workspace(150 << 20)   # two halves of 75 MB: one 50 MB traceback each
+    a.set_workspace(40 << 20)   # two halves of 20 MB: one pair's kept rows and checkpoints each (17 MB; with every flag stored: 50 MB)
     res = a.align_batch([g.t] * 3, [g.q] * 3, g.params, g.strategy, cigar_stride=24000)
     assert all(int(res.offsets[k]) == g.offset and "sha1:" + hashlib.sha1(res.cigars[k].encode()).hexdigest() == g.cigar for k in range(3))
     assert a.timing().dp_launches == 3
