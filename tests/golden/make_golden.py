@@ -224,6 +224,29 @@ def suite_long2():
     return rows
 
 
+def suite_long3():
+    """Long pairs whose paths cross the seams of the checkpointed long-read path with LONG gaps (round 3: the strip kernel keeps the
+    rows below bands of 60 rows and column checkpoints every 256 columns, the walk recomputes blocks in between): deletions and
+    insertions of 70 .. 900 bases laid over band seams and checkpoint columns, several per pair, every strategy."""
+    rng = synth.rng_for(33)
+    rows = []
+    for length, gaps, params, s in ((4200, ((1190, "D", 130), (2500, "I", 300), (3300, "D", 75)), GATK, ol.SOFTCLIP),
+                                    (5000, ((600, "I", 70), (1780, "D", 520), (3999, "I", 260)), GATK, ol.INDEL),
+                                    (6100, ((2040, "D", 900), (4090, "I", 128)), GATK, ol.LEAD_INDEL),
+                                    (4800, ((958, "D", 61), (1918, "D", 62), (2878, "I", 257), (3500, "I", 255)), GATK, ol.IGNORE),
+                                    (4500, ((1500, "D", 240), (3000, "I", 240)), (100, -100, 300, 10), ol.SOFTCLIP),
+                                    (9000, ((2500, "D", 700), (5200, "I", 512), (7700, "D", 64)), GATK, ol.SOFTCLIP)):
+        t, q = synth.ont_pair(rng, length, 0.02, 0.01, 0.01)
+        q = q.copy()
+        for at, kind, n in sorted(gaps, reverse=True):  # (positions in the read; applied from the back so that they stay put)
+            if kind == "D":   # the read lacks n bases of the target: a vertical run
+                q = np.concatenate([q[:at], q[at + n:]])
+            else:             # the read has n extra bases: a horizontal run
+                q = np.concatenate([q[:at], synth.random_genome(rng, n), q[at:]])
+        rows.append(record("long3", t.tobytes(), q.tobytes(), params, s, hash_cigar=True))
+    return rows
+
+
 def suite_bam():
     # real Illumina reads: the reference repo's own test resource (src/test/resources/HiSeq.1mb.1RG.2k_lines.bam,
     # kept here as a data fixture); target = the reference bases under the read rebuilt from CIGAR + MD
@@ -242,7 +265,7 @@ def suite_bam():
 
 SUITE_FUNCS = {"known": suite_known, "tiny": suite_tiny, "random": suite_random, "ties": suite_ties,
                "shapes": suite_shapes, "config1": suite_config1, "window": suite_window, "long": suite_long, "long2": suite_long2,
-               "bam": suite_bam}
+               "long3": suite_long3, "bam": suite_bam}
 
 
 def main():

@@ -8,7 +8,7 @@ GOLDEN_DIR = os.path.join(HERE, "golden")
 
 Golden = namedtuple("Golden", "suite t q params strategy offset cigar score crc")
 
-SUITES = ("known", "tiny", "random", "ties", "shapes", "config1", "window", "long", "long2", "bam")
+SUITES = ("known", "tiny", "random", "ties", "shapes", "config1", "window", "long", "long2", "long3", "bam")
 
 
 def load(suite):

@@ -118,6 +118,26 @@ def test_golden_long2(aligner):
     assert off == g.offset and "sha1:" + hashlib.sha1(cigar.encode()).hexdigest() == g.cigar and tuple(ez) == g.score
 
 
+def test_golden_long3_gaps_across_the_seams(aligner):
+    """Six long pairs from the compiled reference whose paths carry gaps of 61 .. 900 cells laid over the seams of the
+    checkpointed long-read path (bands of 60 rows, checkpoint columns every 256 columns): runs that cross several recomputed blocks
+    upwards and to the left, every strategy, two parameter sets -- default choice (strip kernel, no flags stored), the same with
+    every flag stored, and the workgroup kernels."""
+    rows = golden_io.load("long3")
+    assert len(rows) == 6
+    assert run_groups(aligner, rows) == 6
+    assert aligner.timing().fill_kernel == 6 and aligner.slot_layout(0) == 6
+    for mode in ("stored", "coop"):
+        forced = sw.MicrosoftSmithWaterman(0)
+        if mode == "stored":
+            forced.set_lane_checkpoint(1)
+        else:
+            forced.set_strip_kernel(1)
+        assert run_groups(forced, rows) == 6
+        assert forced.timing().fill_kernel == (6 if mode == "stored" else 5)
+        forced.close()
+
+
 @pytest.mark.parametrize("rows,carry", [(64, 0), (64, 1), (16, 1)])
 def test_stripe_rows_and_carry_variants(rows, carry):
     """The int32 fill kernel with 64-row stripes (one pair per wave, wave_shr DPP) and / or the carry in the HBM
@@ -273,8 +293,8 @@ def test_strip_kernel_long_reads(stored):
     forced = sw.MicrosoftSmithWaterman(0)
     forced.set_strip_kernel(2)
     forced.set_lane_checkpoint(1 if stored else 0)
-    gs = [g for g in golden_io.load("long") + golden_io.load("long2") if g.params == (200, -150, 260, 11) and len(g.t) <= 16384]
-    assert len(gs) >= 12
+    gs = [g for g in golden_io.load("long") + golden_io.load("long2") + golden_io.load("long3") if g.params == (200, -150, 260, 11) and len(g.t) <= 16384]
+    assert len(gs) >= 17
     assert run_groups(forced, gs) == len(gs)
     assert forced.timing().fill_kernel == 6
     rng = synth.rng_for(77)

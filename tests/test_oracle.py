@@ -31,7 +31,7 @@ def test_golden_counts():
     # the fixture inventory promised in DESIGN.md
     n = {s: len(golden_io.load(s)) for s in golden_io.SUITES}
     assert n["known"] == 24 and n["tiny"] == 14880 and n["random"] == 2000
-    assert n["config1"] == 1000 and n["window"] == 512 and n["long"] == 9 and n["long2"] == 10
+    assert n["config1"] == 1000 and n["window"] == 512 and n["long"] == 9 and n["long2"] == 10 and n["long3"] == 6
 
 
 def test_survey_known_answers():
