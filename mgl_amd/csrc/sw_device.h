@@ -195,9 +195,10 @@ __host__ __device__ inline int64_t strip16_scratch_bytes(int ql, int waves) { re
 constexpr int STRIP_CK_COLS = 256;
 __host__ __device__ inline int strip16_ck_bands(int tl, int rows, int k) { return (tl + rows * k - 1) / (rows * k); }
 __host__ __device__ inline int strip16_ck_ccs(int tl, int ql, int rows, int k) { return (ql + STRIP_CPS * k * strip16_ck_bands(tl, rows, k)) / STRIP_CK_COLS + 2; }
+__host__ __device__ inline int strip16_ck_row_stride(int ql) { return (ql + 4) & ~3; } // entries per kept row: column j at index j - 1, rows 32-byte aligned
 __host__ __device__ inline int64_t strip16_ck_words(int tl, int ql, int rows, int k)
 {
-    return ((int64_t)strip16_ck_bands(tl, rows, k) * (ql + 1) + (int64_t)strip16_ck_ccs(tl, ql, rows, k) * (tl + 1)) * 2;
+    return ((((int64_t)strip16_ck_bands(tl, rows, k) * strip16_ck_row_stride(ql) + (int64_t)strip16_ck_ccs(tl, ql, rows, k) * (tl + 1)) + 3) & ~(int64_t)3) * 2;
 }
 int strip16_lds_bytes(int max_ql, int waves);
 bool strip16_range_ok(int match, int mismatch, int gopen, int gext);

@@ -123,7 +123,8 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     // NOTB: the rows and checkpoints kept instead of the flags (strip16_ck_words): int2 entries
     const int K = NOTB ? a.strip_k : 1;
     int2 *const rows_rec = reinterpret_cast<int2 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words);
-    int2 *const ck_rec = rows_rec + (size_t)strip16_ck_bands(a.uni_tl, SR, K) * (a.uni_ql + 1);
+    const int row_stride = strip16_ck_row_stride(a.uni_ql);
+    int2 *const ck_rec = rows_rec + (size_t)strip16_ck_bands(a.uni_tl, SR, K) * row_stride;
     const int bandA = gA / K, bandB = gB / K;
     // the strip whose last row is the row below a band (and not the matrix's last rows): it writes that row
     const bool rowsA = NOTB && (gA + 1) % K == 0 && (gA + 1) * SR < tl, rowsB = NOTB && (gB + 1) % K == 0 && (gB + 1) * SR < tl;
@@ -146,6 +147,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
             ih = dpp_wave_shr1(l0h, out_h[u]);
             ie = dpp_wave_shr1(l0e, out_e[u]);
         };
+        int2 keptA[CPS] = {}, keptB[CPS] = {}; // NOTB: the row below a band, this step's columns
         // (wave-uniform: the DPP moves below need the lane before to be enabled; what an idle lane computes feeds nothing real)
         if (__builtin_amdgcn_ballot_w64(actA || actB)) {
             // ---- 2. a half that starts now: column 0 of its rows (sw.cpp:24,38,47-49), its baseline on its first row
@@ -200,14 +202,9 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                 out_h[u] = pk_add(h[SR - 1], bres);
                 out_e[u] = pk_add(e, bres);
                 if (NOTB) { // {H[i][j], E entering row i + 1} of the row below a band, as true scores (stored = X + (i + j) e - baseline)
-                    if (rowsA && actA) {
-                        const int i = (gA + 1) * SR, j = CPS * cgA + u + 1;
-                        if (j <= ql) rows_rec[(size_t)bandA * (a.uni_ql + 1) + j] = make_int2(lo16(h[SR - 1]) + base_a - (i + j) * gext, lo16(e) + base_a - (i + 1 + j) * gext);
-                    }
-                    if (rowsB && actB) {
-                        const int i = (gB + 1) * SR, j = CPS * cgB + u + 1;
-                        if (j <= ql) rows_rec[(size_t)bandB * (a.uni_ql + 1) + j] = make_int2(hi16(h[SR - 1]) + base_b - (i + j) * gext, hi16(e) + base_b - (i + 1 + j) * gext);
-                    }
+                    const int iA = (gA + 1) * SR, iB = (gB + 1) * SR, jA = CPS * cgA + u + 1, jB = CPS * cgB + u + 1;
+                    keptA[u] = make_int2(lo16(h[SR - 1]) + base_a - (iA + jA) * gext, lo16(e) + base_a - (iA + 1 + jA) * gext);
+                    keptB[u] = make_int2(hi16(h[SR - 1]) + base_b - (iB + jB) * gext, hi16(e) + base_b - (iB + 1 + jB) * gext);
                 }
                 if (u == ulast && ((cgA == NCG - 1 && actA) || (cgB == NCG - 1 && actB))) {
                     // column ql of this strip's rows: parked in the lane's own scratch lines with the baseline that goes with it,
@@ -236,6 +233,31 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                         rowbuf[2 * j] = (int)v;
                         rowbuf[2 * j + 1] = own_last_b ? base_b : base_a;
                     }
+                }
+            }
+        }
+        // ---- 4a. the row below a band (NOTB): the group's four columns as one aligned 32-byte piece (column j at entry j - 1)
+        if (NOTB && CPS == 4) {
+            if (rowsA && actA) {
+                int2 *const dst = rows_rec + (size_t)bandA * row_stride + CPS * cgA;
+                if (CPS * cgA + CPS <= ql) {
+                    reinterpret_cast<int4 *>(dst)[0] = make_int4(keptA[0].x, keptA[0].y, keptA[1].x, keptA[1].y);
+                    reinterpret_cast<int4 *>(dst)[1] = make_int4(keptA[2].x, keptA[2].y, keptA[3].x, keptA[3].y);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < CPS; ++u)
+                        if (CPS * cgA + u + 1 <= ql) dst[u] = keptA[u];
+                }
+            }
+            if (rowsB && actB) {
+                int2 *const dst = rows_rec + (size_t)bandB * row_stride + CPS * cgB;
+                if (CPS * cgB + CPS <= ql) {
+                    reinterpret_cast<int4 *>(dst)[0] = make_int4(keptB[0].x, keptB[0].y, keptB[1].x, keptB[1].y);
+                    reinterpret_cast<int4 *>(dst)[1] = make_int4(keptB[2].x, keptB[2].y, keptB[3].x, keptB[3].y);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < CPS; ++u)
+                        if (CPS * cgB + u + 1 <= ql) dst[u] = keptB[u];
                 }
             }
         }

@@ -9,8 +9,9 @@
 // row; what a lane needs from its own row (H of the column before, the horizontal-gap value) it keeps.  The recurrence and its four
 // decisions are those of every fill kernel here (sw.cpp:51-93): diag = H[i-1][j-1] + (t == q ? match : mismatch); F > diag; E >
 // max(diag, F); H = max; E' = max(H - o, E - e) and F' likewise, extension winning ties -- so the nibble of a cell {F > diag, E > max,
-// E' opened, F' opened} is bit for bit what the fill would have stored.  Flags go to LDS, [row][column / 8] dwords, and the walk reads
-// them there: every lane runs the same walk (wave-uniform state), lane 0 stores the text.
+// E' opened, F' opened} is bit for bit what the fill would have stored.  Flags go to LDS, one dword per lane per eight STEPS (cell
+// (row l, column c) of the block sits at step c + l: the store is the same instruction for every lane, no lane-dependent branch), and
+// the walk reads them there: every lane runs the same walk (wave-uniform state), lane 0 stores the text.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -22,7 +23,7 @@ namespace mgl_sw_dev {
 namespace {
 
 constexpr int BC = STRIP_CK_COLS;     // columns per block
-constexpr int FW = BC / 8;            // flag dwords per row
+constexpr int FW = (BC + 64) / 8;     // flag dwords per row: one nibble per STEP of the block's wavefront (columns + rows - 1 steps)
 
 __device__ __forceinline__ int dpp_shr1(int lane0_value, int src) { return __builtin_amdgcn_update_dpp(lane0_value, src, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int border_of(int k, int gopen, int gext, bool indel) { return (indel && k > 0) ? -gopen - (k - 1) * gext : 0; } // sw.cpp:29-40,47-49
@@ -35,7 +36,7 @@ struct BlockMoves {
     bool indel;
     int rbk, kcols;            // rows per band (K strips), CPS * K: how far a band's checkpoint columns lie before the band above's
     const int2 *rows, *ck;     // what the fill kept (strip16_ck_words)
-    int ql_cap, tl_cap;
+    int row_stride, tl_cap;    // entries per kept row (column j at j - 1), rows per checkpoint column
     unsigned *flags;           // LDS: [64 rows][FW] dwords
     unsigned char *qb;         // LDS: the block's query bases
     int lane;
@@ -76,7 +77,7 @@ struct BlockMoves {
                 h_ = border_of(j, gopen, gext, indel);
                 e_ = h_ - gopen;
             } else {
-                const int2 v = rows[(size_t)(b - 1) * (ql_cap + 1) + j];
+                const int2 v = rows[(size_t)(b - 1) * row_stride + (j - 1)];
                 h_ = v.x;
                 e_ = v.y;
             }
@@ -85,10 +86,9 @@ struct BlockMoves {
         if (jl > 0) top(jl, corner, dummy);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        // hup_prev: H of the row above at the column before this lane's current one (the diagonal input)
+        // hdiag: H of the row above at the column before this lane's current one (the diagonal input)
         int hdiag = dpp_shr1(corner, hleft); // lane l: H[i-1][jl] = the lane above's left border; lane 0: the corner
         int h_out = hleft, e_out = 0;        // what this lane handed down in its last step
-        unsigned acc = 0;
         const int steps = nc + nr - 1;
         int tops_h[2] = {0, 0}, tops_e[2] = {0, 0}; // the kept row, 64 columns per fetch, one fetch ahead
         auto fetch = [&](int s0, int &h_, int &e_) {
@@ -96,33 +96,33 @@ struct BlockMoves {
             if (j <= jr) top(j, h_, e_);
         };
         fetch(0, tops_h[0], tops_e[0]);
+        const int gopen_ = gopen, gext_ = gext, match_ = match, mismatch_ = mismatch;
         for (int s0 = 0; s0 < steps; s0 += 64) {
             fetch(s0 + 64, tops_h[1], tops_e[1]);
-            const int send = min(64, steps - s0);
-            for (int ds = 0; ds < send; ++ds) {
-                const int s = s0 + ds, c = s - lane; // this lane's column within the block, 0-based
-                // what comes down from the row above: lane 0 from the kept row (column s), the others from the lane above's last step
-                const int l0h = __builtin_amdgcn_readlane(tops_h[0], ds), l0e = __builtin_amdgcn_readlane(tops_e[0], ds);
-                const int hup = dpp_shr1(l0h, h_out), e = dpp_shr1(l0e, e_out);
-                if (row_ok && c >= 0 && c < nc) {
-                    const int sub = (int)qb[c] == tb_ ? match : mismatch;
+            for (int s8 = s0; s8 < min(s0 + 64, steps); s8 += 8) {
+                unsigned acc = 0;
+#pragma unroll
+                for (int ds = 0; ds < 8; ++ds) {
+                    const int s = s8 + ds, c = s - lane; // this lane's column within the block, 0-based (steps past the last: idle for every lane)
+                    // what comes down from the row above: lane 0 from the kept row (column s), the others from the lane above's last step
+                    const int l0h = __builtin_amdgcn_readlane(tops_h[0], s & 63), l0e = __builtin_amdgcn_readlane(tops_e[0], s & 63);
+                    const int hup = dpp_shr1(l0h, h_out), e = dpp_shr1(l0e, e_out);
+                    const bool active = row_ok && (unsigned)c < (unsigned)nc;
+                    const int sub = (int)qb[min(max(c, 0), BC - 1)] == tb_ ? match_ : mismatch_;
                     const int diag = hdiag + sub;
                     const unsigned dF = f > diag;
                     const int sm = max(diag, f);
                     const unsigned dE = e > sm;
                     const int hn = max(sm, e);
-                    const int open = hn - gopen;
-                    const unsigned eo = open > e - gext, fo = open > f - gext; // a new gap wins only strictly (sw.cpp:73-93)
-                    e_out = max(open, e - gext);
-                    f = max(open, f - gext);
-                    h_out = hn;
-                    acc |= (dF | (dE << 1) | (eo << 2) | (fo << 3)) << (4 * (c & 7));
-                    if ((c & 7) == 7 || c == nc - 1) {
-                        flags[lane * FW + (c >> 3)] = acc;
-                        acc = 0;
-                    }
+                    const int open = hn - gopen_, ee = e - gext_, fe = f - gext_;
+                    const unsigned eo = open > ee, fo = open > fe; // a new gap wins only strictly (sw.cpp:73-93)
+                    e_out = active ? max(open, ee) : e_out;
+                    f = active ? max(open, fe) : f;
+                    h_out = active ? hn : h_out;
+                    acc |= (dF | (dE << 1) | (eo << 2) | (fo << 3)) << (4 * ds);
+                    hdiag = hup;
                 }
-                hdiag = hup;
+                flags[lane * FW + (s8 >> 3)] = acc; // (the nibbles of idle steps are never read)
             }
             tops_h[0] = tops_h[1];
             tops_e[0] = tops_e[1];
@@ -134,8 +134,8 @@ struct BlockMoves {
     {
         const int b = (i - 1) / rbk, cc = cc_of(b, j);
         if (b != cur_b || cc != cur_cc || i > imax || j > jr) compute(b, cc, i, j);
-        const int c = j - jl - 1;
-        return (flags[(i - r0 - 1) * FW + (c >> 3)] >> (4 * (c & 7))) & 15u;
+        const int l = i - r0 - 1, st = (j - jl - 1) + l; // row of the block, step of its wavefront
+        return (flags[l * FW + (st >> 3)] >> (4 * (st & 7))) & 15u;
     }
     __device__ __forceinline__ int diag_run(int, int) const { return 0; }
     // +k rows up, -k columns left, 0 diagonal: what the reference stores (sw.cpp:60-71); run lengths as TbView::vrun / hrun
@@ -193,8 +193,8 @@ __global__ __launch_bounds__(64) void sw_strip_ck_walk_kernel(const TbArgs a, co
     mv.rbk = a.strip_rows * a.strip_k;
     mv.kcols = STRIP_CPS * a.strip_k;
     mv.rows = reinterpret_cast<const int2 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words);
-    mv.ck = mv.rows + (size_t)strip16_ck_bands(tl_cap, a.strip_rows, a.strip_k) * (ql_cap + 1);
-    mv.ql_cap = ql_cap;
+    mv.row_stride = strip16_ck_row_stride(ql_cap);
+    mv.ck = mv.rows + (size_t)strip16_ck_bands(tl_cap, a.strip_rows, a.strip_k) * mv.row_stride;
     mv.tl_cap = tl_cap;
     mv.flags = flags;
     mv.qb = qb;
