@@ -360,8 +360,9 @@ def main():
                          "shard dist.shard_range(pairs, r, N) of it; weak: every rank its own --pairs pairs")
     ap.add_argument("--tl", type=int, default=256, help="reference window length")
     ap.add_argument("--ql", type=int, default=150, help="read length")
-    ap.add_argument("--workspace-gib", type=float, default=DEFAULT_WORKSPACE_GIB,
-                    help="traceback workspace per GPU (208 GiB: the 10 M-pair batch is one launch; the card has 288 GB)")
+    ap.add_argument("--workspace-gib", type=float, default=None,
+                    help=f"workspace per GPU; default: {DEFAULT_WORKSPACE_GIB:.0f} GiB (the 10 M-pair batch is one launch; the card has 288 GB), "
+                         "or what the card has free beside the batch if that is less")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (long reads, PairHMM, protein)")
     ap.add_argument("--no-extra", action="store_true", help="skip the PCIe-inclusive and tl=1000 legs (SURVEY 8d)")
@@ -396,7 +397,6 @@ def main():
     n_local = hi - lo
 
     aligner = MicrosoftSmithWaterman(dev_index)
-    aligner.set_workspace(int(args.workspace_gib * (1 << 30)))
     data_label = "synthetic"
     if args.dataset != "synthetic":
         assert args.input == "ascii", "--dataset bam/fastx use the ASCII wire format"
@@ -413,6 +413,10 @@ def main():
         batch = device_batch.window_batch(seed, n_local, dev, window=args.tl, read_len=args.ql, first=lo)
         ascii_twin = batch
     cells = n_local * args.tl * args.ql   # of this rank, per step
+    if args.workspace_gib is None:   # what a smaller card (or a shared one) has left beside the batch, 12 GiB of slack
+        free, _total = torch.cuda.mem_get_info(dev)
+        args.workspace_gib = max(1.0, min(DEFAULT_WORKSPACE_GIB, (free - (12 << 30)) / (1 << 30)))
+    aligner.set_workspace(int(args.workspace_gib * (1 << 30)))
 
     def step():
         batch.run(aligner, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP)

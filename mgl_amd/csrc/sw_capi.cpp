@@ -325,7 +325,9 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // ... and a device-resident batch is sorted on the device (launch_regroup), at the price of one short synchronisation per
     // chunk: the host has to know how many pairs landed in full blocks before it can size the two launches
     const bool auto_group_dev_on = debug_knobs().auto_group;
-    const bool regroup_dev = !hooks && auto_group_dev_on && n >= 1024 && (int64_t)max_tl * max_ql <= (1ll << 20) && !score_only_hint &&
+    // (the sort scans the whole (tl, ql) grid per chunk: worth it only where the pairs outnumber an eighth of its cells -- a few
+    // thousand short pairs under a large bound would pay milliseconds for it)
+    const bool regroup_dev = !hooks && auto_group_dev_on && n >= 1024 && (int64_t)max_tl * max_ql <= (1ll << 20) && n * 8 >= (int64_t)max_tl * max_ql && !score_only_hint &&
                              (tset.len != nullptr || !tset.packed2) && (qset.len != nullptr || !qset.packed2);
     const bool auto_group = geom == GEOM_MIXED && ((hooks && hooks->regroup) || regroup_dev) && ctx->precision != 32 && !d_matrix && match > 0 &&
                             !ctx->stripe_rows && ctx->cooperative < 2 && ctx->carry_memory == 0 && max_ql < kRows64MinQuery &&

@@ -86,7 +86,7 @@ class DeviceBatch:
         return ts, qs
 
 
-WORKLOAD_BLOCK = 1 << 20  # pairs per generation block of the window workload
+WORKLOAD_BLOCK = 1 << 16  # pairs per generation block of the window workload (small batches materialise one block, not a million pairs)
 
 
 def window_batch(seed, n_pairs, device, window=256, read_len=150, genome_len=1 << 24, sub=0.01, ins=0.001,

@@ -101,4 +101,4 @@ if "--json" in sys.argv:
                       "device_resident_sorted_by_caller_with_promise_gcups": figures.get("grouped geometry"),
                       "host_buffers_pcie_inclusive_gcups": round(cells / dt / 1e9, 1),
                       "note": "mixed geometries: the library sorts every chunk by (tl, ql) itself -- counting sort on the GPU for device-resident "
-                              "batches, on the host for host buffers -- full blocks of eight through the packed kernel, the rest through int32"}))
+                              "batches, on the host for host buffers -- whole waves of one geometry through the lane kernel, full blocks of eight through the packed kernel, the rest through int32"}))
