@@ -171,7 +171,7 @@ int main()
     // through the packed and int32 parts -- both entries, several chunks (threshold lowered: MGL_SW_DEBUG_LANE_GROUP_MIN)
     {
         Batch most;
-        for (int k = 0; k < 2600; ++k) {
+        for (int k = 0; k < 5200; ++k) { // (a device-resident batch is sorted only when n * 8 >= max_tl * max_ql)
             const bool odd = k % 9 == 0;
             std::string t = rnd(g, odd ? 200 + (int)(g() % 57) : 256), q = t.substr(g() % 40, odd ? 100 + g() % 51 : 150);
             q[g() % q.size()] = 'T';

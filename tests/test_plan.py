@@ -42,7 +42,9 @@ def test_configs0_plumbing_case_is_the_int32_kernel():
 def test_configs3_long_reads_take_the_strip_kernel():
     p = plan(n=2304, max_tl=10300, max_ql=10300, parameters=GATK, workspace=BENCH_WS)
     assert p.fill_kernel == STRIP16 and p.waves_per_pair == 4 and 20 <= p.rows <= 32 and p.precision_bits == 16
-    assert p.chunk_pairs == 768 and p.chunks == 3 and p.workspace_halves == 2, "whole rounds of the chip: 256 CUs x 3 workgroups"
+    assert p.chunk_pairs == 2304 and p.chunks == 1, "17 MB of kept rows per pair: the whole batch is one launch (three chunks measured slower)"
+    p = plan(n=2304, max_tl=10300, max_ql=10300, parameters=GATK, workspace=16 << 30)
+    assert p.fill_kernel == STRIP16 and p.chunks > 1 and p.workspace_halves == 2, "a smaller workspace: chunks, two halves in flight"
     p = plan(n=8, max_tl=31000, max_ql=30500, parameters=GATK, workspace=BENCH_WS)   # beyond the strip kernel's 16 384 rows
     assert p.fill_kernel == COOP16 and p.waves_per_pair == 16
 
