@@ -79,6 +79,7 @@ typedef struct mgl_sw_timing {
 #define MGL_SW_KERNEL_COOP16 5    /* sw_dp_coop16_kernel: long reads, packed int16, 128 rows/wave */
 #define MGL_SW_KERNEL_STRIP16 6   /* sw_dp16_strip_kernel: long reads, one 32-row strip per lane-half */
 #define MGL_SW_KERNEL_LANE16_CK 7 /* sw_dp16_lane_ck_kernel: the lane kernel, checkpoints instead of stored flags */
+#define MGL_SW_KERNEL_SMALL 8     /* sw_small_kernel: small batches, one wave per pair, scores kept in LDS, fill + walk in one launch */
 
 /* What the library WOULD do with a batch: the planner's decisions, without running anything (mgl_sw_explain). */
 typedef struct mgl_sw_plan {
@@ -151,6 +152,13 @@ int mgl_sw_ctx_set_lane_kernel(mgl_sw_ctx *ctx, int mode);
  * (chunks sorted by geometry, from two rounds of the chip on); 1 = never (the flags of every cell are stored: needed before
  * mgl_sw_ctx_expand_slot); 2 = same as 0 (tests) */
 int mgl_sw_ctx_set_lane_checkpoint(mgl_sw_ctx *ctx, int mode);
+/* small batches are latency bound: up to MGL_SW_SMALL_BATCH_PAIRS pairs whose targets have at most 512 rows and whose matrix of kept
+ * scores fits a workgroup's LDS (256 x 150, 400 x 190, ...) run one wave per pair in ONE launch that fills, walks and writes the text
+ * (sw_small.hip; nothing of the workspace is touched).  0 (default) = those batches, on a context none of whose other kernel
+ * choices has been forced; 1 = never; 2 = every batch whose bounds allow it, whatever its size and the other settings (the
+ * coalescing front-end of mgl_sw_align) */
+int mgl_sw_ctx_set_small_kernel(mgl_sw_ctx *ctx, int mode);
+#define MGL_SW_SMALL_BATCH_PAIRS 2048
 /* 1 = HIP events around every kernel launch of a call, on the streams the kernels run on, read back by
  * mgl_sw_ctx_get_timing (the call itself stays asynchronous); 2 = additionally stamp the shader clock
  * inside the fill kernel (diagnostic; a few extra instructions per workgroup); 3 = as 1, summed over every call until

@@ -7,6 +7,8 @@
 // JNI export built on it -- parks the calling thread, a dispatcher thread merges the requests that share one
 // parameter set and strategy into a device batch (mgl_sw_align_batch), and every caller gets exactly the answer
 // the direct call would have produced.  Host code only: queues, one std::thread, condition variables.
+// A device round trip is a few dozen microseconds (one launch of sw_small_kernel), the same order as waking a parked thread: callers
+// and dispatcher therefore spin for a short while (MGL_SW_COALESCE_SPIN_US, default 200) before they park on their condition variables.
 #include "../../include/mgl_sw.h"
 
 #include <algorithm>
@@ -48,9 +50,18 @@ struct Request {
     int *cigar_len, *offset;
     mgl_sw_score *ez;
     int rc = MGL_SW_OK;
-    bool done = false; // guarded by the shard's mutex
+    std::atomic<bool> done{false}; // set under the shard's mutex (parked callers), read without it by callers that still spin
     int shard = 0;
 };
+
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
 
 using Key = std::tuple<int, int, int, int, int>; // normalised match, mismatch, open, extend, strategy
 
@@ -86,11 +97,22 @@ class Coalescer {
             const auto ex = expect_.find(key);
             const int expect = ex == expect_.end() ? 1 : ex->second;
             // wake the dispatcher when it is idle, when a batch is full, or when the callers it expects are all back
-            if (++pending_ == 1 || (int)qd.size() >= max_batch_ || (int)qd.size() == expect) cv_work_.notify_one();
+            const int pend = pending_.fetch_add(1, std::memory_order_release) + 1;
+            if (parked_ && (pend == 1 || (int)qd.size() >= max_batch_ || (int)qd.size() == expect)) cv_work_.notify_one();
+        }
+        // the answer is usually back within a device round trip: spin that long before parking
+        if (spin_us_ > 0) {
+            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us_);
+            do {
+                for (int k = 0; k < 64; ++k) {
+                    if (r.done.load(std::memory_order_acquire)) return r.rc;
+                    cpu_relax();
+                }
+            } while (std::chrono::steady_clock::now() < until);
         }
         Shard &sh = shards_[my_shard];
         std::unique_lock<std::mutex> lk(sh.mu);
-        sh.cv.wait(lk, [&] { return r.done; });
+        sh.cv.wait(lk, [&] { return r.done.load(std::memory_order_acquire); });
         return r.rc;
     }
 
@@ -124,7 +146,7 @@ class Coalescer {
     {
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
-            cv_work_.wait(lk, [&] { return stop_ || pending_ > 0; });
+            wait_for_work(lk, [&] { return stop_ || pending_.load(std::memory_order_acquire) > 0; }, std::chrono::steady_clock::time_point::max());
             if (stop_) {
                 fail_all(MGL_SW_ERR_DEVICE);
                 return;
@@ -149,7 +171,9 @@ class Coalescer {
                 earliest = std::min(earliest, deadline);
             }
             if (!ready) {
-                cv_work_.wait_until(lk, earliest);
+                // more callers are expected (or the window is still open): until one arrives or the earliest deadline passes
+                const int seen = pending_.load(std::memory_order_acquire);
+                wait_for_work(lk, [&] { return stop_ || pending_.load(std::memory_order_acquire) != seen; }, earliest);
                 continue;
             }
             const Key key = *ready;
@@ -160,7 +184,7 @@ class Coalescer {
                 qd.pop_front();
             }
             if (!qd.empty()) oldest_[key] = now; // the rest starts a new waiting period
-            pending_ -= (int)batch.size();
+            pending_.fetch_sub((int)batch.size(), std::memory_order_release);
             expect_[key] = (int)batch.size();
             const auto t_first = oldest_[key];
             lk.unlock();
@@ -181,6 +205,33 @@ class Coalescer {
         }
     }
 
+    // The dispatcher's wait: spin (lock released) while the traffic is hot, then park on the condition variable.  `ready` is
+    // evaluated with the lock released while spinning: it may only read atomics.
+    template <typename Pred>
+    void wait_for_work(std::unique_lock<std::mutex> &lk, Pred ready, std::chrono::steady_clock::time_point deadline)
+    {
+        if (ready()) return;
+        if (spin_us_ > 0) {
+            const auto until = std::min(deadline, std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us_));
+            lk.unlock();
+            bool ok = false;
+            do {
+                for (int k = 0; k < 64 && !ok; ++k) {
+                    ok = ready();
+                    if (!ok) cpu_relax();
+                }
+            } while (!ok && std::chrono::steady_clock::now() < until);
+            lk.lock();
+            if (ok || ready() || std::chrono::steady_clock::now() >= deadline) return;
+        }
+        parked_ = true;
+        if (deadline == std::chrono::steady_clock::time_point::max())
+            cv_work_.wait(lk, ready);
+        else
+            cv_work_.wait_until(lk, deadline, ready);
+        parked_ = false;
+    }
+
     // hand the results back: per shard, mark its requests done under the shard's mutex, then wake that shard
     // (a request lives on its caller's stack and is gone the moment that caller sees done: sort the batch by shard
     // first, then touch every request exactly once, under its shard's mutex)
@@ -192,7 +243,7 @@ class Coalescer {
             if (by_shard[s].empty()) continue;
             {
                 std::lock_guard<std::mutex> lk(shards_[s].mu);
-                for (Request *r : by_shard[s]) r->done = true;
+                for (Request *r : by_shard[s]) r->done.store(true, std::memory_order_release); // (r is gone from here on)
             }
             shards_[s].cv.notify_all();
         }
@@ -207,7 +258,7 @@ class Coalescer {
                 all.push_back(r);
             }
         queues_.clear();
-        pending_ = 0;
+        pending_.store(0, std::memory_order_release);
         release(all);
     }
 
@@ -226,6 +277,8 @@ class Coalescer {
             // small batches are latency bound: one workgroup of four waves per pair (sw_dp_coop.hip) finishes a
             // 256 x 150 pair in a quarter of the time of one wave walking its 16 stripes (tests/cpp/coalesce_bench)
             mgl_sw_ctx_set_cooperative(ctx_, 4);
+            // ... and where a pair's matrix of scores fits LDS, one wave does everything in one launch (sw_small.hip)
+            mgl_sw_ctx_set_small_kernel(ctx_, 2);
         }
         // lay the batch out in the context's pinned staging buffer (see mgl_sw_align_batch_staged)
         int stride = 16, max_tl = 1, max_ql = 1;
@@ -238,6 +291,9 @@ class Coalescer {
             max_ql = std::max(max_ql, r->ql);
         }
         stride = std::min((stride + 3) & ~3, 1 << 16); // a slot larger than any caller's buffer is pointless
+        // ... and so is one larger than any CIGAR of these pairs: an element of length n takes at most 2 n characters and the
+        // lengths add up to at most tl + ql (the slot is zero-filled over the link)
+        stride = std::min(stride, (2 * (max_tl + max_ql) + 4 + 3) & ~3);
         const size_t offs = (size_t)(n + 1) * 8, t_pad = (t_bytes + 7) & ~(size_t)7, q_pad = (q_bytes + 7) & ~(size_t)7;
         const size_t in_bytes = 2 * offs + t_pad + q_pad;
         const size_t out_bytes = (size_t)n * (12 + sizeof(mgl_sw_score)) + (size_t)n * stride;
@@ -300,10 +356,12 @@ class Coalescer {
     std::map<Key, std::deque<Request *>> queues_;
     std::map<Key, std::chrono::steady_clock::time_point> oldest_;
     std::map<Key, int> expect_; // size of the previous batch of this key
-    int pending_ = 0;
+    std::atomic<int> pending_{0};
+    bool parked_ = false; // the dispatcher sleeps on cv_work_ (guarded by mu_): only then a submission has to notify
+    const int spin_us_ = [] { const char *e = getenv("MGL_SW_COALESCE_SPIN_US"); return e ? atoi(e) : 200; }();
     int max_batch_ = 0, max_wait_us_ = 0;
     std::atomic<bool> enabled_{false};
-    bool stop_ = false;
+    std::atomic<bool> stop_{false};
     std::thread worker_;
     mgl_sw_ctx *ctx_ = nullptr;
     int64_t n_batches_ = 0, n_pairs_ = 0;

@@ -95,6 +95,7 @@ struct mgl_sw_ctx {
     int cooperative = 0;  // 0 = choose per batch, 1 = never, 2..16 = always, that many waves per pair (tests)
     int strip_kernel = 0; // long reads, one strip per lane-half (sw_dp16_strip.hip): 0 = by size, 1 = never, 2 = whenever eligible (tests)
     int lane_kernel = 0;  // two-pairs-per-lane packed kernel: 0 = large uniform batches, 1 = never, 2 = whenever eligible (tests)
+    int small_kernel = 0; // small batches, one wave per pair in one launch (sw_small.hip): 0 = by size on an unforced context, 1 = never, 2 = whenever the bounds allow
     int lane_checkpoint = 0; // ... in its checkpointed form (sw_dp16_lane_ck.hip, no stored traceback): 0 = by default, 1 = never, 2 = always
     int last_rows = 16;
     hipStream_t aux = nullptr;                       // traceback stream
@@ -271,6 +272,78 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         mgl_sw_normalize_params(&match, &mismatch, &gopen, &gext);
     }
 
+    // small batches are latency bound (the coalesced one-pair-per-call traffic of alignNative): one wave per pair keeps the pair's H
+    // matrix in LDS, walks the path off it and writes the text, all in ONE launch that touches no workspace (sw_small.hip)
+    {
+        bool wide = false;
+        const bool unforced = ctx->precision == 0 && ctx->stripe_rows == 0 && ctx->cooperative == 0 && ctx->carry_memory == 0 && ctx->lane_kernel != 2 &&
+                              ctx->strip_kernel != 2 && ctx->lane_checkpoint != 1;
+        if (!hooks && !d_matrix && !score_only_hint && !binary_cigar && ctx->small_kernel != 1 &&
+            (ctx->small_kernel == 2 || (unforced && n <= MGL_SW_SMALL_BATCH_PAIRS)) &&
+            ((int64_t)match - mismatch + gopen + 2 * (int64_t)gext) * ((int64_t)max_tl + max_ql) < (1ll << 30) &&
+            small_supported(max_tl, max_ql, cigar_stride, match, mismatch, gopen, gext, &wide)) {
+            if (explain) {
+                mgl_sw_plan &pl = *explain;
+                pl = mgl_sw_plan{};
+                pl.fill_kernel = MGL_SW_KERNEL_SMALL;
+                pl.precision_bits = 32;
+                pl.rows = ((max_tl + 63) / 64 + 1) & ~1;
+                pl.waves_per_block = 1;
+                pl.waves_per_pair = 1;
+                pl.traceback = 1;
+                pl.fused_walk = 1;
+                pl.fill_streams = 1;
+                pl.workspace_halves = 1;
+                pl.chunk_pairs = n;
+                pl.chunks = 1;
+                return MGL_SW_OK;
+            }
+            HIP_TRY(ctx, hipSetDevice(ctx->device));
+            if (ctx->profiling == 3) {
+                ctx->timing.cells += cells_hint;
+            } else {
+                ctx->timing = mgl_sw_timing{};
+                ctx->timing.cells = cells_hint;
+                ctx->pool_used = 0;
+            }
+            TbArgs ta{};
+            ta.t = tset;
+            ta.q = qset;
+            ta.first = 0;
+            ta.count = n;
+            ta.strategy = strategy;
+            ta.match = match;
+            ta.mismatch = mismatch;
+            ta.gopen = gopen;
+            ta.gext = gext;
+            ta.offset = d_offset;
+            ta.score = d_score;
+            ta.cigar = d_cigar;
+            ta.cigar_stride = cigar_stride;
+            ta.cigar_len = d_cigar_len;
+            ta.status = d_status;
+            hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
+            if (ctx->profiling) {
+                while ((int)ctx->pool.size() < ctx->pool_used + 4) {
+                    hipEvent_t e = nullptr;
+                    HIP_TRY(ctx, hipEventCreate(&e));
+                    ctx->pool.push_back(e);
+                }
+                for (int i = 0; i < 4; ++i) pe[i] = ctx->pool[(size_t)ctx->pool_used + i];
+                ctx->pool_used += 4;
+                ctx->diag_blocks = 0;
+            }
+            if (pe[0]) HIP_TRY(ctx, hipEventRecord(pe[0], stream));
+            HIP_TRY(ctx, launch_small(ta, max_tl, max_ql, wide, stream));
+            for (int i = 1; i < 4; ++i)
+                if (pe[i]) HIP_TRY(ctx, hipEventRecord(pe[i], stream));
+            ctx->last_chunk_count = 0; // (nothing of the matrix leaves the chip: no slot to expand)
+            ctx->timing.dp_launches++;
+            ctx->timing.packed16 = 0;
+            ctx->timing.fill_kernel = MGL_SW_KERNEL_SMALL;
+            return MGL_SW_OK;
+        }
+    }
     // packed-int16 kernel: one geometry per batch (or per block of eight pairs) and a score range that fits 16 bits;
     // four waves per block while their LDS carve fits, else two or one
     const int lds_extra = d_matrix ? MATRIX_DIM * MATRIX_DIM * 2 : 0;
@@ -1008,6 +1081,14 @@ int mgl_sw_ctx_set_cooperative(mgl_sw_ctx *ctx, int mode)
     return MGL_SW_OK;
 }
 
+int mgl_sw_ctx_set_small_kernel(mgl_sw_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->small_kernel = mode;
+    return MGL_SW_OK;
+}
+
 int mgl_sw_ctx_set_lane_checkpoint(mgl_sw_ctx *ctx, int mode)
 {
     if (!ctx || mode < 0 || mode > 2) return MGL_SW_ERR_BAD_ARG;
@@ -1377,7 +1458,7 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
         const size_t offs = (size_t)(n + 1) * 8, t_pad = (t_bytes + 7) & ~(size_t)7, q_pad = (q_bytes + 7) & ~(size_t)7;
         const size_t in_bytes = 2 * offs + t_pad + q_pad;
         const size_t out_bytes = (size_t)n * (12 + sizeof(mgl_sw_score)) + (size_t)n * (size_t)cigar_stride;
-        if (n <= (1 << 20) && (cigar_stride & 3) == 0 && in_bytes + out_bytes <= (1u << 20)) {
+        if (n <= (1 << 20) && in_bytes + out_bytes <= (1u << 20)) {
             void *in = nullptr, *out = nullptr;
             int rc = stage_buffers_nolock(ctx, in_bytes, out_bytes, &in, &out);
             if (rc != MGL_SW_OK) return rc;

@@ -206,6 +206,10 @@ hipError_t launch_dp16_strip(const DpArgs &a, int waves, int rows, hipStream_t s
 hipError_t launch_dp_coop16(const DpArgs &a, int waves_per_block, hipStream_t stream); // a.sps_cap = coop16_sps_for(max_ql)
 hipError_t launch_traceback(const TbArgs &a, hipStream_t stream);
 hipError_t launch_strip_ck_walk(const TbArgs &a, int max_tl, int max_ql, hipStream_t stream); // layout 6: one wave per pair, blocks recomputed (sw_strip_walk.hip)
+// small batches: one wave per pair, H kept in LDS, fill + walk + text in ONE launch (sw_small.hip); a.match .. a.gext, a.cigar etc. as for the walks
+bool small_supported(int max_tl, int max_ql, int cigar_stride, int match, int mismatch, int gopen, int gext, bool *wide); // *wide: the kept scores need 32 bits
+int small_lds_bytes(int max_tl, int max_ql, int cigar_stride, bool wide);
+hipError_t launch_small(const TbArgs &a, int max_tl, int max_ql, bool wide, hipStream_t stream);
 
 // Device-side sort of a chunk by geometry (sw_kernels.hip): a counting sort over the (tl, ql) grid [1, max_tl] x [1, max_ql].
 // Slots [0, total[0]) hold the full blocks of eight pairs of one geometry, cell after cell; the left-over pairs (fewer than

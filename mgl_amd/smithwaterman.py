@@ -232,6 +232,11 @@ class MicrosoftSmithWaterman:
         1 = never (needed before expand_slot), 2 = on."""
         _check(_lib.lib().mgl_sw_ctx_set_lane_checkpoint(self._ensure(), int(mode)))
 
+    def set_small_kernel(self, mode):
+        """Small batches (up to 2 048 pairs whose score matrix fits LDS): one wave per pair, fill + walk in one launch.
+        0 = default (on, unless another kernel choice is forced), 1 = never, 2 = whenever the bounds allow."""
+        _check(_lib.lib().mgl_sw_ctx_set_small_kernel(self._ensure(), int(mode)))
+
     def set_profiling(self, on=True):
         _check(_lib.lib().mgl_sw_ctx_set_profiling(self._ensure(), int(on)))
 

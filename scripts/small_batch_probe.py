@@ -1,30 +1,33 @@
-"""Latency anatomy of a small batch (the coalescing front-end's unit of work): kernel times from HIP events vs wall time."""
+"""Small batches: the one-wave-per-pair kernel that fills, walks and writes the text in one launch (sw_small_kernel) against the
+kernels a batch of that size takes otherwise, device-resident batches, wall time per call including the synchronisation.
+`uniform` = the caller promises one geometry (the packed kernel is then available to the general path).
+Usage: python scripts/small_batch_probe.py [tl] [ql]"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
-import numpy as np
-from mgl_amd import synth
-from mgl_amd.smithwaterman import MicrosoftSmithWaterman, GATK_PARAMETERS, SWOverhangStrategy
+import torch
+from mgl_amd import device_batch
+from mgl_amd.smithwaterman import MicrosoftSmithWaterman
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-g, ws, reads = synth.window_batch(7, n, genome_len=1 << 20)
-ts = [g[w:w + 256].tobytes() for w in ws]
-qs = [r.tobytes() for r in reads]
-for coop, rows in ((1, 16), (1, 64), (4, 0), (2, 0)):
-    a = MicrosoftSmithWaterman(0)
-    a.set_cooperative(coop)
-    a.set_precision(32)
-    if rows:
-        a.set_stripe_rows(rows)
-    for prof in (0, 1):
-        a.set_profiling(prof)
-        for _ in range(20):
-            a.align_batch(ts, qs, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP)
-        t0 = time.perf_counter()
-        reps = 200
-        for _ in range(reps):
-            a.align_batch(ts, qs, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP)
-        dt = (time.perf_counter() - t0) / reps
-        tm = a.timing()
-        print(f"n={n} cooperative={coop} rows={rows} profiling={prof}: {dt*1e6:.1f} us per call (python incl.), fill {tm.dp_ms*1e3:.1f} us, traceback {tm.tb_ms*1e3:.1f} us", flush=True)
-    a.close()
+tl = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+ql = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+dev = torch.device("cuda", 0)
+for n in (1, 16, 64, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768):
+    b = device_batch.window_batch(42, n, dev, window=tl, read_len=ql)
+    line = f"{n:6d} pairs:"
+    for uniform in (True, False):
+        b.uniform = uniform
+        for mode, name in ((2, "small"), (1, "other")):
+            a = MicrosoftSmithWaterman(0)
+            a.set_small_kernel(mode)
+            b.run(a); torch.cuda.synchronize()
+            reps = 20 if n <= 4096 else 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                b.run(a)
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            line += f"  {'uni' if uniform else 'mix'} {name} k{a.timing().fill_kernel} {dt*1e6:8.1f} us {n*tl*ql/dt/1e9:6.0f} GCUPS"
+            a.close()
+    print(line, flush=True)
+    del b

@@ -128,6 +128,22 @@ hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &w, hipStream_t)
 }
 hipError_t launch_traceback(const TbArgs &a, hipStream_t) { walk(a, false); return hipSuccess; }
 hipError_t launch_strip_ck_walk(const TbArgs &a, int, int, hipStream_t) { walk(a, false); return hipSuccess; }
+bool small_supported(int max_tl, int max_ql, int, int, int, int, int, bool *wide)
+{
+    if (wide) *wide = false;
+    return max_tl <= 512 && (int64_t)max_tl * max_ql <= 60000;
+}
+int small_lds_bytes(int, int, int, bool) { return 0; }
+hipError_t launch_small(const TbArgs &a, int, int, bool, hipStream_t)
+{
+    g_match = a.match;
+    g_mismatch = a.mismatch;
+    g_gopen = a.gopen;
+    g_gext = a.gext;
+    ++fake_fill_launches;
+    walk(a, false);
+    return hipSuccess;
+}
 hipError_t launch_regroup(const RegroupArgs &a, hipStream_t)
 {
     // the device's counting sort, sequentially (fake device memory is host memory)

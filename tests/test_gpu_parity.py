@@ -44,10 +44,69 @@ def run_groups(aligner, rows):
     return n
 
 
+@pytest.mark.parametrize("small", [0, 1], ids=["default", "no_small_kernel"])
 @pytest.mark.parametrize("suite", ["known", "tiny", "random", "ties", "shapes", "config1", "window", "bam"])
-def test_golden_suite(aligner, suite):
+def test_golden_suite(aligner, suite, small):
+    """default: batches of up to 2 048 pairs whose score matrix fits LDS take sw_small_kernel; with it switched off the same
+    batches take the general kernels, as larger ones do"""
     rows = golden_io.load(suite)
-    assert run_groups(aligner, rows) == len(rows)
+    aligner.set_small_kernel(small)
+    try:
+        assert run_groups(aligner, rows) == len(rows)
+    finally:
+        aligner.set_small_kernel(0)
+
+
+def _gapped_pairs(rng, n, tl, ql, ragged=False):
+    """pairs with one long gap each (either way), substitutions, and every fifth pair unrelated"""
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    ts, qs = [], []
+    for k in range(n):
+        tlk = int(rng.integers(max(1, tl // 2), tl + 1)) if ragged and k % 3 else tl
+        qlk = int(rng.integers(max(1, ql // 2), ql + 1)) if ragged and k % 3 else ql
+        t = alpha[rng.integers(0, 4, tlk)]
+        if k % 5 == 4:
+            q = alpha[rng.integers(0, 4, qlk)]
+        else:
+            src = np.resize(t[int(rng.integers(0, max(1, tlk // 3))):], qlk + 200).copy()
+            gap = int(rng.integers(1, 70))
+            at = int(rng.integers(1, max(2, qlk - 1)))
+            if k % 5 in (0, 1):
+                src = np.concatenate([src[:at], src[at + gap:]])
+            elif k % 5 == 2:
+                src = np.concatenate([src[:at], alpha[rng.integers(0, 4, gap)], src[at:]])
+            sub = rng.random(len(src)) < 0.03
+            src[sub] = alpha[rng.integers(0, 4, int(sub.sum()))]
+            q = src[:qlk]
+        ts.append(t.tobytes())
+        qs.append(q.tobytes())
+    return ts, qs
+
+
+@pytest.mark.parametrize("tl,ql", [(256, 150), (512, 150), (1, 1), (5, 3), (64, 65), (65, 64), (129, 40), (128, 300), (300, 200), (400, 190),
+                                   (37, 500), (2, 700), (511, 1)])
+def test_small_kernel(tl, ql):
+    """sw_small_kernel (one wave per pair, H kept in LDS, the walk reads every move off the scores): uniform and ragged batches, gaps
+    up to 70 cells either way, unrelated pairs, every strategy; parameter sets whose scores fit 16 bits and ones that need the
+    32-bit form of the kept matrix; ties between gap lengths (1, -1, 1, 1 and 5, -4, 10, 1 make many)."""
+    rng = np.random.default_rng(tl * 11 + ql)
+    a = sw.MicrosoftSmithWaterman(0)
+    took = 0
+    try:
+        for ragged in (False, True):
+            ts, qs = _gapped_pairs(rng, 120, tl, ql, ragged)
+            for params in [(200, -150, 260, 11), (1, -1, 1, 1), (5, -4, 10, 1), (10, -30, 40, 1), (1000, -800, 1500, 50), (3, -3, 0, 0)]:
+                for strategy in ol.STRATEGIES:
+                    res = a.align_batch(ts, qs, params, strategy)
+                    took += a.timing().fill_kernel == 8
+                    off, sc, cg = ol.oracle_align_batch(ts, qs, params, strategy, nthreads=4)
+                    assert (res.offsets == off).all(), (params, strategy, ragged)
+                    assert (res.scores == sc).all(), (params, strategy, ragged)
+                    assert res.cigars == cg, (params, strategy, ragged)
+        # (256 x 150 with scores beyond 16 bits is the largest matrix that fits LDS in 32-bit form; larger ones take the general kernels)
+        assert took >= (40 if tl * ql <= 256 * 150 else 32), took
+    finally:
+        a.close()
 
 
 def test_bam_pairs_device_formats(aligner):
