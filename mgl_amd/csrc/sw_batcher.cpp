@@ -25,6 +25,8 @@
 #include <tuple>
 #include <vector>
 
+#include <sched.h>
+
 // sw_capi.cpp (library-internal, not part of include/mgl_sw.h: hidden visibility, not exported from the .so)
 #define MGL_SW_INTERNAL __attribute__((visibility("hidden")))
 extern "C" MGL_SW_INTERNAL int mgl_sw_stage_buffers(mgl_sw_ctx *ctx, size_t in_bytes, size_t out_bytes, void **in, void **out);
@@ -34,25 +36,8 @@ extern "C" MGL_SW_INTERNAL int mgl_sw_align_batch_staged(mgl_sw_ctx *ctx, int n,
 
 namespace {
 
-// Callers sleep on one of a few condition variables chosen by thread, each with its own mutex: a finished batch then
-// wakes its callers shard by shard instead of stampeding every parked thread through the submission lock.
-constexpr int kShards = 32;
-struct Shard {
-    std::mutex mu;
-    std::condition_variable cv;
-};
-
-struct Request {
-    const char *t, *q;
-    int tl, ql;
-    char *cigar;
-    int cigar_cap;
-    int *cigar_len, *offset;
-    mgl_sw_score *ez;
-    int rc = MGL_SW_OK;
-    std::atomic<bool> done{false}; // set under the shard's mutex (parked callers), read without it by callers that still spin
-    int shard = 0;
-};
+using Clock = std::chrono::steady_clock;
+using Key = std::tuple<int, int, int, int, int>; // normalised match, mismatch, open, extend, strategy
 
 inline void cpu_relax()
 {
@@ -63,7 +48,93 @@ inline void cpu_relax()
 #endif
 }
 
-using Key = std::tuple<int, int, int, int, int>; // normalised match, mismatch, open, extend, strategy
+// Where a caller sleeps when its answer takes longer than it is willing to spin: one slot per calling thread (by order of first
+// call; threads beyond kSlots share), so that a finished batch wakes exactly its parked callers and nobody else.
+constexpr int kSlots = 256;
+struct WaitSlot {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<bool> parked{false};
+};
+
+struct Request {
+    const char *t, *q;
+    int tl, ql;
+    char *cigar;
+    int cigar_cap;
+    int *cigar_len, *offset;
+    mgl_sw_score *ez;
+    Key key;
+    Clock::time_point arrived;
+    int rc = MGL_SW_OK;
+    std::atomic<Request *> next{nullptr};
+    std::atomic<bool> done{false}; // the dispatcher's last touch: the request lives on its caller's stack and is gone once this reads true
+    WaitSlot *slot = nullptr;
+};
+
+// The submission queue: many callers push, the dispatcher pops (D. Vyukov's intrusive MPSC queue).  A push is ONE exchange on a
+// shared cache line; the sixteen callers of a batch all come back within microseconds of each other, and behind a lock (even a
+// spinning one: lock word, queue, counters) their arrivals spread over ~1.5 us each on a two-socket host.
+class SubmissionQueue {
+  public:
+    SubmissionQueue() : tail_(&stub_), head_(&stub_) {}
+    // (every access is sequentially consistent: the dispatcher raises its `parked` flag and then looks here, a caller links its
+    // request in here and then looks at the flag -- one of the two must see the other)
+    void push(Request *r)
+    {
+        r->next.store(nullptr);
+        Request *prev = tail_.exchange(r);
+        prev->next.store(r); // (until this store `prev` cannot be popped: it is never freed under us)
+    }
+    // consumer only; nullptr: empty, or a push is half done (its caller is about to finish it)
+    Request *pop()
+    {
+        Request *head = head_, *next = head->next.load();
+        if (head == &stub_) {
+            if (!next) return nullptr;
+            head_ = head = next;
+            next = head->next.load();
+        }
+        if (next) {
+            head_ = next;
+            return head;
+        }
+        if (head != tail_.load()) return nullptr;
+        push(&stub_);
+        next = head->next.load();
+        if (!next) return nullptr;
+        head_ = next;
+        return head;
+    }
+
+  private:
+    alignas(64) std::atomic<Request *> tail_; // the callers' cache line
+    alignas(64) Request *head_;               // the dispatcher's
+    Request stub_;
+};
+
+// CPUs this process may use: its affinity mask, cut by the cgroup's CPU quota (containers)
+int usable_cpus()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    long long quota = -1, period = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "max 100000" or "1600000 100000"
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { // v1
+        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(h, "%lld", &period) != 1) period = 0;
+            fclose(h);
+        }
+    }
+    if (quota > 0 && period > 0) n = (int)std::min<long long>(n, std::max<long long>(1, quota / period));
+    return std::max(1, n);
+}
 
 class Coalescer {
   public:
@@ -75,91 +146,138 @@ class Coalescer {
 
     void configure(int max_batch, int max_wait_us)
     {
-        std::lock_guard<std::mutex> lk(mu_);
-        max_batch_ = max_batch;
-        max_wait_us_ = max_wait_us;
+        std::lock_guard<std::mutex> lk(cfg_mu_);
+        max_batch_.store(max_batch);
+        max_wait_us_.store(max_wait_us);
         enabled_.store(max_batch > 0 && max_wait_us >= 0);
         if (enabled_ && !worker_.joinable()) worker_ = std::thread([this] { run(); });
-        cv_work_.notify_all();
+        wake_dispatcher();
     }
     bool enabled() const { return enabled_.load(std::memory_order_relaxed); }
 
-    int submit(Request &r, const Key &key)
+    int submit(Request &r)
     {
-        static std::atomic<unsigned> next_shard{0};
-        thread_local const int my_shard = (int)(next_shard.fetch_add(1) % kShards);
-        r.shard = my_shard;
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            auto &qd = queues_[key];
-            if (qd.empty()) oldest_[key] = std::chrono::steady_clock::now();
-            qd.push_back(&r);
-            const auto ex = expect_.find(key);
-            const int expect = ex == expect_.end() ? 1 : ex->second;
-            // wake the dispatcher when it is idle, when a batch is full, or when the callers it expects are all back
-            const int pend = pending_.fetch_add(1, std::memory_order_release) + 1;
-            if (parked_ && (pend == 1 || (int)qd.size() >= max_batch_ || (int)qd.size() == expect)) cv_work_.notify_one();
-        }
-        // the answer is usually back within a device round trip: spin that long before parking
-        if (spin_us_ > 0) {
-            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us_);
+        static std::atomic<int> threads_seen{0};
+        thread_local const int my_index = threads_seen.fetch_add(1);
+        r.slot = &slots_[my_index % kSlots];
+        r.arrived = Clock::now();
+        queue_.push(&r);
+        if (parked_.load(std::memory_order_seq_cst)) wake_dispatcher(); // (it re-checks the queue after raising the flag: no arrival is lost)
+        // the answer is usually back within a device round trip: spin that long before parking -- the first threads of the process
+        // only, as many as leave the dispatcher and the HIP runtime a CPU each (spinning threads beyond the CPUs this process may use
+        // only take the time slices of the ones that have work)
+        if (spin_us_ > 0 && my_index < spin_slots_) {
+            const auto until = Clock::now() + std::chrono::microseconds(spin_us_);
             do {
                 for (int k = 0; k < 64; ++k) {
                     if (r.done.load(std::memory_order_acquire)) return r.rc;
                     cpu_relax();
                 }
-            } while (std::chrono::steady_clock::now() < until);
+            } while (Clock::now() < until);
         }
-        Shard &sh = shards_[my_shard];
-        std::unique_lock<std::mutex> lk(sh.mu);
-        sh.cv.wait(lk, [&] { return r.done.load(std::memory_order_acquire); });
+        WaitSlot &sl = *r.slot;
+        std::unique_lock<std::mutex> lk(sl.mu);
+        sl.parked.store(true, std::memory_order_seq_cst); // before the first look at `done` below: the dispatcher sets `done`, then looks here
+        sl.cv.wait(lk, [&] { return r.done.load(std::memory_order_seq_cst); });
+        sl.parked.store(false, std::memory_order_relaxed);
         return r.rc;
     }
 
     void stats(int64_t *batches, int64_t *pairs)
     {
-        std::lock_guard<std::mutex> lk(mu_);
-        *batches = n_batches_;
-        *pairs = n_pairs_;
+        *batches = n_batches_.load();
+        *pairs = n_pairs_.load();
     }
 
     ~Coalescer()
     {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            stop_ = true;
-            cv_work_.notify_all();
-        }
+        stop_.store(true);
+        wake_dispatcher();
         if (worker_.joinable()) worker_.join();
-        if (timing_ && n_batches_) {
-            const double nb = (double)n_batches_;
-            fprintf(stderr, "[mgl_sw] coalescer: %lld batches, mean %.1f pairs; per batch: %.1f us collecting, %.1f us processing "
+        const int64_t nbi = n_batches_.load();
+        if (timing_ && nbi) {
+            const double nb = (double)nbi;
+            fprintf(stderr, "[mgl_sw] coalescer: %lld batches, mean %.1f pairs; per batch: %.1f us collecting (first caller %.1f us after the "
+                            "previous release, last %.1f us after the first), %.1f us processing "
                             "(%.1f layout, %.1f device round trip, %.1f hand-out), %.1f us waking the callers\n",
-                    (long long)n_batches_, (double)n_pairs_ / nb, t_wait_ / nb, t_process_ / nb, t_layout_ / nb, t_device_ / nb,
+                    (long long)nbi, (double)n_pairs_.load() / nb, t_wait_ / nb, t_idle_ / nb, t_spread_ / nb, t_process_ / nb, t_layout_ / nb, t_device_ / nb,
                     t_scatter_ / nb, t_release_ / nb);
         }
         if (ctx_) mgl_sw_ctx_destroy(ctx_);
     }
 
   private:
+    void wake_dispatcher()
+    {
+        {
+            std::lock_guard<std::mutex> lk(park_mu_);
+            poke_ = true;
+        }
+        park_cv_.notify_one();
+    }
+
+    // move what the callers have pushed into the per-key queues (dispatcher only); returns the number moved
+    int drain()
+    {
+        int n = 0;
+        while (Request *r = queue_.pop()) {
+            auto &qd = queues_[r->key];
+            if (qd.empty()) oldest_[r->key] = r->arrived;
+            qd.push_back(r);
+            newest_ = r->arrived;
+            ++pending_;
+            ++n;
+        }
+        return n;
+    }
+
+    // until a caller arrives, `deadline` passes or somebody pokes (configure, destructor): spin while the traffic is hot, then park
+    void wait_for_arrivals(Clock::time_point deadline)
+    {
+        if (spin_us_ > 0) {
+            const auto until = std::min(deadline, Clock::now() + std::chrono::microseconds(spin_us_));
+            do {
+                for (int k = 0; k < 64; ++k) {
+                    if (drain() > 0 || stop_.load(std::memory_order_relaxed)) return;
+                    cpu_relax();
+                }
+            } while (Clock::now() < until);
+            if (Clock::now() >= deadline) return;
+        }
+        parked_.store(true, std::memory_order_seq_cst);
+        if (drain() == 0) { // (a push that completes from here on sees the flag and pokes)
+            std::unique_lock<std::mutex> lk(park_mu_);
+            if (deadline == Clock::time_point::max())
+                park_cv_.wait(lk, [&] { return poke_; });
+            else
+                park_cv_.wait_until(lk, deadline, [&] { return poke_; });
+            poke_ = false;
+        }
+        parked_.store(false, std::memory_order_seq_cst);
+    }
+
     void run()
     {
-        std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
-            wait_for_work(lk, [&] { return stop_ || pending_.load(std::memory_order_acquire) > 0; }, std::chrono::steady_clock::time_point::max());
-            if (stop_) {
+            drain();
+            if (stop_.load()) {
                 fail_all(MGL_SW_ERR_DEVICE);
                 return;
             }
-            // pick the queue that is full, or whose oldest request has waited long enough; otherwise sleep until
-            // the earliest deadline (new arrivals wake us up too)
-            const auto now = std::chrono::steady_clock::now();
-            const int max_batch = std::max(1, max_batch_); // coalescing switched off with requests still queued: drain them
+            if (pending_ == 0) {
+                wait_for_arrivals(Clock::time_point::max());
+                continue;
+            }
+            // pick the queue that is full, or whose oldest request has waited long enough; otherwise wait until the
+            // earliest deadline (new arrivals end the wait too)
+            const auto now = Clock::now();
+            const int max_batch = std::max(1, max_batch_.load()); // coalescing switched off with requests still queued: drain them
+            const int max_wait_us = std::max(0, max_wait_us_.load());
             const Key *ready = nullptr;
             auto earliest = now + std::chrono::hours(1);
             for (auto &kv : queues_) {
                 if (kv.second.empty()) continue;
-                const auto deadline = oldest_[kv.first] + std::chrono::microseconds(max_wait_us_);
+                const auto deadline = oldest_[kv.first] + std::chrono::microseconds(max_wait_us);
                 // as many callers as the previous batch held are back: nobody else is expected, go at once (a lone caller
                 // never waits; sixteen steady callers are dispatched when the sixteenth arrives, not at the deadline)
                 const auto ex = expect_.find(kv.first);
@@ -171,9 +289,7 @@ class Coalescer {
                 earliest = std::min(earliest, deadline);
             }
             if (!ready) {
-                // more callers are expected (or the window is still open): until one arrives or the earliest deadline passes
-                const int seen = pending_.load(std::memory_order_acquire);
-                wait_for_work(lk, [&] { return stop_ || pending_.load(std::memory_order_acquire) != seen; }, earliest);
+                wait_for_arrivals(earliest);
                 continue;
             }
             const Key key = *ready;
@@ -183,74 +299,49 @@ class Coalescer {
                 batch.push_back(qd.front());
                 qd.pop_front();
             }
+            const auto t_first = oldest_[key], t_last = newest_;
             if (!qd.empty()) oldest_[key] = now; // the rest starts a new waiting period
-            pending_.fetch_sub((int)batch.size(), std::memory_order_release);
+            pending_ -= (int)batch.size();
             expect_[key] = (int)batch.size();
-            const auto t_first = oldest_[key];
-            lk.unlock();
-            const auto t_a = std::chrono::steady_clock::now();
+            const auto t_a = Clock::now();
             process(key, batch);
-            const auto t_b = std::chrono::steady_clock::now();
+            const auto t_b = Clock::now();
+            const int64_t n_in_batch = (int64_t)batch.size();
             release(batch);
-            const auto t_c = std::chrono::steady_clock::now();
-            lk.lock();
-            ++n_batches_;
-            n_pairs_ += (int64_t)batch.size();
+            const auto t_c = Clock::now();
+            n_pairs_.fetch_add(n_in_batch);
+            const int64_t nb = n_batches_.fetch_add(1) + 1;
             if (timing_) { // diagnostic (MGL_SW_DEBUG_COALESCE_TIMING): where a batch's round trip goes, microseconds
-                auto us = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::micro>(d).count(); };
+                auto us = [](Clock::duration d) { return std::chrono::duration<double, std::micro>(d).count(); };
                 t_wait_ += us(now - t_first);
+                if (nb > 1) {
+                    t_idle_ += us(t_first - released_); // from the previous batch's release to this one's first caller
+                    t_spread_ += us(t_last - t_first);  // ... to its last
+                }
+                released_ = t_c;
                 t_process_ += us(t_b - t_a);
                 t_release_ += us(t_c - t_b);
             }
         }
     }
 
-    // The dispatcher's wait: spin (lock released) while the traffic is hot, then park on the condition variable.  `ready` is
-    // evaluated with the lock released while spinning: it may only read atomics.
-    template <typename Pred>
-    void wait_for_work(std::unique_lock<std::mutex> &lk, Pred ready, std::chrono::steady_clock::time_point deadline)
-    {
-        if (ready()) return;
-        if (spin_us_ > 0) {
-            const auto until = std::min(deadline, std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us_));
-            lk.unlock();
-            bool ok = false;
-            do {
-                for (int k = 0; k < 64 && !ok; ++k) {
-                    ok = ready();
-                    if (!ok) cpu_relax();
-                }
-            } while (!ok && std::chrono::steady_clock::now() < until);
-            lk.lock();
-            if (ok || ready() || std::chrono::steady_clock::now() >= deadline) return;
-        }
-        parked_ = true;
-        if (deadline == std::chrono::steady_clock::time_point::max())
-            cv_work_.wait(lk, ready);
-        else
-            cv_work_.wait_until(lk, deadline, ready);
-        parked_ = false;
-    }
-
-    // hand the results back: per shard, mark its requests done under the shard's mutex, then wake that shard
-    // (a request lives on its caller's stack and is gone the moment that caller sees done: sort the batch by shard
-    // first, then touch every request exactly once, under its shard's mutex)
+    // hand the results back.  `done` is the last touch of a request (it lives on its caller's stack); whether that caller sleeps is
+    // read from its thread's slot AFTER that (the caller raises `parked` before it looks at `done`: one of the two sees the other)
     void release(const std::vector<Request *> &batch)
     {
-        std::vector<Request *> by_shard[kShards];
-        for (Request *r : batch) by_shard[r->shard].push_back(r);
-        for (int s = 0; s < kShards; ++s) {
-            if (by_shard[s].empty()) continue;
-            {
-                std::lock_guard<std::mutex> lk(shards_[s].mu);
-                for (Request *r : by_shard[s]) r->done.store(true, std::memory_order_release); // (r is gone from here on)
+        for (Request *r : batch) {
+            WaitSlot *sl = r->slot;
+            r->done.store(true, std::memory_order_seq_cst);
+            if (sl->parked.load(std::memory_order_seq_cst)) {
+                { std::lock_guard<std::mutex> lk(sl->mu); } // (the sleeper is inside wait(), or has not looked at `done` yet)
+                sl->cv.notify_all();
             }
-            shards_[s].cv.notify_all();
         }
     }
 
     void fail_all(int rc)
     {
+        drain();
         std::vector<Request *> all;
         for (auto &kv : queues_)
             for (Request *r : kv.second) {
@@ -258,7 +349,7 @@ class Coalescer {
                 all.push_back(r);
             }
         queues_.clear();
-        pending_.store(0, std::memory_order_release);
+        pending_ = 0;
         release(all);
     }
 
@@ -350,23 +441,30 @@ class Coalescer {
         }
     }
 
-    std::mutex mu_;
-    std::condition_variable cv_work_;
-    Shard shards_[kShards];
+    SubmissionQueue queue_;
+    WaitSlot slots_[kSlots];
+    // the dispatcher's own (no lock: nobody else touches them)
     std::map<Key, std::deque<Request *>> queues_;
-    std::map<Key, std::chrono::steady_clock::time_point> oldest_;
+    std::map<Key, Clock::time_point> oldest_;
     std::map<Key, int> expect_; // size of the previous batch of this key
-    std::atomic<int> pending_{0};
-    bool parked_ = false; // the dispatcher sleeps on cv_work_ (guarded by mu_): only then a submission has to notify
-    const int spin_us_ = [] { const char *e = getenv("MGL_SW_COALESCE_SPIN_US"); return e ? atoi(e) : 200; }();
-    int max_batch_ = 0, max_wait_us_ = 0;
-    std::atomic<bool> enabled_{false};
+    int pending_ = 0;
+    Clock::time_point newest_{}, released_{};
+    // parking the dispatcher
+    std::mutex park_mu_;
+    std::condition_variable park_cv_;
+    bool poke_ = false; // guarded by park_mu_
+    std::atomic<bool> parked_{false};
     std::atomic<bool> stop_{false};
+    std::mutex cfg_mu_;
+    std::atomic<int> max_batch_{0}, max_wait_us_{0};
+    std::atomic<bool> enabled_{false};
+    const int spin_slots_ = [] { const char *e = getenv("MGL_SW_COALESCE_SPIN_SLOTS"); return e ? atoi(e) : std::max(0, usable_cpus() - 2); }();
+    const int spin_us_ = [] { const char *e = getenv("MGL_SW_COALESCE_SPIN_US"); return e ? atoi(e) : 200; }();
     std::thread worker_;
     mgl_sw_ctx *ctx_ = nullptr;
-    int64_t n_batches_ = 0, n_pairs_ = 0;
+    std::atomic<int64_t> n_batches_{0}, n_pairs_{0};
     const bool timing_ = getenv("MGL_SW_DEBUG_COALESCE_TIMING") != nullptr;
-    double t_wait_ = 0, t_process_ = 0, t_release_ = 0, t_layout_ = 0, t_device_ = 0, t_scatter_ = 0;
+    double t_wait_ = 0, t_process_ = 0, t_release_ = 0, t_layout_ = 0, t_device_ = 0, t_scatter_ = 0, t_idle_ = 0, t_spread_ = 0;
 };
 
 struct EnvInit {
@@ -404,7 +502,8 @@ extern "C" MGL_SW_INTERNAL int mgl_sw_coalesced_align(const char *t, int tl, con
     r.cigar_len = cigar_len;
     r.offset = offset;
     r.ez = ez;
-    return Coalescer::instance().submit(r, Key(match, mismatch, gopen, gext, strategy));
+    r.key = Key(match, mismatch, gopen, gext, strategy);
+    return Coalescer::instance().submit(r);
 }
 
 extern "C" {

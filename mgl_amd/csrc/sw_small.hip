@@ -68,74 +68,81 @@ struct SmallGeom {
     int CS;     // dwords per kept column: the column's rows (two per dword in the 16-bit form), made odd against the lanes' stride
     int R, nl;  // rows per lane, lanes that own rows
     int match, mismatch, gopen, gext;
+    int base;   // what is kept of cell (i, j) is V = H + (i + j) * gext - base
     bool indel, wide;
 };
 
-// the kept scores: H[i][j] for 1 <= i <= tl, 1 <= j <= ql, column-major (a lane's rows of one column are neighbours: one address
-// register and immediate offsets in the fill; the lanes of a step, one column apart, are R/2 - CS or R - CS dwords apart, an odd
-// number: 64 different banks); the borders are formulas
+// the kept scores: V[i][j] = H[i][j] + (i + j) * gext - base for 1 <= i <= tl, 1 <= j <= ql, column-major (a lane's rows of one
+// column are neighbours: one address register and immediate offsets in the fill; the lanes of a step, one column apart, are
+// R/2 - CS or R - CS dwords apart, an odd number: 64 different banks); at() gives H back; the borders are formulas
 struct KeptScores {
     const uint32_t *hm;
-    int CS, gopen, gext;
+    int CS, gopen, gext, base;
     bool indel, wide;
     __device__ __forceinline__ int at(int i, int j) const
     {
         if (i == 0 || j == 0) return edge_score(i + j, gopen, gext, indel);
-        if (wide) return (int)hm[(j - 1) * CS + (i - 1)];
+        const int un = base - (i + j) * gext;
+        if (wide) return (int)hm[(j - 1) * CS + (i - 1)] + un;
         const uint32_t w = hm[(j - 1) * CS + ((i - 1) >> 1)];
-        return (int)(int16_t)(((i - 1) & 1) ? (w >> 16) : (w & 0xffffu));
+        return (int)(int16_t)(((i - 1) & 1) ? (w >> 16) : (w & 0xffffu)) + un;
     }
 };
 
+// The fill.  Values carry the offset (i + j) * gext - base: every decision compares values of one cell, so the decisions are those of
+// sw.cpp:51-96, but extending a gap needs no instruction, both new gaps start from the same H - (o - e), and the constant `base`
+// (it enters through the borders and travels with every maximum) centres the range of the 16-bit form.
 template <int R, bool WIDE>
-__device__ __forceinline__ void small_fill(const SmallGeom &g, uint32_t *hm, const uint8_t *ts, const uint8_t *qs, const int lane, int &best,
-                                           int &best_i)
+__device__ __forceinline__ void small_fill(const SmallGeom &g, uint32_t *hm, const uint8_t *ts, const uint8_t *qs, const int lane)
 {
     const int i0 = R * lane; // the row above this lane's first row
+    const int gext = g.gext, o_e = g.gopen - g.gext, ql = g.ql, CS = g.CS;
     int h[R], f[R], tb[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = i0 + 1 + r;
-        h[r] = edge_score(i, g.gopen, g.gext, g.indel); // H[i][0]
-        f[r] = h[r] - g.gopen;                          // F[i][1] (sw.cpp:47-49)
-        tb[r] = i <= g.tl ? (int)ts[i - 1] : 0x100;     // rows past tl: never equal to a query byte; their scores go nowhere
+        h[r] = edge_score(i, g.gopen, gext, g.indel) + i * gext - g.base; // V[i][0]
+        f[r] = h[r] - o_e;                                                 // F[i][1] (sw.cpp:47-49)
+        tb[r] = i <= g.tl ? (int)ts[i - 1] : 0x100;                        // rows past tl: never equal to a query byte; their scores go nowhere
     }
-    int up_diag = edge_score(i0, g.gopen, g.gext, g.indel); // H[i0][j-1]: column 0 until this lane starts
-    int e_bot = 0;                                          // E leaving this lane's last row, as of the previous step
-    int qb = 0;                                             // this lane's query base: lane 0's of `lane` steps ago
-    best = NEG_INF;
-    best_i = -1;
-    int match = g.match, mismatch = g.mismatch;
-    asm volatile("" : "+v"(match), "+v"(mismatch));
-    const int gopen = g.gopen, gext = g.gext, ql = g.ql, tl = g.tl, CS = g.CS;
+    int up_diag = edge_score(i0, g.gopen, gext, g.indel) + i0 * gext - g.base; // V[i0][j-1]: column 0 until this lane starts
+    int e_bot = 0;                                                             // E leaving this lane's last row, as of the previous step
+    int match2 = g.match + 2 * gext, mismatch2 = g.mismatch + 2 * gext;        // the diagonal moves the offset by 2 e
+    asm volatile("" : "+v"(match2), "+v"(mismatch2));
     const int steps = ql + g.nl - 1;
     const unsigned my_ql = lane < g.nl ? (unsigned)ql : 0u; // lanes without rows never start
     uint32_t *wp = hm + (WIDE ? i0 : (i0 >> 1)) - lane * CS;  // column j - 1 = s - lane: + s * CS
-    int edge_j = g.indel ? -gopen : 0;                       // H[0][j] of lane 0's column j = s + 1
-    const int edge_step = g.indel ? gext : 0;
-    for (int s0 = 0; s0 < steps; s0 += 64) {
-        // the query bases of the next 64 steps, one per lane: lane 0's base of step s0 + u is read out of lane u (no LDS access, and
-        // therefore no wait for the stores of the step before, inside the loop)
-        int q64 = qs[min(s0 + lane, ql - 1)];
-        asm volatile("" : "+v"(q64)); // (the wait for this read belongs here, not at the head of the loop below)
-        const int nu = min(64, steps - s0);
-        for (int u = 0; u < nu; ++u) {
+    // V[0][j] of lane 0's column j = s + 1: j e - base, or with leading / trailing gaps charged -o - (j - 1) e + j e - base
+    int edge_j = (g.indel ? -o_e : gext) - g.base;
+    const int edge_step = g.indel ? 0 : gext;
+    // this lane's query bases of the next four steps: bytes s0 - lane .. + 3 of the query, out of two aligned dwords (before the
+    // lane starts and behind the query's end these are addresses of other LDS data or of none -- read as whatever, never used)
+    const int q_shift = (-lane) & 3;
+    const uint32_t *qd = reinterpret_cast<const uint32_t *>(qs) + ((0 - lane) >> 2);
+    uint32_t q_lo = qd[0], q_hi = qd[1];
+    for (int s0 = 0; s0 < steps; s0 += 4) {
+        const uint32_t qw = __builtin_amdgcn_alignbyte(q_hi, q_lo, q_shift);
+        qd += 1;
+        q_lo = qd[0]; // (used one block later: by then four steps of stores sit behind it in the queue, nothing waits)
+        q_hi = qd[1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
             const int j = s0 + u - lane + 1;
-            qb = from_lane_below(__builtin_amdgcn_readlane(q64, u), qb);
-            const int up_h = from_lane_below(edge_j, h[R - 1]);  // H[i0][j]
-            int up_e = from_lane_below(edge_j - gopen, e_bot);   // E[i0 + 1][j] (row 0: sw.cpp:31-35)
-            edge_j -= edge_step;
+            const int qb = (int)((qw >> (8 * u)) & 0xffu);
+            const int up_h = from_lane_below(edge_j, h[R - 1]);  // V[i0][j]
+            int up_e = from_lane_below(edge_j - o_e, e_bot);     // E[i0 + 1][j] (row 0: sw.cpp:31-35)
+            edge_j += edge_step;
             if ((unsigned)(j - 1) < my_ql) {
                 int dg = up_diag;
                 up_diag = up_h;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const int diag = dg + (tb[r] == qb ? match : mismatch); // sw.cpp:55
-                    const int hn = max(max(diag, f[r]), up_e);              // sw.cpp:60-71
-                    const int open = hn - gopen;
+                    const int diag = dg + (tb[r] == qb ? match2 : mismatch2); // sw.cpp:55
+                    const int hn = max(max(diag, f[r]), up_e);                // sw.cpp:60-71
+                    const int open = hn - o_e;
                     dg = h[r];
-                    f[r] = max(open, f[r] - gext); // F[i][j + 1], sw.cpp:84-93
-                    up_e = max(open, up_e - gext); // E[i + 1][j], sw.cpp:73-82
+                    f[r] = max(open, f[r]); // F[i][j + 1], sw.cpp:84-93
+                    up_e = max(open, up_e); // E[i + 1][j], sw.cpp:73-82
                     h[r] = hn;
                 }
                 e_bot = up_e;
@@ -145,15 +152,6 @@ __device__ __forceinline__ void small_fill(const SmallGeom &g, uint32_t *hm, con
                 } else {
 #pragma unroll
                     for (int r = 0; r < R; r += 2) wp[r >> 1] = ((uint32_t)h[r] & 0xffffu) | ((uint32_t)h[r + 1] << 16);
-                }
-                if (j == ql) { // last column: sw.cpp:100-104 (>=: the later row wins)
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const int i = i0 + 1 + r;
-                        const bool take = i <= tl && h[r] >= best;
-                        best = take ? h[r] : best;
-                        best_i = take ? i : best_i;
-                    }
                 }
             }
             wp += CS;
@@ -250,17 +248,24 @@ int small_lds_bytes(int max_tl, int max_ql, int cigar_stride, bool wide)
 {
     // (small_column_words(tl) <= (tl + 7) / 2 + 1, or tl + 8, for every tl <= max_tl)
     const int64_t kept = (int64_t)(wide ? max_tl + 8 : (max_tl + 7) / 2 + 1) * max_ql * 4;
-    const int64_t b = kept + ((max_tl + 3) & ~3) + ((max_ql + 3) & ~3) + small_text_cap(max_tl, max_ql, cigar_stride);
+    const int64_t b = kept + ((max_tl + 3) & ~3) + ((max_ql + 3) & ~3) + small_text_cap(max_tl, max_ql, cigar_stride) + 8;
     return b > (1 << 30) ? (1 << 30) : (int)b;
 }
-// can the kept scores be 16-bit?  H <= match * min(tl, ql) (gaps and borders cost, mismatches do not pay) and
-// H[i][j] >= E[i][j] >= H[0][j] - o - (i - 1) e >= -2 o - (i + j) e
+// can the kept scores be 16-bit?  What is kept is V = H + (i + j) e - base with
+//   H <= match * min(tl, ql)                          (gaps and borders cost, mismatches do not pay)
+//   H[i][j] >= E[i][j] >= H[0][j] - o - (i - 1) e >= -2 o - (i + j) e
+// so V + base lies in [-2 o - (tl + ql) e, match * min(tl, ql) + (tl + ql) e]; base is the middle of that range
+__host__ __device__ inline int small_base(int tl, int ql, int match, int gopen, int gext)
+{
+    const int hi = match * (tl < ql ? tl : ql) + (tl + ql) * gext, lo = -2 * gopen - (tl + ql) * gext;
+    return (hi + lo) / 2;
+}
 bool small_fits_int16(int max_tl, int max_ql, int match, int mismatch, int gopen, int gext)
 {
     if (match < 0 || mismatch > match || gopen < 0 || gext < 0) return false;
-    const int64_t hi = (int64_t)match * (max_tl < max_ql ? max_tl : max_ql);
-    const int64_t lo = 2 * (int64_t)gopen + ((int64_t)max_tl + max_ql) * gext;
-    return hi <= 32767 && lo <= 32768;
+    const int64_t hi = (int64_t)match * (max_tl < max_ql ? max_tl : max_ql) + ((int64_t)max_tl + max_ql) * gext;
+    const int64_t lo = -2 * (int64_t)gopen - ((int64_t)max_tl + max_ql) * gext;
+    return hi - lo <= 65000; // (the span; every pair of the batch centres its own)
 }
 
 __global__ __launch_bounds__(64) void sw_small_kernel(const TbArgs a, const int max_tl, const int max_ql, const int wide)
@@ -283,6 +288,7 @@ __global__ __launch_bounds__(64) void sw_small_kernel(const TbArgs a, const int 
     g.indel = (a.strategy & (OS_INDEL | OS_LEAD_ID)) != 0;
     g.wide = wide != 0;
     g.CS = small_column_words(tl, g.wide);
+    g.base = g.wide ? 0 : small_base(tl, ql, g.match, g.gopen, g.gext);
 
     // carve (by this pair's own lengths: never more than the batch's bounds give)
     uint32_t *hm = lds;
@@ -318,13 +324,12 @@ __global__ __launch_bounds__(64) void sw_small_kernel(const TbArgs a, const int 
     __builtin_amdgcn_wave_barrier();
     SMALL_PHASE(0); // staging
 
-    int best, best_i;
 #define MGL_SMALL_FILL(RR)                                                                  \
     case RR:                                                                                \
         if (g.wide)                                                                         \
-            small_fill<RR, true>(g, hm, ts, qs, lane, best, best_i);                        \
+            small_fill<RR, true>(g, hm, ts, qs, lane);                                      \
         else                                                                                \
-            small_fill<RR, false>(g, hm, ts, qs, lane, best, best_i);                       \
+            small_fill<RR, false>(g, hm, ts, qs, lane);                                     \
         break;
     switch (g.R) {
         MGL_SMALL_FILL(2)
@@ -338,9 +343,15 @@ __global__ __launch_bounds__(64) void sw_small_kernel(const TbArgs a, const int 
     __builtin_amdgcn_wave_barrier();
     SMALL_PHASE(1); // fill
 
-    KeptScores hs{hm, g.CS, g.gopen, g.gext, g.indel, g.wide};
+    KeptScores hs{hm, g.CS, g.gopen, g.gext, g.base, g.indel, g.wide};
     // last column: best score, the later row on ties (sw.cpp:100-104)
-    int mqe = best, mqe_t = best_i;
+    int mqe = NEG_INF, mqe_t = -1;
+    for (int i = lane + 1; i <= tl; i += 64) {
+        const int sc = hs.at(i, ql);
+        const bool take = sc >= mqe;
+        mqe = take ? sc : mqe;
+        mqe_t = take ? i : mqe_t;
+    }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
         const int ob = __shfl_xor(mqe, m), oi = __shfl_xor(mqe_t, m);
