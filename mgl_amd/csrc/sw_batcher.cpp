@@ -25,7 +25,11 @@
 #include <tuple>
 #include <vector>
 
+#include <climits>
+#include <linux/futex.h>
 #include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 // sw_capi.cpp (library-internal, not part of include/mgl_sw.h: hidden visibility, not exported from the .so)
 #define MGL_SW_INTERNAL __attribute__((visibility("hidden")))
@@ -48,14 +52,35 @@ inline void cpu_relax()
 #endif
 }
 
-// Where a caller sleeps when its answer takes longer than it is willing to spin: one slot per calling thread (by order of first
-// call; threads beyond kSlots share), so that a finished batch wakes exactly its parked callers and nobody else.
-constexpr int kSlots = 256;
-struct WaitSlot {
-    std::mutex mu;
-    std::condition_variable cv;
-    std::atomic<bool> parked{false};
+// Where callers sleep when their answer takes longer than they are willing to spin: ONE futex word for all of them.  A finished batch
+// sets its requests' `done` flags, bumps the word and wakes every sleeper with a single system call (48 sleeping callers of a batch
+// of 64: one FUTEX_WAKE instead of 48 condition-variable notifications, no mutex for the woken threads to queue up on); a sleeper
+// whose request was not in that batch goes back to sleep on the new value.
+class WakeWord {
+  public:
+    // sleep until `done` reads true
+    void wait(const std::atomic<bool> &done)
+    {
+        sleepers_.fetch_add(1, std::memory_order_seq_cst);
+        for (;;) {
+            const uint32_t seen = word_.load(std::memory_order_seq_cst);
+            if (done.load(std::memory_order_seq_cst)) break;
+            syscall(SYS_futex, reinterpret_cast<uint32_t *>(&word_), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0); // returns at once if the word moved on
+        }
+        sleepers_.fetch_sub(1, std::memory_order_seq_cst);
+    }
+    // after the `done` flags of a batch have been set
+    void wake_all()
+    {
+        word_.fetch_add(1, std::memory_order_seq_cst);
+        if (sleepers_.load(std::memory_order_seq_cst) > 0) syscall(SYS_futex, reinterpret_cast<uint32_t *>(&word_), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+    }
+
+  private:
+    alignas(64) std::atomic<uint32_t> word_{0};
+    alignas(64) std::atomic<int> sleepers_{0};
 };
+static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "the futex word is the atomic itself");
 
 struct Request {
     const char *t, *q;
@@ -69,7 +94,6 @@ struct Request {
     int rc = MGL_SW_OK;
     std::atomic<Request *> next{nullptr};
     std::atomic<bool> done{false}; // the dispatcher's last touch: the request lives on its caller's stack and is gone once this reads true
-    WaitSlot *slot = nullptr;
 };
 
 // The submission queue: many callers push, the dispatcher pops (D. Vyukov's intrusive MPSC queue).  A push is ONE exchange on a
@@ -159,7 +183,6 @@ class Coalescer {
     {
         static std::atomic<int> threads_seen{0};
         thread_local const int my_index = threads_seen.fetch_add(1);
-        r.slot = &slots_[my_index % kSlots];
         r.arrived = Clock::now();
         queue_.push(&r);
         if (parked_.load(std::memory_order_seq_cst)) wake_dispatcher(); // (it re-checks the queue after raising the flag: no arrival is lost)
@@ -175,11 +198,7 @@ class Coalescer {
                 }
             } while (Clock::now() < until);
         }
-        WaitSlot &sl = *r.slot;
-        std::unique_lock<std::mutex> lk(sl.mu);
-        sl.parked.store(true, std::memory_order_seq_cst); // before the first look at `done` below: the dispatcher sets `done`, then looks here
-        sl.cv.wait(lk, [&] { return r.done.load(std::memory_order_seq_cst); });
-        sl.parked.store(false, std::memory_order_relaxed);
+        wake_.wait(r.done);
         return r.rc;
     }
 
@@ -325,18 +344,12 @@ class Coalescer {
         }
     }
 
-    // hand the results back.  `done` is the last touch of a request (it lives on its caller's stack); whether that caller sleeps is
-    // read from its thread's slot AFTER that (the caller raises `parked` before it looks at `done`: one of the two sees the other)
+    // hand the results back.  `done` is the last touch of a request (it lives on its caller's stack): spinning callers leave at once,
+    // the sleeping ones on the one wake-up call behind the loop
     void release(const std::vector<Request *> &batch)
     {
-        for (Request *r : batch) {
-            WaitSlot *sl = r->slot;
-            r->done.store(true, std::memory_order_seq_cst);
-            if (sl->parked.load(std::memory_order_seq_cst)) {
-                { std::lock_guard<std::mutex> lk(sl->mu); } // (the sleeper is inside wait(), or has not looked at `done` yet)
-                sl->cv.notify_all();
-            }
-        }
+        for (Request *r : batch) r->done.store(true, std::memory_order_seq_cst);
+        wake_.wake_all();
     }
 
     void fail_all(int rc)
@@ -442,7 +455,7 @@ class Coalescer {
     }
 
     SubmissionQueue queue_;
-    WaitSlot slots_[kSlots];
+    WakeWord wake_;
     // the dispatcher's own (no lock: nobody else touches them)
     std::map<Key, std::deque<Request *>> queues_;
     std::map<Key, Clock::time_point> oldest_;
