@@ -33,6 +33,7 @@ def run(cases, seed, log=print):
     """returns (mismatching batches, batches that took the packed kernel)"""
     rng = np.random.default_rng(seed)
     a = MicrosoftSmithWaterman(0)
+    a.set_small_kernel(1)   # eight pairs per batch: without this a default context runs one wave per pair (sw_small.hip), not the packed kernel under test
     bad = packed = 0
     for case in range(cases):
         gext = int(rng.integers(0, 40))

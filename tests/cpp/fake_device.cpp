@@ -49,6 +49,15 @@ static void walk(const TbArgs &a, bool scores_only)
             for (int k = 0; k < ql; ++k) qb[(size_t)k] = (uint8_t)"ACGT"[a.q.at(a.q.off[p], k)];
             q = qb.data();
         }
+        // the checker is compiled without the thread sanitizer in the TSan build (it is the stand-in for the kernels, not the code under
+        // test, and instrumented it took six minutes): read the inputs here, in instrumented code, so that a race between the
+        // library's host side and the "device" reading a sequence is still seen
+        {
+            unsigned sum = 0;
+            for (int k = 0; k < tl; ++k) sum += t[k];
+            for (int k = 0; k < ql; ++k) sum += q[k];
+            asm volatile("" : : "r"(sum)); // (keeps the loops)
+        }
         const int64_t o = a.dest ? a.dest[p] : p;
         std::vector<char> text((size_t)(tl + ql + 4) * 12);
         int len = 0, off = 0;

@@ -20,6 +20,9 @@ pytestmark = pytest.mark.gpu
 def aligner():
     a = sw.MicrosoftSmithWaterman(0)
     assert a.load(), "libmgl_sw_hip.so could not create a GPU context"
+    # the tests of this module were written for the batched kernels and assert which one ran; sw_small_kernel (small batches on a
+    # default context) has its own tests below and is switched on by test_golden_suite[default]
+    a.set_small_kernel(1)
     yield a
     a.close()
 
@@ -54,7 +57,7 @@ def test_golden_suite(aligner, suite, small):
     try:
         assert run_groups(aligner, rows) == len(rows)
     finally:
-        aligner.set_small_kernel(0)
+        aligner.set_small_kernel(1)
 
 
 def _gapped_pairs(rng, n, tl, ql, ragged=False):
@@ -783,6 +786,7 @@ def test_host_entry_sorts_mixed_batches_by_geometry_itself():
     rows = [g for g in golden_io.load("bam") if g.suite != "bamwin" and g.strategy == ol.SOFTCLIP]
     assert len(rows) > 1024 and len({(len(g.t), len(g.q)) for g in rows}) > 10
     b = sw.MicrosoftSmithWaterman(0)
+    b.set_small_kernel(1)                                           # (3 304 / 2 = 1 652 pairs: a default context would run one wave per pair)
     res = b.align_batch([g.t for g in rows], [g.q for g in rows], rows[0].params, ol.SOFTCLIP)
     assert b.timing().packed16 == 1
     for k, g in enumerate(rows):

@@ -8,7 +8,7 @@ from mgl_amd import _lib
 GATK = (200, -150, 260, 11)
 UNIFORM, SCORE_ONLY = _lib.FLAG_UNIFORM_GEOMETRY, _lib.FLAG_SCORE_ONLY
 BENCH_WS = 208 << 30   # bench.py's workspace
-DP32, DP16, DP32_64, COOP, LANE16, COOP16, STRIP16, LANE16_CK = range(8)
+DP32, DP16, DP32_64, COOP, LANE16, COOP16, STRIP16, LANE16_CK, SMALL = range(9)
 
 
 def plan(**kw):
@@ -17,7 +17,18 @@ def plan(**kw):
 
 def test_symbol_and_struct():
     p = plan(n=8, max_tl=10, max_ql=10)
-    assert p.fill_kernel == DP32 and p.chunks == 1 and p.chunk_pairs == 8
+    assert p.fill_kernel == SMALL and p.chunks == 1 and p.chunk_pairs == 8
+
+
+def test_small_batches_take_one_wave_per_pair_in_one_launch():
+    """sw_small.hip: up to MGL_SW_SMALL_BATCH_PAIRS pairs, targets of at most 512 rows, the matrix of scores within a workgroup's LDS."""
+    p = plan(n=16, max_tl=256, max_ql=150, parameters=GATK)    # a coalesced batch of alignNative calls
+    assert p.fill_kernel == SMALL and p.waves_per_pair == 1 and p.fused_walk == 1 and p.traceback == 1 and p.workspace_bytes == 0
+    assert plan(n=2048, max_tl=256, max_ql=150, parameters=GATK).fill_kernel == SMALL
+    assert plan(n=2049, max_tl=256, max_ql=150, parameters=GATK).fill_kernel != SMALL
+    assert plan(n=16, max_tl=513, max_ql=100, parameters=GATK).fill_kernel != SMALL, "more than 512 rows"
+    assert plan(n=16, max_tl=512, max_ql=400, parameters=GATK).fill_kernel != SMALL, "the scores do not fit LDS"
+    assert plan(n=16, max_tl=256, max_ql=150, parameters=GATK, flags=SCORE_ONLY).fill_kernel != SMALL
 
 
 def test_configs1_headline_is_one_launch_of_the_checkpointed_lane_kernel():
@@ -93,6 +104,8 @@ def test_mixed_geometries_are_sorted_by_the_library():
     tight = plan(n=4_000_000, max_tl=256, max_ql=150, parameters=GATK)                           # 4 GiB: chunks below the lane kernel's crossover
     assert tight.sorted_by_library == 1 and tight.fill_kernel == DP16
     few = plan(n=500, max_tl=256, max_ql=150, parameters=GATK)
+    assert few.sorted_by_library == 0 and few.fill_kernel == SMALL, "one wave per pair needs no common geometry"
+    few = plan(n=500, max_tl=600, max_ql=150, parameters=GATK)
     assert few.sorted_by_library == 0 and few.fill_kernel == DP32
 
 
