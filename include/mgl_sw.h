@@ -202,6 +202,21 @@ int mgl_sw_align(const char *t, int tl, const char *q, int ql, int match, int mi
 int mgl_sw_set_coalescing(int max_batch, int max_wait_us);
 /* device batches flushed / pairs served by the coalescer so far */
 int mgl_sw_coalescing_stats(int64_t *batches, int64_t *pairs);
+/*
+ * ... and in front of the coalescer, for pairs of the size GATK sends (targets up to 512 bases, queries up to 2 048, the matrix of
+ * scores within a workgroup's LDS: 256 x 150, 400 x 190, ...): every calling thread leases a MAILBOX in pinned host memory and one
+ * resident wave that serves it (sw_service.hip).  A call writes its pair into the mailbox and spins until the wave hands the
+ * result back: no kernel launch, no stream synchronisation and no other thread on the request path (this replaces the
+ * launch-per-call of ..._MicrosoftSmithWaterman.cpp:44-71's callers).  A wave ends by itself when its mailbox has been quiet for
+ * idle_us (default 1 000; environment MGL_SW_SERVICE_IDLE_US) or after MGL_SW_SERVICE_LIFE_MS (default 50) -- a resident
+ * kernel holds up device-wide synchronisation for that long at most -- and the next call launches it again.  `slots` mailboxes at
+ * most (default 64, environment MGL_SW_SERVICE_SLOTS, at most 128); threads beyond that, and pairs that do not fit, take the
+ * coalescer.  slots = 0 switches the service off; idle_us = 0 keeps the current value.  Follows mgl_sw_set_coalescing: with
+ * coalescing off every call is a direct call.
+ */
+int mgl_sw_set_service(int slots, int idle_us);
+/* calls served through mailboxes / launches of the service kernel so far */
+int mgl_sw_service_stats(int64_t *calls, int64_t *launches);
 
 /*
  * Batch, host buffers.  Pair k is targets[t_off[k] .. t_off[k+1]) against

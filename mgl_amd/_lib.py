@@ -21,7 +21,7 @@ OK, ERR_BAD_ARG, ERR_CIGAR_OVERFLOW, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED = ra
 
 # every symbol include/mgl_sw.h declares (tests check that the library exports them all)
 SYMBOLS = (
-    "mgl_sw_version", "mgl_sw_strerror", "mgl_sw_device_count", "mgl_sw_max_query_len", "mgl_sw_max_lds_query_len", "mgl_sw_ctx_set_carry_memory", "mgl_sw_ctx_set_stripe_rows", "mgl_sw_ctx_set_cooperative", "mgl_sw_ctx_set_strip_kernel", "mgl_sw_ctx_set_lane_kernel", "mgl_sw_ctx_set_lane_checkpoint", "mgl_sw_ctx_set_small_kernel", "mgl_sw_ctx_create",
+    "mgl_sw_version", "mgl_sw_strerror", "mgl_sw_device_count", "mgl_sw_max_query_len", "mgl_sw_max_lds_query_len", "mgl_sw_ctx_set_carry_memory", "mgl_sw_ctx_set_stripe_rows", "mgl_sw_ctx_set_cooperative", "mgl_sw_ctx_set_strip_kernel", "mgl_sw_ctx_set_lane_kernel", "mgl_sw_ctx_set_lane_checkpoint", "mgl_sw_ctx_set_small_kernel", "mgl_sw_set_service", "mgl_sw_service_stats", "mgl_sw_ctx_create",
     "mgl_sw_ctx_destroy", "mgl_sw_last_error", "mgl_sw_ctx_set_workspace", "mgl_sw_ctx_set_profiling", "mgl_sw_ctx_set_precision",
     "mgl_sw_ctx_get_timing", "mgl_sw_normalize_params", "mgl_sw_align", "mgl_sw_align_batch", "mgl_sw_align_batch_status",
     "mgl_sw_align_batch_device", "mgl_sw_align_batch_device_2bit", "mgl_sw_align_batch_device_matrix", "mgl_sw_align_batch_device_indexed", "mgl_sw_backtrack_matrix", "mgl_sw_ctx_expand_slot", "mgl_sw_ctx_slot_layout",
@@ -133,6 +133,8 @@ def lib():
     L.mgl_sw_band_fill.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp] + [C.c_int] * 5 + [C.POINTER(Score)]
     L.mgl_sw_group_by_geometry.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     L.mgl_sw_coalescing_stats.argtypes = [i64p, i64p]
+    L.mgl_sw_set_service.argtypes = [C.c_int, C.c_int]
+    L.mgl_sw_service_stats.argtypes = [i64p, i64p]
     L.mgl_sw_ctx_expand_slot.argtypes = [vp, C.c_int64, C.c_int, C.c_int, i32p]
     L.mgl_sw_ctx_slot_layout.argtypes = [vp, C.c_int64, C.POINTER(C.c_int)]
     L.mgl_sw_align_batch_status.argtypes = [vp, C.c_int64, vp, vp, vp, vp] + [C.c_int] * 5 + [vp, vp, vp, C.c_int, vp, vp]

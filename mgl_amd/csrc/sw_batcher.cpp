@@ -10,6 +10,7 @@
 // A device round trip is a few dozen microseconds (one launch of sw_small_kernel), the same order as waking a parked thread: callers
 // and dispatcher therefore spin for a short while (MGL_SW_COALESCE_SPIN_US, default 200) before they park on their condition variables.
 #include "../../include/mgl_sw.h"
+#include "sw_host.h"
 
 #include <algorithm>
 #include <atomic>
@@ -42,15 +43,6 @@ namespace {
 
 using Clock = std::chrono::steady_clock;
 using Key = std::tuple<int, int, int, int, int>; // normalised match, mismatch, open, extend, strategy
-
-inline void cpu_relax()
-{
-#if defined(__x86_64__) || defined(__i386__)
-    __builtin_ia32_pause();
-#else
-    std::this_thread::yield();
-#endif
-}
 
 // Where callers sleep when their answer takes longer than they are willing to spin: ONE futex word for all of them.  A finished batch
 // sets its requests' `done` flags, bumps the word and wakes every sleeper with a single system call (48 sleeping callers of a batch
@@ -136,29 +128,6 @@ class SubmissionQueue {
     alignas(64) Request *head_;               // the dispatcher's
     Request stub_;
 };
-
-// CPUs this process may use: its affinity mask, cut by the cgroup's CPU quota (containers)
-int usable_cpus()
-{
-    int n = (int)std::thread::hardware_concurrency();
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
-    long long quota = -1, period = 0;
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "max 100000" or "1600000 100000"
-        char q[32] = {0};
-        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
-        fclose(f);
-    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { // v1
-        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
-        fclose(g);
-        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
-            if (fscanf(h, "%lld", &period) != 1) period = 0;
-            fclose(h);
-        }
-    }
-    if (quota > 0 && period > 0) n = (int)std::min<long long>(n, std::max<long long>(1, quota / period));
-    return std::max(1, n);
-}
 
 class Coalescer {
   public:

@@ -1926,6 +1926,10 @@ MGL_SW_INTERNAL int mgl_sw_align_batch_staged(mgl_sw_ctx *ctx, int n, size_t in_
 MGL_SW_INTERNAL bool mgl_sw_coalescing_enabled();
 MGL_SW_INTERNAL int mgl_sw_coalesced_align(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen, int gext,
                            int strategy, char *cigar, int cigar_cap, int *cigar_len, int *offset, mgl_sw_score *ez);
+// sw_service.cpp: the calling thread's mailbox and resident wave; MGL_SW_SERVICE_DECLINED = not this call (geometry, no mailbox left, switched off)
+constexpr int MGL_SW_SERVICE_DECLINED = 1 << 20;
+MGL_SW_INTERNAL int mgl_sw_service_align(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen, int gext, int strategy,
+                                         char *cigar, int cigar_cap, int *cigar_len, int *offset, mgl_sw_score *ez);
 
 static mgl_sw_ctx *thread_ctx(int *rc)
 {
@@ -1972,9 +1976,12 @@ int mgl_sw_align(const char *t, int tl, const char *q, int ql, int match, int mi
 {
     if (!t || !q || tl < 1 || ql < 1 || !cigar || cigar_cap < 1 || !cigar_len || !offset || !strategy_ok(strategy))
         return MGL_SW_ERR_BAD_ARG;
-    if (mgl_sw_coalescing_enabled())
+    if (mgl_sw_coalescing_enabled()) {
+        const int rc = mgl_sw_service_align(t, tl, q, ql, match, mismatch, gopen, gext, strategy, cigar, cigar_cap, cigar_len, offset, ez);
+        if (rc != MGL_SW_SERVICE_DECLINED) return rc;
         return mgl_sw_coalesced_align(t, tl, q, ql, match, mismatch, gopen, gext, strategy, cigar, cigar_cap, cigar_len,
                                       offset, ez);
+    }
     return align_direct(t, tl, q, ql, match, mismatch, gopen, gext, strategy, cigar, cigar_cap, cigar_len, offset, ez);
 }
 

@@ -1,0 +1,122 @@
+// sw_service.hip -- one pair per call (the reference's alignNative pattern, ..._MicrosoftSmithWaterman.cpp:44-71) with no launch and no
+// synchronisation on the request path.
+//
+// Every calling thread owns a MAILBOX in pinned host memory (ServiceMailbox, sw_device.h); ONE resident grid serves them, workgroup k
+// (one wave) mailbox k:
+//
+//   host:  writes the pair and its parameters into the mailbox, then a new sequence number (seq_a, seq_b), and spins on done_seq;
+//   wave:  lanes 0-15 read the mailbox's first line over the link until it shows a number not yet served, then the wave runs the
+//          pair -- small_pair() of sw_small_pair.h: sequences straight out of the mailbox, H kept in LDS, the walk off the scores,
+//          text and results straight into the mailbox -- and stores the number into done_seq behind a system-scope release.
+//
+// One grid, not one kernel per mailbox: HIP multiplexes its streams onto four hardware queues, and a resident kernel holds up every
+// kernel behind it in its queue -- sixteen one-wave kernels on sixteen streams ran four at a time (measured: 85 k pairs/s from 16
+// threads, each wave living out its whole lifetime while twelve others waited).  The grid has a stream of its own, created at the
+// highest priority so that it shares its queue with none of the library's other streams.
+//
+// The grid must never outlive its use (a resident kernel blocks every device-wide synchronisation of the process): every turn of
+// a wave's poll loop compares the 100 MHz clock with the time of the last request ANY wave has served (ServiceControl, device
+// memory) and with the time of the launch, and the loop ends when the service has been quiet for `idle_ticks`, when the grid is
+// `life_ticks` old, or when the host asks (quit_gen) -- conditions every wave reaches whatever the host does.  The first wave that
+// decides to end latches stop_gen, and the others end at their next look: the grid is never half alive for longer than a poll, so
+// the caller that finds its wave gone (state EXITED) can launch the next grid on the same stream at once (sw_service.cpp); the new
+// waves pick up whatever numbers are waiting.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <atomic>
+
+#undef MGL_SMALL_PHASES
+#include "sw_small_pair.h"
+
+namespace mgl_sw_dev {
+
+namespace {
+
+__device__ __forceinline__ uint32_t load_system(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void store_system(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+} // namespace
+
+__global__ __launch_bounds__(64) void sw_service_kernel(ServiceMailbox *const mailboxes, ServiceControl *const ctl, const uint32_t gen, const uint32_t idle_ticks,
+                                                        const uint32_t life_ticks)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x;
+    ServiceMailbox *const mb = mailboxes + blockIdx.x;
+    uint32_t served = __builtin_amdgcn_readfirstlane(load_system(&mb->done_seq)); // (the last number a wave of an earlier grid handed back)
+    if (lane == 0) store_system(&mb->state, gen << 4 | SERVICE_RUNNING);
+    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+    uint64_t t_own = t_start; // this mailbox's last request
+    const uint32_t *line0 = reinterpret_cast<const uint32_t *>(mb);
+    for (;;) {
+        // the first line of the mailbox, one dword per lane: one read over the link per turn
+        const uint32_t w = lane < 16 ? load_system(line0 + lane) : 0u;
+        const uint32_t seq_a = __builtin_amdgcn_readlane(w, 0), seq_b = __builtin_amdgcn_readlane(w, 15);
+        const uint32_t quit_gen = __builtin_amdgcn_readlane(w, 10);
+        if (seq_a == seq_b && seq_a != served) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // the sequences were written before the number
+            TbArgs a{};
+            a.t = SeqSet{mb->t, nullptr, nullptr, 0, 0};
+            a.q = SeqSet{mb->q, nullptr, nullptr, 0, 0};
+            const int tl = (int)__builtin_amdgcn_readlane(w, 1), ql = (int)__builtin_amdgcn_readlane(w, 2);
+            a.match = (int)__builtin_amdgcn_readlane(w, 3);
+            a.mismatch = (int)__builtin_amdgcn_readlane(w, 4);
+            a.gopen = (int)__builtin_amdgcn_readlane(w, 5);
+            a.gext = (int)__builtin_amdgcn_readlane(w, 6);
+            a.strategy = (int)__builtin_amdgcn_readlane(w, 7);
+            a.cigar_stride = (int)__builtin_amdgcn_readlane(w, 8);
+            const int wide = (int)__builtin_amdgcn_readlane(w, 9);
+            a.offset = &mb->offset;
+            a.score = &mb->score;
+            a.cigar = mb->cigar;
+            a.cigar_len = &mb->cigar_len;
+            a.status = &mb->status;
+            // (the host has checked the bounds: tl <= SERVICE_MAX_TL, ql <= SERVICE_MAX_QL, the stride within the mailbox's text, LDS)
+            small_pair<false>(a, 0, tl, ql, 0, 0, lds, wide, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); // results before the number
+            if (lane == 0) store_system(&mb->done_seq, seq_a);
+            served = seq_a;
+            __builtin_amdgcn_wave_barrier();
+            t_own = __builtin_amdgcn_s_memrealtime();
+            if (lane == 0) __hip_atomic_fetch_max(&ctl->last_activity, (unsigned long long)t_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        const uint32_t stop_gen = __hip_atomic_load(&ctl->stop_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t heard = __hip_atomic_load(&ctl->last_activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t now = __builtin_amdgcn_s_memrealtime();
+        // (generations are compared as signed differences: the counter may wrap)
+        if ((int32_t)(quit_gen - gen) >= 0 || (int32_t)(stop_gen - gen) >= 0) break;
+        const uint64_t last = heard > t_start ? heard : t_start;
+        if ((int64_t)(now - last) > (int64_t)idle_ticks || now - t_start > life_ticks) {
+            if (lane == 0) __hip_atomic_fetch_max(&ctl->stop_gen, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (generations grow: max is "latest")
+            break;
+        }
+        // a mailbox in use is looked at as fast as the link answers; one that has been quiet for 200 us every few microseconds
+        if (now - t_own > 20000)
+            __builtin_amdgcn_s_sleep(127);
+        else
+            __builtin_amdgcn_s_sleep(4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (lane == 0) store_system(&mb->state, gen << 4 | SERVICE_EXITED);
+}
+
+hipError_t launch_service(ServiceMailbox *mailboxes, ServiceControl *ctl, int slots, uint32_t gen, uint32_t idle_ticks, uint32_t life_ticks, hipStream_t stream)
+{
+    if (slots < 1) return hipErrorInvalidValue;
+    static std::atomic<unsigned long long> raised{0}; // the attribute is per device: raised once on each
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = dev < 64 ? 1ull << dev : 0ull;
+    if (!(raised.load(std::memory_order_acquire) & bit)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_service_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SERVICE_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        raised.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(sw_service_kernel, dim3((unsigned)slots), dim3(64), (size_t)SERVICE_LDS_BYTES, stream, mailboxes, ctl, gen, idle_ticks, life_ticks);
+    return hipGetLastError();
+}
+
+} // namespace mgl_sw_dev

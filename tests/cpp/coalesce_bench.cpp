@@ -1,6 +1,7 @@
 // coalesce_bench.cpp -- the calling pattern of GATK's alignNative (one pair per call, many threads;
 // /root/reference/src/main/java/com/microsoft/mgl/smithwaterman/MicrosoftSmithWaterman.java:66-86) from native
-// threads, against mgl_sw_align with and without the coalescing front-end (mgl_amd/csrc/sw_batcher.cpp).
+// threads, against mgl_sw_align: through the mailbox service (mgl_amd/csrc/sw_service.cpp; MGL_SW_SERVICE_SLOTS=0 switches it off),
+// through the coalescing front-end (sw_batcher.cpp), or as direct calls.
 //   coalesce_bench <threads> <calls per thread> <coalesce wait us | -1 = direct> [tl] [ql]
 // Every thread checks its results against a direct call made once at start-up (same pair set for all threads).
 #include <atomic>
@@ -55,10 +56,12 @@ int main(int argc, char **argv)
         });
     for (auto &th : pool) th.join();
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    int64_t batches = 0, pairs = 0;
+    int64_t batches = 0, pairs = 0, mailbox_calls = 0, launches = 0;
     mgl_sw_coalescing_stats(&batches, &pairs);
+    mgl_sw_service_stats(&mailbox_calls, &launches);
     mgl_sw_set_coalescing(0, 0);
-    printf("%d threads x %d calls, %dx%d, %s: %.0f pairs/s (%.3f s), mean batch %.1f, wrong results %d\n", threads, calls, tl, ql,
-           wait_us >= 0 ? "coalesced" : "direct", (double)threads * calls / dt, dt, batches ? (double)pairs / batches : 1.0, bad.load());
+    printf("%d threads x %d calls, %dx%d, %s: %.0f pairs/s (%.3f s), %lld through mailboxes (%lld launches), %lld coalesced (mean batch %.1f), wrong results %d\n",
+           threads, calls, tl, ql, wait_us >= 0 ? "front-end" : "direct", (double)threads * calls / dt, dt, (long long)mailbox_calls, (long long)launches,
+           (long long)pairs, batches ? (double)pairs / batches : 1.0, bad.load());
     return bad ? 1 : 0;
 }

@@ -6,7 +6,10 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../mgl_amd/csrc/sw_device.h"
@@ -151,6 +154,75 @@ hipError_t launch_small(const TbArgs &a, int, int, bool, hipStream_t)
     g_gext = a.gext;
     ++fake_fill_launches;
     walk(a, false);
+    return hipSuccess;
+}
+bool small_fits_int16(int, int, int, int, int, int) { return true; }
+// the resident wave of sw_service.hip as a detached thread: the same protocol on the same mailbox (what the sanitizers watch is
+// the host side of it), the checker where small_pair() stands
+std::atomic<long long> fake_service_waves{0}, fake_service_pairs{0};
+static std::atomic<unsigned long long> g_service_last{0};
+static std::atomic<uint32_t> g_service_stop{0};
+hipError_t launch_service(ServiceMailbox *mailboxes, ServiceControl *, int slots, uint32_t gen, uint32_t idle_ticks, uint32_t life_ticks, hipStream_t)
+{
+    static std::mutex order;              // "the stream": a grid starts when the one before it has ended
+    struct Joiner {                       // (the last grid's threads end by their own conditions: joined when the process ends)
+        std::vector<std::thread> v;
+        ~Joiner()
+        {
+            for (auto &t : v) t.join();
+        }
+    };
+    static Joiner joiner;
+    std::vector<std::thread> &prev = joiner.v;
+    std::lock_guard<std::mutex> lk(order);
+    for (auto &t : prev) t.join();
+    prev.clear();
+    using Clock = std::chrono::steady_clock;
+    static const auto epoch = Clock::now();
+    for (int k = 0; k < slots; ++k) {
+        ++fake_service_waves;
+        prev.emplace_back([mb = mailboxes + k, gen, idle_ticks, life_ticks] {
+            auto ticks = [] { return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - epoch).count() / 10; };
+            uint32_t served = __atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE);
+            __atomic_store_n(&mb->state, gen << 4 | (uint32_t)SERVICE_RUNNING, __ATOMIC_RELEASE);
+            const unsigned long long t_start = ticks();
+            for (;;) {
+                const uint32_t seq_a = __atomic_load_n(&mb->seq_a, __ATOMIC_ACQUIRE), seq_b = __atomic_load_n(&mb->seq_b, __ATOMIC_ACQUIRE);
+                const uint32_t quit_gen = __atomic_load_n(&mb->quit_gen, __ATOMIC_ACQUIRE);
+                if (seq_a == seq_b && seq_a != served) {
+                    std::vector<char> text((size_t)(mb->tl + mb->ql + 4) * 12);
+                    int len = 0, off = 0;
+                    swo_score ez;
+                    if (swo_align(mb->t, mb->tl, mb->q, mb->ql, mb->match, mb->mismatch, mb->gopen, mb->gext, mb->strategy, text.data(), (int)text.size(), &len, &off,
+                                  &ez, nullptr) != SWO_OK)
+                        abort();
+                    const bool injected = mb->ql >= 8 && memcmp(mb->q, "NNNNNNNN", 8) == 0; // (the same fault injection as walk())
+                    mb->status = injected ? ERR_DEVICE : len > mb->cigar_stride ? ERR_CIGAR_OVERFLOW : 0;
+                    mb->cigar_len = injected ? 0 : len;
+                    mb->offset = mb->status ? 0 : off;
+                    if (!mb->status) memcpy(mb->cigar, text.data(), (size_t)len);
+                    mb->score = Score{ez.mqe, ez.mqe_t, ez.max, ez.max_t, ez.max_q, ez.seg_length};
+                    ++fake_service_pairs;
+                    __atomic_store_n(&mb->done_seq, seq_a, __ATOMIC_RELEASE);
+                    served = seq_a;
+                    unsigned long long now = ticks(), seen = g_service_last.load();
+                    while (seen < now && !g_service_last.compare_exchange_weak(seen, now)) {
+                    }
+                    continue;
+                }
+                const unsigned long long now = ticks(), last = std::max(g_service_last.load(), t_start);
+                if ((int32_t)(quit_gen - gen) >= 0 || (int32_t)(g_service_stop.load() - gen) >= 0) break;
+                if ((long long)(now - last) > (long long)idle_ticks || now - t_start > life_ticks) {
+                    uint32_t seen = g_service_stop.load();
+                    while (seen < gen && !g_service_stop.compare_exchange_weak(seen, gen)) {
+                    }
+                    break;
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(20)); // (32 "waves" and 48 callers share a handful of CPUs here)
+            }
+            __atomic_store_n(&mb->state, gen << 4 | (uint32_t)SERVICE_EXITED, __ATOMIC_RELEASE);
+        });
+    }
     return hipSuccess;
 }
 hipError_t launch_regroup(const RegroupArgs &a, hipStream_t)

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <random>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -23,7 +24,7 @@
 #include "../../oracle/sw_oracle.h"
 
 namespace mgl_sw_dev {
-extern std::atomic<long long> fake_fill_launches, fake_walk_pairs, fake_packed_pairs;
+extern std::atomic<long long> fake_fill_launches, fake_walk_pairs, fake_packed_pairs, fake_service_waves, fake_service_pairs;
 }
 
 #define CHECK(x)                                                          \
@@ -289,13 +290,21 @@ int main()
         mgl_sw_multi_destroy(m);
     }
 
-    // ---- 48 threads, one pair per call (the way GATK drives alignNative), through the coalescing front-end
-    {
+    // ---- 48 threads, one pair per call (the way GATK drives alignNative): through the coalescing front-end alone, then with the
+    // mailbox service in front of it -- 32 mailboxes for 48 threads (sixteen threads keep to the coalescer), a grid that gives up after
+    // 3 ms of silence and threads that all pause for 12 ms in the middle, so that calls find their wave gone and launch the grid again
+    for (int with_service = 0; with_service < 2; ++with_service) {
         CHECK(mgl_sw_set_coalescing(64, 200) == 0);
+        CHECK(mgl_sw_set_service(with_service ? 32 : 0, 3000) == 0);
+        const auto t_section = std::chrono::steady_clock::now();
+        int64_t batches0 = 0, pairs0 = 0, calls0 = 0, launches0 = 0;
+        CHECK(mgl_sw_coalescing_stats(&batches0, &pairs0) == 0 && mgl_sw_service_stats(&calls0, &launches0) == 0);
         std::atomic<int> bad{0}, overflow_seen{0}, device_seen{0};
         auto worker = [&](int id) {
             std::mt19937 r((unsigned)id * 7919u + 1u);
             for (int it = 0; it < 120; ++it) {
+                if (with_service && it % 40 == 39) std::this_thread::sleep_for(std::chrono::milliseconds(12));
+                // (poisoned pairs at it = 7, 47, 87; too-small buffers every tenth call of thread 9)
                 const int tl = 40 + (int)(r() % 200), ql = 8 + (int)(r() % 100);
                 std::string t = rnd(r, tl), q = rnd(r, ql);
                 const bool poison = id == 5 && it % 40 == 7; // the fake device fails this pair (see below)
@@ -323,9 +332,18 @@ int main()
         std::vector<std::thread> th;
         for (int id = 0; id < 48; ++id) th.emplace_back(worker, id);
         for (auto &x : th) x.join();
-        int64_t batches = 0, pairs = 0;
-        CHECK(mgl_sw_coalescing_stats(&batches, &pairs) == 0 && pairs == 48 * 120 && batches < pairs);
+        int64_t batches = 0, pairs = 0, calls = 0, launches = 0;
+        CHECK(mgl_sw_coalescing_stats(&batches, &pairs) == 0 && mgl_sw_service_stats(&calls, &launches) == 0);
+        batches -= batches0, pairs -= pairs0, calls -= calls0, launches -= launches0;
+        CHECK(pairs + calls == 48 * 120 && batches < pairs);
+        if (with_service)
+            CHECK(calls >= 32 * 120 && launches >= 2 && // (a thread that ends early hands its mailbox to one that had none; grids grow as threads arrive)
+                  mgl_sw_dev::fake_service_waves.load() >= 32 && calls == mgl_sw_dev::fake_service_pairs.load());
+        else
+            CHECK(calls == 0 && launches == 0);
         CHECK(bad.load() == 0 && overflow_seen.load() > 0 && device_seen.load() == 3);
+        std::fprintf(stderr, "one pair per call, %s: %lld through mailboxes (%lld grids), %lld coalesced in %lld batches, %.1f s\n", with_service ? "32 mailboxes" : "coalescer only",
+                     (long long)calls, (long long)launches, (long long)pairs, (long long)batches, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_section).count());
         CHECK(mgl_sw_set_coalescing(0, 0) == 0);
     }
     std::printf("host-san ok: %lld fill launches, %lld pairs walked\n", mgl_sw_dev::fake_fill_launches.load(), mgl_sw_dev::fake_walk_pairs.load());

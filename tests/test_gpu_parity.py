@@ -1261,9 +1261,11 @@ def test_odd_parameter_sets():
     assert mod.run(lambda *x: None) == 0
 
 
-def test_coalescing_front_end():
-    """Many threads calling the one-pair entry (the way GATK drives alignNative) are merged into device
-    batches by the coalescer and each gets exactly the answer of the direct call."""
+@pytest.mark.parametrize("mailboxes", [0, 8, 64], ids=["coalescer", "8_mailboxes", "mailboxes"])
+def test_coalescing_front_end(mailboxes):
+    """Many threads calling the one-pair entry (the way GATK drives alignNative): merged into device batches by the coalescer, or
+    -- with the mailbox service in front of it (sw_service.hip: one resident wave per calling thread, no launch per call) -- served
+    by their own waves, threads beyond the mailboxes still through the coalescer.  Each gets exactly the answer of the direct call."""
     import ctypes as C
     import threading
 
@@ -1283,9 +1285,11 @@ def test_coalescing_front_end():
         results[k] = (rc, off.value, buf.raw[: ln.value].decode(),
                       (ez.mqe, ez.mqe_t, ez.max, ez.max_t, ez.max_q, ez.seg_length))
 
-    b0, p0 = C.c_int64(), C.c_int64()
+    b0, p0, c0, l0 = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
     L.mgl_sw_coalescing_stats(C.byref(b0), C.byref(p0))
+    L.mgl_sw_service_stats(C.byref(c0), C.byref(l0))
     assert L.mgl_sw_set_coalescing(256, 2000) == 0
+    assert L.mgl_sw_set_service(mailboxes, 300) == 0    # (waves that give up after 300 us of silence: some calls find theirs gone)
     try:
         threads = [threading.Thread(target=lambda lo=lo: [call(k) for k in range(lo, len(rows), 32)]) for lo in range(32)]
         for t in threads:
@@ -1300,11 +1304,19 @@ def test_coalescing_front_end():
         assert rc == _lib.ERR_CIGAR_OVERFLOW and ln.value == len(g.cigar)
     finally:
         assert L.mgl_sw_set_coalescing(0, 0) == 0
-    b1, p1 = C.c_int64(), C.c_int64()
+        assert L.mgl_sw_set_service(64, 1000) == 0
+    b1, p1, c1, l1 = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
     L.mgl_sw_coalescing_stats(C.byref(b1), C.byref(p1))
-    assert p1.value - p0.value == len(rows) + 1
-    # (how many share a batch depends on how fast Python's threads come back against a device round trip of a few dozen microseconds)
-    assert b1.value - b0.value < len(rows) * 3 // 4, "calls were not merged into batches"
+    L.mgl_sw_service_stats(C.byref(c1), C.byref(l1))
+    served = c1.value - c0.value
+    assert p1.value - p0.value + served == len(rows) + 1
+    if mailboxes == 0:
+        assert served == 0
+        # (how many share a batch depends on how fast Python's threads come back against a device round trip of a few dozen microseconds)
+        assert b1.value - b0.value < len(rows) * 3 // 4, "calls were not merged into batches"
+    else:
+        # every pair of these suites fits a mailbox except the few whose matrix of scores is beyond a workgroup's LDS
+        assert served >= (len(rows) // 8 if mailboxes == 8 else len(rows) * 3 // 4) and 1 <= l1.value - l0.value <= served
     for k, g in enumerate(rows):
         assert results[k] == (0, g.offset, g.cigar, g.score), (k, results[k], g)
     # and the direct path still works after switching it off

@@ -2,7 +2,8 @@
 and sw_multi.cpp are built against a fake HIP runtime + a fake device backend (tests/cpp/fake_hip, fake_device.cpp -- the
 CPU checker stands where the kernels stand) with -fsanitize=address,undefined and again with -fsanitize=thread, and
 tests/cpp/host_san_driver.cpp drives them: chunked mixed batches (the per-chunk sort by geometry on its helper thread,
-dest map, per-pair status), the lane-kernel path, the multi-device entry, 48 threads through the coalescing front-end
+dest map, per-pair status), the lane-kernel path, the multi-device entry, 48 threads through the coalescing front-end and
+through the mailbox service in front of it (sw_service.cpp against a fake grid of threads that speaks the waves' protocol)
 incl. an injected device-side failure.  Also the restatement itself under ASan."""
 import os
 import subprocess
@@ -27,7 +28,9 @@ def test_host_side_under_asan_ubsan():
 
 
 def test_host_side_under_tsan():
-    _run("host_san_tsan", {"TSAN_OPTIONS": "halt_on_error=1"})
+    # (a grid of the mailbox service lives 20 ms by default: under the thread sanitizer that is a handful of calls, and every launch of
+    # the fake grid creates and joins 32 threads; 200 ms leaves the launches to the growing grid and the pauses of the driver)
+    _run("host_san_tsan", {"TSAN_OPTIONS": "halt_on_error=1", "MGL_SW_SERVICE_LIFE_MS": "200"})
 
 
 def test_restatement_under_asan():
