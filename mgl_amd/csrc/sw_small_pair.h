@@ -158,9 +158,14 @@ __device__ __forceinline__ void small_fill(const SmallGeom &g, uint32_t *hm, con
     const int steps = ql + g.nl - 1;
     const unsigned my_ql = lane < g.nl ? (unsigned)ql : 0u; // lanes without rows never start
     uint32_t *wp = hm + (WIDE ? i0 : (i0 >> 1)) - lane * CS;  // column j - 1 = s - lane: + s * CS
-    // V[0][j] of lane 0's column j = s + 1: j e - base, or with leading / trailing gaps charged -o - (j - 1) e + j e - base
-    int edge_j = (g.indel ? -o_e : gext) - g.base;
-    const int edge_step = g.indel ? 0 : gext;
+    // V[0][j] of lane 0's column j = s + 1: j e - base, or with leading / trailing gaps charged -o - (j - 1) e + j e - base.  Lane 0 has
+    // no lane below it: the DPP move leaves its registers as they are, so what arrives "from below" there is what the register held --
+    // the border, moved on by one column per step by an add that the other lanes' moves overwrite (one VALU instruction per register
+    // and step, where a border kept in scalar registers cost a scalar add and a move each)
+    int up_h = (g.indel ? -o_e : gext) - g.base - (g.indel ? 0 : gext); // (one step early: the loop adds first)
+    int up_e = up_h - o_e;
+    int edge_step = g.indel ? 0 : gext;
+    asm volatile("" : "+v"(edge_step));
     // this lane's query bases of the next four steps: bytes s0 - lane .. + 3 of the query, out of two aligned dwords (before the
     // lane starts and behind the query's end these are addresses of other LDS data or of none -- read as whatever, never used)
     const int q_shift = (-lane) & 3;
@@ -175,29 +180,29 @@ __device__ __forceinline__ void small_fill(const SmallGeom &g, uint32_t *hm, con
         for (int u = 0; u < 4; ++u) {
             const int j = s0 + u - lane + 1;
             const int qb = (int)((qw >> (8 * u)) & 0xffu);
-            const int up_h = from_lane_below(edge_j, h[R - 1]);  // V[i0][j]
-            int up_e = from_lane_below(edge_j - o_e, e_bot);     // E[i0 + 1][j] (row 0: sw.cpp:31-35)
-            edge_j += edge_step;
+            up_h = from_lane_below(up_h + edge_step, h[R - 1]); // V[i0][j]
+            up_e = from_lane_below(up_e + edge_step, e_bot);    // E[i0 + 1][j] (row 0: sw.cpp:31-35)
             if ((unsigned)(j - 1) < my_ql) {
+                int e_run = up_e;
                 int dg = up_diag;
                 up_diag = up_h;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int diag = dg + (tb[r] == qb ? match2 : mismatch2); // sw.cpp:55
-                    const int hn = max(max(diag, f[r]), up_e);                // sw.cpp:60-71
+                    const int hn = max(max(diag, f[r]), e_run);               // sw.cpp:60-71
                     const int open = hn - o_e;
                     dg = h[r];
-                    f[r] = max(open, f[r]); // F[i][j + 1], sw.cpp:84-93
-                    up_e = max(open, up_e); // E[i + 1][j], sw.cpp:73-82
+                    f[r] = max(open, f[r]);   // F[i][j + 1], sw.cpp:84-93
+                    e_run = max(open, e_run); // E[i + 1][j], sw.cpp:73-82
                     h[r] = hn;
                 }
-                e_bot = up_e;
+                e_bot = e_run;
                 if (WIDE) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) wp[r] = (uint32_t)h[r];
                 } else {
 #pragma unroll
-                    for (int r = 0; r < R; r += 2) wp[r >> 1] = ((uint32_t)h[r] & 0xffffu) | ((uint32_t)h[r + 1] << 16);
+                    for (int r = 0; r < R; r += 2) wp[r >> 1] = __builtin_amdgcn_perm((uint32_t)h[r + 1], (uint32_t)h[r], 0x05040100u); // low halves of both, one instruction
                 }
             }
             wp += CS;
