@@ -219,14 +219,22 @@ def secondary_workloads():
         except Exception as e:  # noqa: BLE001 -- a secondary line must never take the headline down
             out[name] = {"error": repr(e)[:200]}
     # the reference's own calling pattern: one pair per call from 16 native threads through the
-    # coalescing front-end, and one active region per call through the JNI-shaped PairHMM entry -- latency, not throughput
+    # front-end of mgl_sw_align, and one active region per call through the JNI-shaped PairHMM entry -- latency, not throughput
     try:
         exe = os.path.join(ROOT, "tests", "cpp", "coalesce_bench")
         if os.path.exists(exe):
-            r = subprocess.run([exe, "16", "3000", "50"], capture_output=True, text=True, timeout=120)
-            m = re.search(r"coalesced: ([0-9.]+) pairs/s .* wrong results (\d+)", r.stdout)
-            if m:
-                out["one_pair_per_call, 16 native threads (mgl_sw_align, 256x150)"] = {"pairs_per_s": float(m.group(1)), "checked": m.group(2) == "0"}
+            # mailboxes (sw_service.hip: a resident wave per calling thread, no launch per call), then the coalescer alone
+            line = {}
+            for key, env in (("pairs_per_s", {}), ("coalescer_only_pairs_per_s", {"MGL_SW_SERVICE_SLOTS": "0"})):
+                r = subprocess.run([exe, "16", "3000", "50"], capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
+                m = re.search(r"front-end: ([0-9.]+) pairs/s .*?(\d+) through mailboxes .* wrong results (\d+)", r.stdout)
+                if m:
+                    line[key] = float(m.group(1))
+                    line["checked"] = line.get("checked", True) and m.group(3) == "0"
+                    if not env:
+                        line["through_mailboxes"] = int(m.group(2))
+            if line:
+                out["one_pair_per_call, 16 native threads (mgl_sw_align, 256x150)"] = line
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pairhmm_region_latency.py")], capture_output=True, text=True, timeout=120)
         m = re.search(r"= 800 pairs: ([0-9.]+) us per call", r.stdout)
         if m:
