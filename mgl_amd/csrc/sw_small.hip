@@ -16,7 +16,7 @@ namespace mgl_sw_dev {
 int small_lds_bytes(int max_tl, int max_ql, int cigar_stride, bool wide)
 {
     // (small_column_words(tl) <= (tl + 7) / 2 + 1, or tl + 8, for every tl <= max_tl)
-    const int64_t kept = (int64_t)(wide ? max_tl + 8 : (max_tl + 7) / 2 + 1) * max_ql * 4;
+    const int64_t kept = (int64_t)(wide ? max_tl + 8 : (max_tl + 7) / 2 + 1) * (max_ql + 1) * 4; // (+ one spare column)
     const int64_t b = kept + ((max_tl + 3) & ~3) + ((max_ql + 3) & ~3) + small_text_cap(max_tl, max_ql, cigar_stride) + 8;
     return b > (1 << 30) ? (1 << 30) : (int)b;
 }

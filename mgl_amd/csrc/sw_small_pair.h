@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "sw_device.h"
 #include "sw_traceback.h"
 
@@ -171,7 +173,16 @@ __device__ __forceinline__ void small_fill(const SmallGeom &g, uint32_t *hm, con
     const int q_shift = (-lane) & 3;
     const uint32_t *qd = reinterpret_cast<const uint32_t *>(qs) + ((0 - lane) >> 2);
     uint32_t q_lo = qd[0], q_hi = qd[1];
-    for (int s0 = 0; s0 < steps; s0 += 4) {
+    // four steps (the four query bases of one dword).  MASKED: lanes whose column lies outside 1 .. ql sit the step out (the ramps of
+    // the wavefront: the lanes above have not started, the lanes below are through); without it every lane has a cell in every
+    // step -- no compare, no exec juggling, no branch: a lone wave pays ~5 cycles for every instruction of any kind.
+    // The diagonal candidates of all rows are taken from the previous column's H before any row overwrites it: H stays in place (no
+    // copy per row) and the additions leave the chain of maxima.
+    // CLAMP (with !MASKED): lanes that are through compute on (what they produce reaches nobody: a lane only ever hands values to the
+    // lane above it, which is through one step later) and store into the spare column behind the matrix
+    uint32_t *const wp_spare = hm + (WIDE ? i0 : (i0 >> 1)) + ql * CS;
+    auto block = [&](auto masked, auto clamp, const int s0) {
+        constexpr bool MASKED = decltype(masked)::value, CLAMP = decltype(clamp)::value;
         const uint32_t qw = __builtin_amdgcn_alignbyte(q_hi, q_lo, q_shift);
         qd += 1;
         q_lo = qd[0]; // (used one block later: by then four steps of stores sit behind it in the queue, nothing waits)
@@ -182,32 +193,44 @@ __device__ __forceinline__ void small_fill(const SmallGeom &g, uint32_t *hm, con
             const int qb = (int)((qw >> (8 * u)) & 0xffu);
             up_h = from_lane_below(up_h + edge_step, h[R - 1]); // V[i0][j]
             up_e = from_lane_below(up_e + edge_step, e_bot);    // E[i0 + 1][j] (row 0: sw.cpp:31-35)
-            if ((unsigned)(j - 1) < my_ql) {
-                int e_run = up_e;
-                int dg = up_diag;
+            if (!MASKED || (unsigned)(j - 1) < my_ql) {
+                int diag[R];
+                diag[0] = up_diag + (tb[0] == qb ? match2 : mismatch2); // sw.cpp:55
+#pragma unroll
+                for (int r = 1; r < R; ++r) diag[r] = h[r - 1] + (tb[r] == qb ? match2 : mismatch2);
                 up_diag = up_h;
+                int e_run = up_e;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const int diag = dg + (tb[r] == qb ? match2 : mismatch2); // sw.cpp:55
-                    const int hn = max(max(diag, f[r]), e_run);               // sw.cpp:60-71
+                    const int hn = max(max(diag[r], f[r]), e_run); // sw.cpp:60-71
                     const int open = hn - o_e;
-                    dg = h[r];
                     f[r] = max(open, f[r]);   // F[i][j + 1], sw.cpp:84-93
                     e_run = max(open, e_run); // E[i + 1][j], sw.cpp:73-82
                     h[r] = hn;
                 }
                 e_bot = e_run;
+                uint32_t *const out = CLAMP ? (wp < wp_spare ? wp : wp_spare) : wp;
                 if (WIDE) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) wp[r] = (uint32_t)h[r];
+                    for (int r = 0; r < R; ++r) out[r] = (uint32_t)h[r];
                 } else {
 #pragma unroll
-                    for (int r = 0; r < R; r += 2) wp[r >> 1] = __builtin_amdgcn_perm((uint32_t)h[r + 1], (uint32_t)h[r], 0x05040100u); // low halves of both, one instruction
+                    for (int r = 0; r < R; r += 2) out[r >> 1] = __builtin_amdgcn_perm((uint32_t)h[r + 1], (uint32_t)h[r], 0x05040100u); // low halves of both, one instruction
                 }
             }
             wp += CS;
         }
+    };
+    // every lane is inside the matrix from step 63 (the last lane has started) to step ql - 1 (the first one is through) -- when all
+    // 64 lanes own rows; blocks of four steps that lie within that run unmasked
+    int s0 = 0;
+    if (g.nl == 64) {
+        for (; s0 < 64 && s0 < steps; s0 += 4) block(std::true_type{}, std::false_type{}, s0);
+        for (; s0 + 3 <= ql - 1; s0 += 4) block(std::false_type{}, std::false_type{}, s0);
+        if (s0 >= 64) // (the ramp down: from here on every lane has started)
+            for (; s0 < steps; s0 += 4) block(std::false_type{}, std::true_type{}, s0);
     }
+    for (; s0 < steps; s0 += 4) block(std::true_type{}, std::false_type{}, s0);
 }
 
 // the moves of a path, read off the kept scores by the whole wave (every lane returns the same value)
@@ -301,7 +324,7 @@ __device__ __forceinline__ void small_pair(const TbArgs &a, const int64_t o, con
 
     // carve (by this pair's own lengths: never more than the batch's bounds give)
     uint32_t *hm = lds;
-    const int kept_words = g.CS * ql;
+    const int kept_words = g.CS * (ql + 1); // (+ the spare column small_fill's lanes store into once they are through)
     uint8_t *ts = reinterpret_cast<uint8_t *>(hm + kept_words);
     uint8_t *qs = ts + ((tl + 3) & ~3);
     char *text = reinterpret_cast<char *>(qs + ((ql + 3) & ~3));
