@@ -214,7 +214,7 @@ hipError_t launch_small(const TbArgs &a, int max_tl, int max_ql, bool wide, hipS
 bool small_fits_int16(int max_tl, int max_ql, int match, int mismatch, int gopen, int gext);
 
 // ---- one pair per call without a launch on the request path (sw_service.hip; host side: sw_service.cpp).  Every calling thread owns a
-// MAILBOX in pinned host memory; ONE resident grid serves them, workgroup k (one wave) mailbox k: the thread writes its pair and a
+// MAILBOX (ServiceRequest + ServiceReply below); ONE resident grid serves them, workgroup k (one wave) mailbox k: the thread writes its pair and a
 // new sequence number there, the wave -- polling over the link -- runs small_pair() on it and writes the results and the same number
 // back.  The grid ends by itself -- all its waves within microseconds of each other, through the `stop` latch in device memory -- when
 // no mailbox has had a request for `idle_ticks`, when it has lived `life_ticks` (100 MHz ticks), or when the host asks (`quit`);
@@ -223,33 +223,40 @@ constexpr int SERVICE_MAX_TL = 512, SERVICE_MAX_QL = 2048;
 constexpr int SERVICE_TEXT_BYTES = (2 * (SERVICE_MAX_TL + SERVICE_MAX_QL) + 4 + 3) & ~3;
 constexpr int SERVICE_LDS_BYTES = 160 * 1024;
 enum : uint32_t { SERVICE_IDLE = 0, SERVICE_RUNNING = 1, SERVICE_EXITED = 3, SERVICE_LAUNCHED = 4 }; // low four bits of `state`; above them the grid's generation
-struct alignas(64) ServiceMailbox {
-    // line 0, written by the host.  The wave takes a request when seq_a and seq_b both show a number it has not served: whatever order
-    // the two halves of the line cross the link in, a half that shows the new number shows the new fields before it.
+// A mailbox is two pieces.  The REQUEST is written by the calling thread and read by the wave: it lives in fine-grained DEVICE memory
+// where the host can store into device memory directly (large BAR: posted writes over the link, and the wave polls its own HBM instead
+// of reading host memory -- 2.3 us against 3.5 per round trip of a 512-byte request, scripts/ubench/bar_probe.hip), else in pinned host
+// memory.  The REPLY is written by the wave and read by the host: pinned host memory always (host reads over the BAR are slow).
+struct alignas(64) ServiceRequest {
+    // line 0.  The wave takes a request when seq_a and seq_b both show a number it has not served: whatever order the pieces of the
+    // line arrive in, the fields were complete (fenced) before either number was written.
     uint32_t seq_a;
     int32_t tl, ql, match, mismatch, gopen, gext, strategy; // (normalised parameters)
     int32_t cigar_stride, wide;
     uint32_t quit_gen; // grids up to this generation are asked to end
     int32_t pad0[4];
     uint32_t seq_b;
-    // line 1, written by the wave: the results first, done_seq last
+    uint8_t t[SERVICE_MAX_TL];
+    uint8_t q[SERVICE_MAX_QL];
+};
+struct alignas(64) ServiceReply {
+    // the results first, done_seq last
     uint32_t done_seq;
     uint32_t state; // generation << 4 | SERVICE_*: the host writes LAUNCHED before a launch, the wave RUNNING when it starts and EXITED as its last store
     int32_t offset, cigar_len, status;
     Score score;
     int32_t pad1[5];
-    uint8_t t[SERVICE_MAX_TL];
-    uint8_t q[SERVICE_MAX_QL];
     char cigar[SERVICE_TEXT_BYTES];
 };
-static_assert(offsetof(ServiceMailbox, done_seq) == 64 && offsetof(ServiceMailbox, t) == 128, "two header lines");
+static_assert(offsetof(ServiceRequest, t) == 64 && offsetof(ServiceReply, cigar) == 64, "one header line each");
 struct ServiceControl { // device memory, zeroed once
     unsigned long long last_activity; // 100 MHz time of the last request any wave has served
     uint32_t stop_gen;                // the waves of grids up to this generation end at their next look
     uint32_t pad;
 };
-// `slots` workgroups on mailboxes[0 .. slots)
-hipError_t launch_service(ServiceMailbox *mailboxes, ServiceControl *ctl, int slots, uint32_t gen, uint32_t idle_ticks, uint32_t life_ticks, hipStream_t stream);
+// `slots` workgroups on mailboxes 0 .. slots - 1
+hipError_t launch_service(const ServiceRequest *requests, ServiceReply *replies, ServiceControl *ctl, int slots, uint32_t gen, uint32_t idle_ticks,
+                          uint32_t life_ticks, hipStream_t stream);
 
 // Device-side sort of a chunk by geometry (sw_kernels.hip): a counting sort over the (tl, ql) grid [1, max_tl] x [1, max_ql].
 // Slots [0, total[0]) hold the full blocks of eight pairs of one geometry, cell after cell; the left-over pairs (fewer than

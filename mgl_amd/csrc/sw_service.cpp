@@ -39,7 +39,8 @@ inline uint32_t load_acquire(const uint32_t *p) { return __atomic_load_n(p, __AT
 inline void store_release(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 
 struct Slot {
-    ServiceMailbox *mb = nullptr; // host address
+    ServiceRequest *rq = nullptr; // where the host writes (device memory behind the BAR, or pinned host memory)
+    ServiceReply *rp = nullptr;   // where the host reads (pinned host memory)
     int index = 0;
     uint32_t seq = 0;
     bool leased = false;
@@ -67,14 +68,19 @@ class ServicePool {
     {
         g_pool_alive.store(false);
         std::lock_guard<std::mutex> lk(mu_);
-        if (!base_) return;
-        for (int k = 0; k < grid_slots_; ++k) __atomic_store_n(&base_[k].quit_gen, grid_gen_, __ATOMIC_RELEASE);
+        if (!reps_) return;
+        for (int k = 0; k < grid_slots_; ++k) __atomic_store_n(&reqs_[k].quit_gen, grid_gen_, __ATOMIC_RELEASE);
+        flush_stores();
         (void)hipSetDevice(device_);
         (void)hipStreamSynchronize(stream_); // (bounded by the waves' own conditions even if the request went unseen)
         (void)hipStreamDestroy(stream_);
         (void)hipFree(ctl_);
-        (void)hipHostFree(base_);
-        base_ = nullptr;
+        if (over_bar_)
+            (void)hipFree(reqs_);
+        else
+            (void)hipHostFree(reqs_);
+        (void)hipHostFree(reps_);
+        reps_ = nullptr;
     }
 
     void configure(int slots, int idle_us)
@@ -109,7 +115,7 @@ class ServicePool {
         if (cap == 0) return nullptr;
         std::lock_guard<std::mutex> lk(mu_);
         if (broken_) return nullptr;
-        if (!base_ && !allocate_locked()) return nullptr;
+        if (!reps_ && !allocate_locked()) return nullptr;
         for (int k = 0; k < cap; ++k)
             if (!slots_[k].leased) {
                 slots_[k].leased = true;
@@ -123,21 +129,26 @@ class ServicePool {
     int call(Slot &s, const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen, int gext, int strategy, int stride,
              int wide, char *cigar, int cigar_cap, int *cigar_len, int *offset, mgl_sw_score *ez)
     {
-        ServiceMailbox &mb = *s.mb;
-        memcpy(mb.t, t, (size_t)tl);
-        memcpy(mb.q, q, (size_t)ql);
-        mb.tl = tl;
-        mb.ql = ql;
-        mb.match = match;
-        mb.mismatch = mismatch;
-        mb.gopen = gopen;
-        mb.gext = gext;
-        mb.strategy = strategy;
-        mb.cigar_stride = stride;
-        mb.wide = wide;
+        ServiceRequest &rq = *s.rq;
+        ServiceReply &mb = *s.rp;
+        memcpy(rq.t, t, (size_t)tl);
+        memcpy(rq.q, q, (size_t)ql);
+        rq.tl = tl;
+        rq.ql = ql;
+        rq.match = match;
+        rq.mismatch = mismatch;
+        rq.gopen = gopen;
+        rq.gext = gext;
+        rq.strategy = strategy;
+        rq.cigar_stride = stride;
+        rq.wide = wide;
         const uint32_t seq = ++s.seq;
-        store_release(&mb.seq_a, seq);
-        store_release(&mb.seq_b, seq);
+        // (device memory behind the BAR is write-combining for the host: stores leave in no particular order, and only when a buffer is
+        // evicted or a fence says so -- the pair before the numbers, the numbers at once)
+        flush_stores();
+        store_release(&rq.seq_a, seq);
+        store_release(&rq.seq_b, seq);
+        flush_stores();
         calls_.fetch_add(1, std::memory_order_relaxed);
         // the answer is a device-side latency away (tens of microseconds): spin; a thread that has spun for long gives its CPU away between looks
         // With more than two calling threads per CPU a spinning caller only keeps others from posting their pairs: such callers sleep
@@ -182,29 +193,63 @@ class ServicePool {
   private:
     bool allocate_locked()
     {
-        void *p = nullptr, *d = nullptr, *c = nullptr;
-        int lo = 0, hi = 0;
-        if (hipSetDevice(device_) != hipSuccess || hipHostMalloc(&p, sizeof(ServiceMailbox) * MAX_SLOTS, hipHostMallocDefault) != hipSuccess) {
+        void *p = nullptr, *d = nullptr, *c = nullptr, *r = nullptr, *rd = nullptr;
+        int lo = 0, hi = 0, large_bar = 0;
+        if (hipSetDevice(device_) != hipSuccess || hipHostMalloc(&p, sizeof(ServiceReply) * MAX_SLOTS, hipHostMallocDefault) != hipSuccess) {
             broken_ = true;
             return false;
         }
-        memset(p, 0, sizeof(ServiceMailbox) * MAX_SLOTS);
+        memset(p, 0, sizeof(ServiceReply) * MAX_SLOTS);
+        // the requests: device memory the host stores into directly, where the platform allows (MGL_SW_SERVICE_BAR=0: never)
+        const char *const bar = getenv("MGL_SW_SERVICE_BAR");
+        if ((!bar || atoi(bar) != 0) && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device_) == hipSuccess && large_bar &&
+            hipExtMallocWithFlags(&r, sizeof(ServiceRequest) * MAX_SLOTS, hipDeviceMallocFinegrained) == hipSuccess) {
+            if (hipMemset(r, 0, sizeof(ServiceRequest) * MAX_SLOTS) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
+                over_bar_ = true;
+                rd = r;
+            } else {
+                (void)hipFree(r);
+                r = nullptr;
+            }
+        }
+        if (!r) {
+            if (hipHostMalloc(&r, sizeof(ServiceRequest) * MAX_SLOTS, hipHostMallocDefault) != hipSuccess || hipHostGetDevicePointer(&rd, r, 0) != hipSuccess) {
+                if (r) (void)hipHostFree(r);
+                (void)hipHostFree(p);
+                broken_ = true;
+                return false;
+            }
+            memset(r, 0, sizeof(ServiceRequest) * MAX_SLOTS);
+        }
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // (hi = the numerically lowest = the highest priority: the library's other streams are normal or lowest)
         if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess || hipMalloc(&c, sizeof(ServiceControl)) != hipSuccess ||
             hipMemset(c, 0, sizeof(ServiceControl)) != hipSuccess || hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi) != hipSuccess) {
             if (c) (void)hipFree(c);
+            if (over_bar_)
+                (void)hipFree(r);
+            else
+                (void)hipHostFree(r);
             (void)hipHostFree(p);
             broken_ = true;
             return false;
         }
-        base_ = static_cast<ServiceMailbox *>(p);
-        base_dev_ = static_cast<ServiceMailbox *>(d);
+        reps_ = static_cast<ServiceReply *>(p);
+        reps_dev_ = static_cast<ServiceReply *>(d);
+        reqs_ = static_cast<ServiceRequest *>(r);
+        reqs_dev_ = static_cast<const ServiceRequest *>(rd);
         ctl_ = static_cast<ServiceControl *>(c);
         for (int k = 0; k < MAX_SLOTS; ++k) {
-            slots_[k].mb = base_ + k;
+            slots_[k].rq = reqs_ + k;
+            slots_[k].rp = reps_ + k;
             slots_[k].index = k;
         }
         return true;
+    }
+    void flush_stores() const
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        if (over_bar_) __builtin_ia32_sfence();
+#endif
     }
     void give_back(Slot *s)
     {
@@ -218,22 +263,23 @@ class ServicePool {
     {
         std::lock_guard<std::mutex> lk(mu_);
         if (broken_) return MGL_SW_ERR_DEVICE;
-        const uint32_t st = load_acquire(&s.mb->state);
+        const uint32_t st = load_acquire(&s.rp->state);
         const bool covered = s.index < grid_slots_;
         if (covered && ((st & 15u) == SERVICE_LAUNCHED || (st & 15u) == SERVICE_RUNNING)) return MGL_SW_OK; // somebody else has
         if (covered && (st >> 4) != grid_gen_) return MGL_SW_OK; // (EXITED of an older grid, written late over the LAUNCHED of the current one: its wave is on its way)
         (void)seen;
         if (hipSetDevice(device_) != hipSuccess) return MGL_SW_ERR_DEVICE;
         // the running grid (if this mailbox is beyond it, it may be busy with the others) is asked to end; the next one starts behind it on the stream
-        for (int k = 0; k < grid_slots_; ++k) __atomic_store_n(&base_[k].quit_gen, grid_gen_, __ATOMIC_RELEASE);
+        for (int k = 0; k < grid_slots_; ++k) __atomic_store_n(&reqs_[k].quit_gen, grid_gen_, __ATOMIC_RELEASE);
+        flush_stores();
         const uint32_t gen = (grid_gen_ + 1) & 0x0fffffffu;
         const int n = used_slots_;
-        for (int k = 0; k < n; ++k) store_release(&base_[k].state, gen << 4 | SERVICE_LAUNCHED);
+        for (int k = 0; k < n; ++k) store_release(&reps_[k].state, gen << 4 | SERVICE_LAUNCHED);
         const uint32_t idle = (uint32_t)std::min<int64_t>((int64_t)idle_us_.load() * 100, 0x7fffffff);
         const uint32_t life = (uint32_t)std::min<int64_t>((int64_t)life_ms_.load() * 100000, 0x7fffffff);
-        const hipError_t e = launch_service(base_dev_, ctl_, n, gen, idle, life, stream_);
+        const hipError_t e = launch_service(reqs_dev_, reps_dev_, ctl_, n, gen, idle, life, stream_);
         if (e != hipSuccess) {
-            for (int k = 0; k < n; ++k) store_release(&base_[k].state, grid_gen_ << 4 | SERVICE_EXITED);
+            for (int k = 0; k < n; ++k) store_release(&reps_[k].state, grid_gen_ << 4 | SERVICE_EXITED);
             broken_ = true;
             return e == hipErrorOutOfMemory ? MGL_SW_ERR_NOMEM : MGL_SW_ERR_DEVICE;
         }
@@ -245,7 +291,10 @@ class ServicePool {
 
     std::mutex mu_;
     Slot slots_[MAX_SLOTS];
-    ServiceMailbox *base_ = nullptr, *base_dev_ = nullptr; // MAX_SLOTS mailboxes, one pinned allocation
+    ServiceRequest *reqs_ = nullptr;            // MAX_SLOTS requests as the host writes them ...
+    const ServiceRequest *reqs_dev_ = nullptr;  // ... and as the waves read them
+    ServiceReply *reps_ = nullptr, *reps_dev_ = nullptr; // MAX_SLOTS replies, pinned host memory
+    bool over_bar_ = false;                     // the requests are device memory the host stores into over the BAR
     ServiceControl *ctl_ = nullptr;
     hipStream_t stream_ = nullptr;
     // guarded by mu_

@@ -1,13 +1,14 @@
 // sw_service.hip -- one pair per call (the reference's alignNative pattern, ..._MicrosoftSmithWaterman.cpp:44-71) with no launch and no
 // synchronisation on the request path.
 //
-// Every calling thread owns a MAILBOX in pinned host memory (ServiceMailbox, sw_device.h); ONE resident grid serves them, workgroup k
-// (one wave) mailbox k:
+// Every calling thread owns a MAILBOX (ServiceRequest + ServiceReply, sw_device.h); ONE resident grid serves them, workgroup k (one
+// wave) mailbox k:
 //
-//   host:  writes the pair and its parameters into the mailbox, then a new sequence number (seq_a, seq_b), and spins on done_seq;
-//   wave:  lanes 0-15 read the mailbox's first line over the link until it shows a number not yet served, then the wave runs the
-//          pair -- small_pair() of sw_small_pair.h: sequences straight out of the mailbox, H kept in LDS, the walk off the scores,
-//          text and results straight into the mailbox -- and stores the number into done_seq behind a system-scope release.
+//   host:  writes the pair and its parameters into the request -- fine-grained device memory behind the large BAR where the platform
+//          has one, else pinned host memory -- then a new sequence number (seq_a, seq_b), and spins on the reply's done_seq;
+//   wave:  lanes 0-15 read the request's first line until it shows a number not yet served, then the wave runs the pair --
+//          small_pair() of sw_small_pair.h: sequences straight out of the request, H kept in LDS, the walk off the scores, text and
+//          results straight into the reply (pinned host memory) -- and stores the number into done_seq behind a system-scope release.
 //
 // One grid, not one kernel per mailbox: HIP multiplexes its streams onto four hardware queues, and a resident kernel holds up every
 // kernel behind it in its queue -- sixteen one-wave kernels on sixteen streams ran four at a time (measured: 85 k pairs/s from 16
@@ -38,17 +39,18 @@ __device__ __forceinline__ void store_system(uint32_t *p, uint32_t v) { __hip_at
 
 } // namespace
 
-__global__ __launch_bounds__(64) void sw_service_kernel(ServiceMailbox *const mailboxes, ServiceControl *const ctl, const uint32_t gen, const uint32_t idle_ticks,
-                                                        const uint32_t life_ticks)
+__global__ __launch_bounds__(64) void sw_service_kernel(const ServiceRequest *const requests, ServiceReply *const replies, ServiceControl *const ctl, const uint32_t gen,
+                                                        const uint32_t idle_ticks, const uint32_t life_ticks)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
-    ServiceMailbox *const mb = mailboxes + blockIdx.x;
-    uint32_t served = __builtin_amdgcn_readfirstlane(load_system(&mb->done_seq)); // (the last number a wave of an earlier grid handed back)
-    if (lane == 0) store_system(&mb->state, gen << 4 | SERVICE_RUNNING);
+    const ServiceRequest *const rq = requests + blockIdx.x;
+    ServiceReply *const rp = replies + blockIdx.x;
+    uint32_t served = __builtin_amdgcn_readfirstlane(load_system(&rp->done_seq)); // (the last number a wave of an earlier grid handed back)
+    if (lane == 0) store_system(&rp->state, gen << 4 | SERVICE_RUNNING);
     const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
     uint64_t t_own = t_start; // this mailbox's last request
-    const uint32_t *line0 = reinterpret_cast<const uint32_t *>(mb);
+    const uint32_t *line0 = reinterpret_cast<const uint32_t *>(rq);
     for (;;) {
         // the first line of the mailbox, one dword per lane: one read over the link per turn
         const uint32_t w = lane < 16 ? load_system(line0 + lane) : 0u;
@@ -57,8 +59,8 @@ __global__ __launch_bounds__(64) void sw_service_kernel(ServiceMailbox *const ma
         if (seq_a == seq_b && seq_a != served) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // the sequences were written before the number
             TbArgs a{};
-            a.t = SeqSet{mb->t, nullptr, nullptr, 0, 0};
-            a.q = SeqSet{mb->q, nullptr, nullptr, 0, 0};
+            a.t = SeqSet{rq->t, nullptr, nullptr, 0, 0};
+            a.q = SeqSet{rq->q, nullptr, nullptr, 0, 0};
             const int tl = (int)__builtin_amdgcn_readlane(w, 1), ql = (int)__builtin_amdgcn_readlane(w, 2);
             a.match = (int)__builtin_amdgcn_readlane(w, 3);
             a.mismatch = (int)__builtin_amdgcn_readlane(w, 4);
@@ -67,15 +69,15 @@ __global__ __launch_bounds__(64) void sw_service_kernel(ServiceMailbox *const ma
             a.strategy = (int)__builtin_amdgcn_readlane(w, 7);
             a.cigar_stride = (int)__builtin_amdgcn_readlane(w, 8);
             const int wide = (int)__builtin_amdgcn_readlane(w, 9);
-            a.offset = &mb->offset;
-            a.score = &mb->score;
-            a.cigar = mb->cigar;
-            a.cigar_len = &mb->cigar_len;
-            a.status = &mb->status;
+            a.offset = &rp->offset;
+            a.score = &rp->score;
+            a.cigar = rp->cigar;
+            a.cigar_len = &rp->cigar_len;
+            a.status = &rp->status;
             // (the host has checked the bounds: tl <= SERVICE_MAX_TL, ql <= SERVICE_MAX_QL, the stride within the mailbox's text, LDS)
             small_pair<false>(a, 0, tl, ql, 0, 0, lds, wide, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); // results before the number
-            if (lane == 0) store_system(&mb->done_seq, seq_a);
+            if (lane == 0) store_system(&rp->done_seq, seq_a);
             served = seq_a;
             __builtin_amdgcn_wave_barrier();
             t_own = __builtin_amdgcn_s_memrealtime();
@@ -99,10 +101,11 @@ __global__ __launch_bounds__(64) void sw_service_kernel(ServiceMailbox *const ma
             __builtin_amdgcn_s_sleep(4);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    if (lane == 0) store_system(&mb->state, gen << 4 | SERVICE_EXITED);
+    if (lane == 0) store_system(&rp->state, gen << 4 | SERVICE_EXITED);
 }
 
-hipError_t launch_service(ServiceMailbox *mailboxes, ServiceControl *ctl, int slots, uint32_t gen, uint32_t idle_ticks, uint32_t life_ticks, hipStream_t stream)
+hipError_t launch_service(const ServiceRequest *requests, ServiceReply *replies, ServiceControl *ctl, int slots, uint32_t gen, uint32_t idle_ticks, uint32_t life_ticks,
+                          hipStream_t stream)
 {
     if (slots < 1) return hipErrorInvalidValue;
     static std::atomic<unsigned long long> raised{0}; // the attribute is per device: raised once on each
@@ -115,7 +118,7 @@ hipError_t launch_service(ServiceMailbox *mailboxes, ServiceControl *ctl, int sl
         if (e != hipSuccess) return e;
         raised.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL(sw_service_kernel, dim3((unsigned)slots), dim3(64), (size_t)SERVICE_LDS_BYTES, stream, mailboxes, ctl, gen, idle_ticks, life_ticks);
+    hipLaunchKernelGGL(sw_service_kernel, dim3((unsigned)slots), dim3(64), (size_t)SERVICE_LDS_BYTES, stream, requests, replies, ctl, gen, idle_ticks, life_ticks);
     return hipGetLastError();
 }
 

@@ -162,7 +162,8 @@ bool small_fits_int16(int, int, int, int, int, int) { return true; }
 std::atomic<long long> fake_service_waves{0}, fake_service_pairs{0};
 static std::atomic<unsigned long long> g_service_last{0};
 static std::atomic<uint32_t> g_service_stop{0};
-hipError_t launch_service(ServiceMailbox *mailboxes, ServiceControl *, int slots, uint32_t gen, uint32_t idle_ticks, uint32_t life_ticks, hipStream_t)
+hipError_t launch_service(const ServiceRequest *requests, ServiceReply *replies, ServiceControl *, int slots, uint32_t gen, uint32_t idle_ticks, uint32_t life_ticks,
+                          hipStream_t)
 {
     static std::mutex order;              // "the stream": a grid starts when the one before it has ended
     struct Joiner {                       // (the last grid's threads end by their own conditions: joined when the process ends)
@@ -181,10 +182,10 @@ hipError_t launch_service(ServiceMailbox *mailboxes, ServiceControl *, int slots
     static const auto epoch = Clock::now();
     for (int k = 0; k < slots; ++k) {
         ++fake_service_waves;
-        prev.emplace_back([mb = mailboxes + k, gen, idle_ticks, life_ticks] {
+        prev.emplace_back([mb = requests + k, rp = replies + k, gen, idle_ticks, life_ticks] {
             auto ticks = [] { return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - epoch).count() / 10; };
-            uint32_t served = __atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE);
-            __atomic_store_n(&mb->state, gen << 4 | (uint32_t)SERVICE_RUNNING, __ATOMIC_RELEASE);
+            uint32_t served = __atomic_load_n(&rp->done_seq, __ATOMIC_ACQUIRE);
+            __atomic_store_n(&rp->state, gen << 4 | (uint32_t)SERVICE_RUNNING, __ATOMIC_RELEASE);
             const unsigned long long t_start = ticks();
             for (;;) {
                 const uint32_t seq_a = __atomic_load_n(&mb->seq_a, __ATOMIC_ACQUIRE), seq_b = __atomic_load_n(&mb->seq_b, __ATOMIC_ACQUIRE);
@@ -197,13 +198,13 @@ hipError_t launch_service(ServiceMailbox *mailboxes, ServiceControl *, int slots
                                   &ez, nullptr) != SWO_OK)
                         abort();
                     const bool injected = mb->ql >= 8 && memcmp(mb->q, "NNNNNNNN", 8) == 0; // (the same fault injection as walk())
-                    mb->status = injected ? ERR_DEVICE : len > mb->cigar_stride ? ERR_CIGAR_OVERFLOW : 0;
-                    mb->cigar_len = injected ? 0 : len;
-                    mb->offset = mb->status ? 0 : off;
-                    if (!mb->status) memcpy(mb->cigar, text.data(), (size_t)len);
-                    mb->score = Score{ez.mqe, ez.mqe_t, ez.max, ez.max_t, ez.max_q, ez.seg_length};
+                    rp->status = injected ? ERR_DEVICE : len > mb->cigar_stride ? ERR_CIGAR_OVERFLOW : 0;
+                    rp->cigar_len = injected ? 0 : len;
+                    rp->offset = rp->status ? 0 : off;
+                    if (!rp->status) memcpy(rp->cigar, text.data(), (size_t)len);
+                    rp->score = Score{ez.mqe, ez.mqe_t, ez.max, ez.max_t, ez.max_q, ez.seg_length};
                     ++fake_service_pairs;
-                    __atomic_store_n(&mb->done_seq, seq_a, __ATOMIC_RELEASE);
+                    __atomic_store_n(&rp->done_seq, seq_a, __ATOMIC_RELEASE);
                     served = seq_a;
                     unsigned long long now = ticks(), seen = g_service_last.load();
                     while (seen < now && !g_service_last.compare_exchange_weak(seen, now)) {
@@ -220,7 +221,7 @@ hipError_t launch_service(ServiceMailbox *mailboxes, ServiceControl *, int slots
                 }
                 std::this_thread::sleep_for(std::chrono::microseconds(20)); // (32 "waves" and 48 callers share a handful of CPUs here)
             }
-            __atomic_store_n(&mb->state, gen << 4 | (uint32_t)SERVICE_EXITED, __ATOMIC_RELEASE);
+            __atomic_store_n(&rp->state, gen << 4 | (uint32_t)SERVICE_EXITED, __ATOMIC_RELEASE);
         });
     }
     return hipSuccess;

@@ -24,7 +24,8 @@ typedef struct fakeStream *hipStream_t;
 typedef struct fakeEvent *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
-enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1 };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1, hipDeviceAttributeIsLargeBar = 2 };
+enum { hipDeviceMallocFinegrained = 1 };
 
 int fake_hip_device_count(void); /* tests/cpp/fake_device.cpp: FAKE_HIP_DEVICES, default 2 */
 
@@ -35,6 +36,8 @@ static inline const char *hipGetErrorString(hipError_t e) { return e == hipSucce
 static inline hipError_t hipMalloc(void **p, size_t bytes) { *p = malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { *p = malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipExtMallocWithFlags(void **p, size_t bytes, unsigned) { *p = malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 enum { hipHostRegisterDefault = 0 };
 static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
