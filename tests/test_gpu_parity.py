@@ -946,16 +946,25 @@ def test_score_only_flag(aligner):
 
 
 def test_native_threads_through_the_coalescer():
-    """GATK's calling pattern from native threads (tests/cpp/coalesce_bench.cpp): 48 threads, one pair per
-    mgl_sw_align call, merged into device batches by the dispatcher; every answer equals the direct call's."""
+    """GATK's calling pattern from native threads (tests/cpp/coalesce_bench.cpp): 48 threads, one pair per mgl_sw_align call, served by
+    their mailboxes' resident waves or merged into device batches by the dispatcher; every answer equals the direct call's."""
     import os
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "cpp")])
-    for args in (["48", "60", "50"], ["7", "40", "0", "97", "33"]):
-        r = subprocess.run([os.path.join(root, "tests", "cpp", "coalesce_bench")] + args, capture_output=True, text=True)
-        assert r.returncode == 0 and "wrong results 0" in r.stdout, (r.stdout, r.stderr)
+    import re
+
+    # the default front-end (mailboxes, requests over the BAR where there is one); mailboxes whose requests stay in pinned host memory;
+    # a grid that gives up after 30 us of silence and lives 1 ms (calls keep finding their wave gone: the launch races of
+    # sw_service.cpp on the real device); eight mailboxes for 48 threads (the rest through the coalescer); the coalescer alone
+    for env, want_mailboxes in (({}, True), ({"MGL_SW_SERVICE_BAR": "0"}, True), ({"MGL_SW_SERVICE_IDLE_US": "30", "MGL_SW_SERVICE_LIFE_MS": "1"}, True),
+                                ({"MGL_SW_SERVICE_SLOTS": "8"}, True), ({"MGL_SW_SERVICE_SLOTS": "0"}, False)):
+        for args in (["48", "60", "50"], ["7", "40", "0", "97", "33"]):
+            r = subprocess.run([os.path.join(root, "tests", "cpp", "coalesce_bench")] + args, capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
+            assert r.returncode == 0 and "wrong results 0" in r.stdout, (env, r.stdout, r.stderr)
+            served = int(re.search(r"(\d+) through mailboxes", r.stdout).group(1))
+            assert (served > 0) == want_mailboxes, (env, r.stdout)
 
 
 def test_batch_mode_backtrack_matrix(aligner):
