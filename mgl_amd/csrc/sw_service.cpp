@@ -322,10 +322,14 @@ extern "C" MGL_SW_INTERNAL int mgl_sw_service_align(const char *t, int tl, const
     const int stride = std::min((cigar_cap + 3) & ~3, (2 * (tl + ql) + 4 + 3) & ~3); // no CIGAR of this pair is longer than that
     const bool wide = !small_fits_int16(tl, ql, match, mismatch, gopen, gext);
     if (stride > SERVICE_TEXT_BYTES || small_lds_bytes(tl, ql, stride, wide) > SERVICE_LDS_BYTES) return DECLINED;
-    ServicePool &pool = ServicePool::instance();
-    Slot *s = pool.lease();
-    if (!s) return DECLINED;
-    return pool.call(*s, t, tl, q, ql, match, mismatch, gopen, gext, strategy, stride, wide ? 1 : 0, cigar, cigar_cap, cigar_len, offset, ez);
+    try { // (nothing may leave through the C ABI: the caller may be a JVM)
+        ServicePool &pool = ServicePool::instance();
+        Slot *s = pool.lease();
+        if (!s) return DECLINED;
+        return pool.call(*s, t, tl, q, ql, match, mismatch, gopen, gext, strategy, stride, wide ? 1 : 0, cigar, cigar_cap, cigar_len, offset, ez);
+    } catch (...) {
+        return MGL_SW_ERR_DEVICE;
+    }
 }
 
 extern "C" {
@@ -333,14 +337,22 @@ extern "C" {
 int mgl_sw_set_service(int slots, int idle_us)
 {
     if (slots < 0 || idle_us < 0) return MGL_SW_ERR_BAD_ARG;
-    ServicePool::instance().configure(slots, idle_us);
+    try {
+        ServicePool::instance().configure(slots, idle_us);
+    } catch (...) {
+        return MGL_SW_ERR_DEVICE;
+    }
     return MGL_SW_OK;
 }
 
 int mgl_sw_service_stats(int64_t *calls, int64_t *launches)
 {
     if (!calls || !launches) return MGL_SW_ERR_BAD_ARG;
-    ServicePool::instance().stats(calls, launches);
+    try {
+        ServicePool::instance().stats(calls, launches);
+    } catch (...) {
+        return MGL_SW_ERR_DEVICE;
+    }
     return MGL_SW_OK;
 }
 
