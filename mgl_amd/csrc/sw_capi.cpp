@@ -543,6 +543,26 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // inputs cross the link, so small is good; the tails of consecutive launches overlap on the two streams (10 M pairs:
     // 8 chunks 122 ms, 13 chunks 115 ms, 26 chunks of one round 112 ms; one stream: 136-148 ms; scripts/host_sweep.sh)
     if (use_lane && hooks && chunk > lane_round) chunk = lane_rounds ? lane_round : chunk / lane_round * lane_round;
+    // ... and where the batch is many rounds long, the chunks GROW and SHRINK: what cannot hide is the first chunk's way in (nothing
+    // computes until its inputs have crossed the link) and the last chunk's way out, so those are one round each; in between
+    // chunks double up to eight rounds -- a launch of eight rounds runs at 95 % of the long-launch rate, one of a single round at
+    // 75-80 % -- and halve again towards the end: 1, 2, 4, 8, 8, .., 8, 4, 2, 1 rounds.  `chunk` is the largest.
+    const int64_t pyr_unit = (int64_t)ctx->n_cus * (lane_ck_ok ? 8 : lane_rows == 16 ? 16 : 12) * 128; // one round of the chip
+    const int64_t pyr_fit = ws_part / per_pair / pyr_unit; // rounds that fit half the workspace
+    // (2-bit inputs only: ASCII inputs keep the link busy for longer than the kernels run -- 4.2 GB against 64 ms -- and there a chunk's
+    // kernel waits for its whole copy: one round per chunk stays best, registered arrays 85.0 ms against 87.9 with growing chunks)
+    const char *const pyr_env = getenv("MGL_SW_DEBUG_HOST_PYRAMID"); // (the largest chunk in rounds, 0: all chunks two rounds; read per call: the host-sanitizer driver compares both)
+    const int pyr_max = pyr_env ? atoi(pyr_env) : 8;
+    const bool pyramid = use_lane && hooks && lane_rounds && !auto_group && tset.packed2 && pyr_max > 0 && pyr_fit >= 1;
+    if (pyramid) chunk = pyr_unit * std::min<int64_t>(pyr_max, pyr_fit);
+    // the size of the chunk that starts at pair `first` as the k-th of the call
+    auto chunk_at = [&](int64_t first, int64_t k) -> int64_t {
+        const int64_t left = n - first;
+        if (!pyramid) return std::min(chunk, left);
+        const int64_t grow = std::min(chunk, pyr_unit << std::min<int64_t>(k, 8));
+        const int64_t half_left = std::max(pyr_unit, left / 2 / pyr_unit * pyr_unit); // (whole rounds; towards the end: half of what is left)
+        return std::min(left, std::min(grow, half_left));
+    };
     // strip kernel: one pair per workgroup of W waves at three waves per SIMD -- a chunk that is not a whole number of rounds of
     // the chip (n_cus * (12 / W) pairs) ends with a round in which most CUs idle (1 582 pairs per chunk ran as two rounds)
     if (strip16) {
@@ -572,7 +592,9 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         pl.fill_streams = dual ? 2 : 1;
         pl.workspace_halves = halves;
         pl.chunk_pairs = chunk;
-        pl.chunks = (n + chunk - 1) / chunk;
+        pl.chunks = 0;
+        for (int64_t first = 0; first < n; first += chunk_at(first, pl.chunks), ++pl.chunks) {
+        }
         pl.workspace_bytes_per_pair = per_pair;
         pl.workspace_bytes = per_pair * chunk * halves;
         return MGL_SW_OK;
@@ -621,8 +643,8 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     int64_t lane_pairs_last = 0; // sorted chunks: pairs of the last chunk that went through the lane kernel
     struct Pending { int64_t first, count; hipEvent_t ready; } pending[2];
     int n_pending = 0;
-    for (int64_t first = 0; first < n; first += chunk, ++k) {
-        const int64_t count = std::min(chunk, n - first);
+    for (int64_t first = 0, count = 0; first < n; first += count, ++k) {
+        count = chunk_at(first, k);
         const int h = (int)(k & (halves - 1));
         hipStream_t const fs = dual && (k & 1) ? ctx->fill2 : stream; // this chunk's fill stream (same half => same stream: ordered)
         if (hooks) {

@@ -257,6 +257,44 @@ int main()
             mgl_sw_timing tm;
             CHECK(mgl_sw_ctx_get_timing(ctx, &tm) == 0 && tm.dp_launches >= 3);
         }
+        // a LARGE uniform batch (many rounds of the fake chip: four CUs): the chunks grow and shrink -- 1, 2, 4, .. rounds of 4 096 pairs,
+        // halving towards the end -- on two streams and two workspace halves; windows of one packed "genome" against packed reads
+        {
+            const int64_t nu = 40000 + 37;
+            const int utl = 64, uql = 40;
+            std::vector<uint8_t> genome((size_t)(1 << 16)), reads((size_t)nu * uql);
+            for (auto &c : genome) c = (uint8_t)"ACGT"[g() & 3];
+            std::vector<int64_t> ts((size_t)nu), qs((size_t)nu);
+            Batch view;
+            for (int64_t k = 0; k < nu; ++k) {
+                const int64_t w = (int64_t)(g() % (genome.size() - utl));
+                ts[(size_t)k] = w;
+                qs[(size_t)k] = k * uql;
+                std::string t(genome.begin() + w, genome.begin() + w + utl), q = t.substr(g() % (utl - uql + 1), (size_t)uql);
+                q[g() % uql] = "ACGT"[g() & 3];
+                if (k % 7 == 0) q.erase(5, 3).append("ACG"); // a gap
+                memcpy(&reads[(size_t)k * uql], q.data(), (size_t)uql);
+                view.add(t, q);
+            }
+            const std::vector<uint8_t> G = pack(genome), Rd = pack(reads);
+            const Expect ev = expect(view, MGL_SW_OS_SOFTCLIP);
+            CHECK(mgl_sw_ctx_set_workspace(ctx, 1ll << 30) == 0 && mgl_sw_ctx_set_lane_kernel(ctx, 2) == 0);
+            std::vector<int32_t> off((size_t)nu), len((size_t)nu), st((size_t)nu);
+            std::vector<mgl_sw_score> sc((size_t)nu);
+            std::vector<char> cg((size_t)nu * 64, 1);
+            for (const char *pyr : {"8", "0"}) { // growing chunks, then all chunks two rounds: the same answers
+                setenv("MGL_SW_DEBUG_HOST_PYRAMID", pyr, 1);
+                CHECK(mgl_sw_align_batch_2bit(ctx, nu, G.data(), (int64_t)genome.size(), ts.data(), nullptr, Rd.data(), (int64_t)reads.size(), qs.data(), nullptr, utl, uql, 200,
+                                              -150, 260, 11, MGL_SW_OS_SOFTCLIP, off.data(), sc.data(), cg.data(), 64, len.data(), st.data(), MGL_SW_FLAG_UNIFORM_GEOMETRY) == 0);
+                compare(view, ev, off, sc, cg, 64, len, &st);
+                mgl_sw_timing tm;
+                CHECK(mgl_sw_ctx_get_timing(ctx, &tm) == 0 && tm.fill_kernel == MGL_SW_KERNEL_LANE16_CK);
+                // 9.77 rounds: chunks of 1, 2, 3, 1, 1, 1 rounds and the rest (a chunk is at most half of what is left, in whole rounds); without: five chunks of two rounds
+                CHECK(tm.dp_launches == (pyr[0] == '8' ? 7 : 5));
+            }
+            unsetenv("MGL_SW_DEBUG_HOST_PYRAMID");
+            CHECK(mgl_sw_ctx_set_lane_kernel(ctx, 0) == 0);
+        }
         // a pair outside its array, a length above the stated maximum, missing length arrays without the uniform flag
         int64_t ts1[1] = {(int64_t)mixed.t.size() - 10}, qs1[1] = {0};
         int32_t tl1[1] = {40}, ql1[1] = {20}, off1[1], len1[1];

@@ -114,7 +114,9 @@ def test_host_entries_pipeline_chunks_on_two_streams():
     assert a.fill_kernel == LANE16_CK and a.fill_streams == 2 and a.workspace_halves == 2
     assert a.chunk_pairs == 256 * 8 * 128, "ASCII inputs: one round of the chip per chunk (two waves per SIMD, 128 pairs per wave)"
     b = plan(n=10_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, entry=1, packed2=True, workspace=BENCH_WS)
-    assert b.chunk_pairs == 2 * 256 * 8 * 128 and b.chunks == 20, "2-bit inputs: two rounds per chunk"
+    assert b.chunk_pairs == 8 * 256 * 8 * 128 and b.chunks == 11, "2-bit inputs: chunks of 1, 2, 4, 8, 8, 7, 4, 2, 1, 1 rounds and the rest (38.15 rounds in all)"
+    c = plan(n=10_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, entry=1, packed2=True, workspace=16 << 30)
+    assert c.chunk_pairs == 2 * 256 * 8 * 128 and c.chunks == 22, "... no larger than half the workspace holds"
 
 
 def test_explain_reports_what_the_call_would_refuse():
