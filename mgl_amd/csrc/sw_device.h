@@ -68,6 +68,7 @@ struct DpArgs {
     int score_only;           // packed kernel: no traceback flags (MGL_SW_FLAG_SCORE_ONLY)
     int grouped;              // sw_dp16_lane_ck_kernel: every wave of 128 pairs has its own geometry (a chunk sorted by geometry)
     int strip_k;              // sw_dp16_strip_kernel: 0 = the flags of every cell are stored; K > 0 = none are: rows and checkpoints of bands of K strips (strip16_ck_*)
+    int strip_pack;           // ... their entries: 0 = {H, gap value} as two int32; B > 0 = one int32, H << B | (H - gap value) (strip16_pack_bits)
 };
 
 struct TbArgs {
@@ -90,6 +91,7 @@ struct TbArgs {
     int32_t *status_any; // optional: max of all non-zero statuses of the call
     int match, mismatch, gopen, gext; // sw_strip_ck_walk_kernel recomputes the blocks its path crosses
     int strip_rows, strip_k;         // ... rows per strip and strips per kept band of the fill
+    int strip_pack;                  // ... and the form of its entries (DpArgs::strip_pack)
     const int64_t *dest; // optional: output index of input pair p (results of pair p go to offset[dest[p]], cigar slot dest[p], ...);
 };                       // null: p itself.  (Batches the host layer has reordered by geometry hand results back in the caller's order.)
 
@@ -197,9 +199,27 @@ constexpr int STRIP_CK_COLS = 256;
 __host__ __device__ inline int strip16_ck_bands(int tl, int rows, int k) { return (tl + rows * k - 1) / (rows * k); }
 __host__ __device__ inline int strip16_ck_ccs(int tl, int ql, int rows, int k) { return (ql + STRIP_CPS * k * strip16_ck_bands(tl, rows, k)) / STRIP_CK_COLS + 2; }
 __host__ __device__ inline int strip16_ck_row_stride(int ql) { return (ql + 4) & ~3; } // entries per kept row: column j at index j - 1, rows 32-byte aligned
-__host__ __device__ inline int64_t strip16_ck_words(int tl, int ql, int rows, int k)
+// An entry is {H, G}: H of a cell and the gap value that enters the next row (kept rows: E) or the next column (checkpoints: F) from it.
+// G = max(H - o, gap value of the cell itself - e), and that value is no greater than H: H - G lies in [min(o, e), o] -- one int32
+// holds H << B | (H - G) where B bits hold o and H fits the rest (strip16_pack_bits; 0: it does not, two int32 per entry).
+__host__ __device__ inline int strip16_pack_bits(int tl, int ql, int match, int gopen, int gext)
 {
-    return ((((int64_t)strip16_ck_bands(tl, rows, k) * strip16_ck_row_stride(ql) + (int64_t)strip16_ck_ccs(tl, ql, rows, k) * (tl + 1)) + 3) & ~(int64_t)3) * 2;
+    if (match < 0 || gopen < gext || gext < 0) return 0;
+    int b = 1;
+    while ((1 << b) <= gopen) ++b;
+    const int64_t top = (int64_t)match * (tl < ql ? tl : ql), low = (int64_t)gopen + ((int64_t)tl + ql) * gext; // H <= top, H >= -low
+    const int64_t room = (int64_t)1 << (31 - b);
+    return b <= 15 && top < room && low < room ? b : 0;
+}
+__host__ __device__ inline int strip16_pack(int h, int g, int bits) { return (int)((unsigned)h << bits) | (h - g); }
+__host__ __device__ inline void strip16_unpack(int v, int bits, int &h, int &g)
+{
+    h = v >> bits;
+    g = h - (v & ((1 << bits) - 1));
+}
+__host__ __device__ inline int64_t strip16_ck_words(int tl, int ql, int rows, int k, int pack_bits = 0)
+{
+    return ((((int64_t)strip16_ck_bands(tl, rows, k) * strip16_ck_row_stride(ql) + (int64_t)strip16_ck_ccs(tl, ql, rows, k) * (tl + 1)) + 3) & ~(int64_t)3) * (pack_bits ? 1 : 2);
 }
 int strip16_lds_bytes(int max_ql, int waves);
 bool strip16_range_ok(int match, int mismatch, int gopen, int gext);

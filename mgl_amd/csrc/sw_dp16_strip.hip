@@ -29,7 +29,7 @@
 // are written for (67 MB per pair).  In this form the fill runs the score-only column code (9 instead of 17 instructions per two
 // cells) and keeps what sw_strip_ck_walk_kernel (sw_strip_walk.hip) needs to recompute the 60 x 256 blocks the path crosses: the
 // true scores {H, E} of the row below every band of K strips, per column, and {H, F} of every row at the band's checkpoint columns
-// (every STRIP_CK_COLS columns, at the step offset of the band so that all strips of a band save the SAME column): 17 MB per pair.
+// (every STRIP_CK_COLS columns, at the step offset of the band so that all strips of a band save the SAME column): 8 MB per pair as packed entries (DpArgs::strip_pack), 16 as pairs of int32.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -125,6 +125,10 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     int2 *const rows_rec = reinterpret_cast<int2 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words);
     const int row_stride = strip16_ck_row_stride(a.uni_ql);
     int2 *const ck_rec = rows_rec + (size_t)strip16_ck_bands(a.uni_tl, SR, K) * row_stride;
+    // (a.strip_pack = B > 0: the same entries as one int32 each, H << B | (H - gap value): strip16_pack_bits)
+    const int PB = NOTB ? a.strip_pack : 0;
+    int *const rows_pk = reinterpret_cast<int *>(rows_rec);
+    int *const ck_pk = rows_pk + (size_t)strip16_ck_bands(a.uni_tl, SR, K) * row_stride;
     const int bandA = gA / K, bandB = gB / K;
     // the strip whose last row is the row below a band (and not the matrix's last rows): it writes that row
     const bool rowsA = NOTB && (gA + 1) % K == 0 && (gA + 1) * SR < tl, rowsB = NOTB && (gB + 1) % K == 0 && (gB + 1) * SR < tl;
@@ -238,7 +242,17 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
         }
         // ---- 4a. the row below a band (NOTB): the group's four columns as one aligned 32-byte piece (column j at entry j - 1)
         if (NOTB && CPS == 4) {
-            if (rowsA && actA) {
+            if (PB && rowsA && actA) { // one aligned 16-byte piece
+                int *const dst = rows_pk + (size_t)bandA * row_stride + CPS * cgA;
+                if (CPS * cgA + CPS <= ql) {
+                    reinterpret_cast<int4 *>(dst)[0] = make_int4(strip16_pack(keptA[0].x, keptA[0].y, PB), strip16_pack(keptA[1].x, keptA[1].y, PB),
+                                                                 strip16_pack(keptA[2].x, keptA[2].y, PB), strip16_pack(keptA[3].x, keptA[3].y, PB));
+                } else {
+#pragma unroll
+                    for (int u = 0; u < CPS; ++u)
+                        if (CPS * cgA + u + 1 <= ql) dst[u] = strip16_pack(keptA[u].x, keptA[u].y, PB);
+                }
+            } else if (rowsA && actA) {
                 int2 *const dst = rows_rec + (size_t)bandA * row_stride + CPS * cgA;
                 if (CPS * cgA + CPS <= ql) {
                     reinterpret_cast<int4 *>(dst)[0] = make_int4(keptA[0].x, keptA[0].y, keptA[1].x, keptA[1].y);
@@ -249,7 +263,17 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                         if (CPS * cgA + u + 1 <= ql) dst[u] = keptA[u];
                 }
             }
-            if (rowsB && actB) {
+            if (PB && rowsB && actB) {
+                int *const dst = rows_pk + (size_t)bandB * row_stride + CPS * cgB;
+                if (CPS * cgB + CPS <= ql) {
+                    reinterpret_cast<int4 *>(dst)[0] = make_int4(strip16_pack(keptB[0].x, keptB[0].y, PB), strip16_pack(keptB[1].x, keptB[1].y, PB),
+                                                                 strip16_pack(keptB[2].x, keptB[2].y, PB), strip16_pack(keptB[3].x, keptB[3].y, PB));
+                } else {
+#pragma unroll
+                    for (int u = 0; u < CPS; ++u)
+                        if (CPS * cgB + u + 1 <= ql) dst[u] = strip16_pack(keptB[u].x, keptB[u].y, PB);
+                }
+            } else if (rowsB && actB) {
                 int2 *const dst = rows_rec + (size_t)bandB * row_stride + CPS * cgB;
                 if (CPS * cgB + CPS <= ql) {
                     reinterpret_cast<int4 *>(dst)[0] = make_int4(keptB[0].x, keptB[0].y, keptB[1].x, keptB[1].y);
@@ -271,16 +295,30 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                 if (ckA) {
                     const int j = CPS * (cgA + 1), cc = (cgA + 1 + K * bandA) / PER;
                     int2 *const dst = ck_rec + (size_t)cc * (a.uni_tl + 1) + i0A + 1;
+                    int *const dpk = ck_pk + (size_t)cc * (a.uni_tl + 1) + i0A + 1;
 #pragma unroll
                     for (int r = 0; r < SR; ++r)
-                        if (i0A + r < tl) dst[r] = make_int2(lo16(h[r]) + base_a - (i0A + r + 1 + j) * gext, lo16(f[r]) + base_a - (i0A + r + 2 + j) * gext);
+                        if (i0A + r < tl) {
+                            const int hv = lo16(h[r]) + base_a - (i0A + r + 1 + j) * gext, fv = lo16(f[r]) + base_a - (i0A + r + 2 + j) * gext;
+                            if (PB)
+                                dpk[r] = strip16_pack(hv, fv, PB);
+                            else
+                                dst[r] = make_int2(hv, fv);
+                        }
                 }
                 if (ckB) {
                     const int j = CPS * (cgB + 1), cc = (cgB + 1 + K * bandB) / PER;
                     int2 *const dst = ck_rec + (size_t)cc * (a.uni_tl + 1) + i0B + 1;
+                    int *const dpk = ck_pk + (size_t)cc * (a.uni_tl + 1) + i0B + 1;
 #pragma unroll
                     for (int r = 0; r < SR; ++r)
-                        if (i0B + r < tl) dst[r] = make_int2(hi16(h[r]) + base_b - (i0B + r + 1 + j) * gext, hi16(f[r]) + base_b - (i0B + r + 2 + j) * gext);
+                        if (i0B + r < tl) {
+                            const int hv = hi16(h[r]) + base_b - (i0B + r + 1 + j) * gext, fv = hi16(f[r]) + base_b - (i0B + r + 2 + j) * gext;
+                            if (PB)
+                                dpk[r] = strip16_pack(hv, fv, PB);
+                            else
+                                dst[r] = make_int2(hv, fv);
+                        }
                 }
             }
         }

@@ -36,6 +36,7 @@ struct BlockMoves {
     bool indel;
     int rbk, kcols;            // rows per band (K strips), CPS * K: how far a band's checkpoint columns lie before the band above's
     const int2 *rows, *ck;     // what the fill kept (strip16_ck_words)
+    int pack;                  // ... as {H, gap value} pairs (0) or packed into one int32 each (strip16_pack_bits)
     int row_stride, tl_cap;    // entries per kept row (column j at j - 1), rows per checkpoint column
     unsigned *flags;           // LDS: [64 rows][FW] dwords
     unsigned char *qb;         // LDS: the block's query bases
@@ -67,9 +68,13 @@ struct BlockMoves {
             hleft = border_of(i, gopen, gext, indel);
             f = hleft - gopen;
         } else {
-            const int2 v = row_ok ? ck[(size_t)cc * (tl_cap + 1) + i] : make_int2(0, 0);
-            hleft = v.x;
-            f = v.y;
+            if (pack) {
+                strip16_unpack(row_ok ? reinterpret_cast<const int *>(ck)[(size_t)cc * (tl_cap + 1) + i] : 0, pack, hleft, f);
+            } else {
+                const int2 v = row_ok ? ck[(size_t)cc * (tl_cap + 1) + i] : make_int2(0, 0);
+                hleft = v.x;
+                f = v.y;
+            }
         }
         // H[r0][jl]: the first diagonal of lane 0
         auto top = [&](int j, int &h_, int &e_) { // {H[r0][j], E entering row r0 + 1 at column j}
@@ -77,9 +82,13 @@ struct BlockMoves {
                 h_ = border_of(j, gopen, gext, indel);
                 e_ = h_ - gopen;
             } else {
-                const int2 v = rows[(size_t)(b - 1) * row_stride + (j - 1)];
-                h_ = v.x;
-                e_ = v.y;
+                if (pack) {
+                    strip16_unpack(reinterpret_cast<const int *>(rows)[(size_t)(b - 1) * row_stride + (j - 1)], pack, h_, e_);
+                } else {
+                    const int2 v = rows[(size_t)(b - 1) * row_stride + (j - 1)];
+                    h_ = v.x;
+                    e_ = v.y;
+                }
             }
         };
         int corner = jl == 0 ? border_of(r0, gopen, gext, indel) : 0, dummy = 0;
@@ -194,7 +203,10 @@ __global__ __launch_bounds__(64) void sw_strip_ck_walk_kernel(const TbArgs a, co
     mv.kcols = STRIP_CPS * a.strip_k;
     mv.rows = reinterpret_cast<const int2 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words);
     mv.row_stride = strip16_ck_row_stride(ql_cap);
-    mv.ck = mv.rows + (size_t)strip16_ck_bands(tl_cap, a.strip_rows, a.strip_k) * mv.row_stride;
+    mv.pack = a.strip_pack;
+    // (packed entries are one int32 each: the checkpoints start half as far in)
+    mv.ck = a.strip_pack ? reinterpret_cast<const int2 *>(reinterpret_cast<const int *>(mv.rows) + (size_t)strip16_ck_bands(tl_cap, a.strip_rows, a.strip_k) * mv.row_stride)
+                         : mv.rows + (size_t)strip16_ck_bands(tl_cap, a.strip_rows, a.strip_k) * mv.row_stride;
     mv.tl_cap = tl_cap;
     mv.flags = flags;
     mv.qb = qb;

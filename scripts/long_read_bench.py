@@ -70,7 +70,7 @@ if args.json:
     print(json.dumps({"gcups": round(cells * reps / dt / 1e9, 1), "pairs": n, "length": length, "passes": reps, "seconds": round(dt, 1),
                       "ms_per_pass": round(dt * 1e3 / reps, 2),
                       "kernel_ms": {a.fill_kernel_name(tm): round(tm.dp_ms, 2), walk_name: round(tm.tb_ms, 2), "launches": tm.dp_launches},
-                      "traceback": "4 bits per cell in HBM" if spilled else "none stored: kept rows and checkpoints (17 MB per 10 kb pair), the walk recomputes the blocks the path crosses",
+                      "traceback": "4 bits per cell in HBM" if spilled else "none stored: kept rows and checkpoints (8 MB per 10 kb pair), the walk recomputes the blocks the path crosses",
                       "roofline": {"bound": "hbm", "kernel": a.fill_kernel_name(tm), "achieved": round(alg / fill_s / 1e9, 1), "peak": 8000.0,
                                    "unit": "GB/s", "frac": round(alg / fill_s / 1e9 / 8000.0, 5), "traffic": None,
                                    "algorithmic_bytes_per_pass": round(alg), "kernel_gcups": round(cells / fill_s / 1e9, 1),

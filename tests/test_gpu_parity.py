@@ -343,8 +343,8 @@ def test_device_batch_of_mixed_lengths_is_sorted_on_the_device(two_bit):
     a.close()
 
 
-@pytest.mark.parametrize("stored", [False, True], ids=["checkpointed", "stored"])
-def test_strip_kernel_long_reads(stored):
+@pytest.mark.parametrize("stored", [False, True, None], ids=["checkpointed", "stored", "checkpointed_two_words_per_entry"])
+def test_strip_kernel_long_reads(stored, monkeypatch):
     """sw_dp16_strip_kernel (one pair per workgroup, one 32-row strip per lane-half, per-strip 16-bit baselines, hand-over by DPP
     and an LDS mailbox) forced onto the long goldens, onto pairs of awkward lengths under every strategy, and onto ordinary
     short pairs (one wave, mostly idle strips): identical results, traceback included.  Both forms: no flags stored -- kept
@@ -352,6 +352,9 @@ def test_strip_kernel_long_reads(stored):
     flags of every cell stored (layout 4, what mgl_sw_ctx_expand_slot needs)."""
     from mgl_amd import synth
 
+    if stored is None:   # the kept rows and checkpoints as {H, gap value} pairs of int32 instead of one packed int32 per entry
+        monkeypatch.setenv("MGL_SW_DEBUG_STRIP_PACK", "0")
+        stored = False
     forced = sw.MicrosoftSmithWaterman(0)
     forced.set_strip_kernel(2)
     forced.set_lane_checkpoint(1 if stored else 0)
@@ -904,7 +907,7 @@ def test_single_long_pair_through_the_one_pair_entry():
     assert tuple(ez) == g.score
     # a small workspace holds exactly as many pairs as fit, down to one per chunk
     a = sw.MicrosoftSmithWaterman(0)
-    a.set_workspace(40 << 20)   # two halves of 20 MB: one pair's kept rows and checkpoints each (17 MB; with every flag stored: 50 MB)
+    a.set_workspace(20 << 20)   # two halves of 10 MB: one pair's kept rows and checkpoints each (8.5 MB as packed entries; with every flag stored: 50 MB)
     res = a.align_batch([g.t] * 3, [g.q] * 3, g.params, g.strategy, cigar_stride=24000)
     assert all(int(res.offsets[k]) == g.offset and "sha1:" + hashlib.sha1(res.cigars[k].encode()).hexdigest() == g.cigar for k in range(3))
     assert a.timing().dp_launches == 3
