@@ -254,7 +254,7 @@ __device__ __forceinline__ void sw_dp16_lane_body(const DpArgs &a, const TbArgs 
 
 // Register budgets: R rows per strip cost 3R VGPRs of state + ~70: four waves per SIMD (128) at 16 rows, three (168) at 32.
 #define MGL_LANE_KERNEL(NAME, R, MODE, WPS, NVGPR)                                                            \
-    __global__ __launch_bounds__(256, WPS) void NAME(const DpArgs a, const TbArgs walk)                       \
+    __global__ __launch_bounds__(64, WPS) void NAME(const DpArgs a, const TbArgs walk)                        \
     {                                                                                                         \
         sw_dp16_lane_body<R, MODE>(a, walk);                                                                  \
     }
@@ -272,7 +272,7 @@ bool lane16_supported(const SeqSet &t, const SeqSet &q)
 
 hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &walk, int rows, hipStream_t stream)
 {
-    const int waves_per_block = 4;
+    const int waves_per_block = 1; // (the waves share nothing: a workgroup of one releases its registers as soon as it is through -- sw_dp16_lane_ck.hip)
     const int64_t waves = ((a.count + 1) / 2 + 63) / 64;
     const dim3 grid((unsigned)((waves + waves_per_block - 1) / waves_per_block)), block(64 * waves_per_block);
 #define MGL_LAUNCH_LANE(K, KS)                                                                         \

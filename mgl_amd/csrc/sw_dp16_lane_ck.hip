@@ -935,14 +935,21 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
 // Two waves per SIMD (256 registers: no spills in pass 1's loops).  A three-wave build of the same code (168 registers, spills)
 // ran launches of 10 M pairs equally fast in round 2 and shorter ones 2-7 % slower; with pass 2 as it is now it is slower
 // everywhere (1000 x 150, 2.56 M pairs: 62.9 ms against 61.4) and was dropped.
-__global__ __launch_bounds__(256, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, const TbArgs walk) { sw_dp16_lane_ck_body(a, walk); }
+// ONE wave per workgroup: the waves share nothing (no LDS, no barrier), and a workgroup's registers are released only when its LAST wave
+// has ended -- the waves of one workgroup need different numbers of block rounds in pass 2, so with four per workgroup three of the four
+// SIMD slots stood empty until the slowest was through (10 M pairs: 63.99 ms with four, 63.37 with two, 63.06 with one; 1.25 M pairs:
+// 9.05 / 8.88 / 8.85 ms; on a slower box, alternating: 65.4-65.5 ms with four, 64.2-64.3 with one; scripts/wpb_probe.sh)
+#ifndef MGL_CK_WAVES_PER_BLOCK
+#define MGL_CK_WAVES_PER_BLOCK 1
+#endif
+__global__ __launch_bounds__(64 * MGL_CK_WAVES_PER_BLOCK, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, const TbArgs walk) { sw_dp16_lane_ck_body(a, walk); }
 
 // either wire format, the same for both sequence sets (the kernel stages base codes, sw_lane_cell.h)
 bool lane16_ck_supported(const SeqSet &t, const SeqSet &q) { return (t.packed2 != 0) == (q.packed2 != 0); }
 
 hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &walk, hipStream_t stream)
 {
-    const int waves_per_block = 4;
+    const int waves_per_block = MGL_CK_WAVES_PER_BLOCK;
     const int64_t waves = ((a.count + 1) / 2 + 63) / 64;
     const dim3 grid((unsigned)((waves + waves_per_block - 1) / waves_per_block)), block(64 * waves_per_block);
     hipLaunchKernelGGL(sw_dp16_lane_ck_kernel, grid, block, 0, stream, a, walk);
