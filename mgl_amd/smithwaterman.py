@@ -360,6 +360,24 @@ def align(ref, alt, parameters=GATK_PARAMETERS, overhang_strategy=SWOverhangStra
                                                             ez.seg_length)
 
 
+def set_coalescing(max_batch, max_wait_us):
+    """The front-ends of the one-pair entry (mgl_sw_align / alignNative): max_batch = 0 makes every call a direct call."""
+    _check(_lib.lib().mgl_sw_set_coalescing(int(max_batch), int(max_wait_us)))
+
+
+def set_service(slots, idle_us=0):
+    """Mailboxes of the one-pair entry (one resident wave per calling thread, no launch per call): `slots` of them at most, 0 = off
+    (every call through the coalescer); the service grid ends after idle_us of silence (0: keep the current value)."""
+    _check(_lib.lib().mgl_sw_set_service(int(slots), int(idle_us)))
+
+
+def service_stats():
+    """(calls served through mailboxes, launches of the service grid) so far."""
+    calls, launches = C.c_int64(), C.c_int64()
+    _check(_lib.lib().mgl_sw_service_stats(C.byref(calls), C.byref(launches)))
+    return calls.value, launches.value
+
+
 def backtrack_matrix(ref, alt, parameters=GATK_PARAMETERS, overhang_strategy=SWOverhangStrategy.SOFTCLIP):
     """The reference's logical backtrack matrix (calculateMatrix, sw.cpp:5-146) rebuilt on the GPU."""
     ref, alt = bytes(ref), bytes(alt)
