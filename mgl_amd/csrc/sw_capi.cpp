@@ -251,99 +251,47 @@ struct ChunkHooks {
     int32_t *d_status_any = nullptr;   // device word receiving the largest per-pair status
 };
 
-// Enqueue fill + traceback for a device-resident batch on `stream`.
-int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tset, const SeqSet &qset, int max_tl,
-               int max_ql, int match, int mismatch, int gopen, int gext, int strategy, int32_t *d_offset, Score *d_score,
-               char *d_cigar, int cigar_stride, int32_t *d_cigar_len, int32_t *d_status, int64_t cells_hint, int geom,
-               bool binary_cigar = false, const ChunkHooks *hooks = nullptr, const int8_t *d_matrix = nullptr,
-               const uint8_t *d_code = nullptr, bool score_only_hint = false, mgl_sw_plan *explain = nullptr)
+// What the planner decides about a batch: which kernel, in what shape, in what chunks.  plan_batch() is PURE -- the context's settings and the
+// batch's description in, no HIP call, nothing allocated -- so mgl_sw_explain() can report a plan without a GPU and tests/test_plan.py can pin it;
+// run_device() executes it.
+struct BatchPlan {
+    bool use_lane; // the two-pairs-per-lane kernels (sw_dp16_lane*.hip) ...
+    bool lane_ck; // ... in the checkpointed form (no traceback stored, the walk inside the fill kernel)
+    bool use16; // the eight-pairs-per-wave packed kernel (sw_dp16.hip)
+    bool strip16; // long reads: one strip per lane-half (sw_dp16_strip.hip) ...
+    bool coop16; // long reads: one pair per workgroup, packed int16 with a checked window
+    int coop_waves; // waves per pair of the workgroup kernels (0: not those)
+    int strip_waves; // ... its waves per pair
+    int strip_k; // ... strips per kept band (0: every flag stored)
+    int strip_pack; // ... its kept entries packed into one int32 (bits for the gap penalty; 0: two int32)
+    bool auto_group; // a batch of mixed geometries whose chunks the library sorts by (tl, ql)
+    bool lane_group; // ... the geometries with whole waves of 128 pairs through the checkpointed lane kernel
+    int64_t lane_group_stride; // ... words per wave of that part
+    bool score_only; // no traceback, no CIGARs
+    bool fused_walk; // the fill kernel walks its own paths (no traceback kernel)
+    bool use_scratch; // long queries of the int32 kernel: carry ring and query copies in HBM
+    int rows; // target rows per stripe / strip
+    int wpb; // waves per workgroup
+    int wpb16; // ... of the packed kernel
+    int sps_cap; // steps per stripe the LDS carve is sized for
+    int sps32; // ... of the int32 part of a sorted chunk
+    int64_t stride_words; // traceback words per pair / per two pairs / per wave, by layout
+    int64_t stride32_words; // ... of the int32 part of a sorted chunk
+    int64_t per_pair; // workspace bytes per pair
+    int64_t chunk; // pairs per chunk (the largest, where the chunks grow and shrink)
+    bool pyramid; // the host entry of a large 2-bit batch: chunks of 1, 2, 4, 8 .. 8, 4, 2, 1 rounds of the chip
+    int64_t pyr_unit; // ... pairs per round
+    bool overlap; // the traceback of chunk k runs beside the fill of chunk k + 1 (two workspace halves)
+    bool dual; // consecutive chunks alternate between two fill streams (two workspace halves)
+    int halves; // workspace halves in use
+};
+static int plan_batch(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const SeqSet &qset, int max_tl, int max_ql, int match, int mismatch, int gopen, int gext,
+                      int strategy, const Score *d_score, const char *d_cigar, int cigar_stride, int geom, bool binary_cigar, const ChunkHooks *hooks,
+                      const int8_t *d_matrix, bool score_only_hint, BatchPlan &P)
 {
-    if (n == 0) return MGL_SW_OK;
     const bool uniform = geom != GEOM_MIXED;
-    if (n < 0 || !tset.data || !tset.off || !qset.data || !qset.off || !d_offset || !d_cigar || cigar_stride < 1 ||
-        max_tl < 1 || max_ql < 1 || !strategy_ok(strategy))
-        return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch_device: bad argument");
-    if (d_matrix) {
-        // substitution-matrix scoring: `match` / `mismatch` carry the largest / smallest matrix entry (range check and
-        // offset representation of the packed kernel); only the gap penalties go through the sign normalisation
-        int m1 = 1, m2 = -1;
-        mgl_sw_normalize_params(&m1, &m2, &gopen, &gext);
-    } else {
-        mgl_sw_normalize_params(&match, &mismatch, &gopen, &gext);
-    }
-
-    // small batches are latency bound (the coalesced one-pair-per-call traffic of alignNative): one wave per pair keeps the pair's H
-    // matrix in LDS, walks the path off it and writes the text, all in ONE launch that touches no workspace (sw_small.hip)
-    {
-        bool wide = false;
-        const bool unforced = ctx->precision == 0 && ctx->stripe_rows == 0 && ctx->cooperative == 0 && ctx->carry_memory == 0 && ctx->lane_kernel != 2 &&
-                              ctx->strip_kernel != 2 && ctx->lane_checkpoint != 1;
-        if (!hooks && !d_matrix && !score_only_hint && !binary_cigar && ctx->small_kernel != 1 &&
-            (ctx->small_kernel == 2 || (unforced && n <= MGL_SW_SMALL_BATCH_PAIRS)) &&
-            ((int64_t)match - mismatch + gopen + 2 * (int64_t)gext) * ((int64_t)max_tl + max_ql) < (1ll << 30) &&
-            small_supported(max_tl, max_ql, cigar_stride, match, mismatch, gopen, gext, &wide)) {
-            if (explain) {
-                mgl_sw_plan &pl = *explain;
-                pl = mgl_sw_plan{};
-                pl.fill_kernel = MGL_SW_KERNEL_SMALL;
-                pl.precision_bits = 32;
-                pl.rows = ((max_tl + 63) / 64 + 1) & ~1;
-                pl.waves_per_block = 1;
-                pl.waves_per_pair = 1;
-                pl.traceback = 1;
-                pl.fused_walk = 1;
-                pl.fill_streams = 1;
-                pl.workspace_halves = 1;
-                pl.chunk_pairs = n;
-                pl.chunks = 1;
-                return MGL_SW_OK;
-            }
-            HIP_TRY(ctx, hipSetDevice(ctx->device));
-            if (ctx->profiling == 3) {
-                ctx->timing.cells += cells_hint;
-            } else {
-                ctx->timing = mgl_sw_timing{};
-                ctx->timing.cells = cells_hint;
-                ctx->pool_used = 0;
-            }
-            TbArgs ta{};
-            ta.t = tset;
-            ta.q = qset;
-            ta.first = 0;
-            ta.count = n;
-            ta.strategy = strategy;
-            ta.match = match;
-            ta.mismatch = mismatch;
-            ta.gopen = gopen;
-            ta.gext = gext;
-            ta.offset = d_offset;
-            ta.score = d_score;
-            ta.cigar = d_cigar;
-            ta.cigar_stride = cigar_stride;
-            ta.cigar_len = d_cigar_len;
-            ta.status = d_status;
-            hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
-            if (ctx->profiling) {
-                while ((int)ctx->pool.size() < ctx->pool_used + 4) {
-                    hipEvent_t e = nullptr;
-                    HIP_TRY(ctx, hipEventCreate(&e));
-                    ctx->pool.push_back(e);
-                }
-                for (int i = 0; i < 4; ++i) pe[i] = ctx->pool[(size_t)ctx->pool_used + i];
-                ctx->pool_used += 4;
-                ctx->diag_blocks = 0;
-            }
-            if (pe[0]) HIP_TRY(ctx, hipEventRecord(pe[0], stream));
-            HIP_TRY(ctx, launch_small(ta, max_tl, max_ql, wide, stream));
-            for (int i = 1; i < 4; ++i)
-                if (pe[i]) HIP_TRY(ctx, hipEventRecord(pe[i], stream));
-            ctx->last_chunk_count = 0; // (nothing of the matrix leaves the chip: no slot to expand)
-            ctx->timing.dp_launches++;
-            ctx->timing.packed16 = 0;
-            ctx->timing.fill_kernel = MGL_SW_KERNEL_SMALL;
-            return MGL_SW_OK;
-        }
-    }
+    (void)cigar_stride;
+    (void)binary_cigar;
     // packed-int16 kernel: one geometry per batch (or per block of eight pairs) and a score range that fits 16 bits;
     // four waves per block while their LDS carve fits, else two or one
     const int lds_extra = d_matrix ? MATRIX_DIM * MATRIX_DIM * 2 : 0;
@@ -559,14 +507,6 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const int pyr_max = pyr_env ? atoi(pyr_env) : 8;
     const bool pyramid = use_lane && hooks && lane_rounds && !auto_group && tset.packed2 && pyr_max > 0 && pyr_fit >= 1;
     if (pyramid) chunk = pyr_unit * std::min<int64_t>(pyr_max, pyr_fit);
-    // the size of the chunk that starts at pair `first` as the k-th of the call
-    auto chunk_at = [&](int64_t first, int64_t k) -> int64_t {
-        const int64_t left = n - first;
-        if (!pyramid) return std::min(chunk, left);
-        const int64_t grow = std::min(chunk, pyr_unit << std::min<int64_t>(k, 8));
-        const int64_t half_left = std::max(pyr_unit, left / 2 / pyr_unit * pyr_unit); // (whole rounds; towards the end: half of what is left)
-        return std::min(left, std::min(grow, half_left));
-    };
     // strip kernel: one pair per workgroup of W waves at three waves per SIMD -- a chunk that is not a whole number of rounds of
     // the chip (n_cus * (12 / W) pairs) ends with a round in which most CUs idle (1 582 pairs per chunk ran as two rounds)
     if (strip16) {
@@ -580,6 +520,174 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const bool overlap = !fused_walk && n > chunk;
     const bool dual = dual_ok && n > chunk;
     const int halves = overlap || dual ? 2 : 1;
+    P.use_lane = use_lane;
+    P.lane_ck = lane_ck;
+    P.use16 = use16;
+    P.strip16 = strip16;
+    P.coop16 = coop16;
+    P.coop_waves = coop_waves;
+    P.strip_waves = strip_waves;
+    P.strip_k = strip_k;
+    P.strip_pack = strip_pack;
+    P.auto_group = auto_group;
+    P.lane_group = lane_group;
+    P.lane_group_stride = lane_group_stride;
+    P.score_only = score_only;
+    P.fused_walk = fused_walk;
+    P.use_scratch = use_scratch;
+    P.rows = rows;
+    P.wpb = wpb;
+    P.wpb16 = wpb16;
+    P.sps_cap = sps_cap;
+    P.sps32 = sps32;
+    P.stride_words = stride_words;
+    P.stride32_words = stride32_words;
+    P.per_pair = per_pair;
+    P.chunk = chunk;
+    P.pyramid = pyramid;
+    P.pyr_unit = pyr_unit;
+    P.overlap = overlap;
+    P.dual = dual;
+    P.halves = halves;
+    return MGL_SW_OK;
+}
+
+// Enqueue fill + traceback for a device-resident batch on `stream`.
+int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tset, const SeqSet &qset, int max_tl,
+               int max_ql, int match, int mismatch, int gopen, int gext, int strategy, int32_t *d_offset, Score *d_score,
+               char *d_cigar, int cigar_stride, int32_t *d_cigar_len, int32_t *d_status, int64_t cells_hint, int geom,
+               bool binary_cigar = false, const ChunkHooks *hooks = nullptr, const int8_t *d_matrix = nullptr,
+               const uint8_t *d_code = nullptr, bool score_only_hint = false, mgl_sw_plan *explain = nullptr)
+{
+    if (n == 0) return MGL_SW_OK;
+    if (n < 0 || !tset.data || !tset.off || !qset.data || !qset.off || !d_offset || !d_cigar || cigar_stride < 1 ||
+        max_tl < 1 || max_ql < 1 || !strategy_ok(strategy))
+        return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch_device: bad argument");
+    if (d_matrix) {
+        // substitution-matrix scoring: `match` / `mismatch` carry the largest / smallest matrix entry (range check and
+        // offset representation of the packed kernel); only the gap penalties go through the sign normalisation
+        int m1 = 1, m2 = -1;
+        mgl_sw_normalize_params(&m1, &m2, &gopen, &gext);
+    } else {
+        mgl_sw_normalize_params(&match, &mismatch, &gopen, &gext);
+    }
+
+    // small batches are latency bound (the coalesced one-pair-per-call traffic of alignNative): one wave per pair keeps the pair's H
+    // matrix in LDS, walks the path off it and writes the text, all in ONE launch that touches no workspace (sw_small.hip)
+    {
+        bool wide = false;
+        const bool unforced = ctx->precision == 0 && ctx->stripe_rows == 0 && ctx->cooperative == 0 && ctx->carry_memory == 0 && ctx->lane_kernel != 2 &&
+                              ctx->strip_kernel != 2 && ctx->lane_checkpoint != 1;
+        if (!hooks && !d_matrix && !score_only_hint && !binary_cigar && ctx->small_kernel != 1 &&
+            (ctx->small_kernel == 2 || (unforced && n <= MGL_SW_SMALL_BATCH_PAIRS)) &&
+            ((int64_t)match - mismatch + gopen + 2 * (int64_t)gext) * ((int64_t)max_tl + max_ql) < (1ll << 30) &&
+            small_supported(max_tl, max_ql, cigar_stride, match, mismatch, gopen, gext, &wide)) {
+            if (explain) {
+                mgl_sw_plan &pl = *explain;
+                pl = mgl_sw_plan{};
+                pl.fill_kernel = MGL_SW_KERNEL_SMALL;
+                pl.precision_bits = 32;
+                pl.rows = ((max_tl + 63) / 64 + 1) & ~1;
+                pl.waves_per_block = 1;
+                pl.waves_per_pair = 1;
+                pl.traceback = 1;
+                pl.fused_walk = 1;
+                pl.fill_streams = 1;
+                pl.workspace_halves = 1;
+                pl.chunk_pairs = n;
+                pl.chunks = 1;
+                return MGL_SW_OK;
+            }
+            HIP_TRY(ctx, hipSetDevice(ctx->device));
+            if (ctx->profiling == 3) {
+                ctx->timing.cells += cells_hint;
+            } else {
+                ctx->timing = mgl_sw_timing{};
+                ctx->timing.cells = cells_hint;
+                ctx->pool_used = 0;
+            }
+            TbArgs ta{};
+            ta.t = tset;
+            ta.q = qset;
+            ta.first = 0;
+            ta.count = n;
+            ta.strategy = strategy;
+            ta.match = match;
+            ta.mismatch = mismatch;
+            ta.gopen = gopen;
+            ta.gext = gext;
+            ta.offset = d_offset;
+            ta.score = d_score;
+            ta.cigar = d_cigar;
+            ta.cigar_stride = cigar_stride;
+            ta.cigar_len = d_cigar_len;
+            ta.status = d_status;
+            hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
+            if (ctx->profiling) {
+                while ((int)ctx->pool.size() < ctx->pool_used + 4) {
+                    hipEvent_t e = nullptr;
+                    HIP_TRY(ctx, hipEventCreate(&e));
+                    ctx->pool.push_back(e);
+                }
+                for (int i = 0; i < 4; ++i) pe[i] = ctx->pool[(size_t)ctx->pool_used + i];
+                ctx->pool_used += 4;
+                ctx->diag_blocks = 0;
+            }
+            if (pe[0]) HIP_TRY(ctx, hipEventRecord(pe[0], stream));
+            HIP_TRY(ctx, launch_small(ta, max_tl, max_ql, wide, stream));
+            for (int i = 1; i < 4; ++i)
+                if (pe[i]) HIP_TRY(ctx, hipEventRecord(pe[i], stream));
+            ctx->last_chunk_count = 0; // (nothing of the matrix leaves the chip: no slot to expand)
+            ctx->timing.dp_launches++;
+            ctx->timing.packed16 = 0;
+            ctx->timing.fill_kernel = MGL_SW_KERNEL_SMALL;
+            return MGL_SW_OK;
+        }
+    }
+    // ---- the plan (plan_batch above: pure), then its execution
+    BatchPlan P{};
+    {
+        const int prc = plan_batch(ctx, n, tset, qset, max_tl, max_ql, match, mismatch, gopen, gext, strategy, d_score, d_cigar, cigar_stride, geom, binary_cigar, hooks,
+                                   d_matrix, score_only_hint, P);
+        if (prc != MGL_SW_OK) return prc;
+    }
+    const bool use_lane = P.use_lane;
+    const bool lane_ck = P.lane_ck;
+    const bool use16 = P.use16;
+    const bool strip16 = P.strip16;
+    const bool coop16 = P.coop16;
+    const int coop_waves = P.coop_waves;
+    const int strip_waves = P.strip_waves;
+    const int strip_k = P.strip_k;
+    const int strip_pack = P.strip_pack;
+    const bool auto_group = P.auto_group;
+    const bool lane_group = P.lane_group;
+    const int64_t lane_group_stride = P.lane_group_stride;
+    const bool score_only = P.score_only;
+    const bool fused_walk = P.fused_walk;
+    const bool use_scratch = P.use_scratch;
+    const int rows = P.rows;
+    const int wpb = P.wpb;
+    const int wpb16 = P.wpb16;
+    const int sps_cap = P.sps_cap;
+    const int sps32 = P.sps32;
+    const int64_t stride_words = P.stride_words;
+    const int64_t stride32_words = P.stride32_words;
+    const int64_t per_pair = P.per_pair;
+    const int64_t chunk = P.chunk;
+    const bool pyramid = P.pyramid;
+    const int64_t pyr_unit = P.pyr_unit;
+    const bool overlap = P.overlap;
+    const bool dual = P.dual;
+    const int halves = P.halves;
+    // the size of the chunk that starts at pair `first` as the k-th of the call
+    auto chunk_at = [&](int64_t first, int64_t k) -> int64_t {
+        const int64_t left = n - first;
+        if (!pyramid) return std::min(chunk, left);
+        const int64_t grow = std::min(chunk, pyr_unit << std::min<int64_t>(k, 8));
+        const int64_t half_left = std::max(pyr_unit, left / 2 / pyr_unit * pyr_unit); // (whole rounds; towards the end: half of what is left)
+        return std::min(left, std::min(grow, half_left));
+    };
     if (explain) { // mgl_sw_explain: everything above is pure (the context's settings and the batch's description); nothing below is
         mgl_sw_plan &pl = *explain;
         pl = mgl_sw_plan{};
