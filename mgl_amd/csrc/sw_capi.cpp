@@ -78,6 +78,7 @@ struct mgl_sw_ctx {
     size_t pin_res_cap[3] = {0, 0, 0};
     hipEvent_t res_copied[3] = {nullptr, nullptr, nullptr};
     hipStream_t d2h = nullptr;
+    hipStream_t h2d_hi = nullptr, d2h_hi = nullptr; // the same two at the highest priority (queues of their own): mgl_sw_align_batch_2bit swaps them in
     void *pin_grp[2] = {nullptr, nullptr};
     size_t pin_grp_cap[2] = {0, 0};
     DevBuf d_grp[2];
@@ -1100,6 +1101,15 @@ int mgl_sw_ctx_create(int device, mgl_sw_ctx **out)
     bool ok = hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, prio_lo) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&ctx->h2d, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&ctx->fill2, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&ctx->d2h, hipStreamNonBlocking) == hipSuccess;
+    // The runtime spreads a process's streams over four hardware queues, and which of this context's four (fills on two, copies in,
+    // copies out) end up sharing one depends on what else the process has created before: behind torch.cuda.set_device the packed host
+    // entry ran at 5 120 GCUPS, with the context created first at 5 770 (scripts/host_packed_probe.py) -- a copy stream sat behind a fill
+    // stream's kernels.  Its copies are small and its pipeline short, so that entry uses copy streams of the HIGHEST priority, which have
+    // queues of their own: 5 590-5 610 whatever the order.  (The ASCII / mixed entry keeps the ordinary ones: its copies are the bulk of
+    // its time, and its mixed batches lose 3 % behind high-priority copies.)
+    ok = ok && hipStreamCreateWithPriority(&ctx->h2d_hi, hipStreamNonBlocking, prio_hi) == hipSuccess;
+    ok = ok && hipStreamCreateWithPriority(&ctx->d2h_hi, hipStreamNonBlocking, prio_hi) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ctx->in_done, hipEventDisableTiming) == hipSuccess;
     for (auto &e : ctx->out_ready) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -1138,6 +1148,8 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
         if (ctx->res_copied[r]) (void)hipEventDestroy(ctx->res_copied[r]);
     }
     if (ctx->d2h) (void)hipStreamDestroy(ctx->d2h);
+    if (ctx->h2d_hi) (void)hipStreamDestroy(ctx->h2d_hi);
+    if (ctx->d2h_hi) (void)hipStreamDestroy(ctx->d2h_hi);
     for (int h = 0; h < 2; ++h) {
         if (ctx->pin_grp[h]) (void)hipHostFree(ctx->pin_grp[h]);
         if (ctx->grp_copied[h]) (void)hipEventDestroy(ctx->grp_copied[h]);
@@ -1847,6 +1859,18 @@ int mgl_sw_align_batch_2bit(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_ba
     if (!ctx) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (n == 0) return MGL_SW_OK;
+    // this entry's copies go over the high-priority copy streams (mgl_sw_ctx_create says why); everything it enqueues on them has
+    // completed when it returns
+    struct CopyStreams {
+        mgl_sw_ctx *c;
+        explicit CopyStreams(mgl_sw_ctx *c_) : c(c_) { swap(); }
+        ~CopyStreams() { swap(); }
+        void swap() const
+        {
+            std::swap(c->h2d, c->h2d_hi);
+            std::swap(c->d2h, c->d2h_hi);
+        }
+    } const copy_streams(ctx);
     const bool uniform = (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) != 0, grouped = (flags & MGL_SW_FLAG_GROUPED_GEOMETRY) != 0;
     if (n < 0 || !target_bases || !t_start || !query_bases || !q_start || !offset_out || !cigar_out || cigar_stride < 1 || max_tl < 1 || max_ql < 1 ||
         target_base_count < 1 || query_base_count < 1 || !strategy_ok(strategy) || ((!t_len || !q_len) && !uniform))
