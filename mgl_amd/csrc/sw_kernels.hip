@@ -984,26 +984,40 @@ __device__ __forceinline__ int regroup_cell(const RegroupArgs &a, int64_t p)
 // sort lost a third of its speed behind that L2 channel.  So a block of 1024 pairs first counts its cells in an LDS hash
 // table (LDS atomics), then adds each distinct cell's count to the global counter once; a pair's rank is the block's base
 // for the cell plus its rank inside the block.
-constexpr int RG_BLOCK = 1024, RG_TABLE = 2048;
+// A workgroup takes RG_TILES tiles of 1024 pairs through ONE table: 4 M unsorted reads of 51 lengths in blocks of 1 024 pairs were
+// still 200 000 global adds on 51 addresses -- 0.93 ms for the count and 0.95 for the scatter where nothing else ran; eight tiles per
+// workgroup leave an eighth of them.  A pair whose cell finds no place in the table (more distinct cells in 8 192 pairs than the
+// table holds: not with read lengths, possible with arbitrary batches) adds to the global counter itself.
+constexpr int RG_BLOCK = 1024, RG_TABLE = 2048, RG_TILES = 8;
 struct RegroupTable {
     int key[RG_TABLE], num[RG_TABLE], base[RG_TABLE];
 };
-__device__ __forceinline__ int regroup_take(int32_t *cnt, int c, bool valid, RegroupTable &tab, bool want_rank)
+// the pairs of this thread: k0 + u * RG_BLOCK, u = 0 .. RG_TILES - 1; c[u] their cells, valid[u].  want_rank: rank[u] = the pair's
+// rank among the pairs of its cell (whatever order the atomics give).
+__device__ __forceinline__ void regroup_take(int32_t *cnt, const int (&c)[RG_TILES], const bool (&valid)[RG_TILES], RegroupTable &tab, bool want_rank, int (&rank)[RG_TILES])
 {
     for (int x = threadIdx.x; x < RG_TABLE; x += blockDim.x) {
         tab.key[x] = -1;
         tab.num[x] = 0;
     }
     __syncthreads();
-    int h = (int)(((unsigned)c * 2654435761u) >> 21) & (RG_TABLE - 1), local = 0;
-    if (valid) {
-        for (;;) {
-            const int old = atomicCAS(&tab.key[h], -1, c);
-            if (old == -1 || old == c) {
-                local = atomicAdd(&tab.num[h], 1);
-                break;
+    int slot[RG_TILES], local[RG_TILES];
+#pragma unroll
+    for (int u = 0; u < RG_TILES; ++u) {
+        slot[u] = -1;
+        local[u] = 0;
+        if (valid[u]) {
+            int h = (int)(((unsigned)c[u] * 2654435761u) >> 21) & (RG_TABLE - 1);
+            for (int probes = 0; probes < RG_TABLE; ++probes) {
+                const int old = atomicCAS(&tab.key[h], -1, c[u]);
+                if (old == -1 || old == c[u]) {
+                    local[u] = atomicAdd(&tab.num[h], 1);
+                    slot[u] = h;
+                    break;
+                }
+                h = (h + 1) & (RG_TABLE - 1);
             }
-            h = (h + 1) & (RG_TABLE - 1); // (at most 1024 distinct keys in 2048 entries: the probe ends)
+            if (slot[u] < 0) local[u] = atomicAdd(cnt + c[u], 1); // (the table is full of other cells: this pair counts for itself)
         }
     }
     __syncthreads();
@@ -1015,14 +1029,22 @@ __device__ __forceinline__ int regroup_take(int32_t *cnt, int c, bool valid, Reg
                 atomicAdd(cnt + tab.key[x], tab.num[x]);
         }
     __syncthreads();
-    return valid && want_rank ? tab.base[h] + local : 0;
+#pragma unroll
+    for (int u = 0; u < RG_TILES; ++u) rank[u] = !valid[u] || !want_rank ? 0 : slot[u] >= 0 ? tab.base[slot[u]] + local[u] : local[u];
 }
 __global__ __launch_bounds__(RG_BLOCK) void sw_regroup_count_kernel(const RegroupArgs a)
 {
     __shared__ RegroupTable tab;
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = k < a.count;
-    (void)regroup_take(a.cnt, valid ? regroup_cell(a, a.first + k) : 0, valid, tab, false);
+    const int64_t k0 = (int64_t)blockIdx.x * (RG_BLOCK * RG_TILES) + threadIdx.x;
+    int c[RG_TILES], rank[RG_TILES];
+    bool valid[RG_TILES];
+#pragma unroll
+    for (int u = 0; u < RG_TILES; ++u) {
+        const int64_t k = k0 + (int64_t)u * RG_BLOCK;
+        valid[u] = k < a.count;
+        c[u] = valid[u] ? regroup_cell(a, a.first + k) : 0;
+    }
+    regroup_take(a.cnt, c, valid, tab, false, rank);
 }
 // one workgroup: exclusive prefix sums over the grid, 1024 cells at a time, of the pairs in blocks of 128 (lane_blocks only), of
 // the pairs in the remaining full blocks of eight, and of the left-over pairs; full_start is relative to the end of the blocks
@@ -1090,27 +1112,37 @@ __global__ __launch_bounds__(1024) void sw_regroup_scan_kernel(const RegroupArgs
 __global__ __launch_bounds__(RG_BLOCK) void sw_regroup_scatter_kernel(const RegroupArgs a)
 {
     __shared__ RegroupTable tab;
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = k < a.count;
-    const int64_t p = a.first + (valid ? k : 0);
-    const int c = regroup_cell(a, p);
-    const int pos = regroup_take(a.cnt, c, valid, tab, true);
-    if (!valid) return;
-    const int nl = a.nlane[c], nf = a.nfull[c];
-    const int64_t slot = pos < nl ? a.total[1] + a.lane_start[c] + pos
-                         : pos < nf ? a.total[1] + a.full_start[c] + (pos - nl) : a.total[0] + a.rest_start[c] + (pos - nf);
-    a.t_start[slot] = a.t.off[p];
-    a.q_start[slot] = a.q.off[p];
-    a.dest[slot] = p;
-    a.t_len[slot] = a.t.length(p);
-    a.q_len[slot] = a.q.length(p);
+    const int64_t k0 = (int64_t)blockIdx.x * (RG_BLOCK * RG_TILES) + threadIdx.x;
+    int c[RG_TILES], rank[RG_TILES];
+    bool valid[RG_TILES];
+#pragma unroll
+    for (int u = 0; u < RG_TILES; ++u) {
+        const int64_t k = k0 + (int64_t)u * RG_BLOCK;
+        valid[u] = k < a.count;
+        c[u] = regroup_cell(a, a.first + (valid[u] ? k : 0));
+    }
+    regroup_take(a.cnt, c, valid, tab, true, rank);
+#pragma unroll
+    for (int u = 0; u < RG_TILES; ++u) {
+        if (!valid[u]) continue;
+        const int64_t p = a.first + k0 + (int64_t)u * RG_BLOCK;
+        const int cc = c[u], pos = rank[u];
+        const int nl = a.nlane[cc], nf = a.nfull[cc];
+        const int64_t slot = pos < nl ? a.total[1] + a.lane_start[cc] + pos
+                             : pos < nf ? a.total[1] + a.full_start[cc] + (pos - nl) : a.total[0] + a.rest_start[cc] + (pos - nf);
+        a.t_start[slot] = a.t.off[p];
+        a.q_start[slot] = a.q.off[p];
+        a.dest[slot] = p;
+        a.t_len[slot] = a.t.length(p);
+        a.q_len[slot] = a.q.length(p);
+    }
 }
 
 hipError_t launch_regroup(const RegroupArgs &a, hipStream_t stream)
 {
     hipError_t e = hipMemsetAsync(a.cnt, 0, (size_t)a.max_tl * a.max_ql * 4, stream);
     if (e != hipSuccess) return e;
-    const unsigned blocks = (unsigned)((a.count + RG_BLOCK - 1) / RG_BLOCK);
+    const unsigned blocks = (unsigned)((a.count + RG_BLOCK * RG_TILES - 1) / (RG_BLOCK * RG_TILES));
     hipLaunchKernelGGL(sw_regroup_count_kernel, dim3(blocks), dim3(RG_BLOCK), 0, stream, a);
     hipLaunchKernelGGL(sw_regroup_scan_kernel, dim3(1), dim3(1024), 0, stream, a);
     hipLaunchKernelGGL(sw_regroup_scatter_kernel, dim3(blocks), dim3(RG_BLOCK), 0, stream, a);
