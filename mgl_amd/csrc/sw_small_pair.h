@@ -140,7 +140,12 @@ struct KeptScores {
 // The fill.  Values carry the offset (i + j) * gext - base: every decision compares values of one cell, so the decisions are those of
 // sw.cpp:51-96, but extending a gap needs no instruction, both new gaps start from the same H - (o - e), and the constant `base`
 // (it enters through the borders and travels with every maximum) centres the range of the 16-bit form.
-template <int R, bool WIDE>
+// CODES: the staged sequences hold base codes -- a target base its code 0 .. 3, a query base its code or 4 for a byte that is none of
+// ACGT (small_pair stages them so when every target byte is one of ACGT) -- and "do the bases differ" is looked up four columns at a
+// time: one v_perm_b32 per row and block of four steps (the row's table: byte c = 0 iff the target base has code c; the selector:
+// the four query codes; code 4 selects the constant 1), then a multiply and a three-operand add per cell where the byte compare
+// took a compare, a select and an add.  Raw bytes (CODES = false) are compared as they are (sw.cpp:55: N == N, a != A).
+template <int R, bool WIDE, bool CODES>
 __device__ __forceinline__ void small_fill(const SmallGeom &g, uint32_t *hm, const uint8_t *ts, const uint8_t *qs, const int lane)
 {
     const int i0 = R * lane; // the row above this lane's first row
@@ -151,12 +156,16 @@ __device__ __forceinline__ void small_fill(const SmallGeom &g, uint32_t *hm, con
         const int i = i0 + 1 + r;
         h[r] = edge_score(i, g.gopen, gext, g.indel) + i * gext - g.base; // V[i][0]
         f[r] = h[r] - o_e;                                                 // F[i][1] (sw.cpp:47-49)
-        tb[r] = i <= g.tl ? (int)ts[i - 1] : 0x100;                        // rows past tl: never equal to a query byte; their scores go nowhere
+        if (CODES)
+            tb[r] = i <= g.tl ? (int)(0x01010101u ^ (1u << (8 * (ts[i - 1] & 3)))) : 0x01010101; // the row's table; rows past tl differ from everything
+        else
+            tb[r] = i <= g.tl ? (int)ts[i - 1] : 0x100; // rows past tl: never equal to a query byte; their scores go nowhere
     }
     int up_diag = edge_score(i0, g.gopen, gext, g.indel) + i0 * gext - g.base; // V[i0][j-1]: column 0 until this lane starts
     int e_bot = 0;                                                             // E leaving this lane's last row, as of the previous step
     int match2 = g.match + 2 * gext, mismatch2 = g.mismatch + 2 * gext;        // the diagonal moves the offset by 2 e
-    asm volatile("" : "+v"(match2), "+v"(mismatch2));
+    int delta = g.mismatch - g.match;
+    asm volatile("" : "+v"(match2), "+v"(mismatch2), "+v"(delta));
     const int steps = ql + g.nl - 1;
     const unsigned my_ql = lane < g.nl ? (unsigned)ql : 0u; // lanes without rows never start
     uint32_t *wp = hm + (WIDE ? i0 : (i0 >> 1)) - lane * CS;  // column j - 1 = s - lane: + s * CS
@@ -187,6 +196,11 @@ __device__ __forceinline__ void small_fill(const SmallGeom &g, uint32_t *hm, con
         qd += 1;
         q_lo = qd[0]; // (used one block later: by then four steps of stores sit behind it in the queue, nothing waits)
         q_hi = qd[1];
+        uint32_t differ4[R]; // CODES: byte u = 1 where the row's base and the query base of step u differ
+        if (CODES) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) differ4[r] = __builtin_amdgcn_perm(0x01010101u, (uint32_t)tb[r], qw);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = s0 + u - lane + 1;
@@ -195,9 +209,15 @@ __device__ __forceinline__ void small_fill(const SmallGeom &g, uint32_t *hm, con
             up_e = from_lane_below(up_e + edge_step, e_bot);    // E[i0 + 1][j] (row 0: sw.cpp:31-35)
             if (!MASKED || (unsigned)(j - 1) < my_ql) {
                 int diag[R];
-                diag[0] = up_diag + (tb[0] == qb ? match2 : mismatch2); // sw.cpp:55
+                if (CODES) { // sw.cpp:55 by lookup
+                    diag[0] = up_diag + match2 + (int)((differ4[0] >> (8 * u)) & 0xffu) * delta;
 #pragma unroll
-                for (int r = 1; r < R; ++r) diag[r] = h[r - 1] + (tb[r] == qb ? match2 : mismatch2);
+                    for (int r = 1; r < R; ++r) diag[r] = h[r - 1] + match2 + (int)((differ4[r] >> (8 * u)) & 0xffu) * delta;
+                } else {
+                    diag[0] = up_diag + (tb[0] == qb ? match2 : mismatch2); // sw.cpp:55
+#pragma unroll
+                    for (int r = 1; r < R; ++r) diag[r] = h[r - 1] + (tb[r] == qb ? match2 : mismatch2);
+                }
                 up_diag = up_h;
                 int e_run = up_e;
 #pragma unroll
@@ -336,13 +356,33 @@ __device__ __forceinline__ void small_pair(const TbArgs &a, const int64_t o, con
 #endif
     // the bases come over the link when the batch sits in pinned host memory (the coalescing front-end's): every load of a
     // sequence is in flight before the first one is used -- one round trip, not one per 64 bases
-    for (int x0 = 0; x0 < tl; x0 += 512) {
+    // Base codes where the target allows it: A 0, C 1, T 2, G 3 (bits 1 and 2 of the letter); a byte is "one of ACGT" when the letter of
+    // its code is the byte itself.  The whole target (at most 512 bytes) is in registers before the wave decides.
+    auto code_of = [](int b, bool &is_base) {
+        const int c = (b >> 1) & 3;
+        is_base = (int)((0x47544341u >> (8 * c)) & 0xffu) == b;
+        return c;
+    };
+    bool codes;
+    {
         int v[8];
+        bool bad = false;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = x0 + 64 * k + lane < tl ? a.t.at(t0, x0 + 64 * k + lane) : 0;
+        for (int k = 0; k < 8; ++k) v[k] = 64 * k + lane < tl ? a.t.at(t0, 64 * k + lane) : 'A';
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            bool ok;
+            (void)code_of(v[k], ok);
+            bad |= !ok;
+        }
+        codes = __builtin_amdgcn_ballot_w64(bad) == 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            if (x0 + 64 * k + lane < tl) ts[x0 + 64 * k + lane] = (uint8_t)v[k];
+            if (64 * k + lane < tl) {
+                bool ok;
+                const int c = code_of(v[k], ok);
+                ts[64 * k + lane] = (uint8_t)(codes ? c : v[k]);
+            }
     }
     for (int x0 = 0; x0 < ql; x0 += 512) {
         int v[8];
@@ -350,7 +390,11 @@ __device__ __forceinline__ void small_pair(const TbArgs &a, const int64_t o, con
         for (int k = 0; k < 8; ++k) v[k] = x0 + 64 * k + lane < ql ? a.q.at(q0, x0 + 64 * k + lane) : 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            if (x0 + 64 * k + lane < ql) qs[x0 + 64 * k + lane] = (uint8_t)v[k];
+            if (x0 + 64 * k + lane < ql) {
+                bool ok;
+                const int c = code_of(v[k], ok);
+                qs[x0 + 64 * k + lane] = (uint8_t)(codes ? (ok ? c : 4) : v[k]);
+            }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -358,10 +402,17 @@ __device__ __forceinline__ void small_pair(const TbArgs &a, const int64_t o, con
 
 #define MGL_SMALL_FILL(RR)                                                                  \
     case RR:                                                                                \
-        if (g.wide)                                                                         \
-            small_fill<RR, true>(g, hm, ts, qs, lane);                                      \
-        else                                                                                \
-            small_fill<RR, false>(g, hm, ts, qs, lane);                                     \
+        if (g.wide) {                                                                       \
+            if (codes)                                                                      \
+                small_fill<RR, true, true>(g, hm, ts, qs, lane);                            \
+            else                                                                            \
+                small_fill<RR, true, false>(g, hm, ts, qs, lane);                           \
+        } else {                                                                            \
+            if (codes)                                                                      \
+                small_fill<RR, false, true>(g, hm, ts, qs, lane);                           \
+            else                                                                            \
+                small_fill<RR, false, false>(g, hm, ts, qs, lane);                          \
+        }                                                                                   \
         break;
     switch (g.R) {
         MGL_SMALL_FILL(2)

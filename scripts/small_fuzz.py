@@ -40,6 +40,9 @@ for gi in range(n_geo):
             sub = rng.random(len(src)) < 0.04
             src[sub] = alpha[rng.integers(0, 4, int(sub.sum()))]
             q = src[:qlk]
+        if k % 7 == 3:   # bytes outside ACGT in the QUERY alone (a target of ACGT is staged as base codes: such a byte must differ from every base)
+            q = q.copy()
+            q[rng.integers(0, len(q), 1 + len(q) // 40)] = np.frombuffer(b"NaRc", np.uint8)[rng.integers(0, 4, 1 + len(q) // 40)]
         ts.append(t.tobytes()); qs.append(q.tobytes())
     res = a.align_batch(ts, qs, params, strategy)
     took = a.timing().fill_kernel == 8
