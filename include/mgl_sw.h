@@ -152,13 +152,15 @@ int mgl_sw_ctx_set_lane_kernel(mgl_sw_ctx *ctx, int mode);
  * (chunks sorted by geometry, from two rounds of the chip on); 1 = never (the flags of every cell are stored: needed before
  * mgl_sw_ctx_expand_slot); 2 = same as 0 (tests) */
 int mgl_sw_ctx_set_lane_checkpoint(mgl_sw_ctx *ctx, int mode);
-/* small batches are latency bound: up to MGL_SW_SMALL_BATCH_PAIRS pairs whose targets have at most 512 rows and whose matrix of kept
+/* small batches are latency bound: up to MGL_SW_SMALL_BATCH_PAIRS pairs (MGL_SW_SMALL_BATCH_PAIRS_MIXED without a promise of one geometry:
+ * measured crossovers, scripts/small_batch_probe.py) whose targets have at most 512 rows and whose matrix of kept
  * scores fits a workgroup's LDS (256 x 150, 400 x 190, ...) run one wave per pair in ONE launch that fills, walks and writes the text
  * (sw_small.hip; nothing of the workspace is touched).  0 (default) = those batches, on a context none of whose other kernel
  * choices has been forced; 1 = never; 2 = every batch whose bounds allow it, whatever its size and the other settings (the
  * coalescing front-end of mgl_sw_align) */
 int mgl_sw_ctx_set_small_kernel(mgl_sw_ctx *ctx, int mode);
-#define MGL_SW_SMALL_BATCH_PAIRS 2048
+#define MGL_SW_SMALL_BATCH_PAIRS 5120
+#define MGL_SW_SMALL_BATCH_PAIRS_MIXED 8192
 /* 1 = HIP events around every kernel launch of a call, on the streams the kernels run on, read back by
  * mgl_sw_ctx_get_timing (the call itself stays asynchronous); 2 = additionally stamp the shader clock
  * inside the fill kernel (diagnostic; a few extra instructions per workgroup); 3 = as 1, summed over every call until

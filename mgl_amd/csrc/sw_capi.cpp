@@ -577,10 +577,13 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // matrix in LDS, walks the path off it and writes the text, all in ONE launch that touches no workspace (sw_small.hip)
     {
         bool wide = false;
+        // (the crossovers were measured where two pairs' matrices share a CU's LDS: a geometry that leaves room for one halves them)
+        const int64_t small_limit = (geom == GEOM_MIXED ? MGL_SW_SMALL_BATCH_PAIRS_MIXED : MGL_SW_SMALL_BATCH_PAIRS) /
+                                    (small_lds_bytes(max_tl, max_ql, cigar_stride, !small_fits_int16(max_tl, max_ql, match, mismatch, gopen, gext)) > 80 * 1024 ? 2 : 1);
         const bool unforced = ctx->precision == 0 && ctx->stripe_rows == 0 && ctx->cooperative == 0 && ctx->carry_memory == 0 && ctx->lane_kernel != 2 &&
                               ctx->strip_kernel != 2 && ctx->lane_checkpoint != 1;
         if (!hooks && !d_matrix && !score_only_hint && !binary_cigar && ctx->small_kernel != 1 &&
-            (ctx->small_kernel == 2 || (unforced && n <= MGL_SW_SMALL_BATCH_PAIRS)) &&
+            (ctx->small_kernel == 2 || (unforced && n <= small_limit)) &&
             ((int64_t)match - mismatch + gopen + 2 * (int64_t)gext) * ((int64_t)max_tl + max_ql) < (1ll << 30) &&
             small_supported(max_tl, max_ql, cigar_stride, match, mismatch, gopen, gext, &wide)) {
             if (explain) {

@@ -24,8 +24,12 @@ def test_small_batches_take_one_wave_per_pair_in_one_launch():
     """sw_small.hip: up to MGL_SW_SMALL_BATCH_PAIRS pairs, targets of at most 512 rows, the matrix of scores within a workgroup's LDS."""
     p = plan(n=16, max_tl=256, max_ql=150, parameters=GATK)    # a coalesced batch of alignNative calls
     assert p.fill_kernel == SMALL and p.waves_per_pair == 1 and p.fused_walk == 1 and p.traceback == 1 and p.workspace_bytes == 0
-    assert plan(n=2048, max_tl=256, max_ql=150, parameters=GATK).fill_kernel == SMALL
-    assert plan(n=2049, max_tl=256, max_ql=150, parameters=GATK).fill_kernel != SMALL
+    # (measured crossovers, scripts/small_batch_probe.py: 256 x 150 pairs, 241 us against 348 at 4 096 pairs, 464 against 363 at 8 192 with one
+    # geometry promised -- 455 against 523 without)
+    assert plan(n=8192, max_tl=256, max_ql=150, parameters=GATK).fill_kernel == SMALL
+    assert plan(n=8193, max_tl=256, max_ql=150, parameters=GATK).fill_kernel != SMALL
+    assert plan(n=5120, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM).fill_kernel == SMALL
+    assert plan(n=5121, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM).fill_kernel != SMALL
     assert plan(n=16, max_tl=513, max_ql=100, parameters=GATK).fill_kernel != SMALL, "more than 512 rows"
     assert plan(n=16, max_tl=512, max_ql=400, parameters=GATK).fill_kernel != SMALL, "the scores do not fit LDS"
     assert plan(n=16, max_tl=256, max_ql=150, parameters=GATK, flags=SCORE_ONLY).fill_kernel != SMALL
