@@ -108,6 +108,7 @@ int main()
     const Expect em = expect(mixed, MGL_SW_OS_SOFTCLIP);
     mgl_sw_ctx *ctx = nullptr;
     CHECK(mgl_sw_ctx_create(0, &ctx) == 0);
+    CHECK(mgl_sw_ctx_set_small_kernel(ctx, 1) == 0); // (these batches of a few thousand pairs are here for the chunked paths, not for the one-wave-per-pair kernel)
     for (int stride : {128, 4}) {
         CHECK(mgl_sw_ctx_set_workspace(ctx, 96ll << 20) == 0); // ~2 200 pairs per half: three chunks, the halves are reused
         const int64_t n = mixed.n();
