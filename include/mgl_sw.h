@@ -206,8 +206,9 @@ int mgl_sw_set_coalescing(int max_batch, int max_wait_us);
 int mgl_sw_coalescing_stats(int64_t *batches, int64_t *pairs);
 /*
  * ... and in front of the coalescer, for pairs of the size GATK sends (targets up to 512 bases, queries up to 2 048, the matrix of
- * scores within a workgroup's LDS: 256 x 150, 400 x 190, ...): every calling thread leases a MAILBOX in pinned host memory and one
- * resident wave that serves it (sw_service.hip).  A call writes its pair into the mailbox and spins until the wave hands the
+ * scores within a workgroup's LDS: 256 x 150, 400 x 190, ...): every calling thread leases a MAILBOX -- its request half in device
+ * memory the host stores into over the large BAR where the platform has one (MGL_SW_SERVICE_BAR=0: never), else in pinned host
+ * memory; its reply half in pinned host memory -- and one resident wave that serves it (sw_service.hip).  A call writes its pair into the mailbox and spins until the wave hands the
  * result back: no kernel launch, no stream synchronisation and no other thread on the request path (this replaces the
  * launch-per-call of ..._MicrosoftSmithWaterman.cpp:44-71's callers).  A wave ends by itself when its mailbox has been quiet for
  * idle_us (default 1 000; environment MGL_SW_SERVICE_IDLE_US) or after MGL_SW_SERVICE_LIFE_MS (default 50) -- a resident
