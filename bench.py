@@ -36,7 +36,9 @@ from mgl_amd import device_batch, dist  # noqa: E402
 from mgl_amd.smithwaterman import GATK_PARAMETERS, MicrosoftSmithWaterman, SWOverhangStrategy  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
-DEFAULT_WORKSPACE_GIB = 208.0  # the 10 M-pair batch of configs[1] is ONE launch of the lane kernel (the card has 288 GB)
+DEFAULT_WORKSPACE_GIB = 8.0  # the 10 M-pair batch of configs[1] is ONE launch: a persistent grid of 2 048 waves, 2 MB of workspace each + 32 B per pair = 4.5 GB (round 3: 208 GiB)
+PCIE_WORKSPACE_GIB = 12.0    # the host entries run two launches side by side (two workspace halves): 2 048 wave slots each
+TL1000_WORKSPACE_GIB = 24.0  # tl = 1000: 7.3 MB per wave slot
 
 
 def algorithmic_bytes_per_pair(tl, ql, packed2=False, traceback_spilled=False, cigar_bytes=0.0):
@@ -254,6 +256,7 @@ def pcie_inclusive_leg(aligner, batch, args):
     from mgl_amd import _lib
 
     n, tl, ql, stride = batch.n, batch.max_tl, batch.max_ql, batch.cigar_stride
+    aligner.set_workspace(int(max(args.workspace_gib, PCIE_WORKSPACE_GIB) * (1 << 30)))
     t, q = batch.targets.cpu().numpy(), batch.queries.cpu().numpy()
     toff, qoff = batch.t_off.cpu().numpy(), batch.q_off.cpu().numpy()
     off, sc = np.zeros(n, np.int32), np.zeros((n, 6), np.int32)
@@ -333,6 +336,7 @@ def tl1000_leg(aligner, args, dev):
     """the tl = 1000 variant of config 2 (same cell count: pairs/4 windows of 1000 bases), device resident
     like the headline, cross-checked against the CPU checker on a sample."""
     n = max(8, args.pairs * args.tl // 1000 // 8 * 8)
+    aligner.set_workspace(int(max(args.workspace_gib, TL1000_WORKSPACE_GIB) * (1 << 30)))
     b = device_batch.window_batch(args.seed, n, dev, window=1000, read_len=args.ql)
     b.run(aligner, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP)
     torch.cuda.synchronize(dev)
@@ -369,7 +373,7 @@ def main():
     ap.add_argument("--tl", type=int, default=256, help="reference window length")
     ap.add_argument("--ql", type=int, default=150, help="read length")
     ap.add_argument("--workspace-gib", type=float, default=None,
-                    help=f"workspace per GPU; default: {DEFAULT_WORKSPACE_GIB:.0f} GiB (the 10 M-pair batch is one launch; the card has 288 GB), "
+                    help=f"workspace per GPU for the headline; default: {DEFAULT_WORKSPACE_GIB:.0f} GiB (the 10 M-pair batch is one launch of a persistent grid), "
                          "or what the card has free beside the batch if that is less")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (long reads, PairHMM, protein)")

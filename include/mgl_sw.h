@@ -96,7 +96,9 @@ typedef struct mgl_sw_plan {
     int64_t chunk_pairs;        /* pairs per launch */
     int64_t chunks;             /* launches of the fill kernel for this batch */
     int64_t workspace_bytes_per_pair;
-    int64_t workspace_bytes;    /* of the context's workspace that this batch would use */
+    int64_t workspace_bytes;    /* of the context's workspace that this batch would use (per-pair bytes of a chunk + the fixed part, per half) */
+    int64_t workspace_fixed_bytes; /* of those, the part that does not grow with the batch: the regions of sw_dp16_lane_ck_kernel's persistent grid, one per wave slot */
+    int64_t resident_waves;     /* wave slots of that grid (0: the kernel is launched one wave or workgroup per unit of work) */
 } mgl_sw_plan;
 
 typedef struct mgl_sw_ctx mgl_sw_ctx; /* opaque: one GPU, its workspace and stream */

@@ -47,7 +47,7 @@ class Plan(C.Structure):
     """mgl_sw_plan: what the library would do with a batch (mgl_sw_explain)."""
     _fields_ = [(n, C.c_int32) for n in ("fill_kernel", "precision_bits", "rows", "waves_per_block", "waves_per_pair", "traceback", "fused_walk",
                                          "sorted_by_library", "fill_streams", "workspace_halves")] + [
-        (n, C.c_int64) for n in ("chunk_pairs", "chunks", "workspace_bytes_per_pair", "workspace_bytes")]
+        (n, C.c_int64) for n in ("chunk_pairs", "chunks", "workspace_bytes_per_pair", "workspace_bytes", "workspace_fixed_bytes", "resident_waves")]
 
 
 def explain(n, max_tl, max_ql, parameters=(200, -150, 260, 11), strategy=1, flags=0, packed2=False, entry=0, workspace=0, ctx=None):

@@ -67,6 +67,10 @@ struct mgl_sw_ctx {
     int64_t ws_limit = kDefaultWorkspace;
     // kernel workspace, two halves: the traceback of chunk k (aux stream) overlaps the fill of chunk k+1
     DevBuf tb[2], rec[2], bnd[2], diag, scratch;
+    // sw_dp16_lane_ck_kernel's tile counters: a ring of words, one per launch (zeroed on the launch's stream right before it; a word comes
+    // round again after kTileCounters launches of this context, which are ordered behind each other by then: same half, same stream)
+    DevBuf tile_ctr;
+    uint64_t tile_seq = 0;
     // small-batch entry of the coalescing front-end: one pinned host buffer each way, mirrored on the device
     void *pin_in = nullptr, *pin_out = nullptr;
     size_t pin_in_cap = 0, pin_out_cap = 0;
@@ -155,6 +159,7 @@ const DebugKnobs &debug_knobs()
     }();
     return k;
 }
+constexpr int kTileCounters = 64;
 constexpr int kHostChunks = 32; // a host entry cuts a batch into about this many chunks (the units of its copy / compute pipeline)
 
 int geom_of(int flags)
@@ -214,6 +219,9 @@ constexpr int kRows64MinQuery = 1024;
 // 65 536 pairs 2 442 against 2 425, 131 072 pairs 4 342 against 2 731, 262 144 pairs 4 931 against 2 930; in round 2 it crossed at
 // 262 144, with the flags of every cell stored at 524 288)
 constexpr int64_t kLaneMinPairs = 128 * 640;
+// ... in the form that stores the flags of every cell (three waves per SIMD: a round of the chip is 393 216 pairs) from 524 288 on (round 2's
+// measurement); it is what a batch gets whose workspace cannot hold the checkpointed form's regions, or that asks for scores only
+constexpr int64_t kLaneStoredMinPairs = 524288;
 // ... and a sorted chunk's whole waves of one geometry get a launch of their own from this many pairs on
 constexpr int64_t kLaneGroupMinPairs = 128 * 1024;
 
@@ -279,6 +287,8 @@ struct BatchPlan {
     int64_t stride_words; // traceback words per pair / per two pairs / per wave, by layout
     int64_t stride32_words; // ... of the int32 part of a sorted chunk
     int64_t per_pair; // workspace bytes per pair
+    int64_t lane_slots; // the checkpointed lane kernel's persistent grid: wave slots of a launch (= regions of a workspace half)
+    int64_t fixed_bytes; // ... the bytes of those regions: workspace of a half that does not grow with the chunk
     int64_t chunk; // pairs per chunk (the largest, where the chunks grow and shrink)
     bool pyramid; // the host entry of a large 2-bit batch: chunks of 1, 2, 4, 8 .. 8, 4, 2, 1 rounds of the chip
     int64_t pyr_unit; // ... pairs per round
@@ -327,18 +337,27 @@ static int plan_batch(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const SeqS
     // chip at a time -- 128 pairs per wave, three (32-row strips) or four waves per SIMD -- on two alternating streams)
     // (the checkpointed form runs two waves per SIMD, the forms that store every flag three (32-row strips) or four)
     const bool lane_ck_on = debug_knobs().lane_ck;
-    const bool lane_ck_ok = lane_rows == 32 && d_cigar != nullptr && ctx->lane_checkpoint != 1 && (ctx->lane_checkpoint == 2 || lane_ck_on);
+    // The checkpointed form is a PERSISTENT grid (sw_dp16_lane_ck.hip): a launch keeps one region per wave SLOT -- at most the waves the
+    // chip holds at two per SIMD, 4 GB on an MI355X at 256 x 150 -- and 32 bytes of record per pair, however many pairs it holds.  The
+    // regions take at most three quarters of a workspace part (host entries run two launches side by side: two parts); a workspace that
+    // cannot hold one wave per SIMD leaves the batch to the kernels that store their flags.
+    const int64_t ck_region = lane_ck_region_bytes(max_tl, max_ql), ck_chip = (int64_t)ctx->n_cus * LANE_CK_WAVES_PER_CU;
+    const int64_t ck_part = hooks ? ctx->ws_limit / 2 : ctx->ws_limit;
+    const int64_t ck_slots_max = std::min<int64_t>(ck_chip, ck_part / 4 * 3 / ck_region);
+    const bool ck_fits = ck_slots_max >= ((ctx->lane_kernel == 2 || ctx->lane_checkpoint == 2) ? 1 : ck_chip / 2); // (forced by a test: any number of slots)
+    const int64_t ck_launch_max = ck_fits ? (ck_part - ck_slots_max * ck_region) / (int64_t)sizeof(DpRecord) / 128 * 128 : 0;
+    const bool lane_ck_ok = lane_rows == 32 && d_cigar != nullptr && ctx->lane_checkpoint != 1 && (ctx->lane_checkpoint == 2 || lane_ck_on) && ck_fits;
     // (a host entry's chunk: one round where the inputs are ASCII -- 0.1 GB per round over the link before the first kernel can
     // start -- two where they are 2-bit packed: 10 M pairs 69.1 ms against 72.4 with one, 72.3 with four; ASCII: 83.1 / 84.5 / 87.2)
     const int64_t lane_round = (int64_t)ctx->n_cus * (lane_ck_ok ? 8 : lane_rows == 16 ? 16 : 12) * 128 * (hooks && tset.packed2 ? 2 : 1);
     constexpr int host_chunks_l = kHostChunks;
     const bool lane_rounds = hooks && n >= 4 * lane_round;
     const int64_t lane_launch = std::min<int64_t>(lane_rounds ? n : hooks ? std::max<int64_t>(n / host_chunks_l, (int64_t)256 * 1024) : n,
-                                                  std::min<int64_t>(n, ctx->ws_limit / ((lane_ck_ok ? lane_ck_words(max_tl, max_ql) + lane_ck_scratch_bytes(max_tl, max_ql) / 4 : lane_tb_words(max_tl, max_ql, lane_rows)) * 4 / 128 + 1)));
+                                                  std::min<int64_t>(n, lane_ck_ok ? ck_launch_max : ctx->ws_limit / (lane_tb_words(max_tl, max_ql, lane_rows) * 4 / 128 + 1)));
     // (its checkpointed form stages base codes and takes either wire format; the form that stores every flag reads ASCII only)
     const bool lane_ck_wanted = lane_ck_ok && !score_only_hint; // (a 2-bit batch gets the lane kernel only in this form)
     const bool use_lane = geom == GEOM_UNIFORM && ctx->precision != 32 && !d_matrix && match > 0 && ctx->lane_kernel != 1 &&
-                          (ctx->lane_kernel == 2 || lane_launch >= (hooks ? 2 * kLaneMinPairs : kLaneMinPairs)) && // (the host entry's chunks: as measured before)
+                          (ctx->lane_kernel == 2 || lane_launch >= (hooks ? 2 : 1) * (lane_ck_wanted ? kLaneMinPairs : kLaneStoredMinPairs)) && // (the host entry's chunks: as measured before)
                           (lane16_supported(tset, qset) || (lane_ck_wanted && lane16_ck_supported(tset, qset))) &&
                           dp16_range_ok(max_tl, max_ql, match, mismatch, gopen, gext, strategy);
     // a batch of mixed geometries whose chunks the host entry sorts by geometry (hooks->regroup): full blocks of eight pairs
@@ -462,7 +481,8 @@ static int plan_batch(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const SeqS
     // (auto-grouped chunks: the packed regions first, the int32 regions of the left-over pairs behind them)
     const int sps32 = sps_for_rows(max_ql, 16);
     const int64_t stride32_words = tb_words_for(max_tl, sps32, 16);
-    const int64_t per_pair = use_lane ? ((score_only ? 0 : stride_words * 4) + (lane_ck ? lane_ck_scratch_bytes(max_tl, max_ql) : lane_scratch_bytes(max_tl, max_ql, rows))) / 128 + 1 + (int64_t)sizeof(DpRecord)
+    const int64_t per_pair = lane_ck ? (int64_t)sizeof(DpRecord) // (+ fixed_bytes per half: the persistent grid's regions)
+                             : use_lane ? ((score_only ? 0 : stride_words * 4) + lane_scratch_bytes(max_tl, max_ql, rows)) / 128 + 1 + (int64_t)sizeof(DpRecord)
                              : auto_group ? std::max(std::max(stride_words * 2, stride32_words * 4), lane_group ? (lane_group_stride * 4 + lane_ck_scratch_bytes(max_tl, max_ql)) / 128 + 1 : 0) + (int64_t)sizeof(DpRecord)
                                           : (score_only ? 0 : stride_words * 4 / (use16 ? 2 : 1)) + (int64_t)sizeof(DpRecord);
     // the workspace is split in two halves so that the traceback of one chunk can run (on ctx->aux)
@@ -477,7 +497,9 @@ static int plan_batch(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const SeqS
     // alternate between two streams and two halves, so that the last waves of one launch (the launch's tail, 1-2 ms of a
     // 14 ms chunk with most CUs idle) run beside the first waves of the next
     const bool dual_ok = fused_walk && hooks;
-    const int64_t ws_part = fused_walk && !dual_ok ? ctx->ws_limit : ctx->ws_limit / 2;
+    const int64_t ws_whole = fused_walk && !dual_ok ? ctx->ws_limit : ctx->ws_limit / 2;
+    const int64_t fixed_max = lane_ck ? ck_slots_max * ck_region : 0; // (a chunk of fewer tiles than slots needs fewer regions: fixed_bytes below)
+    const int64_t ws_part = ws_whole - fixed_max;
     if (per_pair * gran > ws_part) {
         char msg[192];
         snprintf(msg, sizeof msg, "traceback of %lld pair(s) (%lld bytes) does not fit half the workspace: raise it with "
@@ -544,6 +566,8 @@ static int plan_batch(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const SeqS
     P.stride_words = stride_words;
     P.stride32_words = stride32_words;
     P.per_pair = per_pair;
+    P.lane_slots = lane_ck ? std::min<int64_t>(ck_slots_max, (chunk + 127) / 128) : lane_group ? std::min<int64_t>(ck_chip, (chunk + 127) / 128) : 0;
+    P.fixed_bytes = lane_ck ? P.lane_slots * ck_region : 0;
     P.chunk = chunk;
     P.pyramid = pyramid;
     P.pyr_unit = pyr_unit;
@@ -678,6 +702,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const int64_t stride_words = P.stride_words;
     const int64_t stride32_words = P.stride32_words;
     const int64_t per_pair = P.per_pair;
+    const int64_t lane_slots = P.lane_slots;
     const int64_t chunk = P.chunk;
     const bool pyramid = P.pyramid;
     const int64_t pyr_unit = P.pyr_unit;
@@ -712,13 +737,15 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         for (int64_t first = 0; first < n; first += chunk_at(first, pl.chunks), ++pl.chunks) {
         }
         pl.workspace_bytes_per_pair = per_pair;
-        pl.workspace_bytes = per_pair * chunk * halves;
+        pl.workspace_fixed_bytes = P.fixed_bytes * halves;
+        pl.workspace_bytes = (per_pair * chunk + P.fixed_bytes) * halves;
+        pl.resident_waves = lane_slots;
         return MGL_SW_OK;
     }
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int h = 0; h < halves; ++h) {
-        const size_t regions = (size_t)(use_lane ? (chunk + 127) / 128 : use16 ? (chunk + 1) / 2 : chunk);
+        const size_t regions = (size_t)(lane_ck ? lane_slots : use_lane ? (chunk + 127) / 128 : use16 ? (chunk + 1) / 2 : chunk);
         if (auto_group)
             HIP_TRY(ctx, ctx->tb[h].reserve((size_t)chunk * (size_t)(per_pair - (int64_t)sizeof(DpRecord)) + 64));
         else if (!score_only)
@@ -726,6 +753,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         if (use_lane) HIP_TRY(ctx, ctx->bnd[h].reserve(regions * (size_t)(lane_ck ? lane_ck_scratch_bytes(max_tl, max_ql) : lane_scratch_bytes(max_tl, max_ql, rows))));
         if (lane_group) HIP_TRY(ctx, ctx->bnd[h].reserve((size_t)(chunk / 128 + 1) * (size_t)lane_ck_scratch_bytes(max_tl, max_ql)));
         HIP_TRY(ctx, ctx->rec[h].reserve((size_t)chunk * sizeof(DpRecord)));
+    }
+    if (lane_slots > 0 && !ctx->tile_ctr.p) {
+        HIP_TRY(ctx, ctx->tile_ctr.reserve(kTileCounters * sizeof(unsigned)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->tile_ctr.p, 0, kTileCounters * sizeof(unsigned), stream));
     }
 
     if (use_scratch) {
@@ -879,7 +910,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             const char *const lgm = getenv("MGL_SW_DEBUG_LANE_GROUP_MIN"); // (tests lower the threshold between calls: read per chunk)
             const int64_t lane_group_min = lgm ? (int64_t)atoll(lgm) : kLaneGroupMinPairs;
             const int64_t nl = lane_group && rg.n_lane >= std::max<int64_t>(lane_group_min, 128) ? rg.n_lane : 0;
-            uint32_t *const tb16 = tb_base + (size_t)(nl / 128) * (size_t)lane_group_stride;
+            uint32_t *const tb16 = tb_base + (size_t)std::min<int64_t>(nl / 128, lane_slots) * (size_t)lane_group_stride; // (behind the lane part's regions: one per wave slot)
             lane_pairs_last = nl;
             if (nl > 0) parts[n_parts++] = Part{true, false, 0, nl, ts, qs, tb_base, lane_group_stride, rec_base, rg.d_dest, 32, 4, max_ql};
             if (ng > nl) parts[n_parts++] = Part{false, true, nl, ng - nl, ts, qs, tb16, stride_words, rec_base + nl, rg.d_dest, 16, wpb16, sps_for(max_ql)};
@@ -917,6 +948,15 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             da.grouped = pt.lane && auto_group ? 1 : 0;
             da.strip_k = strip16 ? strip_k : 0;
             da.strip_pack = strip16 ? strip_pack : 0;
+            da.lane_slots = 0;
+            da.tile_ctr = nullptr;
+            if (pt.lane && (lane_ck || da.grouped)) { // the persistent grid: its wave slots and, where the tiles outnumber them, a zeroed counter
+                da.lane_slots = (int)std::min<int64_t>(lane_slots, (pt.count + 127) / 128);
+                if ((pt.count + 127) / 128 > da.lane_slots) {
+                    da.tile_ctr = static_cast<unsigned *>(ctx->tile_ctr.p) + (ctx->tile_seq++ % kTileCounters);
+                    HIP_TRY(ctx, hipMemsetAsync(da.tile_ctr, 0, sizeof(unsigned), fs));
+                }
+            }
             const int per_block = pt.lane ? pt.wpb * 128 : pt.packed ? pt.wpb * 8 : strip16 ? 1 : pt.wpb * (64 / pt.rows);
             if (i == 0) n_blocks = (pt.count + per_block - 1) / per_block;
             if (ctx->profiling == 2 && i == 0) {
@@ -1014,7 +1054,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         ctx->last_packed16 = lane_ck ? 5 : use_lane ? 2 : use16 ? 1 : strip16 ? (strip_k ? 6 : 4) : coop16 ? 3 : 0;
         ctx->timing.dp_launches++;
         ctx->timing.tb_launches++;
-        ctx->timing.tb_bytes += (use_lane ? (count + 127) / 128 : use16 ? (count + 1) / 2 : count) * stride_words * 4;
+        ctx->timing.tb_bytes += (lane_ck ? std::min<int64_t>(lane_slots, (count + 127) / 128) : use_lane ? (count + 127) / 128 : use16 ? (count + 1) / 2 : count) * stride_words * 4;
         ctx->timing.packed16 = (use16 || use_lane) ? 1 : 0;
         ctx->timing.fill_kernel = lane_ck || lane_pairs_last > 0 ? MGL_SW_KERNEL_LANE16_CK : use_lane ? MGL_SW_KERNEL_LANE16 : use16 ? MGL_SW_KERNEL_DP16 : strip16 ? MGL_SW_KERNEL_STRIP16 : coop16 ? MGL_SW_KERNEL_COOP16 : coop_waves ? MGL_SW_KERNEL_COOP : rows == 64 ? MGL_SW_KERNEL_DP32_64 : MGL_SW_KERNEL_DP32;
     }
@@ -1133,7 +1173,7 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
-    for (DevBuf *b : {&ctx->tb[0], &ctx->tb[1], &ctx->rec[0], &ctx->rec[1], &ctx->bnd[0], &ctx->bnd[1], &ctx->diag, &ctx->scratch, &ctx->d_t, &ctx->d_toff, &ctx->d_q, &ctx->d_qoff, &ctx->d_tlen, &ctx->d_qlen, &ctx->d_off, &ctx->d_score,
+    for (DevBuf *b : {&ctx->tb[0], &ctx->tb[1], &ctx->rec[0], &ctx->rec[1], &ctx->bnd[0], &ctx->bnd[1], &ctx->diag, &ctx->scratch, &ctx->tile_ctr, &ctx->d_t, &ctx->d_toff, &ctx->d_q, &ctx->d_qoff, &ctx->d_tlen, &ctx->d_qlen, &ctx->d_off, &ctx->d_score,
                       &ctx->d_cig, &ctx->d_len, &ctx->d_status, &ctx->d_btr, &ctx->d_any, &ctx->d_matrix})
         b->release();
     for (auto &e : ctx->ev)

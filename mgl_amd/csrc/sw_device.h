@@ -69,6 +69,8 @@ struct DpArgs {
     int grouped;              // sw_dp16_lane_ck_kernel: every wave of 128 pairs has its own geometry (a chunk sorted by geometry)
     int strip_k;              // sw_dp16_strip_kernel: 0 = the flags of every cell are stored; K > 0 = none are: rows and checkpoints of bands of K strips (strip16_ck_*)
     int strip_pack;           // ... their entries: 0 = {H, gap value} as two int32; B > 0 = one int32, H << B | (H - gap value) (strip16_pack_bits)
+    int lane_slots;           // sw_dp16_lane_ck_kernel: wave slots of its persistent grid = regions at tb / scratch (lane_ck_slots)
+    unsigned *tile_ctr;       // ... the counter its waves draw their next tile from: zero at launch (needed when the launch holds more tiles than slots)
 };
 
 struct TbArgs {
@@ -166,6 +168,18 @@ __host__ __device__ inline int64_t lane_ck_words(int tl, int ql)
 }
 // per-wave scratch: both queries and both targets of every lane transposed to [4-base block][A | B][lane] dwords
 __host__ __device__ inline int64_t lane_ck_scratch_bytes(int tl, int ql) { return ((int64_t)((ql + 3) / 4) + (int64_t)lane_strips(tl, 32) * 8) * 2 * 64 * 4; }
+// The kernel is a PERSISTENT grid: a launch's waves take tile after tile (128 pairs each) and every wave keeps ONE region
+// (lane_ck_words + lane_ck_scratch_bytes) that it reuses, so a launch needs as many regions as it has wave slots -- at most what the
+// chip holds at two waves per SIMD -- whatever the number of pairs.
+constexpr int LANE_CK_WAVES_PER_CU = 8;
+__host__ __device__ inline int64_t lane_ck_region_bytes(int tl, int ql) { return lane_ck_words(tl, ql) * 4 + lane_ck_scratch_bytes(tl, ql); }
+// wave slots of a launch of `pairs` pairs on n_cus CUs when `bytes` of workspace are left for regions
+__host__ __device__ inline int64_t lane_ck_slots(int64_t pairs, int n_cus, int64_t bytes, int tl, int ql)
+{
+    const int64_t tiles = (pairs + 127) / 128, chip = (int64_t)n_cus * LANE_CK_WAVES_PER_CU, fit = bytes / lane_ck_region_bytes(tl, ql);
+    const int64_t s = tiles < chip ? tiles : chip;
+    return s < fit ? s : fit;
+}
 
 int64_t dp_group_bytes(int sps_cap, int rows); // carry ring + query copies of one pair (LDS, or HBM scratch)
 int dp_lds_bytes(int sps_cap, int waves_per_block, int rows);

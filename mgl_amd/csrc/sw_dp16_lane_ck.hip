@@ -35,6 +35,9 @@
 #ifndef MGL_CK_ABLATE
 #define MGL_CK_ABLATE 0
 #endif
+#if (MGL_CK_ABLATE != 0 || defined(MGL_CK_PHASES)) && !defined(MGL_VARIANT_BUILD)
+#error "MGL_CK_ABLATE / MGL_CK_PHASES are measurement builds (scripts/build_variant.sh defines MGL_VARIANT_BUILD): never the shipped library"
+#endif
 
 // -DMGL_CK_PHASES (scripts/build_variant.sh): every wave adds the shader-clock ticks it spent in each part of the kernel to a
 // device array; mgl_ck_phases_dump() (exported by that build only) prints and clears it
@@ -443,6 +446,31 @@ __device__ __forceinline__ void ck_strip(const int k, const int tl, const int ql
         }
         bo += 64;
     };
+    // columns u and u + 1 of the group together, one row apart (column_pair, sw_lane_cell.h); not for a last strip whose row tl lies
+    // inside it (the row the last-row scan reads is then picked out of the registers after every single column)
+    auto two_columns = [&](const uint2 topa, const uint2 topb, const unsigned qa, const unsigned qb, const int u) {
+        unsigned ea = topa.y, eb = topb.y, ha_last;
+        uint2 mida, midb;
+        if (CODES)
+            column_pair<R, true, true>(h, f, t, code_table((qa >> (8 * u)) & 0xffu), code_table((qb >> (8 * u)) & 0xffu), code_table((qa >> (8 * u + 8)) & 0xffu),
+                                       code_table((qb >> (8 * u + 8)) & 0xffu), hd, topa.x, ea, eb, c, ha_last, &mida, &midb);
+        else
+            column_pair<R, true, false>(h, f, t, __builtin_amdgcn_perm(qb, qa, 0x0c040c00u + 0x00010001u * u), 0u,
+                                        __builtin_amdgcn_perm(qb, qa, 0x0c040c00u + 0x00010001u * (u + 1)), 0u, hd, topa.x, ea, eb, c, ha_last, &mida, &midb);
+        hd = topb.x;
+        if (!(MGL_CK_ABLATE & 4)) {
+            mp[0] = mida;
+            mp[64] = midb;
+        }
+        mp += 128;
+        bo[0] = make_uint2(ha_last, LAST ? 0u : ea); // (LAST: row tl is the strip's last row here -- H[tl][j] for the last-row scan)
+        bo[64] = make_uint2(h[R - 1], LAST ? 0u : eb);
+        bo += 128;
+    };
+#ifndef MGL_CK_COLUMN_PAIRS // (0: every column on its own, round 3's loop -- same results; scripts/build_variant.sh builds it for comparison)
+#define MGL_CK_COLUMN_PAIRS 1
+#endif
+    const bool pairs_ok = MGL_CK_COLUMN_PAIRS && (!LAST || rl == R - 1);
     auto save = [&]() { // the state BEFORE column j: H[.][j-1] and the horizontal-gap values entering column j
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -471,10 +499,15 @@ __device__ __forceinline__ void ck_strip(const int k, const int tl, const int ql
         n3 = bp[192];
         nqa = qst[0];
         nqb = qst[64];
-        one_column(top0, qa, qb, 0);
-        one_column(top1, qa, qb, 1);
-        one_column(top2, qa, qb, 2);
-        one_column(top3, qa, qb, 3);
+        if (pairs_ok) {
+            two_columns(top0, top1, qa, qb, 0);
+            two_columns(top2, top3, qa, qb, 2);
+        } else {
+            one_column(top0, qa, qb, 0);
+            one_column(top1, qa, qb, 1);
+            one_column(top2, qa, qb, 2);
+            one_column(top3, qa, qb, 3);
+        }
     }
     if (j <= ql) { // the last one to three columns (j - 1 is a multiple of four here)
         if (j > 1 && ((j - 1) & (CK - 1)) == 0) save();
@@ -705,12 +738,12 @@ __device__ __forceinline__ void stage_2bit(const uint8_t *data, const int64_t st
     }
 }
 
-__device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbArgs &walk)
+// One TILE = 128 pairs of the launch (pairs 128 gw .. 128 gw + 127), worked on by the wave that sits in wave slot `slot` of the
+// persistent grid: everything the wave keeps while it works -- WaveMem, the staged sequences -- lives in the slot's region, which
+// the wave reuses tile after tile (a lane only ever reads back what it has written for the tile it is working on).
+__device__ __forceinline__ void sw_dp16_lane_ck_tile(const DpArgs &a, const TbArgs &walk, const int64_t gw, const int64_t slot, const int lane)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t n_ls = (a.count + 1) >> 1;
-    if (gw * 64 >= n_ls) return;
 #ifdef MGL_CK_PHASES
     unsigned long long phase_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -743,11 +776,11 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
 
     const int strips = lane_strips(tl, R), nb = lane_ck_blocks(ql);
     // the wave's scratch: both queries and both targets of every lane transposed to [4-base block][A | B][lane] dwords
-    unsigned *const qst = reinterpret_cast<unsigned *>(a.scratch + (size_t)gw * (size_t)lane_ck_scratch_bytes(a.uni_tl, a.uni_ql)) + lane;
+    unsigned *const qst = reinterpret_cast<unsigned *>(a.scratch + (size_t)slot * (size_t)lane_ck_scratch_bytes(a.uni_tl, a.uni_ql)) + lane;
     unsigned *const tst = qst + (size_t)((ql + 3) >> 2) * 128;
     WaveMem wm;
     {
-        uint2 *const region = reinterpret_cast<uint2 *>(a.tb + (size_t)gw * (size_t)a.tb_stride_words);
+        uint2 *const region = reinterpret_cast<uint2 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words);
         wm.bnd = region + lane;
         wm.mid = wm.bnd + (size_t)(strips + 1) * (ql + 1) * 64;
         wm.ck = reinterpret_cast<unsigned *>(region + ((size_t)(strips + 1) * (ql + 1) + (size_t)strips * ql) * 64) + lane;
@@ -756,7 +789,7 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
         wm.mid_off = (unsigned)((strips + 1) * (ql + 1) * 64);
         wm.cku = reinterpret_cast<const unsigned *>(region + ((size_t)(strips + 1) * (ql + 1) + (size_t)strips * ql) * 64);
         wm.blku = reinterpret_cast<const uint32_t *>(region) + ((size_t)(strips + 1) * (ql + 1) * 2 + (size_t)strips * ql * 2 + (size_t)strips * (nb - 1) * 64) * 64;
-        wm.seq = reinterpret_cast<const unsigned *>(a.scratch + (size_t)gw * (size_t)lane_ck_scratch_bytes(a.uni_tl, a.uni_ql));
+        wm.seq = reinterpret_cast<const unsigned *>(a.scratch + (size_t)slot * (size_t)lane_ck_scratch_bytes(a.uni_tl, a.uni_ql));
         wm.t_off = (unsigned)(((ql + 3) >> 2) * 128);
         wm.lane = (unsigned)lane;
     }
@@ -937,26 +970,38 @@ __device__ __forceinline__ void sw_dp16_lane_ck_body(const DpArgs &a, const TbAr
 
 } // namespace
 
-// Two waves per SIMD (256 registers: no spills in pass 1's loops).  A three-wave build of the same code (168 registers, spills)
-// ran launches of 10 M pairs equally fast in round 2 and shorter ones 2-7 % slower; with pass 2 as it is now it is slower
-// everywhere (1000 x 150, 2.56 M pairs: 62.9 ms against 61.4) and was dropped.
-// ONE wave per workgroup: the waves share nothing (no LDS, no barrier), and a workgroup's registers are released only when its LAST wave
-// has ended -- the waves of one workgroup need different numbers of block rounds in pass 2, so with four per workgroup three of the four
-// SIMD slots stood empty until the slowest was through (10 M pairs: 63.99 ms with four, 63.37 with two, 63.06 with one; 1.25 M pairs:
-// 9.05 / 8.88 / 8.85 ms; on a slower box, alternating: 65.4-65.5 ms with four, 64.2-64.3 with one; scripts/wpb_probe.sh)
-#ifndef MGL_CK_WAVES_PER_BLOCK
-#define MGL_CK_WAVES_PER_BLOCK 1
-#endif
-__global__ __launch_bounds__(64 * MGL_CK_WAVES_PER_BLOCK, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, const TbArgs walk) { sw_dp16_lane_ck_body(a, walk); }
+// A PERSISTENT grid: a.lane_slots waves (at most what the chip holds at two waves per SIMD -- 256 registers: no spills in pass 1's
+// loops), each with one region of the workspace, each taking tile after tile: its first one by its slot number, the following ones
+// off a counter in device memory (a.tile_ctr, zero at launch) until the tiles are gone.  The workspace a launch needs is therefore
+// lane_slots regions (2 MB each at 256 x 150: 4 GB for a whole MI355X) however many pairs it holds -- round 3 gave every TILE a region
+// (15 KB per pair: 208 GiB for the bench's 10 M pairs in one launch, and chunks wherever the workspace was smaller).  Every wave
+// reaches the loop's exit: the counter only grows, a tile's work is bounded, nothing waits for another wave.
+// ONE wave per workgroup: the waves share nothing (no LDS, no barrier), and a workgroup's registers are released only when its LAST
+// wave has ended (round 3, four per workgroup: three of four SIMD slots stood empty until the slowest was through).
+// A three-wave-per-SIMD build of the same code (168 registers, spills) was slower everywhere in round 3 and is gone.
+__global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, const TbArgs walk)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t tiles = (((a.count + 1) >> 1) + 63) >> 6, slots = gridDim.x, slot = blockIdx.x;
+    for (int64_t tile = slot; tile < tiles;) {
+        sw_dp16_lane_ck_tile(a, walk, tile, slot, lane);
+        if (tiles <= slots) break; // (every tile has its wave: the counter is not even touched)
+        unsigned next = 0;
+        if (lane == 0) next = atomicAdd(a.tile_ctr, 1u);
+        tile = slots + (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)next);
+    }
+}
 
 // either wire format, the same for both sequence sets (the kernel stages base codes, sw_lane_cell.h)
 bool lane16_ck_supported(const SeqSet &t, const SeqSet &q) { return (t.packed2 != 0) == (q.packed2 != 0); }
 
+// a.lane_slots regions at a.tb / a.scratch; a.tile_ctr zero when the kernel starts (the caller's memset on `stream`) wherever the
+// launch holds more tiles than slots
 hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &walk, hipStream_t stream)
 {
-    const int waves_per_block = MGL_CK_WAVES_PER_BLOCK;
-    const int64_t waves = ((a.count + 1) / 2 + 63) / 64;
-    const dim3 grid((unsigned)((waves + waves_per_block - 1) / waves_per_block)), block(64 * waves_per_block);
+    const int64_t tiles = ((a.count + 1) / 2 + 63) / 64;
+    if (a.lane_slots < 1 || (tiles > a.lane_slots && !a.tile_ctr)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(tiles < a.lane_slots ? tiles : a.lane_slots)), block(64);
     hipLaunchKernelGGL(sw_dp16_lane_ck_kernel, grid, block, 0, stream, a, walk);
     return hipGetLastError();
 }

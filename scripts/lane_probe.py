@@ -13,7 +13,7 @@ ql = int(sys.argv[3]) if len(sys.argv) > 3 else 150
 dev = torch.device("cuda", 0)
 b = device_batch.window_batch(42, n, dev, window=tl, read_len=ql)
 a = MicrosoftSmithWaterman(0)
-a.set_workspace(128 << 30)
+a.set_workspace(int(os.environ.get("WS_GIB", "8")) << 30)   # the persistent grid: 4.2 GB of regions for the whole chip at 256 x 150 (tl = 1000: WS_GIB=24)
 a.set_lane_kernel(int(os.environ.get("LANE_MODE", "2")))
 for so in ((False,) if os.environ.get('FULL_ONLY') else (False, True)):
     b.run(a, score_only=so); torch.cuda.synchronize()

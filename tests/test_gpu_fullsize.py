@@ -99,12 +99,16 @@ def test_fullsize_reproducible_and_chunking_invariant(full):
     b.run(a)
     torch.cuda.synchronize()
     assert digest(b) == d0, "two runs of the same batch differ"
-    small = sw.MicrosoftSmithWaterman(0)
-    small.set_workspace(2 << 30)
-    b.run(small)
-    torch.cuda.synchronize()
-    assert digest(b) == d0, "results depend on the workspace chunking"
-    small.close()
+    # 4 GiB: the same kernel with fewer wave slots than the chip holds (1 590 regions); 2 GiB: not even one wave per SIMD, the
+    # eight-pairs-per-wave kernel in chunks
+    for ws, kernel in ((4 << 30, 7), (2 << 30, 1)):
+        small = sw.MicrosoftSmithWaterman(0)
+        small.set_workspace(ws)
+        b.run(small)
+        torch.cuda.synchronize()
+        assert small.timing().fill_kernel == kernel
+        assert digest(b) == d0, "results depend on the workspace"
+        small.close()
 
 
 def test_fullsize_int16_equals_int32_on_a_slice(full):
@@ -150,8 +154,8 @@ def test_fullsize_sample_rescoring_and_oracle(full):
 
 def test_fullsize_one_launch_as_the_bench_runs_it(full):
     """The exact configuration the headline is quoted on: bench.py's workspace, so that the 10 M pairs are ONE launch of
-    sw_dp16_lane_ck_kernel (78 125 waves) -- identical to the chunked run of the fixture, and a 20 000-pair sample spread
-    over the whole launch against the CPU checker."""
+    sw_dp16_lane_ck_kernel (78 125 tiles over a persistent grid of 2 048 waves) -- identical to the fixture's run, and a 20 000-pair
+    sample spread over the whole launch against the CPU checker."""
     import bench
 
     a, b = full

@@ -1199,11 +1199,12 @@ def test_lane_kernel_goldens_unaligned_chunked_score_only(lane_aligner):
         assert b.uniform
         small = sw.MicrosoftSmithWaterman(0)
         small.set_lane_kernel(2)
-        small.set_workspace(7 << 20)     # a few waves per chunk (one buffer: the lanes walk their own paths, nothing overlaps)
+        small.set_workspace(7 << 20)     # room for TWO wave slots of the persistent grid: every wave takes tile after tile off the counter, one region each
         b.run(small)
         torch.cuda.synchronize()
         tm = small.timing()
-        assert tm.fill_kernel == 7 and tm.dp_launches > 2
+        assert tm.fill_kernel == 7 and tm.dp_launches == 1
+        assert _lib.explain(len(rows), tl, ql, rows[0].params, flags=_lib.FLAG_UNIFORM_GEOMETRY, ctx=small.ctx).resident_waves == 2
         cg = b.cigar_strings()
         for k, g in enumerate(rows):
             assert (int(b.offsets[k]), cg[k], tuple(int(x) for x in b.scores[k])) == (g.offset, g.cigar, g.score)

@@ -11,6 +11,16 @@ BENCH_WS = 208 << 30   # bench.py's workspace
 DP32, DP16, DP32_64, COOP, LANE16, COOP16, STRIP16, LANE16_CK, SMALL = range(9)
 
 
+def lane_ck_region(tl, ql):
+    """sw_device.h: lane_ck_words * 4 + lane_ck_scratch_bytes -- what one wave slot of sw_dp16_lane_ck_kernel keeps."""
+    strips, blocks = (tl + 31) // 32, (ql + 31) // 32
+    words = ((strips + 1) * (ql + 1) * 2 + strips * ql * 2 + strips * (blocks - 1) * 64 + 32 * 4) * 64
+    return words * 4 + ((ql + 3) // 4 + strips * 8) * 2 * 64 * 4
+
+
+REGION_256x150 = lane_ck_region(256, 150)
+
+
 def plan(**kw):
     return _lib.explain(**kw)
 
@@ -41,7 +51,28 @@ def test_configs1_headline_is_one_launch_of_the_checkpointed_lane_kernel():
         assert p.fill_kernel == LANE16_CK and p.precision_bits == 16 and p.rows == 32
         assert p.traceback == 1 and p.fused_walk == 1, "no flags stored; every lane walks its own two pairs"
         assert p.chunks == 1 and p.chunk_pairs == 10_000_000 and p.fill_streams == 1 and p.workspace_halves == 1
-        assert 14_000 < p.workspace_bytes_per_pair < 16_000 and p.workspace_bytes < BENCH_WS
+        # a persistent grid: one region (WaveMem + the staged sequences, 2.0 MB at 256 x 150) per wave SLOT -- two waves per SIMD, 2 048 on
+        # 256 CUs -- and a 32-byte record per pair, however many pairs the launch holds (round 3: a region per 128 pairs, 208 GiB)
+        assert p.resident_waves == 256 * 8 and p.workspace_bytes_per_pair == 32
+        assert p.workspace_fixed_bytes == p.resident_waves * REGION_256x150 and p.workspace_bytes == p.workspace_fixed_bytes + 32 * 10_000_000
+        assert p.workspace_bytes < (5 << 30)
+
+
+def test_headline_fits_a_workspace_of_8_gib_and_less():
+    """The whole 10 M-pair batch is ONE launch from 6 GiB on; below that the grid shrinks (regions take at most three quarters of the
+    workspace), and a workspace that cannot hold one wave per SIMD leaves the batch to the eight-pairs-per-wave kernel."""
+    p = plan(n=10_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, workspace=8 << 30)
+    assert p.fill_kernel == LANE16_CK and p.chunks == 1 and p.chunk_pairs == 10_000_000 and p.resident_waves == 2048
+    p = plan(n=10_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, workspace=4 << 30)
+    assert p.fill_kernel == LANE16_CK and p.chunks == 1 and p.resident_waves == (3 << 30) // REGION_256x150 and 1024 <= p.resident_waves < 2048
+    p = plan(n=10_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, workspace=2 << 30)
+    assert p.fill_kernel == DP16, "fewer than 1 024 wave slots"
+    # a launch of fewer tiles than the chip has slots keeps a region per tile
+    p = plan(n=131_072, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, workspace=8 << 30)
+    assert p.fill_kernel == LANE16_CK and p.resident_waves == 1024 and p.workspace_fixed_bytes == 1024 * REGION_256x150
+    # the tl = 1000 variant: 7.4 MB per slot
+    p = plan(n=2_560_000, max_tl=1000, max_ql=150, parameters=GATK, flags=UNIFORM, workspace=24 << 30)
+    assert p.fill_kernel == LANE16_CK and p.chunks == 1 and p.resident_waves == 2048
 
 
 def test_configs2_one_rank_of_eight():
@@ -119,8 +150,11 @@ def test_host_entries_pipeline_chunks_on_two_streams():
     assert a.chunk_pairs == 256 * 8 * 128, "ASCII inputs: one round of the chip per chunk (two waves per SIMD, 128 pairs per wave)"
     b = plan(n=10_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, entry=1, packed2=True, workspace=BENCH_WS)
     assert b.chunk_pairs == 8 * 256 * 8 * 128 and b.chunks == 11, "2-bit inputs: chunks of 1, 2, 4, 8, 8, 7, 4, 2, 1, 1 rounds and the rest (38.15 rounds in all)"
-    c = plan(n=10_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, entry=1, packed2=True, workspace=16 << 30)
-    assert c.chunk_pairs == 2 * 256 * 8 * 128 and c.chunks == 22, "... no larger than half the workspace holds"
+    # the same pipeline in a workspace of 8 GiB (round 3 needed 208 GiB for it: a region per 128 pairs): two launches side by side,
+    # a persistent grid each, their regions at most three quarters of a half
+    c = plan(n=10_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, entry=1, packed2=True, workspace=8 << 30)
+    assert c.fill_kernel == LANE16_CK and c.chunk_pairs == b.chunk_pairs and c.chunks == 11 and c.workspace_halves == 2
+    assert c.resident_waves == (3 << 30) // REGION_256x150 and c.workspace_bytes <= (8 << 30)
 
 
 def test_explain_reports_what_the_call_would_refuse():
