@@ -295,10 +295,11 @@ struct BatchPlan {
     bool overlap; // the traceback of chunk k runs beside the fill of chunk k + 1 (two workspace halves)
     bool dual; // consecutive chunks alternate between two fill streams (two workspace halves)
     int halves; // workspace halves in use
+    int geom; // the geometry class the batch is planned as (a promise of blocks of eight may be set aside: plan_batch)
 };
-static int plan_batch(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const SeqSet &qset, int max_tl, int max_ql, int match, int mismatch, int gopen, int gext,
-                      int strategy, const Score *d_score, const char *d_cigar, int cigar_stride, int geom, bool binary_cigar, const ChunkHooks *hooks,
-                      const int8_t *d_matrix, bool score_only_hint, BatchPlan &P)
+static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const SeqSet &qset, int max_tl, int max_ql, int match, int mismatch, int gopen, int gext,
+                         int strategy, const Score *d_score, const char *d_cigar, int cigar_stride, int geom, bool binary_cigar, const ChunkHooks *hooks,
+                         const int8_t *d_matrix, bool score_only_hint, BatchPlan &P)
 {
     const bool uniform = geom != GEOM_MIXED;
     (void)cigar_stride;
@@ -341,10 +342,11 @@ static int plan_batch(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const SeqS
     // chip holds at two per SIMD, 4 GB on an MI355X at 256 x 150 -- and 32 bytes of record per pair, however many pairs it holds.  The
     // regions take at most three quarters of a workspace part (host entries run two launches side by side: two parts); a workspace that
     // cannot hold one wave per SIMD leaves the batch to the kernels that store their flags.
-    const int64_t ck_region = lane_ck_region_bytes(max_tl, max_ql), ck_chip = (int64_t)ctx->n_cus * LANE_CK_WAVES_PER_CU;
+    const char *const slots_env = getenv("MGL_SW_DEBUG_LANE_SLOTS"); // (measurements: a grid of this many wave slots instead of what the chip holds; read per call)
+    const int64_t ck_region = lane_ck_region_bytes(max_tl, max_ql), ck_chip = slots_env && atoll(slots_env) > 0 ? atoll(slots_env) : (int64_t)ctx->n_cus * LANE_CK_WAVES_PER_CU;
     const int64_t ck_part = hooks ? ctx->ws_limit / 2 : ctx->ws_limit;
     const int64_t ck_slots_max = std::min<int64_t>(ck_chip, ck_part / 4 * 3 / ck_region);
-    const bool ck_fits = ck_slots_max >= ((ctx->lane_kernel == 2 || ctx->lane_checkpoint == 2) ? 1 : ck_chip / 2); // (forced by a test: any number of slots)
+    const bool ck_fits = ck_slots_max >= ((ctx->lane_kernel == 2 || ctx->lane_checkpoint == 2) ? 1 : std::min<int64_t>(ck_chip, (int64_t)ctx->n_cus * LANE_CK_WAVES_PER_CU) / 2); // (forced by a test: any number of slots)
     const int64_t ck_launch_max = ck_fits ? (ck_part - ck_slots_max * ck_region) / (int64_t)sizeof(DpRecord) / 128 * 128 : 0;
     const bool lane_ck_ok = lane_rows == 32 && d_cigar != nullptr && ctx->lane_checkpoint != 1 && (ctx->lane_checkpoint == 2 || lane_ck_on) && ck_fits;
     // (a host entry's chunk: one round where the inputs are ASCII -- 0.1 GB per round over the link before the first kernel can
@@ -574,6 +576,29 @@ static int plan_batch(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const SeqS
     P.overlap = overlap;
     P.dual = dual;
     P.halves = halves;
+    P.geom = geom;
+    return MGL_SW_OK;
+}
+
+// A caller's promise of blocks of eight (MGL_SW_FLAG_GROUPED_GEOMETRY) used to pin a large device-resident batch to the eight-pairs-per-
+// wave kernel (2.9 TCUPS) although a batch the library sorts itself gets the lane kernel for its whole waves of 128 (4.9): round 3 measured
+// a caller who sorts and promises at 3 013 GCUPS against 4 883 for one who does neither.  Where the library's own sort would run and feed
+// the lane kernel, the promise is therefore set aside and the batch planned as one of mixed geometries (the counting sort of an already
+// sorted chunk adds to each counter once per run of equal pairs and workgroup); everywhere else the promise stands.
+static int plan_batch(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const SeqSet &qset, int max_tl, int max_ql, int match, int mismatch, int gopen, int gext,
+                      int strategy, const Score *d_score, const char *d_cigar, int cigar_stride, int geom, bool binary_cigar, const ChunkHooks *hooks,
+                      const int8_t *d_matrix, bool score_only_hint, BatchPlan &P)
+{
+    const int rc = plan_batch_as(ctx, n, tset, qset, max_tl, max_ql, match, mismatch, gopen, gext, strategy, d_score, d_cigar, cigar_stride, geom, binary_cigar, hooks,
+                                 d_matrix, score_only_hint, P);
+    if (rc != MGL_SW_OK || geom != GEOM_GROUPED || hooks || !P.use16 || P.use_lane) return rc;
+    BatchPlan Q{};
+    const std::string err = ctx->err;
+    if (plan_batch_as(ctx, n, tset, qset, max_tl, max_ql, match, mismatch, gopen, gext, strategy, d_score, d_cigar, cigar_stride, GEOM_MIXED, binary_cigar, hooks,
+                      d_matrix, score_only_hint, Q) == MGL_SW_OK &&
+        Q.auto_group && Q.lane_group && std::min(n, Q.chunk) >= kLaneGroupMinPairs)
+        P = Q;
+    ctx->err = err;
     return MGL_SW_OK;
 }
 

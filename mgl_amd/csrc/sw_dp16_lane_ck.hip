@@ -446,31 +446,6 @@ __device__ __forceinline__ void ck_strip(const int k, const int tl, const int ql
         }
         bo += 64;
     };
-    // columns u and u + 1 of the group together, one row apart (column_pair, sw_lane_cell.h); not for a last strip whose row tl lies
-    // inside it (the row the last-row scan reads is then picked out of the registers after every single column)
-    auto two_columns = [&](const uint2 topa, const uint2 topb, const unsigned qa, const unsigned qb, const int u) {
-        unsigned ea = topa.y, eb = topb.y, ha_last;
-        uint2 mida, midb;
-        if (CODES)
-            column_pair<R, true, true>(h, f, t, code_table((qa >> (8 * u)) & 0xffu), code_table((qb >> (8 * u)) & 0xffu), code_table((qa >> (8 * u + 8)) & 0xffu),
-                                       code_table((qb >> (8 * u + 8)) & 0xffu), hd, topa.x, ea, eb, c, ha_last, &mida, &midb);
-        else
-            column_pair<R, true, false>(h, f, t, __builtin_amdgcn_perm(qb, qa, 0x0c040c00u + 0x00010001u * u), 0u,
-                                        __builtin_amdgcn_perm(qb, qa, 0x0c040c00u + 0x00010001u * (u + 1)), 0u, hd, topa.x, ea, eb, c, ha_last, &mida, &midb);
-        hd = topb.x;
-        if (!(MGL_CK_ABLATE & 4)) {
-            mp[0] = mida;
-            mp[64] = midb;
-        }
-        mp += 128;
-        bo[0] = make_uint2(ha_last, LAST ? 0u : ea); // (LAST: row tl is the strip's last row here -- H[tl][j] for the last-row scan)
-        bo[64] = make_uint2(h[R - 1], LAST ? 0u : eb);
-        bo += 128;
-    };
-#ifndef MGL_CK_COLUMN_PAIRS // (0: every column on its own, round 3's loop -- same results; scripts/build_variant.sh builds it for comparison)
-#define MGL_CK_COLUMN_PAIRS 1
-#endif
-    const bool pairs_ok = MGL_CK_COLUMN_PAIRS && (!LAST || rl == R - 1);
     auto save = [&]() { // the state BEFORE column j: H[.][j-1] and the horizontal-gap values entering column j
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -499,15 +474,10 @@ __device__ __forceinline__ void ck_strip(const int k, const int tl, const int ql
         n3 = bp[192];
         nqa = qst[0];
         nqb = qst[64];
-        if (pairs_ok) {
-            two_columns(top0, top1, qa, qb, 0);
-            two_columns(top2, top3, qa, qb, 2);
-        } else {
-            one_column(top0, qa, qb, 0);
-            one_column(top1, qa, qb, 1);
-            one_column(top2, qa, qb, 2);
-            one_column(top3, qa, qb, 3);
-        }
+        one_column(top0, qa, qb, 0);
+        one_column(top1, qa, qb, 1);
+        one_column(top2, qa, qb, 2);
+        one_column(top3, qa, qb, 3);
     }
     if (j <= ql) { // the last one to three columns (j - 1 is a multiple of four here)
         if (j > 1 && ((j - 1) & (CK - 1)) == 0) save();

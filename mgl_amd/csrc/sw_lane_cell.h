@@ -159,57 +159,6 @@ __device__ __forceinline__ void column(unsigned (&h)[R], unsigned (&f)[R], const
     }
 }
 
-// TWO columns (a = j, b = j + 1) of the score-only form at once, one row apart: cell (r, a) and cell (r - 1, b) depend on nothing
-// of each other (b's cell needs (r - 1, a), (r - 2, a) and (r - 2, b): all of the step before), so every instruction of one has an
-// independent neighbour from the other -- the three-instruction chain max -> sub -> max that carries E down a column no longer
-// stalls the wave that runs alone on its SIMD while the other one waits for memory, and no packed result is consumed by the very
-// next instruction (gfx950 wants a wait state there: the single-column loop carried 92 s_nop per four columns).  Same values,
-// same order of the decisions inside every cell: bit-identical to two calls of column<R, true, MID, CODES>.
-//   qa / qa2, qb / qb2: the columns' tables (CODES) or the columns' bytes; hda = H[-1][j-1], hdb = H[-1][j]; ea, eb: E entering
-//   the strip at the two columns (in), leaving it (out); ha_last: H[R-1][j] (h[R-1] holds column b's when this returns).
-template <int R, bool MID, bool CODES>
-__device__ __forceinline__ void column_pair(unsigned (&h)[R], unsigned (&f)[R], const unsigned (&t)[R], const unsigned qa, const unsigned qa2, const unsigned qb,
-                                            const unsigned qb2, const unsigned hda, const unsigned hdb, unsigned &ea, unsigned &eb, const LaneConsts &c,
-                                            unsigned &ha_last, uint2 *mida, uint2 *midb)
-{
-    auto differ_a = [&](const int r) { return CODES ? __builtin_amdgcn_perm(qa2, qa, t[r]) : pk_min_u(qa ^ t[r], c.one); };
-    auto differ_b = [&](const int r) { return CODES ? __builtin_amdgcn_perm(qb2, qb, t[r]) : pk_min_u(qb ^ t[r], c.one); };
-    unsigned dga = pk_add(hda, pk_mad(differ_a(0), c.delta, c.k2));
-    unsigned dgb = pk_add(hdb, pk_mad(differ_b(0), c.delta, c.k2));
-#pragma unroll
-    for (int r = 0; r <= R; ++r) {
-        const int rb = r - 1;
-        unsigned hna = 0u, hnb = 0u, fra = 0u, frb = 0u;
-        if (r < R) {
-            fra = f[r];
-            hna = pk_max(pk_max(dga, fra), ea);
-        }
-        if (rb >= 0) {
-            frb = f[rb];
-            hnb = pk_max(pk_max(dgb, frb), eb);
-        }
-        // the diagonals of the rows below, from H of the previous column before it is overwritten
-        if (r + 1 < R) dga = pk_add(h[r], pk_mad(differ_a(r + 1), c.delta, c.k2));
-        if (rb >= 0 && rb + 1 < R) dgb = pk_add(h[rb], pk_mad(differ_b(rb + 1), c.delta, c.k2));
-        if (r < R) {
-            const unsigned open = pk_sub(hna, c.o_e);
-            ea = pk_max(open, ea);
-            f[r] = pk_max(open, fra);
-            h[r] = hna;
-            if (MID && r == 15) *mida = make_uint2(hna, ea);
-            if (r == R - 1) ha_last = hna;
-        }
-        if (rb >= 0) {
-            const unsigned open = pk_sub(hnb, c.o_e);
-            eb = pk_max(open, eb);
-            f[rb] = pk_max(open, frb);
-            h[rb] = hnb;
-            if (MID && rb == 15) *midb = make_uint2(hnb, eb);
-            asm volatile("" : "+v"(f[rb]), "+v"(h[rb]));
-        }
-    }
-}
-
 } // namespace
 
 } // namespace mgl_sw_dev

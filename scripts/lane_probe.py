@@ -19,10 +19,11 @@ for so in ((False,) if os.environ.get('FULL_ONLY') else (False, True)):
     b.run(a, score_only=so); torch.cuda.synchronize()
     a.set_profiling(1)
     t0 = time.perf_counter()
-    for _ in range(3):
+    reps = int(os.environ.get("REPS", "3"))
+    for _ in range(reps):
         b.run(a, score_only=so)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 3
+    dt = (time.perf_counter() - t0) / reps
     tm = a.timing()
     a.set_profiling(0)
     print(f"{'score-only' if so else 'full      '}: {n} pairs {tl}x{ql}: {dt*1e3:.2f} ms per call = {n*tl*ql/dt/1e9:.0f} GCUPS; fill kernel "

@@ -1,5 +1,6 @@
-"""The N > 1 path on CPU: shard ranges and the score gather with the gloo backend, world_size 2.
-(The GPU runs use the same code with backend nccl == RCCL.)"""
+"""The N > 1 path on CPU: shard ranges and the score gather with the gloo backend, world sizes 2 and 8 (the node BASELINE configs[2]
+names: uneven shards, ranks with nothing to do, the padding of the equal-size gather).  The GPU runs use the same code with backend
+nccl == RCCL."""
 import os
 import socket
 import sys
@@ -58,6 +59,51 @@ def test_gather_scores_gloo_world2(tmp_path, n_total):
     mp.spawn(_worker, args=(2, _free_port(), n_total, out), nprocs=2, join=True)
     got = torch.load(out)
     assert got.tolist() == [3 * k for k in range(n_total)]
+
+
+def _worker_bench_shape(rank, world, port, n_total, out_path):
+    """What one rank of `bench.py --gpus 8 --pairs n_total` does around its kernels: its contiguous shard of the ONE seeded workload
+    (blocks of the generator cut at shard borders), a score per pair, the barrier, the gather onto rank 0, the max-over-ranks timing."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from mgl_amd import device_batch as db
+
+    db.WORKLOAD_BLOCK = 1 << 10
+    r, lr, w = dist.init(backend="gloo")
+    lo, hi = dist.shard_range(n_total, rank, world)
+    cpu = torch.device("cpu")
+    if hi > lo:
+        b = db.window_batch(5, hi - lo, cpu, genome_len=1 << 16, first=lo)
+        local = b.queries.view(hi - lo, -1).to(torch.int32).sum(dim=1).to(torch.int32)   # stand-in for ScoreMax.max: a function of the pair alone
+    else:
+        local = torch.zeros(0, dtype=torch.int32)
+    dist.barrier()
+    got = dist.gather_scores(local, n_total, dst=0)
+    assert dist.max_over_ranks(float(rank), cpu) == float(world - 1)
+    assert (got is not None) == (rank == 0)
+    if rank == 0:
+        torch.save(got, out_path)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [100003, 5])
+def test_world_size_8_uneven_shards_and_idle_ranks(tmp_path, n_total):
+    """BASELINE configs[2]'s node on CPU: eight ranks over gloo, n_total not divisible by eight (100 003: shards of 12 501 and 12 500;
+    5: three ranks hold nothing and still take part in every collective); the gathered vector equals what ONE rank computes for the
+    whole seeded workload."""
+    from mgl_amd import device_batch as db
+
+    out = str(tmp_path / "gathered8.pt")
+    mp.spawn(_worker_bench_shape, args=(8, _free_port(), n_total, out), nprocs=8, join=True)
+    got = torch.load(out)
+    block = db.WORKLOAD_BLOCK
+    try:
+        db.WORKLOAD_BLOCK = 1 << 10
+        full = db.window_batch(5, n_total, torch.device("cpu"), genome_len=1 << 16)
+    finally:
+        db.WORKLOAD_BLOCK = block
+    want = full.queries.view(n_total, -1).to(torch.int32).sum(dim=1).to(torch.int32)
+    assert got.dtype == torch.int32 and got.shape == (n_total,) and torch.equal(got, want)
 
 
 def test_single_process_is_identity():

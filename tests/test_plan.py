@@ -144,6 +144,22 @@ def test_mixed_geometries_are_sorted_by_the_library():
     assert few.sorted_by_library == 0 and few.fill_kernel == DP32
 
 
+def test_a_promise_of_blocks_of_eight_does_not_keep_a_large_batch_from_the_lane_kernel():
+    """MGL_SW_FLAG_GROUPED_GEOMETRY (a caller who has sorted by read length): round 3 pinned such a batch to the eight-pairs-per-wave
+    kernel -- 3 013 GCUPS where the caller who promised nothing got 4 883.  Where the library's own sort would feed the lane kernel
+    the promise is set aside; a batch too small for lane launches keeps it."""
+    ws = 72 << 30
+    grouped = _lib.FLAG_GROUPED_GEOMETRY
+    big = plan(n=4_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=grouped, workspace=ws)
+    none = plan(n=4_000_000, max_tl=256, max_ql=150, parameters=GATK, workspace=ws)
+    assert big.fill_kernel == LANE16_CK and big.sorted_by_library == 1
+    assert (big.chunk_pairs, big.chunks, big.workspace_halves) == (none.chunk_pairs, none.chunks, none.workspace_halves)
+    small = plan(n=100_000, max_tl=256, max_ql=150, parameters=GATK, flags=grouped, workspace=ws)
+    assert small.fill_kernel == DP16 and small.sorted_by_library == 0
+    tight = plan(n=4_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=grouped)     # 4 GiB: chunks below the lane launches' threshold
+    assert tight.fill_kernel == DP16 and tight.sorted_by_library == 0
+
+
 def test_host_entries_pipeline_chunks_on_two_streams():
     a = plan(n=10_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=UNIFORM, entry=1, workspace=BENCH_WS)
     assert a.fill_kernel == LANE16_CK and a.fill_streams == 2 and a.workspace_halves == 2
