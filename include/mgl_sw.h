@@ -172,8 +172,10 @@ int mgl_sw_ctx_set_profiling(mgl_sw_ctx *ctx, int enable);
  * context (its workspace limit and forced modes included) -- nothing is launched, allocated or copied.  flags: MGL_SW_FLAG_*;
  * packed2: the sequences are 2-bit packed; entry: 0 = device-resident (mgl_sw_align_batch_device*), 1 = host buffers
  * (mgl_sw_align_batch / _status / _2bit).  ctx may be NULL: a default context on a 256-CU device (what the CPU tests pin), with
- * workspace_limit bytes of workspace (0: the default, or the context's own limit when ctx is given).  Returns the status the call
- * itself would return from its planning (MGL_SW_ERR_UNSUPPORTED, ...). */
+ * workspace_limit bytes of workspace (0: the default, or the context's own limit when ctx is given).  Planned with a CIGAR stride of
+ * 64 bytes (the only decision the stride enters is whether a small batch's text fits the one-wave-per-pair kernel's LDS: a call with
+ * a much larger stride may leave that kernel where this plan names it).  Returns the status the call itself would return from its
+ * planning (MGL_SW_ERR_UNSUPPORTED, ...). */
 int mgl_sw_explain(mgl_sw_ctx *ctx, int64_t workspace_limit, int64_t n, int max_tl, int max_ql, int match, int mismatch, int gopen,
                    int gext, int strategy, int flags, int packed2, int entry, mgl_sw_plan *out);
 int mgl_sw_ctx_get_timing(mgl_sw_ctx *ctx, mgl_sw_timing *out); /* waits for the last call's kernels */
@@ -213,9 +215,11 @@ int mgl_sw_coalescing_stats(int64_t *batches, int64_t *pairs);
  * memory; its reply half in pinned host memory -- and one resident wave that serves it (sw_service.hip).  A call writes its pair into the mailbox and spins until the wave hands the
  * result back: no kernel launch, no stream synchronisation and no other thread on the request path (this replaces the
  * launch-per-call of ..._MicrosoftSmithWaterman.cpp:44-71's callers).  A wave ends by itself when its mailbox has been quiet for
- * idle_us (default 1 000; environment MGL_SW_SERVICE_IDLE_US) or after MGL_SW_SERVICE_LIFE_MS (default 50) -- a resident
+ * idle_us (default 1 000; environment MGL_SW_SERVICE_IDLE_US) or after MGL_SW_SERVICE_LIFE_MS (default 20) -- a resident
  * kernel holds up device-wide synchronisation for that long at most -- and the next call launches it again.  `slots` mailboxes at
- * most (default 64, environment MGL_SW_SERVICE_SLOTS, at most 128); threads beyond that, and pairs that do not fit, take the
+ * most (default 64, environment MGL_SW_SERVICE_SLOTS, at most 128, and never more than half the device's CUs: a mailbox's wave holds
+ * its carve of LDS -- 64 KB, the full 160 KB only once a pair has needed it -- for as long as the grid lives); threads beyond that,
+ * pairs that do not fit, and any call whose wave does not answer within 20 s (the service is switched off from then on) take the
  * coalescer.  slots = 0 switches the service off; idle_us = 0 keeps the current value.  Follows mgl_sw_set_coalescing: with
  * coalescing off every call is a direct call.
  */

@@ -70,7 +70,9 @@ struct DpArgs {
     int strip_k;              // sw_dp16_strip_kernel: 0 = the flags of every cell are stored; K > 0 = none are: rows and checkpoints of bands of K strips (strip16_ck_*)
     int strip_pack;           // ... their entries: 0 = {H, gap value} as two int32; B > 0 = one int32, H << B | (H - gap value) (strip16_pack_bits)
     int lane_slots;           // sw_dp16_lane_ck_kernel: wave slots of its persistent grid = regions at tb / scratch (lane_ck_slots)
-    unsigned *tile_ctr;       // ... the counter its waves draw their next tile from: zero at launch (needed when the launch holds more tiles than slots)
+    unsigned *tile_ctr;       // ... four words, zero at launch (needed when the launch holds more tiles than slots): the counter its waves draw their next tile from,
+                              // ~(the fastest tile so far), the number of slow waves that have left early, one spare
+    int lane_no_early_exit;   // ... measurements: slow waves draw tiles to the end like everybody else
 };
 
 struct TbArgs {
@@ -255,7 +257,8 @@ bool small_fits_int16(int max_tl, int max_ql, int match, int mismatch, int gopen
 // the host launches it again when a request finds its wave gone.
 constexpr int SERVICE_MAX_TL = 512, SERVICE_MAX_QL = 2048;
 constexpr int SERVICE_TEXT_BYTES = (2 * (SERVICE_MAX_TL + SERVICE_MAX_QL) + 4 + 3) & ~3;
-constexpr int SERVICE_LDS_BYTES = 160 * 1024;
+constexpr int SERVICE_LDS_BYTES = 160 * 1024;     // the most a mailbox's wave may need: a whole CU's LDS
+constexpr int SERVICE_LDS_DEFAULT = 64 * 1024;    // what a grid is launched with until a request needs more (a 256 x 150 pair: 40 KB): two mailboxes per CU, and room for others
 enum : uint32_t { SERVICE_IDLE = 0, SERVICE_RUNNING = 1, SERVICE_EXITED = 3, SERVICE_LAUNCHED = 4 }; // low four bits of `state`; above them the grid's generation
 // A mailbox is two pieces.  The REQUEST is written by the calling thread and read by the wave: it lives in fine-grained DEVICE memory
 // where the host can store into device memory directly (large BAR: posted writes over the link, and the wave polls its own HBM instead
@@ -268,7 +271,8 @@ struct alignas(64) ServiceRequest {
     int32_t tl, ql, match, mismatch, gopen, gext, strategy; // (normalised parameters)
     int32_t cigar_stride, wide;
     uint32_t quit_gen; // grids up to this generation are asked to end
-    int32_t pad0[4];
+    int32_t lds_need;  // bytes of LDS this pair takes (small_lds_bytes): a wave whose grid was launched with less ends, and the caller launches a larger one
+    int32_t pad0[3];
     uint32_t seq_b;
     uint8_t t[SERVICE_MAX_TL];
     uint8_t q[SERVICE_MAX_QL];
@@ -285,12 +289,17 @@ struct alignas(64) ServiceReply {
 static_assert(offsetof(ServiceRequest, t) == 64 && offsetof(ServiceReply, cigar) == 64, "one header line each");
 struct ServiceControl { // device memory, zeroed once
     unsigned long long last_activity; // 100 MHz time of the last request any wave has served
-    uint32_t stop_gen;                // the waves of grids up to this generation end at their next look
+    uint32_t stop_gen;                // the waves of grids up to this generation end at their next look (the host sets it to gen - 1 in front of every launch)
     uint32_t pad;
 };
 // `slots` workgroups on mailboxes 0 .. slots - 1
+// Generations are 28-bit numbers (the reply's `state` keeps four bits for SERVICE_*) compared modulo 2^28: a is "at or after" b when
+// the 28-bit difference a - b, read as a signed number, is not negative.
+constexpr uint32_t SERVICE_GEN_MASK = 0x0fffffffu;
+__host__ __device__ inline bool service_gen_reached(uint32_t a, uint32_t b) { return (int32_t)((a - b) << 4) >= 0; }
+// `slots` workgroups on mailboxes 0 .. slots - 1, `lds_bytes` of dynamic LDS each
 hipError_t launch_service(const ServiceRequest *requests, ServiceReply *replies, ServiceControl *ctl, int slots, uint32_t gen, uint32_t idle_ticks,
-                          uint32_t life_ticks, hipStream_t stream);
+                          uint32_t life_ticks, int lds_bytes, hipStream_t stream);
 
 // Device-side sort of a chunk by geometry (sw_kernels.hip): a counting sort over the (tl, ql) grid [1, max_tl] x [1, max_ql].
 // Slots [0, total[0]) hold the full blocks of eight pairs of one geometry, cell after cell; the left-over pairs (fewer than

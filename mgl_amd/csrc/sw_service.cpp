@@ -34,6 +34,7 @@ using namespace mgl_sw_dev;
 using Clock = std::chrono::steady_clock;
 
 constexpr int MAX_SLOTS = 128;
+constexpr int SERVICE_DECLINED = 1 << 20; // what mgl_sw_service_align returns for a call that does not go through a mailbox (sw_capi.cpp takes the coalescer then)
 
 inline uint32_t load_acquire(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 inline void store_release(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
@@ -47,6 +48,22 @@ struct Slot {
 };
 
 std::atomic<bool> g_pool_alive{false};
+
+// The service's HIP calls (allocation, launches) happen on the CALLER's thread: its current device is put back when they are done -- a
+// caller with its own HIP or torch state on another GPU must not find it changed by a one-pair call.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
 
 class ServicePool {
   public:
@@ -66,13 +83,22 @@ class ServicePool {
     // library unload / process exit: ask the grid to end, wait until it has, release everything
     ~ServicePool()
     {
-        g_pool_alive.store(false);
-        std::lock_guard<std::mutex> lk(mu_);
-        if (!reps_) return;
-        for (int k = 0; k < grid_slots_; ++k) __atomic_store_n(&reqs_[k].quit_gen, grid_gen_, __ATOMIC_RELEASE);
+        g_pool_alive.store(false); // (from here on the leases of threads that end do not come back: give_back is not called any more)
+        broken_.store(true);       // ... and a call that is still on its way is declined
+        int slots = 0;
+        uint32_t gen = 0;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!reps_) return;
+            slots = grid_slots_;
+            gen = grid_gen_;
+        }
+        // (the lock is NOT held across the wait below: a caller inside relaunch() must be able to finish)
+        for (int k = 0; k < slots; ++k) __atomic_store_n(&reqs_[k].quit_gen, gen, __ATOMIC_RELEASE);
         flush_stores();
-        (void)hipSetDevice(device_);
+        DeviceGuard dev(device_);
         (void)hipStreamSynchronize(stream_); // (bounded by the waves' own conditions even if the request went unseen)
+        std::lock_guard<std::mutex> lk(mu_);
         (void)hipStreamDestroy(stream_);
         (void)hipFree(ctl_);
         if (over_bar_)
@@ -105,7 +131,9 @@ class ServicePool {
             }
         };
         static thread_local Lease mine;
-        const int cap = max_slots_.load(std::memory_order_relaxed);
+        // (a mailbox's wave holds its carve of LDS for as long as the grid lives: never more mailboxes than a quarter of the CUs' worth of
+        // default carves -- two per CU on half the CUs -- whatever the setting; cu_cap_ is known once the pool has allocated)
+        const int cap = std::min(max_slots_.load(std::memory_order_relaxed), cu_cap_.load(std::memory_order_relaxed));
         if (broken_.load(std::memory_order_relaxed)) return nullptr;
         if (mine.s) {
             if (mine.s->index < cap) return mine.s;
@@ -127,7 +155,7 @@ class ServicePool {
     }
 
     int call(Slot &s, const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen, int gext, int strategy, int stride,
-             int wide, char *cigar, int cigar_cap, int *cigar_len, int *offset, mgl_sw_score *ez)
+             int wide, int lds_need, char *cigar, int cigar_cap, int *cigar_len, int *offset, mgl_sw_score *ez)
     {
         ServiceRequest &rq = *s.rq;
         ServiceReply &mb = *s.rp;
@@ -142,6 +170,9 @@ class ServicePool {
         rq.strategy = strategy;
         rq.cigar_stride = stride;
         rq.wide = wide;
+        rq.lds_need = lds_need;
+        // a pair beyond the carve the grids are launched with: the next grid gets the full one (the running grid ends when its wave sees this request)
+        if (lds_need > lds_tier_.load(std::memory_order_relaxed)) lds_tier_.store(SERVICE_LDS_BYTES, std::memory_order_relaxed);
         const uint32_t seq = ++s.seq;
         // (device memory behind the BAR is write-combining for the host: stores leave in no particular order, and only when a buffer is
         // evicted or a fence says so -- the pair before the numbers, the numbers at once)
@@ -175,9 +206,12 @@ class ServicePool {
                 const timespec nap{0, spins < 4200 ? 20000 : 100000};
                 nanosleep(&nap, nullptr);
                 if ((spins & 255) == 0 && Clock::now() - t0 > std::chrono::seconds(20)) {
+                    // No answer: the service is switched off for the rest of the process and THIS call goes the way of a declined one (the
+                    // coalescer; nothing of the caller's was handed to the device: a late answer lands in the mailbox, which stays leased
+                    // to its thread, and is never read).
                     std::lock_guard<std::mutex> lk(mu_);
-                    broken_ = true; // (this mailbox stays leased to its thread: nobody else will wait on it)
-                    return MGL_SW_ERR_DEVICE;
+                    broken_ = true;
+                    return SERVICE_DECLINED;
                 }
             }
         }
@@ -194,11 +228,13 @@ class ServicePool {
     bool allocate_locked()
     {
         void *p = nullptr, *d = nullptr, *c = nullptr, *r = nullptr, *rd = nullptr;
-        int lo = 0, hi = 0, large_bar = 0;
-        if (hipSetDevice(device_) != hipSuccess || hipHostMalloc(&p, sizeof(ServiceReply) * MAX_SLOTS, hipHostMallocDefault) != hipSuccess) {
+        int lo = 0, hi = 0, large_bar = 0, cus = 0;
+        DeviceGuard dev(device_);
+        if (!dev.ok || hipHostMalloc(&p, sizeof(ServiceReply) * MAX_SLOTS, hipHostMallocDefault) != hipSuccess) {
             broken_ = true;
             return false;
         }
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_) == hipSuccess && cus > 0) cu_cap_.store(std::max(1, cus / 2));
         memset(p, 0, sizeof(ServiceReply) * MAX_SLOTS);
         // the requests: device memory the host stores into directly, where the platform allows (MGL_SW_SERVICE_BAR=0: never)
         const char *const bar = getenv("MGL_SW_SERVICE_BAR");
@@ -268,16 +304,18 @@ class ServicePool {
         if (covered && ((st & 15u) == SERVICE_LAUNCHED || (st & 15u) == SERVICE_RUNNING)) return MGL_SW_OK; // somebody else has
         if (covered && (st >> 4) != grid_gen_) return MGL_SW_OK; // (EXITED of an older grid, written late over the LAUNCHED of the current one: its wave is on its way)
         (void)seen;
-        if (hipSetDevice(device_) != hipSuccess) return MGL_SW_ERR_DEVICE;
+        DeviceGuard dev(device_);
+        if (!dev.ok) return MGL_SW_ERR_DEVICE;
         // the running grid (if this mailbox is beyond it, it may be busy with the others) is asked to end; the next one starts behind it on the stream
         for (int k = 0; k < grid_slots_; ++k) __atomic_store_n(&reqs_[k].quit_gen, grid_gen_, __ATOMIC_RELEASE);
         flush_stores();
-        const uint32_t gen = (grid_gen_ + 1) & 0x0fffffffu;
+        uint32_t gen = (grid_gen_ + 1) & SERVICE_GEN_MASK;
+        if (gen == 0) gen = 1; // (0 is what a mailbox that has never been asked to quit holds)
         const int n = used_slots_;
         for (int k = 0; k < n; ++k) store_release(&reps_[k].state, gen << 4 | SERVICE_LAUNCHED);
         const uint32_t idle = (uint32_t)std::min<int64_t>((int64_t)idle_us_.load() * 100, 0x7fffffff);
         const uint32_t life = (uint32_t)std::min<int64_t>((int64_t)life_ms_.load() * 100000, 0x7fffffff);
-        const hipError_t e = launch_service(reqs_dev_, reps_dev_, ctl_, n, gen, idle, life, stream_);
+        const hipError_t e = launch_service(reqs_dev_, reps_dev_, ctl_, n, gen, idle, life, lds_tier_.load(std::memory_order_relaxed), stream_);
         if (e != hipSuccess) {
             for (int k = 0; k < n; ++k) store_release(&reps_[k].state, grid_gen_ << 4 | SERVICE_EXITED);
             broken_ = true;
@@ -303,6 +341,8 @@ class ServicePool {
     int used_slots_ = 0;    // mailboxes handed out so far (a grid covers all of them: a thread that comes back finds its wave)
     int device_ = 0;
     std::atomic<int> max_slots_{64}, idle_us_{1000}, life_ms_{20};
+    std::atomic<int> cu_cap_{MAX_SLOTS};             // half the device's CUs, once known
+    std::atomic<int> lds_tier_{SERVICE_LDS_DEFAULT}; // dynamic LDS of the next grid: the default until a pair has needed more
     std::atomic<int> leased_{0};
     const int cpus_ = usable_cpus();
     std::atomic<int64_t> calls_{0}, launches_{0};
@@ -315,18 +355,19 @@ class ServicePool {
 extern "C" MGL_SW_INTERNAL int mgl_sw_service_align(const char *t, int tl, const char *q, int ql, int match, int mismatch, int gopen, int gext, int strategy,
                                                     char *cigar, int cigar_cap, int *cigar_len, int *offset, mgl_sw_score *ez)
 {
-    constexpr int DECLINED = 1 << 20;
+    constexpr int DECLINED = SERVICE_DECLINED;
     if (tl > SERVICE_MAX_TL || ql > SERVICE_MAX_QL) return DECLINED;
     mgl_sw_normalize_params(&match, &mismatch, &gopen, &gext);
     if (((int64_t)match - mismatch + gopen + 2 * (int64_t)gext) * ((int64_t)tl + ql) >= (1ll << 30)) return DECLINED; // (run_device's bound for 32-bit scores)
     const int stride = std::min((cigar_cap + 3) & ~3, (2 * (tl + ql) + 4 + 3) & ~3); // no CIGAR of this pair is longer than that
     const bool wide = !small_fits_int16(tl, ql, match, mismatch, gopen, gext);
-    if (stride > SERVICE_TEXT_BYTES || small_lds_bytes(tl, ql, stride, wide) > SERVICE_LDS_BYTES) return DECLINED;
+    const int lds_need = small_lds_bytes(tl, ql, stride, wide);
+    if (stride > SERVICE_TEXT_BYTES || lds_need > SERVICE_LDS_BYTES) return DECLINED;
     try { // (nothing may leave through the C ABI: the caller may be a JVM)
         ServicePool &pool = ServicePool::instance();
         Slot *s = pool.lease();
         if (!s) return DECLINED;
-        return pool.call(*s, t, tl, q, ql, match, mismatch, gopen, gext, strategy, stride, wide ? 1 : 0, cigar, cigar_cap, cigar_len, offset, ez);
+        return pool.call(*s, t, tl, q, ql, match, mismatch, gopen, gext, strategy, stride, wide ? 1 : 0, lds_need, cigar, cigar_cap, cigar_len, offset, ez);
     } catch (...) {
         return MGL_SW_ERR_DEVICE;
     }

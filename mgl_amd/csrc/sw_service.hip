@@ -40,7 +40,7 @@ __device__ __forceinline__ void store_system(uint32_t *p, uint32_t v) { __hip_at
 } // namespace
 
 __global__ __launch_bounds__(64) void sw_service_kernel(const ServiceRequest *const requests, ServiceReply *const replies, ServiceControl *const ctl, const uint32_t gen,
-                                                        const uint32_t idle_ticks, const uint32_t life_ticks)
+                                                        const uint32_t idle_ticks, const uint32_t life_ticks, const int lds_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
@@ -56,6 +56,12 @@ __global__ __launch_bounds__(64) void sw_service_kernel(const ServiceRequest *co
         const uint32_t w = lane < 16 ? load_system(line0 + lane) : 0u;
         const uint32_t seq_a = __builtin_amdgcn_readlane(w, 0), seq_b = __builtin_amdgcn_readlane(w, 15);
         const uint32_t quit_gen = __builtin_amdgcn_readlane(w, 10);
+        if (seq_a == seq_b && seq_a != served && (int)__builtin_amdgcn_readlane(w, 11) > lds_bytes) {
+            // a pair that needs more LDS than this grid was launched with (the default leaves room on the CU for other work): the grid
+            // ends -- every wave at its next look -- and the caller, who finds its wave gone, launches one with the larger carve
+            if (lane == 0) __hip_atomic_fetch_max(&ctl->stop_gen, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
         if (seq_a == seq_b && seq_a != served) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // the sequences were written before the number
             TbArgs a{};
@@ -87,8 +93,8 @@ __global__ __launch_bounds__(64) void sw_service_kernel(const ServiceRequest *co
         const uint32_t stop_gen = __hip_atomic_load(&ctl->stop_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint64_t heard = __hip_atomic_load(&ctl->last_activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint64_t now = __builtin_amdgcn_s_memrealtime();
-        // (generations are compared as signed differences: the counter may wrap)
-        if ((int32_t)(quit_gen - gen) >= 0 || (int32_t)(stop_gen - gen) >= 0) break;
+        // (generations are 28-bit numbers compared modulo 2^28: the counter wraps; the host sets stop_gen to gen - 1 in front of every launch)
+        if (service_gen_reached(quit_gen, gen) || service_gen_reached(stop_gen, gen)) break;
         const uint64_t last = heard > t_start ? heard : t_start;
         if ((int64_t)(now - last) > (int64_t)idle_ticks || now - t_start > life_ticks) {
             if (lane == 0) __hip_atomic_fetch_max(&ctl->stop_gen, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (generations grow: max is "latest")
@@ -105,9 +111,9 @@ __global__ __launch_bounds__(64) void sw_service_kernel(const ServiceRequest *co
 }
 
 hipError_t launch_service(const ServiceRequest *requests, ServiceReply *replies, ServiceControl *ctl, int slots, uint32_t gen, uint32_t idle_ticks, uint32_t life_ticks,
-                          hipStream_t stream)
+                          int lds_bytes, hipStream_t stream)
 {
-    if (slots < 1) return hipErrorInvalidValue;
+    if (slots < 1 || lds_bytes < 1 || lds_bytes > SERVICE_LDS_BYTES) return hipErrorInvalidValue;
     static std::atomic<unsigned long long> raised{0}; // the attribute is per device: raised once on each
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -118,7 +124,10 @@ hipError_t launch_service(const ServiceRequest *requests, ServiceReply *replies,
         if (e != hipSuccess) return e;
         raised.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL(sw_service_kernel, dim3((unsigned)slots), dim3(64), (size_t)SERVICE_LDS_BYTES, stream, requests, replies, ctl, gen, idle_ticks, life_ticks);
+    // stop_gen = the generation before this one: whatever an earlier grid latched (or a wrapped counter left) no longer stops this grid
+    e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&ctl->stop_gen), (int)((gen - 1u) & SERVICE_GEN_MASK), 1, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sw_service_kernel, dim3((unsigned)slots), dim3(64), (size_t)lds_bytes, stream, requests, replies, ctl, gen, idle_ticks, life_ticks, lds_bytes);
     return hipGetLastError();
 }
 

@@ -233,7 +233,7 @@ class MicrosoftSmithWaterman:
         _check(_lib.lib().mgl_sw_ctx_set_lane_checkpoint(self._ensure(), int(mode)))
 
     def set_small_kernel(self, mode):
-        """Small batches (up to 2 048 pairs whose score matrix fits LDS): one wave per pair, fill + walk in one launch.
+        """Small batches (up to 5 120 pairs of one promised geometry, 8 192 without a promise -- half where one matrix fills more than half a CU's LDS --: one wave per pair, fill + walk in one launch.
         0 = default (on, unless another kernel choice is forced), 1 = never, 2 = whenever the bounds allow."""
         _check(_lib.lib().mgl_sw_ctx_set_small_kernel(self._ensure(), int(mode)))
 

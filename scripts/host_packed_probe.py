@@ -13,7 +13,7 @@ a = MicrosoftSmithWaterman(0)
 a.set_workspace(int(bench.DEFAULT_WORKSPACE_GIB * (1 << 30)))
 b = device_batch.window_batch(42, n, dev)
 b.run(a); torch.cuda.synchronize()
-args = argparse.Namespace(steps=int(sys.argv[2]) if len(sys.argv) > 2 else 2, seed=42)
+args = argparse.Namespace(steps=int(sys.argv[2]) if len(sys.argv) > 2 else 2, seed=42, workspace_gib=bench.DEFAULT_WORKSPACE_GIB)
 out = bench.pcie_inclusive_leg(a, b, args)
 print(json.dumps({k: (v if not isinstance(v, dict) else {kk: v[kk] for kk in ("ms_per_step", "gcups", "mismatches_vs_headline")}) for k, v in out.items()
                   if k in ("ms_per_step", "gcups", "registered", "packed_2bit", "registered_error")}))

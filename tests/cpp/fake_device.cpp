@@ -21,6 +21,12 @@ int fake_hip_device_count(void)
     return n;
 }
 
+int *fake_hip_current_device(void)
+{
+    static thread_local int d = 0;
+    return &d;
+}
+
 namespace mgl_sw_dev {
 
 std::atomic<long long> fake_fill_launches{0}, fake_walk_pairs{0}, fake_packed_pairs{0};
@@ -136,8 +142,12 @@ hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &w, hipStream_t)
 {
     // the persistent grid's contract (sw_dp16_lane_ck.hip): wave slots, and a zeroed tile counter wherever the tiles outnumber them
     const int64_t tiles = ((a.count + 1) / 2 + 63) / 64;
-    if (a.lane_slots < 1 || (tiles > a.lane_slots && (!a.tile_ctr || *a.tile_ctr != 0u))) return hipErrorInvalidValue;
-    if (a.tile_ctr) *a.tile_ctr = (unsigned)tiles; // (what the real waves leave behind: the next launch on this word must clear it)
+    if (a.lane_slots < 1 || (tiles > a.lane_slots && (!a.tile_ctr || a.tile_ctr[0] != 0u || a.tile_ctr[1] != 0u || a.tile_ctr[2] != 0u))) return hipErrorInvalidValue;
+    if (a.tile_ctr) { // (what the real waves leave behind: the next launch on these words must clear them)
+        a.tile_ctr[0] = (unsigned)tiles;
+        a.tile_ctr[1] = ~100u;
+        a.tile_ctr[2] = (unsigned)(a.lane_slots / 2);
+    }
     remember(a);
     if (w.cigar) walk(w, false);
     return hipSuccess;
@@ -149,7 +159,7 @@ bool small_supported(int max_tl, int max_ql, int, int, int, int, int, bool *wide
     if (wide) *wide = false;
     return max_tl <= 512 && (int64_t)max_tl * max_ql <= 60000;
 }
-int small_lds_bytes(int, int, int, bool) { return 0; }
+int small_lds_bytes(int tl, int ql, int stride, bool wide) { return tl * ql * (wide ? 4 : 2) + tl + ql + stride; } // (about what sw_small.hip's carve takes)
 hipError_t launch_small(const TbArgs &a, int, int, bool, hipStream_t)
 {
     g_match = a.match;
@@ -166,9 +176,12 @@ bool small_fits_int16(int, int, int, int, int, int) { return true; }
 std::atomic<long long> fake_service_waves{0}, fake_service_pairs{0};
 static std::atomic<unsigned long long> g_service_last{0};
 static std::atomic<uint32_t> g_service_stop{0};
+std::atomic<int> fake_service_lds_bytes{0}; // the dynamic LDS of the last grid launched
 hipError_t launch_service(const ServiceRequest *requests, ServiceReply *replies, ServiceControl *, int slots, uint32_t gen, uint32_t idle_ticks, uint32_t life_ticks,
-                          hipStream_t)
+                          int lds_bytes, hipStream_t)
 {
+    if (slots < 1 || lds_bytes < 1 || lds_bytes > SERVICE_LDS_BYTES) return hipErrorInvalidValue;
+    fake_service_lds_bytes = lds_bytes;
     static std::mutex order;              // "the stream": a grid starts when the one before it has ended
     struct Joiner {                       // (the last grid's threads end by their own conditions: joined when the process ends)
         std::vector<std::thread> v;
@@ -182,11 +195,12 @@ hipError_t launch_service(const ServiceRequest *requests, ServiceReply *replies,
     std::lock_guard<std::mutex> lk(order);
     for (auto &t : prev) t.join();
     prev.clear();
+    g_service_stop.store((gen - 1u) & SERVICE_GEN_MASK); // (launch_service's memset in front of the grid)
     using Clock = std::chrono::steady_clock;
     static const auto epoch = Clock::now();
     for (int k = 0; k < slots; ++k) {
         ++fake_service_waves;
-        prev.emplace_back([mb = requests + k, rp = replies + k, gen, idle_ticks, life_ticks] {
+        prev.emplace_back([mb = requests + k, rp = replies + k, gen, idle_ticks, life_ticks, lds_bytes] {
             auto ticks = [] { return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - epoch).count() / 10; };
             uint32_t served = __atomic_load_n(&rp->done_seq, __ATOMIC_ACQUIRE);
             __atomic_store_n(&rp->state, gen << 4 | (uint32_t)SERVICE_RUNNING, __ATOMIC_RELEASE);
@@ -194,6 +208,12 @@ hipError_t launch_service(const ServiceRequest *requests, ServiceReply *replies,
             for (;;) {
                 const uint32_t seq_a = __atomic_load_n(&mb->seq_a, __ATOMIC_ACQUIRE), seq_b = __atomic_load_n(&mb->seq_b, __ATOMIC_ACQUIRE);
                 const uint32_t quit_gen = __atomic_load_n(&mb->quit_gen, __ATOMIC_ACQUIRE);
+                if (seq_a == seq_b && seq_a != served && mb->lds_need > lds_bytes) { // the grid's carve is too small for this pair: the grid ends
+                    uint32_t seen = g_service_stop.load();
+                    while (seen < gen && !g_service_stop.compare_exchange_weak(seen, gen)) {
+                    }
+                    break;
+                }
                 if (seq_a == seq_b && seq_a != served) {
                     std::vector<char> text((size_t)(mb->tl + mb->ql + 4) * 12);
                     int len = 0, off = 0;
@@ -216,7 +236,7 @@ hipError_t launch_service(const ServiceRequest *requests, ServiceReply *replies,
                     continue;
                 }
                 const unsigned long long now = ticks(), last = std::max(g_service_last.load(), t_start);
-                if ((int32_t)(quit_gen - gen) >= 0 || (int32_t)(g_service_stop.load() - gen) >= 0) break;
+                if (service_gen_reached(quit_gen, gen) || service_gen_reached(g_service_stop.load(), gen)) break;
                 if ((long long)(now - last) > (long long)idle_ticks || now - t_start > life_ticks) {
                     uint32_t seen = g_service_stop.load();
                     while (seen < gen && !g_service_stop.compare_exchange_weak(seen, gen)) {

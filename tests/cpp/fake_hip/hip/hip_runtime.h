@@ -30,7 +30,14 @@ enum { hipDeviceMallocFinegrained = 1 };
 int fake_hip_device_count(void); /* tests/cpp/fake_device.cpp: FAKE_HIP_DEVICES, default 2 */
 
 static inline hipError_t hipGetDeviceCount(int *n) { *n = fake_hip_device_count(); return *n > 0 ? hipSuccess : hipErrorNoDevice; }
-static inline hipError_t hipSetDevice(int d) { return d >= 0 && d < fake_hip_device_count() ? hipSuccess : hipErrorInvalidValue; }
+int *fake_hip_current_device(void); /* tests/cpp/fake_device.cpp: the calling thread's current device */
+static inline hipError_t hipSetDevice(int d)
+{
+    if (d < 0 || d >= fake_hip_device_count()) return hipErrorInvalidValue;
+    *fake_hip_current_device() = d;
+    return hipSuccess;
+}
+static inline hipError_t hipGetDevice(int *d) { *d = *fake_hip_current_device(); return hipSuccess; }
 static inline hipError_t hipGetLastError(void) { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : e == hipErrorOutOfMemory ? "out of memory" : "fake hip error"; }
 static inline hipError_t hipMalloc(void **p, size_t bytes) { *p = malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
@@ -48,7 +55,15 @@ static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMem
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = *t = (size_t)8 << 30; return hipSuccess; }
-static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; }
+/* (a chip of four CUs, so that a few thousand pairs are many rounds of it; FAKE_HIP_CUS, read per call, gives another count) */
+static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t a, int)
+{
+    const char *e = a == hipDeviceAttributeMultiprocessorCount ? getenv("FAKE_HIP_CUS") : 0;
+    *v = e ? atoi(e) : 4;
+    return hipSuccess;
+}
+typedef void *hipDeviceptr_t;
+static inline hipError_t hipMemsetD32Async(hipDeviceptr_t d, int v, size_t n, hipStream_t) { for (size_t k = 0; k < n; ++k) ((int *)d)[k] = v; return hipSuccess; }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(1); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (hipStream_t)malloc(1); return hipSuccess; }

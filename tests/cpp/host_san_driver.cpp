@@ -23,8 +23,10 @@
 #include "../../include/mgl_sw.h"
 #include "../../oracle/sw_oracle.h"
 
+int *fake_hip_current_device(void); // tests/cpp/fake_device.cpp: the calling thread's current HIP device
 namespace mgl_sw_dev {
 extern std::atomic<long long> fake_fill_launches, fake_walk_pairs, fake_packed_pairs, fake_service_waves, fake_service_pairs;
+extern std::atomic<int> fake_service_lds_bytes;
 }
 
 #define CHECK(x)                                                          \
@@ -332,6 +334,7 @@ int main()
     // ---- 48 threads, one pair per call (the way GATK drives alignNative): through the coalescing front-end alone, then with the
     // mailbox service in front of it -- 32 mailboxes for 48 threads (sixteen threads keep to the coalescer), a grid that gives up after
     // 3 ms of silence and threads that all pause for 12 ms in the middle, so that calls find their wave gone and launch the grid again
+    setenv("FAKE_HIP_CUS", "64", 1); // (the service hands out mailboxes for half the CUs at most: 32 here)
     for (int with_service = 0; with_service < 2; ++with_service) {
         CHECK(mgl_sw_set_coalescing(64, 200) == 0);
         CHECK(mgl_sw_set_service(with_service ? 32 : 0, 3000) == 0);
@@ -341,10 +344,14 @@ int main()
         std::atomic<int> bad{0}, overflow_seen{0}, device_seen{0};
         auto worker = [&](int id) {
             std::mt19937 r((unsigned)id * 7919u + 1u);
+            // the caller has a HIP device of its own selected: the service's launches (which happen on this thread) must leave it as it is
+            *fake_hip_current_device() = 1;
             for (int it = 0; it < 120; ++it) {
                 if (with_service && it % 40 == 39) std::this_thread::sleep_for(std::chrono::milliseconds(12));
-                // (poisoned pairs at it = 7, 47, 87; too-small buffers every tenth call of thread 9)
-                const int tl = 40 + (int)(r() % 200), ql = 8 + (int)(r() % 100);
+                // (poisoned pairs at it = 7, 47, 87; too-small buffers every tenth call of thread 9; thread 3 sends, once, a pair whose scores
+                // need more LDS than the grids are launched with by default: its wave ends the grid, the next one gets the full carve)
+                const bool large = id == 3 && it == 60;
+                const int tl = large ? 400 : 40 + (int)(r() % 200), ql = large ? 180 : 8 + (int)(r() % 100);
                 std::string t = rnd(r, tl), q = rnd(r, ql);
                 const bool poison = id == 5 && it % 40 == 7; // the fake device fails this pair (see below)
                 if (poison) q.replace(0, 8, "NNNNNNNN");
@@ -366,6 +373,7 @@ int main()
                            memcmp(&ez, &rz, sizeof ez) != 0) {
                     ++bad;
                 }
+                if (*fake_hip_current_device() != 1) ++bad;
             }
         };
         std::vector<std::thread> th;
@@ -376,7 +384,8 @@ int main()
         batches -= batches0, pairs -= pairs0, calls -= calls0, launches -= launches0;
         CHECK(pairs + calls == 48 * 120 && batches < pairs);
         if (with_service)
-            CHECK(calls >= 32 * 120 && launches >= 2 && // (a thread that ends early hands its mailbox to one that had none; grids grow as threads arrive)
+            CHECK(mgl_sw_dev::fake_service_lds_bytes.load() == 160 * 1024 && // (the large pair of thread 3 raised the carve)
+                  calls >= 32 * 120 && launches >= 2 && // (a thread that ends early hands its mailbox to one that had none; grids grow as threads arrive)
                   mgl_sw_dev::fake_service_waves.load() >= 32 && calls == mgl_sw_dev::fake_service_pairs.load());
         else
             CHECK(calls == 0 && launches == 0);
