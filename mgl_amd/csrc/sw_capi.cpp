@@ -67,7 +67,7 @@ struct mgl_sw_ctx {
     int64_t ws_limit = kDefaultWorkspace;
     // kernel workspace, two halves: the traceback of chunk k (aux stream) overlaps the fill of chunk k+1
     DevBuf tb[2], rec[2], bnd[2], diag, scratch;
-    // sw_dp16_lane_ck_kernel's tile counters: a ring of four-word groups, one per launch (zeroed on the launch's stream right before it; a word comes
+    // sw_dp16_lane_ck_kernel's tile counters: a ring of words, one per launch (zeroed on the launch's stream right before it; a word comes
     // round again after kTileCounters launches of this context, which are ordered behind each other by then: same half, same stream)
     DevBuf tile_ctr;
     uint64_t tile_seq = 0;
@@ -780,8 +780,8 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         HIP_TRY(ctx, ctx->rec[h].reserve((size_t)chunk * sizeof(DpRecord)));
     }
     if (lane_slots > 0 && !ctx->tile_ctr.p) {
-        HIP_TRY(ctx, ctx->tile_ctr.reserve(kTileCounters * 4 * sizeof(unsigned)));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->tile_ctr.p, 0, kTileCounters * 4 * sizeof(unsigned), stream));
+        HIP_TRY(ctx, ctx->tile_ctr.reserve(kTileCounters * sizeof(unsigned)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->tile_ctr.p, 0, kTileCounters * sizeof(unsigned), stream));
     }
 
     if (use_scratch) {
@@ -975,14 +975,11 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             da.strip_pack = strip16 ? strip_pack : 0;
             da.lane_slots = 0;
             da.tile_ctr = nullptr;
-            da.lane_no_early_exit = 0;
             if (pt.lane && (lane_ck || da.grouped)) { // the persistent grid: its wave slots and, where the tiles outnumber them, a zeroed counter
                 da.lane_slots = (int)std::min<int64_t>(lane_slots, (pt.count + 127) / 128);
                 if ((pt.count + 127) / 128 > da.lane_slots) {
-                    da.tile_ctr = static_cast<unsigned *>(ctx->tile_ctr.p) + 4 * (ctx->tile_seq++ % kTileCounters);
-                    HIP_TRY(ctx, hipMemsetAsync(da.tile_ctr, 0, 4 * sizeof(unsigned), fs));
-                    const char *const nee = getenv("MGL_SW_DEBUG_LANE_NO_EARLY_EXIT"); // (measurements; read per call)
-                    da.lane_no_early_exit = nee && atoi(nee) != 0;
+                    da.tile_ctr = static_cast<unsigned *>(ctx->tile_ctr.p) + (ctx->tile_seq++ % kTileCounters);
+                    HIP_TRY(ctx, hipMemsetAsync(da.tile_ctr, 0, sizeof(unsigned), fs));
                 }
             }
             const int per_block = pt.lane ? pt.wpb * 128 : pt.packed ? pt.wpb * 8 : strip16 ? 1 : pt.wpb * (64 / pt.rows);

@@ -717,8 +717,7 @@ __device__ __forceinline__ void stage_2bit(const uint8_t *data, const int64_t st
 // One TILE = 128 pairs of the launch (pairs 128 gw .. 128 gw + 127), worked on by the wave that sits in wave slot `slot` of the
 // persistent grid: everything the wave keeps while it works -- WaveMem, the staged sequences -- lives in the slot's region, which
 // the wave reuses tile after tile (a lane only ever reads back what it has written for the tile it is working on).
-// Returns the tile's cells per pair (tl x ql: what its duration is measured against).
-__device__ __forceinline__ int sw_dp16_lane_ck_tile(const DpArgs &a, const TbArgs &walk, const int64_t gw, const int64_t slot, const int lane)
+__device__ __forceinline__ void sw_dp16_lane_ck_tile(const DpArgs &a, const TbArgs &walk, const int64_t gw, const int64_t slot, const int lane)
 {
     const int64_t n_ls = (a.count + 1) >> 1;
 #ifdef MGL_CK_PHASES
@@ -943,7 +942,6 @@ __device__ __forceinline__ int sw_dp16_lane_ck_tile(const DpArgs &a, const TbArg
 #ifdef MGL_CK_PHASES
     if (lane == 0) atomicAdd(&mgl_ck_phase_ticks[9], 1ull);
 #endif
-    return tl * ql;
 }
 
 } // namespace
@@ -953,27 +951,24 @@ __device__ __forceinline__ int sw_dp16_lane_ck_tile(const DpArgs &a, const TbArg
 // off a counter in device memory (a.tile_ctr, zero at launch) until the tiles are gone.  The workspace a launch needs is therefore
 // lane_slots regions (2 MB each at 256 x 150: 4 GB for a whole MI355X) however many pairs it holds -- round 3 gave every TILE a region
 // (15 KB per pair: 208 GiB for the bench's 10 M pairs in one launch, and chunks wherever the workspace was smaller).  Every wave
-// reaches the loop's exit: the counter only grows, a tile's work is bounded, nothing waits for another wave.  (a.tile_ctr: four words,
-// zero at launch -- the counter, ~(the fastest tile seen), the waves that have left early, one spare.)
+// reaches the loop's exit: the counter only grows, a tile's work is bounded, nothing waits for another wave.
 // ONE wave per workgroup: the waves share nothing (no LDS, no barrier), and a workgroup's registers are released only when its LAST
 // wave has ended (round 3, four per workgroup: three of four SIMD slots stood empty until the slowest was through).
 // A three-wave-per-SIMD build of the same code (168 registers, spills) was slower everywhere in round 3 and is gone.
-// WHO TAKES THE LAST TILES.  The SIMD's arbiter serves its OLDER wave first: of the two waves of a SIMD one runs a tile in 1.2 ms, the
-// other -- on what the first leaves free -- in 2.5 (traced, scripts/ck_trace.py: 1 024 slots with 50 tiles of a 10 M-pair launch, 1 024
-// with 25).  That is as good as it gets while there is work for both (1.21 tiles per ms and SIMD; one wave alone: 0.95), but a slow wave
-// that draws one of a launch's last tiles finishes it long after everybody else has gone home: 72 such tiles set the end of a
-// 1.25 M-pair launch at 9.4 ms where a wave per tile (every wave young first, old later) ended at 8.9.  So a wave that is slow -- its
-// last tile took more than 1.5 x the fastest seen so far, per cell -- draws no tile once so few are left that a fast wave will have
-// drawn AND finished it before the slow one could (a quarter of the grid's slots at twice the fastest time).  At most half the grid may
-// leave that way (a.tile_ctr[2] counts them): the others draw until the counter runs out, so every tile is taken whatever the
-// durations look like.
+// HOW THE TWO WAVES OF A SIMD SHARE IT (traced, scripts/ck_trace.py, docs/history.md C.0): the arbiter serves the OLDER wave first -- one
+// wave of every SIMD runs a tile in 1.2 ms, the other, on what the first leaves free, in 2.5 (a 10 M-pair launch: 1 024 slots with 50
+// tiles each, 1 024 with 25); together 1.21 tiles per ms and SIMD, one wave alone 0.95.  The counter evens that out: whoever is through
+// draws the next tile.  Rules that keep the slow waves from drawing a launch's last tiles were built and measured (the end of a
+// 1.25 M-pair launch moved between 8.9 and 9.6 ms either way, box by box) and are gone.
 __global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, const TbArgs walk)
 {
     const int lane = threadIdx.x & 63;
     const int64_t tiles = (((a.count + 1) >> 1) + 63) >> 6, slots = gridDim.x, slot = blockIdx.x;
     for (int64_t tile = slot; tile < tiles;) {
+#ifdef MGL_CK_TRACE
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        const int cells = sw_dp16_lane_ck_tile(a, walk, tile, slot, lane);
+#endif
+        sw_dp16_lane_ck_tile(a, walk, tile, slot, lane);
 #ifdef MGL_CK_TRACE
         if (lane == 0 && tile < (1 << 17)) {
             unsigned hw;
@@ -986,22 +981,9 @@ __global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, 
             mgl_ck_trace[4 * tile + 3] = __builtin_amdgcn_s_memrealtime();
         }
 #endif
-        if (tiles <= slots) break; // (every tile has its wave: the counters are not even touched)
-        unsigned next = 0xffffffffu; // (no tile: slots + next lies beyond every launch)
-        if (lane == 0) {
-            // 100 MHz ticks per 4 096 cells of a pair (a sorted chunk's waves run different geometries)
-            const unsigned long long ticks = __builtin_amdgcn_s_memrealtime() - t0;
-            const unsigned d = (unsigned)min(ticks * 4096ull / (unsigned long long)max(cells, 1), 0x7fffffffull) + 1u;
-            const unsigned seen = ~atomicMax(a.tile_ctr + 1, ~d); // (the word holds ~fastest: zero at launch = nothing seen yet)
-            const unsigned fastest = min(seen, d);
-            const int64_t left = tiles - slots - (int64_t)__hip_atomic_load(a.tile_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // (left alone, the tile would be drawn by one of the slots / 2 fast waves after left / (slots / 2) of their tiles and take one more:
-            // it is done sooner that way when left * fastest / (slots / 2) + fastest < d; half of that margin is kept for a slow wave's gain from
-            // a neighbour that leaves)
-            const bool leave = !a.lane_no_early_exit && d > fastest + (fastest >> 1) && left * 4 * (int64_t)fastest < slots * (int64_t)(d - fastest) &&
-                               atomicAdd(a.tile_ctr + 2, 1u) < (unsigned)(slots >> 1);
-            if (!leave) next = atomicAdd(a.tile_ctr, 1u);
-        }
+        if (tiles <= slots) break; // (every tile has its wave: the counter is not even touched)
+        unsigned next = 0;
+        if (lane == 0) next = atomicAdd(a.tile_ctr, 1u);
         tile = slots + (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)next);
     }
 }
