@@ -983,7 +983,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                 }
             }
             const int per_block = pt.lane ? pt.wpb * 128 : pt.packed ? pt.wpb * 8 : strip16 ? 1 : pt.wpb * (64 / pt.rows);
-            if (i == 0) n_blocks = (pt.count + per_block - 1) / per_block;
+            if (i == 0) n_blocks = da.lane_slots > 0 ? da.lane_slots : (pt.count + per_block - 1) / per_block; // (the persistent grid: one workgroup per wave slot)
             if (ctx->profiling == 2 && i == 0) {
                 HIP_TRY(ctx, ctx->diag.reserve((size_t)n_blocks * 16));
                 da.diag = static_cast<unsigned long long *>(ctx->diag.p);

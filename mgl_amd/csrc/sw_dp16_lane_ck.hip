@@ -964,6 +964,12 @@ __global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, 
 {
     const int lane = threadIdx.x & 63;
     const int64_t tiles = (((a.count + 1) >> 1) + 63) >> 6, slots = gridDim.x, slot = blockIdx.x;
+    // in-kernel clock probe (profiling level 2; off in normal runs): shader-clock ticks and 100 MHz ticks of this wave's whole life
+    unsigned long long diag_t0 = 0, diag_w0 = 0;
+    if (a.diag) {
+        diag_t0 = __builtin_amdgcn_s_memtime();
+        diag_w0 = __builtin_amdgcn_s_memrealtime();
+    }
     for (int64_t tile = slot; tile < tiles;) {
 #ifdef MGL_CK_TRACE
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -985,6 +991,10 @@ __global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, 
         unsigned next = 0;
         if (lane == 0) next = atomicAdd(a.tile_ctr, 1u);
         tile = slots + (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)next);
+    }
+    if (a.diag && lane == 0) {
+        a.diag[2 * slot] = __builtin_amdgcn_s_memtime() - diag_t0;
+        a.diag[2 * slot + 1] = __builtin_amdgcn_s_memrealtime() - diag_w0;
     }
 }
 
