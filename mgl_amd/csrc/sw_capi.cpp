@@ -67,10 +67,11 @@ struct mgl_sw_ctx {
     int64_t ws_limit = kDefaultWorkspace;
     // kernel workspace, two halves: the traceback of chunk k (aux stream) overlaps the fill of chunk k+1
     DevBuf tb[2], rec[2], bnd[2], diag, scratch;
-    // sw_dp16_lane_ck_kernel's tile counters: a ring of words, one per launch (zeroed on the launch's stream right before it; a word comes
-    // round again after kTileCounters launches of this context, which are ordered behind each other by then: same half, same stream)
+    // sw_dp16_lane_ck_kernel's tile counters: a ring of words, one per launch (zeroed once; a word comes round again after kTileCounters
+    // launches of this context, which are ordered behind each other by then: same half, same stream)
     DevBuf tile_ctr;
     uint64_t tile_seq = 0;
+    unsigned tile_total[64] = {}; // where each word of the ring stands (a launch of T > slots tiles moves its word on by exactly T): no resets
     // small-batch entry of the coalescing front-end: one pinned host buffer each way, mirrored on the device
     void *pin_in = nullptr, *pin_out = nullptr;
     size_t pin_in_cap = 0, pin_out_cap = 0;
@@ -975,11 +976,13 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             da.strip_pack = strip16 ? strip_pack : 0;
             da.lane_slots = 0;
             da.tile_ctr = nullptr;
+            da.tile_base = 0;
             if (pt.lane && (lane_ck || da.grouped)) { // the persistent grid: its wave slots and, where the tiles outnumber them, a zeroed counter
                 da.lane_slots = (int)std::min<int64_t>(lane_slots, (pt.count + 127) / 128);
                 if ((pt.count + 127) / 128 > da.lane_slots) {
-                    da.tile_ctr = static_cast<unsigned *>(ctx->tile_ctr.p) + (ctx->tile_seq++ % kTileCounters);
-                    HIP_TRY(ctx, hipMemsetAsync(da.tile_ctr, 0, sizeof(unsigned), fs));
+                    const int word = (int)(ctx->tile_seq++ % kTileCounters);
+                    da.tile_ctr = static_cast<unsigned *>(ctx->tile_ctr.p) + word;
+                    da.tile_base = ctx->tile_total[word]; // (moved on when the launch has been enqueued, below)
                 }
             }
             const int per_block = pt.lane ? pt.wpb * 128 : pt.packed ? pt.wpb * 8 : strip16 ? 1 : pt.wpb * (64 / pt.rows);
@@ -1041,6 +1044,8 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                          : pt.packed ? launch_dp16(das[i], pt.wpb, fs)
                          : strip16 ? launch_dp16_strip(das[i], strip_waves, pt.rows, fs)
                          : coop16 ? launch_dp_coop16(das[i], coop_waves, fs) : coop_waves ? launch_dp_coop(das[i], coop_waves, fs) : launch_dp(das[i], pt.wpb, pt.rows, fs));
+            if (das[i].tile_ctr) // the persistent grid is on its way: its counter will stand `tiles` further on when it ends
+                ctx->tile_total[das[i].tile_ctr - static_cast<unsigned *>(ctx->tile_ctr.p)] += (unsigned)((pt.count + 127) / 128);
         }
         if (pe[1]) HIP_TRY(ctx, hipEventRecord(pe[1], fs));
         if (overlap) {

@@ -70,7 +70,8 @@ struct DpArgs {
     int strip_k;              // sw_dp16_strip_kernel: 0 = the flags of every cell are stored; K > 0 = none are: rows and checkpoints of bands of K strips (strip16_ck_*)
     int strip_pack;           // ... their entries: 0 = {H, gap value} as two int32; B > 0 = one int32, H << B | (H - gap value) (strip16_pack_bits)
     int lane_slots;           // sw_dp16_lane_ck_kernel: wave slots of its persistent grid = regions at tb / scratch (lane_ck_slots)
-    unsigned *tile_ctr;       // ... the counter its waves draw their next tile from: zero at launch (needed when the launch holds more tiles than slots)
+    unsigned *tile_ctr;       // ... the counter its waves draw their next tile from (needed when the launch holds more tiles than slots) ...
+    unsigned tile_base;       // ... and where it stands when the launch starts: a launch of T > lane_slots tiles moves it on by exactly T
 };
 
 struct TbArgs {

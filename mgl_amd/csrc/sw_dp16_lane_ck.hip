@@ -948,7 +948,7 @@ __device__ __forceinline__ void sw_dp16_lane_ck_tile(const DpArgs &a, const TbAr
 
 // A PERSISTENT grid: a.lane_slots waves (at most what the chip holds at two waves per SIMD -- 256 registers: no spills in pass 1's
 // loops), each with one region of the workspace, each taking tile after tile: its first one by its slot number, the following ones
-// off a counter in device memory (a.tile_ctr, zero at launch) until the tiles are gone.  The workspace a launch needs is therefore
+// off a counter in device memory (a.tile_ctr; it stands at a.tile_base when the launch starts) until the tiles are gone.  The workspace a launch needs is therefore
 // lane_slots regions (2 MB each at 256 x 150: 4 GB for a whole MI355X) however many pairs it holds -- round 3 gave every TILE a region
 // (15 KB per pair: 208 GiB for the bench's 10 M pairs in one launch, and chunks wherever the workspace was smaller).  Every wave
 // reaches the loop's exit: the counter only grows, a tile's work is bounded, nothing waits for another wave.
@@ -989,7 +989,7 @@ __global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, 
 #endif
         if (tiles <= slots) break; // (every tile has its wave: the counter is not even touched)
         unsigned next = 0;
-        if (lane == 0) next = atomicAdd(a.tile_ctr, 1u);
+        if (lane == 0) next = atomicAdd(a.tile_ctr, 1u) - a.tile_base; // (modulo 2^32: the counter is never reset)
         tile = slots + (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)next);
     }
     if (a.diag && lane == 0) {
@@ -1001,8 +1001,11 @@ __global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, 
 // either wire format, the same for both sequence sets (the kernel stages base codes, sw_lane_cell.h)
 bool lane16_ck_supported(const SeqSet &t, const SeqSet &q) { return (t.packed2 != 0) == (q.packed2 != 0); }
 
-// a.lane_slots regions at a.tb / a.scratch; a.tile_ctr zero when the kernel starts (the caller's memset on `stream`) wherever the
-// launch holds more tiles than slots
+// a.lane_slots regions at a.tb / a.scratch; wherever the launch holds more tiles than slots: a.tile_ctr, a counter that stands at
+// a.tile_base when the kernel starts and that no other launch in flight uses.  The launch moves it on by exactly `tiles` (tiles - slots
+// draws that find a tile and one per wave that does not), so the host knows where it stands without ever resetting it -- a memset in
+// front of every launch is a KERNEL of its own, and behind a grid that holds every wave slot of the chip it waited for that grid's end
+// (traced in round 4: the two streams of the host entries stopped overlapping).
 hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &walk, hipStream_t stream)
 {
     const int64_t tiles = ((a.count + 1) / 2 + 63) / 64;

@@ -146,7 +146,22 @@ struct BlockMoves {
         const int l = i - r0 - 1, st = (j - jl - 1) + l; // row of the block, step of its wavefront
         return (flags[l * FW + (st >> 3)] >> (4 * (st & 7))) & 15u;
     }
-    __device__ __forceinline__ int diag_run(int, int) const { return 0; }
+    // the number of consecutive diagonal moves from (i, j) inside the block that holds it, up to 64: lane k looks at the flags of cell
+    // (i - k, j - k) -- its own dword of the LDS array -- and one ballot finds where the run ends.  An ONT-style path is a diagonal broken
+    // by an indel every ten cells or so: the walk takes a run per look instead of a cell per look (every look is a dependent LDS read).
+    __device__ __forceinline__ int diag_run(int i, int j)
+    {
+        const int b = (i - 1) / rbk, cc = cc_of(b, j);
+        if (b != cur_b || cc != cur_cc || i > imax || j > jr) compute(b, cc, i, j);
+        const int ii = i - lane, jj = j - lane;
+        bool is_diag = false;
+        if (ii > r0 && jj > jl) {
+            const int l = ii - r0 - 1, st = (jj - jl - 1) + l;
+            is_diag = ((flags[l * FW + (st >> 3)] >> (4 * (st & 7))) & 3u) == 0u; // neither F > diag nor E > max(diag, F): sw.cpp:60-62
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(is_diag);
+        return m == ~0ull ? 64 : (int)__builtin_ctzll(~m);
+    }
     // +k rows up, -k columns left, 0 diagonal: what the reference stores (sw.cpp:60-71); run lengths as TbView::vrun / hrun
     __device__ __forceinline__ int at(int i, int j)
     {

@@ -142,8 +142,8 @@ hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &w, hipStream_t)
 {
     // the persistent grid's contract (sw_dp16_lane_ck.hip): wave slots, and a zeroed tile counter wherever the tiles outnumber them
     const int64_t tiles = ((a.count + 1) / 2 + 63) / 64;
-    if (a.lane_slots < 1 || (tiles > a.lane_slots && (!a.tile_ctr || *a.tile_ctr != 0u))) return hipErrorInvalidValue;
-    if (a.tile_ctr) *a.tile_ctr = (unsigned)tiles; // (what the real waves leave behind: the next launch on this word must clear it)
+    if (a.lane_slots < 1 || (tiles > a.lane_slots && (!a.tile_ctr || *a.tile_ctr != a.tile_base))) return hipErrorInvalidValue;
+    if (tiles > a.lane_slots) *a.tile_ctr += (unsigned)tiles; // (what the real waves leave behind: the next launch on this word starts from there)
     remember(a);
     if (w.cigar) walk(w, false);
     return hipSuccess;
