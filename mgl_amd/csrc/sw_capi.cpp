@@ -72,6 +72,17 @@ struct mgl_sw_ctx {
     DevBuf tile_ctr;
     uint64_t tile_seq = 0;
     unsigned tile_total[64] = {}; // where each word of the ring stands (a launch of T > slots tiles moves its word on by exactly T): no resets
+    // the DIRECT form of the host entries (mgl_sw_align_batch_2bit with every array page-locked by the caller): ONE launch of the persistent
+    // grid while the copy engines bring the inputs in -- into fine-grained device memory, which the waves read uncached, so that what a
+    // copy engine wrote after the grid had started is what they see -- gated by a word in pinned host memory; the results are written by
+    // the waves straight into the caller's arrays (whole lines out of LDS)
+    void *fg[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // targets, queries, t_start, q_start, t_len, q_len
+    size_t fg_cap[6] = {0, 0, 0, 0, 0, 0};
+    int64_t *pin_gate = nullptr;   // [0] pairs arrived, [1] (as int32) a wave gave up waiting
+    std::vector<hipEvent_t> gate_ev;
+    const int64_t *cur_gate = nullptr; // set around run_device by the direct form: device view of pin_gate (null: no gate)
+    bool direct_broken = false;    // a gate once timed out on this context: the direct form is not tried again
+    int32_t *direct_status_any = nullptr; // ... and the device word that collects the largest per-pair status of its launch
     // small-batch entry of the coalescing front-end: one pinned host buffer each way, mirrored on the device
     void *pin_in = nullptr, *pin_out = nullptr;
     size_t pin_in_cap = 0, pin_out_cap = 0;
@@ -977,8 +988,16 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             da.lane_slots = 0;
             da.tile_ctr = nullptr;
             da.tile_base = 0;
+            da.gate = nullptr;
+            da.gate_failed = nullptr;
+            da.gate_timeout_ticks = 0;
             if (pt.lane && (lane_ck || da.grouped)) { // the persistent grid: its wave slots and, where the tiles outnumber them, a zeroed counter
                 da.lane_slots = (int)std::min<int64_t>(lane_slots, (pt.count + 127) / 128);
+                if (ctx->cur_gate && !hooks) { // the direct form of a host entry: the inputs are still arriving
+                    da.gate = ctx->cur_gate;
+                    da.gate_failed = reinterpret_cast<int32_t *>(const_cast<int64_t *>(ctx->cur_gate) + 1);
+                    da.gate_timeout_ticks = 300000000u; // three seconds without the word moving
+                }
                 if ((pt.count + 127) / 128 > da.lane_slots) {
                     const int word = (int)(ctx->tile_seq++ % kTileCounters);
                     da.tile_ctr = static_cast<unsigned *>(ctx->tile_ctr.p) + word;
@@ -1017,8 +1036,11 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             ta.binary_cigar = binary_cigar ? 1 : 0;
             ta.cigar_len = d_cigar_len;
             ta.status = d_status;
-            ta.status_any = hooks ? hooks->d_status_any : nullptr;
+            ta.status_any = hooks ? hooks->d_status_any : ctx->direct_status_any;
             ta.dest = pt.dest;
+            // the checkpointed lane kernel hands a tile's results over in whole lines where the arrays allow it (sw_device.h)
+            const char *const colds = getenv("MGL_SW_DEBUG_COALESCED_OUT"); // (0: every lane stores its own results, as before round 4; read per call: tests compare)
+            ta.coalesced_out = pt.lane && (lane_ck || da.grouped) && !(colds && atoi(colds) == 0) && lane_ck_coalesced_ok(ta) ? 1 : 0;
         }
 
         hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1222,6 +1244,11 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     for (auto *set : {ctx->fill_done, ctx->tb_done})
         for (int h = 0; h < 2; ++h)
             if (set[h]) (void)hipEventDestroy(set[h]);
+    for (auto &f : ctx->fg)
+        if (f) (void)hipFree(f);
+    if (ctx->pin_gate) (void)hipHostFree(ctx->pin_gate);
+    for (auto &e : ctx->gate_ev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->pin_matrix) (void)hipHostFree(ctx->pin_matrix);
     if (ctx->matrix_copied) (void)hipEventDestroy(ctx->matrix_copied);
     if (ctx->ws_idle) (void)hipEventDestroy(ctx->ws_idle);
@@ -1929,6 +1956,167 @@ int mgl_sw_unregister_host_buffer(mgl_sw_ctx *ctx, void *ptr)
     return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_unregister_host_buffer: not a registered buffer");
 }
 
+// ---- the DIRECT form of mgl_sw_align_batch_2bit (round 4).  The chunked form below launches a kernel per chunk and copies every chunk's
+// results back; traced (profiles/r04_host_timeline.txt), its result copies into page-locked arrays run as blit KERNELS, and behind a
+// persistent grid that holds every wave slot of the chip they waited for the grid's end: 11 ms of copies after the last kernel.  Here
+// nothing but the copy ENGINES and one grid works: the inputs go chunk by chunk into fine-grained device memory (read uncached by the
+// waves: what an engine wrote after the grid started is what they see), the host moves the gate word on as each chunk has landed, a
+// wave waits with a tile whose pairs are not there yet (sw_dp16_lane_ck.hip), and the results are written by the waves themselves, in
+// whole lines out of LDS, into the caller's arrays.  Taken when every array is page-locked (mgl_sw_register_host_buffer), the batch has
+// one geometry and plans as one launch of the checkpointed lane kernel, and the result arrays allow whole-line stores; *taken says so.
+// A gate that times out (the copies did not progress while the grid was resident) switches the form off for this context and hands the
+// call to the chunked form.
+static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_bases, size_t t_bytes, const int64_t *t_start, const int32_t *t_len,
+                             const uint8_t *query_bases, size_t q_bytes, const int64_t *q_start, const int32_t *q_len, int max_tl, int max_ql, int match, int mismatch,
+                             int gopen, int gext, int strategy, int32_t *offset_out, mgl_sw_score *score_out, char *cigar_out, int cigar_stride, int32_t *cigar_len_out,
+                             int32_t *status_out, int flags, bool t_sorted, bool q_sorted, int64_t cells, bool *taken)
+{
+    *taken = false;
+    const size_t nn = (size_t)n;
+    const bool uniform = (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) != 0;
+    const char *const off_env = getenv("MGL_SW_DEBUG_HOST_DIRECT"); // (0: always the chunked form; read per call: tests compare the two)
+    if (ctx->direct_broken || !uniform || (flags & MGL_SW_FLAG_BINARY_CIGAR) || (off_env && atoi(off_env) == 0)) return MGL_SW_OK;
+    if (!(ctx->is_registered(target_bases, t_bytes) && ctx->is_registered(query_bases, q_bytes) && ctx->is_registered(t_start, nn * 8) && ctx->is_registered(q_start, nn * 8) &&
+          ctx->is_registered(offset_out, nn * 4) && (!score_out || ctx->is_registered(score_out, nn * sizeof(mgl_sw_score))) &&
+          ctx->is_registered(cigar_out, nn * (size_t)cigar_stride) && (!cigar_len_out || ctx->is_registered(cigar_len_out, nn * 4)) &&
+          (!status_out || ctx->is_registered(status_out, nn * 4))))
+        return MGL_SW_OK;
+    // the device's view of the caller's result arrays
+    void *d_off = nullptr, *d_sc = nullptr, *d_cg = nullptr, *d_len = nullptr, *d_st = nullptr;
+    if (hipHostGetDevicePointer(&d_off, offset_out, 0) != hipSuccess || hipHostGetDevicePointer(&d_cg, cigar_out, 0) != hipSuccess ||
+        (score_out && hipHostGetDevicePointer(&d_sc, score_out, 0) != hipSuccess) || (cigar_len_out && hipHostGetDevicePointer(&d_len, cigar_len_out, 0) != hipSuccess) ||
+        (status_out && hipHostGetDevicePointer(&d_st, status_out, 0) != hipSuccess)) {
+        (void)hipGetLastError();
+        return MGL_SW_OK;
+    }
+    // does the batch plan as ONE launch of the checkpointed lane kernel whose results can leave in whole lines?
+    int m_ = match, x_ = mismatch, o_ = gopen, e_ = gext;
+    mgl_sw_normalize_params(&m_, &x_, &o_, &e_);
+    {
+        const SeqSet ts{reinterpret_cast<const uint8_t *>(8), reinterpret_cast<const int64_t *>(8), nullptr, max_tl, 1}, qs{reinterpret_cast<const uint8_t *>(8), reinterpret_cast<const int64_t *>(8), nullptr, max_ql, 1};
+        BatchPlan P{};
+        const std::string err = ctx->err;
+        const int prc = plan_batch(ctx, n, ts, qs, max_tl, max_ql, m_, x_, o_, e_, strategy, static_cast<const Score *>(d_sc), static_cast<const char *>(d_cg), cigar_stride, GEOM_UNIFORM,
+                                   false, nullptr, nullptr, false, P);
+        ctx->err = err;
+        TbArgs probe{};
+        probe.cigar = static_cast<char *>(d_cg);
+        probe.cigar_stride = cigar_stride;
+        probe.offset = static_cast<int32_t *>(d_off);
+        probe.score = static_cast<Score *>(d_sc);
+        probe.cigar_len = static_cast<int32_t *>(d_len);
+        probe.status = static_cast<int32_t *>(d_st);
+        if (prc != MGL_SW_OK || !P.lane_ck || P.auto_group || P.chunk < n || !lane_ck_coalesced_ok(probe)) return MGL_SW_OK;
+    }
+    *taken = true;
+    // fine-grained device memory for the inputs, the gate word, the chunk events
+    auto fg_reserve = [&](int k, size_t bytes) -> hipError_t {
+        if (bytes <= ctx->fg_cap[k]) return hipSuccess;
+        if (ctx->fg[k]) (void)hipFree(ctx->fg[k]);
+        ctx->fg[k] = nullptr;
+        ctx->fg_cap[k] = 0;
+        const hipError_t e = hipExtMallocWithFlags(&ctx->fg[k], bytes, hipDeviceMallocFinegrained);
+        if (e == hipSuccess) ctx->fg_cap[k] = bytes;
+        return e;
+    };
+    HIP_TRY(ctx, fg_reserve(0, t_bytes + 8));
+    HIP_TRY(ctx, fg_reserve(1, q_bytes + 8));
+    HIP_TRY(ctx, fg_reserve(2, nn * 8));
+    HIP_TRY(ctx, fg_reserve(3, nn * 8));
+    HIP_TRY(ctx, ctx->d_any.reserve(16));
+    if (!ctx->pin_gate) {
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->pin_gate), 64, hipHostMallocDefault));
+        memset(ctx->pin_gate, 0, 64);
+    }
+    void *gate_dev = nullptr;
+    HIP_TRY(ctx, hipHostGetDevicePointer(&gate_dev, ctx->pin_gate, 0));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipStreamSynchronize(st)); // (nothing of an earlier call reads the gate or the inputs any more)
+    __atomic_store_n(&ctx->pin_gate[0], (int64_t)0, __ATOMIC_RELEASE);
+    __atomic_store_n(reinterpret_cast<int32_t *>(&ctx->pin_gate[1]), 0, __ATOMIC_RELEASE);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_any.p, 0, 4, st));
+    // the chunks: small first (nothing computes until the first pairs are there), doubling up to a million pairs
+    std::vector<int64_t> ends;
+    for (int64_t first = 0, c = 32768; first < n; c = std::min<int64_t>(2 * c, 1 << 20)) {
+        first = std::min(n, first + c);
+        ends.push_back(first);
+    }
+    while (ctx->gate_ev.size() < ends.size()) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->gate_ev.push_back(e);
+    }
+    size_t t_done = 0, q_done = 0;
+    auto bring = [&](const uint8_t *src, void *dst, size_t total, bool sorted, const int64_t *start, int uni_len, int64_t first, int64_t end, size_t &done) -> int {
+        size_t upto = total;
+        if (sorted && end < n) {
+            int64_t hi = 0;
+            for (int64_t k = first; k < end; ++k) hi = std::max(hi, start[k] + uni_len); // (starts ascend, one length: the last pair's end -- kept general)
+            upto = std::min(total, (size_t)((hi + 3) >> 2));
+        }
+        if (upto > done) {
+            HIP_TRY(ctx, hipMemcpyAsync(static_cast<uint8_t *>(dst) + done, src + done, upto - done, hipMemcpyHostToDevice, ctx->h2d));
+            done = upto;
+        }
+        return MGL_SW_OK;
+    };
+    for (size_t k = 0; k < ends.size(); ++k) {
+        const int64_t first = k ? ends[k - 1] : 0, end = ends[k];
+        const size_t f = (size_t)first, c = (size_t)(end - first);
+        HIP_TRY(ctx, hipMemcpyAsync(static_cast<int64_t *>(ctx->fg[2]) + f, t_start + f, c * 8, hipMemcpyHostToDevice, ctx->h2d));
+        HIP_TRY(ctx, hipMemcpyAsync(static_cast<int64_t *>(ctx->fg[3]) + f, q_start + f, c * 8, hipMemcpyHostToDevice, ctx->h2d));
+        int rc = bring(target_bases, ctx->fg[0], t_bytes, t_sorted, t_start, max_tl, first, end, t_done);
+        if (rc == MGL_SW_OK) rc = bring(query_bases, ctx->fg[1], q_bytes, q_sorted, q_start, max_ql, first, end, q_done);
+        if (rc != MGL_SW_OK) {
+            drain_streams(ctx, st);
+            return rc;
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->gate_ev[k], ctx->h2d));
+    }
+    (void)t_len;
+    (void)q_len;
+    // the grid: launched at once, its waves wait at the gate
+    const SeqSet ts{static_cast<const uint8_t *>(ctx->fg[0]), static_cast<const int64_t *>(ctx->fg[2]), nullptr, max_tl, 1},
+        qs{static_cast<const uint8_t *>(ctx->fg[1]), static_cast<const int64_t *>(ctx->fg[3]), nullptr, max_ql, 1};
+    ctx->cur_gate = static_cast<const int64_t *>(gate_dev);
+    ChunkHooks none; // (only its status word is used: the launch is the device-resident form)
+    none.d_status_any = static_cast<int32_t *>(ctx->d_any.p);
+    ctx->direct_status_any = none.d_status_any;
+    int rc = run_device(ctx, st, n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext, strategy, static_cast<int32_t *>(d_off), static_cast<Score *>(d_sc),
+                        static_cast<char *>(d_cg), cigar_stride, static_cast<int32_t *>(d_len), static_cast<int32_t *>(d_st), cells, GEOM_UNIFORM);
+    ctx->cur_gate = nullptr;
+    ctx->direct_status_any = nullptr;
+    if (rc != MGL_SW_OK) {
+        __atomic_store_n(&ctx->pin_gate[0], n, __ATOMIC_RELEASE); // (whatever was launched runs out instead of waiting)
+        drain_streams(ctx, st);
+        return rc;
+    }
+    // the gate moves on as the chunks land
+    for (size_t k = 0; k < ends.size(); ++k) {
+        if (hipEventSynchronize(ctx->gate_ev[k]) != hipSuccess) {
+            (void)hipGetLastError();
+            __atomic_store_n(&ctx->pin_gate[0], n, __ATOMIC_RELEASE);
+            drain_streams(ctx, st);
+            return fail(ctx, MGL_SW_ERR_DEVICE, "mgl_sw_align_batch_2bit: an input copy failed");
+        }
+        __atomic_store_n(&ctx->pin_gate[0], ends[k], __ATOMIC_RELEASE);
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->h2d));
+    if (__atomic_load_n(reinterpret_cast<int32_t *>(&ctx->pin_gate[1]), __ATOMIC_ACQUIRE) != 0) {
+        // a wave gave up at the gate: the copies did not move while the grid was resident.  Not again on this context; this call goes the
+        // chunked way (every result is written again)
+        ctx->direct_broken = true;
+        *taken = false;
+        return MGL_SW_OK;
+    }
+    if (status_out) return MGL_SW_OK;
+    int32_t any = 0;
+    HIP_TRY(ctx, hipMemcpy(&any, ctx->d_any.p, 4, hipMemcpyDeviceToHost));
+    if (any != 0) return fail(ctx, any, "a CIGAR did not fit cigar_stride");
+    return MGL_SW_OK;
+}
+
 // ---- host buffers, 2-bit packed bases (the wire format of mgl_sw_align_batch_device_2bit from host memory).  The packed arrays move
 // chunk by chunk with the index arrays when the pairs' start positions ascend (reads packed back to back), or whole before the
 // first chunk (windows into a genome, in any order); results leave as in mgl_sw_align_batch_status.
@@ -2000,6 +2188,13 @@ int mgl_sw_align_batch_2bit(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_ba
     const size_t t_bytes = (size_t)((target_base_count + 3) >> 2), q_bytes = (size_t)((query_base_count + 3) >> 2), nn = (size_t)n;
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // ---- the direct form: every array page-locked by the caller, one geometry, the checkpointed lane kernel in one launch
+    {
+        bool taken = false;
+        const int drc = align_2bit_direct(ctx, n, target_bases, t_bytes, t_start, t_len, query_bases, q_bytes, q_start, q_len, max_tl, max_ql, match, mismatch, gopen, gext,
+                                          strategy, offset_out, score_out, cigar_out, cigar_stride, cigar_len_out, status_out, flags, sc.t_sorted, sc.q_sorted, sc.cells, &taken);
+        if (taken) return drc;
+    }
     HIP_TRY(ctx, ctx->d_t.reserve(t_bytes + 8));
     HIP_TRY(ctx, ctx->d_q.reserve(q_bytes + 8));
     HIP_TRY(ctx, ctx->d_toff.reserve(nn * 8));

@@ -72,6 +72,10 @@ struct DpArgs {
     int lane_slots;           // sw_dp16_lane_ck_kernel: wave slots of its persistent grid = regions at tb / scratch (lane_ck_slots)
     unsigned *tile_ctr;       // ... the counter its waves draw their next tile from (needed when the launch holds more tiles than slots) ...
     unsigned tile_base;       // ... and where it stands when the launch starts: a launch of T > lane_slots tiles moves it on by exactly T
+    const int64_t *gate;      // ... optional (host entries): a word in pinned host memory holding how many pairs of the batch have arrived in device memory
+                              //     so far; a wave waits with a tile until its pairs are there (null: everything is)
+    int32_t *gate_failed;     // ... set to 1 (pinned host memory) by a wave that gives up waiting: gate_timeout_ticks (100 MHz) without the word moving
+    unsigned gate_timeout_ticks;
 };
 
 struct TbArgs {
@@ -96,7 +100,9 @@ struct TbArgs {
     int strip_rows, strip_k;         // ... rows per strip and strips per kept band of the fill
     int strip_pack;                  // ... and the form of its entries (DpArgs::strip_pack)
     const int64_t *dest; // optional: output index of input pair p (results of pair p go to offset[dest[p]], cigar slot dest[p], ...);
-};                       // null: p itself.  (Batches the host layer has reordered by geometry hand results back in the caller's order.)
+                         // null: p itself.  (Batches the host layer has reordered by geometry hand results back in the caller's order.)
+    int coalesced_out;   // sw_dp16_lane_ck_kernel: a wave gathers the results of its 128 pairs in LDS and writes them out in whole lines (lane_ck_coalesced_ok)
+};
 
 // geometry helpers (host and device agree on these); rows = target rows per stripe = lanes per pair (16 or 64)
 __host__ __device__ inline int sps_for_rows(int ql, int rows) { return (ql + rows + 3) & ~3; }
@@ -169,6 +175,18 @@ __host__ __device__ inline int64_t lane_ck_words(int tl, int ql)
 }
 // per-wave scratch: both queries and both targets of every lane transposed to [4-base block][A | B][lane] dwords
 __host__ __device__ inline int64_t lane_ck_scratch_bytes(int tl, int ql) { return ((int64_t)((ql + 3) / 4) + (int64_t)lane_strips(tl, 32) * 8) * 2 * 64 * 4; }
+// Results through LDS: the 128 pairs of a tile are neighbours in every output array (no `dest` reordering), so the wave builds their
+// results -- CIGAR slots of up to 64 bytes, ScoreMax, offset, length, status: 12.5 KB -- in LDS and stores them as whole 1 KB lines instead
+// of one scattered word per lane.  That is what lets the output arrays be the CALLER's page-locked host arrays (the host entries then
+// copy nothing back: partial-line writes over the link cost a packet each).  Needs dword strides and 16-byte aligned bases.
+constexpr int LANE_CK_OUT_STRIDE_MAX = 64;
+constexpr int LANE_CK_OUT_LDS_BYTES = 128 * (LANE_CK_OUT_STRIDE_MAX + 24 + 12);
+__host__ inline bool lane_ck_coalesced_ok(const TbArgs &a)
+{
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    return !a.dest && !a.binary_cigar && a.cigar_stride >= 4 && a.cigar_stride <= LANE_CK_OUT_STRIDE_MAX && (a.cigar_stride & 3) == 0 && al(a.cigar) && al(a.offset) &&
+           al(a.score) && al(a.cigar_len) && al(a.status) && (a.first & 127) == 0;
+}
 // The kernel is a PERSISTENT grid: a launch's waves take tile after tile (128 pairs each) and every wave keeps ONE region
 // (lane_ck_words + lane_ck_scratch_bytes) that it reuses, so a launch needs as many regions as it has wave slots -- at most what the
 // chip holds at two waves per SIMD -- whatever the number of pairs.

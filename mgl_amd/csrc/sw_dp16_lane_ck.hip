@@ -717,7 +717,15 @@ __device__ __forceinline__ void stage_2bit(const uint8_t *data, const int64_t st
 // One TILE = 128 pairs of the launch (pairs 128 gw .. 128 gw + 127), worked on by the wave that sits in wave slot `slot` of the
 // persistent grid: everything the wave keeps while it works -- WaveMem, the staged sequences -- lives in the slot's region, which
 // the wave reuses tile after tile (a lane only ever reads back what it has written for the tile it is working on).
-__device__ __forceinline__ void sw_dp16_lane_ck_tile(const DpArgs &a, const TbArgs &walk, const int64_t gw, const int64_t slot, const int lane)
+// whole lines out of LDS: `bytes` (a multiple of 4) from src (LDS, 16-byte aligned) to dst (global, 16-byte aligned)
+__device__ __forceinline__ void lds_to_global(void *dst, const unsigned char *src, const int bytes, const int lane)
+{
+    const int whole = bytes & ~15;
+    for (int k = lane * 16; k < whole; k += 1024) *reinterpret_cast<uint4 *>(static_cast<unsigned char *>(dst) + k) = *reinterpret_cast<const uint4 *>(src + k);
+    for (int k = whole + lane * 4; k < bytes; k += 256) *reinterpret_cast<unsigned *>(static_cast<unsigned char *>(dst) + k) = *reinterpret_cast<const unsigned *>(src + k);
+}
+
+__device__ __forceinline__ void sw_dp16_lane_ck_tile(const DpArgs &a, const TbArgs &walk_in, const int64_t gw, const int64_t slot, const int lane, unsigned char *out_lds)
 {
     const int64_t n_ls = (a.count + 1) >> 1;
 #ifdef MGL_CK_PHASES
@@ -867,7 +875,19 @@ __device__ __forceinline__ void sw_dp16_lane_ck_tile(const DpArgs &a, const TbAr
     CK_PHASE(2); // last row, records
     // ---- pass 2
     const int64_t pA = a.first + slotA, pB = a.first + slotB;
-    const int64_t oA = walk.dest ? walk.dest[pA] : pA, oB = walk.dest ? walk.dest[pB] : pB;
+    // where the walks write: the caller's arrays, or (walk_in.coalesced_out) this tile's 128 slots of each in LDS -- cigar [128][stride] |
+    // ScoreMax [128] | offset [128] | length [128] | status [128] -- which leave as whole lines below
+    const bool via_lds = walk_in.coalesced_out != 0;
+    TbArgs walk = walk_in;
+    unsigned char *const l_score = out_lds + 128 * LANE_CK_OUT_STRIDE_MAX, *const l_off = l_score + 128 * 24, *const l_len = l_off + 512, *const l_status = l_len + 512;
+    if (via_lds) {
+        walk.cigar = reinterpret_cast<char *>(out_lds);
+        walk.score = walk_in.score ? reinterpret_cast<Score *>(l_score) : nullptr;
+        walk.offset = reinterpret_cast<int32_t *>(l_off);
+        walk.cigar_len = walk_in.cigar_len ? reinterpret_cast<int32_t *>(l_len) : nullptr;
+        walk.status = walk_in.status ? reinterpret_cast<int32_t *>(l_status) : nullptr;
+    }
+    const int64_t oA = via_lds ? 2 * lane : walk.dest ? walk.dest[pA] : pA, oB = via_lds ? 2 * lane + 1 : walk.dest ? walk.dest[pB] : pB;
     PathWalk wa, wb;
     wa.start(walk, rec[0], oA, tl, ql, lvalid, cornerA);
     wb.start(walk, rec[1], oB, tl, ql, validB, cornerB);
@@ -938,6 +958,19 @@ __device__ __forceinline__ void sw_dp16_lane_ck_tile(const DpArgs &a, const TbAr
     CK_PHASE(6);
     if (lvalid) wa.finish(walk, rec[0], oA);
     if (validB) wb.finish(walk, rec[1], oB);
+    if (via_lds) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int64_t p0 = a.first + gw * 128;
+        const int np = (int)min((int64_t)128, a.count - gw * 128); // pairs of this tile
+        lds_to_global(walk_in.cigar + (size_t)p0 * walk_in.cigar_stride, out_lds, np * walk_in.cigar_stride, lane);
+        if (walk_in.score) lds_to_global(walk_in.score + p0, l_score, np * 24, lane);
+        lds_to_global(walk_in.offset + p0, l_off, np * 4, lane);
+        if (walk_in.cigar_len) lds_to_global(walk_in.cigar_len + p0, l_len, np * 4, lane);
+        if (walk_in.status) lds_to_global(walk_in.status + p0, l_status, np * 4, lane);
+        __builtin_amdgcn_wave_barrier(); // (the next tile's walks write the same LDS)
+    }
     CK_PHASE(7); // overhangs, text, results
 #ifdef MGL_CK_PHASES
     if (lane == 0) atomicAdd(&mgl_ck_phase_ticks[9], 1ull);
@@ -962,6 +995,7 @@ __device__ __forceinline__ void sw_dp16_lane_ck_tile(const DpArgs &a, const TbAr
 // 1.25 M-pair launch moved between 8.9 and 9.6 ms either way, box by box) and are gone.
 __global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, const TbArgs walk)
 {
+    __shared__ __attribute__((aligned(16))) unsigned char out_lds[LANE_CK_OUT_LDS_BYTES]; // a tile's results on their way out (TbArgs::coalesced_out)
     const int lane = threadIdx.x & 63;
     const int64_t tiles = (((a.count + 1) >> 1) + 63) >> 6, slots = gridDim.x, slot = blockIdx.x;
     // in-kernel clock probe (profiling level 2; off in normal runs): shader-clock ticks and 100 MHz ticks of this wave's whole life
@@ -970,11 +1004,40 @@ __global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, 
         diag_t0 = __builtin_amdgcn_s_memtime();
         diag_w0 = __builtin_amdgcn_s_memrealtime();
     }
+    int64_t arrived = a.gate ? 0 : INT64_MAX; // pairs of the batch known to be in device memory
     for (int64_t tile = slot; tile < tiles;) {
+        // The host entries run ONE launch over a batch whose inputs are still crossing the link: the copy engines bring them chunk by chunk
+        // and the host moves a.gate on as each chunk has landed.  A wave whose tile is not there yet looks at the word (a read over the
+        // link, so only then) and sleeps in between; the copies do not depend on anything this grid does, so the wait ends -- and if the
+        // word stands still for gate_timeout_ticks the wave raises gate_failed and leaves, its tiles undone (the host sees the flag).
+        if (arrived < a.first + min(a.count, (tile + 1) * 128)) {
+            const int64_t need = a.first + min(a.count, (tile + 1) * 128);
+            unsigned long long since = __builtin_amdgcn_s_memrealtime();
+            int64_t last = arrived;
+            bool gave_up = false;
+            for (;;) {
+                arrived = (int64_t)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.gate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (arrived >= need) break;
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (arrived != last) {
+                    last = arrived;
+                    since = now;
+                } else if (now - since > (unsigned long long)a.gate_timeout_ticks) {
+                    gave_up = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(64);
+            }
+            if (gave_up) {
+                if (lane == 0) __hip_atomic_store(a.gate_failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (the pairs were written by the copy engine before the host moved the word)
+        }
 #ifdef MGL_CK_TRACE
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        sw_dp16_lane_ck_tile(a, walk, tile, slot, lane);
+        sw_dp16_lane_ck_tile(a, walk, tile, slot, lane, out_lds);
 #ifdef MGL_CK_TRACE
         if (lane == 0 && tile < (1 << 17)) {
             unsigned hw;

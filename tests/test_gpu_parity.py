@@ -1567,6 +1567,82 @@ def test_host_entries_packed_and_registered(aligner):
         aligner.set_workspace(4 << 30)
 
 
+def test_direct_host_entry_one_gated_launch_results_in_place(monkeypatch):
+    """mgl_sw_align_batch_2bit with every array page-locked (round 4, the direct form): ONE launch of the persistent grid while the copy
+    engines bring the inputs in behind a gate, results written by the waves straight into the caller's arrays in whole lines out of LDS.
+    Against the chunked form (MGL_SW_DEBUG_HOST_DIRECT=0) byte for byte -- an odd number of pairs: the last tile is partial, the last
+    lane holds one pair -- and against the oracle on a sample; then the same pairs device resident with and without the LDS hand-over."""
+    import torch
+    from mgl_amd import _lib, device_batch as db
+
+    rng = np.random.default_rng(20264)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    genome = alpha[rng.integers(0, 4, 1 << 18)]
+    n, tl, ql = 300_001, 256, 150
+    win = rng.integers(0, len(genome) - tl, n).astype(np.int64)
+    start = rng.integers(0, tl - ql - 4, n)
+    idx = win[:, None] + start[:, None] + np.arange(ql)[None, :]
+    reads = genome[idx]
+    sub = rng.random(reads.shape) < 0.01
+    reads = np.where(sub, alpha[rng.integers(0, 4, reads.shape)], reads).astype(np.uint8)
+    gap = np.nonzero(rng.random(n) < 0.3)[0]          # a deletion of three bases in a third of the reads: the walks need their blocks
+    for k in gap[:20000]:
+        reads[k, 60:-3] = reads[k, 63:]
+        reads[k, -3:] = genome[win[k] + start[k] + ql: win[k] + start[k] + ql + 3]
+    G = db.pack2bit(genome.tobytes())
+    Q = db.pack2bit(reads.tobytes())
+    qst = np.arange(n, dtype=np.int64) * ql
+    params = (200, -150, 260, 11)
+    a = sw.MicrosoftSmithWaterman(0)
+    a.set_workspace(8 << 30)
+
+    def outs():
+        return (np.zeros(n, np.int32), np.zeros((n, 6), np.int32), np.full(n * 64, 7, np.uint8), np.zeros(n, np.int32))
+
+    direct, chunked = outs(), outs()
+    regs = [G, win, Q, qst] + list(direct) + list(chunked)
+    for x in regs:
+        a.register_host_buffer(x)
+    try:
+        a.align_packed_2bit(G, len(genome), win, None, Q, n * ql, qst, None, tl, ql, params, ol.SOFTCLIP, 64, out=direct)
+        assert a.timing().fill_kernel == 7 and a.timing().dp_launches == 1, "the direct form: one launch of sw_dp16_lane_ck_kernel"
+        monkeypatch.setenv("MGL_SW_DEBUG_HOST_DIRECT", "0")
+        a.align_packed_2bit(G, len(genome), win, None, Q, n * ql, qst, None, tl, ql, params, ol.SOFTCLIP, 64, out=chunked)
+        monkeypatch.delenv("MGL_SW_DEBUG_HOST_DIRECT")
+        for d, c in zip(direct, chunked):
+            assert (d == c).all()
+        sample = np.sort(rng.choice(n, 3000, replace=False))
+        sample[-1] = n - 1
+        ts = [genome[win[k]: win[k] + tl].tobytes() for k in sample]
+        qs = [reads[k].tobytes() for k in sample]
+        off, sc, cg = ol.oracle_align_batch(ts, qs, params, ol.SOFTCLIP, nthreads=8)
+        assert (direct[0][sample] == off).all() and (direct[1][sample] == sc).all()
+        assert [direct[2].reshape(n, 64)[k, : direct[3][k]].tobytes().decode() for k in sample] == cg
+        assert (direct[2].reshape(n, 64)[np.arange(64)[None, :] >= direct[3][:, None]] == 0).all(), "zero behind the text"
+    finally:
+        for x in regs:
+            a.unregister_host_buffer(x)
+    # device resident: the LDS hand-over of results on (default) and off
+    dev = torch.device("cuda", 0)
+    tq = torch.from_numpy
+    t_start, q_start = tq(win).to(dev), tq(qst).to(dev)
+    res = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MGL_SW_DEBUG_COALESCED_OUT", mode)
+        b = db.PackedBatch(tq(G).to(dev), t_start, None, tq(Q).to(dev), q_start, None, tl, ql, 64) if hasattr(db, "PackedBatch") else None
+        if b is None:
+            break
+        b.run(a, params, ol.SOFTCLIP)
+        torch.cuda.synchronize()
+        res.append((b.offsets.cpu().numpy(), b.scores.cpu().numpy(), b.cigars.cpu().numpy(), b.cigar_len.cpu().numpy()))
+    monkeypatch.delenv("MGL_SW_DEBUG_COALESCED_OUT", raising=False)
+    if len(res) == 2:
+        for x, y in zip(*res):
+            assert (x == y).all()
+        assert (res[0][0] == direct[0]).all() and (res[0][2].reshape(-1) == direct[2]).all()
+    a.close()
+
+
 def test_binary_cigar_output(aligner):
     """MGL_SW_FLAG_BINARY_CIGAR: BAM-style uint32 elements carry the same elements in the same order as the text."""
     import torch
