@@ -73,11 +73,8 @@ struct mgl_sw_ctx {
     uint64_t tile_seq = 0;
     unsigned tile_total[64] = {}; // where each word of the ring stands (a launch of T > slots tiles moves its word on by exactly T): no resets
     // the DIRECT form of the host entries (mgl_sw_align_batch_2bit with every array page-locked by the caller): ONE launch of the persistent
-    // grid while the copy engines bring the inputs in -- into fine-grained device memory, which the waves read uncached, so that what a
-    // copy engine wrote after the grid had started is what they see -- gated by a word in pinned host memory; the results are written by
-    // the waves straight into the caller's arrays (whole lines out of LDS)
-    void *fg[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // targets, queries, t_start, q_start, t_len, q_len
-    size_t fg_cap[6] = {0, 0, 0, 0, 0, 0};
+    // grid while the copy engines bring the inputs in, gated by a word in pinned host memory; the results are written by the waves straight
+    // into the caller's arrays (whole lines out of LDS)
     int64_t *pin_gate = nullptr;   // [0] pairs arrived, [1] (as int32) a wave gave up waiting
     std::vector<hipEvent_t> gate_ev;
     const int64_t *cur_gate = nullptr; // set around run_device by the direct form: device view of pin_gate (null: no gate)
@@ -145,7 +142,14 @@ struct mgl_sw_ctx {
         const char *c = static_cast<const char *>(p);
         for (const auto &r : registered)
             if (c >= r.first && c + bytes <= r.first + r.second) return true;
-        return false;
+        // ... or page-locked by the caller's own means (hipHostMalloc, a framework's pinned allocator): both ends in pinned host memory
+        if (bytes == 0) return false;
+        hipPointerAttribute_t a0{}, a1{};
+        if (hipPointerGetAttributes(&a0, c) != hipSuccess || hipPointerGetAttributes(&a1, c + bytes - 1) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return a0.type == hipMemoryTypeHost && a1.type == hipMemoryTypeHost;
     }
     std::string err;
     std::mutex mu;
@@ -1244,8 +1248,6 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     for (auto *set : {ctx->fill_done, ctx->tb_done})
         for (int h = 0; h < 2; ++h)
             if (set[h]) (void)hipEventDestroy(set[h]);
-    for (auto &f : ctx->fg)
-        if (f) (void)hipFree(f);
     if (ctx->pin_gate) (void)hipHostFree(ctx->pin_gate);
     for (auto &e : ctx->gate_ev)
         if (e) (void)hipEventDestroy(e);
@@ -1959,10 +1961,11 @@ int mgl_sw_unregister_host_buffer(mgl_sw_ctx *ctx, void *ptr)
 // ---- the DIRECT form of mgl_sw_align_batch_2bit (round 4).  The chunked form below launches a kernel per chunk and copies every chunk's
 // results back; traced (profiles/r04_host_timeline.txt), its result copies into page-locked arrays run as blit KERNELS, and behind a
 // persistent grid that holds every wave slot of the chip they waited for the grid's end: 11 ms of copies after the last kernel.  Here
-// nothing but the copy ENGINES and one grid works: the inputs go chunk by chunk into fine-grained device memory (read uncached by the
-// waves: what an engine wrote after the grid started is what they see), the host moves the gate word on as each chunk has landed, a
-// wave waits with a tile whose pairs are not there yet (sw_dp16_lane_ck.hip), and the results are written by the waves themselves, in
-// whole lines out of LDS, into the caller's arrays.  Taken when every array is page-locked (mgl_sw_register_host_buffer), the batch has
+// nothing but the copy ENGINES and one grid works: the inputs go chunk by chunk into device memory, the host moves the gate word on as
+// each chunk has landed, a wave waits with a tile until its pairs AND the next tile's are there (its aligned loads may touch the first
+// line of the pair behind its last: no line of an input array is ever fetched before its bytes have arrived, and the caches are empty
+// of them when the grid starts), and the results are written by the waves themselves, in whole lines out of LDS, into the caller's
+// arrays.  (Inputs in fine-grained memory, read uncached, were measured first: 77 ms per 10 M pairs against 67 for the chunked form.)  Taken when every array is page-locked (mgl_sw_register_host_buffer), the batch has
 // one geometry and plans as one launch of the checkpointed lane kernel, and the result arrays allow whole-line stores; *taken says so.
 // A gate that times out (the copies did not progress while the grid was resident) switches the form off for this context and hands the
 // call to the chunked form.
@@ -1974,6 +1977,9 @@ static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_b
     *taken = false;
     const size_t nn = (size_t)n;
     const bool uniform = (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) != 0;
+    const bool timing = debug_knobs().host_timing;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_enter = now();
     const char *const off_env = getenv("MGL_SW_DEBUG_HOST_DIRECT"); // (0: always the chunked form; read per call: tests compare the two)
     if (ctx->direct_broken || !uniform || (flags & MGL_SW_FLAG_BINARY_CIGAR) || (off_env && atoi(off_env) == 0)) return MGL_SW_OK;
     if (!(ctx->is_registered(target_bases, t_bytes) && ctx->is_registered(query_bases, q_bytes) && ctx->is_registered(t_start, nn * 8) && ctx->is_registered(q_start, nn * 8) &&
@@ -2009,20 +2015,12 @@ static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_b
         if (prc != MGL_SW_OK || !P.lane_ck || P.auto_group || P.chunk < n || !lane_ck_coalesced_ok(probe)) return MGL_SW_OK;
     }
     *taken = true;
-    // fine-grained device memory for the inputs, the gate word, the chunk events
-    auto fg_reserve = [&](int k, size_t bytes) -> hipError_t {
-        if (bytes <= ctx->fg_cap[k]) return hipSuccess;
-        if (ctx->fg[k]) (void)hipFree(ctx->fg[k]);
-        ctx->fg[k] = nullptr;
-        ctx->fg_cap[k] = 0;
-        const hipError_t e = hipExtMallocWithFlags(&ctx->fg[k], bytes, hipDeviceMallocFinegrained);
-        if (e == hipSuccess) ctx->fg_cap[k] = bytes;
-        return e;
-    };
-    HIP_TRY(ctx, fg_reserve(0, t_bytes + 8));
-    HIP_TRY(ctx, fg_reserve(1, q_bytes + 8));
-    HIP_TRY(ctx, fg_reserve(2, nn * 8));
-    HIP_TRY(ctx, fg_reserve(3, nn * 8));
+    const double t_planned = now();
+    // device memory for the inputs, the gate word, the chunk events
+    HIP_TRY(ctx, ctx->d_t.reserve(t_bytes + 8));
+    HIP_TRY(ctx, ctx->d_q.reserve(q_bytes + 8));
+    HIP_TRY(ctx, ctx->d_toff.reserve(nn * 8));
+    HIP_TRY(ctx, ctx->d_qoff.reserve(nn * 8));
     HIP_TRY(ctx, ctx->d_any.reserve(16));
     if (!ctx->pin_gate) {
         HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->pin_gate), 64, hipHostMallocDefault));
@@ -2035,9 +2033,11 @@ static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_b
     __atomic_store_n(&ctx->pin_gate[0], (int64_t)0, __ATOMIC_RELEASE);
     __atomic_store_n(reinterpret_cast<int32_t *>(&ctx->pin_gate[1]), 0, __ATOMIC_RELEASE);
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_any.p, 0, 4, st));
-    // the chunks: small first (nothing computes until the first pairs are there), doubling up to a million pairs
+    // the chunks: first what gives every wave of the grid its first tile (and the tile behind it: the gate's margin) -- traced with
+    // chunks doubling from 32 k pairs: the sixteen copy commands of the first four cost the waves 1.9 ms at the gate -- then a million
+    // pairs at a time
     std::vector<int64_t> ends;
-    for (int64_t first = 0, c = 32768; first < n; c = std::min<int64_t>(2 * c, 1 << 20)) {
+    for (int64_t first = 0, c = ((int64_t)ctx->n_cus * LANE_CK_WAVES_PER_CU + 2) * 128; first < n; c = 1 << 20) {
         first = std::min(n, first + c);
         ends.push_back(first);
     }
@@ -2046,62 +2046,69 @@ static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_b
         HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->gate_ev.push_back(e);
     }
-    size_t t_done = 0, q_done = 0;
-    auto bring = [&](const uint8_t *src, void *dst, size_t total, bool sorted, const int64_t *start, int uni_len, int64_t first, int64_t end, size_t &done) -> int {
-        size_t upto = total;
-        if (sorted && end < n) {
-            int64_t hi = 0;
-            for (int64_t k = first; k < end; ++k) hi = std::max(hi, start[k] + uni_len); // (starts ascend, one length: the last pair's end -- kept general)
-            upto = std::min(total, (size_t)((hi + 3) >> 2));
-        }
-        if (upto > done) {
-            HIP_TRY(ctx, hipMemcpyAsync(static_cast<uint8_t *>(dst) + done, src + done, upto - done, hipMemcpyHostToDevice, ctx->h2d));
-            done = upto;
-        }
-        return MGL_SW_OK;
-    };
-    for (size_t k = 0; k < ends.size(); ++k) {
-        const int64_t first = k ? ends[k - 1] : 0, end = ends[k];
-        const size_t f = (size_t)first, c = (size_t)(end - first);
-        HIP_TRY(ctx, hipMemcpyAsync(static_cast<int64_t *>(ctx->fg[2]) + f, t_start + f, c * 8, hipMemcpyHostToDevice, ctx->h2d));
-        HIP_TRY(ctx, hipMemcpyAsync(static_cast<int64_t *>(ctx->fg[3]) + f, q_start + f, c * 8, hipMemcpyHostToDevice, ctx->h2d));
-        int rc = bring(target_bases, ctx->fg[0], t_bytes, t_sorted, t_start, max_tl, first, end, t_done);
-        if (rc == MGL_SW_OK) rc = bring(query_bases, ctx->fg[1], q_bytes, q_sorted, q_start, max_ql, first, end, q_done);
-        if (rc != MGL_SW_OK) {
-            drain_streams(ctx, st);
-            return rc;
-        }
-        HIP_TRY(ctx, hipEventRecord(ctx->gate_ev[k], ctx->h2d));
-    }
-    (void)t_len;
-    (void)q_len;
-    // the grid: launched at once, its waves wait at the gate
-    const SeqSet ts{static_cast<const uint8_t *>(ctx->fg[0]), static_cast<const int64_t *>(ctx->fg[2]), nullptr, max_tl, 1},
-        qs{static_cast<const uint8_t *>(ctx->fg[1]), static_cast<const int64_t *>(ctx->fg[3]), nullptr, max_ql, 1};
+    // the grid first: its waves wait at the gate, and everything below -- the host's part of 56 copy commands takes about as long as the
+    // copies themselves, 8 ms per 10 M pairs -- happens beside it (measured with the copies enqueued first: 76 ms per call against 67 for
+    // the chunked form, the grid itself 63)
+    const SeqSet ts{static_cast<const uint8_t *>(ctx->d_t.p), static_cast<const int64_t *>(ctx->d_toff.p), nullptr, max_tl, 1},
+        qs{static_cast<const uint8_t *>(ctx->d_q.p), static_cast<const int64_t *>(ctx->d_qoff.p), nullptr, max_ql, 1};
     ctx->cur_gate = static_cast<const int64_t *>(gate_dev);
-    ChunkHooks none; // (only its status word is used: the launch is the device-resident form)
-    none.d_status_any = static_cast<int32_t *>(ctx->d_any.p);
-    ctx->direct_status_any = none.d_status_any;
+    ctx->direct_status_any = static_cast<int32_t *>(ctx->d_any.p);
     int rc = run_device(ctx, st, n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext, strategy, static_cast<int32_t *>(d_off), static_cast<Score *>(d_sc),
                         static_cast<char *>(d_cg), cigar_stride, static_cast<int32_t *>(d_len), static_cast<int32_t *>(d_st), cells, GEOM_UNIFORM);
     ctx->cur_gate = nullptr;
     ctx->direct_status_any = nullptr;
-    if (rc != MGL_SW_OK) {
-        __atomic_store_n(&ctx->pin_gate[0], n, __ATOMIC_RELEASE); // (whatever was launched runs out instead of waiting)
+    // (from here on a grid may be waiting at the gate: every way out opens it)
+    auto bail = [&](int code) -> int {
+        __atomic_store_n(&ctx->pin_gate[0], n, __ATOMIC_RELEASE);
         drain_streams(ctx, st);
-        return rc;
-    }
-    // the gate moves on as the chunks land
-    for (size_t k = 0; k < ends.size(); ++k) {
-        if (hipEventSynchronize(ctx->gate_ev[k]) != hipSuccess) {
-            (void)hipGetLastError();
-            __atomic_store_n(&ctx->pin_gate[0], n, __ATOMIC_RELEASE);
-            drain_streams(ctx, st);
-            return fail(ctx, MGL_SW_ERR_DEVICE, "mgl_sw_align_batch_2bit: an input copy failed");
+        return code;
+    };
+    if (rc != MGL_SW_OK) return bail(rc);
+    const double t_launched = now();
+    size_t t_done = 0, q_done = 0, landed = 0;
+    auto bring = [&](const uint8_t *src, void *dst, size_t total, bool sorted, const int64_t *start, int uni_len, int64_t first, int64_t end, size_t &done) -> hipError_t {
+        size_t upto = total;
+        if (sorted && end < n) {
+            (void)first;
+            const int64_t hi = start[end - 1] + uni_len; // (the starts ascend and every pair has the one length: the last pair ends last)
+            upto = std::min(total, (size_t)((hi + 3) >> 2));
         }
-        __atomic_store_n(&ctx->pin_gate[0], ends[k], __ATOMIC_RELEASE);
+        hipError_t e = hipSuccess;
+        if (upto > done) {
+            e = hipMemcpyAsync(static_cast<uint8_t *>(dst) + done, src + done, upto - done, hipMemcpyHostToDevice, ctx->h2d);
+            done = upto;
+        }
+        return e;
+    };
+    for (size_t k = 0; k < ends.size(); ++k) {
+        const int64_t first = k ? ends[k - 1] : 0, end = ends[k];
+        const size_t f = (size_t)first, c = (size_t)(end - first);
+        hipError_t e = hipMemcpyAsync(static_cast<int64_t *>(ctx->d_toff.p) + f, t_start + f, c * 8, hipMemcpyHostToDevice, ctx->h2d);
+        if (e == hipSuccess) e = hipMemcpyAsync(static_cast<int64_t *>(ctx->d_qoff.p) + f, q_start + f, c * 8, hipMemcpyHostToDevice, ctx->h2d);
+        if (e == hipSuccess) e = bring(target_bases, ctx->d_t.p, t_bytes, t_sorted, t_start, max_tl, first, end, t_done);
+        if (e == hipSuccess) e = bring(query_bases, ctx->d_q.p, q_bytes, q_sorted, q_start, max_ql, first, end, q_done);
+        if (e == hipSuccess) e = hipEventRecord(ctx->gate_ev[k], ctx->h2d);
+        if (e != hipSuccess) return bail(hip_fail(ctx, e, "mgl_sw_align_batch_2bit: input copy"));
+        // the gate moves on over every chunk that has landed meanwhile
+        while (landed <= k && hipEventQuery(ctx->gate_ev[landed]) == hipSuccess) __atomic_store_n(&ctx->pin_gate[0], ends[landed++], __ATOMIC_RELEASE);
+        (void)hipGetLastError(); // (hipErrorNotReady is not an error)
     }
+    (void)t_len;
+    (void)q_len;
+    const double t_copies = now();
+    for (; landed < ends.size(); ++landed) {
+        if (hipEventSynchronize(ctx->gate_ev[landed]) != hipSuccess) {
+            (void)hipGetLastError();
+            return bail(fail(ctx, MGL_SW_ERR_DEVICE, "mgl_sw_align_batch_2bit: an input copy failed"));
+        }
+        __atomic_store_n(&ctx->pin_gate[0], ends[landed], __ATOMIC_RELEASE);
+    }
+    const double t_gate_open = now();
+    if (timing)
+        fprintf(stderr, "[mgl_sw] direct form: checks and plan %.2f ms, launch %.2f ms, copies enqueued %.2f ms after the launch, all landed %.2f ms after it\n",
+                (t_planned - t_enter) * 1e3, (t_launched - t_planned) * 1e3, (t_copies - t_launched) * 1e3, (t_gate_open - t_launched) * 1e3);
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (timing) fprintf(stderr, "[mgl_sw] direct form: grid ended %.2f ms after the launch (%.2f ms after its last inputs landed)\n", (now() - t_launched) * 1e3, (now() - t_gate_open) * 1e3);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->h2d));
     if (__atomic_load_n(reinterpret_cast<int32_t *>(&ctx->pin_gate[1]), __ATOMIC_ACQUIRE) != 0) {
         // a wave gave up at the gate: the copies did not move while the grid was resident.  Not again on this context; this call goes the

@@ -725,6 +725,9 @@ __device__ __forceinline__ void lds_to_global(void *dst, const unsigned char *sr
     for (int k = whole + lane * 4; k < bytes; k += 256) *reinterpret_cast<unsigned *>(static_cast<unsigned char *>(dst) + k) = *reinterpret_cast<const unsigned *>(src + k);
 }
 
+// VIA_LDS (= walk_in.coalesced_out, a template parameter so that every pointer the walks write through has ONE address space: with the
+// choice made at run time the text went out through flat instructions, whose waits also cover the scalar loads -- pass 2 took twice as long)
+template <bool VIA_LDS>
 __device__ __forceinline__ void sw_dp16_lane_ck_tile(const DpArgs &a, const TbArgs &walk_in, const int64_t gw, const int64_t slot, const int lane, unsigned char *out_lds)
 {
     const int64_t n_ls = (a.count + 1) >> 1;
@@ -877,7 +880,7 @@ __device__ __forceinline__ void sw_dp16_lane_ck_tile(const DpArgs &a, const TbAr
     const int64_t pA = a.first + slotA, pB = a.first + slotB;
     // where the walks write: the caller's arrays, or (walk_in.coalesced_out) this tile's 128 slots of each in LDS -- cigar [128][stride] |
     // ScoreMax [128] | offset [128] | length [128] | status [128] -- which leave as whole lines below
-    const bool via_lds = walk_in.coalesced_out != 0;
+    constexpr bool via_lds = VIA_LDS;
     TbArgs walk = walk_in;
     unsigned char *const l_score = out_lds + 128 * LANE_CK_OUT_STRIDE_MAX, *const l_off = l_score + 128 * 24, *const l_len = l_off + 512, *const l_status = l_len + 512;
     if (via_lds) {
@@ -1010,8 +1013,10 @@ __global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, 
         // and the host moves a.gate on as each chunk has landed.  A wave whose tile is not there yet looks at the word (a read over the
         // link, so only then) and sleeps in between; the copies do not depend on anything this grid does, so the wait ends -- and if the
         // word stands still for gate_timeout_ticks the wave raises gate_failed and leaves, its tiles undone (the host sees the flag).
-        if (arrived < a.first + min(a.count, (tile + 1) * 128)) {
-            const int64_t need = a.first + min(a.count, (tile + 1) * 128);
+        // (a tile's aligned loads may touch the first line of the pair behind its last one: the NEXT tile's pairs must have arrived too, so
+        // that no line of an input array enters a cache before its bytes are there)
+        if (arrived < a.first + min(a.count, (tile + 2) * 128)) {
+            const int64_t need = a.first + min(a.count, (tile + 2) * 128);
             unsigned long long since = __builtin_amdgcn_s_memrealtime();
             int64_t last = arrived;
             bool gave_up = false;
@@ -1032,12 +1037,19 @@ __global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, 
                 if (lane == 0) __hip_atomic_store(a.gate_failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (the pairs were written by the copy engine before the host moved the word)
+            // (No cache holds a line of the pairs that have just arrived -- the margin above; the grid started with empty caches -- so the
+            // loads that follow need no invalidate, and the gate's load is an ordinary dependency of theirs: the branch above.)
+#ifdef MGL_CK_GATE_FENCE
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
         }
 #ifdef MGL_CK_TRACE
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        sw_dp16_lane_ck_tile(a, walk, tile, slot, lane, out_lds);
+        if (walk.coalesced_out)
+            sw_dp16_lane_ck_tile<true>(a, walk, tile, slot, lane, out_lds);
+        else
+            sw_dp16_lane_ck_tile<false>(a, walk, tile, slot, lane, out_lds);
 #ifdef MGL_CK_TRACE
         if (lane == 0 && tile < (1 << 17)) {
             unsigned hw;

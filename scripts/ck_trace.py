@@ -13,13 +13,23 @@ dev = torch.device("cuda", 0)
 b = device_batch.window_batch(42, n, dev, window=256, read_len=150)
 a = MicrosoftSmithWaterman(0)
 a.set_workspace(int(os.environ.get("WS_GIB", "8")) << 30)
+direct = os.environ.get("DIRECT") == "1"   # the direct form of the packed host entry (one gated launch, results into pinned host arrays)
+if direct:
+    from mgl_amd.smithwaterman import GATK_PARAMETERS, SWOverhangStrategy
+    pb, _x = device_batch.window_batch_2bit(42, n, dev)
+    del _x
+    hin = [x.cpu().pin_memory().numpy() for x in (pb.target_bases, pb.t_start, pb.query_bases, pb.q_start)]
+    hout = tuple(x.pin_memory().numpy() for x in (torch.zeros(n, dtype=torch.int32), torch.zeros((n, 6), dtype=torch.int32), torch.zeros(n * 64, dtype=torch.uint8), torch.zeros(n, dtype=torch.int32)))
+    run = lambda: a.align_packed_2bit(hin[0], 1 << 24, hin[1], None, hin[2], n * 150, hin[3], None, 256, 150, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP, 64, out=hout)
+else:
+    run = lambda: b.run(a)
 for rep in range(3):
-    b.run(a); torch.cuda.synchronize()
+    run(); torch.cuda.synchronize()
 L = _lib.lib()
 path = "/tmp/ck_trace.bin"
 assert L.mgl_ck_trace_dump(path.encode()) == 0
 for rep in range(int(os.environ.get("REPS", "8"))):   # back to back, as a timed loop runs them: the trace is the LAST launch's
-    b.run(a)
+    run()
 torch.cuda.synchronize()
 assert L.mgl_ck_trace_dump(path.encode()) == 0
 tiles = (n + 127) // 128
@@ -42,6 +52,11 @@ k[order] = idx - start_of_run
 for g in range(int(k.max()) + 1):
     m = k == g
     print(f"  generation {g}: {m.sum():5d} tiles, start {t0[m].min()/1e3:6.2f} .. {t0[m].max()/1e3:6.2f} ms, end {t1[m].min()/1e3:6.2f} .. {t1[m].max()/1e3:6.2f} ms, duration mean {dur[m].mean():6.0f} us (p5 {np.percentile(dur[m],5):.0f}, p95 {np.percentile(dur[m],95):.0f})")
+# time a slot spent between its tiles (the gate of the direct host form; a tile's own duration starts behind it)
+o2 = np.lexsort((t0, slot))
+gap = t0[o2][1:] - t1[o2][:-1]
+same = slot[o2][1:] == slot[o2][:-1]
+print(f"  between a slot's tiles: total {gap[same].sum()/1e3:.1f} ms over all slots = {gap[same].sum()/len(np.unique(slot))/1e3:.3f} ms per slot; first tiles start {t0[k == 0].mean()/1e3:.3f} ms after the earliest (max {t0[k == 0].max()/1e3:.3f})")
 per_slot = np.bincount(slot)
 print("  tiles per slot:", dict(zip(*np.unique(per_slot[per_slot > 0], return_counts=True))))
 # occupancy of the SIMDs over time
