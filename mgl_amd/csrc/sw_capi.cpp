@@ -1000,7 +1000,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                 if (ctx->cur_gate && !hooks) { // the direct form of a host entry: the inputs are still arriving
                     da.gate = ctx->cur_gate;
                     da.gate_failed = reinterpret_cast<int32_t *>(const_cast<int64_t *>(ctx->cur_gate) + 1);
-                    da.gate_timeout_ticks = 300000000u; // three seconds without the word moving
+                    da.gate_timeout_ticks = 100000000u; // one second without the word moving
                 }
                 if ((pt.count + 127) / 128 > da.lane_slots) {
                     const int word = (int)(ctx->tile_seq++ % kTileCounters);
@@ -1972,7 +1972,7 @@ int mgl_sw_unregister_host_buffer(mgl_sw_ctx *ctx, void *ptr)
 static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_bases, size_t t_bytes, const int64_t *t_start, const int32_t *t_len,
                              const uint8_t *query_bases, size_t q_bytes, const int64_t *q_start, const int32_t *q_len, int max_tl, int max_ql, int match, int mismatch,
                              int gopen, int gext, int strategy, int32_t *offset_out, mgl_sw_score *score_out, char *cigar_out, int cigar_stride, int32_t *cigar_len_out,
-                             int32_t *status_out, int flags, bool t_sorted, bool q_sorted, int64_t cells, bool *taken)
+                             int32_t *status_out, int flags, int64_t target_base_count, int64_t query_base_count, bool *taken)
 {
     *taken = false;
     const size_t nn = (size_t)n;
@@ -2038,7 +2038,7 @@ static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_b
     // pairs at a time
     std::vector<int64_t> ends;
     for (int64_t first = 0, c = ((int64_t)ctx->n_cus * LANE_CK_WAVES_PER_CU + 2) * 128; first < n; c = 1 << 20) {
-        first = std::min(n, first + c);
+        first = n - (first + c) < (1 << 18) ? n : first + c; // (no small last chunk: small copies are blit kernels, see below)
         ends.push_back(first);
     }
     while (ctx->gate_ev.size() < ends.size()) {
@@ -2054,7 +2054,7 @@ static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_b
     ctx->cur_gate = static_cast<const int64_t *>(gate_dev);
     ctx->direct_status_any = static_cast<int32_t *>(ctx->d_any.p);
     int rc = run_device(ctx, st, n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext, strategy, static_cast<int32_t *>(d_off), static_cast<Score *>(d_sc),
-                        static_cast<char *>(d_cg), cigar_stride, static_cast<int32_t *>(d_len), static_cast<int32_t *>(d_st), cells, GEOM_UNIFORM);
+                        static_cast<char *>(d_cg), cigar_stride, static_cast<int32_t *>(d_len), static_cast<int32_t *>(d_st), n * (int64_t)max_tl * max_ql, GEOM_UNIFORM);
     ctx->cur_gate = nullptr;
     ctx->direct_status_any = nullptr;
     // (from here on a grid may be waiting at the gate: every way out opens it)
@@ -2066,13 +2066,47 @@ static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_b
     if (rc != MGL_SW_OK) return bail(rc);
     const double t_launched = now();
     size_t t_done = 0, q_done = 0, landed = 0;
-    auto bring = [&](const uint8_t *src, void *dst, size_t total, bool sorted, const int64_t *start, int uni_len, int64_t first, int64_t end, size_t &done) -> hipError_t {
-        size_t upto = total;
-        if (sorted && end < n) {
-            (void)first;
-            const int64_t hi = start[end - 1] + uni_len; // (the starts ascend and every pair has the one length: the last pair ends last)
-            upto = std::min(total, (size_t)((hi + 3) >> 2));
+    // The index arrays are checked HERE, chunk by chunk beside the running grid, instead of in one pass in front of everything (2.5 ms per
+    // 10 M pairs on eight threads): every pair inside its packed array, and how far into each array the chunk's pairs reach -- that much
+    // of the array travels with the chunk (pairs packed back to back: a slice; windows into a genome, in any order: all of it with the
+    // first chunk).  A chunk's gate opens only when its pairs have passed the check and its bytes have landed, so the grid never
+    // follows an index nobody has looked at.  Eight threads per chunk (one thread: 15 ms per 10 M pairs, and the grid waited for it).
+    struct Reach {
+        bool bad = false;
+        int64_t t_end = 0, q_end = 0;
+    };
+    auto check_range = [&](int64_t lo, int64_t hi) {
+        Reach r;
+        for (int64_t k = lo; k < hi; ++k) { // branch-free: it vectorises
+            const int64_t tv = t_start[k], qv = q_start[k];
+            r.bad |= tv < 0 || qv < 0 || tv + max_tl > target_base_count || qv + max_ql > query_base_count;
+            r.t_end = std::max(r.t_end, tv);
+            r.q_end = std::max(r.q_end, qv);
         }
+        r.t_end += max_tl;
+        r.q_end += max_ql;
+        return r;
+    };
+    auto check = [&](int64_t first, int64_t end) -> Reach {
+        constexpr int kParts = 8;
+        if (end - first < (1 << 18)) return check_range(first, end);
+        std::future<Reach> part[kParts];
+        for (int p = 0; p < kParts; ++p) part[p] = std::async(std::launch::async, check_range, first + (end - first) * p / kParts, first + (end - first) * (p + 1) / kParts);
+        Reach r;
+        for (int p = 0; p < kParts; ++p) {
+            const Reach x = part[p].get();
+            r.bad |= x.bad;
+            r.t_end = std::max(r.t_end, x.t_end);
+            r.q_end = std::max(r.q_end, x.q_end);
+        }
+        return r;
+    };
+    // (whole 2 MB steps, and what would be left behind a step goes with it when it is less than 4 MB: a small or odd-sized copy is not the
+    // copy engines' but a blit KERNEL, which behind a grid that holds every wave slot does not start -- seen: the gate stood still until
+    // the waves gave up)
+    auto bring = [&](const uint8_t *src, void *dst, size_t total, int64_t reach_bases, bool last, size_t &done) -> hipError_t {
+        size_t upto = last ? total : std::min(total, ((size_t)((reach_bases + 3) >> 2) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1));
+        if (total - upto < ((size_t)4 << 20)) upto = total;
         hipError_t e = hipSuccess;
         if (upto > done) {
             e = hipMemcpyAsync(static_cast<uint8_t *>(dst) + done, src + done, upto - done, hipMemcpyHostToDevice, ctx->h2d);
@@ -2085,8 +2119,20 @@ static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_b
         const size_t f = (size_t)first, c = (size_t)(end - first);
         hipError_t e = hipMemcpyAsync(static_cast<int64_t *>(ctx->d_toff.p) + f, t_start + f, c * 8, hipMemcpyHostToDevice, ctx->h2d);
         if (e == hipSuccess) e = hipMemcpyAsync(static_cast<int64_t *>(ctx->d_qoff.p) + f, q_start + f, c * 8, hipMemcpyHostToDevice, ctx->h2d);
-        if (e == hipSuccess) e = bring(target_bases, ctx->d_t.p, t_bytes, t_sorted, t_start, max_tl, first, end, t_done);
-        if (e == hipSuccess) e = bring(query_bases, ctx->d_q.p, q_bytes, q_sorted, q_start, max_ql, first, end, q_done);
+        Reach r;
+        try {
+            r = check(first, end);
+        } catch (const std::exception &) {
+            return bail(fail(ctx, MGL_SW_ERR_NOMEM, "mgl_sw_align_batch_2bit: out of host resources"));
+        }
+        if (r.bad) {
+            // a pair outside its array: the grid is sent home (a negative gate), nothing of this chunk was handed to it
+            __atomic_store_n(&ctx->pin_gate[0], (int64_t)-1, __ATOMIC_RELEASE);
+            drain_streams(ctx, st);
+            return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch_2bit: a pair lies outside its packed array or its length outside [1, max]");
+        }
+        if (e == hipSuccess) e = bring(target_bases, ctx->d_t.p, t_bytes, r.t_end, end == n, t_done);
+        if (e == hipSuccess) e = bring(query_bases, ctx->d_q.p, q_bytes, r.q_end, end == n, q_done);
         if (e == hipSuccess) e = hipEventRecord(ctx->gate_ev[k], ctx->h2d);
         if (e != hipSuccess) return bail(hip_fail(ctx, e, "mgl_sw_align_batch_2bit: input copy"));
         // the gate moves on over every chunk that has landed meanwhile
@@ -2152,6 +2198,16 @@ int mgl_sw_align_batch_2bit(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_ba
     if (n < 0 || !target_bases || !t_start || !query_bases || !q_start || !offset_out || !cigar_out || cigar_stride < 1 || max_tl < 1 || max_ql < 1 ||
         target_base_count < 1 || query_base_count < 1 || !strategy_ok(strategy) || ((!t_len || !q_len) && !uniform))
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch_2bit: bad argument (length arrays are required unless the geometry is uniform)");
+    // ---- the direct form: every array page-locked by the caller, one geometry, the checkpointed lane kernel in one launch (it checks the
+    // index arrays itself, chunk by chunk beside the running grid)
+    if (uniform) {
+        if (hipSetDevice(ctx->device) != hipSuccess) return hip_fail(ctx, hipGetLastError(), "hipSetDevice");
+        bool taken = false;
+        const int drc = align_2bit_direct(ctx, n, target_bases, (size_t)((target_base_count + 3) >> 2), t_start, t_len, query_bases, (size_t)((query_base_count + 3) >> 2), q_start, q_len,
+                                          max_tl, max_ql, match, mismatch, gopen, gext, strategy, offset_out, score_out, cigar_out, cigar_stride, cigar_len_out, status_out, flags,
+                                          target_base_count, query_base_count, &taken);
+        if (taken) return drc;
+    }
     // one pass over the index arrays: every pair inside its array, lengths within the stated maxima, do the starts ascend?
     struct Scan {
         bool bad = false, t_sorted = true, q_sorted = true;
@@ -2195,13 +2251,6 @@ int mgl_sw_align_batch_2bit(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_ba
     const size_t t_bytes = (size_t)((target_base_count + 3) >> 2), q_bytes = (size_t)((query_base_count + 3) >> 2), nn = (size_t)n;
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // ---- the direct form: every array page-locked by the caller, one geometry, the checkpointed lane kernel in one launch
-    {
-        bool taken = false;
-        const int drc = align_2bit_direct(ctx, n, target_bases, t_bytes, t_start, t_len, query_bases, q_bytes, q_start, q_len, max_tl, max_ql, match, mismatch, gopen, gext,
-                                          strategy, offset_out, score_out, cigar_out, cigar_stride, cigar_len_out, status_out, flags, sc.t_sorted, sc.q_sorted, sc.cells, &taken);
-        if (taken) return drc;
-    }
     HIP_TRY(ctx, ctx->d_t.reserve(t_bytes + 8));
     HIP_TRY(ctx, ctx->d_q.reserve(q_bytes + 8));
     HIP_TRY(ctx, ctx->d_toff.reserve(nn * 8));

@@ -1019,10 +1019,14 @@ __global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, 
             const int64_t need = a.first + min(a.count, (tile + 2) * 128);
             unsigned long long since = __builtin_amdgcn_s_memrealtime();
             int64_t last = arrived;
-            bool gave_up = false;
+            bool gave_up = false, left_early = false;
             for (;;) {
                 arrived = (int64_t)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.gate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (arrived >= need) break;
+                if (arrived < 0) { // the host calls the grid off (an index array failed its check): leave, nothing is wrong with the device
+                    left_early = true;
+                    break;
+                }
                 const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                 if (arrived != last) {
                     last = arrived;
@@ -1037,6 +1041,7 @@ __global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, 
                 if (lane == 0) __hip_atomic_store(a.gate_failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
+            if (left_early) break;
             // (No cache holds a line of the pairs that have just arrived -- the margin above; the grid started with empty caches -- so the
             // loads that follow need no invalidate, and the gate's load is an ordinary dependency of theirs: the branch above.)
 #ifdef MGL_CK_GATE_FENCE

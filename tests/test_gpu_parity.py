@@ -1619,6 +1619,17 @@ def test_direct_host_entry_one_gated_launch_results_in_place(monkeypatch):
         assert (direct[0][sample] == off).all() and (direct[1][sample] == sc).all()
         assert [direct[2].reshape(n, 64)[k, : direct[3][k]].tobytes().decode() for k in sample] == cg
         assert (direct[2].reshape(n, 64)[np.arange(64)[None, :] >= direct[3][:, None]] == 0).all(), "zero behind the text"
+        # a pair outside its array, found by the direct form's own check while the grid is already running: the grid is called off, the
+        # call returns the argument error -- and the next call works
+        win_ok = int(win[n - 5])
+        win[n - 5] = len(genome) - tl + 1
+        with pytest.raises(_lib.MglSwError) as bad:
+            a.align_packed_2bit(G, len(genome), win, None, Q, n * ql, qst, None, tl, ql, params, ol.SOFTCLIP, 64, out=chunked)
+        assert bad.value.status == _lib.ERR_BAD_ARG
+        win[n - 5] = win_ok
+        a.align_packed_2bit(G, len(genome), win, None, Q, n * ql, qst, None, tl, ql, params, ol.SOFTCLIP, 64, out=chunked)
+        for d, c in zip(direct, chunked):
+            assert (d == c).all()
     finally:
         for x in regs:
             a.unregister_host_buffer(x)
