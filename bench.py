@@ -261,7 +261,8 @@ def pcie_inclusive_leg(aligner, batch, args):
     timed around the one blocking call and cross-checked against the arrays the device-resident headline run left in HBM.
     Three forms: ASCII bases in pageable memory (the reference's own contract: 4.2 GB in), the same arrays REGISTERED
     (mgl_sw_register_host_buffer), and 2-bit packed bases with windows into one packed genome (SURVEY 8d config 2's wire format:
-    0.54 GB in), registered.  Never `value`."""
+    0.54 GB in) -- in arrays the caller page-locked itself (the entry's direct form: one gated launch, results written in place) and,
+    inside that object, in arrays registered where they lie.  Never `value`."""
     from mgl_amd import _lib
 
     n, tl, ql, stride = batch.n, batch.max_tl, batch.max_ql, batch.cigar_stride
@@ -328,12 +329,31 @@ def pcie_inclusive_leg(aligner, batch, args):
                     aligner.align_packed_2bit(G, 1 << 24, win, None, Q, n * ql, qst, None, tl, ql, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP,
                                               stride, out=(off, sc, cg, ln))
 
-                r = timed(packed_call)
-                r.update({"host_memory": "registered", "input": "2bit (one packed genome + window offsets, packed reads)",
-                          "bytes_in": int(G.nbytes + win.nbytes + Q.nbytes + qst.nbytes), "bytes_out": out["bytes_out"]})
-                out["packed_2bit"] = r
+                r_reg = timed(packed_call)
                 for a_ in packed:
                     aligner.unregister_host_buffer(a_)
+                # the same call on arrays the CALLER page-locked with the runtime's own allocator (hipHostMalloc through torch's pinned
+                # tensors: large pages for the device's page tables; hipHostRegister pins an array's 4 KB pages where they lie -- measured
+                # 3-5 ms per 10 M pairs apart).  Every array pinned: the entry takes its DIRECT form -- one gated launch of the persistent
+                # grid beside the copy engines, results written by the waves into these arrays
+                pin = lambda x: torch.from_numpy(x).pin_memory().numpy()
+                G, win, Q, qst = pin(G), pin(win), pin(Q), pin(qst)
+                poff, psc, pcg, pln = pin(off), pin(sc), pin(cg), pin(ln)
+                save = (off, sc, cg, ln)
+                off, sc, cg, ln = poff, psc, pcg, pln
+
+                def pinned_call():
+                    aligner.align_packed_2bit(G, 1 << 24, win, None, Q, n * ql, qst, None, tl, ql, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP,
+                                              stride, out=(off, sc, cg, ln))
+
+                r = timed(pinned_call)
+                tm_ = aligner.timing()
+                r.update({"host_memory": "page-locked by the caller (hipHostMalloc)", "input": "2bit (one packed genome + window offsets, packed reads)",
+                          "form": "direct: one gated launch, results written into the caller's arrays by the waves" if tm_.dp_launches == 1 else f"chunked ({tm_.dp_launches} launches)",
+                          "bytes_in": int(G.nbytes + win.nbytes + Q.nbytes + qst.nbytes), "bytes_out": out["bytes_out"],
+                          "arrays_registered_in_place (hipHostRegister, 4 KB pages)": {k: r_reg[k] for k in ("ms_per_step", "gcups", "mismatches_vs_headline")}})
+                out["packed_2bit"] = r
+                off, sc, cg, ln = save
         for a_ in regs[4:]:
             aligner.unregister_host_buffer(a_)
     except Exception as e_:  # noqa: BLE001 -- the extra forms must not take the pageable line down

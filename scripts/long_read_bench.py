@@ -66,17 +66,28 @@ if args.json:
     out_bytes = float(b.cigar_len.float().mean().item()) + 36
     alg = sum(len(ts[k]) + len(qs[k]) + 16 + out_bytes + (len(ts[k]) * len(qs[k]) // 2 + 32 if spilled else 0) for k in range(n))
     fill_s = tm.dp_ms / 1e3
+    # HBM bytes per pass by the PMC passes of the shipped build (profiles/pmc_traffic.json: WRITE_SIZE + FETCH_SIZE of the fill and the walk,
+    # per 10 kb pair; other lengths: none taken)
+    traffic, traffic_src = None, None
+    try:
+        for r_ in json.load(open(os.path.join(R, "profiles", "pmc_traffic.json")))["sw_dp16_strip_kernel"]:
+            if (r_["tl"], r_["ql"]) == (length, length) and not spilled and tm.fill_kernel == 6 and "hbm_bytes_per_pair" in r_:
+                traffic, traffic_src = int(r_["hbm_bytes_per_pair"] * n), r_["source"]
+                break
+    except (OSError, KeyError, ValueError):
+        pass
     walk_name = "sw_traceback_wave_kernel" if spilled else "sw_strip_ck_walk_kernel"
     print(json.dumps({"gcups": round(cells * reps / dt / 1e9, 1), "pairs": n, "length": length, "passes": reps, "seconds": round(dt, 1),
                       "ms_per_pass": round(dt * 1e3 / reps, 2),
                       "kernel_ms": {a.fill_kernel_name(tm): round(tm.dp_ms, 2), walk_name: round(tm.tb_ms, 2), "launches": tm.dp_launches},
                       "traceback": "4 bits per cell in HBM" if spilled else "none stored: kept rows and checkpoints (8 MB per 10 kb pair), the walk recomputes the blocks the path crosses",
                       "roofline": {"bound": "hbm", "kernel": a.fill_kernel_name(tm), "achieved": round(alg / fill_s / 1e9, 1), "peak": 8000.0,
-                                   "unit": "GB/s", "frac": round(alg / fill_s / 1e9 / 8000.0, 5), "traffic": None,
+                                   "unit": "GB/s", "frac": round(alg / fill_s / 1e9 / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src,
+                                   "traffic_frac_of_peak": None if traffic is None else round(traffic / (dt / reps) / 8e12, 4),
                                    "algorithmic_bytes_per_pass": round(alg), "kernel_gcups": round(cells / fill_s / 1e9, 1),
                                    "if_traceback_were_spilled_frac": round(sum(len(ts[k]) * len(qs[k]) // 2 for k in range(n)) / fill_s / 1e9 / 8000.0, 4),
                                    "note": ("one strip of 20-32 rows per lane-half, the lane kernel's column code with per-strip 16-bit baselines; VALU-issue "
-                                            "bound; " + ("no flags stored (score-only column code, 9 instructions per two cells), profiles/r03_e_long_reads.txt"
+                                            "bound; " + ("no flags stored (score-only column code, 9 instructions per two cells), profiles/r04_e_secondary_pmc.txt"
                                                          if not spilled else "flags of every cell stored, profiles/r02_d_strip_kernel.txt")
                                             if tm.fill_kernel == 6 else
                                             "packed int16 wavefront, 128 rows per wave, VALU-issue bound (36 VALU instructions per 128-cell step = 87 % of "
