@@ -551,7 +551,10 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
     // strip kernel: one pair per workgroup of W waves at three waves per SIMD -- a chunk that is not a whole number of rounds of
     // the chip (n_cus * (12 / W) pairs) ends with a round in which most CUs idle (1 582 pairs per chunk ran as two rounds)
     if (strip16) {
-        const int64_t round = (int64_t)ctx->n_cus * (12 / strip_waves);
+        // (workgroups per CU: what the kernel's register budget allows -- and, with the query's tables in LDS, what 160 KB hold)
+        const int lds_codes = strip_k > 0 ? strip16_lds_bytes_codes(max_ql, strip_waves) : 0;
+        const int by_lds = lds_codes > 0 && lds_codes <= 64 * 1024 ? std::max(1, (160 * 1024) / (lds_codes + 512)) : 64;
+        const int64_t round = (int64_t)ctx->n_cus * std::min(4 * strip16_waves_per_simd(rows) / strip_waves, by_lds);
         if (chunk > round) chunk = chunk / round * round;
         // (without stored flags the workspace holds 2 304 pairs of 10 kb as ONE chunk, and that is right: the walk kernel's time is a
         // pair's serial chain of ~200 block recomputations whatever the number of pairs -- three chunks of 768 walked three times as
@@ -989,6 +992,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             da.grouped = pt.lane && auto_group ? 1 : 0;
             da.strip_k = strip16 ? strip_k : 0;
             da.strip_pack = strip16 ? strip_pack : 0;
+            {
+                const char *const sce = getenv("MGL_SW_DEBUG_STRIP_CODES"); // (0: the byte-compare form whatever the sequences; read per call: the tests run both forms)
+                da.strip_codes = strip16 && strip_k > 0 && !(sce && atoi(sce) == 0) && strip16_lds_bytes_codes(max_ql, strip_waves) <= 64 * 1024 ? 1 : 0;
+            }
             da.lane_slots = 0;
             da.tile_ctr = nullptr;
             da.tile_base = 0;

@@ -69,6 +69,7 @@ struct DpArgs {
     int grouped;              // sw_dp16_lane_ck_kernel: every wave of 128 pairs has its own geometry (a chunk sorted by geometry)
     int strip_k;              // sw_dp16_strip_kernel: 0 = the flags of every cell are stored; K > 0 = none are: rows and checkpoints of bands of K strips (strip16_ck_*)
     int strip_pack;           // ... their entries: 0 = {H, gap value} as two int32; B > 0 = one int32, H << B | (H - gap value) (strip16_pack_bits)
+    int strip_codes;          // ... and the LDS carve holds the query as one table dword per column (strip16_lds_bytes_codes): pairs whose targets are all ACGT run the base-code form
     int lane_slots;           // sw_dp16_lane_ck_kernel: wave slots of its persistent grid = regions at tb / scratch (lane_ck_slots)
     unsigned *tile_ctr;       // ... the counter its waves draw their next tile from (needed when the launch holds more tiles than slots) ...
     unsigned tile_base;       // ... and where it stands when the launch starts: a launch of T > lane_slots tiles moves it on by exactly T
@@ -222,6 +223,7 @@ constexpr int STRIP_CPS = 4; // columns per step (2 or 4).  Two halve the pipeli
 __host__ __device__ inline int strip16_groups(int ql) { return (ql + STRIP_CPS - 1) / STRIP_CPS; }
 __host__ __device__ inline int strip16_steps(int ql, int waves) { return strip16_groups(ql) + 2 * 64 * waves - 1; }
 __host__ __device__ inline int strip16_qwords(int ql) { return ((((ql + 3) >> 2) + 4) + 3) & ~3; }
+__host__ __device__ inline int strip16_table_words(int ql) { return (strip16_groups(ql) + 1) * 4; } // the CODES form: one dword per query column, whole groups of four + one
 __host__ __device__ inline int64_t tb_words_strip16(int ql, int waves) { return (int64_t)waves * strip16_steps(ql, waves) * STRIP_CPS * 2 * 64 * 4; } // [wave][step][CPS][2][lane] uint4
 __host__ __device__ inline int64_t strip16_scratch_bytes(int ql, int waves) { return ((int64_t)(ql + 8) * 2 + 2 * 33 * 64 * waves) * 4; } // per pair
 // ... without stored flags (DpArgs::strip_k = K > 0, traceback layout 6): per pair {H, E} (int32, true scores) of the row below every band of
@@ -255,6 +257,8 @@ __host__ __device__ inline int64_t strip16_ck_words(int tl, int ql, int rows, in
     return ((((int64_t)strip16_ck_bands(tl, rows, k) * strip16_ck_row_stride(ql) + (int64_t)strip16_ck_ccs(tl, ql, rows, k) * (tl + 1)) + 3) & ~(int64_t)3) * (pack_bits ? 1 : 2);
 }
 int strip16_lds_bytes(int max_ql, int waves);
+int strip16_lds_bytes_codes(int max_ql, int waves); // the query as one table dword per column (DpArgs::strip_codes)
+int strip16_waves_per_simd(int rows);               // what the kernel of that many rows per strip is built for (2 or 3)
 bool strip16_range_ok(int match, int mismatch, int gopen, int gext);
 hipError_t launch_dp16_strip(const DpArgs &a, int waves, int rows, hipStream_t stream); // rows per strip: 20 / 24 / 28 / 32; a.uni_ql = max_ql sizes the regions; a.scratch: strip16_scratch_bytes per pair
 hipError_t launch_dp_coop16(const DpArgs &a, int waves_per_block, hipStream_t stream); // a.sps_cap = coop16_sps_for(max_ql)

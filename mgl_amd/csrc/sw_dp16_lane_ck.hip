@@ -996,9 +996,11 @@ __device__ __forceinline__ void sw_dp16_lane_ck_tile(const DpArgs &a, const TbAr
 // tiles each, 1 024 with 25); together 1.21 tiles per ms and SIMD, one wave alone 0.95.  The counter evens that out: whoever is through
 // draws the next tile.  Rules that keep the slow waves from drawing a launch's last tiles were built and measured (the end of a
 // 1.25 M-pair launch moved between 8.9 and 9.6 ms either way, box by box) and are gone.
-__global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, const TbArgs walk)
+// TWO kernels, one per way the results leave (VIA_LDS: in whole lines out of LDS, TbArgs::coalesced_out; else lane by lane through the
+// caller's pointers): one kernel holding both tile functions had the registers of both to colour at once (192 spilled against 66).
+template <bool VIA_LDS>
+__device__ __forceinline__ void lane_ck_grid(const DpArgs &a, const TbArgs &walk, unsigned char *out_lds)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char out_lds[LANE_CK_OUT_LDS_BYTES]; // a tile's results on their way out (TbArgs::coalesced_out)
     const int lane = threadIdx.x & 63;
     const int64_t tiles = (((a.count + 1) >> 1) + 63) >> 6, slots = gridDim.x, slot = blockIdx.x;
     // in-kernel clock probe (profiling level 2; off in normal runs): shader-clock ticks and 100 MHz ticks of this wave's whole life
@@ -1051,10 +1053,7 @@ __global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, 
 #ifdef MGL_CK_TRACE
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        if (walk.coalesced_out)
-            sw_dp16_lane_ck_tile<true>(a, walk, tile, slot, lane, out_lds);
-        else
-            sw_dp16_lane_ck_tile<false>(a, walk, tile, slot, lane, out_lds);
+        sw_dp16_lane_ck_tile<VIA_LDS>(a, walk, tile, slot, lane, out_lds);
 #ifdef MGL_CK_TRACE
         if (lane == 0 && tile < (1 << 17)) {
             unsigned hw;
@@ -1078,6 +1077,15 @@ __global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, 
     }
 }
 
+__global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_kernel(const DpArgs a, const TbArgs walk)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char out_lds[LANE_CK_OUT_LDS_BYTES]; // a tile's results on their way out
+    lane_ck_grid<true>(a, walk, out_lds);
+}
+
+// results lane by lane through the caller's pointers (scattered destinations, strides the LDS form does not take); no LDS
+__global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_scatter_kernel(const DpArgs a, const TbArgs walk) { lane_ck_grid<false>(a, walk, nullptr); }
+
 // either wire format, the same for both sequence sets (the kernel stages base codes, sw_lane_cell.h)
 bool lane16_ck_supported(const SeqSet &t, const SeqSet &q) { return (t.packed2 != 0) == (q.packed2 != 0); }
 
@@ -1091,7 +1099,10 @@ hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &walk, hipStream_t 
     const int64_t tiles = ((a.count + 1) / 2 + 63) / 64;
     if (a.lane_slots < 1 || (tiles > a.lane_slots && !a.tile_ctr)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(tiles < a.lane_slots ? tiles : a.lane_slots)), block(64);
-    hipLaunchKernelGGL(sw_dp16_lane_ck_kernel, grid, block, 0, stream, a, walk);
+    if (walk.coalesced_out)
+        hipLaunchKernelGGL(sw_dp16_lane_ck_kernel, grid, block, 0, stream, a, walk);
+    else
+        hipLaunchKernelGGL(sw_dp16_lane_ck_scatter_kernel, grid, block, 0, stream, a, walk);
     return hipGetLastError();
 }
 

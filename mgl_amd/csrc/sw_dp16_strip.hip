@@ -49,7 +49,13 @@ __device__ __forceinline__ unsigned dpp_wave_shr1(unsigned lane0_value, unsigned
     return (unsigned)__builtin_amdgcn_update_dpp((int)lane0_value, (int)src, 0x138, 0xf, 0xf, false);
 }
 
-template <int SR, bool NOTB>
+// CODES (round 4; the kernels without stored flags, where the query's tables fit the LDS carve and every target byte of the pair is one
+// of ACGT -- 2-bit packed inputs always): "do the bases differ" is ONE v_perm_b32 per two cells (sw_lane_cell.h: the row's selector picks
+// its code's byte out of the column's table) where the byte compare takes a xor and a min -- 8 instead of 9 instructions per two cells.
+// The tables (one dword per query column: byte c = 0 where the query base has code c, else 1; all ones for a query byte outside the
+// target's alphabet) are built once per pair in LDS, where the byte form keeps the query itself: four times the bytes, and no
+// instruction in the step -- each half reads its four columns' tables with one ds_read_b128.
+template <int SR, bool NOTB, bool CODES>
 __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned char *smem)
 {
     const int L = threadIdx.x & 63;
@@ -67,7 +73,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     const bool indel = (a.strategy & (OS_INDEL | OS_LEAD_ID)) != 0;
 
     // LDS: query as dwords (group cg = bases 4cg+1 .. 4cg+4, zero padded) | mailbox[2][W][8] | last-column key (u64) | scan results
-    const int qwords = strip16_qwords(a.uni_ql);
+    const int qwords = CODES ? strip16_table_words(a.uni_ql) : strip16_qwords(a.uni_ql);
     unsigned *const Q = reinterpret_cast<unsigned *>(smem);
     unsigned *const mbox = Q + qwords;
     unsigned long long *const key = reinterpret_cast<unsigned long long *>(mbox + 2 * W * 8);
@@ -77,12 +83,29 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     int *const rowbuf = reinterpret_cast<int *>(a.scratch + (size_t)slot * (size_t)strip16_scratch_bytes(a.uni_ql, W));
     unsigned *const cap = reinterpret_cast<unsigned *>(rowbuf + (size_t)(a.uni_ql + 8) * 2) + (size_t)ell * 66;
     {
-        for (int x = threadIdx.x; x < qwords; x += blockDim.x) Q[x] = 0u;
         for (int x = threadIdx.x; x < 2 * W * 8; x += blockDim.x) mbox[x] = 0u;
         if (threadIdx.x == 0) key[0] = 0ull;
-        __syncthreads();
-        unsigned char *qb = reinterpret_cast<unsigned char *>(Q);
-        for (int x = threadIdx.x; x < ql; x += blockDim.x) qb[x] = (unsigned char)a.q.at(q0, x);
+        if (CODES) { // column j's table at dword j - 1; behind the query: columns that feed nothing
+            for (int x = threadIdx.x; x < qwords; x += blockDim.x) {
+                unsigned q8 = 32u;
+                if (x < ql) {
+                    const unsigned b = (unsigned)a.q.at(q0, x);
+                    if (a.q.packed2) {
+                        q8 = 8u * b;
+                    } else {
+                        unsigned diff;
+                        const unsigned code = ascii_codes(b, diff);
+                        q8 = (diff & 0xffu) ? 32u : 8u * (code & 3u);
+                    }
+                }
+                Q[x] = code_table(q8);
+            }
+        } else {
+            for (int x = threadIdx.x; x < qwords; x += blockDim.x) Q[x] = 0u;
+            __syncthreads();
+            unsigned char *qb = reinterpret_cast<unsigned char *>(Q);
+            for (int x = threadIdx.x; x < ql; x += blockDim.x) qb[x] = (unsigned char)a.q.at(q0, x);
+        }
         __syncthreads();
     }
 
@@ -106,7 +129,11 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
 #pragma unroll
     for (int r = 0; r < SR; ++r) {
         const int ra = i0A + r, rb = i0B + r; // 0-based row indices
-        t[r] = (unsigned)(ra < tl ? a.t.at(t0, ra) : 0) | ((unsigned)(rb < tl ? a.t.at(t0, rb) : 0) << 16);
+        const unsigned ba = (unsigned)(ra < tl ? a.t.at(t0, ra) : 0), bb = (unsigned)(rb < tl ? a.t.at(t0, rb) : 0);
+        if (CODES) // the row's selector (sw_lane_cell.h): its code for the low half's table, 4 + its code for the high half's
+            t[r] = CODE_SEL | (a.t.packed2 ? ba : (ba >> 1) & 3u) | ((a.t.packed2 ? bb : (bb >> 1) & 3u) << 16);
+        else
+            t[r] = ba | (bb << 16);
         h[r] = f[r] = 0u;
     }
     unsigned hd = 0u;
@@ -116,12 +143,11 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     const int ulast = (ql - 1) % CPS;
     const int gl = (tl - 1) / SR;                     // the strip and (as a scalar) the register row of target row tl
     const int rl_s = __builtin_amdgcn_readfirstlane((tl - 1) % SR);
-    const bool own_last_a = gA == gl, own_last_b = gB == gl;
     int best = NEG_INF, best_i = -1;            // last-column candidates of this lane (both halves merged: later row wins)
 
     uint4 *const tb_wave = reinterpret_cast<uint4 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words) + (size_t)w * steps_cap * CPS * 2 * 64 + L;
     // NOTB: the rows and checkpoints kept instead of the flags (strip16_ck_words): int2 entries
-    const int K = NOTB ? a.strip_k : 1;
+    constexpr int K = NOTB ? 64 / SR : 1; // (= a.strip_k: the host sets it so, launch_dp16_strip checks; a constant here: the divisions below are multiplications)
     int2 *const rows_rec = reinterpret_cast<int2 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words);
     const int row_stride = strip16_ck_row_stride(a.uni_ql);
     int2 *const ck_rec = rows_rec + (size_t)strip16_ck_bands(a.uni_tl, SR, K) * row_stride;
@@ -129,11 +155,22 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     const int PB = NOTB ? a.strip_pack : 0;
     int *const rows_pk = reinterpret_cast<int *>(rows_rec);
     int *const ck_pk = rows_pk + (size_t)strip16_ck_bands(a.uni_tl, SR, K) * row_stride;
-    const int bandA = gA / K, bandB = gB / K;
-    // the strip whose last row is the row below a band (and not the matrix's last rows): it writes that row
-    const bool rowsA = NOTB && (gA + 1) % K == 0 && (gA + 1) * SR < tl, rowsB = NOTB && (gB + 1) % K == 0 && (gB + 1) * SR < tl;
+    // (per step, below: bandA / bandB = the band of K strips a strip belongs to; rowoffA / rowoffB = that band's kept row as a 32-bit index off
+    // the pair's uniform base; rowsA / rowsB = the strip whose last row is the row below a band -- and not the matrix's last rows: it writes that row)
 
     for (int s = 0; s < steps; ++s) {
+        // What a lane knows about its two strips is a handful of small functions of its number.  Left to itself the compiler computes
+        // every one of them (and every intermediate the steps below derive from them) once in front of the loop and keeps it in a
+        // register: some thirty registers the 32 x 3 + 16 of the strips' state leave no room for -- they were spilled (up to 281 per
+        // lane in round 3) and loaded back step after step.  Made opaque here, they are recomputed per step: a dozen instructions
+        // against the ~ 600 of a step's four columns.
+        int el = ell;
+        if (NOTB) asm volatile("" : "+v"(el));
+        const int gA = el, gB = NL + el, i0A = SR * gA, i0B = SR * gB;
+        const bool own_last_a = gA == gl, own_last_b = gB == gl;
+        const int bandA = gA / K, bandB = gB / K;
+        const int rowoffA = bandA * row_stride, rowoffB = bandB * row_stride;
+        const bool rowsA = NOTB && (gA + 1) % K == 0 && (gA + 1) * SR < tl, rowsB = NOTB && (gB + 1) % K == 0 && (gB + 1) * SR < tl;
         const int cgA = s - gA, cgB = s - gB;
         const bool actA = cgA >= 0 && cgA < NCG && i0A < tl, actB = cgB >= 0 && cgB < NCG && i0B < tl;
         // ---- 1. what the strip above handed on in the previous step arrives column by column, right before it is used (below):
@@ -192,23 +229,40 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
             // ---- 4. four columns
             // (a query dword holds 4 / CPS groups; the two halves are 64 W groups apart, so they sit in the same place of their dwords)
             constexpr int GPD = 4 / CPS;
-            const unsigned qa = Q[min(max(cgA / GPD, 0), qwords - 1)], qb = Q[min(max(cgB / GPD, 0), qwords - 1)];
+            static_assert(!CODES || CPS == 4, "the tables of a step are one 16-byte read");
+            const unsigned qa = CODES ? 0u : Q[min(max(cgA / GPD, 0), qwords - 1)], qb = CODES ? 0u : Q[min(max(cgB / GPD, 0), qwords - 1)];
             const unsigned qsel = 0x0c040c00u + 0x00010001u * (unsigned)(CPS * (cgA & (GPD - 1)));
+            uint4 tabA = make_uint4(0u, 0u, 0u, 0u), tabB = tabA; // CODES: the tables of this step's four columns, either half
+            if (CODES) {
+                const uint4 *const T4 = reinterpret_cast<const uint4 *>(Q);
+                tabA = T4[min(max(cgA, 0), (qwords >> 2) - 1)];
+                tabB = T4[min(max(cgB, 0), (qwords >> 2) - 1)];
+            }
             uint4 *tbp = tb_wave + (size_t)s * CPS * 2 * 64;
+            // NOTB: what turns the stored values of the row below a band into true scores at column 4 cg (opaque: one register per half
+            // and step -- left to itself the compiler keeps a loop-invariant part per column and entry, sixteen registers the
+            // 25-to-32-row kernels do not have: spilled, and loaded back in every step)
+            int unA = base_a - ((gA + 1) * SR + CPS * cgA) * gext, unB = base_b - ((gB + 1) * SR + CPS * cgB) * gext;
+            if (NOTB) asm volatile("" : "+v"(unA), "+v"(unB));
 #pragma unroll
             for (int u = 0; u < CPS; ++u) {
                 unsigned ih, e;
                 take(u, ih, e);
                 e = pk_sub(e, bres);
-                const unsigned q = __builtin_amdgcn_perm(qb, qa, qsel + 0x00010001u * (unsigned)u);
-                column<SR, NOTB>(h, f, t, q, hd, e, c, tbp + (size_t)u * 2 * 64);
+                if (CODES) {
+                    const unsigned qA = u == 0 ? tabA.x : u == 1 ? tabA.y : u == 2 ? tabA.z : tabA.w, qB = u == 0 ? tabB.x : u == 1 ? tabB.y : u == 2 ? tabB.z : tabB.w;
+                    column<SR, NOTB, false, true>(h, f, t, qA, hd, e, c, tbp + (size_t)u * 2 * 64, nullptr, qB);
+                } else {
+                    const unsigned q = __builtin_amdgcn_perm(qb, qa, qsel + 0x00010001u * (unsigned)u);
+                    column<SR, NOTB>(h, f, t, q, hd, e, c, tbp + (size_t)u * 2 * 64);
+                }
                 hd = pk_sub(ih, bres);
                 out_h[u] = pk_add(h[SR - 1], bres);
                 out_e[u] = pk_add(e, bres);
                 if (NOTB) { // {H[i][j], E entering row i + 1} of the row below a band, as true scores (stored = X + (i + j) e - baseline)
-                    const int iA = (gA + 1) * SR, iB = (gB + 1) * SR, jA = CPS * cgA + u + 1, jB = CPS * cgB + u + 1;
-                    keptA[u] = make_int2(lo16(h[SR - 1]) + base_a - (iA + jA) * gext, lo16(e) + base_a - (iA + 1 + jA) * gext);
-                    keptB[u] = make_int2(hi16(h[SR - 1]) + base_b - (iB + jB) * gext, hi16(e) + base_b - (iB + 1 + jB) * gext);
+                    const int ue = (u + 1) * gext; // (a scalar per column of the group)
+                    keptA[u] = make_int2(lo16(h[SR - 1]) + (unA - ue), lo16(e) + (unA - ue - gext));
+                    keptB[u] = make_int2(hi16(h[SR - 1]) + (unB - ue), hi16(e) + (unB - ue - gext));
                 }
                 if (u == ulast && ((cgA == NCG - 1 && actA) || (cgB == NCG - 1 && actB))) {
                     // column ql of this strip's rows: parked in the lane's own scratch lines with the baseline that goes with it,
@@ -243,7 +297,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
         // ---- 4a. the row below a band (NOTB): the group's four columns as one aligned 32-byte piece (column j at entry j - 1)
         if (NOTB && CPS == 4) {
             if (PB && rowsA && actA) { // one aligned 16-byte piece
-                int *const dst = rows_pk + (size_t)bandA * row_stride + CPS * cgA;
+                int *const dst = rows_pk + (unsigned)(rowoffA + CPS * cgA);
                 if (CPS * cgA + CPS <= ql) {
                     reinterpret_cast<int4 *>(dst)[0] = make_int4(strip16_pack(keptA[0].x, keptA[0].y, PB), strip16_pack(keptA[1].x, keptA[1].y, PB),
                                                                  strip16_pack(keptA[2].x, keptA[2].y, PB), strip16_pack(keptA[3].x, keptA[3].y, PB));
@@ -253,7 +307,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                         if (CPS * cgA + u + 1 <= ql) dst[u] = strip16_pack(keptA[u].x, keptA[u].y, PB);
                 }
             } else if (rowsA && actA) {
-                int2 *const dst = rows_rec + (size_t)bandA * row_stride + CPS * cgA;
+                int2 *const dst = rows_rec + (unsigned)(rowoffA + CPS * cgA);
                 if (CPS * cgA + CPS <= ql) {
                     reinterpret_cast<int4 *>(dst)[0] = make_int4(keptA[0].x, keptA[0].y, keptA[1].x, keptA[1].y);
                     reinterpret_cast<int4 *>(dst)[1] = make_int4(keptA[2].x, keptA[2].y, keptA[3].x, keptA[3].y);
@@ -264,7 +318,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                 }
             }
             if (PB && rowsB && actB) {
-                int *const dst = rows_pk + (size_t)bandB * row_stride + CPS * cgB;
+                int *const dst = rows_pk + (unsigned)(rowoffB + CPS * cgB);
                 if (CPS * cgB + CPS <= ql) {
                     reinterpret_cast<int4 *>(dst)[0] = make_int4(strip16_pack(keptB[0].x, keptB[0].y, PB), strip16_pack(keptB[1].x, keptB[1].y, PB),
                                                                  strip16_pack(keptB[2].x, keptB[2].y, PB), strip16_pack(keptB[3].x, keptB[3].y, PB));
@@ -274,7 +328,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                         if (CPS * cgB + u + 1 <= ql) dst[u] = strip16_pack(keptB[u].x, keptB[u].y, PB);
                 }
             } else if (rowsB && actB) {
-                int2 *const dst = rows_rec + (size_t)bandB * row_stride + CPS * cgB;
+                int2 *const dst = rows_rec + (unsigned)(rowoffB + CPS * cgB);
                 if (CPS * cgB + CPS <= ql) {
                     reinterpret_cast<int4 *>(dst)[0] = make_int4(keptB[0].x, keptB[0].y, keptB[1].x, keptB[1].y);
                     reinterpret_cast<int4 *>(dst)[1] = make_int4(keptB[2].x, keptB[2].y, keptB[3].x, keptB[3].y);
@@ -293,13 +347,18 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
             const bool ckA = actA && ((cgA + 1 + K * bandA) % PER) == 0, ckB = actB && ((cgB + 1 + K * bandB) % PER) == 0;
             if (__builtin_amdgcn_ballot_w64(ckA || ckB)) {
                 if (ckA) {
+                    // (the row terms are made opaque: computed here, K of 64 steps, not hoisted out of the step loop -- hoisted, they were
+                    // a register per row for the whole loop, spilled in front of it and loaded back here)
+                    int i0 = i0A, ge = gext;
+                    asm volatile("" : "+v"(i0), "+s"(ge));
                     const int j = CPS * (cgA + 1), cc = (cgA + 1 + K * bandA) / PER;
-                    int2 *const dst = ck_rec + (size_t)cc * (a.uni_tl + 1) + i0A + 1;
-                    int *const dpk = ck_pk + (size_t)cc * (a.uni_tl + 1) + i0A + 1;
+                    int2 *const dst = ck_rec + (size_t)cc * (a.uni_tl + 1) + i0 + 1;
+                    int *const dpk = ck_pk + (size_t)cc * (a.uni_tl + 1) + i0 + 1;
+                    int un = base_a - (i0 + 1 + j) * ge; // row r: - r * ge on top
 #pragma unroll
-                    for (int r = 0; r < SR; ++r)
-                        if (i0A + r < tl) {
-                            const int hv = lo16(h[r]) + base_a - (i0A + r + 1 + j) * gext, fv = lo16(f[r]) + base_a - (i0A + r + 2 + j) * gext;
+                    for (int r = 0; r < SR; ++r, un -= ge)
+                        if (i0 + r < tl) {
+                            const int hv = lo16(h[r]) + un, fv = lo16(f[r]) + un - ge;
                             if (PB)
                                 dpk[r] = strip16_pack(hv, fv, PB);
                             else
@@ -307,13 +366,16 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                         }
                 }
                 if (ckB) {
+                    int i0 = i0B, ge = gext;
+                    asm volatile("" : "+v"(i0), "+s"(ge));
                     const int j = CPS * (cgB + 1), cc = (cgB + 1 + K * bandB) / PER;
-                    int2 *const dst = ck_rec + (size_t)cc * (a.uni_tl + 1) + i0B + 1;
-                    int *const dpk = ck_pk + (size_t)cc * (a.uni_tl + 1) + i0B + 1;
+                    int2 *const dst = ck_rec + (size_t)cc * (a.uni_tl + 1) + i0 + 1;
+                    int *const dpk = ck_pk + (size_t)cc * (a.uni_tl + 1) + i0 + 1;
+                    int un = base_b - (i0 + 1 + j) * ge;
 #pragma unroll
-                    for (int r = 0; r < SR; ++r)
-                        if (i0B + r < tl) {
-                            const int hv = hi16(h[r]) + base_b - (i0B + r + 1 + j) * gext, fv = hi16(f[r]) + base_b - (i0B + r + 2 + j) * gext;
+                    for (int r = 0; r < SR; ++r, un -= ge)
+                        if (i0 + r < tl) {
+                            const int hv = hi16(h[r]) + un, fv = hi16(f[r]) + un - ge;
                             if (PB)
                                 dpk[r] = strip16_pack(hv, fv, PB);
                             else
@@ -339,7 +401,8 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        const int i0 = half ? i0B : i0A;
+        int i0 = half ? i0B : i0A;
+        asm volatile("" : "+v"(i0)); // (opaque: the rows' numbers are computed here, not kept in registers -- spilled ones -- from the prologue on)
         if (i0 < tl) {
             const unsigned *cp = cap + (half ? 33 : 0);
             const int bb = (int)__builtin_nontemporal_load(cp + 32);
@@ -400,16 +463,42 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
 // grid = pairs of the chunk, block = 64 * W threads (W <= 4), dynamic LDS = strip16_lds_bytes.  Rows per strip: 32, or fewer when
 // that still covers the longest target with the same number of waves (10 000 rows on 384 strip slots: 27 rows each instead of
 // 313 strips of 32 -- a sixth fewer instructions per column)
+// Waves per SIMD.  Three (168 registers) up to 28 rows per strip, where the kernels hold their state without spilling; TWO (256
+// registers) from 29 rows on: at three, the 32-row kernel spilled inside the column code (16 kb pairs: 99.5 ms per 1 536 pairs against
+// 90.7 with two waves per SIMD; 10 kb pairs, 20 rows: the same either way).  -DMGL_STRIP_OCC2_FROM=N (scripts/build_variant.sh) moves the border.
+#ifndef MGL_STRIP_OCC2_FROM
+#define MGL_STRIP_OCC2_FROM 29
+#endif
+#define MGL_STRIP_OCC(ROWS) ((ROWS) >= MGL_STRIP_OCC2_FROM ? 2 : 3)
+
+// every byte of the pair's target one of ACGT (2-bit packed inputs: by construction)?  The whole workgroup calls this together.
+__device__ __forceinline__ bool strip_target_is_acgt(const DpArgs &a)
+{
+    if (a.t.packed2) return true;
+    const int64_t p = a.first + blockIdx.x, t0 = a.t.off[p];
+    const int tl = a.t.length(p);
+    unsigned bad = 0u;
+    for (int x = threadIdx.x; x < tl; x += blockDim.x) {
+        unsigned diff;
+        ascii_codes((unsigned)a.t.data[t0 + x], diff);
+        bad |= diff & 0xffu;
+    }
+    return __syncthreads_or((int)bad) == 0;
+}
+
 #define MGL_STRIP_KERNEL(NAME, ROWS)                                                     \
-    __global__ __launch_bounds__(256, 3) void NAME(const DpArgs a)                       \
+    __global__ __launch_bounds__(256, MGL_STRIP_OCC(ROWS)) void NAME(const DpArgs a)     \
     {                                                                                    \
         extern __shared__ __attribute__((aligned(16))) unsigned char smem[];             \
-        sw_dp16_strip_body<ROWS, false>(a, smem);                                        \
+        sw_dp16_strip_body<ROWS, false, false>(a, smem);                                 \
     }                                                                                    \
-    __global__ __launch_bounds__(256, 3) void NAME##_ck(const DpArgs a)                  \
+    __global__ __launch_bounds__(256, MGL_STRIP_OCC(ROWS)) void NAME##_ck(const DpArgs a) \
     {                                                                                    \
         extern __shared__ __attribute__((aligned(16))) unsigned char smem[];             \
-        sw_dp16_strip_body<ROWS, true>(a, smem);                                         \
+        if (a.strip_codes && strip_target_is_acgt(a))                                    \
+            sw_dp16_strip_body<ROWS, true, true>(a, smem);                               \
+        else                                                                             \
+            sw_dp16_strip_body<ROWS, true, false>(a, smem);                              \
     }
 MGL_STRIP_KERNEL(sw_dp16_strip_kernel, 32)
 MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r31, 31)
@@ -427,6 +516,9 @@ MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r20, 20)
 #undef MGL_STRIP_KERNEL
 
 int strip16_lds_bytes(int max_ql, int waves) { return strip16_qwords(max_ql) * 4 + 2 * waves * 8 * 4 + 8 + 16 + 64; }
+// ... with the query as one table per column (the CODES form of the kernels without stored flags)
+int strip16_lds_bytes_codes(int max_ql, int waves) { return strip16_table_words(max_ql) * 4 + 2 * waves * 8 * 4 + 8 + 16 + 64; }
+int strip16_waves_per_simd(int rows) { return MGL_STRIP_OCC(rows); }
 
 // The static window of a strip (see the header): 31 rows of one column, 16 + 4 columns of drift, the intermediates of a cell.
 bool strip16_range_ok(int match, int mismatch, int gopen, int gext)
@@ -440,8 +532,8 @@ bool strip16_range_ok(int match, int mismatch, int gopen, int gext)
 
 hipError_t launch_dp16_strip(const DpArgs &a, int waves, int rows, hipStream_t stream)
 {
-    const int lds = strip16_lds_bytes(a.uni_ql, waves);
-    if (lds > 64 * 1024) return hipErrorInvalidValue; // (the host checks)
+    const int lds = a.strip_codes ? strip16_lds_bytes_codes(a.uni_ql, waves) : strip16_lds_bytes(a.uni_ql, waves);
+    if (lds > 64 * 1024 || (a.strip_codes && a.strip_k == 0)) return hipErrorInvalidValue; // (the host checks)
     static void (*const table[13])(const DpArgs) = {sw_dp16_strip_kernel_r20, sw_dp16_strip_kernel_r21, sw_dp16_strip_kernel_r22, sw_dp16_strip_kernel_r23,
                                                     sw_dp16_strip_kernel_r24, sw_dp16_strip_kernel_r25, sw_dp16_strip_kernel_r26, sw_dp16_strip_kernel_r27,
                                                     sw_dp16_strip_kernel_r28, sw_dp16_strip_kernel_r29, sw_dp16_strip_kernel_r30, sw_dp16_strip_kernel_r31,
@@ -451,6 +543,7 @@ hipError_t launch_dp16_strip(const DpArgs &a, int waves, int rows, hipStream_t s
                                                        sw_dp16_strip_kernel_r28_ck, sw_dp16_strip_kernel_r29_ck, sw_dp16_strip_kernel_r30_ck, sw_dp16_strip_kernel_r31_ck,
                                                        sw_dp16_strip_kernel_ck};
     if (rows < 20 || rows > 32) return hipErrorInvalidValue;
+    if (a.strip_k > 0 && a.strip_k != 64 / rows) return hipErrorInvalidValue; // (a constant in the kernels)
     void (*k)(const DpArgs) = a.strip_k > 0 ? table_ck[rows - 20] : table[rows - 20];
     hipLaunchKernelGGL(k, dim3((unsigned)a.count), dim3(64 * waves), lds, stream, a);
     return hipGetLastError();

@@ -343,7 +343,7 @@ def test_device_batch_of_mixed_lengths_is_sorted_on_the_device(two_bit):
     a.close()
 
 
-@pytest.mark.parametrize("stored", [False, True, None], ids=["checkpointed", "stored", "checkpointed_two_words_per_entry"])
+@pytest.mark.parametrize("stored", [False, True, None, "bytes"], ids=["checkpointed", "stored", "checkpointed_two_words_per_entry", "checkpointed_byte_compare"])
 def test_strip_kernel_long_reads(stored, monkeypatch):
     """sw_dp16_strip_kernel (one pair per workgroup, one 32-row strip per lane-half, per-strip 16-bit baselines, hand-over by DPP
     and an LDS mailbox) forced onto the long goldens, onto pairs of awkward lengths under every strategy, and onto ordinary
@@ -354,6 +354,9 @@ def test_strip_kernel_long_reads(stored, monkeypatch):
 
     if stored is None:   # the kept rows and checkpoints as {H, gap value} pairs of int32 instead of one packed int32 per entry
         monkeypatch.setenv("MGL_SW_DEBUG_STRIP_PACK", "0")
+        stored = False
+    if stored == "bytes":  # the byte compare for every pair (default: base codes wherever a pair's target is all ACGT and the query's tables fit the LDS carve)
+        monkeypatch.setenv("MGL_SW_DEBUG_STRIP_CODES", "0")
         stored = False
     forced = sw.MicrosoftSmithWaterman(0)
     forced.set_strip_kernel(2)
@@ -372,6 +375,18 @@ def test_strip_kernel_long_reads(stored, monkeypatch):
             o = ol.oracle_align(t, q, (200, -150, 260, 11), strategy)
             assert (int(res.offsets[k]), res.cigars[k], tuple(int(x) for x in res.scores[k])) == (o["offset"], o["cigar"], o["score"]), (strategy, k)
             assert forced.slot_layout(k) == (4 if stored else 6)
+    # the same pairs as 2-bit packed inputs at unaligned base offsets (base codes by construction): identical to the ASCII run
+    if not stored:
+        import torch
+        from collections import namedtuple
+        Row = namedtuple("Row", "t q")
+        pb = _packed_from_rows([Row(*p) for p in pairs], torch.device("cuda", 0))
+        pb.run(forced, (200, -150, 260, 11), ol.IGNORE)
+        torch.cuda.synchronize()
+        assert forced.timing().fill_kernel == 6 and int((pb.status != 0).sum()) == 0
+        off, sc, cg = pb.offsets.cpu().numpy(), pb.scores.cpu().numpy(), pb.cigar_strings()
+        for k in range(len(pairs)):
+            assert (int(off[k]), cg[k], tuple(int(x) for x in sc[k])) == (int(res.offsets[k]), res.cigars[k], tuple(int(x) for x in res.scores[k])), k
     # four waves per pair (targets of 12 289 .. 16 384 rows), a short query against a long target and the reverse
     wide = [(synth.random_genome(rng, 15000).tobytes(), synth.random_genome(rng, 1800).tobytes())]
     wide.append((wide[0][0][:16384 - 3], wide[0][0][200:1500]))
@@ -380,6 +395,23 @@ def test_strip_kernel_long_reads(stored, monkeypatch):
         res = forced.align_batch([p[0] for p in wide], [p[1] for p in wide], (200, -150, 260, 11), strategy, cigar_stride=40000)
         assert forced.timing().fill_kernel == 6
         for k, (t, q) in enumerate(wide):
+            o = ol.oracle_align(t, q, (200, -150, 260, 11), strategy)
+            assert (int(res.offsets[k]), res.cigars[k], tuple(int(x) for x in res.scores[k])) == (o["offset"], o["cigar"], o["score"]), (strategy, k)
+    # bytes outside ACGT (sw.cpp:55 compares bytes: N == N, a != A): in the query alone -- the base-code form, whose table for such a
+    # byte differs from every code --, in the target -- that pair takes the byte compare --, in both at the same place, lower case
+    gn = bytearray(synth.random_genome(rng, 3000).tobytes())
+    qn = bytearray(gn[100:2600])
+    for x in (5, 700, 701, 702, 2499):
+        qn[x] = ord("N")
+    tn = bytearray(gn)
+    for x in (105, 800, 801, 802, 2599, 2999):
+        tn[x] = ord("N")
+    odd = [(bytes(gn), bytes(qn)), (bytes(tn), bytes(gn[100:2600])), (bytes(tn), bytes(qn)), (bytes(gn).lower(), bytes(gn[50:2000])), (bytes(gn), bytes(gn[50:2000]).lower()),
+           (bytes(gn), bytes(gn[50:1000]) + b"RYKM" + bytes(gn[1004:2000]))]
+    for strategy in (ol.SOFTCLIP, ol.INDEL):
+        res = forced.align_batch([p[0] for p in odd], [p[1] for p in odd], (200, -150, 260, 11), strategy, cigar_stride=8192)
+        assert forced.timing().fill_kernel == 6
+        for k, (t, q) in enumerate(odd):
             o = ol.oracle_align(t, q, (200, -150, 260, 11), strategy)
             assert (int(res.offsets[k]), res.cigars[k], tuple(int(x) for x in res.scores[k])) == (o["offset"], o["cigar"], o["score"]), (strategy, k)
     # sequences that stretch a strip's static window (identical, disjoint, homopolymers, a long gap) under two parameter sets that
