@@ -90,12 +90,17 @@ struct WaveMem {
     const uint32_t *blku;  // blk without the lane, as dwords
     const unsigned *seq;   // the wave's staged sequences: the queries' blocks at 0, the targets' at t_off (dwords)
     unsigned mid_off, t_off, lane;
+    // (the BYTE offset is what is computed in 32 bits: an element index leaves its scaling to 64-bit arithmetic and the load to a
+    // 64-bit address in two registers -- pass 2 holds dozens of these at once)
+    template <class T>
+    __device__ __forceinline__ static T at32(const void *base, unsigned byte_off) { return *reinterpret_cast<const T *>(static_cast<const char *>(base) + byte_off); }
     __device__ __forceinline__ uint2 row16(int m, int ql, int j) const // {H, E} of row 16 m (m >= 0) at column j
     {
-        return rows[(m & 1) ? mid_off + (unsigned)(((m >> 1) * ql + j - 1) * 64) + lane : (unsigned)(((m >> 1) * (ql + 1) + j) * 64) + lane];
+        return at32<uint2>(rows, 8u * ((m & 1) ? mid_off + (unsigned)(((m >> 1) * ql + j - 1) * 64) + lane : (unsigned)(((m >> 1) * (ql + 1) + j) * 64) + lane));
     }
-    __device__ __forceinline__ unsigned qblock(int blk4, int half) const { return seq[(unsigned)((2 * blk4 + half) * 64) + lane]; }
-    __device__ __forceinline__ unsigned tblock(int blk4, int half) const { return seq[t_off + (unsigned)((2 * blk4 + half) * 64) + lane]; }
+    __device__ __forceinline__ unsigned qblock(int blk4, int half) const { return at32<unsigned>(seq, 4u * ((unsigned)((2 * blk4 + half) * 64) + lane)); }
+    __device__ __forceinline__ unsigned tblock(int blk4, int half) const { return at32<unsigned>(seq, 4u * (t_off + (unsigned)((2 * blk4 + half) * 64) + lane)); }
+    __device__ __forceinline__ unsigned flags(int cc, int r4) const { return at32<unsigned>(blku, 4u * ((unsigned)(cc * 256 + r4) + 4u * lane)); } // the block's flags: column cc, rows 4 r4 ..
 };
 
 // ---- pass 2: the walk of one pair (calculateCigar, sw.cpp:149-255) as a machine that can stop at a block's edge and go on in
@@ -173,7 +178,7 @@ struct PathWalk {
 #pragma unroll
         for (int u = 0; u < LOOK; ++u) { // (cells past the block's edge: some valid address, masked in apply())
             const int r = max(rr - u * di, 0), cc = max(cl - u * dj, 0);
-            w[u] = wm.blku[(unsigned)(cc * 256 + (r >> 2)) + 4u * wm.lane];
+            w[u] = wm.flags(cc, r >> 2);
         }
     }
     // returns false when the walk cannot go on inside this block (finished, or the cell it needs next is in another block)
@@ -361,7 +366,9 @@ struct PathWalk {
         return all && !done;
     }
     // overhangs, text, per-pair results (walk_and_write's tail + traceback_one_pair)
-    __device__ __forceinline__ void finish(const TbArgs &a, const DpRecord &r, int64_t o)
+    // (rp: the pair's record where pass 1 left it in memory -- read back here, by the lane that wrote it, rather than carried in a dozen
+    // registers through the whole of pass 2)
+    __device__ __forceinline__ void finish(const TbArgs &a, const DpRecord *rp, int64_t o)
     {
         int off;
         if (a.strategy == OS_SOFTCLIP) { // sw.cpp:225-229
@@ -386,6 +393,7 @@ struct PathWalk {
         if (a.status) a.status[o] = status;
         if (a.status_any && status != 0) atomicMax(a.status_any, status);
         if (a.score) {
+            const DpRecord r = *rp;
             Score sc;
             sc.mqe = r.mqe;
             sc.mqe_t = r.mqe_t;
@@ -530,25 +538,34 @@ __device__ __forceinline__ void ck_block(const int sA, const int bA, const int s
     {
         const unsigned ia = (unsigned)((((sA >> 1) * (g.nb - 1) + max(bA - 1, 0)) * 64 + (sA & 1) * 2 * RB) * 64) + wm.lane;
         const unsigned ib = (unsigned)((((sB >> 1) * (g.nb - 1) + max(bB - 1, 0)) * 64 + (sB & 1) * 2 * RB) * 64) + wm.lane;
-        unsigned va[2 * RB], vb[2 * RB];
+        // one half after the other (both at once: 64 registers of checkpoint values beside the 48 of the block's state -- spilled)
+        unsigned v[2 * RB];
 #pragma unroll
-        for (int x = 0; x < 2 * RB; ++x) va[x] = vb[x] = 0u;
+        for (int x = 0; x < 2 * RB; ++x) v[x] = 0u;
         if (needA && bA > 0) {
 #pragma unroll
-            for (int x = 0; x < 2 * RB; ++x) va[x] = wm.cku[ia + (unsigned)(x * 64)];
-        }
-        if (needB && bB > 0) {
-#pragma unroll
-            for (int x = 0; x < 2 * RB; ++x) vb[x] = wm.cku[ib + (unsigned)(x * 64)];
+            for (int x = 0; x < 2 * RB; ++x) v[x] = WaveMem::at32<unsigned>(wm.cku, 4u * (ia + (unsigned)(x * 64)));
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            const int rowA = sA * RB + r + 1, rowB = sB * RB + r + 1;
-            const int fa_ = border(rowA, g.gopen, g.gext, g.indel) + rowA * g.gext + g.base, fb_ = border(rowB, g.gopen, g.gext, g.indel) + rowB * g.gext + g.base;
-            const unsigned ha = bA > 0 ? va[2 * r] : (unsigned)fa_, hb = bB > 0 ? vb[2 * r] : (unsigned)fb_ << 16;
-            const unsigned ga = bA > 0 ? va[2 * r + 1] : (unsigned)(fa_ - (g.gopen - g.gext)), gb = bB > 0 ? vb[2 * r + 1] : (unsigned)(fb_ - (g.gopen - g.gext)) << 16;
-            h[r] = lo_hi(ha, hb);
-            f[r] = lo_hi(ga, gb);
+            const int rowA = sA * RB + r + 1;
+            const int fa_ = border(rowA, g.gopen, g.gext, g.indel) + rowA * g.gext + g.base;
+            h[r] = bA > 0 ? v[2 * r] : (unsigned)fa_;
+            f[r] = bA > 0 ? v[2 * r + 1] : (unsigned)(fa_ - (g.gopen - g.gext));
+        }
+#pragma unroll
+        for (int x = 0; x < 2 * RB; ++x) v[x] = 0u;
+        if (needB && bB > 0) {
+#pragma unroll
+            for (int x = 0; x < 2 * RB; ++x) v[x] = WaveMem::at32<unsigned>(wm.cku, 4u * (ib + (unsigned)(x * 64)));
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int rowB = sB * RB + r + 1;
+            const int fb_ = border(rowB, g.gopen, g.gext, g.indel) + rowB * g.gext + g.base;
+            const unsigned hb = bB > 0 ? v[2 * r] : (unsigned)fb_ << 16, gb = bB > 0 ? v[2 * r + 1] : (unsigned)(fb_ - (g.gopen - g.gext)) << 16;
+            h[r] = lo_hi(h[r], hb);
+            f[r] = lo_hi(f[r], gb);
         }
     }
     // the row entering the band, per column: row 16 s of the pair (WaveMem::row16; row 0 is the border row, kept like any other)
@@ -727,6 +744,11 @@ __device__ __forceinline__ void lds_to_global(void *dst, const unsigned char *sr
 
 // VIA_LDS (= walk_in.coalesced_out, a template parameter so that every pointer the walks write through has ONE address space: with the
 // choice made at run time the text went out through flat instructions, whose waits also cover the scalar loads -- pass 2 took twice as long)
+// (A wave keeps its slot for all its tiles, so every address of its region is invariant in the kernel's tile loop: the compiler computes
+// them once in front of it and keeps some forty of them in scratch for the kernel's whole life -- a load each where a tile needs one,
+// none inside pass 1's loops.  Making slot and lane opaque per tile recomputes them instead and empties the scratch area by a third,
+// but the kernel ran 2.5 ms per 10 M pairs SLOWER (65.2 against 62.6: the opaque lane number hides its range from the address
+// arithmetic of every store of pass 1) -- measured, scripts/ck_regs_probe.sh, and left alone.)
 template <bool VIA_LDS>
 __device__ __forceinline__ void sw_dp16_lane_ck_tile(const DpArgs &a, const TbArgs &walk_in, const int64_t gw, const int64_t slot, const int lane, unsigned char *out_lds)
 {
@@ -959,8 +981,8 @@ __device__ __forceinline__ void sw_dp16_lane_ck_tile(const DpArgs &a, const TbAr
         CK_PHASE(5); // the walk inside the block
     }
     CK_PHASE(6);
-    if (lvalid) wa.finish(walk, rec[0], oA);
-    if (validB) wb.finish(walk, rec[1], oB);
+    if (lvalid) wa.finish(walk, a.rec + slotA, oA);
+    if (validB) wb.finish(walk, a.rec + slotB, oB);
     if (via_lds) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
