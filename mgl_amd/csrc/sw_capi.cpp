@@ -305,6 +305,8 @@ struct BatchPlan {
     int64_t per_pair; // workspace bytes per pair
     int64_t lane_slots; // the checkpointed lane kernel's persistent grid: wave slots of a launch (= regions of a workspace half)
     int64_t fixed_bytes; // ... the bytes of those regions: workspace of a half that does not grow with the chunk
+    bool group_regions;  // a sorted device-resident chunk sized by slots: the lane part's regions, then left_area bytes for the left-over pairs
+    int64_t left_area, left_pair16, left_pair32; // ... that area (its first half: the packed kernel's pieces, its second: the int32 kernel's) and a pair's bytes in each
     int64_t chunk; // pairs per chunk (the largest, where the chunks grow and shrink)
     bool pyramid; // the host entry of a large 2-bit batch: chunks of 1, 2, 4, 8 .. 8, 4, 2, 1 rounds of the chip
     int64_t pyr_unit; // ... pairs per round
@@ -499,7 +501,20 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
     // (auto-grouped chunks: the packed regions first, the int32 regions of the left-over pairs behind them)
     const int sps32 = sps_for_rows(max_ql, 16);
     const int64_t stride32_words = tb_words_for(max_tl, sps32, 16);
-    const int64_t per_pair = lane_ck ? (int64_t)sizeof(DpRecord) // (+ fixed_bytes per half: the persistent grid's regions)
+    // A device-resident batch the library sorts itself (round 4): the whole waves of one geometry go through the lane kernel's PERSISTENT
+    // grid -- one region per wave slot, however many pairs -- and what is left over (fewer than 128 pairs per geometry, whatever the
+    // data) through the packed and int32 kernels in an area of its own, in as many pieces as that area needs.  A chunk is therefore
+    // sized by its records alone: 4 M reads of 100-150 bases are ONE chunk in an 8 GiB workspace (round 3 sized every pair for the
+    // left-over kernels' traceback, 19 KB: 21 chunks in 8 GiB -- 3 125 GCUPS --, 3 in 72 GiB -- 4 850 --, one in 170 GiB -- 5 320).
+    const int64_t left_pair = std::max(stride_words * 2, stride32_words * 4); // bytes of traceback per left-over pair, either kernel
+    const int64_t grp_slots = std::min<int64_t>(ck_chip, ctx->ws_limit / 4 * 3 / ck_region);
+    const char *const gre = getenv("MGL_SW_DEBUG_GROUP_REGIONS"); // (0: sorted chunks sized per pair, as before round 4; read per call: the tests compare both)
+    const char *const lae = getenv("MGL_SW_DEBUG_LEFT_AREA");     // (bytes of the left-over pairs' area: tests make it small, so that the left-overs take several pieces)
+    const int64_t grp_left_area = lae && atoll(lae) > 0 ? std::max<int64_t>(left_pair * 16, atoll(lae)) / 256 * 256 : std::max<int64_t>(left_pair * 64, std::min<int64_t>(std::min<int64_t>(ctx->ws_limit / 8, (int64_t)1 << 30), 2 * left_pair * ((n + 63) / 64 * 64))) / 256 * 256; // (two halves: the packed kernel's pieces, the int32 kernel's)
+    const bool group_regions = auto_group && lane_group && !hooks && !score_only && !(gre && atoi(gre) == 0) && grp_slots >= std::min<int64_t>(ck_chip, (int64_t)ctx->n_cus * LANE_CK_WAVES_PER_CU) / 2 &&
+                               ctx->ws_limit - grp_slots * ck_region - grp_left_area >= (int64_t)sizeof(DpRecord) * kLaneGroupMinPairs &&
+                               n >= kLaneGroupMinPairs;
+    const int64_t per_pair = lane_ck || group_regions ? (int64_t)sizeof(DpRecord) // (+ fixed_bytes per half: the persistent grid's regions)
                              : use_lane ? ((score_only ? 0 : stride_words * 4) + lane_scratch_bytes(max_tl, max_ql, rows)) / 128 + 1 + (int64_t)sizeof(DpRecord)
                              : auto_group ? std::max(std::max(stride_words * 2, stride32_words * 4), lane_group ? (lane_group_stride * 4 + lane_ck_scratch_bytes(max_tl, max_ql)) / 128 + 1 : 0) + (int64_t)sizeof(DpRecord)
                                           : (score_only ? 0 : stride_words * 4 / (use16 ? 2 : 1)) + (int64_t)sizeof(DpRecord);
@@ -515,8 +530,9 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
     // alternate between two streams and two halves, so that the last waves of one launch (the launch's tail, 1-2 ms of a
     // 14 ms chunk with most CUs idle) run beside the first waves of the next
     const bool dual_ok = fused_walk && hooks;
-    const int64_t ws_whole = fused_walk && !dual_ok ? ctx->ws_limit : ctx->ws_limit / 2;
-    const int64_t fixed_max = lane_ck ? ck_slots_max * ck_region : 0; // (a chunk of fewer tiles than slots needs fewer regions: fixed_bytes below)
+    // (a sorted chunk sized by slots: one buffer as well -- its bulk walks inside its fill kernel, its left-overs are few)
+    const int64_t ws_whole = (fused_walk && !dual_ok) || group_regions ? ctx->ws_limit : ctx->ws_limit / 2;
+    const int64_t fixed_max = lane_ck ? ck_slots_max * ck_region : group_regions ? grp_slots * ck_region + grp_left_area : 0; // (a chunk of fewer tiles than slots needs fewer regions: fixed_bytes below)
     const int64_t ws_part = ws_whole - fixed_max;
     if (per_pair * gran > ws_part) {
         char msg[192];
@@ -561,7 +577,7 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
         // long in total, 75.9 ms against 20.6, and hid behind nothing: 94.4 ms per pass against 72.5)
     }
     chunk = std::min<int64_t>(chunk, n);
-    const bool overlap = !fused_walk && n > chunk;
+    const bool overlap = !fused_walk && !group_regions && n > chunk;
     const bool dual = dual_ok && n > chunk;
     const int halves = overlap || dual ? 2 : 1;
     P.use_lane = use_lane;
@@ -587,8 +603,13 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
     P.stride_words = stride_words;
     P.stride32_words = stride32_words;
     P.per_pair = per_pair;
-    P.lane_slots = lane_ck ? std::min<int64_t>(ck_slots_max, (chunk + 127) / 128) : lane_group ? std::min<int64_t>(ck_chip, (chunk + 127) / 128) : 0;
-    P.fixed_bytes = lane_ck ? P.lane_slots * ck_region : 0;
+    P.lane_slots = lane_ck ? std::min<int64_t>(ck_slots_max, (chunk + 127) / 128) : group_regions ? std::min<int64_t>(grp_slots, (chunk + 127) / 128)
+                   : lane_group ? std::min<int64_t>(ck_chip, (chunk + 127) / 128) : 0;
+    P.fixed_bytes = lane_ck ? P.lane_slots * ck_region : group_regions ? P.lane_slots * ck_region + grp_left_area : 0;
+    P.group_regions = group_regions;
+    P.left_area = group_regions ? grp_left_area : 0;
+    P.left_pair16 = stride_words * 2;
+    P.left_pair32 = stride32_words * 4;
     P.chunk = chunk;
     P.pyramid = pyramid;
     P.pyr_unit = pyr_unit;
@@ -790,12 +811,15 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int h = 0; h < halves; ++h) {
         const size_t regions = (size_t)(lane_ck ? lane_slots : use_lane ? (chunk + 127) / 128 : use16 ? (chunk + 1) / 2 : chunk);
-        if (auto_group)
+        if (P.group_regions)
+            HIP_TRY(ctx, ctx->tb[h].reserve((size_t)lane_slots * (size_t)lane_group_stride * 4 + (size_t)P.left_area + 64));
+        else if (auto_group)
             HIP_TRY(ctx, ctx->tb[h].reserve((size_t)chunk * (size_t)(per_pair - (int64_t)sizeof(DpRecord)) + 64));
         else if (!score_only)
             HIP_TRY(ctx, ctx->tb[h].reserve(regions * (size_t)stride_words * 4));
         if (use_lane) HIP_TRY(ctx, ctx->bnd[h].reserve(regions * (size_t)(lane_ck ? lane_ck_scratch_bytes(max_tl, max_ql) : lane_scratch_bytes(max_tl, max_ql, rows))));
-        if (lane_group) HIP_TRY(ctx, ctx->bnd[h].reserve((size_t)(chunk / 128 + 1) * (size_t)lane_ck_scratch_bytes(max_tl, max_ql)));
+        if (lane_group) // (the persistent grid's staging areas: one per wave slot)
+            HIP_TRY(ctx, ctx->bnd[h].reserve((size_t)(P.group_regions ? lane_slots + 1 : chunk / 128 + 1) * (size_t)lane_ck_scratch_bytes(max_tl, max_ql)));
         HIP_TRY(ctx, ctx->rec[h].reserve((size_t)chunk * sizeof(DpRecord)));
     }
     if (lane_slots > 0 && !ctx->tile_ctr.p) {
@@ -853,12 +877,14 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             DpRecord *rec;
             const int64_t *dest;
             int rows, wpb, sps_cap;
-        } parts[3];
-        int n_parts = 0;
+            bool tb_now; // its traceback follows its fill at once, on the fill stream: the next part uses the same workspace area
+        };
+        std::vector<Part> parts;
+        parts.reserve(8);
         uint32_t *const tb_base = static_cast<uint32_t *>(ctx->tb[h].p);
         DpRecord *const rec_base = static_cast<DpRecord *>(ctx->rec[h].p);
         if (!auto_group) {
-            parts[n_parts++] = Part{use_lane, use16, first, count, tset, qset, tb_base, stride_words, rec_base, nullptr, rows, wpb, sps_cap};
+            parts.push_back(Part{use_lane, use16, first, count, tset, qset, tb_base, stride_words, rec_base, nullptr, rows, wpb, sps_cap, false});
         } else {
             // the index arrays of this half were last read by the kernels of chunk k-2
             if (overlap && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->h2d, ctx->tb_done[h], 0));
@@ -956,14 +982,28 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             const int64_t nl = lane_group && rg.n_lane >= std::max<int64_t>(lane_group_min, 128) ? rg.n_lane : 0;
             uint32_t *const tb16 = tb_base + (size_t)std::min<int64_t>(nl / 128, lane_slots) * (size_t)lane_group_stride; // (behind the lane part's regions: one per wave slot)
             lane_pairs_last = nl;
-            if (nl > 0) parts[n_parts++] = Part{true, false, 0, nl, ts, qs, tb_base, lane_group_stride, rec_base, rg.d_dest, 32, 4, max_ql};
-            if (ng > nl) parts[n_parts++] = Part{false, true, nl, ng - nl, ts, qs, tb16, stride_words, rec_base + nl, rg.d_dest, 16, wpb16, sps_for(max_ql)};
-            if (count > ng)
-                parts[n_parts++] = Part{false, false, ng, count - ng, ts, qs, tb16 + (size_t)((ng - nl) / 2) * (size_t)stride_words, stride32_words,
-                                        rec_base + ng, rg.d_dest, 16, pick_waves_per_block(sps32, 16), sps32};
+            if (nl > 0) parts.push_back(Part{true, false, 0, nl, ts, qs, tb_base, lane_group_stride, rec_base, rg.d_dest, 32, 4, max_ql, false});
+            if (P.group_regions) {
+                // what is left over, in pieces of what its area holds (one piece each wherever the batch's geometries are few): the packed
+                // kernel's pieces in the area's first half, the int32 kernel's in its second; a piece's traceback runs before the
+                // next piece's fill overwrites the flags
+                uint32_t *const area16 = tb_base + (size_t)lane_slots * (size_t)lane_group_stride, *const area32 = area16 + (size_t)(P.left_area / 2 / 4);
+                const int64_t cap16 = std::max<int64_t>(8, P.left_area / 2 / P.left_pair16 / 8 * 8), cap32 = std::max<int64_t>(4, P.left_area / 2 / P.left_pair32 / 4 * 4);
+                for (int64_t f = nl; f < ng; f += cap16)
+                    parts.push_back(Part{false, true, f, std::min(cap16, ng - f), ts, qs, area16, stride_words, rec_base + f, rg.d_dest, 16, wpb16, sps_for(max_ql), f + cap16 < ng});
+                for (int64_t f = ng; f < count; f += cap32)
+                    parts.push_back(Part{false, false, f, std::min(cap32, count - f), ts, qs, area32, stride32_words, rec_base + f, rg.d_dest, 16,
+                                         pick_waves_per_block(sps32, 16), sps32, f + cap32 < count});
+            } else {
+                if (ng > nl) parts.push_back(Part{false, true, nl, ng - nl, ts, qs, tb16, stride_words, rec_base + nl, rg.d_dest, 16, wpb16, sps_for(max_ql), false});
+                if (count > ng)
+                    parts.push_back(Part{false, false, ng, count - ng, ts, qs, tb16 + (size_t)((ng - nl) / 2) * (size_t)stride_words, stride32_words,
+                                         rec_base + ng, rg.d_dest, 16, pick_waves_per_block(sps32, 16), sps32, false});
+            }
         }
-        DpArgs das[3];
-        TbArgs tas[3];
+        const int n_parts = (int)parts.size();
+        std::vector<DpArgs> das((size_t)n_parts);
+        std::vector<TbArgs> tas((size_t)n_parts);
         int64_t n_blocks = 0;
         for (int i = 0; i < n_parts; ++i) {
             const Part &pt = parts[i];
@@ -1079,6 +1119,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                          : coop16 ? launch_dp_coop16(das[i], coop_waves, fs) : coop_waves ? launch_dp_coop(das[i], coop_waves, fs) : launch_dp(das[i], pt.wpb, pt.rows, fs));
             if (das[i].tile_ctr) // the persistent grid is on its way: its counter will stand `tiles` further on when it ends
                 ctx->tile_total[das[i].tile_ctr - static_cast<unsigned *>(ctx->tile_ctr.p)] += (unsigned)((pt.count + 127) / 128);
+            if (pt.tb_now) HIP_TRY(ctx, launch_traceback(tas[i], fs));
         }
         if (pe[1]) HIP_TRY(ctx, hipEventRecord(pe[1], fs));
         if (overlap) {
@@ -1087,7 +1128,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         }
         if (pe[2]) HIP_TRY(ctx, hipEventRecord(pe[2], tb_stream));
         for (int i = 0; i < n_parts && !fused_walk; ++i) {
-            if (das[i].grouped) continue; // walked inside its fill kernel
+            if (das[i].grouped || parts[i].tb_now) continue; // walked inside its fill kernel / behind its fill already
             HIP_TRY(ctx, score_only ? launch_scores_only(tas[i], tb_stream) : tas[i].packed16 == 6 ? launch_strip_ck_walk(tas[i], max_tl, max_ql, tb_stream) : launch_traceback(tas[i], tb_stream));
         }
         if (pe[3]) HIP_TRY(ctx, hipEventRecord(pe[3], tb_stream));

@@ -870,6 +870,56 @@ def test_sorted_chunks_run_big_geometries_on_the_lane_kernel(monkeypatch, reside
     a.close()
 
 
+def test_a_sorted_device_batch_is_one_chunk_sized_by_wave_slots(monkeypatch):
+    """Round 4: a device-resident batch of mixed geometries, large enough for lane launches, is ONE chunk in an 8 GiB workspace -- the
+    lane kernel's persistent grid keeps a region per wave slot, the left-over pairs (here: many, a third of the batch has odd
+    geometries) go through the packed and int32 kernels in pieces of what their area holds.  Identical to the per-pair sizing of
+    round 3 (itself checked against the reference's path above), with the area made small enough for several pieces, and to the
+    CPU restatement on a sample."""
+    import torch
+    from mgl_amd import device_batch, synth
+
+    rng = synth.rng_for(404)
+    n = 260_000   # (two thirds in whole waves of one geometry: above the 131 072 from which a chunk's bulk gets its own lane launch)
+    genome = synth.random_genome(rng, 1 << 19)
+    starts = rng.integers(0, len(genome) - 300, size=n)
+    tls = rng.choice([256, 256, 256, 200], size=n)
+    qls = rng.choice([150, 150, 125, 101], size=n)
+    odd = rng.random(n) < 0.33
+    qls[odd] = rng.integers(1, 151, size=int(odd.sum()))
+    tls[odd] = rng.integers(150, 257, size=int(odd.sum()))
+    reads = synth.illumina_reads(rng, genome, starts + 30, read_len=150, sub=0.02, ins=0.004, dele=0.004)
+    tseqs = [genome[s: s + tl].tobytes() for s, tl in zip(starts, tls)]
+    qseqs = [r[:q].tobytes() for r, q in zip(reads, qls)]
+    td, toff = sw.concat(tseqs)
+    qd, qoff = sw.concat(qseqs)
+    a = sw.MicrosoftSmithWaterman(0)
+    a.set_workspace(8 << 30)
+    outs = []
+    for env in ({}, {"MGL_SW_DEBUG_LEFT_AREA": str(8 << 20)}, {"MGL_SW_DEBUG_GROUP_REGIONS": "0"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        b = device_batch.from_host(td, toff, qd, qoff, "cuda:0", cigar_stride=128)
+        b.run(a, overhang_strategy=ol.SOFTCLIP)
+        torch.cuda.synchronize()
+        tm = a.timing()
+        assert int((b.status != 0).sum()) == 0
+        if "MGL_SW_DEBUG_GROUP_REGIONS" not in env:
+            assert tm.dp_launches == 1 and tm.fill_kernel == 7, "one chunk, its bulk on the lane kernel"
+        else:
+            assert tm.dp_launches > 1, "sized per pair: several chunks in 8 GiB (the last one too small for a lane launch)"
+        outs.append((b.offsets.cpu().numpy(), b.scores.cpu().numpy(), b.cigars.cpu().numpy(), b.cigar_len.cpu().numpy()))
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    for o in outs[1:]:
+        assert all((x == y).all() for x, y in zip(outs[0], o))
+    sample = rng.choice(n, size=4000, replace=False)
+    woff, wsc, wcg = ol.oracle_align_batch([tseqs[k] for k in sample], [qseqs[k] for k in sample], (200, -150, 260, 11), ol.SOFTCLIP, nthreads=8)
+    cg = b.cigar_strings()
+    assert (outs[0][0][sample] == woff).all() and (outs[0][1][sample] == wsc).all() and all(cg[k] == wcg[j] for j, k in enumerate(sample))
+    a.close()
+
+
 def test_grouping_helper_feeds_the_indexed_entry(aligner):
     """What a C caller does with variable-length reads: mgl_sw_group_by_geometry on the host, then the grouped part through
     mgl_sw_align_batch_device_indexed with MGL_SW_FLAG_GROUPED_GEOMETRY (packed kernel) and the rest without the flag."""

@@ -136,7 +136,14 @@ def test_mixed_geometries_are_sorted_by_the_library():
     assert dev.sorted_by_library == 1 and dev.fill_kernel == LANE16_CK and dev.precision_bits == 16, "whole waves of one geometry: the lane kernel"
     host = plan(n=4_000_000, max_tl=256, max_ql=150, parameters=GATK, entry=1, workspace=ws)     # host buffers
     assert host.sorted_by_library == 2 and host.workspace_halves == 2 and host.fill_kernel == LANE16_CK
-    tight = plan(n=4_000_000, max_tl=256, max_ql=150, parameters=GATK)                           # 4 GiB: chunks below the lane kernel's crossover
+    # round 4: a sorted chunk is sized by the lane kernel's wave slots (a region each) + an area for the left-over pairs + a record per pair,
+    # not by 19 KB of left-over traceback per pair: ONE chunk in 8 GiB (round 3: 21) and in 4 GiB
+    for w, slots in ((8 << 30, 2048), (4 << 30, (3 << 30) // REGION_256x150)):
+        p = plan(n=4_000_000, max_tl=256, max_ql=150, parameters=GATK, workspace=w)
+        assert (p.sorted_by_library, p.fill_kernel, p.chunks, p.chunk_pairs, p.workspace_halves) == (1, LANE16_CK, 1, 4_000_000, 1)
+        assert p.resident_waves == slots and p.workspace_bytes <= w and p.workspace_bytes_per_pair == 32
+    assert (dev.chunks, dev.workspace_halves) == (1, 1)
+    tight = plan(n=4_000_000, max_tl=256, max_ql=150, parameters=GATK, workspace=2 << 30)        # 2 GiB: fewer than half the chip's slots -- chunks below the lane kernel's crossover
     assert tight.sorted_by_library == 1 and tight.fill_kernel == DP16
     few = plan(n=500, max_tl=256, max_ql=150, parameters=GATK)
     assert few.sorted_by_library == 0 and few.fill_kernel == SMALL, "one wave per pair needs no common geometry"
@@ -156,7 +163,7 @@ def test_a_promise_of_blocks_of_eight_does_not_keep_a_large_batch_from_the_lane_
     assert (big.chunk_pairs, big.chunks, big.workspace_halves) == (none.chunk_pairs, none.chunks, none.workspace_halves)
     small = plan(n=100_000, max_tl=256, max_ql=150, parameters=GATK, flags=grouped, workspace=ws)
     assert small.fill_kernel == DP16 and small.sorted_by_library == 0
-    tight = plan(n=4_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=grouped)     # 4 GiB: chunks below the lane launches' threshold
+    tight = plan(n=4_000_000, max_tl=256, max_ql=150, parameters=GATK, flags=grouped, workspace=2 << 30)     # 2 GiB: chunks below the lane launches' threshold
     assert tight.fill_kernel == DP16 and tight.sorted_by_library == 0
 
 
