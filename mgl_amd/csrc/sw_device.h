@@ -230,7 +230,7 @@ __host__ __device__ inline int64_t strip16_scratch_bytes(int ql, int waves) { re
 // K strips, all columns -- [band 1 .. NB - 1][column 0 .. ql] -- and {H, F} of every row at the band's checkpoint columns
 // j = STRIP_CK_COLS * cc - CPS * K * band (a staircase: the strips of a band reach such a column K * band steps later than strip 0
 // does) -- [cc][row 0 .. tl]
-constexpr int STRIP_CK_COLS = 256;
+constexpr int STRIP_CK_COLS = 128;
 __host__ __device__ inline int strip16_ck_bands(int tl, int rows, int k) { return (tl + rows * k - 1) / (rows * k); }
 __host__ __device__ inline int strip16_ck_ccs(int tl, int ql, int rows, int k) { return (ql + STRIP_CPS * k * strip16_ck_bands(tl, rows, k)) / STRIP_CK_COLS + 2; }
 __host__ __device__ inline int strip16_ck_row_stride(int ql) { return (ql + 4) & ~3; } // entries per kept row: column j at index j - 1, rows 32-byte aligned
@@ -252,9 +252,17 @@ __host__ __device__ inline void strip16_unpack(int v, int bits, int &h, int &g)
     h = v >> bits;
     g = h - (v & ((1 << bits) - 1));
 }
+// The checkpoint columns (round 4) are kept as the strips hold them: one dword per row, {H, F} as the 16-bit values of the strip's registers
+// (one v_perm_b32 in the fill where converting both to true scores and packing them took seven instructions per row), and the strip's
+// baseline once per checkpoint column and strip: value + baseline = score + (row + column) e, the walk's own representation.
+// Per pair, in dwords: the kept rows [band][column] (one dword per entry where they pack, else two) | the checkpoints [cc][row 0 .. tl] |
+// their baselines [cc][strip].
+__host__ __device__ inline int strip16_ck_strips(int tl, int rows) { return (tl + rows - 1) / rows + 1; }
+__host__ __device__ inline int64_t strip16_ck_off_cols(int tl, int ql, int rows, int k, int pack_bits) { return (int64_t)strip16_ck_bands(tl, rows, k) * strip16_ck_row_stride(ql) * (pack_bits ? 1 : 2); }
+__host__ __device__ inline int64_t strip16_ck_off_base(int tl, int ql, int rows, int k, int pack_bits) { return strip16_ck_off_cols(tl, ql, rows, k, pack_bits) + (int64_t)strip16_ck_ccs(tl, ql, rows, k) * (tl + 1); }
 __host__ __device__ inline int64_t strip16_ck_words(int tl, int ql, int rows, int k, int pack_bits = 0)
 {
-    return ((((int64_t)strip16_ck_bands(tl, rows, k) * strip16_ck_row_stride(ql) + (int64_t)strip16_ck_ccs(tl, ql, rows, k) * (tl + 1)) + 3) & ~(int64_t)3) * (pack_bits ? 1 : 2);
+    return (strip16_ck_off_base(tl, ql, rows, k, pack_bits) + (int64_t)strip16_ck_ccs(tl, ql, rows, k) * strip16_ck_strips(tl, rows) + 3) & ~(int64_t)3;
 }
 int strip16_lds_bytes(int max_ql, int waves);
 int strip16_lds_bytes_codes(int max_ql, int waves); // the query as one table dword per column (DpArgs::strip_codes)

@@ -29,7 +29,8 @@
 // are written for (67 MB per pair).  In this form the fill runs the score-only column code (9 instead of 17 instructions per two
 // cells) and keeps what sw_strip_ck_walk_kernel (sw_strip_walk.hip) needs to recompute the 60 x 256 blocks the path crosses: the
 // true scores {H, E} of the row below every band of K strips, per column, and {H, F} of every row at the band's checkpoint columns
-// (every STRIP_CK_COLS columns, at the step offset of the band so that all strips of a band save the SAME column): 8 MB per pair as packed entries (DpArgs::strip_pack), 16 as pairs of int32.
+// (every STRIP_CK_COLS = 128 columns, at the step offset of the band so that all strips of a band save the SAME column; a dword per row as the
+// strip holds it, and the strip's baseline): 10 MB per 10 kb pair with the rows as packed entries (DpArgs::strip_pack), 17 as pairs of int32.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -150,11 +151,13 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     constexpr int K = NOTB ? 64 / SR : 1; // (= a.strip_k: the host sets it so, launch_dp16_strip checks; a constant here: the divisions below are multiplications)
     int2 *const rows_rec = reinterpret_cast<int2 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words);
     const int row_stride = strip16_ck_row_stride(a.uni_ql);
-    int2 *const ck_rec = rows_rec + (size_t)strip16_ck_bands(a.uni_tl, SR, K) * row_stride;
+    // the checkpoint columns: a dword per row {H, F} as the strip holds them, and the strip's baseline per column (strip16_ck_words)
+    int *const ck_cols = reinterpret_cast<int *>(rows_rec) + strip16_ck_off_cols(a.uni_tl, a.uni_ql, SR, K, NOTB ? a.strip_pack : 0);
+    int *const ck_base = reinterpret_cast<int *>(rows_rec) + strip16_ck_off_base(a.uni_tl, a.uni_ql, SR, K, NOTB ? a.strip_pack : 0);
+    const int ck_strips = strip16_ck_strips(a.uni_tl, SR);
     // (a.strip_pack = B > 0: the same entries as one int32 each, H << B | (H - gap value): strip16_pack_bits)
     const int PB = NOTB ? a.strip_pack : 0;
     int *const rows_pk = reinterpret_cast<int *>(rows_rec);
-    int *const ck_pk = rows_pk + (size_t)strip16_ck_bands(a.uni_tl, SR, K) * row_stride;
     // (per step, below: bandA / bandB = the band of K strips a strip belongs to; rowoffA / rowoffB = that band's kept row as a 32-bit index off
     // the pair's uniform base; rowsA / rowsB = the strip whose last row is the row below a band -- and not the matrix's last rows: it writes that row)
 
@@ -341,46 +344,31 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
         }
         // ---- 4b. checkpoints (NOTB): a band's strips save the column they have just finished when it is one of the band's checkpoint
         // columns j = STRIP_CK_COLS cc - CPS K band -- strip g reaches it (g mod K) steps after the band's first strip, so the wave
-        // takes this branch on K of every 64 steps, a K-th of its lanes each time
+        // takes this branch on K of every 32 steps, a K-th of its lanes each time.  What is saved is the strip's registers as they are --
+        // a dword per row, {H, F} -- and its baseline: the walk computes in the same representation (sw_strip_walk.hip)
         if (NOTB) {
             constexpr int PER = STRIP_CK_COLS / CPS;
             const bool ckA = actA && ((cgA + 1 + K * bandA) % PER) == 0, ckB = actB && ((cgB + 1 + K * bandB) % PER) == 0;
             if (__builtin_amdgcn_ballot_w64(ckA || ckB)) {
                 if (ckA) {
-                    // (the row terms are made opaque: computed here, K of 64 steps, not hoisted out of the step loop -- hoisted, they were
-                    // a register per row for the whole loop, spilled in front of it and loaded back here)
-                    int i0 = i0A, ge = gext;
-                    asm volatile("" : "+v"(i0), "+s"(ge));
-                    const int j = CPS * (cgA + 1), cc = (cgA + 1 + K * bandA) / PER;
-                    int2 *const dst = ck_rec + (size_t)cc * (a.uni_tl + 1) + i0 + 1;
-                    int *const dpk = ck_pk + (size_t)cc * (a.uni_tl + 1) + i0 + 1;
-                    int un = base_a - (i0 + 1 + j) * ge; // row r: - r * ge on top
+                    int i0 = i0A;
+                    asm volatile("" : "+v"(i0)); // (opaque: the addresses are computed here, K of 32 steps, not hoisted out of the step loop)
+                    const int cc = (cgA + 1 + K * bandA) / PER;
+                    int *const dst = ck_cols + (size_t)cc * (a.uni_tl + 1) + i0 + 1;
 #pragma unroll
-                    for (int r = 0; r < SR; ++r, un -= ge)
-                        if (i0 + r < tl) {
-                            const int hv = lo16(h[r]) + un, fv = lo16(f[r]) + un - ge;
-                            if (PB)
-                                dpk[r] = strip16_pack(hv, fv, PB);
-                            else
-                                dst[r] = make_int2(hv, fv);
-                        }
+                    for (int r = 0; r < SR; ++r)
+                        if (i0 + r < tl) dst[r] = (int)__builtin_amdgcn_perm(f[r], h[r], 0x05040100u); // {H, F}: the low halves
+                    ck_base[(size_t)cc * ck_strips + gA] = base_a;
                 }
                 if (ckB) {
-                    int i0 = i0B, ge = gext;
-                    asm volatile("" : "+v"(i0), "+s"(ge));
-                    const int j = CPS * (cgB + 1), cc = (cgB + 1 + K * bandB) / PER;
-                    int2 *const dst = ck_rec + (size_t)cc * (a.uni_tl + 1) + i0 + 1;
-                    int *const dpk = ck_pk + (size_t)cc * (a.uni_tl + 1) + i0 + 1;
-                    int un = base_b - (i0 + 1 + j) * ge;
+                    int i0 = i0B;
+                    asm volatile("" : "+v"(i0));
+                    const int cc = (cgB + 1 + K * bandB) / PER;
+                    int *const dst = ck_cols + (size_t)cc * (a.uni_tl + 1) + i0 + 1;
 #pragma unroll
-                    for (int r = 0; r < SR; ++r, un -= ge)
-                        if (i0 + r < tl) {
-                            const int hv = hi16(h[r]) + un, fv = hi16(f[r]) + un - ge;
-                            if (PB)
-                                dpk[r] = strip16_pack(hv, fv, PB);
-                            else
-                                dst[r] = make_int2(hv, fv);
-                        }
+                    for (int r = 0; r < SR; ++r)
+                        if (i0 + r < tl) dst[r] = (int)__builtin_amdgcn_perm(f[r], h[r], 0x07060302u); // the high halves
+                    ck_base[(size_t)cc * ck_strips + gB] = base_b;
                 }
             }
         }

@@ -23,11 +23,20 @@ namespace mgl_sw_dev {
 namespace {
 
 constexpr int BC = STRIP_CK_COLS;     // columns per block
-constexpr int FW = (BC + 64) / 8;     // flag dwords per row: one nibble per STEP of the block's wavefront (columns + rows - 1 steps)
+constexpr int FW4 = (BC + 64 + 31) / 32 + 1; // uint4 entries per row of the flag array: one per 32 STEPS of the block's wavefront (columns + rows - 1 steps), + 1 against bank conflicts
 
-__device__ __forceinline__ int dpp_shr1(int lane0_value, int src) { return __builtin_amdgcn_update_dpp(lane0_value, src, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_shr1(int lane0_value, int src) { return __builtin_amdgcn_update_dpp(lane0_value, src, 0x138, 0xf, 0xf, false); } // wave_shr:1, lane 0 keeps lane0_value
+__device__ __forceinline__ int dpp_rol1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x134, 0xf, 0xf, false); }                                  // wave_rol:1: lane k takes lane k + 1's, lane 63 lane 0's
 __device__ __forceinline__ int border_of(int k, int gopen, int gext, bool indel) { return (indel && k > 0) ? -gopen - (k - 1) * gext : 0; } // sw.cpp:29-40,47-49
 
+// Round 4: the block's wavefront in the representation the fill kernels use -- every value carries + (i + j) e, so extending a gap costs
+// nothing and both new gaps start from the one H - (o - e) -- with its four decisions taken as the SIGN BITS of four differences, shifted
+// into four bit-plane accumulators by one v_alignbit_b32 each (a cell: 4 subtractions + 4 shifts where compare, select, shift and or took
+// 12), the kept row handed to lane 0 by rotating its 64 columns one lane per step (a readlane, a move and a DPP move per value before), the
+// query read as a dword per four steps, and no lane masked once the last row's lane has started: 22 instructions per step where there
+// were 38.  With the checkpoint columns every 128 columns instead of 256 (a block: 7 KB of flags in LDS instead of 11, so that 4 608 pairs'
+// waves are resident at once; its wavefront a third shorter) the walk kernel takes 9.4 ms per 4 608 pairs of 10 kb where it took 14.3.  The decisions compare values of ONE cell, all shifted alike: bit for
+// bit what the fill would have stored (sw.cpp:60-93).
 struct BlockMoves {
     // the pair
     const SeqSet *t, *q;
@@ -35,11 +44,13 @@ struct BlockMoves {
     int tl, ql, match, mismatch, gopen, gext;
     bool indel;
     int rbk, kcols;            // rows per band (K strips), CPS * K: how far a band's checkpoint columns lie before the band above's
-    const int2 *rows, *ck;     // what the fill kept (strip16_ck_words)
+    const int2 *rows;          // the rows the fill kept (strip16_ck_words) ...
     int pack;                  // ... as {H, gap value} pairs (0) or packed into one int32 each (strip16_pack_bits)
+    const int *ck_cols, *ck_base; // the checkpoint columns: a dword per row, {H, F} as 16-bit values of the strip's registers, and the strips' baselines per column
     int row_stride, tl_cap;    // entries per kept row (column j at j - 1), rows per checkpoint column
-    unsigned *flags;           // LDS: [64 rows][FW] dwords
-    unsigned char *qb;         // LDS: the block's query bases
+    int strip_rows, ck_strips; // rows per strip, baselines per checkpoint column
+    uint4 *flags;              // LDS: [64 rows][FW4]: the bit planes {F > diag, E > max(diag, F), E' opened, F' opened} of 32 steps each, step t of its 32 at bit 31 - t
+    unsigned char *qb;         // LDS: the block's query bases (BC + 8 bytes)
     int lane;
     // the block whose flags are in LDS: rows r0 + 1 .. imax, columns jl + 1 .. jr.  The walk only ever moves up and to the left, so a
     // block is computed up to the cell the walk enters it at and no further (on average half its columns and half its rows: the
@@ -47,6 +58,53 @@ struct BlockMoves {
     int cur_b = -1, cur_cc = -1, r0 = 0, jl = 0, jr = 0, imax = 0;
 
     __device__ __forceinline__ int cc_of(int b, int j) const { return (j - 1 + kcols * b) / BC; }
+    // {H[r0][j], E entering row r0 + 1 at column j} as the fill kept them (true scores)
+    __device__ __forceinline__ void top(int b, int j, int &h_, int &e_) const
+    {
+        if (b == 0) {
+            h_ = border_of(j, gopen, gext, indel);
+            e_ = h_ - gopen;
+        } else if (pack) {
+            strip16_unpack(reinterpret_cast<const int *>(rows)[(size_t)(b - 1) * row_stride + (j - 1)], pack, h_, e_);
+        } else {
+            const int2 v = rows[(size_t)(b - 1) * row_stride + (j - 1)];
+            h_ = v.x;
+            e_ = v.y;
+        }
+    }
+    // four steps of the wavefront.  MASKED: some lane has not reached its first column yet (it keeps what it holds); PLANES: the accumulators
+    template <bool MASKED>
+    __device__ __forceinline__ void steps4(const int s, const unsigned qw, const int tb_, const int match2, const int mismatch2, const int o_e, int &tops_h, int &tops_e,
+                                           int &hdiag, int &h_out, int &e_out, int &f, unsigned (&acc)[4]) const
+    {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            // what comes down from the row above: lane 0 from the kept row (its lane 0 holds this step's column), the others from the lane above's last step
+            const int hup = dpp_shr1(tops_h, h_out), e = dpp_shr1(tops_e, e_out);
+            tops_h = dpp_rol1(tops_h);
+            tops_e = dpp_rol1(tops_e);
+            const int diag = hdiag + ((int)((qw >> (8 * u)) & 0xffu) == tb_ ? match2 : mismatch2);
+            const int sm = max(diag, f);
+            const int hn = max(sm, e);
+            const int open = hn - o_e;
+            // the four decisions (sw.cpp:60-93) as sign bits: F > diag, E > max(diag, F), a new vertical gap wins (strictly), a new horizontal one
+            acc[0] = __builtin_amdgcn_alignbit(acc[0], (unsigned)(diag - f), 31);
+            acc[1] = __builtin_amdgcn_alignbit(acc[1], (unsigned)(sm - e), 31);
+            acc[2] = __builtin_amdgcn_alignbit(acc[2], (unsigned)(e - open), 31);
+            acc[3] = __builtin_amdgcn_alignbit(acc[3], (unsigned)(f - open), 31);
+            const int en = max(open, e), fn = max(open, f);
+            if (MASKED) {
+                const bool started = s + u >= lane;
+                h_out = started ? hn : h_out;
+                f = started ? fn : f;
+            } else {
+                h_out = hn;
+                f = fn;
+            }
+            e_out = en; // (before a lane's first column: read by nobody -- the lane below starts a step later)
+            hdiag = hup;
+        }
+    }
     // flags of rows rbk b + 1 .. and columns jl + 1 .. jr into LDS
     __device__ void compute(int b, int cc, int i_in, int j_in)
     {
@@ -59,95 +117,86 @@ struct BlockMoves {
         const int nr = imax - r0, nc = jr - jl;
         const int i = r0 + lane + 1;                     // this lane's row
         const bool row_ok = lane < nr;
+        const int ge = gext;
         __builtin_amdgcn_wave_barrier();
         for (int x = lane; x < nc; x += 64) qb[x] = (unsigned char)q->at(q0, jl + x);
         const int tb_ = row_ok ? t->at(t0, i - 1) : -1;
-        // left border: H[i][jl], F entering column jl + 1
+        // left border: H[i][jl], F entering column jl + 1 (rows past the block's last: anything -- they feed nothing that is read)
         int hleft, f;
+        // (every value + (row + column) e from here on: the representation the checkpoints are kept in)
         if (jl == 0) {
-            hleft = border_of(i, gopen, gext, indel);
-            f = hleft - gopen;
+            hleft = border_of(i, gopen, ge, indel);
+            f = hleft - gopen + (i + 1) * ge;
+            hleft += i * ge;
         } else {
-            if (pack) {
-                strip16_unpack(row_ok ? reinterpret_cast<const int *>(ck)[(size_t)cc * (tl_cap + 1) + i] : 0, pack, hleft, f);
-            } else {
-                const int2 v = row_ok ? ck[(size_t)cc * (tl_cap + 1) + i] : make_int2(0, 0);
-                hleft = v.x;
-                f = v.y;
-            }
+            const int v = row_ok ? ck_cols[(size_t)cc * (tl_cap + 1) + i] : 0;
+            const int base = row_ok ? ck_base[(size_t)cc * ck_strips + (i - 1) / strip_rows] : 0;
+            hleft = (int)(short)(v & 0xffff) + base;
+            f = (v >> 16) + base;
         }
         // H[r0][jl]: the first diagonal of lane 0
-        auto top = [&](int j, int &h_, int &e_) { // {H[r0][j], E entering row r0 + 1 at column j}
-            if (b == 0) {
-                h_ = border_of(j, gopen, gext, indel);
-                e_ = h_ - gopen;
-            } else {
-                if (pack) {
-                    strip16_unpack(reinterpret_cast<const int *>(rows)[(size_t)(b - 1) * row_stride + (j - 1)], pack, h_, e_);
-                } else {
-                    const int2 v = rows[(size_t)(b - 1) * row_stride + (j - 1)];
-                    h_ = v.x;
-                    e_ = v.y;
-                }
-            }
-        };
-        int corner = jl == 0 ? border_of(r0, gopen, gext, indel) : 0, dummy = 0;
-        if (jl > 0) top(jl, corner, dummy);
+        int corner = jl == 0 ? border_of(r0, gopen, ge, indel) : 0, dummy = 0;
+        if (jl > 0) top(b, jl, corner, dummy);
+        corner += (r0 + jl) * ge;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         // hdiag: H of the row above at the column before this lane's current one (the diagonal input)
         int hdiag = dpp_shr1(corner, hleft); // lane l: H[i-1][jl] = the lane above's left border; lane 0: the corner
         int h_out = hleft, e_out = 0;        // what this lane handed down in its last step
-        const int steps = nc + nr - 1;
-        int tops_h[2] = {0, 0}, tops_e[2] = {0, 0}; // the kept row, 64 columns per fetch, one fetch ahead
+        const int steps = (nc + nr - 1 + 3) & ~3; // (whole groups of four: the steps past the last compute cells nobody reads)
+        // the kept row above the block, 64 columns per fetch (lane k: column jl + 1 + s0 + k), one fetch ahead
         auto fetch = [&](int s0, int &h_, int &e_) {
             const int j = jl + 1 + s0 + lane;
-            if (j <= jr) top(j, h_, e_);
-        };
-        fetch(0, tops_h[0], tops_e[0]);
-        const int gopen_ = gopen, gext_ = gext, match_ = match, mismatch_ = mismatch;
-        for (int s0 = 0; s0 < steps; s0 += 64) {
-            fetch(s0 + 64, tops_h[1], tops_e[1]);
-            for (int s8 = s0; s8 < min(s0 + 64, steps); s8 += 8) {
-                unsigned acc = 0;
-#pragma unroll
-                for (int ds = 0; ds < 8; ++ds) {
-                    const int s = s8 + ds, c = s - lane; // this lane's column within the block, 0-based (steps past the last: idle for every lane)
-                    // what comes down from the row above: lane 0 from the kept row (column s), the others from the lane above's last step
-                    const int l0h = __builtin_amdgcn_readlane(tops_h[0], s & 63), l0e = __builtin_amdgcn_readlane(tops_e[0], s & 63);
-                    const int hup = dpp_shr1(l0h, h_out), e = dpp_shr1(l0e, e_out);
-                    const bool active = row_ok && (unsigned)c < (unsigned)nc;
-                    const int sub = (int)qb[min(max(c, 0), BC - 1)] == tb_ ? match_ : mismatch_;
-                    const int diag = hdiag + sub;
-                    const unsigned dF = f > diag;
-                    const int sm = max(diag, f);
-                    const unsigned dE = e > sm;
-                    const int hn = max(sm, e);
-                    const int open = hn - gopen_, ee = e - gext_, fe = f - gext_;
-                    const unsigned eo = open > ee, fo = open > fe; // a new gap wins only strictly (sw.cpp:73-93)
-                    e_out = active ? max(open, ee) : e_out;
-                    f = active ? max(open, fe) : f;
-                    h_out = active ? hn : h_out;
-                    acc |= (dF | (dE << 1) | (eo << 2) | (fo << 3)) << (4 * ds);
-                    hdiag = hup;
-                }
-                flags[lane * FW + (s8 >> 3)] = acc; // (the nibbles of idle steps are never read)
+            h_ = e_ = 0;
+            if (j <= jr) {
+                top(b, j, h_, e_);
+                h_ += (r0 + j) * ge;
+                e_ += (r0 + 1 + j) * ge;
             }
-            tops_h[0] = tops_h[1];
-            tops_e[0] = tops_e[1];
+        };
+        int tops_h, tops_e, next_h, next_e;
+        fetch(0, tops_h, tops_e);
+        const int match2 = match + 2 * ge, mismatch2 = mismatch + 2 * ge, o_e = gopen - ge;
+        // this lane's query bases of four steps: bytes s - lane .. + 3 of the block's, out of two aligned dwords
+        const unsigned *const qd = reinterpret_cast<const unsigned *>(qb);
+        const unsigned qsh = (unsigned)(-lane) & 3u;
+        auto qword = [&](int s) { return qd[min(max(((s - lane) >> 2) + 1, 0), BC / 4 + 1)]; }; // the dword behind the one that holds byte s - lane
+        unsigned q_lo = qd[min(max((0 - lane) >> 2, 0), BC / 4 + 1)], q_hi = qword(0);
+        unsigned acc[4] = {0u, 0u, 0u, 0u};
+        const int ramp = min(steps, (min(nr, 64) + 3) & ~3); // from here on every lane that owns a row has started
+        for (int s0 = 0; s0 < steps; s0 += 64) {
+            fetch(s0 + 64, next_h, next_e);
+            const int s_end = min(s0 + 64, steps);
+            for (int s = s0; s < s_end; s += 4) {
+                const unsigned qw = __builtin_amdgcn_alignbyte(q_hi, q_lo, qsh);
+                q_lo = q_hi;
+                q_hi = qword(s + 4);
+                if (s < ramp)
+                    steps4<true>(s, qw, tb_, match2, mismatch2, o_e, tops_h, tops_e, hdiag, h_out, e_out, f, acc);
+                else
+                    steps4<false>(s, qw, tb_, match2, mismatch2, o_e, tops_h, tops_e, hdiag, h_out, e_out, f, acc);
+                if (((s + 4) & 31) == 0) flags[lane * FW4 + (s >> 5)] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+            }
+            tops_h = next_h;
+            tops_e = next_e;
+        }
+        if (steps & 31) { // the last, partial group of 32 steps: its first step to bit 31 like everywhere
+            const int sh = 32 - (steps & 31);
+            flags[lane * FW4 + (steps >> 5)] = make_uint4(acc[0] << sh, acc[1] << sh, acc[2] << sh, acc[3] << sh);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
-    __device__ __forceinline__ unsigned cell(int i, int j)
+    // one decision of cell (i, j): plane 0 F > diag, 1 E > max(diag, F), 2 E' opened, 3 F' opened
+    __device__ __forceinline__ unsigned bit(int i, int j, int plane)
     {
         const int b = (i - 1) / rbk, cc = cc_of(b, j);
         if (b != cur_b || cc != cur_cc || i > imax || j > jr) compute(b, cc, i, j);
         const int l = i - r0 - 1, st = (j - jl - 1) + l; // row of the block, step of its wavefront
-        return (flags[l * FW + (st >> 3)] >> (4 * (st & 7))) & 15u;
+        return (reinterpret_cast<const unsigned *>(flags)[(l * FW4 + (st >> 5)) * 4 + plane] >> (31 - (st & 31))) & 1u;
     }
     // the number of consecutive diagonal moves from (i, j) inside the block that holds it, up to 64: lane k looks at the flags of cell
-    // (i - k, j - k) -- its own dword of the LDS array -- and one ballot finds where the run ends.  An ONT-style path is a diagonal broken
+    // (i - k, j - k) -- its own entry of the LDS array -- and one ballot finds where the run ends.  An ONT-style path is a diagonal broken
     // by an indel every ten cells or so: the walk takes a run per look instead of a cell per look (every look is a dependent LDS read).
     __device__ __forceinline__ int diag_run(int i, int j)
     {
@@ -157,7 +206,8 @@ struct BlockMoves {
         bool is_diag = false;
         if (ii > r0 && jj > jl) {
             const int l = ii - r0 - 1, st = (jj - jl - 1) + l;
-            is_diag = ((flags[l * FW + (st >> 3)] >> (4 * (st & 7))) & 3u) == 0u; // neither F > diag nor E > max(diag, F): sw.cpp:60-62
+            const uint2 w = reinterpret_cast<const uint2 *>(flags)[(l * FW4 + (st >> 5)) * 2];
+            is_diag = (((w.x | w.y) >> (31 - (st & 31))) & 1u) == 0u; // neither F > diag nor E > max(diag, F): sw.cpp:60-62
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(is_diag);
         return m == ~0ull ? 64 : (int)__builtin_ctzll(~m);
@@ -165,15 +215,14 @@ struct BlockMoves {
     // +k rows up, -k columns left, 0 diagonal: what the reference stores (sw.cpp:60-71); run lengths as TbView::vrun / hrun
     __device__ __forceinline__ int at(int i, int j)
     {
-        const unsigned c = cell(i, j);
-        if (c & 2u) {
+        if (bit(i, j, 1)) { // E > max(diag, F): up, through the cells that extended the gap
             int n = 1;
-            for (int r = i - 1; r >= 1 && !(cell(r, j) & 4u); --r) ++n;
+            for (int r = i - 1; r >= 1 && !bit(r, j, 2); --r) ++n;
             return n;
         }
-        if (c & 1u) {
+        if (bit(i, j, 0)) { // F > diag: left
             int n = 1;
-            for (int k = j - 1; k >= 1 && !(cell(i, k) & 8u); --k) ++n;
+            for (int k = j - 1; k >= 1 && !bit(i, k, 3); --k) ++n;
             return -n;
         }
         return 0;
@@ -184,8 +233,8 @@ struct BlockMoves {
 
 __global__ __launch_bounds__(64) void sw_strip_ck_walk_kernel(const TbArgs a, const int tl_cap, const int ql_cap)
 {
-    __shared__ unsigned flags[64 * FW];
-    __shared__ unsigned char qb[BC];
+    __shared__ uint4 flags[64 * FW4];
+    __shared__ __attribute__((aligned(16))) unsigned char qb[BC + 16];
     const int lane = threadIdx.x;
     const int64_t slot = blockIdx.x;
     const int64_t p = a.first + slot;
@@ -219,9 +268,10 @@ __global__ __launch_bounds__(64) void sw_strip_ck_walk_kernel(const TbArgs a, co
     mv.rows = reinterpret_cast<const int2 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words);
     mv.row_stride = strip16_ck_row_stride(ql_cap);
     mv.pack = a.strip_pack;
-    // (packed entries are one int32 each: the checkpoints start half as far in)
-    mv.ck = a.strip_pack ? reinterpret_cast<const int2 *>(reinterpret_cast<const int *>(mv.rows) + (size_t)strip16_ck_bands(tl_cap, a.strip_rows, a.strip_k) * mv.row_stride)
-                         : mv.rows + (size_t)strip16_ck_bands(tl_cap, a.strip_rows, a.strip_k) * mv.row_stride;
+    mv.ck_cols = reinterpret_cast<const int *>(mv.rows) + strip16_ck_off_cols(tl_cap, ql_cap, a.strip_rows, a.strip_k, a.strip_pack);
+    mv.ck_base = reinterpret_cast<const int *>(mv.rows) + strip16_ck_off_base(tl_cap, ql_cap, a.strip_rows, a.strip_k, a.strip_pack);
+    mv.ck_strips = strip16_ck_strips(tl_cap, a.strip_rows);
+    mv.strip_rows = a.strip_rows;
     mv.tl_cap = tl_cap;
     mv.flags = flags;
     mv.qb = qb;

@@ -1,10 +1,12 @@
 #!/bin/bash
-# round 4: does the walk of one chunk hide under the fill of the next now that the 20-row kernel leaves registers for a walk wave per SIMD?
+# round 4: the long-read suites and the 10 kb / 16 kb rates after the walk kernel's rewrite
 set -o pipefail
-O=gpurun_out/${1:-r04_overlap}; mkdir -p $O
+O=gpurun_out/${1:-r04_walk}; mkdir -p $O
+timeout -k 10 800 python -m pytest tests -x -q -m gpu -k "long or strip" > $O/tests.log 2>&1; rc=$?; echo "long tests rc=$rc" | tee -a $O/summary.txt; tail -2 $O/tests.log | tee -a $O/summary.txt
+[ $rc -eq 0 ] || exit 1
+timeout -k 10 400 python scripts/long_fuzz.py > $O/fuzz.log 2>&1; rc=$?; echo "long fuzz rc=$rc" | tee -a $O/summary.txt; tail -2 $O/fuzz.log | cut -c1-300 | tee -a $O/summary.txt
+[ $rc -eq 0 ] || exit 1
 run() { label=$1; shift; echo "== $label" | tee -a $O/summary.txt; env "$@" 2>&1 | grep -E "pairs of|GCUPS" | tee -a $O/summary.txt; }
-run "10 kb, 2304 pairs, one chunk (64 GiB)" timeout -k 10 200 python scripts/long_read_bench.py 2304 64 10000 0 --seconds 5 &&
-run "10 kb, 2304 pairs, chunks of 768 (24 GiB)" timeout -k 10 200 python scripts/long_read_bench.py 2304 24 10000 0 --seconds 5 &&
-run "10 kb, 2304 pairs, chunks of 1536 (36 GiB)" timeout -k 10 200 python scripts/long_read_bench.py 2304 36 10000 0 --seconds 5 &&
-run "10 kb, 4608 pairs, chunks of 768 (24 GiB)" timeout -k 10 200 python scripts/long_read_bench.py 4608 24 10000 0 --seconds 5 &&
-run "10 kb, 4608 pairs, one chunk (128 GiB)" timeout -k 10 200 python scripts/long_read_bench.py 4608 128 10000 0 --seconds 5
+run "10 kb, 4608 pairs" timeout -k 10 200 python scripts/long_read_bench.py 4608 230 10000 2 --seconds 5 &&
+run "10 kb, 2304 pairs" timeout -k 10 200 python scripts/long_read_bench.py 2304 230 10000 0 --seconds 5 &&
+run "16 kb, 1536 pairs" timeout -k 10 200 python scripts/long_read_bench.py 1536 230 16000 0 --seconds 5

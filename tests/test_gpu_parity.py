@@ -989,7 +989,7 @@ def test_single_long_pair_through_the_one_pair_entry():
     assert tuple(ez) == g.score
     # a small workspace holds exactly as many pairs as fit, down to one per chunk
     a = sw.MicrosoftSmithWaterman(0)
-    a.set_workspace(20 << 20)   # two halves of 10 MB: one pair's kept rows and checkpoints each (8.5 MB as packed entries; with every flag stored: 50 MB)
+    a.set_workspace(24 << 20)   # two halves of 12 MB: one pair's kept rows and checkpoints each (10.1 MB as packed entries -- checkpoint columns every 128 from round 4 on; with every flag stored: 50 MB)
     res = a.align_batch([g.t] * 3, [g.q] * 3, g.params, g.strategy, cigar_stride=24000)
     assert all(int(res.offsets[k]) == g.offset and "sha1:" + hashlib.sha1(res.cigars[k].encode()).hexdigest() == g.cigar for k in range(3))
     assert a.timing().dp_launches == 3
