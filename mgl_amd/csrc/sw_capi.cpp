@@ -447,7 +447,7 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
         // worth it when enough of the issued lanes are real cells: strips of the 128 W slots x useful steps of all steps
         // rows per strip: as few as still cover the longest target with these waves (fewer rows = fewer instructions per column)
         int sr_ = 32;
-        for (int cand = 31; cand >= 20; --cand)
+        for (int cand = 31; cand >= 17; --cand)
             if ((max_tl + cand - 1) / cand <= 128 * sw_) sr_ = cand;
         const double used = (double)((max_tl + sr_ - 1) / sr_) / (128.0 * sw_) * strip16_groups(max_ql) / (double)strip16_steps(max_ql, sw_);
         // (measured against the kernels it replaces, pairs of n x n: 1.5 kb 1 354 against 1 124 GCUPS at used = 0.44; 2 kb 1 844 / 1 014;

@@ -268,7 +268,7 @@ int strip16_lds_bytes(int max_ql, int waves);
 int strip16_lds_bytes_codes(int max_ql, int waves); // the query as one table dword per column (DpArgs::strip_codes)
 int strip16_waves_per_simd(int rows);               // what the kernel of that many rows per strip is built for (2 or 3)
 bool strip16_range_ok(int match, int mismatch, int gopen, int gext);
-hipError_t launch_dp16_strip(const DpArgs &a, int waves, int rows, hipStream_t stream); // rows per strip: 20 / 24 / 28 / 32; a.uni_ql = max_ql sizes the regions; a.scratch: strip16_scratch_bytes per pair
+hipError_t launch_dp16_strip(const DpArgs &a, int waves, int rows, hipStream_t stream); // rows per strip: 17 .. 32; a.uni_ql = max_ql sizes the regions; a.scratch: strip16_scratch_bytes per pair
 hipError_t launch_dp_coop16(const DpArgs &a, int waves_per_block, hipStream_t stream); // a.sps_cap = coop16_sps_for(max_ql)
 hipError_t launch_traceback(const TbArgs &a, hipStream_t stream);
 hipError_t launch_strip_ck_walk(const TbArgs &a, int max_tl, int max_ql, hipStream_t stream); // layout 6: one wave per pair, blocks recomputed (sw_strip_walk.hip)

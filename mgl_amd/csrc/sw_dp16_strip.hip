@@ -501,6 +501,9 @@ MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r23, 23)
 MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r22, 22)
 MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r21, 21)
 MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r20, 20)
+MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r19, 19) // (round 4: targets of 8 193 .. 9 728 rows on the 512 strip slots of four waves -- with 20 rows
+MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r18, 18) // at least, 8 300 rows filled 415 of them: 3 835 GCUPS between 4 640 at 8 150 and 4 550 at 10 000)
+MGL_STRIP_KERNEL(sw_dp16_strip_kernel_r17, 17)
 #undef MGL_STRIP_KERNEL
 
 int strip16_lds_bytes(int max_ql, int waves) { return strip16_qwords(max_ql) * 4 + 2 * waves * 8 * 4 + 8 + 16 + 64; }
@@ -522,17 +525,17 @@ hipError_t launch_dp16_strip(const DpArgs &a, int waves, int rows, hipStream_t s
 {
     const int lds = a.strip_codes ? strip16_lds_bytes_codes(a.uni_ql, waves) : strip16_lds_bytes(a.uni_ql, waves);
     if (lds > 64 * 1024 || (a.strip_codes && a.strip_k == 0)) return hipErrorInvalidValue; // (the host checks)
-    static void (*const table[13])(const DpArgs) = {sw_dp16_strip_kernel_r20, sw_dp16_strip_kernel_r21, sw_dp16_strip_kernel_r22, sw_dp16_strip_kernel_r23,
+    static void (*const table[16])(const DpArgs) = {sw_dp16_strip_kernel_r17, sw_dp16_strip_kernel_r18, sw_dp16_strip_kernel_r19, sw_dp16_strip_kernel_r20, sw_dp16_strip_kernel_r21, sw_dp16_strip_kernel_r22, sw_dp16_strip_kernel_r23,
                                                     sw_dp16_strip_kernel_r24, sw_dp16_strip_kernel_r25, sw_dp16_strip_kernel_r26, sw_dp16_strip_kernel_r27,
                                                     sw_dp16_strip_kernel_r28, sw_dp16_strip_kernel_r29, sw_dp16_strip_kernel_r30, sw_dp16_strip_kernel_r31,
                                                     sw_dp16_strip_kernel};
-    static void (*const table_ck[13])(const DpArgs) = {sw_dp16_strip_kernel_r20_ck, sw_dp16_strip_kernel_r21_ck, sw_dp16_strip_kernel_r22_ck, sw_dp16_strip_kernel_r23_ck,
+    static void (*const table_ck[16])(const DpArgs) = {sw_dp16_strip_kernel_r17_ck, sw_dp16_strip_kernel_r18_ck, sw_dp16_strip_kernel_r19_ck, sw_dp16_strip_kernel_r20_ck, sw_dp16_strip_kernel_r21_ck, sw_dp16_strip_kernel_r22_ck, sw_dp16_strip_kernel_r23_ck,
                                                        sw_dp16_strip_kernel_r24_ck, sw_dp16_strip_kernel_r25_ck, sw_dp16_strip_kernel_r26_ck, sw_dp16_strip_kernel_r27_ck,
                                                        sw_dp16_strip_kernel_r28_ck, sw_dp16_strip_kernel_r29_ck, sw_dp16_strip_kernel_r30_ck, sw_dp16_strip_kernel_r31_ck,
                                                        sw_dp16_strip_kernel_ck};
-    if (rows < 20 || rows > 32) return hipErrorInvalidValue;
+    if (rows < 17 || rows > 32) return hipErrorInvalidValue;
     if (a.strip_k > 0 && a.strip_k != 64 / rows) return hipErrorInvalidValue; // (a constant in the kernels)
-    void (*k)(const DpArgs) = a.strip_k > 0 ? table_ck[rows - 20] : table[rows - 20];
+    void (*k)(const DpArgs) = a.strip_k > 0 ? table_ck[rows - 17] : table[rows - 17];
     hipLaunchKernelGGL(k, dim3((unsigned)a.count), dim3(64 * waves), lds, stream, a);
     return hipGetLastError();
 }
