@@ -167,12 +167,13 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
         // register: some thirty registers the 32 x 3 + 16 of the strips' state leave no room for -- they were spilled (up to 281 per
         // lane in round 3) and loaded back step after step.  Made opaque here, they are recomputed per step: a dozen instructions
         // against the ~ 600 of a step's four columns.
+        // (strips of up to 24 rows leave the registers for them: there they stay loop-invariant -- some 30 instructions a step less)
         int el = ell;
-        if (NOTB) asm volatile("" : "+v"(el));
+        if (NOTB && SR >= 25) asm volatile("" : "+v"(el));
         const int gA = el, gB = NL + el, i0A = SR * gA, i0B = SR * gB;
         const bool own_last_a = gA == gl, own_last_b = gB == gl;
         const int bandA = gA / K, bandB = gB / K;
-        const int rowoffA = bandA * row_stride, rowoffB = bandB * row_stride;
+        const int rowoffA = (int)__umul24((unsigned)bandA, (unsigned)row_stride), rowoffB = (int)__umul24((unsigned)bandB, (unsigned)row_stride); // (both below 2^24: a full-rate multiply)
         const bool rowsA = NOTB && (gA + 1) % K == 0 && (gA + 1) * SR < tl, rowsB = NOTB && (gB + 1) % K == 0 && (gB + 1) * SR < tl;
         const int cgA = s - gA, cgB = s - gB;
         const bool actA = cgA >= 0 && cgA < NCG && i0A < tl, actB = cgB >= 0 && cgB < NCG && i0B < tl;
