@@ -288,7 +288,6 @@ struct BatchPlan {
     int coop_waves; // waves per pair of the workgroup kernels (0: not those)
     int strip_waves; // ... its waves per pair
     int strip_k; // ... strips per kept band (0: every flag stored)
-    int strip_pack; // ... its kept entries packed into one int32 (bits for the gap penalty; 0: two int32)
     bool auto_group; // a batch of mixed geometries whose chunks the library sorts by (tl, ql)
     bool lane_group; // ... the geometries with whole waves of 128 pairs through the checkpointed lane kernel
     int64_t lane_group_stride; // ... words per wave of that part
@@ -437,7 +436,6 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
     // registers per SIMD
     bool strip16 = false;
     int strip_waves = 0, strip_k = 0; // strip_k: strips per kept band of the form without stored flags (0: flags stored)
-    int strip_pack = 0;               // ... its entries packed into one int32 each (strip16_pack_bits; 0: two)
     {
         // waves per pair: as few as hold the target in strips of 32 rows -- but never three: workgroups of three waves run a
         // quarter slower than those of one, two or four (pairs of 8 / 10 / 12 kb with two or four waves: 3.09 / 2.69 / 2.99
@@ -458,14 +456,11 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
         // (without stored flags -- rows of every band of K strips and column checkpoints instead, walked by sw_strip_ck_walk_kernel --
         // a pair takes 8 MB (16 where the entries do not pack): that form is the default where CIGARs are written; mgl_sw_ctx_set_lane_checkpoint(ctx, 1) keeps the flags)
         const int sk_ = (ctx->lane_checkpoint != 1 && d_cigar != nullptr && !score_only_hint) ? 64 / sr_ : 0;
-        const char *const spe = getenv("MGL_SW_DEBUG_STRIP_PACK"); // (0: two int32 per kept entry whatever the parameters; read per call: the tests run both forms)
-        const int sp_ = sk_ && !(spe && atoi(spe) == 0) ? strip16_pack_bits(max_tl, max_ql, match, gopen, gext) : 0;
-        const bool fits = (sk_ ? strip16_ck_words(max_tl, max_ql, sr_, sk_, sp_) : tb_words_strip16(max_ql, sw_)) * 4 + (int64_t)sizeof(DpRecord) <= ctx->ws_limit / 2;
+        const bool fits = (sk_ ? strip16_ck_words(max_tl, max_ql, sr_, sk_) : tb_words_strip16(max_ql, sw_)) * 4 + (int64_t)sizeof(DpRecord) <= ctx->ws_limit / 2;
         if (want && fits && !use16 && !use_lane && !d_matrix && ctx->precision != 32 && ctx->carry_memory == 0 && !ctx->stripe_rows && sw_ <= 4 &&
             strip16_lds_bytes(max_ql, sw_) <= 64 * 1024 && strip16_range_ok(match, mismatch, gopen, gext)) {
             strip16 = true;
             strip_k = sk_;
-            strip_pack = sp_;
             strip_waves = sw_;
             coop16 = false;
             coop_waves = 0;
@@ -495,7 +490,7 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
     const int64_t stride_words = lane_ck ? lane_ck_words(max_tl, max_ql)
                                  : use_lane ? lane_tb_words(max_tl, max_ql, rows)
                                  : use16 ? (geom == GEOM_UNIFORM ? tb_words16_for(max_tl, max_ql) : tb_words16_bound(max_tl, max_ql))
-                                 : strip16 ? (strip_k ? strip16_ck_words(max_tl, max_ql, rows, strip_k, strip_pack) : tb_words_strip16(max_ql, strip_waves))
+                                 : strip16 ? (strip_k ? strip16_ck_words(max_tl, max_ql, rows, strip_k) : tb_words_strip16(max_ql, strip_waves))
                                  : coop16 ? std::max(tb_words_for(max_tl, coop_sps_for(max_ql), 64), tb_words_coop16(max_tl, max_ql)) // either layout
                                          : tb_words_for(max_tl, sps_cap, rows);
     // (auto-grouped chunks: the packed regions first, the int32 regions of the left-over pairs behind them)
@@ -588,7 +583,6 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
     P.coop_waves = coop_waves;
     P.strip_waves = strip_waves;
     P.strip_k = strip_k;
-    P.strip_pack = strip_pack;
     P.auto_group = auto_group;
     P.lane_group = lane_group;
     P.lane_group_stride = lane_group_stride;
@@ -752,7 +746,6 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const int coop_waves = P.coop_waves;
     const int strip_waves = P.strip_waves;
     const int strip_k = P.strip_k;
-    const int strip_pack = P.strip_pack;
     const bool auto_group = P.auto_group;
     const bool lane_group = P.lane_group;
     const int64_t lane_group_stride = P.lane_group_stride;
@@ -1031,7 +1024,6 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             da.score_only = score_only ? 1 : 0;
             da.grouped = pt.lane && auto_group ? 1 : 0;
             da.strip_k = strip16 ? strip_k : 0;
-            da.strip_pack = strip16 ? strip_pack : 0;
             {
                 const char *const sce = getenv("MGL_SW_DEBUG_STRIP_CODES"); // (0: the byte-compare form whatever the sequences; read per call: the tests run both forms)
                 da.strip_codes = strip16 && strip_k > 0 && !(sce && atoi(sce) == 0) && strip16_lds_bytes_codes(max_ql, strip_waves) <= 64 * 1024 ? 1 : 0;
@@ -1076,7 +1068,6 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             ta.gext = gext;
             ta.strip_rows = pt.rows;
             ta.strip_k = strip16 ? strip_k : 0;
-            ta.strip_pack = strip16 ? strip_pack : 0;
             ta.rows_per_stripe = pt.rows;
             ta.uni_ql = max_ql;
             ta.rec = pt.rec;

@@ -68,7 +68,6 @@ struct DpArgs {
     int score_only;           // packed kernel: no traceback flags (MGL_SW_FLAG_SCORE_ONLY)
     int grouped;              // sw_dp16_lane_ck_kernel: every wave of 128 pairs has its own geometry (a chunk sorted by geometry)
     int strip_k;              // sw_dp16_strip_kernel: 0 = the flags of every cell are stored; K > 0 = none are: rows and checkpoints of bands of K strips (strip16_ck_*)
-    int strip_pack;           // ... their entries: 0 = {H, gap value} as two int32; B > 0 = one int32, H << B | (H - gap value) (strip16_pack_bits)
     int strip_codes;          // ... and the LDS carve holds the query as one table dword per column (strip16_lds_bytes_codes): pairs whose targets are all ACGT run the base-code form
     int lane_slots;           // sw_dp16_lane_ck_kernel: wave slots of its persistent grid = regions at tb / scratch (lane_ck_slots)
     unsigned *tile_ctr;       // ... the counter its waves draw their next tile from (needed when the launch holds more tiles than slots) ...
@@ -99,7 +98,6 @@ struct TbArgs {
     int32_t *status_any; // optional: max of all non-zero statuses of the call
     int match, mismatch, gopen, gext; // sw_strip_ck_walk_kernel recomputes the blocks its path crosses
     int strip_rows, strip_k;         // ... rows per strip and strips per kept band of the fill
-    int strip_pack;                  // ... and the form of its entries (DpArgs::strip_pack)
     const int64_t *dest; // optional: output index of input pair p (results of pair p go to offset[dest[p]], cigar slot dest[p], ...);
                          // null: p itself.  (Batches the host layer has reordered by geometry hand results back in the caller's order.)
     int coalesced_out;   // sw_dp16_lane_ck_kernel: a wave gathers the results of its 128 pairs in LDS and writes them out in whole lines (lane_ck_coalesced_ok)
@@ -234,35 +232,23 @@ constexpr int STRIP_CK_COLS = 128;
 __host__ __device__ inline int strip16_ck_bands(int tl, int rows, int k) { return (tl + rows * k - 1) / (rows * k); }
 __host__ __device__ inline int strip16_ck_ccs(int tl, int ql, int rows, int k) { return (ql + STRIP_CPS * k * strip16_ck_bands(tl, rows, k)) / STRIP_CK_COLS + 2; }
 __host__ __device__ inline int strip16_ck_row_stride(int ql) { return (ql + 4) & ~3; } // entries per kept row: column j at index j - 1, rows 32-byte aligned
-// An entry is {H, G}: H of a cell and the gap value that enters the next row (kept rows: E) or the next column (checkpoints: F) from it.
-// G = max(H - o, gap value of the cell itself - e), and that value is no greater than H: H - G lies in [min(o, e), o] -- one int32
-// holds H << B | (H - G) where B bits hold o and H fits the rest (strip16_pack_bits; 0: it does not, two int32 per entry).
-__host__ __device__ inline int strip16_pack_bits(int tl, int ql, int match, int gopen, int gext)
-{
-    if (match < 0 || gopen < gext || gext < 0) return 0;
-    int b = 1;
-    while ((1 << b) <= gopen) ++b;
-    const int64_t top = (int64_t)match * (tl < ql ? tl : ql), low = (int64_t)gopen + ((int64_t)tl + ql) * gext; // H <= top, H >= -low
-    const int64_t room = (int64_t)1 << (31 - b);
-    return b <= 15 && top < room && low < room ? b : 0;
-}
-__host__ __device__ inline int strip16_pack(int h, int g, int bits) { return (int)((unsigned)h << bits) | (h - g); }
-__host__ __device__ inline void strip16_unpack(int v, int bits, int &h, int &g)
-{
-    h = v >> bits;
-    g = h - (v & ((1 << bits) - 1));
-}
-// The checkpoint columns (round 4) are kept as the strips hold them: one dword per row, {H, F} as the 16-bit values of the strip's registers
-// (one v_perm_b32 in the fill where converting both to true scores and packing them took seven instructions per row), and the strip's
-// baseline once per checkpoint column and strip: value + baseline = score + (row + column) e, the walk's own representation.
-// Per pair, in dwords: the kept rows [band][column] (one dword per entry where they pack, else two) | the checkpoints [cc][row 0 .. tl] |
-// their baselines [cc][strip].
+// Round 4: everything the fill keeps is kept AS THE STRIPS HOLD IT -- a dword per entry, {H, gap value} as the two 16-bit values of the
+// strip's registers (one v_perm_b32 in the fill; converting both to true scores and packing them took six to seven instructions per
+// entry, on every lane, for the one strip in K that writes) -- beside the strip's baseline: value + baseline = score + (row + column) e,
+// the walk's own representation.  The rows' baselines move every 16 columns (column j: block (j - 1) / 16), a checkpoint column has one per strip.
+// Per pair, in dwords: the kept rows [band][column] | their baselines [band][16-column block] | the checkpoints [cc][row 0 .. tl] | their
+// baselines [cc][strip].
 __host__ __device__ inline int strip16_ck_strips(int tl, int rows) { return (tl + rows - 1) / rows + 1; }
-__host__ __device__ inline int64_t strip16_ck_off_cols(int tl, int ql, int rows, int k, int pack_bits) { return (int64_t)strip16_ck_bands(tl, rows, k) * strip16_ck_row_stride(ql) * (pack_bits ? 1 : 2); }
-__host__ __device__ inline int64_t strip16_ck_off_base(int tl, int ql, int rows, int k, int pack_bits) { return strip16_ck_off_cols(tl, ql, rows, k, pack_bits) + (int64_t)strip16_ck_ccs(tl, ql, rows, k) * (tl + 1); }
-__host__ __device__ inline int64_t strip16_ck_words(int tl, int ql, int rows, int k, int pack_bits = 0)
+__host__ __device__ inline int strip16_ck_row_blocks(int ql) { return strip16_ck_row_stride(ql) / 16 + 2; }
+__host__ __device__ inline int64_t strip16_ck_off_rowbase(int tl, int ql, int rows, int k) { return (int64_t)strip16_ck_bands(tl, rows, k) * strip16_ck_row_stride(ql); }
+__host__ __device__ inline int64_t strip16_ck_off_cols(int tl, int ql, int rows, int k)
 {
-    return (strip16_ck_off_base(tl, ql, rows, k, pack_bits) + (int64_t)strip16_ck_ccs(tl, ql, rows, k) * strip16_ck_strips(tl, rows) + 3) & ~(int64_t)3;
+    return (strip16_ck_off_rowbase(tl, ql, rows, k) + (int64_t)strip16_ck_bands(tl, rows, k) * strip16_ck_row_blocks(ql) + 3) & ~(int64_t)3;
+}
+__host__ __device__ inline int64_t strip16_ck_off_base(int tl, int ql, int rows, int k) { return strip16_ck_off_cols(tl, ql, rows, k) + (int64_t)strip16_ck_ccs(tl, ql, rows, k) * (tl + 1); }
+__host__ __device__ inline int64_t strip16_ck_words(int tl, int ql, int rows, int k)
+{
+    return (strip16_ck_off_base(tl, ql, rows, k) + (int64_t)strip16_ck_ccs(tl, ql, rows, k) * strip16_ck_strips(tl, rows) + 3) & ~(int64_t)3;
 }
 int strip16_lds_bytes(int max_ql, int waves);
 int strip16_lds_bytes_codes(int max_ql, int waves); // the query as one table dword per column (DpArgs::strip_codes)

@@ -30,7 +30,7 @@
 // cells) and keeps what sw_strip_ck_walk_kernel (sw_strip_walk.hip) needs to recompute the 60 x 256 blocks the path crosses: the
 // true scores {H, E} of the row below every band of K strips, per column, and {H, F} of every row at the band's checkpoint columns
 // (every STRIP_CK_COLS = 128 columns, at the step offset of the band so that all strips of a band save the SAME column; a dword per row as the
-// strip holds it, and the strip's baseline): 10 MB per 10 kb pair with the rows as packed entries (DpArgs::strip_pack), 17 as pairs of int32.
+// strip holds it, and the strip's baseline; the rows likewise, with a baseline per 16 columns): 10 MB per 10 kb pair.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -42,6 +42,10 @@ namespace mgl_sw_dev {
 
 namespace {
 
+// rows per strip from which the kernels are built for two waves per SIMD (see MGL_STRIP_OCC below)
+#ifndef MGL_STRIP_OCC2_FROM
+#define MGL_STRIP_OCC2_FROM 27
+#endif
 constexpr int CPS = STRIP_CPS;       // columns per step
 constexpr int STRIP_LEVEL = -14000;  // where a move of the baseline puts the strip's first row
 
@@ -149,15 +153,13 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     uint4 *const tb_wave = reinterpret_cast<uint4 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words) + (size_t)w * steps_cap * CPS * 2 * 64 + L;
     // NOTB: the rows and checkpoints kept instead of the flags (strip16_ck_words): int2 entries
     constexpr int K = NOTB ? 64 / SR : 1; // (= a.strip_k: the host sets it so, launch_dp16_strip checks; a constant here: the divisions below are multiplications)
-    int2 *const rows_rec = reinterpret_cast<int2 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words);
-    const int row_stride = strip16_ck_row_stride(a.uni_ql);
-    // the checkpoint columns: a dword per row {H, F} as the strip holds them, and the strip's baseline per column (strip16_ck_words)
-    int *const ck_cols = reinterpret_cast<int *>(rows_rec) + strip16_ck_off_cols(a.uni_tl, a.uni_ql, SR, K, NOTB ? a.strip_pack : 0);
-    int *const ck_base = reinterpret_cast<int *>(rows_rec) + strip16_ck_off_base(a.uni_tl, a.uni_ql, SR, K, NOTB ? a.strip_pack : 0);
+    // what is kept instead of the flags (strip16_ck_words, sw_device.h): dwords {H, gap value} as the strips hold them, and their baselines
+    int *const rows_raw = reinterpret_cast<int *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words);
+    const int row_stride = strip16_ck_row_stride(a.uni_ql), row_blocks = strip16_ck_row_blocks(a.uni_ql);
+    int *const rows_base = rows_raw + strip16_ck_off_rowbase(a.uni_tl, a.uni_ql, SR, K);
+    int *const ck_cols = rows_raw + strip16_ck_off_cols(a.uni_tl, a.uni_ql, SR, K);
+    int *const ck_base = rows_raw + strip16_ck_off_base(a.uni_tl, a.uni_ql, SR, K);
     const int ck_strips = strip16_ck_strips(a.uni_tl, SR);
-    // (a.strip_pack = B > 0: the same entries as one int32 each, H << B | (H - gap value): strip16_pack_bits)
-    const int PB = NOTB ? a.strip_pack : 0;
-    int *const rows_pk = reinterpret_cast<int *>(rows_rec);
     // (per step, below: bandA / bandB = the band of K strips a strip belongs to; rowoffA / rowoffB = that band's kept row as a 32-bit index off
     // the pair's uniform base; rowsA / rowsB = the strip whose last row is the row below a band -- and not the matrix's last rows: it writes that row)
 
@@ -167,9 +169,10 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
         // register: some thirty registers the 32 x 3 + 16 of the strips' state leave no room for -- they were spilled (up to 281 per
         // lane in round 3) and loaded back step after step.  Made opaque here, they are recomputed per step: a dozen instructions
         // against the ~ 600 of a step's four columns.
-        // (strips of up to 24 rows leave the registers for them: there they stay loop-invariant -- some 30 instructions a step less)
+        // (strips of up to 24 rows, and those of 29 and more with their 256 registers, leave room for them: there they stay loop-invariant
+        // -- some 30 instructions a step less: 10 kb pairs, 20 rows, 91.2 -> 86.3 ms per 4 608 pairs)
         int el = ell;
-        if (NOTB && SR >= 25) asm volatile("" : "+v"(el));
+        if (NOTB && SR >= 25 && SR < MGL_STRIP_OCC2_FROM) asm volatile("" : "+v"(el));
         const int gA = el, gB = NL + el, i0A = SR * gA, i0B = SR * gB;
         const bool own_last_a = gA == gl, own_last_b = gB == gl;
         const int bandA = gA / K, bandB = gB / K;
@@ -192,7 +195,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
             ih = dpp_wave_shr1(l0h, out_h[u]);
             ie = dpp_wave_shr1(l0e, out_e[u]);
         };
-        int2 keptA[CPS] = {}, keptB[CPS] = {}; // NOTB: the row below a band, this step's columns
+        unsigned keptA[CPS] = {}, keptB[CPS] = {}; // NOTB: the row below a band, this step's columns: {H, E entering the next row} as the strip holds them
         // (wave-uniform: the DPP moves below need the lane before to be enabled; what an idle lane computes feeds nothing real)
         if (__builtin_amdgcn_ballot_w64(actA || actB)) {
             // ---- 2. a half that starts now: column 0 of its rows (sw.cpp:24,38,47-49), its baseline on its first row
@@ -229,6 +232,10 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                 base_a += lo16(d);
                 base_b += hi16(d);
                 bres = pk_add(bres, d);
+                if (NOTB) { // the strip that writes the row below its band: that row's baseline for these 16 columns
+                    if (rowsA && actA) rows_base[bandA * row_blocks + (cgA >> 2)] = base_a;
+                    if (rowsB && actB) rows_base[bandB * row_blocks + (cgB >> 2)] = base_b;
+                }
             }
             // ---- 4. four columns
             // (a query dword holds 4 / CPS groups; the two halves are 64 W groups apart, so they sit in the same place of their dwords)
@@ -243,11 +250,6 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                 tabB = T4[min(max(cgB, 0), (qwords >> 2) - 1)];
             }
             uint4 *tbp = tb_wave + (size_t)s * CPS * 2 * 64;
-            // NOTB: what turns the stored values of the row below a band into true scores at column 4 cg (opaque: one register per half
-            // and step -- left to itself the compiler keeps a loop-invariant part per column and entry, sixteen registers the
-            // 25-to-32-row kernels do not have: spilled, and loaded back in every step)
-            int unA = base_a - ((gA + 1) * SR + CPS * cgA) * gext, unB = base_b - ((gB + 1) * SR + CPS * cgB) * gext;
-            if (NOTB) asm volatile("" : "+v"(unA), "+v"(unB));
 #pragma unroll
             for (int u = 0; u < CPS; ++u) {
                 unsigned ih, e;
@@ -263,10 +265,9 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                 hd = pk_sub(ih, bres);
                 out_h[u] = pk_add(h[SR - 1], bres);
                 out_e[u] = pk_add(e, bres);
-                if (NOTB) { // {H[i][j], E entering row i + 1} of the row below a band, as true scores (stored = X + (i + j) e - baseline)
-                    const int ue = (u + 1) * gext; // (a scalar per column of the group)
-                    keptA[u] = make_int2(lo16(h[SR - 1]) + (unA - ue), lo16(e) + (unA - ue - gext));
-                    keptB[u] = make_int2(hi16(h[SR - 1]) + (unB - ue), hi16(e) + (unB - ue - gext));
+                if (NOTB) { // {H[i][j], E entering row i + 1} of the strip's last row: the low halves, the high halves
+                    keptA[u] = __builtin_amdgcn_perm(e, h[SR - 1], 0x05040100u);
+                    keptB[u] = __builtin_amdgcn_perm(e, h[SR - 1], 0x07060302u);
                 }
                 if (u == ulast && ((cgA == NCG - 1 && actA) || (cgB == NCG - 1 && actB))) {
                     // column ql of this strip's rows: parked in the lane's own scratch lines with the baseline that goes with it,
@@ -298,48 +299,26 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
                 }
             }
         }
-        // ---- 4a. the row below a band (NOTB): the group's four columns as one aligned 32-byte piece (column j at entry j - 1)
+        // ---- 4a. the row below a band (NOTB): the group's four columns as one aligned 16-byte piece (column j at entry j - 1)
         if (NOTB && CPS == 4) {
-            if (PB && rowsA && actA) { // one aligned 16-byte piece
-                int *const dst = rows_pk + (unsigned)(rowoffA + CPS * cgA);
+            if (rowsA && actA) {
+                int *const dst = rows_raw + (unsigned)(rowoffA + CPS * cgA);
                 if (CPS * cgA + CPS <= ql) {
-                    reinterpret_cast<int4 *>(dst)[0] = make_int4(strip16_pack(keptA[0].x, keptA[0].y, PB), strip16_pack(keptA[1].x, keptA[1].y, PB),
-                                                                 strip16_pack(keptA[2].x, keptA[2].y, PB), strip16_pack(keptA[3].x, keptA[3].y, PB));
+                    reinterpret_cast<int4 *>(dst)[0] = make_int4((int)keptA[0], (int)keptA[1], (int)keptA[2], (int)keptA[3]);
                 } else {
 #pragma unroll
                     for (int u = 0; u < CPS; ++u)
-                        if (CPS * cgA + u + 1 <= ql) dst[u] = strip16_pack(keptA[u].x, keptA[u].y, PB);
-                }
-            } else if (rowsA && actA) {
-                int2 *const dst = rows_rec + (unsigned)(rowoffA + CPS * cgA);
-                if (CPS * cgA + CPS <= ql) {
-                    reinterpret_cast<int4 *>(dst)[0] = make_int4(keptA[0].x, keptA[0].y, keptA[1].x, keptA[1].y);
-                    reinterpret_cast<int4 *>(dst)[1] = make_int4(keptA[2].x, keptA[2].y, keptA[3].x, keptA[3].y);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < CPS; ++u)
-                        if (CPS * cgA + u + 1 <= ql) dst[u] = keptA[u];
+                        if (CPS * cgA + u + 1 <= ql) dst[u] = (int)keptA[u];
                 }
             }
-            if (PB && rowsB && actB) {
-                int *const dst = rows_pk + (unsigned)(rowoffB + CPS * cgB);
+            if (rowsB && actB) {
+                int *const dst = rows_raw + (unsigned)(rowoffB + CPS * cgB);
                 if (CPS * cgB + CPS <= ql) {
-                    reinterpret_cast<int4 *>(dst)[0] = make_int4(strip16_pack(keptB[0].x, keptB[0].y, PB), strip16_pack(keptB[1].x, keptB[1].y, PB),
-                                                                 strip16_pack(keptB[2].x, keptB[2].y, PB), strip16_pack(keptB[3].x, keptB[3].y, PB));
+                    reinterpret_cast<int4 *>(dst)[0] = make_int4((int)keptB[0], (int)keptB[1], (int)keptB[2], (int)keptB[3]);
                 } else {
 #pragma unroll
                     for (int u = 0; u < CPS; ++u)
-                        if (CPS * cgB + u + 1 <= ql) dst[u] = strip16_pack(keptB[u].x, keptB[u].y, PB);
-                }
-            } else if (rowsB && actB) {
-                int2 *const dst = rows_rec + (unsigned)(rowoffB + CPS * cgB);
-                if (CPS * cgB + CPS <= ql) {
-                    reinterpret_cast<int4 *>(dst)[0] = make_int4(keptB[0].x, keptB[0].y, keptB[1].x, keptB[1].y);
-                    reinterpret_cast<int4 *>(dst)[1] = make_int4(keptB[2].x, keptB[2].y, keptB[3].x, keptB[3].y);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < CPS; ++u)
-                        if (CPS * cgB + u + 1 <= ql) dst[u] = keptB[u];
+                        if (CPS * cgB + u + 1 <= ql) dst[u] = (int)keptB[u];
                 }
             }
         }
@@ -452,12 +431,11 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
 // grid = pairs of the chunk, block = 64 * W threads (W <= 4), dynamic LDS = strip16_lds_bytes.  Rows per strip: 32, or fewer when
 // that still covers the longest target with the same number of waves (10 000 rows on 384 strip slots: 27 rows each instead of
 // 313 strips of 32 -- a sixth fewer instructions per column)
-// Waves per SIMD.  Three (168 registers) up to 28 rows per strip, where the kernels hold their state without spilling; TWO (256
-// registers) from 29 rows on: at three, the 32-row kernel spilled inside the column code (16 kb pairs: 99.5 ms per 1 536 pairs against
-// 90.7 with two waves per SIMD; 10 kb pairs, 20 rows: the same either way).  -DMGL_STRIP_OCC2_FROM=N (scripts/build_variant.sh) moves the border.
-#ifndef MGL_STRIP_OCC2_FROM
-#define MGL_STRIP_OCC2_FROM 29
-#endif
+// Waves per SIMD.  Three (168 registers) up to 26 rows per strip; TWO (256 registers) from 27 rows on: at three, the 32-row kernel spilled
+// inside the column code (16 kb pairs: 99.5 ms per 1 536 pairs against 90.7 with two waves per SIMD; 10 kb pairs, 20 rows: the same either
+// way), and from 27 rows per strip on (targets of 13 313 rows and more) a pair's query tables leave LDS for two workgroups per CU anyway
+// (14 kb pairs, 28 rows: 4 524 GCUPS at two against 4 340 at three; 13 kb, 26 rows, three workgroups per CU: 4 581 at three against
+// 4 350 at two).  -DMGL_STRIP_OCC2_FROM=N (scripts/build_variant.sh) moves the border.
 #define MGL_STRIP_OCC(ROWS) ((ROWS) >= MGL_STRIP_OCC2_FROM ? 2 : 3)
 
 // every byte of the pair's target one of ACGT (2-bit packed inputs: by construction)?  The whole workgroup calls this together.

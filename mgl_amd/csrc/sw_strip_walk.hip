@@ -44,11 +44,12 @@ struct BlockMoves {
     int tl, ql, match, mismatch, gopen, gext;
     bool indel;
     int rbk, kcols;            // rows per band (K strips), CPS * K: how far a band's checkpoint columns lie before the band above's
-    const int2 *rows;          // the rows the fill kept (strip16_ck_words) ...
-    int pack;                  // ... as {H, gap value} pairs (0) or packed into one int32 each (strip16_pack_bits)
-    const int *ck_cols, *ck_base; // the checkpoint columns: a dword per row, {H, F} as 16-bit values of the strip's registers, and the strips' baselines per column
-    int row_stride, tl_cap;    // entries per kept row (column j at j - 1), rows per checkpoint column
-    int strip_rows, ck_strips; // rows per strip, baselines per checkpoint column
+    // what the fill kept (strip16_ck_words): dwords {H, gap value} as 16-bit values of the strips' registers, beside the strips' baselines --
+    // value + baseline = score + (row + column) e, the representation compute() works in
+    const int *rows, *rows_base;  // the row below every band [band][column j at j - 1] and its baselines [band][(j - 1) / 16]
+    const int *ck_cols, *ck_base; // the checkpoint columns [cc][row] and their baselines [cc][strip]
+    int row_stride, row_blocks, tl_cap; // entries per kept row, baselines per kept row, rows per checkpoint column
+    int strip_rows, ck_strips;    // rows per strip, baselines per checkpoint column
     uint4 *flags;              // LDS: [64 rows][FW4]: the bit planes {F > diag, E > max(diag, F), E' opened, F' opened} of 32 steps each, step t of its 32 at bit 31 - t
     unsigned char *qb;         // LDS: the block's query bases (BC + 8 bytes)
     int lane;
@@ -58,18 +59,17 @@ struct BlockMoves {
     int cur_b = -1, cur_cc = -1, r0 = 0, jl = 0, jr = 0, imax = 0;
 
     __device__ __forceinline__ int cc_of(int b, int j) const { return (j - 1 + kcols * b) / BC; }
-    // {H[r0][j], E entering row r0 + 1 at column j} as the fill kept them (true scores)
+    // {H[r0][j], E entering row r0 + 1 at column j}, each + (its row + column) e
     __device__ __forceinline__ void top(int b, int j, int &h_, int &e_) const
     {
         if (b == 0) {
-            h_ = border_of(j, gopen, gext, indel);
-            e_ = h_ - gopen;
-        } else if (pack) {
-            strip16_unpack(reinterpret_cast<const int *>(rows)[(size_t)(b - 1) * row_stride + (j - 1)], pack, h_, e_);
+            const int hb = border_of(j, gopen, gext, indel);
+            h_ = hb + j * gext;
+            e_ = hb - gopen + (j + 1) * gext;
         } else {
-            const int2 v = rows[(size_t)(b - 1) * row_stride + (j - 1)];
-            h_ = v.x;
-            e_ = v.y;
+            const int v = rows[(size_t)(b - 1) * row_stride + (j - 1)], base = rows_base[(b - 1) * row_blocks + ((j - 1) >> 4)];
+            h_ = (int)(short)(v & 0xffff) + base;
+            e_ = (v >> 16) + base;
         }
     }
     // four steps of the wavefront.  MASKED: some lane has not reached its first column yet (it keeps what it holds); PLANES: the accumulators
@@ -135,9 +135,8 @@ struct BlockMoves {
             f = (v >> 16) + base;
         }
         // H[r0][jl]: the first diagonal of lane 0
-        int corner = jl == 0 ? border_of(r0, gopen, ge, indel) : 0, dummy = 0;
+        int corner = border_of(r0, gopen, ge, indel) + r0 * ge, dummy = 0;
         if (jl > 0) top(b, jl, corner, dummy);
-        corner += (r0 + jl) * ge;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         // hdiag: H of the row above at the column before this lane's current one (the diagonal input)
@@ -148,11 +147,7 @@ struct BlockMoves {
         auto fetch = [&](int s0, int &h_, int &e_) {
             const int j = jl + 1 + s0 + lane;
             h_ = e_ = 0;
-            if (j <= jr) {
-                top(b, j, h_, e_);
-                h_ += (r0 + j) * ge;
-                e_ += (r0 + 1 + j) * ge;
-            }
+            if (j <= jr) top(b, j, h_, e_);
         };
         int tops_h, tops_e, next_h, next_e;
         fetch(0, tops_h, tops_e);
@@ -265,11 +260,12 @@ __global__ __launch_bounds__(64) void sw_strip_ck_walk_kernel(const TbArgs a, co
     mv.indel = (a.strategy & (OS_INDEL | OS_LEAD_ID)) != 0;
     mv.rbk = a.strip_rows * a.strip_k;
     mv.kcols = STRIP_CPS * a.strip_k;
-    mv.rows = reinterpret_cast<const int2 *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words);
+    mv.rows = reinterpret_cast<const int *>(a.tb + (size_t)slot * (size_t)a.tb_stride_words);
     mv.row_stride = strip16_ck_row_stride(ql_cap);
-    mv.pack = a.strip_pack;
-    mv.ck_cols = reinterpret_cast<const int *>(mv.rows) + strip16_ck_off_cols(tl_cap, ql_cap, a.strip_rows, a.strip_k, a.strip_pack);
-    mv.ck_base = reinterpret_cast<const int *>(mv.rows) + strip16_ck_off_base(tl_cap, ql_cap, a.strip_rows, a.strip_k, a.strip_pack);
+    mv.row_blocks = strip16_ck_row_blocks(ql_cap);
+    mv.rows_base = mv.rows + strip16_ck_off_rowbase(tl_cap, ql_cap, a.strip_rows, a.strip_k);
+    mv.ck_cols = mv.rows + strip16_ck_off_cols(tl_cap, ql_cap, a.strip_rows, a.strip_k);
+    mv.ck_base = mv.rows + strip16_ck_off_base(tl_cap, ql_cap, a.strip_rows, a.strip_k);
     mv.ck_strips = strip16_ck_strips(tl_cap, a.strip_rows);
     mv.strip_rows = a.strip_rows;
     mv.tl_cap = tl_cap;

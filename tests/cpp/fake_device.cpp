@@ -131,7 +131,7 @@ int coop16_lds_bytes(int sps_cap, int waves_per_block) { return coop_lds_bytes(s
 hipError_t launch_dp_coop16(const DpArgs &a, int, hipStream_t) { remember(a); return hipSuccess; }
 int strip16_lds_bytes(int max_ql, int waves) { return strip16_qwords(max_ql) * 4 + waves * 64 + 128; }
 int strip16_lds_bytes_codes(int max_ql, int waves) { return strip16_table_words(max_ql) * 4 + waves * 64 + 128; }
-int strip16_waves_per_simd(int rows) { return rows >= 29 ? 2 : 3; }
+int strip16_waves_per_simd(int rows) { return rows >= 27 ? 2 : 3; }
 bool strip16_range_ok(int match, int, int gopen, int gext) { return match > 0 && match <= 300 && gopen >= gext && gopen <= 400; }
 hipError_t launch_dp16_strip(const DpArgs &a, int, int, hipStream_t) { remember(a); return hipSuccess; }
 hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &w, int, hipStream_t)

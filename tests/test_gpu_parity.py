@@ -343,7 +343,7 @@ def test_device_batch_of_mixed_lengths_is_sorted_on_the_device(two_bit):
     a.close()
 
 
-@pytest.mark.parametrize("stored", [False, True, None, "bytes"], ids=["checkpointed", "stored", "checkpointed_two_words_per_entry", "checkpointed_byte_compare"])
+@pytest.mark.parametrize("stored", [False, True, "bytes"], ids=["checkpointed", "stored", "checkpointed_byte_compare"])
 def test_strip_kernel_long_reads(stored, monkeypatch):
     """sw_dp16_strip_kernel (one pair per workgroup, one 32-row strip per lane-half, per-strip 16-bit baselines, hand-over by DPP
     and an LDS mailbox) forced onto the long goldens, onto pairs of awkward lengths under every strategy, and onto ordinary
@@ -352,9 +352,6 @@ def test_strip_kernel_long_reads(stored, monkeypatch):
     flags of every cell stored (layout 4, what mgl_sw_ctx_expand_slot needs)."""
     from mgl_amd import synth
 
-    if stored is None:   # the kept rows and checkpoints as {H, gap value} pairs of int32 instead of one packed int32 per entry
-        monkeypatch.setenv("MGL_SW_DEBUG_STRIP_PACK", "0")
-        stored = False
     if stored == "bytes":  # the byte compare for every pair (default: base codes wherever a pair's target is all ACGT and the query's tables fit the LDS carve)
         monkeypatch.setenv("MGL_SW_DEBUG_STRIP_CODES", "0")
         stored = False
