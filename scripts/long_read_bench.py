@@ -80,14 +80,14 @@ if args.json:
     print(json.dumps({"gcups": round(cells * reps / dt / 1e9, 1), "pairs": n, "length": length, "passes": reps, "seconds": round(dt, 1),
                       "ms_per_pass": round(dt * 1e3 / reps, 2),
                       "kernel_ms": {a.fill_kernel_name(tm): round(tm.dp_ms, 2), walk_name: round(tm.tb_ms, 2), "launches": tm.dp_launches},
-                      "traceback": "4 bits per cell in HBM" if spilled else "none stored: kept rows and checkpoints (8 MB per 10 kb pair), the walk recomputes the blocks the path crosses",
+                      "traceback": "4 bits per cell in HBM" if spilled else "none stored: kept rows and checkpoints (10 MB per 10 kb pair), the walk recomputes the blocks the path crosses",
                       "roofline": {"bound": "hbm", "kernel": a.fill_kernel_name(tm), "achieved": round(alg / fill_s / 1e9, 1), "peak": 8000.0,
                                    "unit": "GB/s", "frac": round(alg / fill_s / 1e9 / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src,
                                    "traffic_frac_of_peak": None if traffic is None else round(traffic / (dt / reps) / 8e12, 4),
                                    "algorithmic_bytes_per_pass": round(alg), "kernel_gcups": round(cells / fill_s / 1e9, 1),
                                    "if_traceback_were_spilled_frac": round(sum(len(ts[k]) * len(qs[k]) // 2 for k in range(n)) / fill_s / 1e9 / 8000.0, 4),
-                                   "note": ("one strip of 20-32 rows per lane-half, the lane kernel's column code with per-strip 16-bit baselines; VALU-issue "
-                                            "bound; " + ("no flags stored (score-only column code, 9 instructions per two cells), profiles/r04_e_secondary_pmc.txt"
+                                   "note": ("one strip of 17-32 rows per lane-half, the lane kernel's column code with per-strip 16-bit baselines; VALU-issue "
+                                            "bound; " + ("no flags stored (score-only column code: 8 instructions per two cells with base codes, 9 with the byte compare), profiles/r04_m_final_pmc.txt"
                                                          if not spilled else "flags of every cell stored, profiles/r02_d_strip_kernel.txt")
                                             if tm.fill_kernel == 6 else
                                             "packed int16 wavefront, 128 rows per wave, VALU-issue bound (36 VALU instructions per 128-cell step = 87 % of "
