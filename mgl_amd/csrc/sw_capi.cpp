@@ -240,6 +240,7 @@ constexpr int64_t kLaneMinPairs = 128 * 640;
 constexpr int64_t kLaneStoredMinPairs = 524288;
 // ... and a sorted chunk's whole waves of one geometry get a launch of their own from this many pairs on
 constexpr int64_t kLaneGroupMinPairs = 128 * 1024;
+constexpr int64_t kSideReserve = 16; // wave slots a sorted chunk's persistent grid leaves to the kernels of its left-over pairs (run_device)
 
 int max_lds_query_len()
 {
@@ -995,6 +996,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             }
         }
         const int n_parts = (int)parts.size();
+        // (a sorted chunk sized by slots: its left-overs run beside its bulk, see the launches below)
+        const char *const sre = getenv("MGL_SW_DEBUG_SIDE_RESERVE"); // (wave slots the bulk's grid leaves free for them; 0: one stream, the left-overs behind the grid; read per call)
+        const int64_t side_reserve = sre ? atoll(sre) : kSideReserve;
+        const bool side = P.group_regions && side_reserve > 0;
         std::vector<DpArgs> das((size_t)n_parts);
         std::vector<TbArgs> tas((size_t)n_parts);
         int64_t n_blocks = 0;
@@ -1035,7 +1040,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             da.gate_failed = nullptr;
             da.gate_timeout_ticks = 0;
             if (pt.lane && (lane_ck || da.grouped)) { // the persistent grid: its wave slots and, where the tiles outnumber them, a zeroed counter
-                da.lane_slots = (int)std::min<int64_t>(lane_slots, (pt.count + 127) / 128);
+                da.lane_slots = (int)std::min<int64_t>(lane_slots - (side && n_parts > 1 ? std::min<int64_t>(side_reserve, lane_slots / 2) : 0), (pt.count + 127) / 128);
                 if (ctx->cur_gate && !hooks) { // the direct form of a host entry: the inputs are still arriving
                     da.gate = ctx->cur_gate;
                     da.gate_failed = reinterpret_cast<int32_t *>(const_cast<int64_t *>(ctx->cur_gate) + 1);
@@ -1098,10 +1103,26 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         }
         hipStream_t tb_stream = overlap ? ctx->aux : fs;
         // this half was last read by the traceback of chunk k-2
-        if (overlap && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(fs, ctx->tb_done[h], 0));
+        if ((overlap || side) && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(fs, ctx->tb_done[h], 0));
+        if (side && n_parts > 1) {
+            // A sorted chunk's left-over pairs -- two short kernels and their walks, a millisecond in a row -- go FIRST and on the second
+            // stream, beside the bulk's persistent grid, which leaves them a few wave slots (kSideReserve): behind a grid that holds every
+            // slot they would wait for its end.  (Their inputs are complete: the host has waited for this chunk's sort, which waited for the
+            // caller's stream.)
+            if (k == 0 && ctx->ws_idle_set) HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ws_idle, 0));
+            for (int i = 0; i < n_parts; ++i) {
+                const Part &pt = parts[i];
+                if (pt.lane) continue;
+                HIP_TRY(ctx, pt.packed ? launch_dp16(das[i], pt.wpb, ctx->aux) : launch_dp(das[i], pt.wpb, pt.rows, ctx->aux));
+                HIP_TRY(ctx, launch_traceback(tas[i], ctx->aux));
+            }
+            HIP_TRY(ctx, hipEventRecord(ctx->tb_done[h], ctx->aux));
+            tb_pending[h] = true;
+        }
         if (pe[0]) HIP_TRY(ctx, hipEventRecord(pe[0], fs));
         for (int i = 0; i < n_parts; ++i) {
             const Part &pt = parts[i];
+            if (side && n_parts > 1 && !pt.lane) continue; // (on the second stream, above)
             TbArgs walk = tas[i];
             if (!fused_walk && !das[i].grouped) walk.cigar = nullptr; // (the waves of a sorted chunk's lane part walk their own paths too)
             HIP_TRY(ctx, pt.lane ? (lane_ck || das[i].grouped ? launch_dp16_lane_ck(das[i], walk, fs) : launch_dp16_lane(das[i], walk, pt.rows, fs))
@@ -1119,7 +1140,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         }
         if (pe[2]) HIP_TRY(ctx, hipEventRecord(pe[2], tb_stream));
         for (int i = 0; i < n_parts && !fused_walk; ++i) {
-            if (das[i].grouped || parts[i].tb_now) continue; // walked inside its fill kernel / behind its fill already
+            if (das[i].grouped || parts[i].tb_now || (side && n_parts > 1)) continue; // walked inside its fill kernel / behind its fill already
             HIP_TRY(ctx, score_only ? launch_scores_only(tas[i], tb_stream) : tas[i].packed16 == 6 ? launch_strip_ck_walk(tas[i], max_tl, max_ql, tb_stream) : launch_traceback(tas[i], tb_stream));
         }
         if (pe[3]) HIP_TRY(ctx, hipEventRecord(pe[3], tb_stream));
@@ -1128,6 +1149,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             tb_pending[h] = true;
         }
         if (auto_group && !hooks) { // this chunk's index arrays are free once its walk is done
+            if (side && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(tb_stream, ctx->tb_done[h], 0)); // (... on either stream)
             HIP_TRY(ctx, hipEventRecord(ctx->srt_free[k & 3], tb_stream));
             srt_used[k & 3] = true;
         }
