@@ -137,7 +137,7 @@ int mgl_sw_ctx_set_stripe_rows(mgl_sw_ctx *ctx, int rows);
  * mgl_sw_max_lds_query_len); 1 = never; 2..16 = always, with that many waves per pair (tests; identical
  * results) */
 int mgl_sw_ctx_set_cooperative(mgl_sw_ctx *ctx, int mode);
-/* queries of 1 024 bases and more against targets of up to 16 384: one pair per workgroup, every lane-half a strip of 17 .. 32
+/* queries of 1 024 bases and more (targets of any length: beyond 16 384 rows in several passes): one pair per workgroup, every lane-half a strip of 17 .. 32
  * target rows kept in registers (sw_dp16_strip.hip), per-strip 16-bit baselines.  0 (default) = taken for such batches when the
  * scoring parameters fit its static 16-bit window and enough of its strip slots would be busy; 1 = never; 2 = whenever
  * eligible, whatever the lengths (tests; identical results) */

@@ -289,6 +289,7 @@ struct BatchPlan {
     int coop_waves; // waves per pair of the workgroup kernels (0: not those)
     int strip_waves; // ... its waves per pair
     int strip_k; // ... strips per kept band (0: every flag stored)
+    int strip_passes; // ... passes of 128 W strips over the target (targets beyond 16 384 rows)
     bool auto_group; // a batch of mixed geometries whose chunks the library sorts by (tl, ql)
     bool lane_group; // ... the geometries with whole waves of 128 pairs through the checkpointed lane kernel
     int64_t lane_group_stride; // ... words per wave of that part
@@ -436,19 +437,27 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
     // per-strip baselines (sw_dp16_strip.hip); W waves per pair hold 128 W strips, W <= 4 keeps three workgroups' worth of
     // registers per SIMD
     bool strip16 = false;
-    int strip_waves = 0, strip_k = 0; // strip_k: strips per kept band of the form without stored flags (0: flags stored)
+    int strip_waves = 0, strip_k = 0, strip_passes = 1; // strip_k: strips per kept band of the form without stored flags (0: flags stored); strip_passes: passes of 128 W strips over the target
     {
         // waves per pair: as few as hold the target in strips of 32 rows -- but never three: workgroups of three waves run a
         // quarter slower than those of one, two or four (pairs of 8 / 10 / 12 kb with two or four waves: 3.09 / 2.69 / 2.99
         // TCUPS, with three: 2.40 / 2.43 / 2.58; three waves do not spread evenly over a CU's four SIMDs)
         int sw_ = ((max_tl + 31) / 32 + 127) / 128;
         if (sw_ == 3) sw_ = 4;
+        // targets beyond the 512 strips of four waves (16 384 rows): several passes of 512 strips each (the kernels without stored flags,
+        // round 4: a later pass takes the row above its first strip from what the pass before kept); before: the workgroup kernels, flags stored
+        int sp_ = 1;
+        if (sw_ > 4) {
+            sp_ = ((max_tl + 31) / 32 + 511) / 512;
+            sw_ = 4;
+        }
         // worth it when enough of the issued lanes are real cells: strips of the 128 W slots x useful steps of all steps
         // rows per strip: as few as still cover the longest target with these waves (fewer rows = fewer instructions per column)
+        // (several passes: 22 rows at least, so that a pass's 512 strips are whole bands of K = 2)
         int sr_ = 32;
-        for (int cand = 31; cand >= 17; --cand)
-            if ((max_tl + cand - 1) / cand <= 128 * sw_) sr_ = cand;
-        const double used = (double)((max_tl + sr_ - 1) / sr_) / (128.0 * sw_) * strip16_groups(max_ql) / (double)strip16_steps(max_ql, sw_);
+        for (int cand = 31; cand >= (sp_ > 1 ? 22 : 17); --cand)
+            if ((max_tl + cand - 1) / cand <= 128 * sw_ * sp_) sr_ = cand;
+        const double used = (double)((max_tl + sr_ - 1) / sr_) / (128.0 * sw_ * sp_) * strip16_groups(max_ql) / (double)strip16_steps(max_ql, sw_);
         // (measured against the kernels it replaces, pairs of n x n: 1.5 kb 1 354 against 1 124 GCUPS at used = 0.44; 2 kb 1 844 / 1 014;
         // 3 kb 2 474 / 870; 4 kb 2 987 / 1 385; 10 kb 2 480 / 1 824)
         const bool want = ctx->strip_kernel == 2 || (ctx->strip_kernel == 0 && (coop_waves || rows == 64) && ctx->cooperative < 2 && used >= 0.4);
@@ -458,10 +467,11 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
         // a pair takes 8 MB (16 where the entries do not pack): that form is the default where CIGARs are written; mgl_sw_ctx_set_lane_checkpoint(ctx, 1) keeps the flags)
         const int sk_ = (ctx->lane_checkpoint != 1 && d_cigar != nullptr && !score_only_hint) ? 64 / sr_ : 0;
         const bool fits = (sk_ ? strip16_ck_words(max_tl, max_ql, sr_, sk_) : tb_words_strip16(max_ql, sw_)) * 4 + (int64_t)sizeof(DpRecord) <= ctx->ws_limit / 2;
-        if (want && fits && !use16 && !use_lane && !d_matrix && ctx->precision != 32 && ctx->carry_memory == 0 && !ctx->stripe_rows && sw_ <= 4 &&
+        if (want && fits && !use16 && !use_lane && !d_matrix && ctx->precision != 32 && ctx->carry_memory == 0 && !ctx->stripe_rows && sw_ <= 4 && (sp_ == 1 || sk_ > 0) &&
             strip16_lds_bytes(max_ql, sw_) <= 64 * 1024 && strip16_range_ok(match, mismatch, gopen, gext)) {
             strip16 = true;
             strip_k = sk_;
+            strip_passes = sp_;
             strip_waves = sw_;
             coop16 = false;
             coop_waves = 0;
@@ -584,6 +594,7 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
     P.coop_waves = coop_waves;
     P.strip_waves = strip_waves;
     P.strip_k = strip_k;
+    P.strip_passes = strip_passes;
     P.auto_group = auto_group;
     P.lane_group = lane_group;
     P.lane_group_stride = lane_group_stride;
@@ -747,6 +758,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     const int coop_waves = P.coop_waves;
     const int strip_waves = P.strip_waves;
     const int strip_k = P.strip_k;
+    const int strip_passes = P.strip_passes;
     const bool auto_group = P.auto_group;
     const bool lane_group = P.lane_group;
     const int64_t lane_group_stride = P.lane_group_stride;
@@ -1029,6 +1041,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             da.score_only = score_only ? 1 : 0;
             da.grouped = pt.lane && auto_group ? 1 : 0;
             da.strip_k = strip16 ? strip_k : 0;
+            da.strip_passes = strip16 ? strip_passes : 0;
             {
                 const char *const sce = getenv("MGL_SW_DEBUG_STRIP_CODES"); // (0: the byte-compare form whatever the sequences; read per call: the tests run both forms)
                 da.strip_codes = strip16 && strip_k > 0 && !(sce && atoi(sce) == 0) && strip16_lds_bytes_codes(max_ql, strip_waves) <= 64 * 1024 ? 1 : 0;

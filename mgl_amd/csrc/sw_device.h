@@ -68,6 +68,7 @@ struct DpArgs {
     int score_only;           // packed kernel: no traceback flags (MGL_SW_FLAG_SCORE_ONLY)
     int grouped;              // sw_dp16_lane_ck_kernel: every wave of 128 pairs has its own geometry (a chunk sorted by geometry)
     int strip_k;              // sw_dp16_strip_kernel: 0 = the flags of every cell are stored; K > 0 = none are: rows and checkpoints of bands of K strips (strip16_ck_*)
+    int strip_passes;         // ... passes over the target: 2 * 64 * waves strips each (targets beyond 16 384 rows; 0 or 1: one)
     int strip_codes;          // ... and the LDS carve holds the query as one table dword per column (strip16_lds_bytes_codes): pairs whose targets are all ACGT run the base-code form
     int lane_slots;           // sw_dp16_lane_ck_kernel: wave slots of its persistent grid = regions at tb / scratch (lane_ck_slots)
     unsigned *tile_ctr;       // ... the counter its waves draw their next tile from (needed when the launch holds more tiles than slots) ...

@@ -60,6 +60,8 @@ __device__ __forceinline__ unsigned dpp_wave_shr1(unsigned lane0_value, unsigned
 // The tables (one dword per query column: byte c = 0 where the query base has code c, else 1; all ones for a query byte outside the
 // target's alphabet) are built once per pair in LDS, where the byte form keeps the query itself: four times the bytes, and no
 // instruction in the step -- each half reads its four columns' tables with one ds_read_b128.
+typedef int strip_int4 __attribute__((ext_vector_type(4)));
+
 template <int SR, bool NOTB, bool CODES>
 __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned char *smem)
 {
@@ -128,19 +130,11 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     }
     const unsigned level = pack2(STRIP_LEVEL, STRIP_LEVEL);
 
-    const int gA = ell, gB = NL + ell;         // this lane's two strips
-    const int i0A = SR * gA, i0B = SR * gB;    // rows i0 + 1 .. i0 + 32
+    // Targets beyond the 2 NL strips of 32 rows the workgroup's lanes hold (16 384 rows with four waves) take several PASSES (round 4;
+    // the kernels without stored flags): pass p computes strips 2 NL p .. 2 NL (p + 1) - 1, and where pass 0 gives strip 0 the border
+    // row by its formula, a later pass takes the row the pass before it kept below its last band (2 NL is a multiple of K = 2 there).
+    const int passes = NOTB ? max(a.strip_passes, 1) : 1;
     unsigned h[SR], f[SR], t[SR];
-#pragma unroll
-    for (int r = 0; r < SR; ++r) {
-        const int ra = i0A + r, rb = i0B + r; // 0-based row indices
-        const unsigned ba = (unsigned)(ra < tl ? a.t.at(t0, ra) : 0), bb = (unsigned)(rb < tl ? a.t.at(t0, rb) : 0);
-        if (CODES) // the row's selector (sw_lane_cell.h): its code for the low half's table, 4 + its code for the high half's
-            t[r] = CODE_SEL | (a.t.packed2 ? ba : (ba >> 1) & 3u) | ((a.t.packed2 ? bb : (bb >> 1) & 3u) << 16);
-        else
-            t[r] = ba | (bb << 16);
-        h[r] = f[r] = 0u;
-    }
     unsigned hd = 0u;
     int base_a = 0, base_b = 0;                // the halves' baselines (int32): true stored value = register + baseline
     unsigned bres = 0u;                        // the same, modulo 2^16, packed
@@ -163,6 +157,30 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     // (per step, below: bandA / bandB = the band of K strips a strip belongs to; rowoffA / rowoffB = that band's kept row as a 32-bit index off
     // the pair's uniform base; rowsA / rowsB = the strip whose last row is the row below a band -- and not the matrix's last rows: it writes that row)
 
+  for (int pass = 0; pass < passes; ++pass) {
+    const int G0 = pass * 2 * NL; // the pass's first strip
+    {
+        const int i0A = SR * (G0 + ell), i0B = SR * (G0 + NL + ell); // rows i0 + 1 .. i0 + SR
+#pragma unroll
+        for (int r = 0; r < SR; ++r) {
+            const int ra = i0A + r, rb = i0B + r; // 0-based row indices
+            const unsigned ba = (unsigned)(ra < tl ? a.t.at(t0, ra) : 0), bb = (unsigned)(rb < tl ? a.t.at(t0, rb) : 0);
+            if (CODES) // the row's selector (sw_lane_cell.h): its code for the low half's table, 4 + its code for the high half's
+                t[r] = CODE_SEL | (a.t.packed2 ? ba : (ba >> 1) & 3u) | ((a.t.packed2 ? bb : (bb >> 1) & 3u) << 16);
+            else
+                t[r] = ba | (bb << 16);
+            h[r] = f[r] = 0u;
+        }
+    }
+    // the row that enters this pass's first strip (passes behind the first): where the pass before kept it
+    const int top_band = G0 / K - 1;
+    const int *const top_raw = rows_raw + (size_t)max(top_band, 0) * row_stride, *const top_base = rows_base + (size_t)max(top_band, 0) * row_blocks;
+    strip_int4 top_v = {0, 0, 0, 0};
+    int top_b = 0;
+    if (pass > 0 && w == 0) { // (column group 0; the next group is fetched a step ahead, below)
+        top_v = __builtin_nontemporal_load(reinterpret_cast<const strip_int4 *>(top_raw));
+        top_b = __builtin_nontemporal_load(top_base);
+    }
     for (int s = 0; s < steps; ++s) {
         // What a lane knows about its two strips is a handful of small functions of its number.  Left to itself the compiler computes
         // every one of them (and every intermediate the steps below derive from them) once in front of the loop and keeps it in a
@@ -173,11 +191,13 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
         // -- some 30 instructions a step less: 10 kb pairs, 20 rows, 91.2 -> 86.3 ms per 4 608 pairs)
         int el = ell;
         if (NOTB && SR >= 25 && SR < MGL_STRIP_OCC2_FROM) asm volatile("" : "+v"(el));
-        const int gA = el, gB = NL + el, i0A = SR * gA, i0B = SR * gB;
-        const bool own_last_a = gA == gl, own_last_b = gB == gl;
-        const int bandA = gA / K, bandB = gB / K;
+        const int gA = el, gB = NL + el;       // the strips' places in the pass's pipeline ...
+        const int GA = G0 + gA, GB = G0 + gB;  // ... and their numbers in the pair
+        const int i0A = SR * GA, i0B = SR * GB;
+        const bool own_last_a = GA == gl, own_last_b = GB == gl;
+        const int bandA = GA / K, bandB = GB / K;
         const int rowoffA = (int)__umul24((unsigned)bandA, (unsigned)row_stride), rowoffB = (int)__umul24((unsigned)bandB, (unsigned)row_stride); // (both below 2^24: a full-rate multiply)
-        const bool rowsA = NOTB && (gA + 1) % K == 0 && (gA + 1) * SR < tl, rowsB = NOTB && (gB + 1) % K == 0 && (gB + 1) * SR < tl;
+        const bool rowsA = NOTB && (GA + 1) % K == 0 && (GA + 1) * SR < tl, rowsB = NOTB && (GB + 1) % K == 0 && (GB + 1) * SR < tl;
         const int cgA = s - gA, cgB = s - gB;
         const bool actA = cgA >= 0 && cgA < NCG && i0A < tl, actB = cgB >= 0 && cgB < NCG && i0B < tl;
         // ---- 1. what the strip above handed on in the previous step arrives column by column, right before it is used (below):
@@ -188,9 +208,14 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
             unsigned l0h = mb_in[u], l0e = mb_in[4 + u];
             if (w == 0) {
                 const int j = CPS * s + u + 1;
-                const int hb0 = border(j, gopen, gext, indel) + j * gext;
+                int hb0 = border(j, gopen, gext, indel) + j * gext, eb0 = hb0 - (gopen - gext);
+                if (pass > 0) { // {H, E} of the row above, as the pass before kept them: 16-bit values + their baseline (residues are all that is handed on)
+                    const int v = u == 0 ? top_v.x : u == 1 ? top_v.y : u == 2 ? top_v.z : top_v.w;
+                    hb0 = (v & 0xffff) + top_b;
+                    eb0 = (v >> 16) + top_b;
+                }
                 l0h = ((unsigned)hb0 & 0xffffu) | (l0h << 16);
-                l0e = ((unsigned)(hb0 - (gopen - gext)) & 0xffffu) | (l0e << 16);
+                l0e = ((unsigned)eb0 & 0xffffu) | (l0e << 16);
             }
             ih = dpp_wave_shr1(l0h, out_h[u]);
             ie = dpp_wave_shr1(l0e, out_e[u]);
@@ -338,7 +363,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
 #pragma unroll
                     for (int r = 0; r < SR; ++r)
                         if (i0 + r < tl) dst[r] = (int)__builtin_amdgcn_perm(f[r], h[r], 0x05040100u); // {H, F}: the low halves
-                    ck_base[(size_t)cc * ck_strips + gA] = base_a;
+                    ck_base[(size_t)cc * ck_strips + GA] = base_a;
                 }
                 if (ckB) {
                     int i0 = i0B;
@@ -348,9 +373,14 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
 #pragma unroll
                     for (int r = 0; r < SR; ++r)
                         if (i0 + r < tl) dst[r] = (int)__builtin_amdgcn_perm(f[r], h[r], 0x07060302u); // the high halves
-                    ck_base[(size_t)cc * ck_strips + gB] = base_b;
+                    ck_base[(size_t)cc * ck_strips + GB] = base_b;
                 }
             }
+        }
+        if (pass > 0 && w == 0) { // the next group of the row above (strip 0 is at column group s + 1 then; behind the query: the last group again)
+            const int cgn = min(s + 1, NCG - 1);
+            top_v = __builtin_nontemporal_load(reinterpret_cast<const strip_int4 *>(top_raw + CPS * cgn));
+            top_b = __builtin_nontemporal_load(top_base + (cgn >> 2));
         }
         // ---- 5. the last lane of every wave posts what it hands on; one barrier per step
         if (L == 63) {
@@ -365,11 +395,11 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
     }
 
     // ---- last column (sw.cpp:100-104: >= so the later row wins; compare scores, not stored values): every lane looks at the two
-    // columns it parked, then the candidates meet in one 64-bit LDS atomic (score first, then the larger row)
+    // columns it parked in this pass, then (after the last pass) the candidates meet in one 64-bit LDS atomic (score first, then the larger row)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        int i0 = half ? i0B : i0A;
+        int i0 = SR * (G0 + (half ? NL : 0) + ell);
         asm volatile("" : "+v"(i0)); // (opaque: the rows' numbers are computed here, not kept in registers -- spilled ones -- from the prologue on)
         if (i0 < tl) {
             const unsigned *cp = cap + (half ? 33 : 0);
@@ -385,6 +415,8 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
             }
         }
     }
+    __syncthreads(); // (the next pass's first steps must not overtake a wave that is still in this one: the mailboxes)
+  } // passes
     if (best_i > 0) atomicMax(key, ((unsigned long long)(unsigned)(best + 0x40000000) << 32) | (unsigned)best_i);
     __threadfence();
     __syncthreads();
@@ -393,7 +425,7 @@ __device__ __forceinline__ void sw_dp16_strip_body(const DpArgs &a, unsigned cha
         int rm = NEG_INF, rd = 0x7fffffff, rj = 0x7fffffff;
         for (int j = 1 + L; j <= ql; j += 64) {
             const unsigned v = (unsigned)__builtin_nontemporal_load(rowbuf + 2 * j);
-            const int sc = (gl >= NL ? hi16(v) : lo16(v)) + __builtin_nontemporal_load(rowbuf + 2 * j + 1) - (tl + j) * gext, d = abs(tl - j);
+            const int sc = (gl % (2 * NL) >= NL ? hi16(v) : lo16(v)) + __builtin_nontemporal_load(rowbuf + 2 * j + 1) - (tl + j) * gext, d = abs(tl - j);
             const bool take = sc > rm || (sc == rm && (d < rd || (d == rd && j < rj)));
             rm = take ? sc : rm;
             rd = take ? d : rd;

@@ -91,8 +91,13 @@ def test_configs3_long_reads_take_the_strip_kernel():
     assert p.chunk_pairs == 2304 and p.chunks == 1, "17 MB of kept rows per pair: the whole batch is one launch (three chunks measured slower)"
     p = plan(n=2304, max_tl=10300, max_ql=10300, parameters=GATK, workspace=16 << 30)
     assert p.fill_kernel == STRIP16 and p.chunks > 1 and p.workspace_halves == 2, "a smaller workspace: chunks, two halves in flight"
-    p = plan(n=8, max_tl=31000, max_ql=30500, parameters=GATK, workspace=BENCH_WS)   # beyond the strip kernel's 16 384 rows
-    assert p.fill_kernel == COOP16 and p.waves_per_pair == 16
+    # beyond the 16 384 rows that four waves' strips hold: round 4 takes the target in two passes of 512 strips (31 rows each: whole
+    # bands of two strips per pass); round 3 ran such pairs on the workgroup kernel with every flag stored (967 GCUPS at 30 kb; now 4 620)
+    p = plan(n=8, max_tl=31000, max_ql=30500, parameters=GATK, workspace=BENCH_WS)
+    assert p.fill_kernel == STRIP16 and p.waves_per_pair == 4 and p.rows == 31 and p.traceback == 1
+    # ... and queries whose bytes no longer fit the LDS carve keep the workgroup kernel
+    p = plan(n=8, max_tl=31000, max_ql=70000, parameters=GATK, workspace=BENCH_WS)
+    assert p.fill_kernel == COOP16
 
 
 def test_tl1000_variant():
