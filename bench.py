@@ -12,7 +12,10 @@ by default 10 M Illumina-style 150 bp reads, each against its own 256-base refer
 With N > 1 the ONE seeded 10 M-pair workload is sharded contiguously over the ranks (strong scaling, BASELINE.json
 configs[2] / SURVEY.md 8d config 3: 1.25 M pairs per GPU at N = 8; each rank generates only its shard), there is no
 data-path collective, and the step ends with the RCCL gather of the int32 scores onto rank 0 (north_star);
-`--scaling weak` gives every rank its own --pairs instead.
+`--scaling weak` gives every rank its own --pairs instead.  With N > 1 a rank keeps TWO steps in flight (`--steps-in-flight`,
+`config.steps_in_flight`: two contexts on two streams take the steps in turn, so that the tail of one shard's launch -- a tenth
+of it at 1.25 M pairs -- runs beside the start of the next; the line also carries rank 0's step time one at a time); on one GPU the
+default is one in flight, and the roofline's launch durations are those of launches that have the chip to themselves.
 
 Rank 0 prints ONE JSON line.  `value` = whole-job GCUPS = sum(tl*ql) over all ranks and steps /
 max-over-ranks wall time.  `roofline` prices the dominant kernel (sw_dp_kernel) against HBM
@@ -21,6 +24,7 @@ path (oracle/_ref, built from /root/reference in the authoring container) timed 
 cores on a bounded sample of the same batch and cross-checked against the GPU results.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -406,6 +410,11 @@ def main():
                     help=f"workspace per GPU for the headline; default: {DEFAULT_WORKSPACE_GIB:.0f} GiB (the 10 M-pair batch is one launch of a persistent grid), "
                          "or what the card has free beside the batch if that is less")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline leg")
+    ap.add_argument("--steps-in-flight", type=int, choices=(1, 2), default=None,
+                    help="2: two contexts on two streams take the steps in turn, so that the next step's grid moves into the wave slots the "
+                         "last one's tail leaves free (default with more than one rank, where a step is a shard of 1.25 M pairs and its tail "
+                         "a tenth of it); 1: one context, one stream (default on one GPU: the launch durations of the roofline stay those of "
+                         "launches that have the chip to themselves)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (long reads, PairHMM, protein)")
     ap.add_argument("--no-extra", action="store_true", help="skip the PCIe-inclusive and tl=1000 legs (SURVEY 8d)")
     ap.add_argument("--dump-scores", help="rank 0 writes the gathered int32 score vector of the last step here (.npy)")
@@ -460,18 +469,43 @@ def main():
         args.workspace_gib = max(1.0, min(DEFAULT_WORKSPACE_GIB, (free - (12 << 30)) / (1 << 30)))
     aligner.set_workspace(int(args.workspace_gib * (1 << 30)))
 
+    # Steps in flight.  A rank's shard of configs[2] is 1.25 M pairs: five tiles per wave slot of the persistent grid, and the launch's
+    # last tiles leave most slots idle for a millisecond of its nine.  A caller with batch after batch to align keeps TWO in
+    # flight -- a context and a stream each, taken in turn -- and the next grid's workgroups move into the slots the tail frees:
+    # 7.8 ms per step instead of 8.9, the long-launch rate (scripts/step_overlap_probe.py).  Every step is still a whole pass over the
+    # shard into result arrays of its own; K steps are K passes.
+    in_flight = args.steps_in_flight or (2 if distributed else 1)
+    lanes = [(aligner, batch, None)]
+    if in_flight == 2:
+        import copy
+        aligner2 = MicrosoftSmithWaterman(dev_index)
+        aligner2.set_workspace(int(args.workspace_gib * (1 << 30)))
+        batch2 = copy.copy(batch)  # the same inputs, result arrays of its own
+        for name in ("offsets", "scores", "cigars", "cigar_len", "status"):
+            setattr(batch2, name, torch.empty_like(getattr(batch, name)))
+        lanes = [(aligner, batch, torch.cuda.Stream(dev)), (aligner2, batch2, torch.cuda.Stream(dev))]
+        # (the batch was generated on torch's current stream: the two side streams must not start before its kernels have finished --
+        # a grid that reads index arrays still being written walks out of its sequences)
+        torch.cuda.synchronize(dev)
+        for _al, _bt, st in lanes:
+            st.wait_stream(torch.cuda.current_stream(dev))
+    step_no = [0]
+
     def step():
-        batch.run(aligner, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP)
-        if distributed:
-            # the only inter-GPU exchange: ScoreMax.max of every pair onto rank 0 (RCCL gather), in shard order
-            if args.scaling == "strong":
-                return dist.gather_scores(batch.scores[:, 2].contiguous(), n_total, dst=0)
-            return dist.gather_scores(batch.scores[:, 2].contiguous(), n_total, dst=0)
-        return batch.scores[:, 2]
+        al, bt, st = lanes[step_no[0] % len(lanes)]
+        step_no[0] += 1
+        with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
+            bt.run(al, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP)
+            if distributed:
+                # the only inter-GPU exchange: ScoreMax.max of every pair onto rank 0 (RCCL gather), in shard order
+                return dist.gather_scores(bt.scores[:, 2].contiguous(), n_total, dst=0)
+            return bt.scores[:, 2]
 
     gathered = None
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, len(lanes) if args.warmup else 0)):
         step()
+    torch.cuda.synchronize(dev)
+    step_no[0] = 0
     # HIP events around every kernel launch, on the streams the kernels run on (asynchronous: they are
     # read back after the timed region) -> the MEAN launch duration over the timed steps for the roofline
     aligner.set_profiling(3)  # summed over the timed steps, read once afterwards
@@ -484,15 +518,33 @@ def main():
     dist.barrier()
     elapsed = dist.max_over_ranks(time.perf_counter() - t0, dev)
 
-    status_bad = int((batch.status != 0).sum().item())
+    status_bad = int(sum(int((bt.status != 0).sum().item()) for _al, bt, _st in lanes))
+    if in_flight == 2:
+        assert torch.equal(lanes[0][1].scores, lanes[1][1].scores) and torch.equal(lanes[0][1].cigars, lanes[1][1].cigars), "the two contexts disagree"
 
     tm = aligner.timing()  # kernel durations summed over the timed steps (HIP events recorded in the timed region)
+    if in_flight == 2:
+        # (two grids side by side: a launch's events span the other one's tail too.  The roofline's launch duration is that of ONE more
+        # launch, untimed, with the chip to itself)
+        torch.cuda.synchronize(dev)
+        aligner.set_profiling(1)
+        for _ in range(2):  # (the second one: the first follows an idle moment of the chip)
+            batch.run(aligner, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP)
+        torch.cuda.synchronize(dev)
+        tm = aligner.timing()
+        # ... and, for the reader of the line, what this rank's steps take ONE at a time (five of them, untimed, no gather)
+        aligner.set_profiling(0)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            batch.run(aligner, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP)
+        torch.cuda.synchronize(dev)
+        one_in_flight_ms = (time.perf_counter() - t1) / 5 * 1e3
     # the shader clock under this load, measured inside the kernel on one extra, untimed step (profiling level 2: every wave stamps
     # s_memtime and the 100 MHz s_memrealtime around its life): what the issue-bound fraction below is computed against
     clock_mhz = 0
     try:
         aligner.set_profiling(2)
-        step()
+        batch.run(aligner, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP)
         torch.cuda.synchronize(dev)
         clock_mhz = int(aligner.timing().clock_mhz)
     except Exception:  # noqa: BLE001 -- no clock, no issue fraction
@@ -510,7 +562,7 @@ def main():
     # (tm sums the HIP events of every launch of the timed loop: mgl_sw_ctx_set_profiling(ctx, 3))
     launches = max(1, tm.dp_launches)
     avg_launch_s = tm.dp_ms / 1e3 / launches
-    pairs_per_launch = n_local * args.steps / launches
+    pairs_per_launch = n_local * (1 if in_flight == 2 else args.steps) / launches
     spills = fill_kernel not in ("sw_dp16_lane_ck_kernel",)  # every other fill kernel writes the 4-bit traceback to HBM
     cigar_bytes = float(batch.cigar_len.float().mean().item())
     per_pair = algorithmic_bytes_per_pair(args.tl, args.ql, args.input == "2bit", spills, cigar_bytes)
@@ -557,10 +609,16 @@ def main():
             "pairs_total": n_total, "pairs_per_gpu": n_local, "target_len": args.tl, "query_len": args.ql, "input": args.input,
             "parallelism": (f"pairs sharded over {world} GPU(s), one process per GPU, score gather onto rank 0 only"
                             if world > 1 else "1 GPU"),
+            "steps_in_flight": in_flight,
+            **({"rank0_ms_per_step_one_in_flight": round(one_in_flight_ms, 3),
+                "steps_in_flight_note": "two contexts on two streams take the steps in turn: the next step's grid moves into the wave slots the last one's tail "
+                                        "leaves free; every step is a whole pass over the shard into result arrays of its own.  roofline.avg_launch_ms is that of "
+                                        "one more launch with the chip to itself (a launch's events beside another grid span that grid's tail too)"}
+               if in_flight == 2 else {}),
         },
         "reads_per_s": round(n_total * args.steps / elapsed, 1),
-        "kernel_ms": ({fill_kernel: round(tm.dp_ms / args.steps, 3), "path_walk": "inside the fill kernel (every lane walks its own two pairs)",
-                       "launches_per_step": launches / args.steps, "averaged_over_steps": args.steps}
+        "kernel_ms": ({fill_kernel: round(tm.dp_ms / (1 if in_flight == 2 else args.steps), 3), "path_walk": "inside the fill kernel (every lane walks its own two pairs)",
+                       "launches_per_step": launches / (1 if in_flight == 2 else args.steps), "averaged_over_steps": 1 if in_flight == 2 else args.steps}
                       if fill_kernel in ("sw_dp16_lane_kernel", "sw_dp16_lane_ck_kernel") else
                       {fill_kernel: round(tm.dp_ms / args.steps, 3), "sw_traceback_kernel": round(tm.tb_ms / args.steps, 3),
                        "launches_per_step": launches / args.steps, "averaged_over_steps": args.steps}),
