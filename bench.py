@@ -196,7 +196,7 @@ def secondary_workloads():
         # rounds of the chip for the strip kernel with four waves per pair, 256 CUs x 3 workgroups; 37 GiB of kept rows and checkpoints),
         # passes repeated for 30 s; CPU baseline (the reference's align_avx) on 64 of the pairs.  (Rounds 1-3 ran 2 304 pairs per pass:
         # 4 086 GCUPS on this build against 4 357 -- the walk kernel, one wave per pair, fills the chip only from ~ 4 000 pairs on.)
-        "long_reads_10kb (configs[3] shape, 4608 pairs per pass, >= 30 s)": ["scripts/long_read_bench.py", "4608", "230", "10000", "1", "--seconds", "30",
+        "long_reads_10kb (configs[3] shape, 4608 pairs per pass, >= 30 s)": ["scripts/long_read_bench.py", "4608", "110", "10000", "1", "--seconds", "30", "--in-flight-seconds", "6",
                                                                              "--cpu-pairs", "64", "--json"],
         "mixed_read_lengths (4 M reads of 100-150 bases x 256-base windows, no geometry promise from the caller)": ["scripts/grouped_bench.py", "4000000", "100", "--json"],
         "pairhmm_150x300 (SURVEY 8f rank 3, 1.6 M pairs)": ["scripts/pairhmm_bench.py", "--steps", "3", "--cpu-seconds", "3", "--json"],

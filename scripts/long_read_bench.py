@@ -22,6 +22,7 @@ ap.add_argument("check", nargs="?", type=int, default=2, help="pairs compared wi
 ap.add_argument("--seconds", type=float, default=0, help="repeat the batch until this much GPU time has been spent")
 ap.add_argument("--cpu-pairs", type=int, default=0, help="time the reference's CPU path (oracle/_ref) on this many pairs")
 ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic pairs (the batch cycles through them)")
+ap.add_argument("--in-flight-seconds", type=float, default=0, help="after the timed passes: this many seconds of passes with TWO in flight (a second context and stream)")
 ap.add_argument("--json", action="store_true", help="print one JSON line with the figures and a roofline object (bench.py reads it)")
 args = ap.parse_args()
 PARAMS = (200, -150, 260, 11)  # GATK_PARAMETERS after the sign normalisation of the JNI boundary
@@ -57,6 +58,37 @@ print(f"{n} pairs of ~{length} x {length}, {reps} pass(es): {dt*1e3/reps:.1f} ms
       f"{dt:.1f} s (last pass: fill {tm.dp_ms:.1f} ms in {tm.dp_launches} launches, traceback {tm.tb_ms:.1f} ms, "
       f"traceback workspace {tm.tb_bytes/2**30:.1f} GiB)", flush=True)
 assert int((b.status != 0).sum()) == 0
+two_in_flight = None
+if args.in_flight_seconds > 0:
+    # pass after pass with TWO in flight: a second context (its own workspace) and result arrays, two streams taking the passes in turn --
+    # the walk of one pass (one wave per pair) runs beside the fill of the next
+    a.set_profiling(0)
+    a2 = MicrosoftSmithWaterman(0)
+    a2.set_workspace(int(args.workspace_gib * (1 << 30)))
+    b2 = device_batch.DeviceBatch(b.targets, b.t_off, b.queries, b.q_off, b.max_tl, b.max_ql, b.cigar_stride)
+    lanes = [(a, b, torch.cuda.Stream()), (a2, b2, torch.cuda.Stream())]
+    torch.cuda.synchronize()
+    for al, bt, st in lanes:
+        with torch.cuda.stream(st):
+            bt.run(al)
+    torch.cuda.synchronize()
+    k, t1 = 0, time.perf_counter()
+    while True:
+        for al, bt, st in lanes:
+            with torch.cuda.stream(st):
+                bt.run(al)
+        k += 2
+        if k % 8 == 0:  # (the host's clock: keep the queues a few passes deep, not hundreds)
+            torch.cuda.synchronize()
+            if time.perf_counter() - t1 >= args.in_flight_seconds:
+                break
+    torch.cuda.synchronize()
+    dt2 = time.perf_counter() - t1
+    assert torch.equal(b.scores, b2.scores) and torch.equal(b.cigars, b2.cigars) and int((b2.status != 0).sum()) == 0
+    two_in_flight = {"gcups": round(cells * k / dt2 / 1e9, 1), "ms_per_pass": round(dt2 * 1e3 / k, 2), "passes": k, "seconds": round(dt2, 1)}
+    print(f"two passes in flight (two contexts, two streams in turn): {dt2*1e3/k:.1f} ms per pass = {cells*k/dt2/1e9:.1f} GCUPS over {dt2:.1f} s; "
+          f"both contexts' results identical", flush=True)
+    a2.close()
 if args.json:
     import json
     # HBM roofline of the fill kernel (north_star's roofline; the kernel is VALU-issue bound): algorithmic bytes per pair =
@@ -78,7 +110,7 @@ if args.json:
         pass
     walk_name = "sw_traceback_wave_kernel" if spilled else "sw_strip_ck_walk_kernel"
     print(json.dumps({"gcups": round(cells * reps / dt / 1e9, 1), "pairs": n, "length": length, "passes": reps, "seconds": round(dt, 1),
-                      "ms_per_pass": round(dt * 1e3 / reps, 2),
+                      "ms_per_pass": round(dt * 1e3 / reps, 2), "two_passes_in_flight": two_in_flight,
                       "kernel_ms": {a.fill_kernel_name(tm): round(tm.dp_ms, 2), walk_name: round(tm.tb_ms, 2), "launches": tm.dp_launches},
                       "traceback": "4 bits per cell in HBM" if spilled else "none stored: kept rows and checkpoints (10 MB per 10 kb pair), the walk recomputes the blocks the path crosses",
                       "roofline": {"bound": "hbm", "kernel": a.fill_kernel_name(tm), "achieved": round(alg / fill_s / 1e9, 1), "peak": 8000.0,
