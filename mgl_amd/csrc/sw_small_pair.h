@@ -130,9 +130,9 @@ struct KeptScores {
     __device__ __forceinline__ int at(int i, int j) const
     {
         if (i == 0 || j == 0) return edge_score(i + j, gopen, gext, indel);
-        const int un = base - (i + j) * gext;
-        if (wide) return (int)hm[(j - 1) * CS + (i - 1)] + un;
-        const uint32_t w = hm[(j - 1) * CS + ((i - 1) >> 1)];
+        const int un = base - __mul24(i + j, gext); // (24-bit products: one pass each where a 32-bit multiply takes four)
+        if (wide) return (int)hm[__mul24(j - 1, CS) + (i - 1)] + un;
+        const uint32_t w = hm[__mul24(j - 1, CS) + ((i - 1) >> 1)];
         return (int)(int16_t)(((i - 1) & 1) ? (w >> 16) : (w & 0xffffu)) + un;
     }
 };
