@@ -1,7 +1,7 @@
 """Differential run over long pairs with the library's own kernel choice (strip kernel, 16-bit workgroup kernel, int32 workgroup
 kernel, by geometry and parameters): batches of random pairs -- related (ONT-style noise, with a long deletion or insertion now and
 then) or unrelated, lengths drawn per batch from a different range -- against the reference's own code (oracle/_ref, AVX2 path) on
-the host cores: offsets and CIGAR bytes must be identical.  python scripts/long_fuzz.py [batches] [pairs per batch]"""
+the host cores: offsets and CIGAR bytes must be identical.  python scripts/long_fuzz.py [batches] [pairs per batch] [passes]"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -17,6 +17,8 @@ rng = synth.rng_for(31337)
 lib = ol.ref(); cores = host_cores()
 PARAMS = [(200, -150, 260, 11), (100, -100, 300, 10), (25, -50, 110, 6), (400, -300, 500, 20)]
 RANGES = [(1500, 4095), (4096, 4400), (4096, 8192), (8000, 12288), (9500, 10500), (12289, 16384), (3000, 16500), (600, 2500), (15000, 20000)]
+if len(sys.argv) > 3 and sys.argv[3] == "passes":  # targets beyond 16 384 rows: several passes of the strip kernel (round 4)
+    RANGES = [(16385, 17000), (17000, 24000), (24000, 33000), (32700, 40000)]
 a = MicrosoftSmithWaterman(0)
 a.set_workspace(64 << 30)
 total = bad = 0
