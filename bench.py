@@ -509,12 +509,20 @@ def main():
     lanes = [(aligner, batch, None)]
     if in_flight == 2:
         import copy
-        aligner2 = MicrosoftSmithWaterman(dev_index)
-        aligner2.set_workspace(int(args.workspace_gib * (1 << 30)))
-        batch2 = copy.copy(batch)  # the same inputs, result arrays of its own
-        for name in ("offsets", "scores", "cigars", "cigar_len", "status"):
-            setattr(batch2, name, torch.empty_like(getattr(batch, name)))
-        lanes = [(aligner, batch, torch.cuda.Stream(dev)), (aligner2, batch2, torch.cuda.Stream(dev))]
+        try:
+            aligner2 = MicrosoftSmithWaterman(dev_index)
+            aligner2.set_workspace(int(args.workspace_gib * (1 << 30)))
+            batch2 = copy.copy(batch)  # the same inputs, result arrays of its own
+            for name in ("offsets", "scores", "cigars", "cigar_len", "status"):
+                setattr(batch2, name, torch.empty_like(getattr(batch, name)))
+            torch.cuda.synchronize(dev)
+            batch2.run(aligner2, GATK_PARAMETERS, SWOverhangStrategy.SOFTCLIP)  # (its workspace exists from here on -- or the card has no room for it)
+            torch.cuda.synchronize(dev)
+            lanes = [(aligner, batch, torch.cuda.Stream(dev)), (aligner2, batch2, torch.cuda.Stream(dev))]
+        except Exception as e:  # noqa: BLE001 -- no room for a second context: one step in flight, as on one GPU
+            print(f"bench: a second context could not be set up ({e!r}): one step in flight", file=sys.stderr)
+            in_flight = 1
+    if in_flight == 2:
         # (the batch was generated on torch's current stream: the two side streams must not start before its kernels have finished --
         # a grid that reads index arrays still being written walks out of its sequences)
         torch.cuda.synchronize(dev)
