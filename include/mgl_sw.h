@@ -29,7 +29,11 @@
 extern "C" {
 #endif
 
-#define MGL_SW_VERSION 101
+/* 102 (round 5): mgl_sw_plan has its round-4 fields workspace_fixed_bytes / resident_waves UNDER A NEW NUMBER (round 4 grew the struct and
+ * kept 101), mgl_sw_explain_sized and mgl_sw_ctx_check are new.  A caller built against another number must not pass its mgl_sw_plan to
+ * mgl_sw_explain (the library writes sizeof(mgl_sw_plan) of ITS header): compare mgl_sw_version() with MGL_SW_VERSION at load time -- the
+ * Python mirror does (mgl_amd/_lib.py) -- or call mgl_sw_explain_sized, which never writes beyond the size it is given. */
+#define MGL_SW_VERSION 102
 
 /* overhang strategies: sw_common.h:22-25 (= MicrosoftSmithWaterman.java:39-56) */
 #define MGL_SW_OS_SOFTCLIP 0x01
@@ -178,7 +182,16 @@ int mgl_sw_ctx_set_profiling(mgl_sw_ctx *ctx, int enable);
  * planning (MGL_SW_ERR_UNSUPPORTED, ...). */
 int mgl_sw_explain(mgl_sw_ctx *ctx, int64_t workspace_limit, int64_t n, int max_tl, int max_ql, int match, int mismatch, int gopen,
                    int gext, int strategy, int flags, int packed2, int entry, mgl_sw_plan *out);
+/* ... the same for a caller whose mgl_sw_plan may be older or newer than the library's: at most out_size bytes of *out are written (the
+ * struct only ever grows at its end), and what the library does not know of a larger struct is zeroed. */
+int mgl_sw_explain_sized(mgl_sw_ctx *ctx, int64_t workspace_limit, int64_t n, int max_tl, int max_ql, int match, int mismatch, int gopen,
+                         int gext, int strategy, int flags, int packed2, int entry, mgl_sw_plan *out, size_t out_size);
 int mgl_sw_ctx_get_timing(mgl_sw_ctx *ctx, mgl_sw_timing *out); /* waits for the last call's kernels */
+/* What a kernel found out about itself AFTER the call that enqueued it returned (the device entries do not wait for their kernels):
+ * today, a persistent grid of sw_dp16_lane_ck_kernel that drew a tile number no launch of its size can draw -- its counter did not
+ * stand at zero, tiles may be undone.  Synchronise the stream, then ask: MGL_SW_OK, or MGL_SW_ERR_DEVICE (sticky: every later call on
+ * the context reports it too; destroy the context).  The host entries ask by themselves before they return.  Waits for nothing. */
+int mgl_sw_ctx_check(mgl_sw_ctx *ctx);
 
 /* Sign normalisation of the JNI boundary
  * (..._MicrosoftSmithWaterman.cpp:51-55): match > 0, mismatch < 0, open > 0,

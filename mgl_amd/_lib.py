@@ -29,7 +29,11 @@ SYMBOLS = (
     "mgl_sw_multi_create", "mgl_sw_multi_destroy", "mgl_sw_multi_device_count", "mgl_sw_multi_ctx", "mgl_sw_multi_set_workspace",
     "mgl_sw_multi_last_error", "mgl_sw_align_batch_multi", "mgl_sw_multi_last_shards", "mgl_sw_shard_by_cells",
     "mgl_sw_align_batch_2bit", "mgl_sw_register_host_buffer", "mgl_sw_unregister_host_buffer", "mgl_sw_explain",
+    "mgl_sw_explain_sized", "mgl_sw_ctx_check",
 )
+# MGL_SW_VERSION of the include/mgl_sw.h this mirror was written against: the structs below (Plan, Timing) are that header's, and the
+# library writes sizeof(ITS struct) through the pointers it is given -- so a library of another version is refused at load time
+ABI_VERSION = 102
 
 
 class Score(C.Structure):
@@ -92,6 +96,8 @@ def lib():
     L = C.CDLL(LIB_PATH, mode=os.RTLD_NOW)
     vp, i32p, i64p, cp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_char_p
     L.mgl_sw_version.restype = C.c_int
+    if L.mgl_sw_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} is MGL_SW_VERSION {L.mgl_sw_version()}, this mirror of include/mgl_sw.h is {ABI_VERSION}: rebuild (make -C mgl_amd/csrc)")
     L.mgl_sw_strerror.restype = C.c_char_p
     L.mgl_sw_strerror.argtypes = [C.c_int]
     L.mgl_sw_device_count.restype = C.c_int
@@ -153,6 +159,8 @@ def lib():
     L.mgl_sw_align_batch_2bit.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int] + [C.c_int] * 5 + [
         vp, vp, vp, C.c_int, vp, vp, C.c_int]
     L.mgl_sw_explain.argtypes = [vp, C.c_int64, C.c_int64] + [C.c_int] * 10 + [C.POINTER(Plan)]
+    L.mgl_sw_explain_sized.argtypes = [vp, C.c_int64, C.c_int64] + [C.c_int] * 10 + [vp, C.c_size_t]
+    L.mgl_sw_ctx_check.argtypes = [vp]
     L.mgl_sw_register_host_buffer.argtypes = [vp, vp, C.c_size_t]
     L.mgl_sw_unregister_host_buffer.argtypes = [vp, vp]
     _lib = L

@@ -67,11 +67,13 @@ struct mgl_sw_ctx {
     int64_t ws_limit = kDefaultWorkspace;
     // kernel workspace, two halves: the traceback of chunk k (aux stream) overlaps the fill of chunk k+1
     DevBuf tb[2], rec[2], bnd[2], diag, scratch;
-    // sw_dp16_lane_ck_kernel's tile counters: a ring of words, one per launch (zeroed once; a word comes round again after kTileCounters
-    // launches of this context, which are ordered behind each other by then: same half, same stream)
+    // sw_dp16_lane_ck_kernel's tile counters: a ring of entries {draws, waves out}, one per launch, a 64-byte line each (zeroed once; an
+    // entry comes round again after kTileCounters launches of this context, which are ordered behind each other by then: same half,
+    // same stream).  The host keeps NO copy of where an entry stands: the grid's last wave out puts it back to zero, however the launch
+    // ended (sw_dp16_lane_ck.hip) -- round 4's host-side copy went out of step when a gated launch was called off.
     DevBuf tile_ctr;
     uint64_t tile_seq = 0;
-    unsigned tile_total[64] = {}; // where each word of the ring stands (a launch of T > slots tiles moves its word on by exactly T): no resets
+    int32_t *pin_fault = nullptr; // pinned host word: a wave drew a tile number no launch of its size can draw (DpArgs::grid_fault); sticky, see grid_fault_check()
     // the DIRECT form of the host entries (mgl_sw_align_batch_2bit with every array page-locked by the caller): ONE launch of the persistent
     // grid while the copy engines bring the inputs in, gated by a word in pinned host memory; the results are written by the waves straight
     // into the caller's arrays (whole lines out of LDS)
@@ -176,6 +178,7 @@ const DebugKnobs &debug_knobs()
     return k;
 }
 constexpr int kTileCounters = 64;
+constexpr int kTileCounterWords = 16; // an entry's two words on a 64-byte line of their own
 constexpr int kHostChunks = 32; // a host entry cuts a batch into about this many chunks (the units of its copy / compute pipeline)
 
 int geom_of(int flags)
@@ -201,6 +204,16 @@ int hip_fail(mgl_sw_ctx *ctx, hipError_t e, const char *where)
         hipError_t e_ = (call);                                \
         if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
     } while (0)
+
+// A persistent grid whose wave drew a tile number that no launch of its size can draw has left tiles undone (its counter did not stand
+// at zero: sw_dp16_lane_ck.hip).  That cannot happen by anything the library does -- which is exactly why it is checked: the flag is
+// sticky, every later call on the context and mgl_sw_ctx_check() report it, no result after it is handed out as good.
+int grid_fault_check(mgl_sw_ctx *ctx)
+{
+    if (ctx->pin_fault && __atomic_load_n(ctx->pin_fault, __ATOMIC_ACQUIRE) != 0)
+        return fail(ctx, MGL_SW_ERR_DEVICE, "a persistent grid found its tile counter out of range: results of this context since its last good check are not valid");
+    return MGL_SW_OK;
+}
 
 bool strategy_ok(int s)
 {
@@ -659,6 +672,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     if (n < 0 || !tset.data || !tset.off || !qset.data || !qset.off || !d_offset || !d_cigar || cigar_stride < 1 ||
         max_tl < 1 || max_ql < 1 || !strategy_ok(strategy))
         return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch_device: bad argument");
+    if (!explain) {
+        const int frc = grid_fault_check(ctx);
+        if (frc != MGL_SW_OK) return frc;
+    }
     if (d_matrix) {
         // substitution-matrix scoring: `match` / `mismatch` carry the largest / smallest matrix entry (range check and
         // offset representation of the packed kernel); only the gap penalties go through the sign normalisation
@@ -829,8 +846,12 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         HIP_TRY(ctx, ctx->rec[h].reserve((size_t)chunk * sizeof(DpRecord)));
     }
     if (lane_slots > 0 && !ctx->tile_ctr.p) {
-        HIP_TRY(ctx, ctx->tile_ctr.reserve(kTileCounters * sizeof(unsigned)));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->tile_ctr.p, 0, kTileCounters * sizeof(unsigned), stream));
+        HIP_TRY(ctx, ctx->tile_ctr.reserve((size_t)kTileCounters * kTileCounterWords * sizeof(unsigned)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->tile_ctr.p, 0, (size_t)kTileCounters * kTileCounterWords * sizeof(unsigned), stream));
+    }
+    if (lane_slots > 0 && !ctx->pin_fault) {
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->pin_fault), 64, hipHostMallocDefault));
+        memset(ctx->pin_fault, 0, 64);
     }
 
     if (use_scratch) {
@@ -1048,7 +1069,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             }
             da.lane_slots = 0;
             da.tile_ctr = nullptr;
-            da.tile_base = 0;
+            da.grid_fault = nullptr;
             da.gate = nullptr;
             da.gate_failed = nullptr;
             da.gate_timeout_ticks = 0;
@@ -1058,11 +1079,13 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                     da.gate = ctx->cur_gate;
                     da.gate_failed = reinterpret_cast<int32_t *>(const_cast<int64_t *>(ctx->cur_gate) + 1);
                     da.gate_timeout_ticks = 100000000u; // one second without the word moving
+                    if (const char *const gte = getenv("MGL_SW_DEBUG_GATE_TIMEOUT_TICKS")) da.gate_timeout_ticks = (unsigned)atoll(gte); // (tests take the give-up path with it; read per call)
                 }
-                if ((pt.count + 127) / 128 > da.lane_slots) {
-                    const int word = (int)(ctx->tile_seq++ % kTileCounters);
-                    da.tile_ctr = static_cast<unsigned *>(ctx->tile_ctr.p) + word;
-                    da.tile_base = ctx->tile_total[word]; // (moved on when the launch has been enqueued, below)
+                if ((pt.count + 127) / 128 > da.lane_slots) { // (an entry of the ring: at zero, its last launch's last wave has seen to that)
+                    da.tile_ctr = static_cast<unsigned *>(ctx->tile_ctr.p) + (size_t)(ctx->tile_seq++ % kTileCounters) * kTileCounterWords;
+                    void *fault_dev = nullptr;
+                    HIP_TRY(ctx, hipHostGetDevicePointer(&fault_dev, ctx->pin_fault, 0));
+                    da.grid_fault = static_cast<int32_t *>(fault_dev);
                 }
             }
             const int per_block = pt.lane ? pt.wpb * 128 : pt.packed ? pt.wpb * 8 : strip16 ? 1 : pt.wpb * (64 / pt.rows);
@@ -1142,8 +1165,6 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                          : pt.packed ? launch_dp16(das[i], pt.wpb, fs)
                          : strip16 ? launch_dp16_strip(das[i], strip_waves, pt.rows, fs)
                          : coop16 ? launch_dp_coop16(das[i], coop_waves, fs) : coop_waves ? launch_dp_coop(das[i], coop_waves, fs) : launch_dp(das[i], pt.wpb, pt.rows, fs));
-            if (das[i].tile_ctr) // the persistent grid is on its way: its counter will stand `tiles` further on when it ends
-                ctx->tile_total[das[i].tile_ctr - static_cast<unsigned *>(ctx->tile_ctr.p)] += (unsigned)((pt.count + 127) / 128);
             if (pt.tb_now) HIP_TRY(ctx, launch_traceback(tas[i], fs));
         }
         if (pe[1]) HIP_TRY(ctx, hipEventRecord(pe[1], fs));
@@ -1323,6 +1344,7 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
         for (int h = 0; h < 2; ++h)
             if (set[h]) (void)hipEventDestroy(set[h]);
     if (ctx->pin_gate) (void)hipHostFree(ctx->pin_gate);
+    if (ctx->pin_fault) (void)hipHostFree(ctx->pin_fault);
     for (auto &e : ctx->gate_ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->pin_matrix) (void)hipHostFree(ctx->pin_matrix);
@@ -1365,6 +1387,16 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
 }
 
 const char *mgl_sw_last_error(const mgl_sw_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+// Asynchronous faults of the device entries: they return when their kernels are ENQUEUED, so what a kernel finds out about itself
+// later (today: a persistent grid whose tile counter was out of range) can only be reported afterwards.  The caller synchronises its
+// stream, then asks here; every later call on the context reports the same (sticky).  The host entries ask by themselves.
+int mgl_sw_ctx_check(mgl_sw_ctx *ctx)
+{
+    if (!ctx) return MGL_SW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return grid_fault_check(ctx);
+}
 
 int mgl_sw_ctx_set_workspace(mgl_sw_ctx *ctx, int64_t bytes)
 {
@@ -1483,6 +1515,18 @@ int mgl_sw_ctx_get_timing(mgl_sw_ctx *ctx, mgl_sw_timing *out)
     *out = ctx->timing;
     if (ctx->profiling == 3) ctx->timing = mgl_sw_timing{}; // the next calls start a new sum
     return MGL_SW_OK;
+}
+
+// (a caller whose header is older or newer than the library's: never more than out_size bytes written, include/mgl_sw.h)
+int mgl_sw_explain_sized(mgl_sw_ctx *ctx, int64_t workspace_limit, int64_t n, int max_tl, int max_ql, int match, int mismatch, int gopen, int gext,
+                         int strategy, int flags, int packed2, int entry, mgl_sw_plan *out, size_t out_size)
+{
+    if (!out || out_size < 8) return MGL_SW_ERR_BAD_ARG;
+    mgl_sw_plan full{};
+    const int rc = mgl_sw_explain(ctx, workspace_limit, n, max_tl, max_ql, match, mismatch, gopen, gext, strategy, flags, packed2, entry, &full);
+    memset(out, 0, out_size);
+    memcpy(out, &full, std::min(out_size, sizeof full));
+    return rc;
 }
 
 int mgl_sw_explain(mgl_sw_ctx *ctx, int64_t workspace_limit, int64_t n, int max_tl, int max_ql, int match, int mismatch, int gopen, int gext,
@@ -1994,6 +2038,7 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (ctx->d2h) HIP_TRY(ctx, hipStreamSynchronize(ctx->d2h)); // (results copied straight into registered arrays)
+    if (const int frc = grid_fault_check(ctx)) return frc;
     if (host_timing)
         fprintf(stderr, "[mgl_sw] host entry: %.1f ms enqueue (%.1f ms in input copies, %.1f ms in result copies), %.1f ms drain\n",
                 (t_enq - t_begin) * 1e3, t_in * 1e3, t_out * 1e3, (now() - t_enq) * 1e3);
@@ -2111,8 +2156,10 @@ static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_b
     // chunks doubling from 32 k pairs: the sixteen copy commands of the first four cost the waves 1.9 ms at the gate -- then a million
     // pairs at a time
     std::vector<int64_t> ends;
-    for (int64_t first = 0, c = ((int64_t)ctx->n_cus * LANE_CK_WAVES_PER_CU + 2) * 128; first < n; c = 1 << 20) {
-        first = n - (first + c) < (1 << 18) ? n : first + c; // (no small last chunk: small copies are blit kernels, see below)
+    const char *const dce = getenv("MGL_SW_DEBUG_DIRECT_CHUNK"); // (pairs per later chunk; tests make a batch of a few thousand pairs cross many gates with it; read per call)
+    const int64_t later = dce ? std::max<int64_t>(128, atoll(dce)) : (int64_t)1 << 20;
+    for (int64_t first = 0, c = ((int64_t)ctx->n_cus * LANE_CK_WAVES_PER_CU + 2) * 128; first < n; c = later) {
+        first = n - (first + c) < later / 4 ? n : first + c; // (no small last chunk: small copies are blit kernels, see below)
         ends.push_back(first);
     }
     while (ctx->gate_ev.size() < ends.size()) {
@@ -2131,9 +2178,11 @@ static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_b
                         static_cast<char *>(d_cg), cigar_stride, static_cast<int32_t *>(d_len), static_cast<int32_t *>(d_st), n * (int64_t)max_tl * max_ql, GEOM_UNIFORM);
     ctx->cur_gate = nullptr;
     ctx->direct_status_any = nullptr;
-    // (from here on a grid may be waiting at the gate: every way out opens it)
+    // (from here on a grid may be waiting at the gate: every way out that is not the good one CALLS IT OFF -- a negative gate: the waves
+    // leave at their next look, those inside a tile after it; round 4 opened the gate to n here, and the grid then worked through pairs
+    // whose index arrays and bases had not been copied or checked: stale or uninitialised offsets followed into device memory)
     auto bail = [&](int code) -> int {
-        __atomic_store_n(&ctx->pin_gate[0], n, __ATOMIC_RELEASE);
+        __atomic_store_n(&ctx->pin_gate[0], (int64_t)-1, __ATOMIC_RELEASE);
         drain_streams(ctx, st);
         return code;
     };
@@ -2230,6 +2279,7 @@ static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_b
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (timing) fprintf(stderr, "[mgl_sw] direct form: grid ended %.2f ms after the launch (%.2f ms after its last inputs landed)\n", (now() - t_launched) * 1e3, (now() - t_gate_open) * 1e3);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->h2d));
+    if (const int frc = grid_fault_check(ctx)) return frc;
     if (__atomic_load_n(reinterpret_cast<int32_t *>(&ctx->pin_gate[1]), __ATOMIC_ACQUIRE) != 0) {
         // a wave gave up at the gate: the copies did not move while the grid was resident.  Not again on this context; this call goes the
         // chunked way (every result is written again)
@@ -2400,6 +2450,7 @@ int mgl_sw_align_batch_2bit(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_ba
     HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (ctx->d2h) HIP_TRY(ctx, hipStreamSynchronize(ctx->d2h));
+    if (const int frc = grid_fault_check(ctx)) return frc;
     if (status_out) return MGL_SW_OK;
     int32_t any = 0;
     HIP_TRY(ctx, hipMemcpy(&any, ctx->d_any.p, 4, hipMemcpyDeviceToHost));

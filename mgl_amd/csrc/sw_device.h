@@ -71,8 +71,9 @@ struct DpArgs {
     int strip_passes;         // ... passes over the target: 2 * 64 * waves strips each (targets beyond 16 384 rows; 0 or 1: one)
     int strip_codes;          // ... and the LDS carve holds the query as one table dword per column (strip16_lds_bytes_codes): pairs whose targets are all ACGT run the base-code form
     int lane_slots;           // sw_dp16_lane_ck_kernel: wave slots of its persistent grid = regions at tb / scratch (lane_ck_slots)
-    unsigned *tile_ctr;       // ... the counter its waves draw their next tile from (needed when the launch holds more tiles than slots) ...
-    unsigned tile_base;       // ... and where it stands when the launch starts: a launch of T > lane_slots tiles moves it on by exactly T
+    unsigned *tile_ctr;       // ... two words {draws, waves out}, zero when the launch starts (needed when the launch holds more tiles than slots): the waves
+                              //     draw their next tile from the first and count themselves out in the second; the last wave out zeroes both
+    int32_t *grid_fault;      // ... optional: set to 1 (pinned host memory) by a wave that draws a number no launch of this size can draw
     const int64_t *gate;      // ... optional (host entries): a word in pinned host memory holding how many pairs of the batch have arrived in device memory
                               //     so far; a wave waits with a tile until its pairs are there (null: everything is)
     int32_t *gate_failed;     // ... set to 1 (pinned host memory) by a wave that gives up waiting: gate_timeout_ticks (100 MHz) without the word moving
@@ -264,6 +265,11 @@ bool small_supported(int max_tl, int max_ql, int cigar_stride, int match, int mi
 int small_lds_bytes(int max_tl, int max_ql, int cigar_stride, bool wide);
 hipError_t launch_small(const TbArgs &a, int max_tl, int max_ql, bool wide, hipStream_t stream);
 bool small_fits_int16(int max_tl, int max_ql, int match, int mismatch, int gopen, int gext);
+// small_pair() multiplies by `mismatch - match` and by gext with v_mul_i32_i24 / v_mad_i32_i24 (one pass where a 32-bit multiply takes
+// four, and a lone wave waits for every pass): exact while both operands are 24-bit numbers.  The other factors are row and column
+// numbers (tl <= 512, ql <= SERVICE_MAX_QL or the LDS bound) and a 0 / 1 byte.  Parameters beyond that -- the reference takes any int --
+// go to the other kernels (normalised parameters: match > 0 > mismatch, gext > 0).
+__host__ __device__ inline bool small_mul24_ok(int match, int mismatch, int gext) { return (int64_t)match - mismatch < (1 << 23) && gext < (1 << 23); }
 
 // ---- one pair per call without a launch on the request path (sw_service.hip; host side: sw_service.cpp).  Every calling thread owns a
 // MAILBOX (ServiceRequest + ServiceReply below); ONE resident grid serves them, workgroup k (one wave) mailbox k: the thread writes its pair and a

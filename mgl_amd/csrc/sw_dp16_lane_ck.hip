@@ -1006,7 +1006,7 @@ __device__ __forceinline__ void sw_dp16_lane_ck_tile(const DpArgs &a, const TbAr
 
 // A PERSISTENT grid: a.lane_slots waves (at most what the chip holds at two waves per SIMD -- 256 registers: no spills in pass 1's
 // loops), each with one region of the workspace, each taking tile after tile: its first one by its slot number, the following ones
-// off a counter in device memory (a.tile_ctr; it stands at a.tile_base when the launch starts) until the tiles are gone.  The workspace a launch needs is therefore
+// off a counter in device memory (a.tile_ctr[0]; zero when the launch starts) until the tiles are gone.  The workspace a launch needs is therefore
 // lane_slots regions (2 MB each at 256 x 150: 4 GB for a whole MI355X) however many pairs it holds -- round 3 gave every TILE a region
 // (15 KB per pair: 208 GiB for the bench's 10 M pairs in one launch, and chunks wherever the workspace was smaller).  Every wave
 // reaches the loop's exit: the counter only grows, a tile's work is bounded, nothing waits for another wave.
@@ -1066,9 +1066,12 @@ __device__ __forceinline__ void lane_ck_grid(const DpArgs &a, const TbArgs &walk
                 break;
             }
             if (left_early) break;
-            // (No cache holds a line of the pairs that have just arrived -- the margin above; the grid started with empty caches -- so the
-            // loads that follow need no invalidate, and the gate's load is an ordinary dependency of theirs: the branch above.)
-#ifdef MGL_CK_GATE_FENCE
+            // An acquire fence between the look that let the wave through and the loads of the pairs it announced: once per WAIT (a wave
+            // waits a handful of times while the inputs cross the link, never once they are there), so it costs nothing that can be
+            // measured -- and without it the order of those loads behind a relaxed load rested on a branch and on the argument that no
+            // cache holds a line of pairs that have just arrived (the margin above; the grid starts with empty caches).  That argument
+            // still holds; the fence is what makes the order the language's, not the hardware's.  (-DMGL_CK_NO_GATE_FENCE: round 4's form.)
+#ifndef MGL_CK_NO_GATE_FENCE
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
         }
@@ -1090,8 +1093,30 @@ __device__ __forceinline__ void lane_ck_grid(const DpArgs &a, const TbArgs &walk
 #endif
         if (tiles <= slots) break; // (every tile has its wave: the counter is not even touched)
         unsigned next = 0;
-        if (lane == 0) next = atomicAdd(a.tile_ctr, 1u) - a.tile_base; // (modulo 2^32: the counter is never reset)
+        if (lane == 0) {
+            next = atomicAdd(a.tile_ctr, 1u);
+            // The waves of one launch draw `tiles` times at most (tiles - slots draws that find a tile, one per wave that does not), so a
+            // larger number means the word did not stand at zero when the launch started: somebody else's launch is on it, or memory is
+            // not what it was.  The host finds the flag at its next look (mgl_sw_ctx_check, every later call): MGL_SW_ERR_DEVICE, never
+            // a silent tile left undone.
+            if (next >= (unsigned)tiles && a.grid_fault) __hip_atomic_store(a.grid_fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         tile = slots + (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)next);
+    }
+    // THE LAST WAVE OUT ZEROES THE COUNTER (round 5).  Every wave of the grid comes through here -- after its last draw, or from the gate
+    // when the host has called the launch off or the gate stood still -- and counts itself out in a.tile_ctr[1]; the one that finds
+    // slots - 1 there knows that nobody will draw again and puts both words back to zero.  So a launch finds its counter at zero however
+    // the launch before it on that word ended.  (Round 4 never reset the word and kept a host-side copy of where it stood, "moved on by
+    // exactly `tiles` per launch" -- which a launch called off at its gate did not do: the copy and the word parted, and 64 launches later
+    // the grid that came round to that word left its tiles undone with status 0.)
+    if (tiles > slots && lane == 0) {
+        const unsigned out = __hip_atomic_fetch_add(a.tile_ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (out == (unsigned)slots - 1u) {
+            __hip_atomic_store(a.tile_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.tile_ctr + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (out >= (unsigned)slots && a.grid_fault) {
+            __hip_atomic_store(a.grid_fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (a.diag && lane == 0) {
         a.diag[2 * slot] = __builtin_amdgcn_s_memtime() - diag_t0;
@@ -1111,11 +1136,11 @@ __global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_scatter_kernel(const Dp
 // either wire format, the same for both sequence sets (the kernel stages base codes, sw_lane_cell.h)
 bool lane16_ck_supported(const SeqSet &t, const SeqSet &q) { return (t.packed2 != 0) == (q.packed2 != 0); }
 
-// a.lane_slots regions at a.tb / a.scratch; wherever the launch holds more tiles than slots: a.tile_ctr, a counter that stands at
-// a.tile_base when the kernel starts and that no other launch in flight uses.  The launch moves it on by exactly `tiles` (tiles - slots
-// draws that find a tile and one per wave that does not), so the host knows where it stands without ever resetting it -- a memset in
-// front of every launch is a KERNEL of its own, and behind a grid that holds every wave slot of the chip it waited for that grid's end
-// (traced in round 4: the two streams of the host entries stopped overlapping).
+// a.lane_slots regions at a.tb / a.scratch; wherever the launch holds more tiles than slots: a.tile_ctr, two words {draws, waves out}
+// that stand at zero when the kernel starts and that no other launch in flight uses.  The grid's last wave out puts them back to zero
+// (above), so no launch needs a reset in front of it -- a memset in front of every launch is a KERNEL of its own, and behind a grid that
+// holds every wave slot of the chip it waited for that grid's end (traced in round 4: the two streams of the host entries stopped
+// overlapping).
 hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &walk, hipStream_t stream)
 {
     const int64_t tiles = ((a.count + 1) / 2 + 63) / 64;

@@ -359,6 +359,7 @@ extern "C" MGL_SW_INTERNAL int mgl_sw_service_align(const char *t, int tl, const
     if (tl > SERVICE_MAX_TL || ql > SERVICE_MAX_QL) return DECLINED;
     mgl_sw_normalize_params(&match, &mismatch, &gopen, &gext);
     if (((int64_t)match - mismatch + gopen + 2 * (int64_t)gext) * ((int64_t)tl + ql) >= (1ll << 30)) return DECLINED; // (run_device's bound for 32-bit scores)
+    if (!small_mul24_ok(match, mismatch, gext)) return DECLINED; // (small_pair()'s 24-bit products)
     const int stride = std::min((cigar_cap + 3) & ~3, (2 * (tl + ql) + 4 + 3) & ~3); // no CIGAR of this pair is longer than that
     const bool wide = !small_fits_int16(tl, ql, match, mismatch, gopen, gext);
     const int lds_need = small_lds_bytes(tl, ql, stride, wide);

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64) void sw_small_kernel(const TbArgs a, const int 
 }
 bool small_supported(int max_tl, int max_ql, int cigar_stride, int match, int mismatch, int gopen, int gext, bool *wide)
 {
-    if (max_tl > 512 || max_tl < 1 || max_ql < 1) return false;
+    if (max_tl > 512 || max_tl < 1 || max_ql < 1 || !small_mul24_ok(match, mismatch, gext)) return false;
     bool w = !small_fits_int16(max_tl, max_ql, match, mismatch, gopen, gext);
     if (small_lds_bytes(max_tl, max_ql, cigar_stride, w) > 160 * 1024) return false;
     if (wide) *wide = w;

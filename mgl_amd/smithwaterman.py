@@ -245,6 +245,11 @@ class MicrosoftSmithWaterman:
         _check(_lib.lib().mgl_sw_ctx_get_timing(self._ensure(), C.byref(t)))
         return t
 
+    def check(self):
+        """mgl_sw_ctx_check: what a kernel found out about itself after the (asynchronous) device entry that enqueued it returned --
+        synchronise the stream first.  Raises MglSwError(ERR_DEVICE) when a persistent grid found its tile counter out of range."""
+        _check(_lib.lib().mgl_sw_ctx_check(self._ensure()), self._ctx)
+
     @staticmethod
     def fill_kernel_name(timing):
         """Name of the fill kernel a Timing record belongs to (MGL_SW_KERNEL_*)."""

@@ -140,22 +140,133 @@ hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &w, int, hipStream_t)
     if (w.cigar) walk(w, false);
     return hipSuccess;
 }
-hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &w, hipStream_t)
+// ---- the persistent grid of sw_dp16_lane_ck.hip, protocol for protocol.  Device resident (no gate): done before the launch returns.
+// With a gate (the DIRECT form of the host entries: the grid is launched FIRST and its inputs arrive beside it) the grid is a THREAD
+// that goes through the waves' own loop -- wait at the gate for the tile's pairs and the next tile's, leave on a negative gate, give
+// up when the word stands still for gate_timeout_ticks, draw the next tile, count itself out, the last wave out zeroes the counter --
+// and is joined where the real stream would be synchronised (fake_hip_join_stream, called by the fake hipStreamSynchronize).
+std::atomic<long long> fake_gated_grids{0}, fake_gate_leavers{0}, fake_gate_give_ups{0};
+namespace {
+std::mutex g_async_mu;
+std::vector<std::pair<hipStream_t, std::thread>> g_async;
+
+void lane_ck_wave(const DpArgs &a, const TbArgs &w, int64_t tiles, int64_t slots, int64_t slot)
 {
-    // the persistent grid's contract (sw_dp16_lane_ck.hip): wave slots, and a zeroed tile counter wherever the tiles outnumber them
+    using Clock = std::chrono::steady_clock;
+    int64_t arrived = a.gate ? 0 : INT64_MAX;
+    for (int64_t tile = slot; tile < tiles;) {
+        const int64_t need = a.first + std::min(a.count, (tile + 2) * 128);
+        if (arrived < need) {
+            auto since = Clock::now();
+            int64_t last = arrived;
+            bool gave_up = false, left_early = false;
+            for (;;) {
+                arrived = __atomic_load_n(a.gate, __ATOMIC_ACQUIRE);
+                if (arrived >= need) break;
+                if (arrived < 0) {
+                    left_early = true;
+                    break;
+                }
+                const auto now = Clock::now();
+                if (arrived != last) {
+                    last = arrived;
+                    since = now;
+                } else if (std::chrono::duration_cast<std::chrono::nanoseconds>(now - since).count() > (long long)a.gate_timeout_ticks * 10) {
+                    gave_up = true;
+                    break;
+                }
+                std::this_thread::yield();
+            }
+            if (gave_up) {
+                __atomic_store_n(a.gate_failed, 1, __ATOMIC_RELEASE);
+                ++fake_gate_give_ups;
+                break;
+            }
+            if (left_early) {
+                ++fake_gate_leavers;
+                break;
+            }
+        }
+        if (w.cigar) {
+            TbArgs part = w;
+            part.first = w.first + tile * 128;
+            part.count = std::min<int64_t>(128, w.count - tile * 128);
+            walk(part, false);
+        }
+        if (tiles <= slots) break;
+        const unsigned next = __atomic_fetch_add(a.tile_ctr, 1u, __ATOMIC_ACQ_REL);
+        if (next >= (unsigned)tiles && a.grid_fault) __atomic_store_n(a.grid_fault, 1, __ATOMIC_RELEASE);
+        tile = slots + (int64_t)next;
+    }
+    if (tiles > slots) {
+        const unsigned out = __atomic_fetch_add(a.tile_ctr + 1, 1u, __ATOMIC_ACQ_REL);
+        if (out == (unsigned)slots - 1u) {
+            __atomic_store_n(a.tile_ctr, 0u, __ATOMIC_RELEASE);
+            __atomic_store_n(a.tile_ctr + 1, 0u, __ATOMIC_RELEASE);
+        } else if (out >= (unsigned)slots && a.grid_fault) {
+            __atomic_store_n(a.grid_fault, 1, __ATOMIC_RELEASE);
+        }
+    }
+}
+} // namespace
+} // namespace mgl_sw_dev
+
+void fake_hip_join_stream(hipStream_t s)
+{
+    std::vector<std::thread> mine;
+    {
+        std::lock_guard<std::mutex> lk(mgl_sw_dev::g_async_mu);
+        for (auto it = mgl_sw_dev::g_async.begin(); it != mgl_sw_dev::g_async.end();)
+            if (!s || it->first == s) {
+                mine.push_back(std::move(it->second));
+                it = mgl_sw_dev::g_async.erase(it);
+            } else {
+                ++it;
+            }
+    }
+    for (auto &t : mine) t.join();
+}
+
+// fault injection for the host-sanitizer driver: the k-th asynchronous copy from now fails (0: none does)
+static std::atomic<int> g_copy_fail_in{0};
+void fake_hip_fail_copy_in(int k) { g_copy_fail_in = k; }
+int fake_hip_copy_should_fail(void)
+{
+    int v = g_copy_fail_in.load();
+    while (v > 0 && !g_copy_fail_in.compare_exchange_weak(v, v - 1)) {
+    }
+    return v == 1;
+}
+
+namespace mgl_sw_dev {
+hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &w, hipStream_t stream)
+{
+    // the persistent grid's contract (sw_dp16_lane_ck.hip): wave slots, and wherever the tiles outnumber them a counter entry that
+    // stands at {0, 0} -- the last wave of the launch before it on that entry has seen to that, HOWEVER that launch ended
     const int64_t tiles = ((a.count + 1) / 2 + 63) / 64;
-    if (a.lane_slots < 1 || (tiles > a.lane_slots && (!a.tile_ctr || *a.tile_ctr != a.tile_base))) return hipErrorInvalidValue;
-    if (tiles > a.lane_slots) *a.tile_ctr += (unsigned)tiles; // (what the real waves leave behind: the next launch on this word starts from there)
+    if (a.lane_slots < 1 || (tiles > a.lane_slots && (!a.tile_ctr || __atomic_load_n(a.tile_ctr, __ATOMIC_ACQUIRE) != 0 || __atomic_load_n(a.tile_ctr + 1, __ATOMIC_ACQUIRE) != 0)))
+        return hipErrorInvalidValue;
+    const int64_t slots = std::min<int64_t>(tiles, a.lane_slots);
     remember(a);
-    if (w.cigar) walk(w, false);
+    if (!a.gate) {
+        for (int64_t s = 0; s < slots; ++s) lane_ck_wave(a, w, tiles, slots, s);
+        return hipSuccess;
+    }
+    ++fake_gated_grids;
+    std::lock_guard<std::mutex> lk(g_async_mu);
+    g_async.emplace_back(stream, std::thread([a, w, tiles, slots, m = g_match, x = g_mismatch, o = g_gopen, e = g_gext] {
+        g_match = m, g_mismatch = x, g_gopen = o, g_gext = e;
+        // (the waves one after the other: wave 0 draws most of the tiles -- any order of draws is one the real grid may produce)
+        for (int64_t s = 0; s < slots; ++s) lane_ck_wave(a, w, tiles, slots, s);
+    }));
     return hipSuccess;
 }
 hipError_t launch_traceback(const TbArgs &a, hipStream_t) { walk(a, false); return hipSuccess; }
 hipError_t launch_strip_ck_walk(const TbArgs &a, int, int, hipStream_t) { walk(a, false); return hipSuccess; }
-bool small_supported(int max_tl, int max_ql, int, int, int, int, int, bool *wide)
+bool small_supported(int max_tl, int max_ql, int, int match, int mismatch, int, int gext, bool *wide)
 {
     if (wide) *wide = false;
-    return max_tl <= 512 && (int64_t)max_tl * max_ql <= 60000;
+    return max_tl <= 512 && (int64_t)max_tl * max_ql <= 60000 && small_mul24_ok(match, mismatch, gext);
 }
 int small_lds_bytes(int tl, int ql, int stride, bool wide) { return tl * ql * (wide ? 4 : 2) + tl + ql + stride; } // (about what sw_small.hip's carve takes)
 hipError_t launch_small(const TbArgs &a, int, int, bool, hipStream_t)

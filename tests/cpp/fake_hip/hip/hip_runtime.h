@@ -1,6 +1,7 @@
 /*
  * hip/hip_runtime.h -- a FAKE, TEST-ONLY HIP runtime: "device" memory is host memory, streams and events are tokens,
- * every "asynchronous" call completes before it returns.  It exists so that the HOST side of the library (sw_capi.cpp,
+ * every "asynchronous" call completes before it returns -- but for a GATED launch of the persistent grid, which fake_device.cpp runs as a
+ * thread (its inputs arrive after the launch) and which hipStreamSynchronize / hipDeviceSynchronize join.  It exists so that the HOST side of the library (sw_capi.cpp,
  * sw_batcher.cpp, sw_multi.cpp: chunking, hooks, the per-chunk sort by geometry, sharding, the coalescer's threads) can be
  * built with -fsanitize=address,undefined and -fsanitize=thread on a CPU and driven hard (GPU sanitizers are not available
  * on this pool).  The kernels' place is taken by tests/cpp/fake_device.cpp.  Never on the product's include path.
@@ -44,7 +45,9 @@ static inline hipError_t hipMalloc(void **p, size_t bytes) { *p = malloc(bytes ?
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { *p = malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipExtMallocWithFlags(void **p, size_t bytes, unsigned) { *p = malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-static inline hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+void fake_hip_join_stream(hipStream_t s); /* tests/cpp/fake_device.cpp: waits for the gated grids launched on s (NULL: on any stream) */
+int fake_hip_copy_should_fail(void);      /* ... fault injection: this asynchronous copy is to fail (fake_hip_fail_copy_in) */
+static inline hipError_t hipDeviceSynchronize(void) { fake_hip_join_stream((hipStream_t)0); return hipSuccess; }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 enum { hipHostRegisterDefault = 0 };
 static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
@@ -54,7 +57,12 @@ enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMe
 typedef struct hipPointerAttribute_t { int type; } hipPointerAttribute_t;
 static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { a->type = hipMemoryTypeUnregistered; return hipSuccess; } /* (nothing is pinned behind the library's back here) */
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
-static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t)
+{
+    if (fake_hip_copy_should_fail()) return hipErrorInvalidValue;
+    memmove(d, s, n);
+    return hipSuccess;
+}
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = *t = (size_t)8 << 30; return hipSuccess; }
@@ -71,7 +79,7 @@ static inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(1); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (hipStream_t)malloc(1); return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
-static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t s) { fake_hip_join_stream(s); return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)malloc(1); return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (hipEvent_t)malloc(1); return hipSuccess; }

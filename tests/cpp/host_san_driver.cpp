@@ -24,8 +24,9 @@
 #include "../../oracle/sw_oracle.h"
 
 int *fake_hip_current_device(void); // tests/cpp/fake_device.cpp: the calling thread's current HIP device
+void fake_hip_fail_copy_in(int k);  // ... the k-th asynchronous copy from now fails (0: none)
 namespace mgl_sw_dev {
-extern std::atomic<long long> fake_fill_launches, fake_walk_pairs, fake_packed_pairs, fake_service_waves, fake_service_pairs;
+extern std::atomic<long long> fake_fill_launches, fake_walk_pairs, fake_packed_pairs, fake_service_waves, fake_service_pairs, fake_gated_grids, fake_gate_leavers, fake_gate_give_ups;
 extern std::atomic<int> fake_service_lds_bytes;
 }
 
@@ -296,6 +297,85 @@ int main()
                 CHECK(tm.dp_launches == (pyr[0] == '8' ? 7 : 5));
             }
             unsetenv("MGL_SW_DEBUG_HOST_PYRAMID");
+            // ---- the DIRECT form of the same entry (every array registered): ONE gated launch of the persistent grid -- here a thread that
+            // speaks the waves' protocol (fake_device.cpp) -- while the host checks and copies the chunks beside it.  Every way a gated launch
+            // can END EARLY, then more launches on the SAME context than its ring of tile counters has entries: the launch that comes round to
+            // an entry a called-off grid has used must find it at zero (round 4's host-side copy of the counters did not: the review's finding).
+            {
+                void *regs[] = {const_cast<uint8_t *>(G.data()), ts.data(), const_cast<uint8_t *>(Rd.data()), qs.data(), off.data(), sc.data(), cg.data(), len.data(), st.data()};
+                const size_t bytes[] = {G.size(), ts.size() * 8, Rd.size(), qs.size() * 8, off.size() * 4, sc.size() * sizeof(mgl_sw_score), cg.size(), len.size() * 4, st.size() * 4};
+                for (int i = 0; i < 9; ++i) CHECK(mgl_sw_register_host_buffer(ctx, regs[i], bytes[i]) == 0);
+                setenv("MGL_SW_DEBUG_DIRECT_CHUNK", "8192", 1); // (chunks of 4 352, then 8 192 pairs: five gates)
+                auto direct = [&](int64_t count) {
+                    return mgl_sw_align_batch_2bit(ctx, count, G.data(), (int64_t)genome.size(), ts.data(), nullptr, Rd.data(), (int64_t)reads.size(), qs.data(), nullptr, utl, uql, 200,
+                                                   -150, 260, 11, MGL_SW_OS_SOFTCLIP, off.data(), sc.data(), cg.data(), 64, len.data(), st.data(), MGL_SW_FLAG_UNIFORM_GEOMETRY);
+                };
+                auto wipe = [&] {
+                    std::fill(off.begin(), off.end(), -77);
+                    std::fill(cg.begin(), cg.end(), (char)1);
+                };
+                const long long grids0 = mgl_sw_dev::fake_gated_grids.load();
+                wipe();
+                CHECK(direct(nu) == 0);
+                CHECK(mgl_sw_dev::fake_gated_grids.load() == grids0 + 1); // the direct form was taken: one gated launch
+                compare(view, ev, off, sc, cg, 64, len, &st);
+                mgl_sw_timing tm;
+                CHECK(mgl_sw_ctx_get_timing(ctx, &tm) == 0 && tm.fill_kernel == MGL_SW_KERNEL_LANE16_CK && tm.dp_launches == 1);
+                // (a) a pair outside its array in the FIRST chunk: no gate ever opens, every wave leaves from its first look
+                const long long leavers0 = mgl_sw_dev::fake_gate_leavers.load();
+                const int64_t keep_first = ts[100], keep_last = ts[(size_t)nu - 5];
+                ts[100] = (int64_t)genome.size() - utl + 1;
+                CHECK(direct(nu) == MGL_SW_ERR_BAD_ARG);
+                ts[100] = keep_first;
+                CHECK(mgl_sw_dev::fake_gate_leavers.load() == leavers0 + 32); // all 32 waves of the four fake CUs
+                // (b) ... in the LAST chunk: the grid is called off in the middle of its work
+                ts[(size_t)nu - 5] = -1;
+                CHECK(direct(nu) == MGL_SW_ERR_BAD_ARG);
+                ts[(size_t)nu - 5] = keep_last;
+                // (c) an input copy that fails behind the launch: the grid is called off too (round 4 opened the gate to n here, and the
+                // grid went through pairs nobody had copied or checked)
+                const long long walked0 = mgl_sw_dev::fake_walk_pairs.load();
+                fake_hip_fail_copy_in(4);
+                CHECK(direct(nu) == MGL_SW_ERR_DEVICE);
+                fake_hip_fail_copy_in(0);
+                CHECK(mgl_sw_dev::fake_walk_pairs.load() - walked0 < nu); // (... not all of them)
+                CHECK(mgl_sw_ctx_check(ctx) == 0);
+                // (d) more counter-using launches than the ring has entries (64), each compared with the checker: 38 tiles on 32 wave slots
+                const int64_t ns = 32 * 128 + 700;
+                Batch head;
+                for (int64_t k = 0; k < ns; ++k)
+                    head.add(std::string(view.t.begin() + view.toff[(size_t)k], view.t.begin() + view.toff[(size_t)k + 1]),
+                             std::string(view.q.begin() + view.qoff[(size_t)k], view.q.begin() + view.qoff[(size_t)k + 1]));
+                const Expect eh = expect(head, MGL_SW_OS_SOFTCLIP);
+                for (int it = 0; it < 70; ++it) {
+                    wipe();
+                    CHECK(direct(ns) == 0);
+                    compare(head, eh, off, sc, cg, 64, len, &st);
+                }
+                CHECK(mgl_sw_dev::fake_gated_grids.load() == grids0 + 4 + 70);
+                // (e) a gate that "stands still" (a time-out of zero ticks): the waves give up, the call goes the chunked way and is right, the
+                // direct form is off for this context from then on -- and the ring is gone round once more, through the device entry
+                const long long gave0 = mgl_sw_dev::fake_gate_give_ups.load();
+                setenv("MGL_SW_DEBUG_GATE_TIMEOUT_TICKS", "0", 1);
+                wipe();
+                CHECK(direct(nu) == 0);
+                unsetenv("MGL_SW_DEBUG_GATE_TIMEOUT_TICKS");
+                CHECK(mgl_sw_dev::fake_gate_give_ups.load() > gave0);
+                compare(view, ev, off, sc, cg, 64, len, &st);
+                const long long grids1 = mgl_sw_dev::fake_gated_grids.load();
+                wipe();
+                CHECK(direct(nu) == 0 && mgl_sw_dev::fake_gated_grids.load() == grids1); // (chunked from now on)
+                compare(view, ev, off, sc, cg, 64, len, &st);
+                for (int it = 0; it < 70; ++it) {
+                    wipe();
+                    CHECK(mgl_sw_align_batch_device_2bit(ctx, nullptr, ns, G.data(), ts.data(), nullptr, Rd.data(), qs.data(), nullptr, utl, uql, 200, -150, 260, 11, MGL_SW_OS_SOFTCLIP,
+                                                         off.data(), sc.data(), cg.data(), 64, len.data(), st.data(), MGL_SW_FLAG_UNIFORM_GEOMETRY) == 0);
+                    compare(head, eh, off, sc, cg, 64, len, &st);
+                }
+                CHECK(mgl_sw_ctx_check(ctx) == 0);
+                unsetenv("MGL_SW_DEBUG_DIRECT_CHUNK");
+                for (int i = 0; i < 9; ++i) CHECK(mgl_sw_unregister_host_buffer(ctx, regs[i]) == 0);
+            }
             CHECK(mgl_sw_ctx_set_lane_kernel(ctx, 0) == 0);
         }
         // a pair outside its array, a length above the stated maximum, missing length arrays without the uniform flag

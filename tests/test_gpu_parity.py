@@ -112,6 +112,30 @@ def test_small_kernel(tl, ql):
         a.close()
 
 
+def test_parameters_beyond_24_bits_leave_the_one_wave_kernel():
+    """small_pair() multiplies by `mismatch - match` and by the gap extension with 24-bit multiplies (one pass on a lone wave where the
+    32-bit one takes four).  The reference takes any int (sw.cpp:5-146 computes in plain int), and the library's own bound --
+    parameters x lengths < 2^30 -- admits match = 2^24 on a tiny pair: such parameters must go to the kernels that multiply in 32 bits
+    (small_mul24_ok), through the batch entry and through the one-pair front-ends alike."""
+    rng = np.random.default_rng(24)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    ts = [alpha[rng.integers(0, 4, 20)].tobytes() for _ in range(40)]
+    qs = [t[3:15] if k % 3 else alpha[rng.integers(0, 4, 12)].tobytes() for k, t in enumerate(ts)]
+    a = sw.MicrosoftSmithWaterman(0)
+    try:
+        for params in [(1 << 24, -3, 5, 2), (7, -(1 << 24), 5, 2), (5, -3, (1 << 23) + 9, 1 << 23), (1 << 22, -(1 << 22) - 1, 9, 3)]:
+            for strategy in ol.STRATEGIES:
+                off, sc, cg = ol.oracle_align_batch(ts, qs, params, strategy, nthreads=2)
+                res = a.align_batch(ts, qs, params, strategy)
+                assert a.timing().fill_kernel != 8, "not the one-wave-per-pair kernel"
+                assert (res.offsets == off).all() and (res.scores == sc).all() and res.cigars == cg, (params, strategy)
+                for k in (0, 1, 5):
+                    cigar, offset, ez = sw.align(ts[k], qs[k], params, strategy)
+                    assert (offset, cigar, tuple(ez)) == (int(off[k]), cg[k], tuple(int(x) for x in sc[k])), (params, strategy, k)
+    finally:
+        a.close()
+
+
 def test_bam_pairs_device_formats(aligner):
     """Real Illumina reads (tests/golden/HiSeq.1mb.1RG.2k_lines.bam) against 256-base windows, through the
     device-resident entry in both wire formats (ASCII, 2-bit packed) and with BAM-style binary CIGAR output:
@@ -1731,6 +1755,117 @@ def test_direct_host_entry_one_gated_launch_results_in_place(monkeypatch):
         for x, y in zip(*res):
             assert (x == y).all()
         assert (res[0][0] == direct[0]).all() and (res[0][2].reshape(-1) == direct[2]).all()
+    a.close()
+
+
+def test_persistent_grid_counter_after_a_called_off_launch(monkeypatch):
+    """Round 4's review: the persistent grid's tile counter was never reset and the host kept a copy of where each of its 64 ring words
+    stood -- which a gated launch that ends early (a bad index array, a gate that stands still) did not move as far: 64 counter-using
+    launches later the grid on that word left every tile beyond its first 2 048 undone, status 0.  Now the grid's last wave out zeroes the
+    counter however the launch ended (sw_dp16_lane_ck.hip).  Here: a direct-form call of 700 000 pairs with the bad pair in the FIRST chunk
+    (no gate ever opens: all 5 469 tiles undone), one called off in its LAST chunk, one whose gate "stands still" (a time-out of one tick:
+    every wave gives up, the call goes the chunked way), then 70 further counter-using launches on the SAME context, each compared byte
+    for byte with what a fresh context returns, and mgl_sw_ctx_check."""
+    import torch
+    from mgl_amd import _lib, device_batch as db
+
+    rng = np.random.default_rng(5150)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    genome = alpha[rng.integers(0, 4, 1 << 18)]
+    n, tl, ql = 700_000, 256, 150
+    win = rng.integers(0, len(genome) - tl, n).astype(np.int64)
+    start = rng.integers(0, tl - ql - 4, n)
+    reads = genome[win[:, None] + start[:, None] + np.arange(ql)[None, :]]
+    sub = rng.random(reads.shape) < 0.01
+    reads = np.where(sub, alpha[rng.integers(0, 4, reads.shape)], reads).astype(np.uint8)
+    for k in np.nonzero(rng.random(n) < 0.2)[0][:30000]:  # a deletion of three bases: these walks need their blocks
+        reads[k, 60:-3] = reads[k, 63:]
+        reads[k, -3:] = genome[win[k] + start[k] + ql: win[k] + start[k] + ql + 3]
+    G, Q = db.pack2bit(genome.tobytes()), db.pack2bit(reads.tobytes())
+    qst = np.arange(n, dtype=np.int64) * ql
+    params = (200, -150, 260, 11)
+
+    def outs():
+        return (np.full(n, -77, np.int32), np.full((n, 6), -77, np.int32), np.full(n * 64, 7, np.uint8), np.full(n, -77, np.int32))
+
+    def run(a, out, count=n):
+        a.align_packed_2bit(G, len(genome), win[:count], None, Q, n * ql, qst[:count], None, tl, ql, params, ol.SOFTCLIP, 64,
+                            out=tuple(x[: count * (64 if x.ndim == 1 and x.dtype == np.uint8 else 1)] for x in out))
+
+    fresh = sw.MicrosoftSmithWaterman(0)
+    fresh.set_workspace(8 << 30)
+    good, work = outs(), outs()
+    regs = [G, win, Q, qst] + list(good) + list(work)
+    for x in regs:
+        fresh.register_host_buffer(x)
+    run(fresh, good)
+    assert fresh.timing().fill_kernel == 7 and fresh.timing().dp_launches == 1, "the direct form: one gated launch"
+    sample = np.sort(rng.choice(n, 2000, replace=False))
+    off, sc, cg = ol.oracle_align_batch([genome[win[k]: win[k] + tl].tobytes() for k in sample], [reads[k].tobytes() for k in sample], params, ol.SOFTCLIP, nthreads=8)
+    assert (good[0][sample] == off).all() and (good[1][sample] == sc).all()
+    assert [good[2].reshape(n, 64)[k, : good[3][k]].tobytes().decode() for k in sample] == cg
+    for x in regs:
+        fresh.unregister_host_buffer(x)
+    fresh.close()
+
+    a = sw.MicrosoftSmithWaterman(0)
+    a.set_workspace(8 << 30)
+    for x in regs:
+        a.register_host_buffer(x)
+    try:
+        for bad_at, bad_value in ((1000, len(genome) - tl + 1), (n - 5, -1)):  # first chunk (262 400 pairs), last chunk
+            keep = int(win[bad_at])
+            win[bad_at] = bad_value
+            with pytest.raises(_lib.MglSwError) as bad:
+                run(a, work)
+            assert bad.value.status == _lib.ERR_BAD_ARG
+            win[bad_at] = keep
+        a.check()
+        # (many tiles through the gate: a grid of 64 wave slots takes its 5 469 tiles one after the other while the chunks arrive)
+        monkeypatch.setenv("MGL_SW_DEBUG_LANE_SLOTS", "64")
+        monkeypatch.setenv("MGL_SW_DEBUG_DIRECT_CHUNK", "65536")
+        run(a, work)
+        assert a.timing().dp_launches == 1
+        monkeypatch.delenv("MGL_SW_DEBUG_LANE_SLOTS")
+        monkeypatch.delenv("MGL_SW_DEBUG_DIRECT_CHUNK")
+        for g, w in zip(good, work):
+            assert (g == w).all()
+        # the ring goes round: 70 counter-using launches (300 001 pairs: 2 344 tiles on 2 048 slots), the direct form each time
+        m = 300_001
+        for it in range(70):
+            for w in work:
+                w[...] = 9
+            run(a, work, m)
+            assert a.timing().dp_launches == 1
+            for g, w in zip(good, work):
+                k = m * (64 if w.ndim == 1 and w.dtype == np.uint8 else 1)
+                assert (g[:k] == w[:k]).all(), it
+        # a gate that stands still: every wave gives up at its first look, the call is done again the chunked way -- and is right
+        monkeypatch.setenv("MGL_SW_DEBUG_GATE_TIMEOUT_TICKS", "1")
+        for w in work:
+            w[...] = 9
+        run(a, work)
+        monkeypatch.delenv("MGL_SW_DEBUG_GATE_TIMEOUT_TICKS")
+        assert a.timing().dp_launches > 1, "the chunked form took over"
+        for g, w in zip(good, work):
+            assert (g == w).all()
+        a.check()
+    finally:
+        for x in regs:
+            a.unregister_host_buffer(x)
+    # ... and once more round the ring through the device entry on the same context
+    dev = torch.device("cuda", 0)
+    tq = torch.from_numpy
+    m = 300_001
+    b = db.PackedBatch(tq(G).to(dev), tq(win[:m]).to(dev), None, tq(Q).to(dev), tq(qst[:m]).to(dev), None, tl, ql, 64)
+    for it in range(70):
+        b.offsets.fill_(9)
+        b.cigars.fill_(9)
+        b.run(a, params, ol.SOFTCLIP)
+        torch.cuda.synchronize()
+        a.check()
+        assert (b.offsets.cpu().numpy() == good[0][:m]).all() and (b.cigars.cpu().numpy().reshape(-1) == good[2][: m * 64]).all(), it
+        assert (b.scores.cpu().numpy() == good[1][:m]).all() and (b.cigar_len.cpu().numpy() == good[3][:m]).all()
     a.close()
 
 
