@@ -68,30 +68,23 @@ def host_cores():
     return n
 
 
-def pmc_valu(tl, ql, kernel):
-    """VALU counters of the committed PMC passes for this kernel and geometry (or None)."""
+def pmc_entry(tl, ql, kernel):
+    """(entry, current, why) -- the committed rocprofv3 PMC passes for this kernel and geometry (profiles/pmc_traffic.json), and whether
+    they were taken on the kernel sources THIS run is built from: the entry carries a hash of mgl_amd/csrc/<its .hip files + the headers
+    they include>, recomputed here (scripts/src_hash.py; no git needed on the GPU box).  A stale or unhashed entry is never printed as a
+    number: `traffic` / `valu` become null with `why` beside them."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        for r in rec[kernel]:
-            if (r["tl"], r["ql"]) == (tl, ql):
-                return r.get("valu")
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+        import src_hash
 
-
-def pmc_traffic_per_pair(tl, ql, kernel="sw_dp_kernel"):
-    """HBM bytes per pair of sw_dp_kernel from the committed rocprofv3 PMC passes
-    (profiles/pmc_traffic.json: WRITE_SIZE + 2 x FETCH_SIZE, the gfx950 correction of
-    MI355X_MICROARCH.md), or None when no pass was taken for this geometry."""
-    try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        for r in rec[kernel]:
+        for r in reversed(rec[kernel]):  # (the newest entry of a geometry last)
             if (r["tl"], r["ql"]) == (tl, ql):
-                return r["hbm_bytes_per_pair"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+                ok, why = src_hash.check(r)
+                return r, ok, why
+    except (OSError, KeyError, ValueError, ImportError) as e:
+        return None, False, f"no PMC entry readable ({e!r})"
+    return None, False, "no PMC pass was taken for this kernel and geometry"
 
 
 def cpu_baseline(batch, target_seconds=15.0, max_pairs=10_000_000):
@@ -506,10 +499,14 @@ def main():
     # 7.8 ms per step instead of 8.9, the long-launch rate (scripts/step_overlap_probe.py).  Every step is still a whole pass over the
     # shard into result arrays of its own; K steps are K passes.
     in_flight = args.steps_in_flight or (2 if distributed else 1)
+    in_flight_note = None
     lanes = [(aligner, batch, None)]
     if in_flight == 2:
         import copy
+        aligner2 = None
         try:
+            if os.environ.get("MGL_BENCH_DEBUG_NO_SECOND_CONTEXT") == str(rank):  # (tests/test_gpu_multirank.py: the degraded path, on purpose)
+                raise RuntimeError("injected: no room for a second context")
             aligner2 = MicrosoftSmithWaterman(dev_index)
             aligner2.set_workspace(int(args.workspace_gib * (1 << 30)))
             batch2 = copy.copy(batch)  # the same inputs, result arrays of its own
@@ -522,6 +519,21 @@ def main():
         except Exception as e:  # noqa: BLE001 -- no room for a second context: one step in flight, as on one GPU
             print(f"bench: a second context could not be set up ({e!r}): one step in flight", file=sys.stderr)
             in_flight = 1
+            in_flight_note = f"rank {rank}: a second context could not be set up ({e!r})"[:300]
+    in_flight_requested = args.steps_in_flight or (2 if distributed else 1)
+    # (every rank runs the same number of steps -- each ends in the gather -- so they agree: one rank without room puts all at one in flight)
+    if distributed:
+        who = int(dist.min_over_ranks(rank if in_flight < in_flight_requested else 1 << 30, dev))  # (the first rank that fell back, if any: a collective every rank takes part in)
+        if who < (1 << 30) and in_flight_requested == 2:
+            in_flight_note = in_flight_note or f"rank {who} had no room for a second context: every rank keeps one step in flight (each step ends in the gather: the ranks must agree)"
+            if in_flight == 2:
+                lanes = [(aligner, batch, None)]
+            in_flight = 1
+    if in_flight == 1 and in_flight_requested == 2:
+        if aligner2 is not None:  # (its workspace goes back to the card)
+            aligner2.close()
+            aligner2 = batch2 = None
+            torch.cuda.empty_cache()
     if in_flight == 2:
         # (the batch was generated on torch's current stream: the two side streams must not start before its kernels have finished --
         # a grid that reads index arrays still being written walks out of its sequences)
@@ -555,7 +567,10 @@ def main():
         gathered = step()
     torch.cuda.synchronize(dev)
     dist.barrier()
-    elapsed = dist.max_over_ranks(time.perf_counter() - t0, dev)
+    elapsed_here = time.perf_counter() - t0
+    elapsed = dist.max_over_ranks(elapsed_here, dev)
+    per_rank_s = dist.all_ranks(elapsed_here, dev)  # (every rank's own clock around the same K steps)
+    comm = dist.describe()                         # what the COMMUNICATOR says, not the environment
 
     status_bad = int(sum(int((bt.status != 0).sum().item()) for _al, bt, _st in lanes))
     if in_flight == 2:
@@ -606,9 +621,10 @@ def main():
     cigar_bytes = float(batch.cigar_len.float().mean().item())
     per_pair = algorithmic_bytes_per_pair(args.tl, args.ql, args.input == "2bit", spills, cigar_bytes)
     achieved = pairs_per_launch * per_pair / avg_launch_s / 1e9
-    tpp = pmc_traffic_per_pair(args.tl, args.ql, fill_kernel)
+    pmc, pmc_current, pmc_why = pmc_entry(args.tl, args.ql, fill_kernel)
+    tpp = pmc["hbm_bytes_per_pair"] if pmc and pmc_current else None
     traffic = None if tpp is None else round(tpp * pairs_per_launch)  # HBM bytes per launch (PMC)
-    valu = pmc_valu(args.tl, args.ql, fill_kernel)
+    valu = pmc.get("valu") if pmc and pmc_current else None
     valu_obj = None
     if valu and not (1000 <= clock_mhz <= 3000):
         valu_obj = {"issue_frac": None, "note": "the in-kernel clock probe returned no plausible clock: the issue-bound fraction is not computed against an assumed one",
@@ -633,7 +649,7 @@ def main():
         "metric": "GCUPS (+ aligned reads/s) for 150 bp short-read batch",
         "value": round(total_cells / elapsed / 1e9, 2),
         "unit": "GCUPS",
-        "n_gpus": world,
+        "n_gpus": comm["world_size"],
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -649,6 +665,13 @@ def main():
             "parallelism": (f"pairs sharded over {world} GPU(s), one process per GPU, score gather onto rank 0 only"
                             if world > 1 else "1 GPU"),
             "steps_in_flight": in_flight,
+            **({"steps_in_flight_requested": in_flight_requested, "steps_in_flight_degraded": in_flight_note} if in_flight != in_flight_requested else {}),
+            # the communicator's own account (torch.distributed.get_world_size() / get_backend(): "nccl" is RCCL on ROCm), the devices it
+            # spans, and every rank's own clock around the K timed steps -- `value` uses the max
+            "distributed": {"world_size": comm["world_size"], "backend": comm["backend"], "launched_with_world_size_env": world,
+                            "gpus_visible": torch.cuda.device_count(), "ranks_per_gpu": max(1, -(-comm["world_size"] // max(1, torch.cuda.device_count()))),
+                            "per_rank_ms_per_step": {"min": round(min(per_rank_s) / args.steps * 1e3, 3), "max": round(max(per_rank_s) / args.steps * 1e3, 3),
+                                                     "all": [round(x / args.steps * 1e3, 3) for x in per_rank_s]}},
             **({"rank0_ms_per_step_one_in_flight": round(one_in_flight_ms, 3),
                 "steps_in_flight_note": "two contexts on two streams take the steps in turn: the next step's grid moves into the wave slots the last one's tail "
                                         "leaves free; every step is a whole pass over the shard into result arrays of its own.  roofline.avg_launch_ms is that of "
@@ -667,6 +690,9 @@ def main():
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic,
+            # where `traffic` and `valu` come from: the committed PMC passes, printed only when taken on the kernel sources of THIS build
+            "counters": {"file": "profiles/pmc_traffic.json", "commit": pmc.get("commit") if pmc else None, "src_hash": pmc.get("src_hash") if pmc else None,
+                         "current": bool(pmc_current), "why": pmc_why},
             "algorithmic_bytes_per_pair": round(per_pair, 1),
             "pairs_per_launch": round(pairs_per_launch, 1),
             "avg_launch_ms": round(avg_launch_s * 1e3, 4),

@@ -80,6 +80,7 @@ struct mgl_sw_ctx {
     int64_t *pin_gate = nullptr;   // [0] pairs arrived, [1] (as int32) a wave gave up waiting
     std::vector<hipEvent_t> gate_ev;
     const int64_t *cur_gate = nullptr; // set around run_device by the direct form: device view of pin_gate (null: no gate)
+    int64_t *cur_gate_dev = nullptr;   // ... and the gate's mirror in device memory (DpArgs::gate_dev: two words behind d_any's status word, zeroed with it)
     bool direct_broken = false;    // a gate once timed out on this context: the direct form is not tried again
     int32_t *direct_status_any = nullptr; // ... and the device word that collects the largest per-pair status of its launch
     // small-batch entry of the coalescing front-end: one pinned host buffer each way, mirrored on the device
@@ -287,6 +288,11 @@ struct ChunkHooks {
     std::function<int(int64_t first, int64_t count, hipEvent_t results_ready)> after_traceback;
     // optional: sort the chunk by geometry (slot buffers `half` are free to overwrite when this is called)
     std::function<int(int64_t first, int64_t count, int half, hipStream_t fill_stream, Regroup *out)> regroup;
+    // optional (round 5), instead of `regroup`: the chunks of a batch of mixed geometries are sorted ON THE DEVICE (launch_regroup, the
+    // device-resident entries' counting sort), two chunks ahead of the fills, and bring_ahead(first, count) enqueues that chunk's inputs
+    // on ctx->h2d in front of its sort -- the host never looks at a pair (a host-side sort of 4 M pairs took longer than their
+    // alignment: 86.8 ms per call against 23.4 device resident)
+    std::function<int(int64_t first, int64_t count)> bring_ahead;
     int32_t *d_status_any = nullptr;   // device word receiving the largest per-pair status
 };
 
@@ -322,6 +328,7 @@ struct BatchPlan {
     bool group_regions;  // a sorted device-resident chunk sized by slots: the lane part's regions, then left_area bytes for the left-over pairs
     int64_t left_area, left_pair16, left_pair32; // ... that area (its first half: the packed kernel's pieces, its second: the int32 kernel's) and a pair's bytes in each
     int64_t chunk; // pairs per chunk (the largest, where the chunks grow and shrink)
+    bool dev_sort_host; // a host batch of mixed geometries whose chunks the device sorts (hooks->bring_ahead): a short first and last chunk, two fill streams
     bool pyramid; // the host entry of a large 2-bit batch: chunks of 1, 2, 4, 8 .. 8, 4, 2, 1 rounds of the chip
     int64_t pyr_unit; // ... pairs per round
     bool overlap; // the traceback of chunk k runs beside the fill of chunk k + 1 (two workspace halves)
@@ -402,7 +409,8 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
     const bool auto_group_dev_on = debug_knobs().auto_group;
     // (the sort scans the whole (tl, ql) grid per chunk: worth it only where the pairs outnumber an eighth of its cells -- a few
     // thousand short pairs under a large bound would pay milliseconds for it)
-    const bool regroup_dev = !hooks && auto_group_dev_on && n >= 1024 && (int64_t)max_tl * max_ql <= (1ll << 20) && n * 8 >= (int64_t)max_tl * max_ql && !score_only_hint &&
+    const bool hooks_dev_sort = hooks && hooks->bring_ahead && !hooks->regroup; // (a host entry whose chunks the DEVICE sorts)
+    const bool regroup_dev = (!hooks || hooks_dev_sort) && auto_group_dev_on && n >= 1024 && (int64_t)max_tl * max_ql <= (1ll << 20) && n * 8 >= (int64_t)max_tl * max_ql && !score_only_hint &&
                              (tset.len != nullptr || !tset.packed2) && (qset.len != nullptr || !qset.packed2);
     const bool auto_group = geom == GEOM_MIXED && ((hooks && hooks->regroup) || regroup_dev) && ctx->precision != 32 && !d_matrix && match > 0 &&
                             !ctx->stripe_rows && ctx->cooperative < 2 && ctx->carry_memory == 0 && max_ql < kRows64MinQuery &&
@@ -526,12 +534,16 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
     // sized by its records alone: 4 M reads of 100-150 bases are ONE chunk in an 8 GiB workspace (round 3 sized every pair for the
     // left-over kernels' traceback, 19 KB: 21 chunks in 8 GiB -- 3 125 GCUPS --, 3 in 72 GiB -- 4 850 --, one in 170 GiB -- 5 320).
     const int64_t left_pair = std::max(stride_words * 2, stride32_words * 4); // bytes of traceback per left-over pair, either kernel
-    const int64_t grp_slots = std::min<int64_t>(ck_chip, ctx->ws_limit / 4 * 3 / ck_region);
+    // (A host batch sorted on the device was also run with consecutive chunks on two streams and two halves of the workspace, so that one
+    // grid's end lay beside the next grid's start: 32.8 ms per 4 M mixed reads against 33.1 on one stream, for twice the regions -- what
+    // the call waited for was the host's own preparation in front of the first launch, not the grids' ends.  One stream, one set of regions.)
+    const int64_t grp_ws = ctx->ws_limit;
+    const int64_t grp_slots = std::min<int64_t>(ck_chip, grp_ws / 4 * 3 / ck_region);
     const char *const gre = getenv("MGL_SW_DEBUG_GROUP_REGIONS"); // (0: sorted chunks sized per pair, as before round 4; read per call: the tests compare both)
     const char *const lae = getenv("MGL_SW_DEBUG_LEFT_AREA");     // (bytes of the left-over pairs' area: tests make it small, so that the left-overs take several pieces)
     const int64_t grp_left_area = lae && atoll(lae) > 0 ? std::max<int64_t>(left_pair * 16, atoll(lae)) / 256 * 256 : std::max<int64_t>(left_pair * 64, std::min<int64_t>(std::min<int64_t>(ctx->ws_limit / 8, (int64_t)1 << 30), 2 * left_pair * ((n + 63) / 64 * 64))) / 256 * 256; // (two halves: the packed kernel's pieces, the int32 kernel's)
-    const bool group_regions = auto_group && lane_group && !hooks && !score_only && !(gre && atoi(gre) == 0) && grp_slots >= std::min<int64_t>(ck_chip, (int64_t)ctx->n_cus * LANE_CK_WAVES_PER_CU) / 2 &&
-                               ctx->ws_limit - grp_slots * ck_region - grp_left_area >= (int64_t)sizeof(DpRecord) * kLaneGroupMinPairs &&
+    const bool group_regions = auto_group && lane_group && (!hooks || hooks_dev_sort) && !score_only && !(gre && atoi(gre) == 0) && grp_slots >= std::min<int64_t>(ck_chip, (int64_t)ctx->n_cus * LANE_CK_WAVES_PER_CU) / 2 &&
+                               grp_ws - grp_slots * ck_region - grp_left_area >= (int64_t)sizeof(DpRecord) * kLaneGroupMinPairs &&
                                n >= kLaneGroupMinPairs;
     const int64_t per_pair = lane_ck || group_regions ? (int64_t)sizeof(DpRecord) // (+ fixed_bytes per half: the persistent grid's regions)
                              : use_lane ? ((score_only ? 0 : stride_words * 4) + lane_scratch_bytes(max_tl, max_ql, rows)) / 128 + 1 + (int64_t)sizeof(DpRecord)
@@ -564,8 +576,16 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
     // chunk k-1 move while chunk k computes), so a batch is cut into ~32 even when the workspace would hold it whole
     // (10 M pairs: 133 ms in 46 chunks, 143 in 12, scripts/host_entry_probe.py)
     constexpr int host_chunks = kHostChunks;
-    if (hooks && !(use_lane && lane_rounds))
+    if (hooks && !(use_lane && lane_rounds) && !(hooks_dev_sort && group_regions))
         chunk = std::min<int64_t>(chunk, std::max<int64_t>((n / host_chunks + gran - 1) / gran * gran, (int64_t)256 * 1024));
+    // ... a host batch sorted on the device and sized by wave slots: a chunk is a launch of the persistent grid (its end leaves slots idle:
+    // few chunks), and what cannot hide is the first chunk's way in and the last one's results on their way out (small chunks) -- about a
+    // million pairs each, eight chunks at least from 4 M pairs on (MGL_SW_DEBUG_HOST_SORT_CHUNK: measurements; read per call)
+    if (hooks_dev_sort && group_regions) {
+        const char *const hce = getenv("MGL_SW_DEBUG_HOST_SORT_CHUNK");
+        const int64_t want = hce && atoll(hce) > 0 ? atoll(hce) : std::max<int64_t>((int64_t)1 << 20, (n / 8 + 1023) / 1024 * 1024);
+        chunk = std::min<int64_t>(chunk, std::max<int64_t>(want / 128 * 128, hce && atoll(hce) > 0 ? 128 : 128 * 1024));
+    }
     // lane kernel behind the host entry: one round of the chip per chunk.  A chunk that is not a whole number of rounds leaves
     // most CUs idle during its last one (1.25 M pairs = 3.2 rounds ran as 4), and nothing computes while the first chunk's
     // inputs cross the link, so small is good; the tails of consecutive launches overlap on the two streams (10 M pairs:
@@ -630,6 +650,7 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
     P.left_pair16 = stride_words * 2;
     P.left_pair32 = stride32_words * 4;
     P.chunk = chunk;
+    P.dev_sort_host = hooks_dev_sort && group_regions;
     P.pyramid = pyramid;
     P.pyr_unit = pyr_unit;
     P.overlap = overlap;
@@ -800,6 +821,15 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     // the size of the chunk that starts at pair `first` as the k-th of the call
     auto chunk_at = [&](int64_t first, int64_t k) -> int64_t {
         const int64_t left = n - first;
+        if (P.dev_sort_host) {
+            // what cannot hide is the first chunk's way in (nothing computes until its inputs have crossed the link and its sort is done) and
+            // the last chunk's results on their way out: those two are half a chunk
+            const int64_t half = std::max<int64_t>(128, chunk / 2 / 128 * 128);
+            if (n <= chunk) return left; // (one chunk holds the batch)
+            if (k == 0) return half;
+            if (left > chunk + half) return chunk;
+            return left - half >= chunk / 4 ? (left - half) / 128 * 128 : left; // (no launch for a sliver: it goes with the last chunk)
+        }
         if (!pyramid) return std::min(chunk, left);
         const int64_t grow = std::min(chunk, pyr_unit << std::min<int64_t>(k, 8));
         const int64_t half_left = std::max(pyr_unit, left / 2 / pyr_unit * pyr_unit); // (whole rounds; towards the end: half of what is left)
@@ -817,7 +847,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
         pl.waves_per_pair = strip16 ? strip_waves : coop_waves;
         pl.traceback = score_only ? 2 : lane_ck || (strip16 && strip_k) ? 1 : 0;
         pl.fused_walk = fused_walk ? 1 : 0;
-        pl.sorted_by_library = auto_group ? (hooks ? 2 : 1) : 0;
+        pl.sorted_by_library = auto_group ? (hooks && hooks->regroup ? 2 : 1) : 0;
         pl.fill_streams = dual ? 2 : 1;
         pl.workspace_halves = halves;
         pl.chunk_pairs = chunk;
@@ -878,6 +908,8 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     }
 
     bool tb_pending[2] = {false, false};
+    bool side_grid_pending[2] = {false, false}; // a sorted chunk's grid has been enqueued on the fill stream of half h (fill_done[h] follows it)
+    int64_t sort_next_first = 0, sorted_chunks = 0; // device sort, two chunks ahead: where the next chunk to sort starts, how many have been enqueued
     bool srt_used[4] = {false, false, false, false};
     int64_t k = 0;
     // result copies trail the launches by two chunks: the traceback of chunk k-2 is what the fill of chunk k waits
@@ -885,6 +917,61 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     int64_t lane_pairs_last = 0; // sorted chunks: pairs of the last chunk that went through the lane kernel
     struct Pending { int64_t first, count; hipEvent_t ready; } pending[2];
     int n_pending = 0;
+    // ---- the device-side sort of a batch of mixed geometries (auto_group without a host-side regroup hook), used inside the loop below
+    // the sort of chunk k runs on the copy stream (idle for a device-resident batch) while chunk k-1 is being filled:
+    // it is enqueued one chunk ahead, and only that stream is synchronised to read the block total
+    auto sort_chunk = [&](int64_t f, int64_t c, int hh, RegroupArgs *out) -> int { // hh = chunk number mod 4
+        const size_t cells_n = (size_t)max_tl * max_ql;
+        int64_t *d = static_cast<int64_t *>(ctx->d_srt[hh].p);
+        int32_t *g = static_cast<int32_t *>(ctx->d_grid.p);
+        RegroupArgs ra;
+        ra.t = tset;
+        ra.q = qset;
+        ra.first = f;
+        ra.count = c;
+        ra.max_tl = max_tl;
+        ra.max_ql = max_ql;
+        ra.cnt = g;
+        ra.nfull = g + cells_n;
+        ra.full_start = g + 2 * cells_n;
+        ra.rest_start = g + 3 * cells_n;
+        ra.nlane = g + 4 * cells_n;
+        ra.lane_start = g + 5 * cells_n;
+        ra.lane_blocks = lane_group ? 1 : 0;
+        ra.total = reinterpret_cast<int64_t *>(g + 6 * cells_n) + 2 * hh;
+        ra.t_start = d;
+        ra.q_start = d + c;
+        ra.dest = d + 2 * c;
+        ra.t_len = reinterpret_cast<int32_t *>(d + 3 * c);
+        ra.q_len = ra.t_len + c;
+        if (out) {
+            *out = ra;
+            return MGL_SW_OK;
+        }
+        // these index arrays were last read by the kernels of the chunk four before this one
+        if (srt_used[hh]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->h2d, ctx->srt_free[hh], 0));
+        if (hooks && hooks->bring_ahead) { // a host batch: this chunk's inputs cross the link in front of its sort, on the same stream
+            const int brc = hooks->bring_ahead(f, c);
+            if (brc != MGL_SW_OK) return brc;
+        }
+        HIP_TRY(ctx, launch_regroup(ra, ctx->h2d));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_total + 2 * hh, ra.total, 16, hipMemcpyDeviceToHost, ctx->h2d));
+        HIP_TRY(ctx, hipEventRecord(ctx->srt_done[hh], ctx->h2d));
+        return MGL_SW_OK;
+    };
+    // the sorts run two chunks ahead of the fills (beside a fill kernel that has the chip a sort of unsorted reads takes
+    // 2-3 ms, longer than one chunk's fill); chunk j starts where chunk j - 1 ended (chunk_at: the chunks need not be alike)
+    // (sort_until(j): the sorts of the chunks up to number j are enqueued)
+    auto sort_until = [&](int64_t j) -> int {
+        while (sorted_chunks <= j && sort_next_first < n) {
+            const int64_t f = sort_next_first, c = chunk_at(f, sorted_chunks);
+            sort_next_first += c;
+            const int src = sort_chunk(f, c, (int)(sorted_chunks & 3), nullptr);
+            if (src != MGL_SW_OK) return src;
+            ++sorted_chunks;
+        }
+        return MGL_SW_OK;
+    };
     for (int64_t first = 0, count = 0; first < n; first += count, ++k) {
         count = chunk_at(first, k);
         const int h = (int)(k & (halves - 1));
@@ -893,6 +980,7 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             const int hrc = hooks->before_fill(first, count, fs);
             if (hrc != MGL_SW_OK) return hrc;
         }
+        bool sort_more = false;
         // what this chunk launches: one part normally; a chunk the host entry has sorted by geometry has a packed part
         // (full blocks of eight) and an int32 part (the left-over pairs), each with its own kernels and workspace regions
         struct Part {
@@ -917,55 +1005,14 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             if (overlap && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->h2d, ctx->tb_done[h], 0));
             Regroup rg;
             rg.lane_blocks = lane_group;
-            if (hooks) {
+            if (hooks && hooks->regroup) {
                 const int hrc = hooks->regroup(first, count, h, fs, &rg);
                 if (hrc != MGL_SW_OK) return hrc;
             } else {
-                // the sort of chunk k runs on the copy stream (idle for a device-resident batch) while chunk k-1 is being filled:
-                // it is enqueued one chunk ahead, and only that stream is synchronised to read the block total
-                auto sort_chunk = [&](int64_t f, int64_t c, int hh, RegroupArgs *out) -> int { // hh = chunk number mod 4
-                    const size_t cells_n = (size_t)max_tl * max_ql;
-                    int64_t *d = static_cast<int64_t *>(ctx->d_srt[hh].p);
-                    int32_t *g = static_cast<int32_t *>(ctx->d_grid.p);
-                    RegroupArgs ra;
-                    ra.t = tset;
-                    ra.q = qset;
-                    ra.first = f;
-                    ra.count = c;
-                    ra.max_tl = max_tl;
-                    ra.max_ql = max_ql;
-                    ra.cnt = g;
-                    ra.nfull = g + cells_n;
-                    ra.full_start = g + 2 * cells_n;
-                    ra.rest_start = g + 3 * cells_n;
-                    ra.nlane = g + 4 * cells_n;
-                    ra.lane_start = g + 5 * cells_n;
-                    ra.lane_blocks = lane_group ? 1 : 0;
-                    ra.total = reinterpret_cast<int64_t *>(g + 6 * cells_n) + 2 * hh;
-                    ra.t_start = d;
-                    ra.q_start = d + c;
-                    ra.dest = d + 2 * c;
-                    ra.t_len = reinterpret_cast<int32_t *>(d + 3 * c);
-                    ra.q_len = ra.t_len + c;
-                    if (out) {
-                        *out = ra;
-                        return MGL_SW_OK;
-                    }
-                    // these index arrays were last read by the kernels of the chunk four before this one
-                    if (srt_used[hh]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->h2d, ctx->srt_free[hh], 0));
-                    HIP_TRY(ctx, launch_regroup(ra, ctx->h2d));
-                    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_total + 2 * hh, ra.total, 16, hipMemcpyDeviceToHost, ctx->h2d));
-                    HIP_TRY(ctx, hipEventRecord(ctx->srt_done[hh], ctx->h2d));
-                    return MGL_SW_OK;
-                };
-                // chunk j = pairs [j * chunk, ...): the sorts run two chunks ahead of the fills (beside a fill kernel that has the
-                // chip a sort of unsorted reads takes 2-3 ms, longer than one chunk's fill)
-                auto sort_ahead = [&](int64_t j) -> int {
-                    const int64_t f = j * chunk;
-                    return f < n ? sort_chunk(f, std::min(chunk, n - f), (int)(j & 3), nullptr) : MGL_SW_OK;
-                };
                 if (k == 0) {
                     const size_t cells_n = (size_t)max_tl * max_ql;
+                    sort_next_first = 0;
+                    sorted_chunks = 0;
                     for (int b = 0; b < 4; ++b) {
                         HIP_TRY(ctx, ctx->d_srt[b].reserve((size_t)chunk * 32));
                         if (!ctx->srt_free[b]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->srt_free[b], hipEventDisableTiming));
@@ -976,10 +1023,13 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                     // (the caller's stream may still be producing the inputs)
                     HIP_TRY(ctx, hipEventRecord(ctx->fill_done[0], stream));
                     HIP_TRY(ctx, hipStreamWaitEvent(ctx->h2d, ctx->fill_done[0], 0));
-                    for (int64_t j = 0; j < 2; ++j) {
-                        const int src = sort_ahead(j);
-                        if (src != MGL_SW_OK) return src;
-                    }
+                }
+                // A HOST batch: what stands in front of a chunk's sort is the host's own work on that chunk -- a look at its index arrays, its
+                // copy commands (bring_ahead) -- and in front of the FIRST launch nothing hides it: the first chunk alone, then the launch, then
+                // the chunks ahead (traced: chunks 0, 1 and 2 prepared before the first kernel started, 8 ms into a call of 33).
+                {
+                    const int src = sort_until(hooks ? k : k + 1);
+                    if (src != MGL_SW_OK) return src;
                 }
                 HIP_TRY(ctx, hipEventSynchronize(ctx->srt_done[k & 3])); // the sort of THIS chunk, enqueued two iterations ago
                 RegroupArgs ra;
@@ -993,10 +1043,11 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
                 rg.n_lane = ctx->pin_total[2 * (k & 3) + 1];
                 if (rg.n_grouped < 0 || rg.n_grouped > count || (rg.n_grouped & 7) || rg.n_lane < 0 || rg.n_lane > rg.n_grouped || (rg.n_lane & 127))
                     return fail(ctx, MGL_SW_ERR_DEVICE, "sorting a chunk by geometry failed");
-                {
-                    const int src = sort_ahead(k + 2);
+                if (!hooks) { // (device resident: nothing of the host's stands in front of a sort)
+                    const int src = sort_until(k + 2);
                     if (src != MGL_SW_OK) return src;
                 }
+                sort_more = hooks != nullptr; // (a host batch: behind this chunk's launches, below)
             }
             const SeqSet ts{tset.data, rg.d_t_start, rg.d_t_len, max_tl, tset.packed2}, qs{qset.data, rg.d_q_start, rg.d_q_len, max_ql, qset.packed2};
             const int64_t ng = rg.n_grouped;
@@ -1071,12 +1122,14 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             da.tile_ctr = nullptr;
             da.grid_fault = nullptr;
             da.gate = nullptr;
+            da.gate_dev = nullptr;
             da.gate_failed = nullptr;
             da.gate_timeout_ticks = 0;
             if (pt.lane && (lane_ck || da.grouped)) { // the persistent grid: its wave slots and, where the tiles outnumber them, a zeroed counter
                 da.lane_slots = (int)std::min<int64_t>(lane_slots - (side && n_parts > 1 ? std::min<int64_t>(side_reserve, lane_slots / 2) : 0), (pt.count + 127) / 128);
                 if (ctx->cur_gate && !hooks) { // the direct form of a host entry: the inputs are still arriving
                     da.gate = ctx->cur_gate;
+                    da.gate_dev = ctx->cur_gate_dev;
                     da.gate_failed = reinterpret_cast<int32_t *>(const_cast<int64_t *>(ctx->cur_gate) + 1);
                     da.gate_timeout_ticks = 100000000u; // one second without the word moving
                     if (const char *const gte = getenv("MGL_SW_DEBUG_GATE_TIMEOUT_TICKS")) da.gate_timeout_ticks = (unsigned)atoll(gte); // (tests take the give-up path with it; read per call)
@@ -1146,6 +1199,11 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             // slot they would wait for its end.  (Their inputs are complete: the host has waited for this chunk's sort, which waited for the
             // caller's stream.)
             if (k == 0 && ctx->ws_idle_set) HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ws_idle, 0));
+            // ... and, from the second chunk on, behind the grid of the chunk BEFORE (round 5): the chunks share one workspace -- this chunk's
+            // left-overs keep their records behind its own whole waves' (rec_base + f), where the last chunk's grid, still running on the other
+            // stream, keeps the records of ITS whole waves.  Never met while a chunk held a hundred million pairs (sized by records alone); a
+            // host batch sorted on the device is cut into chunks of a million: the first multi-chunk run returned CIGARs that did not fit.
+            if (side_grid_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->fill_done[h], 0));
             for (int i = 0; i < n_parts; ++i) {
                 const Part &pt = parts[i];
                 if (pt.lane) continue;
@@ -1172,6 +1230,10 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             HIP_TRY(ctx, hipEventRecord(ctx->fill_done[h], fs));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->fill_done[h], 0));
         }
+        if (side) { // (the next chunk's left-overs, on the second stream, wait for this chunk's grid: above)
+            HIP_TRY(ctx, hipEventRecord(ctx->fill_done[h], fs));
+            side_grid_pending[h] = true;
+        }
         if (pe[2]) HIP_TRY(ctx, hipEventRecord(pe[2], tb_stream));
         for (int i = 0; i < n_parts && !fused_walk; ++i) {
             if (das[i].grouped || parts[i].tb_now || (side && n_parts > 1)) continue; // walked inside its fill kernel / behind its fill already
@@ -1182,10 +1244,14 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
             HIP_TRY(ctx, hipEventRecord(ctx->tb_done[h], ctx->aux));
             tb_pending[h] = true;
         }
-        if (auto_group && !hooks) { // this chunk's index arrays are free once its walk is done
-            if (side && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(tb_stream, ctx->tb_done[h], 0)); // (... on either stream)
+        if (auto_group && !(hooks && hooks->regroup)) { // sorted on the device: this chunk's index arrays are free once its walk is done
+            if (side && tb_pending[h]) HIP_TRY(ctx, hipStreamWaitEvent(tb_stream, ctx->tb_done[h], 0)); // (... on either stream: the results a host entry copies out are complete behind this too)
             HIP_TRY(ctx, hipEventRecord(ctx->srt_free[k & 3], tb_stream));
             srt_used[k & 3] = true;
+        }
+        if (sort_more) { // a host batch sorted on the device: the chunks ahead are prepared BEHIND this chunk's launches
+            const int src = sort_until(k + 2);
+            if (src != MGL_SW_OK) return src;
         }
         if (hooks) {
             if (n_pending == 2) {
@@ -1552,6 +1618,7 @@ int mgl_sw_explain(mgl_sw_ctx *ctx, int64_t workspace_limit, int64_t n, int max_
         qs{dummy8, dummy64, packed2 && !uniform ? dummy32 : nullptr, max_ql, packed2 ? 1 : 0};
     ChunkHooks hooks; // a host entry: the hooks exist (they are not called), and the ASCII one sorts mixed batches itself
     if (entry == 1 && !packed2) hooks.regroup = [](int64_t, int64_t, int, hipStream_t, Regroup *) { return MGL_SW_OK; };
+    if (entry == 1 && packed2) hooks.bring_ahead = [](int64_t, int64_t) { return MGL_SW_OK; }; // (mgl_sw_align_batch_2bit: mixed geometries are sorted on the device)
     int32_t off_ = 0;
     char cg_ = 0;
     Score sc_{};
@@ -1770,6 +1837,10 @@ int mgl_sw_align_batch(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const
                                      offset_out, score_out, cigar_out, cigar_stride, cigar_len_out, nullptr);
 }
 
+static int align_ascii_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const uint8_t *queries, int tl, int ql, int match, int mismatch, int gopen, int gext,
+                              int strategy, int32_t *offset_out, mgl_sw_score *score_out, char *cigar_out, int cigar_stride, int32_t *cigar_len_out, int32_t *status_out,
+                              bool *taken);
+
 int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const int64_t *t_off,
                               const uint8_t *queries, const int64_t *q_off, int match, int mismatch, int gopen,
                               int gext, int strategy, int32_t *offset_out, mgl_sw_score *score_out, char *cigar_out,
@@ -1866,6 +1937,15 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     }
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // ---- the direct form (round 5: the reference's own wire format, ASCII bases in host memory, MicrosoftSmithWaterman.java:71-86): one
+    // geometry, every array page-locked by the caller, the checkpointed lane kernel in one launch -- the grid waits at its gate while the
+    // copy engines bring the bases in, the results are written by the waves into the caller's arrays
+    if (uniform == GEOM_UNIFORM) {
+        bool taken = false;
+        const int drc = align_ascii_direct(ctx, n, targets, queries, max_tl, max_ql, match, mismatch, gopen, gext, strategy, offset_out, score_out, cigar_out, cigar_stride,
+                                           cigar_len_out, status_out, &taken);
+        if (taken) return drc;
+    }
     HIP_TRY(ctx, ctx->d_t.reserve(t_bytes));
     HIP_TRY(ctx, ctx->d_q.reserve(q_bytes));
     HIP_TRY(ctx, ctx->d_toff.reserve((size_t)(n + 1) * 8));
@@ -1875,7 +1955,7 @@ int mgl_sw_align_batch_status(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets
     HIP_TRY(ctx, ctx->d_cig.reserve((size_t)n * cigar_stride));
     HIP_TRY(ctx, ctx->d_len.reserve((size_t)n * 4));
     HIP_TRY(ctx, ctx->d_status.reserve((size_t)n * 4));
-    HIP_TRY(ctx, ctx->d_any.reserve(16));
+    HIP_TRY(ctx, ctx->d_any.reserve(64));
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_any.p, 0, 4, st));
     // everything moves chunk by chunk, overlapped with the kernels: a chunk's offsets (16 bytes per pair) go with its bases
@@ -2140,7 +2220,7 @@ static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_b
     HIP_TRY(ctx, ctx->d_q.reserve(q_bytes + 8));
     HIP_TRY(ctx, ctx->d_toff.reserve(nn * 8));
     HIP_TRY(ctx, ctx->d_qoff.reserve(nn * 8));
-    HIP_TRY(ctx, ctx->d_any.reserve(16));
+    HIP_TRY(ctx, ctx->d_any.reserve(64));
     if (!ctx->pin_gate) {
         HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->pin_gate), 64, hipHostMallocDefault));
         memset(ctx->pin_gate, 0, 64);
@@ -2151,7 +2231,7 @@ static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_b
     HIP_TRY(ctx, hipStreamSynchronize(st)); // (nothing of an earlier call reads the gate or the inputs any more)
     __atomic_store_n(&ctx->pin_gate[0], (int64_t)0, __ATOMIC_RELEASE);
     __atomic_store_n(reinterpret_cast<int32_t *>(&ctx->pin_gate[1]), 0, __ATOMIC_RELEASE);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_any.p, 0, 4, st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_any.p, 0, 64, st)); // (the status word and, 16 bytes on, the gate's mirror)
     // the chunks: first what gives every wave of the grid its first tile (and the tile behind it: the gate's margin) -- traced with
     // chunks doubling from 32 k pairs: the sixteen copy commands of the first four cost the waves 1.9 ms at the gate -- then a million
     // pairs at a time
@@ -2173,10 +2253,12 @@ static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_b
     const SeqSet ts{static_cast<const uint8_t *>(ctx->d_t.p), static_cast<const int64_t *>(ctx->d_toff.p), nullptr, max_tl, 1},
         qs{static_cast<const uint8_t *>(ctx->d_q.p), static_cast<const int64_t *>(ctx->d_qoff.p), nullptr, max_ql, 1};
     ctx->cur_gate = static_cast<const int64_t *>(gate_dev);
+    ctx->cur_gate_dev = reinterpret_cast<int64_t *>(static_cast<char *>(ctx->d_any.p) + 16);
     ctx->direct_status_any = static_cast<int32_t *>(ctx->d_any.p);
     int rc = run_device(ctx, st, n, ts, qs, max_tl, max_ql, match, mismatch, gopen, gext, strategy, static_cast<int32_t *>(d_off), static_cast<Score *>(d_sc),
                         static_cast<char *>(d_cg), cigar_stride, static_cast<int32_t *>(d_len), static_cast<int32_t *>(d_st), n * (int64_t)max_tl * max_ql, GEOM_UNIFORM);
     ctx->cur_gate = nullptr;
+    ctx->cur_gate_dev = nullptr;
     ctx->direct_status_any = nullptr;
     // (from here on a grid may be waiting at the gate: every way out that is not the good one CALLS IT OFF -- a negative gate: the waves
     // leave at their next look, those inside a tile after it; round 4 opened the gate to n here, and the grid then worked through pairs
@@ -2294,6 +2376,148 @@ static int align_2bit_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_b
     return MGL_SW_OK;
 }
 
+// ---- the DIRECT form of mgl_sw_align_batch / _status (round 5): the reference's own calling contract -- ASCII bases in host memory,
+// MicrosoftSmithWaterman.java:71-86 -- for a batch of one geometry whose arrays the caller has page-locked.  As align_2bit_direct above:
+// the persistent grid is launched first and waits at its gate, the copy engines bring the bases in chunk by chunk, the waves write the
+// results into the caller's arrays.  What differs: 4.06 GB cross the link for 10 M pairs of 256 x 150 where the packed form sends 0.54 --
+// the LINK is the bound (73-76 ms against the grid's 64), every wave stands at the gate most of the time (hence the gate's mirror in device
+// memory, sw_dp16_lane_ck.hip: one wave per microsecond looks at the host's word, not 2 048), and what the call takes beyond the link's
+// time is the first chunk's way in and the tiles of the last chunk -- so the chunks are 262 144 pairs (110 MB, two milliseconds) and the last
+// ones halve down to 16 384.  The offset arrays do not travel at all: the scan of mgl_sw_align_batch_status has found every pair tl x ql, so pair k starts
+// at k * tl, and a kernel in front of the grid writes exactly that into the device's copies (160 MB less on the link).
+static int align_ascii_direct(mgl_sw_ctx *ctx, int64_t n, const uint8_t *targets, const uint8_t *queries, int tl, int ql, int match, int mismatch, int gopen, int gext,
+                              int strategy, int32_t *offset_out, mgl_sw_score *score_out, char *cigar_out, int cigar_stride, int32_t *cigar_len_out, int32_t *status_out,
+                              bool *taken)
+{
+    *taken = false;
+    const size_t nn = (size_t)n, t_bytes = nn * (size_t)tl, q_bytes = nn * (size_t)ql;
+    const char *const off_env = getenv("MGL_SW_DEBUG_HOST_DIRECT"); // (0: always the chunked form; read per call: tests compare the two)
+    if (ctx->direct_broken || (off_env && atoi(off_env) == 0)) return MGL_SW_OK;
+    if (!(ctx->is_registered(targets, t_bytes) && ctx->is_registered(queries, q_bytes) && ctx->is_registered(offset_out, nn * 4) &&
+          (!score_out || ctx->is_registered(score_out, nn * sizeof(mgl_sw_score))) && ctx->is_registered(cigar_out, nn * (size_t)cigar_stride) &&
+          (!cigar_len_out || ctx->is_registered(cigar_len_out, nn * 4)) && (!status_out || ctx->is_registered(status_out, nn * 4))))
+        return MGL_SW_OK;
+    void *d_off = nullptr, *d_sc = nullptr, *d_cg = nullptr, *d_len = nullptr, *d_st = nullptr;
+    if (hipHostGetDevicePointer(&d_off, offset_out, 0) != hipSuccess || hipHostGetDevicePointer(&d_cg, cigar_out, 0) != hipSuccess ||
+        (score_out && hipHostGetDevicePointer(&d_sc, score_out, 0) != hipSuccess) || (cigar_len_out && hipHostGetDevicePointer(&d_len, cigar_len_out, 0) != hipSuccess) ||
+        (status_out && hipHostGetDevicePointer(&d_st, status_out, 0) != hipSuccess)) {
+        (void)hipGetLastError();
+        return MGL_SW_OK;
+    }
+    int m_ = match, x_ = mismatch, o_ = gopen, e_ = gext;
+    mgl_sw_normalize_params(&m_, &x_, &o_, &e_);
+    {   // does the batch plan as ONE launch of the checkpointed lane kernel whose results can leave in whole lines?
+        const SeqSet ts{reinterpret_cast<const uint8_t *>(8), reinterpret_cast<const int64_t *>(8), nullptr, tl, 0}, qs{reinterpret_cast<const uint8_t *>(8), reinterpret_cast<const int64_t *>(8), nullptr, ql, 0};
+        BatchPlan P{};
+        const std::string err = ctx->err;
+        const int prc = plan_batch(ctx, n, ts, qs, tl, ql, m_, x_, o_, e_, strategy, static_cast<const Score *>(d_sc), static_cast<const char *>(d_cg), cigar_stride, GEOM_UNIFORM, false, nullptr,
+                                   nullptr, false, P);
+        ctx->err = err;
+        TbArgs probe{};
+        probe.cigar = static_cast<char *>(d_cg);
+        probe.cigar_stride = cigar_stride;
+        probe.offset = static_cast<int32_t *>(d_off);
+        probe.score = static_cast<Score *>(d_sc);
+        probe.cigar_len = static_cast<int32_t *>(d_len);
+        probe.status = static_cast<int32_t *>(d_st);
+        if (prc != MGL_SW_OK || !P.lane_ck || P.auto_group || P.chunk < n || !lane_ck_coalesced_ok(probe)) return MGL_SW_OK;
+    }
+    *taken = true;
+    HIP_TRY(ctx, ctx->d_t.reserve(t_bytes + 64));
+    HIP_TRY(ctx, ctx->d_q.reserve(q_bytes + 64));
+    HIP_TRY(ctx, ctx->d_toff.reserve((nn + 1) * 8));
+    HIP_TRY(ctx, ctx->d_qoff.reserve((nn + 1) * 8));
+    HIP_TRY(ctx, ctx->d_any.reserve(64));
+    if (!ctx->pin_gate) {
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->pin_gate), 64, hipHostMallocDefault));
+        memset(ctx->pin_gate, 0, 64);
+    }
+    void *gate_dev = nullptr;
+    HIP_TRY(ctx, hipHostGetDevicePointer(&gate_dev, ctx->pin_gate, 0));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipStreamSynchronize(st)); // (nothing of an earlier call reads the gate or the inputs any more)
+    __atomic_store_n(&ctx->pin_gate[0], (int64_t)0, __ATOMIC_RELEASE);
+    __atomic_store_n(reinterpret_cast<int32_t *>(&ctx->pin_gate[1]), 0, __ATOMIC_RELEASE);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_any.p, 0, 64, st));
+    // the offsets, made where they are used (in front of the grid, on its stream: done before the grid's first wave looks at one)
+    HIP_TRY(ctx, launch_iota64(static_cast<int64_t *>(ctx->d_toff.p), n + 1, tl, st));
+    HIP_TRY(ctx, launch_iota64(static_cast<int64_t *>(ctx->d_qoff.p), n + 1, ql, st));
+    const char *const dce = getenv("MGL_SW_DEBUG_DIRECT_CHUNK"); // (pairs per chunk; read per call)
+    // (measured, 10 M pairs of 256 x 150, chunks all alike: 65 536 pairs 53.8 GB/s and the grid ends 1.9 ms behind the last byte; 131 072: 55.3
+    // and 2.4; 262 144: 56.0 and 3.3; 524 288: 56.1 and 5.1 -- large chunks for the link, small ones for the end: the last chunk and a half
+    // goes in pieces that halve down to 16 384 pairs)
+    const int64_t per = std::max<int64_t>(128, (dce ? atoll(dce) : (int64_t)256 * 1024) / 128 * 128), least = std::min<int64_t>(per, 16384);
+    std::vector<int64_t> ends;
+    for (int64_t first = 0; first < n;) {
+        const int64_t left = n - first;
+        int64_t c = per;
+        if (left <= per + per / 2) c = left / 2 >= least ? (left / 2 + 127) / 128 * 128 : left;
+        first = std::min(n, first + c);
+        ends.push_back(first);
+    }
+    while (ctx->gate_ev.size() < ends.size()) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->gate_ev.push_back(e);
+    }
+    const SeqSet ts{static_cast<const uint8_t *>(ctx->d_t.p), static_cast<const int64_t *>(ctx->d_toff.p), nullptr, tl, 0},
+        qs{static_cast<const uint8_t *>(ctx->d_q.p), static_cast<const int64_t *>(ctx->d_qoff.p), nullptr, ql, 0};
+    ctx->cur_gate = static_cast<const int64_t *>(gate_dev);
+    ctx->cur_gate_dev = reinterpret_cast<int64_t *>(static_cast<char *>(ctx->d_any.p) + 16);
+    ctx->direct_status_any = static_cast<int32_t *>(ctx->d_any.p);
+    int rc = run_device(ctx, st, n, ts, qs, tl, ql, match, mismatch, gopen, gext, strategy, static_cast<int32_t *>(d_off), static_cast<Score *>(d_sc), static_cast<char *>(d_cg),
+                        cigar_stride, static_cast<int32_t *>(d_len), static_cast<int32_t *>(d_st), n * (int64_t)tl * ql, GEOM_UNIFORM);
+    ctx->cur_gate = nullptr;
+    ctx->cur_gate_dev = nullptr;
+    ctx->direct_status_any = nullptr;
+    // (from here on a grid may be waiting at the gate: every way out that is not the good one calls it off)
+    auto bail = [&](int code) -> int {
+        __atomic_store_n(&ctx->pin_gate[0], (int64_t)-1, __ATOMIC_RELEASE);
+        drain_streams(ctx, st);
+        return code;
+    };
+    if (rc != MGL_SW_OK) return bail(rc);
+    const bool timing = debug_knobs().host_timing;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_launched = now();
+    size_t landed = 0;
+    for (size_t k = 0; k < ends.size(); ++k) {
+        const size_t f = (size_t)(k ? ends[k - 1] : 0), c = (size_t)ends[k] - f;
+        hipError_t e = hipMemcpyAsync(static_cast<uint8_t *>(ctx->d_t.p) + f * (size_t)tl, targets + f * (size_t)tl, c * (size_t)tl, hipMemcpyHostToDevice, ctx->h2d);
+        if (e == hipSuccess) e = hipMemcpyAsync(static_cast<uint8_t *>(ctx->d_q.p) + f * (size_t)ql, queries + f * (size_t)ql, c * (size_t)ql, hipMemcpyHostToDevice, ctx->h2d);
+        if (e == hipSuccess) e = hipEventRecord(ctx->gate_ev[k], ctx->h2d);
+        if (e != hipSuccess) return bail(hip_fail(ctx, e, "mgl_sw_align_batch: input copy"));
+        // the gate moves on over every chunk that has landed meanwhile
+        while (landed <= k && hipEventQuery(ctx->gate_ev[landed]) == hipSuccess) __atomic_store_n(&ctx->pin_gate[0], ends[landed++], __ATOMIC_RELEASE);
+        (void)hipGetLastError(); // (hipErrorNotReady is not an error)
+    }
+    for (; landed < ends.size(); ++landed) {
+        if (hipEventSynchronize(ctx->gate_ev[landed]) != hipSuccess) {
+            (void)hipGetLastError();
+            return bail(fail(ctx, MGL_SW_ERR_DEVICE, "mgl_sw_align_batch: an input copy failed"));
+        }
+        __atomic_store_n(&ctx->pin_gate[0], ends[landed], __ATOMIC_RELEASE);
+    }
+    const double t_gate_open = now();
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (timing)
+        fprintf(stderr, "[mgl_sw] direct form, ASCII: %zu chunks of %lld pairs; all inputs landed %.2f ms after the launch (%.1f GB/s), the grid ended %.2f ms after that\n", ends.size(),
+                (long long)per, (t_gate_open - t_launched) * 1e3, (double)(t_bytes + q_bytes) / (t_gate_open - t_launched) / 1e9, (now() - t_gate_open) * 1e3);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->h2d));
+    if (const int frc = grid_fault_check(ctx)) return frc;
+    if (__atomic_load_n(reinterpret_cast<int32_t *>(&ctx->pin_gate[1]), __ATOMIC_ACQUIRE) != 0) {
+        // a wave gave up at the gate: not again on this context; this call goes the chunked way (every result is written again)
+        ctx->direct_broken = true;
+        *taken = false;
+        return MGL_SW_OK;
+    }
+    if (status_out) return MGL_SW_OK;
+    int32_t any = 0;
+    HIP_TRY(ctx, hipMemcpy(&any, ctx->d_any.p, 4, hipMemcpyDeviceToHost));
+    if (any != 0) return fail(ctx, any, "a CIGAR did not fit cigar_stride");
+    return MGL_SW_OK;
+}
+
 // ---- host buffers, 2-bit packed bases (the wire format of mgl_sw_align_batch_device_2bit from host memory).  The packed arrays move
 // chunk by chunk with the index arrays when the pairs' start positions ascend (reads packed back to back), or whole before the
 // first chunk (windows into a genome, in any order); results leave as in mgl_sw_align_batch_status.
@@ -2351,10 +2575,14 @@ int mgl_sw_align_batch_2bit(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_ba
         }
         return r;
     };
+    // (mixed geometries, round 5: no pass over the whole batch in front of everything -- 3 ms per 4 M pairs on eight threads before the
+    // first copy command --: every chunk's index arrays are looked at when the chunk is brought in, bring_chunk below)
+    const bool dev_sort = !uniform && !grouped;
     Scan sc;
     try {
         constexpr int kParts = 8;
-        if (n >= (1 << 21)) {
+        if (dev_sort) {
+        } else if (n >= (1 << 21)) {
             std::future<Scan> part[kParts];
             // (disjoint ranges: the pair at a range's start is compared with the one before it, `k > 0`, so the borders are covered)
             for (int p = 0; p < kParts; ++p) part[p] = std::async(std::launch::async, scan_range, n * p / kParts, n * (p + 1) / kParts);
@@ -2388,7 +2616,7 @@ int mgl_sw_align_batch_2bit(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_ba
     HIP_TRY(ctx, ctx->d_cig.reserve(nn * (size_t)cigar_stride));
     HIP_TRY(ctx, ctx->d_len.reserve(nn * 4));
     HIP_TRY(ctx, ctx->d_status.reserve(nn * 4));
-    HIP_TRY(ctx, ctx->d_any.reserve(16));
+    HIP_TRY(ctx, ctx->d_any.reserve(64));
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_any.p, 0, 4, st));
 
@@ -2400,10 +2628,10 @@ int mgl_sw_align_batch_2bit(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_ba
                      int64_t count, size_t &done) -> int {
         size_t upto = total;
         if (sorted && first + count < n) {
-            const int64_t last = first + count - 1;
-            int64_t hi = start[last] + (len ? len[last] : uni_len);
-            for (int64_t k = first; k < last; ++k) hi = std::max(hi, start[k] + (len ? len[k] : uni_len)); // (starts ascend, ends need not)
-            upto = std::min(total, (size_t)((hi + 3) >> 2));
+            // (starts ascend, ends need not: no pair of the chunk reaches beyond its last start + the longest sequence -- a bound, not a
+            // scan of the chunk: a few bytes too many cross the link, and the calling thread does not walk a million pairs per chunk)
+            (void)len;
+            upto = std::min(total, (size_t)((start[first + count - 1] + uni_len + 3) >> 2));
         }
         if (upto > done) {
             HIP_TRY(ctx, hipMemcpyAsync(static_cast<uint8_t *>(dst.p) + done, src + done, upto - done, hipMemcpyHostToDevice, ctx->h2d));
@@ -2411,8 +2639,37 @@ int mgl_sw_align_batch_2bit(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_ba
         }
         return MGL_SW_OK;
     };
-    hooks.before_fill = [&](int64_t first, int64_t count, hipStream_t fill_stream) -> int {
+    int64_t brought = 0; // pairs [0, brought) have had their inputs enqueued on ctx->h2d (the chunks come in order)
+    auto bring_chunk = [&](int64_t first, int64_t count) -> int {
+        if (first + count <= brought) return MGL_SW_OK;
         const size_t f = (size_t)first, c = (size_t)count;
+        if (dev_sort) {
+            // this chunk's index arrays, looked at now: every pair inside its array and within the stated maxima; do the starts still ascend
+            // (then the packed arrays travel slice by slice with the chunks -- once they do not, the rest of the array goes at once)?
+            Scan r;
+            try {
+                constexpr int kParts = 8;
+                if (count >= (1 << 18)) {
+                    std::future<Scan> part[kParts];
+                    for (int p = 0; p < kParts; ++p) part[p] = std::async(std::launch::async, scan_range, first + count * p / kParts, first + count * (p + 1) / kParts);
+                    for (int p = 0; p < kParts; ++p) {
+                        const Scan x = part[p].get();
+                        r.bad |= x.bad;
+                        r.t_sorted &= x.t_sorted;
+                        r.q_sorted &= x.q_sorted;
+                        r.cells += x.cells;
+                    }
+                } else {
+                    r = scan_range(first, first + count);
+                }
+            } catch (const std::exception &) {
+                return fail(ctx, MGL_SW_ERR_NOMEM, "mgl_sw_align_batch_2bit: out of host resources");
+            }
+            if (r.bad) return fail(ctx, MGL_SW_ERR_BAD_ARG, "mgl_sw_align_batch_2bit: a pair lies outside its packed array or its length outside [1, max]");
+            sc.t_sorted &= r.t_sorted;
+            sc.q_sorted &= r.q_sorted;
+            sc.cells += r.cells;
+        }
         HIP_TRY(ctx, hipMemcpyAsync(static_cast<int64_t *>(ctx->d_toff.p) + f, t_start + f, c * 8, hipMemcpyHostToDevice, ctx->h2d));
         HIP_TRY(ctx, hipMemcpyAsync(static_cast<int64_t *>(ctx->d_qoff.p) + f, q_start + f, c * 8, hipMemcpyHostToDevice, ctx->h2d));
         if (!uniform) {
@@ -2422,10 +2679,24 @@ int mgl_sw_align_batch_2bit(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_ba
         int rc = bring(target_bases, ctx->d_t, t_bytes, sc.t_sorted, t_start, uniform ? nullptr : t_len, max_tl, first, count, t_done);
         if (rc == MGL_SW_OK) rc = bring(query_bases, ctx->d_q, q_bytes, sc.q_sorted, q_start, uniform ? nullptr : q_len, max_ql, first, count, q_done);
         if (rc != MGL_SW_OK) return rc;
+        brought = first + count;
+        return MGL_SW_OK;
+    };
+    hooks.before_fill = [&](int64_t first, int64_t count, hipStream_t fill_stream) -> int {
+        // (a chunk the device sort has brought in ahead of its fill -- bring_ahead below -- is there already: run_device waits for that sort,
+        // which sits behind the chunk's copies on ctx->h2d, before it launches anything of the chunk)
+        if (first + count <= brought) return MGL_SW_OK;
+        const int rc = bring_chunk(first, count);
+        if (rc != MGL_SW_OK) return rc;
         HIP_TRY(ctx, hipEventRecord(ctx->in_done, ctx->h2d));
         HIP_TRY(ctx, hipStreamWaitEvent(fill_stream, ctx->in_done, 0));
         return MGL_SW_OK;
     };
+    // Mixed geometries (round 5): the chunks are sorted by (tl, ql) ON THE DEVICE, as the device-resident entries' are -- whole waves of
+    // one geometry through the checkpointed lane kernel's persistent grid, the rest through the packed and int32 kernels -- each chunk's
+    // inputs brought in front of its sort, two chunks ahead of the fills.  (Before: no sort at all on this entry -- every pair through the
+    // int32 kernel, 1 475 GCUPS on 4 M reads of 100-150 bases against 5 480 device resident.)
+    if (!uniform && !grouped) hooks.bring_ahead = bring_chunk;
     ResultPump pump(ctx, offset_out, score_out, cigar_out, cigar_stride, cigar_len_out, status_out, n);
     hooks.after_traceback = [&](int64_t first, int64_t count, hipEvent_t results_ready) -> int { return pump.after_traceback(first, count, results_ready); };
 
@@ -2440,6 +2711,7 @@ int mgl_sw_align_batch_2bit(mgl_sw_ctx *ctx, int64_t n, const uint8_t *target_ba
     } catch (const std::exception &) {
         rc = fail(ctx, MGL_SW_ERR_NOMEM, "mgl_sw_align_batch_2bit: out of host resources");
     }
+    if (dev_sort && ctx->profiling != 3) ctx->timing.cells = sc.cells; // (counted chunk by chunk, above)
     const int res_rc = pump.join();
     if (rc == MGL_SW_OK && res_rc != MGL_SW_OK) rc = fail(ctx, MGL_SW_ERR_DEVICE, "mgl_sw_align_batch_2bit: copying results out failed");
     if (rc != MGL_SW_OK) {

@@ -76,6 +76,8 @@ struct DpArgs {
     int32_t *grid_fault;      // ... optional: set to 1 (pinned host memory) by a wave that draws a number no launch of this size can draw
     const int64_t *gate;      // ... optional (host entries): a word in pinned host memory holding how many pairs of the batch have arrived in device memory
                               //     so far; a wave waits with a tile until its pairs are there (null: everything is)
+    int64_t *gate_dev;        // ... and its mirror in DEVICE memory, zeroed in front of the launch: [0] the word as a wave last read it over the link, [1] the 100 MHz time of
+                              //     that look -- the waiting waves watch the mirror, one of them per microsecond looks at the host's word (sw_dp16_lane_ck.hip)
     int32_t *gate_failed;     // ... set to 1 (pinned host memory) by a wave that gives up waiting: gate_timeout_ticks (100 MHz) without the word moving
     unsigned gate_timeout_ticks;
 };
@@ -339,6 +341,7 @@ struct RegroupArgs {
 };
 hipError_t launch_regroup(const RegroupArgs &a, hipStream_t stream);
 hipError_t launch_scores_only(const TbArgs &a, hipStream_t stream); // DpRecord -> ScoreMax, no path walk
+hipError_t launch_iota64(int64_t *dst, int64_t n, int64_t step, hipStream_t stream); // dst[k] = k * step, k = 0 .. n - 1 (the offsets of a uniform ASCII batch, made where they are used)
 hipError_t launch_cigar_from_matrix(const int32_t *btr, int tl, int ql, int strategy, const Score &ez, char *cigar,
                                     int cap, int32_t *out3, hipStream_t stream);
 hipError_t launch_expand(const uint32_t *tbw, const DpRecord *rec, int tl, int ql, int packed16, int half, int rows,

@@ -1041,31 +1041,55 @@ __device__ __forceinline__ void lane_ck_grid(const DpArgs &a, const TbArgs &walk
         // that no line of an input array enters a cache before its bytes are there)
         if (arrived < a.first + min(a.count, (tile + 2) * 128)) {
             const int64_t need = a.first + min(a.count, (tile + 2) * 128);
-            unsigned long long since = __builtin_amdgcn_s_memrealtime();
-            int64_t last = arrived;
-            bool gave_up = false, left_early = false;
-            for (;;) {
-                arrived = (int64_t)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.gate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (arrived >= need) break;
-                if (arrived < 0) { // the host calls the grid off (an index array failed its check): leave, nothing is wrong with the device
-                    left_early = true;
-                    break;
+            // ONE wave at a time looks at the host's word (round 5).  Packed inputs arrive eight times faster than the grid consumes them:
+            // a wave seldom waits.  ASCII inputs do not -- the link is the bound, every wave of the grid stands at the gate most of the
+            // time -- and 2 048 waves each reading a word over the link every few microseconds put a gigabyte per second of read
+            // completions on the very direction the inputs travel in.  So the word has a mirror in DEVICE memory (a.gate_dev[0]) that the
+            // waiting waves watch, and whoever finds the mirror older than a microsecond (a.gate_dev[1], 100 MHz ticks; a compare-and-swap
+            // picks one wave) reads the host's word and moves the mirror on.  A negative word (the host calls the grid off) goes into the
+            // mirror as it is.
+            int lo = 0, hi = 0, flags = 0; // lane 0 waits, everybody else waits for lane 0: {seen.lo, seen.hi, 1 = gave up}
+            if (lane == 0) {
+                unsigned long long since = __builtin_amdgcn_s_memrealtime();
+                long long last = arrived, seen;
+                for (;;) {
+                    seen = (long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.gate_dev), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (seen >= need || seen < 0) break;
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    const unsigned long long polled = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.gate_dev) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (now - polled >= 100ull) {
+                        unsigned long long expect = polled;
+                        if (__hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long *>(a.gate_dev) + 1, &expect, now, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            const long long v = (long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.gate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            if (v < 0)
+                                __hip_atomic_store(reinterpret_cast<long long *>(a.gate_dev), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            else
+                                __hip_atomic_fetch_max(reinterpret_cast<long long *>(a.gate_dev), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            seen = v;
+                            if (seen >= need || seen < 0) break;
+                        }
+                    }
+                    if (seen != last) {
+                        last = seen;
+                        since = now;
+                    } else if (now - since > (unsigned long long)a.gate_timeout_ticks) {
+                        flags = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(32);
                 }
-                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                if (arrived != last) {
-                    last = arrived;
-                    since = now;
-                } else if (now - since > (unsigned long long)a.gate_timeout_ticks) {
-                    gave_up = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(64);
+                lo = (int)(unsigned)(unsigned long long)seen;
+                hi = (int)(unsigned)((unsigned long long)seen >> 32);
             }
-            if (gave_up) {
+            lo = __builtin_amdgcn_readfirstlane(lo);
+            hi = __builtin_amdgcn_readfirstlane(hi);
+            flags = __builtin_amdgcn_readfirstlane(flags);
+            arrived = (int64_t)((unsigned long long)(unsigned)lo | (unsigned long long)(unsigned)hi << 32);
+            if (flags & 1) { // the word stood still for gate_timeout_ticks: the host sees the flag and does the call again the chunked way
                 if (lane == 0) __hip_atomic_store(a.gate_failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
-            if (left_early) break;
+            if (arrived < 0) break; // the host calls the grid off (an index array failed its check, a copy failed): leave, nothing is wrong with the device
             // An acquire fence between the look that let the wave through and the loads of the pairs it announced: once per WAIT (a wave
             // waits a handful of times while the inputs cross the link, never once they are there), so it costs nothing that can be
             // measured -- and without it the order of those loads behind a relaxed load rested on a branch and on the argument that no

@@ -1138,6 +1138,17 @@ __global__ __launch_bounds__(RG_BLOCK) void sw_regroup_scatter_kernel(const Regr
     }
 }
 
+__global__ __launch_bounds__(256) void sw_iota64_kernel(int64_t *dst, int64_t n, int64_t step)
+{
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) dst[k] = k * step;
+}
+hipError_t launch_iota64(int64_t *dst, int64_t n, int64_t step, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sw_iota64_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, stream, dst, n, step);
+    return hipGetLastError();
+}
+
 hipError_t launch_regroup(const RegroupArgs &a, hipStream_t stream)
 {
     hipError_t e = hipMemsetAsync(a.cnt, 0, (size_t)a.max_tl * a.max_ql * 4, stream);

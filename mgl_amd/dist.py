@@ -87,6 +87,32 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def all_ranks(value, device):
+    """The python float of every rank, in rank order, on every rank (per-rank step times for the bench line)."""
+    if not dist.is_initialized():
+        return [float(value)]
+    t = torch.tensor([float(value)], device="cpu" if dist.get_backend() == "gloo" else device, dtype=torch.float64)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
+def min_over_ranks(value, device):
+    """MIN of a python number over all ranks (a decision every rank must take the same way, e.g. steps in flight)."""
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], device="cpu" if dist.get_backend() == "gloo" else device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item())
+
+
+def describe():
+    """What the communicator itself reports (not the environment): {"world_size", "backend"}; one process: world_size 1, no backend."""
+    if not dist.is_initialized():
+        return {"world_size": 1, "backend": None}
+    return {"world_size": int(dist.get_world_size()), "backend": str(dist.get_backend())}
+
+
 def barrier():
     if dist.is_initialized():
         if dist.get_backend() == "nccl":

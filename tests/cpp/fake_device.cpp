@@ -403,6 +403,11 @@ hipError_t launch_regroup(const RegroupArgs &a, hipStream_t)
     return hipSuccess;
 }
 hipError_t launch_scores_only(const TbArgs &a, hipStream_t) { walk(a, true); return hipSuccess; }
+hipError_t launch_iota64(int64_t *dst, int64_t n, int64_t step, hipStream_t)
+{
+    for (int64_t k = 0; k < n; ++k) dst[k] = k * step;
+    return hipSuccess;
+}
 hipError_t launch_cigar_from_matrix(const int32_t *, int, int, int, const Score &, char *, int, int32_t *, hipStream_t) { return hipErrorInvalidValue; }
 hipError_t launch_expand(const uint32_t *, const DpRecord *, int, int, int, int, int, int32_t *, hipStream_t, int) { return hipErrorInvalidValue; }
 hipError_t launch_band_fill(const int32_t *, const int32_t *, int, int32_t *, int, int, int, int32_t *, int32_t *, int32_t *, int, int, int, int, int,

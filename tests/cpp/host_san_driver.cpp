@@ -172,6 +172,35 @@ int main()
         int32_t btr_probe[4];
         if (lane_mode == 2) CHECK(mgl_sw_ctx_expand_slot(ctx, 0, 1, 1, btr_probe) == MGL_SW_ERR_UNSUPPORTED); // no stored traceback to expand
     }
+    // ---- the same uniform batch as ASCII bases in REGISTERED arrays: the direct form of mgl_sw_align_batch_status (round 5) -- one gated
+    // launch, six chunks of bases brought in beside it, the offsets written on the "device" (launch_iota64), results in place
+    {
+        CHECK(mgl_sw_ctx_set_lane_kernel(ctx, 2) == 0 && mgl_sw_ctx_set_lane_checkpoint(ctx, 0) == 0 && mgl_sw_ctx_set_workspace(ctx, 1ll << 30) == 0);
+        const int64_t n = uni.n();
+        std::vector<int32_t> off((size_t)n), len((size_t)n), st((size_t)n);
+        std::vector<mgl_sw_score> sc((size_t)n);
+        std::vector<char> cg((size_t)n * 64, 1);
+        void *regs[] = {uni.t.data(), uni.q.data(), off.data(), sc.data(), cg.data(), len.data(), st.data()};
+        const size_t bytes[] = {uni.t.size(), uni.q.size(), off.size() * 4, sc.size() * sizeof(mgl_sw_score), cg.size(), len.size() * 4, st.size() * 4};
+        for (int i = 0; i < 7; ++i) CHECK(mgl_sw_register_host_buffer(ctx, regs[i], bytes[i]) == 0);
+        setenv("MGL_SW_DEBUG_DIRECT_CHUNK", "512", 1);
+        const long long grids0 = mgl_sw_dev::fake_gated_grids.load();
+        CHECK(mgl_sw_align_batch_status(ctx, n, uni.t.data(), uni.toff.data(), uni.q.data(), uni.qoff.data(), 200, -150, 260, 11, MGL_SW_OS_INDEL, off.data(), sc.data(),
+                                        cg.data(), 64, len.data(), st.data()) == 0);
+        CHECK(mgl_sw_dev::fake_gated_grids.load() == grids0 + 1);
+        compare(uni, eu, off, sc, cg, 64, len, &st);
+        // a copy that fails behind the launch: the grid is called off, the call fails, the next one works
+        fake_hip_fail_copy_in(5);
+        CHECK(mgl_sw_align_batch_status(ctx, n, uni.t.data(), uni.toff.data(), uni.q.data(), uni.qoff.data(), 200, -150, 260, 11, MGL_SW_OS_INDEL, off.data(), sc.data(),
+                                        cg.data(), 64, len.data(), st.data()) == MGL_SW_ERR_DEVICE);
+        fake_hip_fail_copy_in(0);
+        std::fill(off.begin(), off.end(), -3);
+        CHECK(mgl_sw_align_batch_status(ctx, n, uni.t.data(), uni.toff.data(), uni.q.data(), uni.qoff.data(), 200, -150, 260, 11, MGL_SW_OS_INDEL, off.data(), sc.data(),
+                                        cg.data(), 64, len.data(), st.data()) == 0);
+        compare(uni, eu, off, sc, cg, 64, len, &st);
+        unsetenv("MGL_SW_DEBUG_DIRECT_CHUNK");
+        for (int i = 0; i < 7; ++i) CHECK(mgl_sw_unregister_host_buffer(ctx, regs[i]) == 0);
+    }
     // ---- a mixed batch with one dominant geometry: the sorted chunks' whole waves of 128 go through the (fake) lane kernel, the rest
     // through the packed and int32 parts -- both entries, several chunks (threshold lowered: MGL_SW_DEBUG_LANE_GROUP_MIN)
     {
@@ -377,6 +406,51 @@ int main()
                 for (int i = 0; i < 9; ++i) CHECK(mgl_sw_unregister_host_buffer(ctx, regs[i]) == 0);
             }
             CHECK(mgl_sw_ctx_set_lane_kernel(ctx, 0) == 0);
+        }
+        // ---- MANY short pairs of mixed lengths through the packed host entry (round 5): enough of them (>= 131 072) that the chunks are sized by
+        // wave slots and sorted on the "device" (launch_regroup) two chunks ahead of the fills, each chunk's inputs brought in front of its
+        // sort; whole waves of one geometry through the lane kernel's grid, the left-overs in pieces; results back in the caller's order
+        {
+            const int64_t nm = 140000 + 77;
+            const int mtl = 24, mql = 16;
+            std::vector<uint8_t> genome((size_t)(1 << 14)), reads((size_t)nm * mql);
+            for (auto &c : genome) c = (uint8_t)"ACGT"[g() & 3];
+            std::vector<int64_t> ts((size_t)nm), qs((size_t)nm);
+            std::vector<int32_t> tl((size_t)nm), ql((size_t)nm);
+            Batch view;
+            for (int64_t k = 0; k < nm; ++k) {
+                const int64_t w = (int64_t)(g() % (genome.size() - mtl));
+                tl[(size_t)k] = k % 1000 == 3 ? 10 + (int)(g() % 14) : mtl;
+                ql[(size_t)k] = 12 + (int)(g() % 5);
+                ts[(size_t)k] = w;
+                qs[(size_t)k] = k * mql;
+                std::string t(genome.begin() + w, genome.begin() + w + tl[(size_t)k]), q = t.substr(0, (size_t)std::min(ql[(size_t)k], tl[(size_t)k]));
+                q.resize((size_t)ql[(size_t)k], 'G');
+                q[g() % q.size()] = "ACGT"[g() & 3];
+                memcpy(&reads[(size_t)k * mql], q.data(), q.size());
+                view.add(t, q);
+            }
+            const std::vector<uint8_t> G = pack(genome), Rd = pack(reads);
+            const Expect ev = expect(view, MGL_SW_OS_SOFTCLIP);
+            CHECK(mgl_sw_ctx_set_workspace(ctx, 1ll << 30) == 0 && mgl_sw_ctx_set_lane_kernel(ctx, 0) == 0);
+            std::vector<int32_t> off((size_t)nm), len((size_t)nm), st((size_t)nm);
+            std::vector<mgl_sw_score> sc((size_t)nm);
+            std::vector<char> cg((size_t)nm * 64, 1);
+            setenv("MGL_SW_DEBUG_LANE_GROUP_MIN", "128", 1); // (a chunk's whole waves of one geometry get their launch of the lane kernel however few they are)
+            for (const char *chunk : {"0", "32768"}) { // one chunk, then six on two streams
+                setenv("MGL_SW_DEBUG_HOST_SORT_CHUNK", chunk, 1);
+                std::fill(off.begin(), off.end(), -5);
+                CHECK(mgl_sw_align_batch_2bit(ctx, nm, G.data(), (int64_t)genome.size(), ts.data(), tl.data(), Rd.data(), (int64_t)reads.size(), qs.data(), ql.data(), mtl, mql, 200,
+                                              -150, 260, 11, MGL_SW_OS_SOFTCLIP, off.data(), sc.data(), cg.data(), 64, len.data(), st.data(), 0) == 0);
+                compare(view, ev, off, sc, cg, 64, len, &st);
+                mgl_sw_timing tm;
+                CHECK(mgl_sw_ctx_get_timing(ctx, &tm) == 0);
+                // (a short first and last chunk: 16 384, 3 x 32 768, 8 960, 16 429 pairs)
+                if (tm.fill_kernel != MGL_SW_KERNEL_LANE16_CK || tm.dp_launches != (chunk[0] == '0' ? 1 : 6)) std::fprintf(stderr, "mixed host batch, chunk %s: kernel %d, %d launches\n", chunk, tm.fill_kernel, tm.dp_launches);
+                CHECK(tm.fill_kernel == MGL_SW_KERNEL_LANE16_CK && tm.dp_launches == (chunk[0] == '0' ? 1 : 6));
+            }
+            unsetenv("MGL_SW_DEBUG_HOST_SORT_CHUNK");
+            unsetenv("MGL_SW_DEBUG_LANE_GROUP_MIN");
         }
         // a pair outside its array, a length above the stated maximum, missing length arrays without the uniform flag
         int64_t ts1[1] = {(int64_t)mixed.t.size() - 10}, qs1[1] = {0};

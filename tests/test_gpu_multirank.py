@@ -65,6 +65,42 @@ def test_two_ranks_share_the_gpu_over_gloo(tmp_path):
 
 
 @pytest.mark.gpu
+def test_four_ranks_two_steps_in_flight_each_and_the_degraded_path(tmp_path):
+    """The shape `bench.py --gpus 8` runs in, rehearsed as far as this pool allows: FOUR ranks over gloo on the one GPU (a box admits six
+    processes on its card: this one, the launcher's children -- eight ranks would be refused), each with TWO steps in flight (two contexts,
+    two streams: eight contexts on the card), the line carrying what the COMMUNICATOR reports and every rank's own step time.  Then the
+    same with rank 2 unable to set up its second context: every rank falls back to one step in flight (the ranks must agree: each step
+    ends in the gather), and the line says so instead of a stderr print."""
+    global PAIRS
+    keep, PAIRS = PAIRS, 120_000
+    try:
+        d4, s4 = _bench(4, [], tmp_path, "n4")
+        d1, s1 = _bench(1, [], tmp_path, "n1b")
+        env_keep = os.environ.get("MGL_BENCH_DEBUG_NO_SECOND_CONTEXT")
+        os.environ["MGL_BENCH_DEBUG_NO_SECOND_CONTEXT"] = "2"
+        try:
+            dd, sd = _bench(4, [], tmp_path, "n4d")
+        finally:
+            if env_keep is None:
+                del os.environ["MGL_BENCH_DEBUG_NO_SECOND_CONTEXT"]
+            else:
+                os.environ["MGL_BENCH_DEBUG_NO_SECOND_CONTEXT"] = env_keep
+    finally:
+        PAIRS = keep
+    c = d4["config"]
+    assert d4["n_gpus"] == 4 and c["distributed"] == dict(c["distributed"], world_size=4, backend="gloo", launched_with_world_size_env=4, gpus_visible=1, ranks_per_gpu=4)
+    assert c["steps_in_flight"] == 2 and "steps_in_flight_degraded" not in c
+    pr = c["distributed"]["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 4 and pr["min"] == min(pr["all"]) and pr["max"] == max(pr["all"]) and abs(pr["max"] - d4["ms_per_step"]) < 0.01
+    assert c["pairs_per_gpu"] == 30_000 and d4["cigar_overflows"] == 0
+    assert (s4 == s1).all() and s4.shape == (120_000,)
+    c = dd["config"]
+    assert c["steps_in_flight"] == 1 and c["steps_in_flight_requested"] == 2 and "rank 2" in c["steps_in_flight_degraded"]
+    assert (sd == s1).all()
+    assert d1["config"]["distributed"]["world_size"] == 1 and d1["roofline"]["counters"]["file"] == "profiles/pmc_traffic.json"
+
+
+@pytest.mark.gpu
 def test_one_rank_over_rccl(tmp_path):
     """The `nccl` branch of mgl_amd/dist.py (RCCL: init_process_group(device_id=...), the gather, barrier(device_ids=...), the
     max-over-ranks all-reduce) executed once on the one GPU of this box: torchrun with ONE rank and the backend the 8-GPU run

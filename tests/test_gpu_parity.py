@@ -1869,6 +1869,140 @@ def test_persistent_grid_counter_after_a_called_off_launch(monkeypatch):
     a.close()
 
 
+def test_ascii_direct_host_entry(monkeypatch):
+    """mgl_sw_align_batch_status with every array page-locked and one geometry (round 5): the reference's own wire format -- ASCII bases
+    in host memory, MicrosoftSmithWaterman.java:71-86 -- through ONE gated launch of the persistent grid while the copy engines bring the
+    bases in; the offsets never cross the link (a kernel writes k * tl), the results are written by the waves into the caller's arrays.
+    Against the chunked form byte for byte, with targets that hold N and lower-case letters (raw byte semantics, sw.cpp:55), small chunks
+    on a small grid (many tiles through the gate), and the oracle on a sample."""
+    rng = np.random.default_rng(808)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    n, tl, ql = 300_001, 256, 150
+    t = alpha[rng.integers(0, 4, (n, tl))]
+    start = rng.integers(0, tl - ql - 4, n)
+    q = t[np.arange(n)[:, None], start[:, None] + np.arange(ql)[None, :]].copy()
+    q = np.where(rng.random(q.shape) < 0.01, alpha[rng.integers(0, 4, q.shape)], q).astype(np.uint8)
+    odd = rng.choice(n, 4000, replace=False)
+    t[odd[:2000], 100] = ord("N")          # N == N matches (sw.cpp:55), and the wave that holds it stages raw bytes
+    q[odd[:1000], 100 - start[odd[:1000]].clip(0, 100)] = ord("N")
+    t[odd[2000:], 30:40] |= 0x20           # lower case differs from upper case
+    for k in np.nonzero(rng.random(n) < 0.2)[0][:20000]:
+        q[k, 70:-3] = q[k, 73:]
+    td, qd = np.ascontiguousarray(t.reshape(-1)), np.ascontiguousarray(q.reshape(-1))
+    toff, qoff = np.arange(n + 1, dtype=np.int64) * tl, np.arange(n + 1, dtype=np.int64) * ql
+    params = (200, -150, 260, 11)
+    a = sw.MicrosoftSmithWaterman(0)
+    a.set_workspace(8 << 30)
+
+    def outs():
+        return (np.full(n, -7, np.int32), np.full((n, 6), -7, np.int32), np.full(n * 64, 7, np.uint8), np.full(n, -7, np.int32))
+
+    from mgl_amd import _lib
+    L = _lib.lib()
+
+    def run(o):
+        rc = L.mgl_sw_align_batch_status(a.ctx, n, td.ctypes.data, toff.ctypes.data, qd.ctypes.data, qoff.ctypes.data, *params, int(ol.SOFTCLIP), o[0].ctypes.data,
+                                         o[1].ctypes.data, o[2].ctypes.data, 64, o[3].ctypes.data, None)
+        assert rc == 0, rc
+
+    direct, small, chunked = outs(), outs(), outs()
+    regs = [td, qd] + list(direct) + list(small) + list(chunked)
+    for x in regs:
+        a.register_host_buffer(x)
+    try:
+        run(direct)
+        assert a.timing().fill_kernel == 7 and a.timing().dp_launches == 1, "the direct form: one launch of sw_dp16_lane_ck_kernel"
+        monkeypatch.setenv("MGL_SW_DEBUG_LANE_SLOTS", "96")
+        monkeypatch.setenv("MGL_SW_DEBUG_DIRECT_CHUNK", "16384")
+        run(small)
+        assert a.timing().dp_launches == 1
+        monkeypatch.delenv("MGL_SW_DEBUG_LANE_SLOTS")
+        monkeypatch.delenv("MGL_SW_DEBUG_DIRECT_CHUNK")
+        monkeypatch.setenv("MGL_SW_DEBUG_HOST_DIRECT", "0")
+        run(chunked)
+        assert a.timing().dp_launches > 1
+        monkeypatch.delenv("MGL_SW_DEBUG_HOST_DIRECT")
+        for d, s_, c in zip(direct, small, chunked):
+            assert (d == c).all() and (s_ == c).all()
+        sample = np.sort(np.concatenate([rng.choice(n, 2000, replace=False), odd[:300], odd[2000:2300], [n - 1]]))
+        off, sc, cg = ol.oracle_align_batch([t[k].tobytes() for k in sample], [q[k].tobytes() for k in sample], params, ol.SOFTCLIP, nthreads=8)
+        assert (direct[0][sample] == off).all() and (direct[1][sample] == sc).all()
+        assert [direct[2].reshape(n, 64)[k, : direct[3][k]].tobytes().decode() for k in sample] == cg
+    finally:
+        for x in regs:
+            a.unregister_host_buffer(x)
+    a.close()
+
+
+def test_mixed_lengths_from_host_memory_are_sorted_on_the_device(monkeypatch):
+    """mgl_sw_align_batch_2bit WITHOUT the uniform flag (round 5): the chunks of a host batch of mixed geometries are sorted by (tl, ql)
+    on the device -- whole waves of one geometry through the checkpointed lane kernel, the rest through the packed and int32 kernels --
+    each chunk's inputs brought in front of its sort, two chunks ahead of the fills, results back in the caller's order.  400 000 reads of
+    100-150 bases (a few odd geometries, a few one-base queries) against 256-base windows, from page-locked and from pageable arrays, in
+    one chunk and in four: identical to the device-resident entry, and to the oracle on a sample."""
+    import torch
+    from mgl_amd import device_batch as db
+
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    n, tl = 400_000, 256
+    genome = alpha[rng.integers(0, 4, 1 << 20)]
+    win = rng.integers(0, len(genome) - tl, n).astype(np.int64)
+    qlen = rng.integers(100, 151, n).astype(np.int32)
+    qlen[rng.choice(n, 300, replace=False)] = rng.integers(1, 100, 300)
+    tlen = np.full(n, tl, np.int32)
+    tlen[rng.choice(n, 300, replace=False)] = rng.integers(150, 256, 300)
+    start = rng.integers(0, 100, n)
+    reads = genome[win[:, None] + start[:, None] + np.arange(150)[None, :]]
+    reads = np.where(rng.random(reads.shape) < 0.02, alpha[rng.integers(0, 4, reads.shape)], reads).astype(np.uint8)
+    for k in np.nonzero(rng.random(n) < 0.1)[0]:
+        reads[k, 50:-2] = reads[k, 52:]   # a deletion of two bases
+    G, Q = db.pack2bit(genome.tobytes()), db.pack2bit(reads.tobytes())
+    qst = np.arange(n, dtype=np.int64) * 150
+    params = (200, -150, 260, 11)
+    a = sw.MicrosoftSmithWaterman(0)
+    a.set_workspace(8 << 30)
+    dev = torch.device("cuda", 0)
+    tq = torch.from_numpy
+    want = db.PackedBatch(tq(G).to(dev), tq(win).to(dev), tq(tlen).to(dev), tq(Q).to(dev), tq(qst).to(dev), tq(qlen).to(dev), tl, 150, 64)
+    want.run(a, params, ol.SOFTCLIP)
+    torch.cuda.synchronize()
+    w = (want.offsets.cpu().numpy(), want.scores.cpu().numpy(), want.cigars.cpu().numpy().reshape(-1), want.cigar_len.cpu().numpy())
+    assert int((want.status != 0).sum()) == 0
+    sample = np.sort(rng.choice(n, 1500, replace=False))
+    ts = [genome[win[k]: win[k] + tlen[k]].tobytes() for k in sample]
+    qs = [reads[k, : qlen[k]].tobytes() for k in sample]
+    off, sc, cg = ol.oracle_align_batch(ts, qs, params, ol.SOFTCLIP, nthreads=8)
+    assert (w[0][sample] == off).all() and (w[1][sample] == sc).all()
+    assert [w[2].reshape(n, 64)[k, : w[3][k]].tobytes().decode() for k in sample] == cg
+
+    def outs():
+        return (np.full(n, -7, np.int32), np.full((n, 6), -7, np.int32), np.full(n * 64, 7, np.uint8), np.full(n, -7, np.int32))
+
+    pinned = [G, win, Q, qst, tlen, qlen]
+    for chunk_env, pin in ((None, True), ("131072", True), ("131072", False)):
+        got = outs()
+        regs = (pinned + list(got)) if pin else []
+        for x in regs:
+            a.register_host_buffer(x)
+        if chunk_env:
+            monkeypatch.setenv("MGL_SW_DEBUG_HOST_SORT_CHUNK", chunk_env)
+            monkeypatch.setenv("MGL_SW_DEBUG_LANE_GROUP_MIN", "128")  # (a chunk's whole waves of one geometry get their lane-kernel launch below 131 072 pairs too)
+        try:
+            a.align_packed_2bit(G, len(genome), win, tlen, Q, n * 150, qst, qlen, tl, 150, params, ol.SOFTCLIP, 64, out=got)
+            tm = a.timing()
+            assert tm.fill_kernel == 7, "the bulk of every chunk: sw_dp16_lane_ck_kernel"
+            assert tm.dp_launches == (1 if chunk_env is None else 4), tm.dp_launches  # (65 536, 131 072, 131 072, 72 320 pairs: a short first chunk, no launch for a sliver)
+        finally:
+            monkeypatch.delenv("MGL_SW_DEBUG_HOST_SORT_CHUNK", raising=False)
+            monkeypatch.delenv("MGL_SW_DEBUG_LANE_GROUP_MIN", raising=False)
+            for x in regs:
+                a.unregister_host_buffer(x)
+        for g_, w_ in zip(got, w):
+            assert (g_ == w_).all(), (chunk_env, pin)
+    a.close()
+
+
 def test_binary_cigar_output(aligner):
     """MGL_SW_FLAG_BINARY_CIGAR: BAM-style uint32 elements carry the same elements in the same order as the text."""
     import torch
