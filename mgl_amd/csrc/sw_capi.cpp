@@ -605,6 +605,16 @@ static int plan_batch_as(mgl_sw_ctx *ctx, int64_t n, const SeqSet &tset, const S
     if (pyramid) chunk = pyr_unit * std::min<int64_t>(pyr_max, pyr_fit);
     // strip kernel: one pair per workgroup of W waves at three waves per SIMD -- a chunk that is not a whole number of rounds of
     // the chip (n_cus * (12 / W) pairs) ends with a round in which most CUs idle (1 582 pairs per chunk ran as two rounds)
+    // the eight-pairs-per-wave kernel, a chunk of several rounds of the chip: WHOLE rounds (round 5).  Its workgroups are resident for their
+    // pairs' lifetime (LDS: nine waves per CU at 300 residues) and a sorted batch's neighbours take alike, so a launch runs round after
+    // round -- and one of 3 379 waves on 2 304 slots runs 1.47 rounds in the time of two (the protein bench, 74 launches: counters in
+    // profiles/r05_b_protein_pmc.txt, VALU busy 51 %).  MGL_SW_DEBUG_WHOLE_ROUNDS=0: as before (measurements; read per call)
+    if (use16 && !use_lane && !auto_group && !hooks) {
+        const char *const wre = getenv("MGL_SW_DEBUG_WHOLE_ROUNDS");
+        const int lds_block = dp16_lds_bytes(sps_for(max_ql), wpb16) + lds_extra;
+        const int64_t round = (int64_t)ctx->n_cus * std::max(1, 160 * 1024 / std::max(lds_block, 1)) * wpb16 * 8;
+        if (!(wre && atoi(wre) == 0) && chunk > round && chunk < n) chunk = chunk / round * round;
+    }
     if (strip16) {
         // (workgroups per CU: what the kernel's register budget allows -- and, with the query's tables in LDS, what 160 KB hold)
         const int lds_codes = strip_k > 0 ? strip16_lds_bytes_codes(max_ql, strip_waves) : 0;

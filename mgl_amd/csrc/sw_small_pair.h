@@ -108,6 +108,33 @@ __device__ __forceinline__ void wave_max_pair(int &hi, uint32_t &lo)
     lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
 }
 
+// The wave's largest value, in every lane: six DPP stages folded into the maximum itself (v_max_*_dpp: a lane the stage does not reach keeps
+// its own value).  The reductions of a pair sit on its latency path and a lone wave pays ~5 cycles for every instruction of any kind: the
+// lexicographic (value, key) form above takes eleven instructions a stage, this one one -- so the maxima of the last column and the last
+// row are taken in two passes each (the best score; then, among the lanes that hold it, the best key): round 5.
+// (inline assembly: the compiler keeps the DPP move and the maximum apart -- v_mov, v_mov_dpp, s_nop, v_max: four issue slots a stage;
+// a DPP operand read behind a VALU write of the same register needs two wait states: the s_nop 1 between the stages)
+#define MGL_SMALL_DPP_MAX(OP)                                                            \
+    asm volatile("s_nop 1\n\t" /* (whatever VALU instruction wrote v last: inside this block, where nothing can be scheduled behind it) */ \
+                 OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"     \
+                 OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"     \
+                 OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"     \
+                 OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"     \
+                 OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"  \
+                 OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"       \
+                 : "+v"(v))
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    MGL_SMALL_DPP_MAX("v_max_i32_dpp");
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    MGL_SMALL_DPP_MAX("v_max_u32_dpp");
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+#undef MGL_SMALL_DPP_MAX
+
 // H on row 0 / column 0 (k = the other index): sw.cpp:29-40,47-49
 __device__ __forceinline__ int edge_score(int k, int gopen, int gext, bool indel) { return (indel && k > 0) ? -gopen - (k - 1) * gext : 0; }
 
@@ -429,33 +456,37 @@ __device__ __forceinline__ void small_pair(const TbArgs &a, const int64_t o, con
     SMALL_PHASE(1); // fill
 
     KeptScores hs{hm, g.CS, g.gopen, g.gext, g.base, g.indel, g.wide};
-    // last column: best score, the later row on ties (sw.cpp:100-104)
-    int mqe = NEG_INF, mqe_t = -1;
-    for (int i = lane + 1; i <= tl; i += 64) {
-        const int sc = hs.at(i, ql);
-        const bool take = sc >= mqe;
-        mqe = take ? sc : mqe;
-        mqe_t = take ? i : mqe_t;
-    }
+    // last column: best score, the later row on ties (sw.cpp:100-104).  A lane looks at the rows it OWNS (R neighbours of column ql in the
+    // kept matrix: one address, immediate offsets) -- then the wave's best score, then the largest row among the lanes that hold it
+    int mqe = NEG_INF, mqe_t = 0;
     {
-        uint32_t key = mqe_t < 0 ? 0u : (uint32_t)mqe_t;
-        wave_max_pair(mqe, key);
-        mqe_t = (int)key;
+        const int i0 = g.R * lane;
+        const uint32_t *const colp = hm + (ql - 1) * g.CS + (g.wide ? i0 : i0 >> 1); // this lane's rows of column ql (whole lanes: rows past tl exist)
+        const int un0 = g.base - (i0 + 1 + ql) * g.gext;
+        for (int r = 0; r < g.R; ++r) { // (a scalar loop: R is the pair's)
+            const int raw = g.wide ? (int)colp[r] : (int)(int16_t)((r & 1) ? colp[r >> 1] >> 16 : colp[r >> 1] & 0xffffu);
+            const int sc = i0 + 1 + r <= tl ? raw + un0 - r * g.gext : NEG_INF;
+            mqe_t = sc >= mqe ? i0 + 1 + r : mqe_t;
+            mqe = max(sc, mqe);
+        }
+        const int m = wave_max_i32(mqe);
+        mqe_t = (int)wave_max_u32(mqe == m ? (uint32_t)mqe_t : 0u);
+        mqe = m;
     }
-    // last row: best score, then closest to the diagonal, then smallest column (sw.cpp:106-127)
-    int rm = NEG_INF, rd = 0x7fffffff, rj = 0x7fffffff;
-    for (int j = lane + 1; j <= ql; j += 64) {
-        const int sc = hs.at(tl, j);
-        const int d = abs(tl - j);
-        const bool take = sc > rm || (sc == rm && d < rd);
-        rm = take ? sc : rm;
-        rd = take ? d : rd;
-        rj = take ? j : rj;
-    }
+    // last row: best score, then closest to the diagonal, then smallest column (sw.cpp:106-127): the best score first, then the best
+    // (distance, column) among the cells that hold it (both below 2^16 -- the kept scores of a longer query would not fit LDS)
+    int rm = NEG_INF, rd, rj;
     {
-        // (smaller distance, then smaller column: both below 2^16 -- the kept scores of a longer query would not fit LDS)
-        uint32_t key = rm == NEG_INF ? 0u : (uint32_t)(0xffff - rd) << 16 | (uint32_t)(0xffff - rj);
-        wave_max_pair(rm, key);
+        uint32_t key = 0u;
+        for (int j = lane + 1; j <= ql; j += 64) {
+            const int sc = hs.at(tl, j);
+            const uint32_t k2 = (uint32_t)(0xffff - abs(tl - j)) << 16 | (uint32_t)(0xffff - j);
+            key = sc > rm ? k2 : sc == rm ? max(key, k2) : key;
+            rm = max(sc, rm);
+        }
+        const int m = wave_max_i32(rm);
+        key = wave_max_u32(rm == m ? key : 0u);
+        rm = m;
         rd = 0xffff - (int)(key >> 16);
         rj = 0xffff - (int)(key & 0xffffu);
     }

@@ -19,7 +19,7 @@ ap.add_argument("--db", type=int, default=5000)
 ap.add_argument("--query-len", type=int, default=300)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--stride", type=int, default=256, help="CIGAR bytes kept per pair (longer ones are flagged, not written)")
-ap.add_argument("--workspace-gib", type=float, default=16)
+ap.add_argument("--workspace-gib", type=float, default=64, help="round 5: 64 (22 launches of whole rounds of the chip per pass; 16: 109 launches, 1 751 GCUPS against 2 079)")
 ap.add_argument("--check", type=int, default=200)
 ap.add_argument("--score-only", action="store_true", help="MGL_SW_FLAG_SCORE_ONLY: the database-search pre-filter mode")
 ap.add_argument("--seconds", type=float, default=0.0, help="repeat the pass for at least this long (SURVEY 8d: a seeded subset sized to >= 30 s) instead of --steps times")
@@ -127,8 +127,12 @@ if args.json:
            "kernel_ms": {"fill": round(tm.dp_ms, 3), "traceback": round(tm.tb_ms, 3), "launches": int(tm.dp_launches)},
            "roofline": {"bound": "hbm", "achieved": round(alg * n / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg * n / dt / 8e12, 4), "traffic": None,
                         "algorithmic_bytes_per_alignment": round(alg, 1),
-                        "note": "the traceback is spilled (four flags per cell, tl x ql / 2 bytes per alignment): the kernel is LDS-occupancy bound -- 12 B of LDS per query "
-                                "residue and group of two pairs limit a CU to 9 waves (DESIGN 9) -- not HBM bound"},
+                        "note": "the traceback is spilled (four flags per cell, tl x ql / 2 bytes per alignment).  Counters (profiles/r05_b_protein_pmc.txt, rocprofv3 --pmc, the 74-launch build): "
+                                "SQ_INSTS_VALU 3.79e10 per pass = 23.6 per two-cell step (the DNA form: 19.6; the two table look-ups are LDS gathers) -> VALU issue 51 % of the "
+                                "pass; SQ_LDS_IDX_ACTIVE 4.15e10 cycles per pass = 56 % of it, half of them bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.51: 64 lanes "
+                                "gathering out of a 2 KB table); nine waves per CU (12 B of LDS per query residue and group of two pairs); WRITE_SIZE 105 GB per pass = 0.87-1.06 TB/s.  "
+                                "Neither pipe is full: the launches were -- 3 379 waves on 2 304 slots ran 1.47 rounds in the time of two; whole rounds per chunk and a 64 GiB "
+                                "workspace: 1 684 -> 2 079 GCUPS"},
            "parity": "no reference path exists for this workload (mgl scores by byte equality only, sw.cpp:55): checked against the CPU restatement's extension, parity with the reference neither pinned nor claimed"}
     if cpu:
         out["cpu_no_reference_path"] = cpu
