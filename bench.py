@@ -78,8 +78,8 @@ def pmc_entry(tl, ql, kernel):
         import src_hash
 
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        for r in reversed(rec[kernel]):  # (the newest entry of a geometry last)
-            if (r["tl"], r["ql"]) == (tl, ql):
+        for r in rec[kernel]:  # (the newest entry of a geometry first; what it replaces carries "superseded")
+            if (r["tl"], r["ql"]) == (tl, ql) and not r.get("superseded"):
                 ok, why = src_hash.check(r)
                 return r, ok, why
     except (OSError, KeyError, ValueError, ImportError) as e:
