@@ -102,11 +102,14 @@ if args.json:
     # per 10 kb pair; other lengths: none taken)
     traffic, traffic_src = None, None
     try:
+        sys.path.insert(0, os.path.join(R, "scripts"))
+        import src_hash  # (an entry's counters are printed only when they were taken on the kernel sources this run is built from)
         for r_ in json.load(open(os.path.join(R, "profiles", "pmc_traffic.json")))["sw_dp16_strip_kernel"]:
-            if (r_["tl"], r_["ql"]) == (length, length) and not spilled and tm.fill_kernel == 6 and "hbm_bytes_per_pair" in r_:
-                traffic, traffic_src = int(r_["hbm_bytes_per_pair"] * n), r_["source"]
+            if (r_["tl"], r_["ql"]) == (length, length) and not r_.get("superseded") and not spilled and tm.fill_kernel == 6 and "hbm_bytes_per_pair" in r_:
+                ok_, why_ = src_hash.check(r_)
+                traffic, traffic_src = (int(r_["hbm_bytes_per_pair"] * n), r_["source"]) if ok_ else (None, "profiles/pmc_traffic.json: " + why_)
                 break
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, ImportError):
         pass
     walk_name = "sw_traceback_wave_kernel" if spilled else "sw_strip_ck_walk_kernel"
     print(json.dumps({"gcups": round(cells * reps / dt / 1e9, 1), "pairs": n, "length": length, "passes": reps, "seconds": round(dt, 1),

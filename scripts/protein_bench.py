@@ -122,10 +122,21 @@ if args.json:
     k_s = (tm.dp_ms + tm.tb_ms) / 1e3 if tm.dp_ms > 0 else dt
     mean_tl = float(lens.mean())
     alg = mean_tl + QL + 24 + 36 + (0 if args.score_only else mean_tl * QL / 2)
+    traffic, traffic_why = None, "no PMC entry"
+    try:
+        sys.path.insert(0, os.path.join(R, "scripts"))
+        import src_hash
+        for r_ in json.load(open(os.path.join(R, "profiles", "pmc_traffic.json")))["sw_dp16_matrix_kernel"]:
+            if not r_.get("superseded") and tm.packed16 and not args.score_only and (Q, args.db, QL) == (400, 5000, 300):
+                ok_, traffic_why = src_hash.check(r_)
+                traffic = int(r_["hbm_bytes_per_pair"] * n) if ok_ else None
+                break
+    except (OSError, KeyError, ValueError, ImportError) as e_:
+        traffic_why = repr(e_)
     out = {"gcups": round(cells / dt / 1e9, 1), "pairs_per_pass": int(n), "alignments_per_s": round(n / dt, 1), "ms_per_pass": round(dt * 1e3, 3), "passes": steps,
            "seconds": round(total_s, 1), "kernel": "sw_dp16_matrix_kernel" if tm.packed16 else "sw_dp_matrix_kernel",
            "kernel_ms": {"fill": round(tm.dp_ms, 3), "traceback": round(tm.tb_ms, 3), "launches": int(tm.dp_launches)},
-           "roofline": {"bound": "hbm", "achieved": round(alg * n / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg * n / dt / 8e12, 4), "traffic": None,
+           "roofline": {"bound": "hbm", "achieved": round(alg * n / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg * n / dt / 8e12, 4), "traffic": traffic, "traffic_per": "pass", "counters": traffic_why,
                         "algorithmic_bytes_per_alignment": round(alg, 1),
                         "note": "the traceback is spilled (four flags per cell, tl x ql / 2 bytes per alignment).  Counters (profiles/r05_b_protein_pmc.txt, rocprofv3 --pmc, the 74-launch build): "
                                 "SQ_INSTS_VALU 3.79e10 per pass = 23.6 per two-cell step (the DNA form: 19.6; the two table look-ups are LDS gathers) -> VALU issue 51 % of the "
