@@ -179,7 +179,7 @@ const DebugKnobs &debug_knobs()
     return k;
 }
 constexpr int kTileCounters = 64;
-constexpr int kTileCounterWords = 16; // an entry's two words on a 64-byte line of their own
+constexpr int kTileCounterWords = 16; // an entry's two words (ONE 64-bit atomic object to the kernel) on a 64-byte line of their own
 constexpr int kHostChunks = 32; // a host entry cuts a batch into about this many chunks (the units of its copy / compute pipeline)
 
 int geom_of(int flags)

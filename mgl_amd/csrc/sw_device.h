@@ -71,8 +71,9 @@ struct DpArgs {
     int strip_passes;         // ... passes over the target: 2 * 64 * waves strips each (targets beyond 16 384 rows; 0 or 1: one)
     int strip_codes;          // ... and the LDS carve holds the query as one table dword per column (strip16_lds_bytes_codes): pairs whose targets are all ACGT run the base-code form
     int lane_slots;           // sw_dp16_lane_ck_kernel: wave slots of its persistent grid = regions at tb / scratch (lane_ck_slots)
-    unsigned *tile_ctr;       // ... two words {draws, waves out}, zero when the launch starts (needed when the launch holds more tiles than slots): the waves
-                              //     draw their next tile from the first and count themselves out in the second; the last wave out zeroes both
+    unsigned *tile_ctr;       // ... two words {draws, waves out} used as ONE 64-bit atomic object (8-byte aligned), zero when the launch starts (needed when the
+                              //     launch holds more tiles than slots): the waves draw their next tile from the low half and count themselves out in the high
+                              //     half; the last wave out zeroes the word
     int32_t *grid_fault;      // ... optional: set to 1 (pinned host memory) by a wave that draws a number no launch of this size can draw
     const int64_t *gate;      // ... optional (host entries): a word in pinned host memory holding how many pairs of the batch have arrived in device memory
                               //     so far; a wave waits with a tile until its pairs are there (null: everything is)

@@ -1032,6 +1032,7 @@ __device__ __forceinline__ void lane_ck_grid(const DpArgs &a, const TbArgs &walk
         diag_w0 = __builtin_amdgcn_s_memrealtime();
     }
     int64_t arrived = a.gate ? 0 : INT64_MAX; // pairs of the batch known to be in device memory
+    unsigned long long *const ctr = reinterpret_cast<unsigned long long *>(a.tile_ctr); // {draws, waves out}: ONE object (below)
     for (int64_t tile = slot; tile < tiles;) {
         // The host entries run ONE launch over a batch whose inputs are still crossing the link: the copy engines bring them chunk by chunk
         // and the host moves a.gate on as each chunk has landed.  A wave whose tile is not there yet looks at the word (a read over the
@@ -1118,7 +1119,7 @@ __device__ __forceinline__ void lane_ck_grid(const DpArgs &a, const TbArgs &walk
         if (tiles <= slots) break; // (every tile has its wave: the counter is not even touched)
         unsigned next = 0;
         if (lane == 0) {
-            next = atomicAdd(a.tile_ctr, 1u);
+            next = (unsigned)__hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // The waves of one launch draw `tiles` times at most (tiles - slots draws that find a tile, one per wave that does not), so a
             // larger number means the word did not stand at zero when the launch started: somebody else's launch is on it, or memory is
             // not what it was.  The host finds the flag at its next look (mgl_sw_ctx_check, every later call): MGL_SW_ERR_DEVICE, never
@@ -1128,16 +1129,21 @@ __device__ __forceinline__ void lane_ck_grid(const DpArgs &a, const TbArgs &walk
         tile = slots + (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)next);
     }
     // THE LAST WAVE OUT ZEROES THE COUNTER (round 5).  Every wave of the grid comes through here -- after its last draw, or from the gate
-    // when the host has called the launch off or the gate stood still -- and counts itself out in a.tile_ctr[1]; the one that finds
-    // slots - 1 there knows that nobody will draw again and puts both words back to zero.  So a launch finds its counter at zero however
-    // the launch before it on that word ended.  (Round 4 never reset the word and kept a host-side copy of where it stood, "moved on by
-    // exactly `tiles` per launch" -- which a launch called off at its gate did not do: the copy and the word parted, and 64 launches later
-    // the grid that came round to that word left its tiles undone with status 0.)
+    // when the host has called the launch off or the gate stood still -- and counts itself out in the word's HIGH half; the one that
+    // finds slots - 1 there knows that nobody will draw again and puts the word back to zero.  So a launch finds its counter at zero
+    // however the launch before it on that word ended.  (Round 4 never reset the word and kept a host-side copy of where it stood, "moved
+    // on by exactly `tiles` per launch" -- which a launch called off at its gate did not do: the copy and the word parted, and 64 launches
+    // later the grid that came round to that word left its tiles undone with status 0.)
+    // Draws (low half) and waves out (high half) are ONE 64-bit atomic object on purpose: a wave's draws come before its count-out in
+    // that object's modification order (same thread, same object), the last count-out reads the value every other count-out has left,
+    // and the store of zero follows it -- all with RELAXED operations.  As two words the same chain needed an acquire-release on every
+    // wave's way out, which on this chip is a write-back and an invalidate of the XCD's L2 (buffer_wbl2 / buffer_inv, 2 048 of them
+    // while the last tiles are still writing their rows): against round 4's library on one box, launches of 2 M pairs were
+    // 1.3-1.6 % behind it in that form and are 0.7 % behind it in this one (profiles/r05_ab_r04_vs_head.txt; 10 M pairs: level).
     if (tiles > slots && lane == 0) {
-        const unsigned out = __hip_atomic_fetch_add(a.tile_ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned out = (unsigned)(__hip_atomic_fetch_add(ctr, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
         if (out == (unsigned)slots - 1u) {
-            __hip_atomic_store(a.tile_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.tile_ctr + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctr, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (out >= (unsigned)slots && a.grid_fault) {
             __hip_atomic_store(a.grid_fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -1160,8 +1166,8 @@ __global__ __launch_bounds__(64, 2) void sw_dp16_lane_ck_scatter_kernel(const Dp
 // either wire format, the same for both sequence sets (the kernel stages base codes, sw_lane_cell.h)
 bool lane16_ck_supported(const SeqSet &t, const SeqSet &q) { return (t.packed2 != 0) == (q.packed2 != 0); }
 
-// a.lane_slots regions at a.tb / a.scratch; wherever the launch holds more tiles than slots: a.tile_ctr, two words {draws, waves out}
-// that stand at zero when the kernel starts and that no other launch in flight uses.  The grid's last wave out puts them back to zero
+// a.lane_slots regions at a.tb / a.scratch; wherever the launch holds more tiles than slots: a.tile_ctr, one 64-bit word {draws, waves out}
+// that stands at zero when the kernel starts and that no other launch in flight uses.  The grid's last wave out puts them back to zero
 // (above), so no launch needs a reset in front of it -- a memset in front of every launch is a KERNEL of its own, and behind a grid that
 // holds every wave slot of the chip it waited for that grid's end (traced in round 4: the two streams of the host entries stopped
 // overlapping).

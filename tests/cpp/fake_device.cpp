@@ -154,6 +154,7 @@ void lane_ck_wave(const DpArgs &a, const TbArgs &w, int64_t tiles, int64_t slots
 {
     using Clock = std::chrono::steady_clock;
     int64_t arrived = a.gate ? 0 : INT64_MAX;
+    unsigned long long *const ctr = reinterpret_cast<unsigned long long *>(a.tile_ctr);
     for (int64_t tile = slot; tile < tiles;) {
         const int64_t need = a.first + std::min(a.count, (tile + 2) * 128);
         if (arrived < need) {
@@ -194,15 +195,14 @@ void lane_ck_wave(const DpArgs &a, const TbArgs &w, int64_t tiles, int64_t slots
             walk(part, false);
         }
         if (tiles <= slots) break;
-        const unsigned next = __atomic_fetch_add(a.tile_ctr, 1u, __ATOMIC_ACQ_REL);
+        const unsigned next = (unsigned)__atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED); // (one 64-bit object {draws, waves out}, relaxed: as the kernel)
         if (next >= (unsigned)tiles && a.grid_fault) __atomic_store_n(a.grid_fault, 1, __ATOMIC_RELEASE);
         tile = slots + (int64_t)next;
     }
     if (tiles > slots) {
-        const unsigned out = __atomic_fetch_add(a.tile_ctr + 1, 1u, __ATOMIC_ACQ_REL);
+        const unsigned out = (unsigned)(__atomic_fetch_add(ctr, 1ull << 32, __ATOMIC_RELAXED) >> 32);
         if (out == (unsigned)slots - 1u) {
-            __atomic_store_n(a.tile_ctr, 0u, __ATOMIC_RELEASE);
-            __atomic_store_n(a.tile_ctr + 1, 0u, __ATOMIC_RELEASE);
+            __atomic_store_n(ctr, 0ull, __ATOMIC_RELAXED);
         } else if (out >= (unsigned)slots && a.grid_fault) {
             __atomic_store_n(a.grid_fault, 1, __ATOMIC_RELEASE);
         }
@@ -244,7 +244,7 @@ hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &w, hipStream_t str
     // the persistent grid's contract (sw_dp16_lane_ck.hip): wave slots, and wherever the tiles outnumber them a counter entry that
     // stands at {0, 0} -- the last wave of the launch before it on that entry has seen to that, HOWEVER that launch ended
     const int64_t tiles = ((a.count + 1) / 2 + 63) / 64;
-    if (a.lane_slots < 1 || (tiles > a.lane_slots && (!a.tile_ctr || __atomic_load_n(a.tile_ctr, __ATOMIC_ACQUIRE) != 0 || __atomic_load_n(a.tile_ctr + 1, __ATOMIC_ACQUIRE) != 0)))
+    if (a.lane_slots < 1 || (tiles > a.lane_slots && (!a.tile_ctr || __atomic_load_n(reinterpret_cast<unsigned long long *>(a.tile_ctr), __ATOMIC_ACQUIRE) != 0)))
         return hipErrorInvalidValue;
     const int64_t slots = std::min<int64_t>(tiles, a.lane_slots);
     remember(a);
