@@ -84,6 +84,7 @@ typedef struct mgl_sw_timing {
 #define MGL_SW_KERNEL_STRIP16 6   /* sw_dp16_strip_kernel: long reads, one 32-row strip per lane-half */
 #define MGL_SW_KERNEL_LANE16_CK 7 /* sw_dp16_lane_ck_kernel: the lane kernel, checkpoints instead of stored flags */
 #define MGL_SW_KERNEL_SMALL 8     /* sw_small_kernel: small batches, one wave per pair, scores kept in LDS, fill + walk in one launch */
+#define MGL_SW_KERNEL_LANE16_MATRIX 9 /* sw_dp16_lane_matrix_kernel: substitution matrix, two pairs per lane, tiles that share their target */
 
 /* What the library WOULD do with a batch: the planner's decisions, without running anything (mgl_sw_explain). */
 typedef struct mgl_sw_plan {
@@ -324,6 +325,13 @@ int mgl_sw_shard_by_cells(int64_t n, const int64_t *t_off, const int64_t *q_off,
  * (offsets are written as 0, cigar_len as 0, the CIGAR slots are left untouched); every other batch runs the full
  * path.  Not a reference feature (align_* always builds the CIGAR): a pre-filter mode for database searches. */
 #define MGL_SW_FLAG_SCORE_ONLY 0x8
+/* MGL_SW_FLAG_SHARED_TARGET (mgl_sw_align_batch_device_matrix only; ignored elsewhere): a promise that every aligned block of 128
+ * consecutive pairs (pairs 128k .. 128k+127; the last block may be shorter) shares ONE target -- the same d_t_off and d_t_len -- and
+ * one query length: a database search laid out database sequence by database sequence.  Such a batch runs on a kernel that gives every
+ * lane two pairs and looks the scores of a column up as one row of a per-strip profile (sw_dp16_lane_matrix.hip); gap penalties and
+ * matrix must satisfy 0 <= S + gopen + gext <= 255 for every entry and the score range 16 bits, else the flag is read as
+ * MGL_SW_FLAG_GROUPED_GEOMETRY.  A block that breaks the promise is NOT computed: its pairs get MGL_SW_ERR_BAD_ARG in d_status_out. */
+#define MGL_SW_FLAG_SHARED_TARGET 0x10
 int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_targets,
                               const int64_t *d_t_off, const uint8_t *d_queries,
                               const int64_t *d_q_off, int max_tl, int max_ql, int match,

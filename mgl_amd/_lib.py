@@ -17,6 +17,7 @@ FLAG_UNIFORM_GEOMETRY = 1
 FLAG_BINARY_CIGAR = 2
 FLAG_GROUPED_GEOMETRY = 4
 FLAG_SCORE_ONLY = 8
+FLAG_SHARED_TARGET = 0x10
 OK, ERR_BAD_ARG, ERR_CIGAR_OVERFLOW, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED = range(6)
 
 # every symbol include/mgl_sw.h declares (tests check that the library exports them all)
@@ -64,7 +65,7 @@ def explain(n, max_tl, max_ql, parameters=(200, -150, 260, 11), strategy=1, flag
     return p
 
 
-FILL_KERNEL_NAMES = ("sw_dp_kernel", "sw_dp16_kernel", "sw_dp64_kernel", "sw_dp_coop_kernel", "sw_dp16_lane_kernel", "sw_dp_coop16_kernel", "sw_dp16_strip_kernel", "sw_dp16_lane_ck_kernel")
+FILL_KERNEL_NAMES = ("sw_dp_kernel", "sw_dp16_kernel", "sw_dp64_kernel", "sw_dp_coop_kernel", "sw_dp16_lane_kernel", "sw_dp_coop16_kernel", "sw_dp16_strip_kernel", "sw_dp16_lane_ck_kernel", "sw_small_kernel", "sw_dp16_lane_matrix_kernel")
 
 
 def _sources_newer():

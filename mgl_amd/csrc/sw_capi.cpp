@@ -184,7 +184,7 @@ constexpr int kHostChunks = 32; // a host entry cuts a batch into about this man
 
 int geom_of(int flags)
 {
-    return (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) ? GEOM_UNIFORM : (flags & MGL_SW_FLAG_GROUPED_GEOMETRY) ? GEOM_GROUPED : GEOM_MIXED;
+    return (flags & MGL_SW_FLAG_UNIFORM_GEOMETRY) ? GEOM_UNIFORM : (flags & (MGL_SW_FLAG_GROUPED_GEOMETRY | MGL_SW_FLAG_SHARED_TARGET)) ? GEOM_GROUPED : GEOM_MIXED; // (tiles of 128 that share a target are blocks of eight of one geometry)
 }
 
 int fail(mgl_sw_ctx *ctx, int status, const std::string &what)
@@ -1301,6 +1301,120 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
     return MGL_SW_OK;
 }
 
+// MGL_SW_FLAG_SHARED_TARGET on the substitution-matrix entry: tiles of 128 consecutive pairs that share their target (and their query
+// length) go through sw_dp16_lane_matrix_kernel -- ONE launch of a persistent grid whatever the number of pairs, a region of the
+// largest geometry per wave slot, the waves walk their own paths.  kNotTaken: the batch is left to run_device (parameters the
+// kernel's byte table cannot hold, a score range beyond 16 bits, a workspace that cannot give every SIMD a wave, score-only calls).
+constexpr int kNotTaken = -1000;
+int run_shared_target(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tset, const SeqSet &qset, int max_tl, int max_ql, int smax, int smin, int gopen,
+                      int gext, int strategy, int32_t *d_offset, Score *d_score, char *d_cigar, int cigar_stride, int32_t *d_cigar_len, int32_t *d_status,
+                      bool binary_cigar, const int8_t *d_matrix, const uint8_t *d_code)
+{
+    if (n < 1 || !tset.data || !tset.off || !qset.data || !qset.off || !d_offset || !d_cigar || cigar_stride < 1 || max_tl < 1 || max_ql < 1 || !strategy_ok(strategy))
+        return kNotTaken; // (run_device says what is wrong)
+    int m1 = 1, m2 = -1;
+    mgl_sw_normalize_params(&m1, &m2, &gopen, &gext);
+    if (ctx->precision == 32 || ctx->lane_kernel == 1 || tset.packed2 || qset.packed2 || !lane16_matrix_params_ok(smin, smax, gopen, gext) ||
+        !dp16_range_ok(max_tl, max_ql, smax, smin, gopen, gext, strategy) || lane16_matrix_lds_bytes(max_tl) > 64 * 1024)
+        return kNotTaken;
+    const int64_t tb_words = lane_tb_words(max_tl, max_ql, 32), scratch = lane_scratch_bytes(max_tl, max_ql, 32);
+    const int64_t region = tb_words * 4 + scratch, tiles = (n + 127) / 128;
+    const int64_t chip = (int64_t)ctx->n_cus * 12; // three waves per SIMD (168 registers)
+    const int64_t slots = std::min<int64_t>(std::min<int64_t>(chip, tiles), (ctx->ws_limit - n * (int64_t)sizeof(DpRecord)) / region);
+    if (slots < std::min<int64_t>(tiles, (int64_t)ctx->n_cus * 4)) return kNotTaken; // (fewer than a wave per SIMD: the kernels that keep less per pair do better)
+    const int frc = grid_fault_check(ctx);
+    if (frc != MGL_SW_OK) return frc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, ctx->tb[0].reserve((size_t)slots * (size_t)tb_words * 4));
+    HIP_TRY(ctx, ctx->bnd[0].reserve((size_t)slots * (size_t)scratch));
+    if (!ctx->tile_ctr.p) {
+        HIP_TRY(ctx, ctx->tile_ctr.reserve((size_t)kTileCounters * kTileCounterWords * sizeof(unsigned)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->tile_ctr.p, 0, (size_t)kTileCounters * kTileCounterWords * sizeof(unsigned), stream));
+    }
+    if (!ctx->pin_fault) {
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->pin_fault), 64, hipHostMallocDefault));
+        memset(ctx->pin_fault, 0, 64);
+    }
+    if (ctx->ws_idle_set) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ws_idle, 0));
+    if (ctx->profiling != 3) {
+        ctx->timing = mgl_sw_timing{};
+        ctx->pool_used = 0;
+    }
+    DpArgs da{};
+    da.t = tset;
+    da.q = qset;
+    da.first = 0;
+    da.count = n;
+    da.match = smax;
+    da.mismatch = smin;
+    da.gopen = gopen;
+    da.gext = gext;
+    da.strategy = strategy;
+    da.uni_tl = max_tl;
+    da.uni_ql = max_ql;
+    da.tb = static_cast<uint32_t *>(ctx->tb[0].p);
+    da.tb_stride_words = tb_words;
+    da.scratch = static_cast<unsigned char *>(ctx->bnd[0].p);
+    da.matrix = d_matrix;
+    da.code = d_code;
+    da.lane_slots = (int)slots;
+    if (tiles > slots) {
+        da.tile_ctr = static_cast<unsigned *>(ctx->tile_ctr.p) + (size_t)(ctx->tile_seq++ % kTileCounters) * kTileCounterWords;
+        void *fault_dev = nullptr;
+        HIP_TRY(ctx, hipHostGetDevicePointer(&fault_dev, ctx->pin_fault, 0));
+        da.grid_fault = static_cast<int32_t *>(fault_dev);
+    }
+    TbArgs ta{};
+    ta.t = tset;
+    ta.q = qset;
+    ta.first = 0;
+    ta.count = n;
+    ta.strategy = strategy;
+    ta.tb = da.tb;
+    ta.tb_stride_words = tb_words;
+    ta.packed16 = 2;
+    ta.rows_per_stripe = 32;
+    ta.strip_rows = 32;
+    ta.uni_ql = max_ql;
+    ta.match = smax;
+    ta.mismatch = smin;
+    ta.gopen = gopen;
+    ta.gext = gext;
+    ta.offset = d_offset;
+    ta.score = d_score;
+    ta.cigar = d_cigar;
+    ta.cigar_stride = cigar_stride;
+    ta.binary_cigar = binary_cigar ? 1 : 0;
+    ta.cigar_len = d_cigar_len;
+    ta.status = d_status;
+    hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (ctx->profiling) {
+        while ((int)ctx->pool.size() < ctx->pool_used + 4) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(ctx, hipEventCreate(&e));
+            ctx->pool.push_back(e);
+        }
+        for (int i = 0; i < 4; ++i) pe[i] = ctx->pool[(size_t)ctx->pool_used + i];
+        ctx->pool_used += 4;
+        HIP_TRY(ctx, hipEventRecord(pe[0], stream));
+    }
+    HIP_TRY(ctx, launch_dp16_lane_matrix(da, ta, stream));
+    if (pe[0]) {
+        HIP_TRY(ctx, hipEventRecord(pe[1], stream));
+        HIP_TRY(ctx, hipEventRecord(pe[2], stream)); // (the walk is inside the fill)
+        HIP_TRY(ctx, hipEventRecord(pe[3], stream));
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ws_idle, stream));
+    ctx->ws_idle_set = true;
+    ctx->last_chunk_count = 0; // (no slot to expand: the flags of a tile are gone with the next one)
+    ctx->timing.dp_launches++;
+    ctx->timing.tb_launches++;
+    ctx->timing.tb_bytes += slots * tb_words * 4;
+    ctx->timing.packed16 = 1;
+    ctx->timing.fill_kernel = MGL_SW_KERNEL_LANE16_MATRIX;
+    return MGL_SW_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -1702,6 +1816,11 @@ int mgl_sw_align_batch_device_matrix(mgl_sw_ctx *ctx, void *stream, int64_t n, c
     for (int k = 0; k < MATRIX_DIM * MATRIX_DIM; ++k) {
         cmax = std::max<int>(cmax, matrix[k]);
         cmin = std::min<int>(cmin, matrix[k]);
+    }
+    if ((flags & MGL_SW_FLAG_SHARED_TARGET) && !(flags & MGL_SW_FLAG_SCORE_ONLY)) {
+        const int rc = run_shared_target(ctx, st, n, ts, qs, max_tl, max_ql, cmax, cmin, gopen, gext, strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out),
+                                         d_cigar_out, cigar_stride, d_cigar_len_out, d_status_out, (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, dm, dc);
+        if (rc != kNotTaken) return rc;
     }
     return run_device(ctx, st, n, ts, qs, max_tl, max_ql, cmax, cmin, gopen, gext, strategy, d_offset_out,
                       reinterpret_cast<Score *>(d_score_out), d_cigar_out, cigar_stride, d_cigar_len_out, d_status_out, 0,

@@ -214,6 +214,10 @@ bool lane16_ck_supported(const SeqSet &t, const SeqSet &q); // sw_dp16_lane_ck_k
 struct TbArgs;
 // a.scratch = per-wave scratch, a.tb_stride_words per wave; walk.cigar != null: every lane also walks the paths of its two pairs
 hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &walk, int rows, hipStream_t stream);
+// sw_dp16_lane_matrix.hip: substitution-matrix scoring, two pairs per lane, tiles of 128 pairs that share their target (MGL_SW_FLAG_SHARED_TARGET)
+bool lane16_matrix_params_ok(int smin, int smax, int gopen, int gext); // every S + e + o a byte
+int lane16_matrix_lds_bytes(int max_tl);
+hipError_t launch_dp16_lane_matrix(const DpArgs &a, const TbArgs &walk, hipStream_t stream);
 hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &walk, hipStream_t stream); // a.tb_stride_words = lane_ck_words per wave; walk.cigar != null
 hipError_t launch_dp(const DpArgs &a, int waves_per_block, int rows, hipStream_t stream);
 int coop_lds_bytes(int sps_cap, int waves_per_block);

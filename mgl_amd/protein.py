@@ -89,11 +89,12 @@ class IndexedBatch:
 
 
 def run_matrix(batch, aligner, code, matrix, gap_open=11, gap_extend=1, overhang_strategy=1, stream=None, binary_cigar=False,
-               grouped=False, score_only=False):
+               grouped=False, score_only=False, shared_target=False):
     """mgl_sw_align_batch_device_matrix on a device_batch.DeviceBatch / IndexedBatch (ASCII wire format); no sync.
     ``grouped``: every aligned block of eight pairs has one (tl, ql) (MGL_SW_FLAG_GROUPED_GEOMETRY) -- true for a
     database search laid out as pair = d * Q + q with Q a multiple of eight -- which makes the packed-int16 kernel
-    eligible."""
+    eligible.  ``shared_target``: every aligned block of 128 pairs shares its target and has one query length
+    (MGL_SW_FLAG_SHARED_TARGET, DatabaseSearch below): two pairs per lane, the scores of a column out of a per-strip profile."""
     import torch
 
     if stream is None:
@@ -110,6 +111,53 @@ def run_matrix(batch, aligner, code, matrix, gap_open=11, gap_extend=1, overhang
         int(gap_open), int(gap_extend), int(overhang_strategy), batch.offsets.data_ptr(), batch.scores.data_ptr(),
         batch.cigars.data_ptr(), batch.cigar_stride, batch.cigar_len.data_ptr(), batch.status.data_ptr(),
         (_lib.FLAG_BINARY_CIGAR if binary_cigar else 0) | (_lib.FLAG_GROUPED_GEOMETRY if grouped else 0) |
-        (_lib.FLAG_UNIFORM_GEOMETRY if getattr(batch, "uniform", False) else 0) | (_lib.FLAG_SCORE_ONLY if score_only else 0))
+        (_lib.FLAG_UNIFORM_GEOMETRY if getattr(batch, "uniform", False) else 0) | (_lib.FLAG_SCORE_ONLY if score_only else 0) |
+        (_lib.FLAG_SHARED_TARGET if shared_target else 0))
     if rc != _lib.OK:
         raise _lib.MglSwError(rc, L.mgl_sw_last_error(aligner.ctx).decode())
+
+
+class DatabaseSearch:
+    """Q queries of ONE length against D database sequences, laid out for MGL_SW_FLAG_SHARED_TARGET: the first Qs = Q - Q % 128
+    queries of every database sequence are tiles of 128 pairs that share it (batch ``shared``, pair = rank(d) * Qs + q, longest database sequence first), the other
+    Qr = Q % 128 queries a second batch (``rest``, pair = d * Qr + (q - Qs); blocks of eight of one geometry when Qr % 8 == 0).
+    ``db``: uint8 residues of all database sequences, ``db_off`` int64[D + 1]; ``queries``: uint8 [Q, QL].  where(d, q) -> (batch, pair)."""
+
+    def __init__(self, db, db_off, queries, device, cigar_stride=256):
+        import torch
+
+        db_off = np.asarray(db_off, dtype=np.int64)
+        lens = np.diff(db_off)
+        # the longest database sequences FIRST: the kernel is a persistent grid that draws tile after tile, and a tile's work is its
+        # target's length -- 2 000-residue tiles at the end of the queue would leave most of the chip waiting for the last few waves
+        self.order = np.argsort(-lens, kind="stable")
+        self.rank = np.empty_like(self.order)
+        self.rank[self.order] = np.arange(len(lens))
+        starts, lens = db_off[:-1][self.order], lens[self.order]
+        D, (Q, QL) = len(lens), queries.shape
+        self.D, self.Q, self.QL = D, Q, QL
+        self.Qs, self.Qr = Q - Q % 128, Q % 128
+        self.cells = int(lens.sum()) * Q * QL
+        t = torch.from_numpy(np.ascontiguousarray(db)).to(device)
+        qd = torch.from_numpy(np.ascontiguousarray(queries).reshape(-1)).to(device)
+
+        def part(q0, qn):
+            if qn == 0:
+                return None
+            t_start = torch.from_numpy(np.repeat(starts, qn)).to(device)
+            t_len = torch.from_numpy(np.repeat(lens, qn).astype(np.int32)).to(device)
+            q_start = torch.from_numpy(np.tile((q0 + np.arange(qn, dtype=np.int64)) * QL, D)).to(device)
+            q_len = torch.full((D * qn,), QL, dtype=torch.int32, device=device)
+            return IndexedBatch(t, t_start, t_len, qd, q_start, q_len, int(lens.max()), QL, cigar_stride)
+
+        self.shared, self.rest = part(0, self.Qs), part(self.Qs, self.Qr)
+
+    def run(self, aligner, code, matrix, gap_open=11, gap_extend=1, overhang_strategy=1, stream=None):
+        if self.shared is not None:
+            run_matrix(self.shared, aligner, code, matrix, gap_open, gap_extend, overhang_strategy, stream, shared_target=True)
+        if self.rest is not None:
+            run_matrix(self.rest, aligner, code, matrix, gap_open, gap_extend, overhang_strategy, stream, grouped=self.Qr % 8 == 0)
+
+    def where(self, d, q):
+        d = int(self.rank[d])
+        return (self.shared, d * self.Qs + q) if q < self.Qs else (self.rest, d * self.Qr + q - self.Qs)

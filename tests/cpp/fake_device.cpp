@@ -140,6 +140,11 @@ hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &w, int, hipStream_t)
     if (w.cigar) walk(w, false);
     return hipSuccess;
 }
+// sw_dp16_lane_matrix.hip (MGL_SW_FLAG_SHARED_TARGET): the fake device has no substitution-matrix arithmetic -- the host layer is told that the
+// kernel's byte table cannot hold the parameters and takes its other path
+bool lane16_matrix_params_ok(int, int, int, int) { return false; }
+int lane16_matrix_lds_bytes(int) { return 0; }
+hipError_t launch_dp16_lane_matrix(const DpArgs &, const TbArgs &, hipStream_t) { return hipErrorInvalidValue; }
 // ---- the persistent grid of sw_dp16_lane_ck.hip, protocol for protocol.  Device resident (no gate): done before the launch returns.
 // With a gate (the DIRECT form of the host entries: the grid is launched FIRST and its inputs arrive beside it) the grid is a THREAD
 // that goes through the waves' own loop -- wait at the gate for the tile's pairs and the next tile's, leave on a negative gate, give
