@@ -1319,9 +1319,11 @@ int run_shared_target(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqS
         return kNotTaken;
     const int64_t tb_words = lane_tb_words(max_tl, max_ql, 32), scratch = lane_scratch_bytes(max_tl, max_ql, 32);
     const int64_t region = tb_words * 4 + scratch, tiles = (n + 127) / 128;
-    const int64_t chip = (int64_t)ctx->n_cus * 12; // three waves per SIMD (168 registers)
-    const int64_t slots = std::min<int64_t>(std::min<int64_t>(chip, tiles), (ctx->ws_limit - n * (int64_t)sizeof(DpRecord)) / region);
-    if (slots < std::min<int64_t>(tiles, (int64_t)ctx->n_cus * 4)) return kNotTaken; // (fewer than a wave per SIMD: the kernels that keep less per pair do better)
+    const char *const slots_env = getenv("MGL_SW_DEBUG_LANE_SLOTS"); // (tests: a grid of this many wave slots, so that a few tiles already draw from the counter; read per call)
+    const int64_t forced = slots_env ? atoll(slots_env) : 0;
+    const int64_t chip = forced > 0 ? forced : (int64_t)ctx->n_cus * 12; // three waves per SIMD (168 registers)
+    const int64_t slots = std::min<int64_t>(std::min<int64_t>(chip, tiles), ctx->ws_limit / region);
+    if (slots < 1 || (forced <= 0 && slots < std::min<int64_t>(tiles, (int64_t)ctx->n_cus * 4))) return kNotTaken; // (fewer than a wave per SIMD: the kernels that keep less per pair do better)
     const int frc = grid_fault_check(ctx);
     if (frc != MGL_SW_OK) return frc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -178,7 +178,13 @@ __device__ __forceinline__ void lm_strip(const int i0, const int tl, const int q
 
 } // namespace
 
-__global__ __launch_bounds__(64, 3) void sw_dp16_lane_matrix_kernel(const DpArgs a, const TbArgs walk)
+// -DMGL_LM_WAVES=2 (scripts/build_variant.sh): two waves per SIMD, 256 registers -- a measurement build
+#ifndef MGL_LM_WAVES
+#define MGL_LM_WAVES 3
+#elif !defined(MGL_VARIANT_BUILD)
+#error "MGL_LM_WAVES is a measurement switch (scripts/build_variant.sh defines MGL_VARIANT_BUILD): never the shipped library"
+#endif
+__global__ __launch_bounds__(64, MGL_LM_WAVES) void sw_dp16_lane_matrix_kernel(const DpArgs a, const TbArgs walk)
 {
     constexpr int R = LM_R;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -150,3 +150,100 @@ def test_blosum62_batches_bit_exact():
         protein.run_matrix(b, a, code, mat)
     assert "too long" in str(ex.value)
     a.close()
+
+
+def _tiles(rng, shapes, last_count):
+    """Tiles of 128 pairs that share their target (the last one `last_count` pairs): queries of one length per tile, diverged
+    fragments of the target, unrelated sequences, ambiguity codes, lower case and junk bytes among them."""
+    ts, qs = [], []
+    for k, (tl, ql) in enumerate(shapes):
+        t = protein.random_proteins(rng, 1, tl)[0]
+        for p in range(last_count if k == len(shapes) - 1 else 128):
+            if p % 3 and tl >= ql:
+                s0 = int(rng.integers(0, tl - ql + 1)); q = t[s0:s0 + ql].copy()
+                mut = rng.random(ql) < 0.3
+                if mut.any(): q[mut] = protein.random_proteins(rng, 1, int(mut.sum()))[0]
+            else:
+                q = protein.random_proteins(rng, 1, ql)[0]
+            if p % 19 == 0 and ql >= 6: q[-6:] = np.frombuffer(b"BZX*u!", np.uint8)
+            ts.append(t.tobytes()); qs.append(q.tobytes())
+    return ts, qs
+
+
+def _shared_batch(ts, qs, dev, stride):
+    """IndexedBatch over ONE copy of each tile's target: pair k points at its tile's target (the promise of MGL_SW_FLAG_SHARED_TARGET)."""
+    import torch
+
+    tdata, t_start, t_len, seen = [], [], [], {}
+    pos = 0
+    for k, t in enumerate(ts):
+        key = (k // 128, t)
+        if key not in seen:
+            seen[key] = pos; tdata.append(np.frombuffer(t, np.uint8)); pos += len(t)
+        t_start.append(seen[key]); t_len.append(len(t))
+    qd, qoff = sw.concat(qs)
+    return protein.IndexedBatch(torch.from_numpy(np.concatenate(tdata)).to(dev), torch.tensor(t_start, dtype=torch.int64, device=dev),
+                                torch.tensor(t_len, dtype=torch.int32, device=dev), torch.from_numpy(qd).to(dev),
+                                torch.from_numpy(qoff[:-1].copy()).to(dev), torch.from_numpy(np.diff(qoff).astype(np.int32)).to(dev),
+                                max(len(t) for t in ts), max(len(q) for q in qs), stride)
+
+
+@pytest.mark.gpu
+def test_tiles_that_share_their_target_bit_exact(monkeypatch):
+    """MGL_SW_FLAG_SHARED_TARGET (sw_dp16_lane_matrix.hip): tiles of 128 pairs on one target, two pairs per lane, the scores of a column out
+    of the strip's profile -- against the CPU restatement's extension, every strategy, strips that end inside a target, queries of 1 .. 301
+    residues, a short last tile with an odd pair count; a grid of five wave slots (the tiles outnumber them: the counter, twice on one
+    context); parameters the byte table cannot hold (the flag is then read as the grouped promise); a tile that breaks the promise."""
+    import torch
+
+    rng = np.random.default_rng(11)
+    code, mat = protein.blosum62()
+    dev = torch.device("cuda", 0)
+    shapes = [(1, 1), (5, 3), (31, 4), (32, 5), (33, 7), (63, 33), (64, 150), (65, 301), (100, 2), (257, 64), (700, 300), (96, 299), (40, 40), (333, 130)]
+    a = sw.MicrosoftSmithWaterman(0)
+    for strategy, (o, e) in zip(ol.STRATEGIES, [(11, 1), (10, 2), (5, 5), (12, 1)]):
+        ts, qs = _tiles(rng, shapes, 77)
+        b = _shared_batch(ts, qs, dev, 1024)
+        off, sc, cg = oracle_matrix_batch(ts, qs, code, mat, o, e, strategy, 1024)
+        for slots in (None, "5", "5"):
+            if slots: monkeypatch.setenv("MGL_SW_DEBUG_LANE_SLOTS", slots)
+            b.offsets.fill_(-7); b.scores.fill_(-7); b.status.fill_(-7)
+            protein.run_matrix(b, a, code, mat, o, e, strategy, shared_target=True)
+            torch.cuda.synchronize()
+            monkeypatch.delenv("MGL_SW_DEBUG_LANE_SLOTS", raising=False)
+            assert a.fill_kernel_name(a.timing()) == "sw_dp16_lane_matrix_kernel"
+            assert int((b.status != 0).sum()) == 0
+            assert (b.offsets.cpu().numpy() == off).all() and (b.scores.cpu().numpy() == sc).all() and b.cigar_strings() == cg
+        a.check()
+    # gap penalties under which an entry S + e + o is negative: the byte table cannot hold them, the batch takes the packed kernel
+    ts, qs = _tiles(rng, shapes[3:9], 128)
+    b = _shared_batch(ts, qs, dev, 1024)
+    protein.run_matrix(b, a, code, mat, 2, 1, ol.SOFTCLIP, shared_target=True)
+    torch.cuda.synchronize()
+    assert a.fill_kernel_name(a.timing()) == "sw_dp16_kernel"
+    off, sc, cg = oracle_matrix_batch(ts, qs, code, mat, 2, 1, ol.SOFTCLIP, 1024)
+    assert (b.offsets.cpu().numpy() == off).all() and (b.scores.cpu().numpy() == sc).all() and b.cigar_strings() == cg
+    # a broken promise: one pair of tile 2 points one residue further into the targets, one pair of tile 4 has a shorter query -- those two
+    # tiles are NOT computed (MGL_SW_ERR_BAD_ARG for their pairs), the others are right
+    ts, qs = _tiles(rng, [(64, 50)] * 6, 128)
+    b = _shared_batch(ts, qs, dev, 512)
+    b.t_off[2 * 128 + 77] += 1
+    b.q_len[4 * 128 + 5] -= 1
+    b.status.fill_(0)
+    protein.run_matrix(b, a, code, mat, 11, 1, ol.SOFTCLIP, shared_target=True)
+    torch.cuda.synchronize()
+    st = b.status.cpu().numpy().reshape(6, 128)
+    assert (st[[2, 4]] == 1).all() and (st[[0, 1, 3, 5]] == 0).all()
+    off, sc, cg = oracle_matrix_batch(ts, qs, code, mat, 11, 1, ol.SOFTCLIP, 512)
+    good = np.repeat(np.array([1, 1, 0, 1, 0, 1], bool), 128)
+    assert (b.offsets.cpu().numpy()[good] == off[good]).all() and (b.scores.cpu().numpy()[good] == sc[good]).all()
+    assert [c for c, g in zip(b.cigar_strings(), good) if g] == [c for c, g in zip(cg, good) if g]
+    # a caller whose max_tl is smaller than a tile's target: that tile does not fit its region and is refused the same way
+    ts, qs = _tiles(rng, [(40, 30), (90, 30), (40, 30)], 128)
+    b = _shared_batch(ts, qs, dev, 512)
+    b.max_tl = 64
+    protein.run_matrix(b, a, code, mat, 11, 1, ol.SOFTCLIP, shared_target=True)
+    torch.cuda.synchronize()
+    st = b.status.cpu().numpy().reshape(3, 128)
+    assert (st[1] == 1).all() and (st[[0, 2]] == 0).all()
+    a.close()
