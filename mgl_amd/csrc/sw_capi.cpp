@@ -1308,8 +1308,9 @@ int run_device(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tse
 constexpr int kNotTaken = -1000;
 int run_shared_target(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqSet &tset, const SeqSet &qset, int max_tl, int max_ql, int smax, int smin, int gopen,
                       int gext, int strategy, int32_t *d_offset, Score *d_score, char *d_cigar, int cigar_stride, int32_t *d_cigar_len, int32_t *d_status,
-                      bool binary_cigar, const int8_t *d_matrix, const uint8_t *d_code)
+                      bool binary_cigar, const int8_t *d_matrix, const uint8_t *d_code, bool score_only)
 {
+    if (score_only && !d_score) return kNotTaken;
     if (n < 1 || !tset.data || !tset.off || !qset.data || !qset.off || !d_offset || !d_cigar || cigar_stride < 1 || max_tl < 1 || max_ql < 1 || !strategy_ok(strategy))
         return kNotTaken; // (run_device says what is wrong)
     int m1 = 1, m2 = -1;
@@ -1317,7 +1318,7 @@ int run_shared_target(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqS
     if (ctx->precision == 32 || ctx->lane_kernel == 1 || tset.packed2 || qset.packed2 || !lane16_matrix_params_ok(smin, smax, gopen, gext) ||
         !dp16_range_ok(max_tl, max_ql, smax, smin, gopen, gext, strategy) || lane16_matrix_lds_bytes(max_tl) > 64 * 1024)
         return kNotTaken;
-    const int64_t tb_words = lane_tb_words(max_tl, max_ql, 32), scratch = lane_scratch_bytes(max_tl, max_ql, 32);
+    const int64_t tb_words = score_only ? 0 : lane_tb_words(max_tl, max_ql, 32), scratch = lane_scratch_bytes(max_tl, max_ql, 32); // (scores only: no flags, the carry row alone)
     const int64_t region = tb_words * 4 + scratch, tiles = (n + 127) / 128;
     const char *const slots_env = getenv("MGL_SW_DEBUG_LANE_SLOTS"); // (tests: a grid of this many wave slots, so that a few tiles already draw from the counter; read per call)
     const int64_t forced = slots_env ? atoll(slots_env) : 0;
@@ -1327,7 +1328,7 @@ int run_shared_target(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqS
     const int frc = grid_fault_check(ctx);
     if (frc != MGL_SW_OK) return frc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, ctx->tb[0].reserve((size_t)slots * (size_t)tb_words * 4));
+    if (tb_words) HIP_TRY(ctx, ctx->tb[0].reserve((size_t)slots * (size_t)tb_words * 4));
     HIP_TRY(ctx, ctx->bnd[0].reserve((size_t)slots * (size_t)scratch));
     if (!ctx->tile_ctr.p) {
         HIP_TRY(ctx, ctx->tile_ctr.reserve((size_t)kTileCounters * kTileCounterWords * sizeof(unsigned)));
@@ -1359,6 +1360,7 @@ int run_shared_target(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqS
     da.scratch = static_cast<unsigned char *>(ctx->bnd[0].p);
     da.matrix = d_matrix;
     da.code = d_code;
+    da.score_only = score_only ? 1 : 0;
     da.lane_slots = (int)slots;
     if (tiles > slots) {
         da.tile_ctr = static_cast<unsigned *>(ctx->tile_ctr.p) + (size_t)(ctx->tile_seq++ % kTileCounters) * kTileCounterWords;
@@ -1819,9 +1821,10 @@ int mgl_sw_align_batch_device_matrix(mgl_sw_ctx *ctx, void *stream, int64_t n, c
         cmax = std::max<int>(cmax, matrix[k]);
         cmin = std::min<int>(cmin, matrix[k]);
     }
-    if ((flags & MGL_SW_FLAG_SHARED_TARGET) && !(flags & MGL_SW_FLAG_SCORE_ONLY)) {
+    if (flags & MGL_SW_FLAG_SHARED_TARGET) {
         const int rc = run_shared_target(ctx, st, n, ts, qs, max_tl, max_ql, cmax, cmin, gopen, gext, strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out),
-                                         d_cigar_out, cigar_stride, d_cigar_len_out, d_status_out, (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, dm, dc);
+                                         d_cigar_out, cigar_stride, d_cigar_len_out, d_status_out, (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, dm, dc,
+                                         (flags & MGL_SW_FLAG_SCORE_ONLY) != 0);
         if (rc != kNotTaken) return rc;
     }
     return run_device(ctx, st, n, ts, qs, max_tl, max_ql, cmax, cmin, gopen, gext, strategy, d_offset_out,

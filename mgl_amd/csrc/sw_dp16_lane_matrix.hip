@@ -51,7 +51,8 @@ constexpr int LM_LDS_T = LM_LDS_SP + MATRIX_DIM * LM_R;       // the tile's targ
 // row (out); hlast: H of the last row (out).  sa / sb: the column's 32 score bytes of pair A / pair B, row r in byte r & 3 of dword
 // r >> 2; sel[k] picks byte k of both into the halves.  The flags are column<R, false>()'s (sw_lane_cell.h), bit for bit.
 // LAST: hlast = H of register row rl (the target's last row; the rows below it are computed and thrown away).
-template <int R, bool LAST>
+// NOTB (MGL_SW_FLAG_SCORE_ONLY): no flags are formed or stored -- 7 of the 16 instructions of a step are left.
+template <int R, bool LAST, bool NOTB>
 __device__ __forceinline__ void column_sp(unsigned (&ho)[R], unsigned (&f)[R], const uint4 (&sa)[R / 16], const uint4 (&sb)[R / 16], const unsigned hdo,
                                           unsigned &e, unsigned &hlast, const LaneConsts &c, const unsigned (&sel)[4], uint4 *tbp, const int rl)
 {
@@ -73,16 +74,18 @@ __device__ __forceinline__ void column_sp(unsigned (&ho)[R], unsigned (&f)[R], c
         const unsigned open = pk_sub(hn, c.o_e);
         const unsigned eo = pk_max(open, e);
         const unsigned fo = pk_max(open, fr);
-        const unsigned d1 = pk_sub_sat(diag, fr);
-        const unsigned d2 = pk_sub_sat(sm, e);
-        const unsigned d3 = pk_sub_sat(e, open);
-        const unsigned d4 = pk_sub_sat(fr, open);
-        const unsigned p12 = __builtin_amdgcn_perm(d1, d2, 0x0b0a0908u);
-        const unsigned p34 = __builtin_amdgcn_perm(d3, d4, 0x0b0a0908u);
-        const int U = r & 3;
-        const unsigned low = U == 0 ? 0u : w[(r >> 2) & 3];
-        w[(r >> 2) & 3] = and_or(p34, c.k34[U], U == 0 ? (p12 & c.k12[0]) : and_or(p12, c.k12[U], low));
-        if ((r & 15) == 15) tbp[(size_t)(r >> 4) * 64] = make_uint4(w[0], w[1], w[2], w[3]);
+        if (!NOTB) {
+            const unsigned d1 = pk_sub_sat(diag, fr);
+            const unsigned d2 = pk_sub_sat(sm, e);
+            const unsigned d3 = pk_sub_sat(e, open);
+            const unsigned d4 = pk_sub_sat(fr, open);
+            const unsigned p12 = __builtin_amdgcn_perm(d1, d2, 0x0b0a0908u);
+            const unsigned p34 = __builtin_amdgcn_perm(d3, d4, 0x0b0a0908u);
+            const int U = r & 3;
+            const unsigned low = U == 0 ? 0u : w[(r >> 2) & 3];
+            w[(r >> 2) & 3] = and_or(p34, c.k34[U], U == 0 ? (p12 & c.k12[0]) : and_or(p12, c.k12[U], low));
+            if ((r & 15) == 15) tbp[(size_t)(r >> 4) * 64] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
         ho[r] = open;
         f[r] = fo;
         e = eo;
@@ -94,7 +97,7 @@ __device__ __forceinline__ void column_sp(unsigned (&ho)[R], unsigned (&f)[R], c
     }
 }
 
-template <int R, bool LAST>
+template <int R, bool LAST, bool NOTB>
 __device__ __forceinline__ void lm_strip(const int i0, const int tl, const int ql, uint2 *bnd, const unsigned *qst, const unsigned char *sp, uint4 *&tbp,
                                          const LaneConsts &c, const unsigned (&sel)[4], const int gopen, const int gext, const int base, const bool indel,
                                          int &bestA, int &bestA_i, int &bestB, int &bestB_i)
@@ -123,8 +126,8 @@ __device__ __forceinline__ void lm_strip(const int i0, const int tl, const int q
     };
     auto one_column = [&](const uint2 top, const uint4 (&sa)[R / 16], const uint4 (&sb)[R / 16]) {
         unsigned e = top.y, hlast;
-        column_sp<R, LAST>(ho, f, sa, sb, hdo, e, hlast, c, sel, tbp, rl);
-        tbp += (R / 16) * 64;
+        column_sp<R, LAST, NOTB>(ho, f, sa, sb, hdo, e, hlast, c, sel, tbp, rl);
+        if (!NOTB) tbp += (R / 16) * 64;
         hdo = pk_sub(top.x, c.o_e);
         bp[0] = make_uint2(hlast, LAST ? 0u : e);
         bp += 64;
@@ -176,18 +179,10 @@ __device__ __forceinline__ void lm_strip(const int i0, const int tl, const int q
     }
 }
 
-} // namespace
-
-// -DMGL_LM_WAVES=2 (scripts/build_variant.sh): two waves per SIMD, 256 registers -- a measurement build
-#ifndef MGL_LM_WAVES
-#define MGL_LM_WAVES 3
-#elif !defined(MGL_VARIANT_BUILD)
-#error "MGL_LM_WAVES is a measurement switch (scripts/build_variant.sh defines MGL_VARIANT_BUILD): never the shipped library"
-#endif
-__global__ __launch_bounds__(64, MGL_LM_WAVES) void sw_dp16_lane_matrix_kernel(const DpArgs a, const TbArgs walk)
+template <bool NOTB>
+__device__ __forceinline__ void lm_body(const DpArgs &a, const TbArgs &walk, unsigned char *smem)
 {
     constexpr int R = LM_R;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const int64_t tiles = (a.count + 127) >> 7, slots = gridDim.x, slot = blockIdx.x;
     unsigned long long *const ctr = reinterpret_cast<unsigned long long *>(a.tile_ctr); // {draws, waves out}: ONE object (sw_dp16_lane_ck.hip)
@@ -299,9 +294,9 @@ __global__ __launch_bounds__(64, MGL_LM_WAVES) void sw_dp16_lane_matrix_kernel(c
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (k < strips - 1)
-                    lm_strip<R, false>(k * R, tl, ql, bnd, qst, sp, tbp, c, sel, gopen, gext, base, indel, bestA, bestA_i, bestB, bestB_i);
+                    lm_strip<R, false, NOTB>(k * R, tl, ql, bnd, qst, sp, tbp, c, sel, gopen, gext, base, indel, bestA, bestA_i, bestB, bestB_i);
                 else
-                    lm_strip<R, true>(k * R, tl, ql, bnd, qst, sp, tbp, c, sel, gopen, gext, base, indel, bestA, bestA_i, bestB, bestB_i);
+                    lm_strip<R, true, NOTB>(k * R, tl, ql, bnd, qst, sp, tbp, c, sel, gopen, gext, base, indel, bestA, bestA_i, bestB, bestB_i);
             }
             // ---- last row (sw.cpp:116-127), order-free form (sw_dp16_lane.hip)
             int rmA = NEG_INF, rdA = 0x7fffffff, rjA = 0x7fffffff, rmB = NEG_INF, rdB = 0x7fffffff, rjB = 0x7fffffff;
@@ -334,16 +329,33 @@ __global__ __launch_bounds__(64, MGL_LM_WAVES) void sw_dp16_lane_matrix_kernel(c
                     r.seg = row_wins ? ql - rj : 0;
                     r.g_tail = 0;
                     r.sps = R;
-                    // the lane walks the paths of its own two pairs right here: the flags are its own stores
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    TbView view;
-                    view.base = tb_region;
-                    view.set_schedule(r, ql, R);
-                    view.packed16 = 2;
-                    view.half = half;
-                    view.lane = lane;
-                    view.ql = ql;
-                    traceback_one_pair(walk, view, r, half ? pB : pA, tl, ql);
+                    if (NOTB) { // scores only: offset 0, an empty CIGAR (sw_scores_only_kernel)
+                        const int64_t p = half ? pB : pA, o = walk.dest ? walk.dest[p] : p;
+                        walk.offset[o] = 0;
+                        if (walk.cigar_len) walk.cigar_len[o] = 0;
+                        if (walk.status) walk.status[o] = 0;
+                        if (walk.score) {
+                            Score sc;
+                            sc.mqe = r.mqe;
+                            sc.mqe_t = r.mqe_t;
+                            sc.max = r.max;
+                            sc.max_t = r.max_t;
+                            sc.max_q = r.max_q;
+                            sc.seg_length = r.seg;
+                            walk.score[o] = sc;
+                        }
+                    } else {
+                        // the lane walks the paths of its own two pairs right here: the flags are its own stores
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        TbView view;
+                        view.base = tb_region;
+                        view.set_schedule(r, ql, R);
+                        view.packed16 = 2;
+                        view.half = half;
+                        view.lane = lane;
+                        view.ql = ql;
+                        traceback_one_pair(walk, view, r, half ? pB : pA, tl, ql);
+                    }
                 }
             }
         }
@@ -364,6 +376,27 @@ __global__ __launch_bounds__(64, MGL_LM_WAVES) void sw_dp16_lane_matrix_kernel(c
     }
 }
 
+} // namespace
+
+// -DMGL_LM_WAVES=2 (scripts/build_variant.sh): two waves per SIMD, 256 registers -- a measurement build
+#ifndef MGL_LM_WAVES
+#define MGL_LM_WAVES 3
+#elif !defined(MGL_VARIANT_BUILD)
+#error "MGL_LM_WAVES is a measurement switch (scripts/build_variant.sh defines MGL_VARIANT_BUILD): never the shipped library"
+#endif
+__global__ __launch_bounds__(64, MGL_LM_WAVES) void sw_dp16_lane_matrix_kernel(const DpArgs a, const TbArgs walk)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lm_body<false>(a, walk, smem);
+}
+
+// MGL_SW_FLAG_SCORE_ONLY: the same fill without flags, regions or walk (a database search's pre-filter)
+__global__ __launch_bounds__(64, MGL_LM_WAVES) void sw_dp16_lane_matrix_score_kernel(const DpArgs a, const TbArgs walk)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lm_body<true>(a, walk, smem);
+}
+
 // the table's bias is the gap's: every S + e + o must be a byte (above)
 bool lane16_matrix_params_ok(int smin, int smax, int gopen, int gext) { return gext >= 0 && gopen >= gext && smin + gext + gopen >= 0 && smax + gext + gopen <= 255; }
 int lane16_matrix_lds_bytes(int max_tl) { return LM_LDS_T + (lane_strips(max_tl, LM_R) * LM_R + 15) / 16 * 16; }
@@ -373,13 +406,14 @@ int lane16_matrix_lds_bytes(int max_tl) { return LM_LDS_T + (lane_strips(max_tl,
 hipError_t launch_dp16_lane_matrix(const DpArgs &a, const TbArgs &walk, hipStream_t stream)
 {
     const int64_t tiles = (a.count + 127) / 128;
-    if (a.lane_slots < 1 || !a.matrix || !a.code || !walk.cigar || a.t.packed2 || a.q.packed2 || (tiles > a.lane_slots && !a.tile_ctr)) return hipErrorInvalidValue;
+    if (a.lane_slots < 1 || !a.matrix || !a.code || (!walk.cigar && !a.score_only) || a.t.packed2 || a.q.packed2 || (tiles > a.lane_slots && !a.tile_ctr)) return hipErrorInvalidValue;
     const int lds = lane16_matrix_lds_bytes(a.uni_tl);
+    auto kernel = a.score_only ? sw_dp16_lane_matrix_score_kernel : sw_dp16_lane_matrix_kernel;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_dp16_lane_matrix_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(sw_dp16_lane_matrix_kernel, dim3((unsigned)std::min<int64_t>(tiles, a.lane_slots)), dim3(64), lds, stream, a, walk);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)std::min<int64_t>(tiles, a.lane_slots)), dim3(64), lds, stream, a, walk);
     return hipGetLastError();
 }
 

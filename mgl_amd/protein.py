@@ -180,15 +180,17 @@ class DatabaseSearch:
         self.shared, self.rest = part(order[n_long:], 0, self.Qs), part(order[n_long:], self.Qs, self.Qr)
         self.long = part(order[:n_long], 0, Q)
 
-    def run(self, aligner, code, matrix, gap_open=11, gap_extend=1, overhang_strategy=1, stream=None):
-        """Enqueue the search on ``stream`` (default: torch's current stream); no sync.  (The two small batches on a second context and
-        stream, to fill the tail of the tiles' persistent grid, measured slower: 63.5 against 58.2 ms per pass.)"""
+    def run(self, aligner, code, matrix, gap_open=11, gap_extend=1, overhang_strategy=1, stream=None, score_only=False):
+        """Enqueue the search on ``stream`` (default: torch's current stream); no sync.  ``score_only``: MGL_SW_FLAG_SCORE_ONLY, the
+        pre-filter mode (all six ScoreMax fields, no CIGAR).  (The two small batches on a second context and stream, to fill the tail
+        of the tiles' persistent grid, measured slower: 63.5 against 58.2 ms per pass.)"""
+        kw = dict(stream=stream, score_only=score_only)
         if self.shared is not None:
-            run_matrix(self.shared, aligner, code, matrix, gap_open, gap_extend, overhang_strategy, stream, shared_target=True)
+            run_matrix(self.shared, aligner, code, matrix, gap_open, gap_extend, overhang_strategy, shared_target=True, **kw)
         if self.long is not None:
-            run_matrix(self.long, aligner, code, matrix, gap_open, gap_extend, overhang_strategy, stream, grouped=self.Q % 8 == 0)
+            run_matrix(self.long, aligner, code, matrix, gap_open, gap_extend, overhang_strategy, grouped=self.Q % 8 == 0, **kw)
         if self.rest is not None:
-            run_matrix(self.rest, aligner, code, matrix, gap_open, gap_extend, overhang_strategy, stream, grouped=self.Qr % 8 == 0)
+            run_matrix(self.rest, aligner, code, matrix, gap_open, gap_extend, overhang_strategy, grouped=self.Qr % 8 == 0, **kw)
 
     def batches(self):
         return [b for b in (self.long, self.shared, self.rest) if b is not None]

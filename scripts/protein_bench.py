@@ -52,10 +52,10 @@ dev = torch.device("cuda", 0)
 cells = int(lens.sum()) * Q * QL
 a = sw.MicrosoftSmithWaterman(0)
 a.set_workspace(int(args.workspace_gib * (1 << 30)))
-shared = args.layout == "shared" and not args.score_only and not os.environ.get("MGL_PROTEIN_INT32")
+shared = args.layout == "shared" and not os.environ.get("MGL_PROTEIN_INT32")
 if shared:
     ds = protein.DatabaseSearch(db, db_off, queries, dev, args.stride, workspace_bytes=int(args.workspace_gib * (1 << 30)))
-    run_pass = lambda: ds.run(a, code, mat, 11, 1)
+    run_pass = lambda: ds.run(a, code, mat, 11, 1, score_only=args.score_only)
     batches = ds.batches()
     where = ds.where
 else:
@@ -85,7 +85,7 @@ run_pass(); torch.cuda.synchronize()
 tm = a.timing()
 a.set_profiling(0)
 over = sum(int((x.status != 0).sum()) for x in batches)
-kernels = "sw_dp16_lane_matrix_kernel (tiles of 128 pairs that share their target) + sw_dp16_matrix_kernel (the rest)" if shared else ("sw_dp16_matrix_kernel" if tm.packed16 else "sw_dp_matrix_kernel")
+kernels = f"sw_dp16_lane_matrix{'_score' if args.score_only else ''}_kernel (tiles of 128 pairs that share their target) + sw_dp16_matrix{'_score' if args.score_only else ''}_kernel (the rest)" if shared else ("sw_dp16_matrix_kernel" if tm.packed16 else "sw_dp_matrix_kernel")
 layout_note = ""
 if shared:
     layout_note = (f"; {ds.shared.n} pairs in tiles on targets up to {ds.shared_max_tl} residues, {0 if ds.rest is None else ds.rest.n} beyond whole tiles, "

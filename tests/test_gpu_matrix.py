@@ -214,6 +214,12 @@ def test_tiles_that_share_their_target_bit_exact(monkeypatch):
             assert a.fill_kernel_name(a.timing()) == "sw_dp16_lane_matrix_kernel"
             assert int((b.status != 0).sum()) == 0
             assert (b.offsets.cpu().numpy() == off).all() and (b.scores.cpu().numpy() == sc).all() and b.cigar_strings() == cg
+        # MGL_SW_FLAG_SCORE_ONLY: the same six fields without flags, regions or walk
+        b.scores.fill_(-7); b.offsets.fill_(-7); b.cigar_len.fill_(-7)
+        protein.run_matrix(b, a, code, mat, o, e, strategy, shared_target=True, score_only=True)
+        torch.cuda.synchronize()
+        assert a.fill_kernel_name(a.timing()) == "sw_dp16_lane_matrix_kernel"
+        assert (b.scores.cpu().numpy() == sc).all() and int(b.offsets.abs().sum()) == 0 and int(b.cigar_len.abs().sum()) == 0 and int((b.status != 0).sum()) == 0
         a.check()
     # gap penalties under which an entry S + e + o is negative: the byte table cannot hold them, the batch takes the packed kernel
     ts, qs = _tiles(rng, shapes[3:9], 128)
