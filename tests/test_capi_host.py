@@ -181,3 +181,22 @@ def test_shard_by_cells_helper():
 
     if not torch.cuda.is_available():
         assert L.mgl_sw_multi_create(2, None, C.byref(h)) == _lib.ERR_DEVICE
+
+
+def test_python_mirror_of_the_header_constants():
+    """mgl_amd/_lib.py repeats the header's flags, status codes and fill-kernel ids: the numbers must be the header's (no GPU, no library)."""
+    import re
+
+    from mgl_amd import _lib
+
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mgl_sw.h")).read()
+    defines = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+(MGL_SW_[A-Z0-9_]+)\s+(0x[0-9a-fA-F]+|\d+)\b", text)}
+    for name in ("UNIFORM_GEOMETRY", "BINARY_CIGAR", "GROUPED_GEOMETRY", "SCORE_ONLY", "SHARED_TARGET"):
+        assert getattr(_lib, "FLAG_" + name) == defines["MGL_SW_FLAG_" + name], name
+    flags = [defines[k] for k in defines if k.startswith("MGL_SW_FLAG_")]
+    assert len(set(flags)) == len(flags) and all(f & (f - 1) == 0 for f in flags)   # one bit each
+    assert _lib.ABI_VERSION == defines["MGL_SW_VERSION"]
+    kernels = sorted((v, k) for k, v in defines.items() if k.startswith("MGL_SW_KERNEL_"))
+    assert [v for v, _ in kernels] == list(range(len(kernels))) and len(_lib.FILL_KERNEL_NAMES) == len(kernels)
+    for v, k in kernels:   # MGL_SW_KERNEL_LANE16_CK -> sw_dp16_lane_ck_kernel, ...
+        assert re.search(rf"#define {k} {v}\s+/\* {re.escape(_lib.FILL_KERNEL_NAMES[v])}\b", text), (k, _lib.FILL_KERNEL_NAMES[v])
