@@ -253,3 +253,44 @@ def test_tiles_that_share_their_target_bit_exact(monkeypatch):
     st = b.status.cpu().numpy().reshape(3, 128)
     assert (st[1] == 1).all() and (st[[0, 2]] == 0).all()
     a.close()
+
+
+@pytest.mark.gpu
+def test_database_search_layout_every_pair_where_it_says():
+    """mgl_amd.protein.DatabaseSearch: 136 queries against 9 database sequences -- tiles of 128 per sequence (longest first), 8 queries beyond
+    whole tiles, two sequences too long for the tile class -- every (d, q) found by where() and equal to the CPU restatement's extension."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    code, mat = protein.blosum62()
+    lens = np.array([60, 333, 41, 700, 129, 64, 1200, 95, 256])
+    db_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    db = protein.random_proteins(rng, 1, int(db_off[-1]))[0]
+    Q, QL = 136, 70
+    queries = protein.random_proteins(rng, Q, QL)
+    for q in range(0, Q, 3):   # diverged fragments of database sequences
+        d = int(rng.integers(0, len(lens)))
+        if lens[d] >= QL:
+            s0 = int(rng.integers(0, lens[d] - QL + 1)); frag = db[db_off[d] + s0: db_off[d] + s0 + QL].copy()
+            mut = rng.random(QL) < 0.3
+            frag[mut] = protein.random_proteins(rng, 1, int(mut.sum()))[0]
+            queries[q] = frag
+    ds = protein.DatabaseSearch(db, db_off, queries, torch.device("cuda", 0), cigar_stride=1024, shared_max_tl=512)
+    assert ds.shared.n == 7 * 128 and ds.rest.n == 7 * 8 and ds.long.n == 2 * Q and ds.shared_max_tl == 512
+    a = sw.MicrosoftSmithWaterman(0)
+    ds.run(a, code, mat, 11, 1, ol.SOFTCLIP)
+    torch.cuda.synchronize()
+    ts = [db[db_off[d]:db_off[d + 1]].tobytes() for d in range(len(lens)) for q in range(Q)]
+    qs = [queries[q].tobytes() for d in range(len(lens)) for q in range(Q)]
+    off, sc, cg = oracle_matrix_batch(ts, qs, code, mat, 11, 1, ol.SOFTCLIP, 1024)
+    host = {id(b): (b.offsets.cpu().numpy(), b.scores.cpu().numpy(), b.status.cpu().numpy(), b.cigar_strings()) for b in ds.batches()}
+    seen = set()
+    for d in range(len(lens)):
+        for q in range(Q):
+            b, p = ds.where(d, q)
+            o_, s_, st_, c_ = host[id(b)]
+            k = d * Q + q
+            assert (id(b), p) not in seen and st_[p] == 0 and o_[p] == off[k] and (s_[p] == sc[k]).all() and c_[p] == cg[k], (d, q)
+            seen.add((id(b), p))
+    assert len(seen) == len(lens) * Q == sum(b.n for b in ds.batches())
+    a.close()
