@@ -195,7 +195,7 @@ def secondary_workloads():
         "pairhmm_150x300 (SURVEY 8f rank 3, 1.6 M pairs)": ["scripts/pairhmm_bench.py", "--steps", "3", "--cpu-seconds", "3", "--json"],
         # configs[4] to the standard of configs[3]: a seeded subset (400 queries x 5 000 database sequences = 2 M alignments per pass) repeated for
         # >= 30 s, with a roofline object and a CPU figure (the restatement's matrix extension: there is no reference path to time)
-        "protein_blosum62 (configs[4] shape, 2 M alignments per pass, >= 30 s, no reference path: parity unpinned)": ["scripts/protein_bench.py", "--steps", "2", "--seconds", "30", "--check", "50", "--workspace-gib", "128",
+        "protein_blosum62 (configs[4] shape, 2 M alignments per pass, >= 30 s, no reference path: parity unpinned)": ["scripts/protein_bench.py", "--steps", "2", "--seconds", "30", "--check", "50", "--workspace-gib", "64",
                                                                                                              "--cpu-seconds", "10", "--json"],
     }
     for name, cmd in runs.items():

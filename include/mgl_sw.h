@@ -331,6 +331,8 @@ int mgl_sw_shard_by_cells(int64_t n, const int64_t *t_off, const int64_t *q_off,
  * lane two pairs and looks the scores of a column up as one row of a per-strip profile (sw_dp16_lane_matrix.hip); gap penalties and
  * matrix must satisfy 0 <= S + gopen + gext <= 255 for every entry and the score range 16 bits, else the flag is read as
  * MGL_SW_FLAG_GROUPED_GEOMETRY.  A block that breaks the promise is NOT computed: its pairs get MGL_SW_ERR_BAD_ARG in d_status_out.
+ * The call looks at every block's lengths before it launches (8 bytes per block back to the host: it waits for `stream` once) and sizes its
+ * workspace by the largest blocks; the blocks may come in any order.
  * Combines with MGL_SW_FLAG_SCORE_ONLY (needs d_score_out) and MGL_SW_FLAG_BINARY_CIGAR. */
 #define MGL_SW_FLAG_SHARED_TARGET 0x10
 int mgl_sw_align_batch_device(mgl_sw_ctx *ctx, void *stream, int64_t n, const uint8_t *d_targets,

@@ -83,6 +83,8 @@ struct mgl_sw_ctx {
     int64_t *cur_gate_dev = nullptr;   // ... and the gate's mirror in device memory (DpArgs::gate_dev: two words behind d_any's status word, zeroed with it)
     bool direct_broken = false;    // a gate once timed out on this context: the direct form is not tried again
     int32_t *direct_status_any = nullptr; // ... and the device word that collects the largest per-pair status of its launch
+    void *pin_tiles = nullptr;          // run_shared_target: the tiles' geometries on their way in, their order and the slots' regions on their way out (page-locked)
+    size_t pin_tiles_cap = 0;
     // small-batch entry of the coalescing front-end: one pinned host buffer each way, mirrored on the device
     void *pin_in = nullptr, *pin_out = nullptr;
     size_t pin_in_cap = 0, pin_out_cap = 0;
@@ -1318,18 +1320,60 @@ int run_shared_target(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqS
     if (ctx->precision == 32 || ctx->lane_kernel == 1 || tset.packed2 || qset.packed2 || !lane16_matrix_params_ok(smin, smax, gopen, gext) ||
         !dp16_range_ok(max_tl, max_ql, smax, smin, gopen, gext, strategy) || lane16_matrix_lds_bytes(max_tl) > 64 * 1024)
         return kNotTaken;
-    const int64_t tb_words = score_only ? 0 : lane_tb_words(max_tl, max_ql, 32), scratch = lane_scratch_bytes(max_tl, max_ql, 32); // (scores only: no flags, the carry row alone)
-    const int64_t region = tb_words * 4 + scratch, tiles = (n + 127) / 128;
+    const int64_t tiles = (n + 127) / 128;
     const char *const slots_env = getenv("MGL_SW_DEBUG_LANE_SLOTS"); // (tests: a grid of this many wave slots, so that a few tiles already draw from the counter; read per call)
     const int64_t forced = slots_env ? atoll(slots_env) : 0;
     const int64_t chip = forced > 0 ? forced : (int64_t)ctx->n_cus * 12; // three waves per SIMD (168 registers)
-    const int64_t slots = std::min<int64_t>(std::min<int64_t>(chip, tiles), ctx->ws_limit / region);
-    if (slots < 1 || (forced <= 0 && slots < std::min<int64_t>(tiles, (int64_t)ctx->n_cus * 4))) return kNotTaken; // (fewer than a wave per SIMD: the kernels that keep less per pair do better)
     const int frc = grid_fault_check(ctx);
     if (frc != MGL_SW_OK) return frc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (tb_words) HIP_TRY(ctx, ctx->tb[0].reserve((size_t)slots * (size_t)tb_words * 4));
-    HIP_TRY(ctx, ctx->bnd[0].reserve((size_t)slots * (size_t)scratch));
+    if (ctx->ws_idle_set) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ws_idle, 0));
+    // ---- every tile's geometry comes back (8 bytes per tile; the one synchronisation of this path: the regions are sized by it)
+    const size_t geo_bytes = (size_t)tiles * 8, order_off = (geo_bytes + 255) / 256 * 256, off_off = order_off + ((size_t)tiles * 4 + 255) / 256 * 256;
+    HIP_TRY(ctx, ctx->d_grid.reserve(off_off + (size_t)(chip + 1) * 8 + 256));
+    unsigned char *const dg = static_cast<unsigned char *>(ctx->d_grid.p);
+    HIP_TRY(ctx, launch_tile_geometry(tset, qset, 0, n, reinterpret_cast<int32_t *>(dg), stream));
+    const size_t pin_need = off_off + (size_t)(chip + 1) * 8 + 256; // (page-locked, the context's: the copies back need no second wait)
+    if (ctx->pin_tiles_cap < pin_need) {
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        if (ctx->pin_tiles) (void)hipHostFree(ctx->pin_tiles);
+        ctx->pin_tiles = nullptr;
+        ctx->pin_tiles_cap = 0;
+        HIP_TRY(ctx, hipHostMalloc(&ctx->pin_tiles, pin_need * 2, hipHostMallocDefault));
+        ctx->pin_tiles_cap = pin_need * 2;
+    }
+    unsigned char *const hp = static_cast<unsigned char *>(ctx->pin_tiles);
+    const int32_t *const geo = reinterpret_cast<const int32_t *>(hp);
+    HIP_TRY(ctx, hipMemcpyAsync(hp, dg, geo_bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    std::vector<int64_t> need((size_t)tiles);
+    int true_max_tl = 1;
+    for (int64_t k = 0; k < tiles; ++k) {
+        const int tl = geo[2 * (size_t)k], ql = geo[2 * (size_t)k + 1];
+        const bool ok = tl >= 1 && ql >= 1 && tl <= max_tl && ql <= max_ql;
+        need[(size_t)k] = ok ? lane16_matrix_region_bytes(tl, ql, score_only) : 0; // (a geometry outside the caller's bounds: the kernel refuses the tile)
+        if (ok) true_max_tl = std::max(true_max_tl, tl);
+    }
+    int32_t *const order = reinterpret_cast<int32_t *>(hp + order_off);
+    for (int64_t k = 0; k < tiles; ++k) order[(size_t)k] = (int32_t)k;
+    std::stable_sort(order, order + tiles, [&](int32_t x, int32_t y) { return need[(size_t)x] > need[(size_t)y]; });
+    // wave slot s starts on the s-th largest tile: its region holds exactly that one, and everything it draws later.  As many slots as the
+    // workspace has room for (the sum over the largest tiles), at most what the chip holds
+    int64_t slots = 0, total = 0;
+    int64_t *const slot_off = reinterpret_cast<int64_t *>(hp + off_off);
+    slot_off[0] = 0;
+    while (slots < std::min<int64_t>(chip, tiles)) {
+        const int64_t r = std::max<int64_t>(need[(size_t)order[(size_t)slots]], 256);
+        if (total + r > ctx->ws_limit) break;
+        total += r;
+        slot_off[++slots] = total;
+    }
+    if (slots < 1 || (forced <= 0 && slots < std::min<int64_t>(tiles, (int64_t)ctx->n_cus * 4))) return kNotTaken; // (fewer than a wave per SIMD: the kernels that keep less per pair do better)
+    HIP_TRY(ctx, ctx->tb[0].reserve((size_t)total));
+    // (the page-locked buffer is read by these two copies only: the next call waits for this one's kernels -- ws_idle, and its own look at
+    // the geometries -- before it writes there again)
+    HIP_TRY(ctx, hipMemcpyAsync(dg + order_off, order, (size_t)tiles * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dg + off_off, slot_off, (size_t)(slots + 1) * 8, hipMemcpyHostToDevice, stream));
     if (!ctx->tile_ctr.p) {
         HIP_TRY(ctx, ctx->tile_ctr.reserve((size_t)kTileCounters * kTileCounterWords * sizeof(unsigned)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->tile_ctr.p, 0, (size_t)kTileCounters * kTileCounterWords * sizeof(unsigned), stream));
@@ -1338,11 +1382,11 @@ int run_shared_target(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqS
         HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->pin_fault), 64, hipHostMallocDefault));
         memset(ctx->pin_fault, 0, 64);
     }
-    if (ctx->ws_idle_set) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ws_idle, 0));
     if (ctx->profiling != 3) {
         ctx->timing = mgl_sw_timing{};
         ctx->pool_used = 0;
     }
+    const int64_t tb_words = 0;
     DpArgs da{};
     da.t = tset;
     da.q = qset;
@@ -1353,11 +1397,12 @@ int run_shared_target(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqS
     da.gopen = gopen;
     da.gext = gext;
     da.strategy = strategy;
-    da.uni_tl = max_tl;
+    da.uni_tl = std::min(max_tl, true_max_tl); // (sizes the kernel's LDS copy of a tile's target)
     da.uni_ql = max_ql;
     da.tb = static_cast<uint32_t *>(ctx->tb[0].p);
     da.tb_stride_words = tb_words;
-    da.scratch = static_cast<unsigned char *>(ctx->bnd[0].p);
+    da.tile_order = reinterpret_cast<const int32_t *>(dg + order_off);
+    da.slot_off = reinterpret_cast<const int64_t *>(dg + off_off);
     da.matrix = d_matrix;
     da.code = d_code;
     da.score_only = score_only ? 1 : 0;
@@ -1413,7 +1458,7 @@ int run_shared_target(mgl_sw_ctx *ctx, hipStream_t stream, int64_t n, const SeqS
     ctx->last_chunk_count = 0; // (no slot to expand: the flags of a tile are gone with the next one)
     ctx->timing.dp_launches++;
     ctx->timing.tb_launches++;
-    ctx->timing.tb_bytes += slots * tb_words * 4;
+    ctx->timing.tb_bytes += total;
     ctx->timing.packed16 = 1;
     ctx->timing.fill_kernel = MGL_SW_KERNEL_LANE16_MATRIX;
     return MGL_SW_OK;
@@ -1541,6 +1586,7 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     if (ctx->pin_fault) (void)hipHostFree(ctx->pin_fault);
     for (auto &e : ctx->gate_ev)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->pin_tiles) (void)hipHostFree(ctx->pin_tiles);
     if (ctx->pin_matrix) (void)hipHostFree(ctx->pin_matrix);
     if (ctx->matrix_copied) (void)hipEventDestroy(ctx->matrix_copied);
     if (ctx->ws_idle) (void)hipEventDestroy(ctx->ws_idle);
@@ -1822,9 +1868,14 @@ int mgl_sw_align_batch_device_matrix(mgl_sw_ctx *ctx, void *stream, int64_t n, c
         cmin = std::min<int>(cmin, matrix[k]);
     }
     if (flags & MGL_SW_FLAG_SHARED_TARGET) {
-        const int rc = run_shared_target(ctx, st, n, ts, qs, max_tl, max_ql, cmax, cmin, gopen, gext, strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out),
+        int rc = kNotTaken;
+        try { // (the tiles' geometries and their order are host vectors: no C++ exception crosses the C ABI)
+            rc = run_shared_target(ctx, st, n, ts, qs, max_tl, max_ql, cmax, cmin, gopen, gext, strategy, d_offset_out, reinterpret_cast<Score *>(d_score_out),
                                          d_cigar_out, cigar_stride, d_cigar_len_out, d_status_out, (flags & MGL_SW_FLAG_BINARY_CIGAR) != 0, dm, dc,
                                          (flags & MGL_SW_FLAG_SCORE_ONLY) != 0);
+        } catch (const std::exception &) {
+            return fail(ctx, MGL_SW_ERR_NOMEM, "mgl_sw_align_batch_device_matrix: out of host memory");
+        }
         if (rc != kNotTaken) return rc;
     }
     return run_device(ctx, st, n, ts, qs, max_tl, max_ql, cmax, cmin, gopen, gext, strategy, d_offset_out,

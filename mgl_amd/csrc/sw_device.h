@@ -81,6 +81,10 @@ struct DpArgs {
                               //     that look -- the waiting waves watch the mirror, one of them per microsecond looks at the host's word (sw_dp16_lane_ck.hip)
     int32_t *gate_failed;     // ... set to 1 (pinned host memory) by a wave that gives up waiting: gate_timeout_ticks (100 MHz) without the word moving
     unsigned gate_timeout_ticks;
+    // sw_dp16_lane_matrix_kernel: the tiles in the order they are drawn (largest region first) and where the region of wave slot s starts and
+    // ends (bytes off tb; slot_off[s + 1] - slot_off[s] = what the s-th largest tile needs: every later draw needs less)
+    const int32_t *tile_order;
+    const int64_t *slot_off;
 };
 
 struct TbArgs {
@@ -218,6 +222,11 @@ hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &walk, int rows, hipSt
 bool lane16_matrix_params_ok(int smin, int smax, int gopen, int gext); // every S + e + o a byte
 int lane16_matrix_lds_bytes(int max_tl);
 hipError_t launch_dp16_lane_matrix(const DpArgs &a, const TbArgs &walk, hipStream_t stream);
+// ... what a tile of geometry tl x ql keeps in its wave slot's region: the flags (none when only scores are wanted), then the carry row and the queries as codes
+__host__ __device__ inline int64_t lane16_matrix_tb_bytes(int tl, int ql, bool score_only) { return score_only ? 0 : lane_tb_words(tl, ql, 32) * 4; }
+__host__ __device__ inline int64_t lane16_matrix_region_bytes(int tl, int ql, bool score_only) { return (lane16_matrix_tb_bytes(tl, ql, score_only) + lane_scratch_bytes(tl, ql, 32) + 255) / 256 * 256; }
+// ... {target length, query length} of every tile's first pair, for the host to size the regions by
+hipError_t launch_tile_geometry(const SeqSet &t, const SeqSet &q, int64_t first, int64_t count, int32_t *out, hipStream_t stream);
 hipError_t launch_dp16_lane_ck(const DpArgs &a, const TbArgs &walk, hipStream_t stream); // a.tb_stride_words = lane_ck_words per wave; walk.cigar != null
 hipError_t launch_dp(const DpArgs &a, int waves_per_block, int rows, hipStream_t stream);
 int coop_lds_bytes(int sps_cap, int waves_per_block);

@@ -22,10 +22,13 @@
 //
 // A PERSISTENT grid (as sw_dp16_lane_ck.hip's): a wave keeps ONE region -- the traceback flags of a tile, [strip][column][R/16][lane]
 // uint4 as sw_dp16_lane.hip stores them, and the carry row between strips -- walks its 128 paths itself right behind the fill
-// (sw_traceback.h, the flags are the lane's own stores) and takes the next tile off a counter, so the workspace is wave slots x
-// one region of the largest geometry however many pairs the call holds.  A tile whose pairs do not share one target and one query
-// length, or exceed the region, breaks the caller's promise: its pairs get MGL_SW_ERR_BAD_ARG in the status array and the call's
-// status word, nothing is computed for them (never a wrong result).
+// (sw_traceback.h, the flags are the lane's own stores) and takes the next tile off a counter.  The tiles are drawn LARGEST FIRST
+// (DpArgs::tile_order: the host has looked at every tile's geometry -- launch_tile_geometry, 8 bytes per tile back over the link -- and
+// sorted them by what they keep), wave slot s starts on the s-th largest tile and its region is sized for exactly that one
+// (DpArgs::slot_off): whatever a slot draws later needs less.  So the workspace is the sum over the S largest tiles, not S times
+// the largest (a protein database's lengths are log-normal: 41 GB instead of 117 for 3 072 slots on the bench's), and the queue ends on
+// its shortest tiles.  A tile whose pairs do not share one target and one query length breaks the caller's promise: its pairs get
+// MGL_SW_ERR_BAD_ARG in the status array and the call's status word, nothing is computed for them (never a wrong result).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -213,13 +216,12 @@ __device__ __forceinline__ void lm_body(const DpArgs &a, const TbArgs &walk, uns
     }
     const int sp_bias = gopen + gext; // an entry = S + 2e + (o - e)
 
-    // the slot's region: traceback words, then (scratch) the carry row and the two queries as codes
-    unsigned char *const wave_scratch = a.scratch + (size_t)slot * (size_t)lane_scratch_bytes(a.uni_tl, a.uni_ql, R);
-    uint2 *const bnd = reinterpret_cast<uint2 *>(wave_scratch) + lane;
-    unsigned *const qst = reinterpret_cast<unsigned *>(wave_scratch + (size_t)lane_bnd_entries(a.uni_ql) * 8) + lane;
-    uint32_t *const tb_region = a.tb + (size_t)slot * (size_t)a.tb_stride_words;
+    // the slot's region: the tile's traceback words, then the carry row and the two queries as codes (laid out per tile: its geometry)
+    unsigned char *const region = reinterpret_cast<unsigned char *>(a.tb) + a.slot_off[slot];
+    const int64_t region_cap = a.slot_off[slot + 1] - a.slot_off[slot];
 
-    for (int64_t tile = slot; tile < tiles;) {
+    for (int64_t draw = slot; draw < tiles;) {
+        const int64_t tile = a.tile_order[draw];
         const int64_t p0 = a.first + tile * 128;
         const int cnt = (int)min((int64_t)128, a.count - tile * 128);
         const bool lvalid = 2 * lane < cnt, validB = 2 * lane + 1 < cnt;
@@ -230,7 +232,11 @@ __device__ __forceinline__ void lm_body(const DpArgs &a, const TbArgs &walk, uns
         const unsigned t0lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)t0), t0hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)t0 >> 32));
         const int64_t tstart = (int64_t)((unsigned long long)t0lo | (unsigned long long)t0hi << 32);
         const bool mine = a.t.off[pA] == tstart && a.t.off[pB] == tstart && a.t.length(pA) == tl && a.t.length(pB) == tl && a.q.length(pA) == ql && a.q.length(pB) == ql;
-        const bool fits = tl >= 1 && ql >= 1 && tl <= a.uni_tl && ql <= a.uni_ql;
+        const bool fits = tl >= 1 && ql >= 1 && tl <= a.uni_tl && ql <= a.uni_ql && lane16_matrix_region_bytes(tl, ql, NOTB) <= region_cap;
+        unsigned char *const wave_scratch = region + lane16_matrix_tb_bytes(tl, ql, NOTB);
+        uint2 *const bnd = reinterpret_cast<uint2 *>(wave_scratch) + lane;
+        unsigned *const qst = reinterpret_cast<unsigned *>(wave_scratch + (size_t)lane_bnd_entries(ql) * 8) + lane;
+        uint32_t *const tb_region = reinterpret_cast<uint32_t *>(region);
         if (__builtin_amdgcn_ballot_w64(!mine) != 0ull || !fits) {
             const int bad = 1; // MGL_SW_ERR_BAD_ARG
             if (lvalid) {
@@ -365,7 +371,7 @@ __device__ __forceinline__ void lm_body(const DpArgs &a, const TbArgs &walk, uns
             next = (unsigned)__hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (next >= (unsigned)tiles && a.grid_fault) __hip_atomic_store(a.grid_fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        tile = slots + (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)next);
+        draw = slots + (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)next);
     }
     if (tiles > slots && lane == 0) { // the last wave out zeroes the counter (sw_dp16_lane_ck.hip)
         const unsigned out = (unsigned)(__hip_atomic_fetch_add(ctr, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
@@ -397,16 +403,31 @@ __global__ __launch_bounds__(64, MGL_LM_WAVES) void sw_dp16_lane_matrix_score_ke
     lm_body<true>(a, walk, smem);
 }
 
+// {tl, ql} of every tile's first pair (the kernel checks that the tile's other pairs agree)
+__global__ __launch_bounds__(256) void sw_tile_geometry_kernel(const SeqSet t, const SeqSet q, const int64_t first, const int64_t count, int32_t *out)
+{
+    const int64_t tile = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (tile * 128 >= count) return;
+    out[2 * tile] = t.length(first + tile * 128);
+    out[2 * tile + 1] = q.length(first + tile * 128);
+}
+hipError_t launch_tile_geometry(const SeqSet &t, const SeqSet &q, int64_t first, int64_t count, int32_t *out, hipStream_t stream)
+{
+    const int64_t tiles = (count + 127) / 128;
+    hipLaunchKernelGGL(sw_tile_geometry_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, stream, t, q, first, count, out);
+    return hipGetLastError();
+}
+
 // the table's bias is the gap's: every S + e + o must be a byte (above)
 bool lane16_matrix_params_ok(int smin, int smax, int gopen, int gext) { return gext >= 0 && gopen >= gext && smin + gext + gopen >= 0 && smax + gext + gopen <= 255; }
 int lane16_matrix_lds_bytes(int max_tl) { return LM_LDS_T + (lane_strips(max_tl, LM_R) * LM_R + 15) / 16 * 16; }
 
-// a.lane_slots regions of lane_tb_words(a.uni_tl, a.uni_ql, 32) words at a.tb (a.tb_stride_words apart) and of lane_scratch_bytes() at
-// a.scratch; a.tile_ctr (zero) where the tiles outnumber the slots; walk.cigar set: the waves walk their own paths
+// a.lane_slots regions at a.tb + a.slot_off[s] (a.slot_off: lane_slots + 1 entries), the tiles drawn in the order a.tile_order;
+// a.tile_ctr (zero) where the tiles outnumber the slots; walk.cigar set (or a.score_only): the waves walk their own paths
 hipError_t launch_dp16_lane_matrix(const DpArgs &a, const TbArgs &walk, hipStream_t stream)
 {
     const int64_t tiles = (a.count + 127) / 128;
-    if (a.lane_slots < 1 || !a.matrix || !a.code || (!walk.cigar && !a.score_only) || a.t.packed2 || a.q.packed2 || (tiles > a.lane_slots && !a.tile_ctr)) return hipErrorInvalidValue;
+    if (a.lane_slots < 1 || !a.matrix || !a.code || !a.tile_order || !a.slot_off || (!walk.cigar && !a.score_only) || a.t.packed2 || a.q.packed2 || (tiles > a.lane_slots && !a.tile_ctr)) return hipErrorInvalidValue;
     const int lds = lane16_matrix_lds_bytes(a.uni_tl);
     auto kernel = a.score_only ? sw_dp16_lane_matrix_score_kernel : sw_dp16_lane_matrix_kernel;
     if (lds > 64 * 1024) {

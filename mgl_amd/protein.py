@@ -134,14 +134,14 @@ class DatabaseSearch:
     """Q queries of ONE length against D database sequences, laid out for MGL_SW_FLAG_SHARED_TARGET: the first Qs = Q - Q % 128
     queries of every database sequence are tiles of 128 pairs that share it (batch ``shared``, pair = rank(d) * Qs + q, longest
     database sequence first), the other Qr = Q % 128 queries a second batch (``rest``, pair = rank(d) * Qr + (q - Qs); blocks of
-    eight of one geometry when Qr % 8 == 0).  The kernel keeps one region of the LARGEST geometry per wave slot: database sequences
-    longer than ``shared_max_tl`` -- by default the length up to which ``workspace_bytes`` (what the aligner's set_workspace was given;
-    the library's own default is a quarter of the device's memory, 72 GB on an MI355X) hold a region for every slot of the chip
-    (``wave_slots``: 12 per CU) -- go, all their queries, into a third batch (``long``, pair = k * Q + q) for the packed kernel: a few
-    per cent of the cells of a protein database, instead of two thirds of the wave slots.
+    eight of one geometry when Qr % 8 == 0).  The library sizes a wave slot's region by the tile it starts on (it looks at every tile's
+    geometry and draws the largest first), so a database's long tail costs what it holds, not the number of slots times the longest
+    sequence.  ``shared_max_tl`` / ``workspace_bytes`` (optional; default: neither) send database sequences longer than a bound -- given,
+    or the length up to which ``workspace_bytes`` would hold a region of THAT length for each of ``wave_slots`` slots -- with all their
+    queries into a third batch (``long``, pair = k * Q + q) for the packed kernel.
     ``db``: uint8 residues of all database sequences, ``db_off`` int64[D + 1]; ``queries``: uint8 [Q, QL].  where(d, q) -> (batch, pair)."""
 
-    def __init__(self, db, db_off, queries, device, cigar_stride=256, workspace_bytes=64 << 30, wave_slots=256 * 12, shared_max_tl=None):
+    def __init__(self, db, db_off, queries, device, cigar_stride=256, workspace_bytes=None, wave_slots=256 * 12, shared_max_tl=None):
         import torch
 
         db_off = np.asarray(db_off, dtype=np.int64)

@@ -22,7 +22,7 @@ ap.add_argument("--db", type=int, default=5000)
 ap.add_argument("--query-len", type=int, default=300)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--stride", type=int, default=256, help="CIGAR bytes kept per pair (longer ones are flagged, not written)")
-ap.add_argument("--workspace-gib", type=float, default=128, help="shared layout: 128 holds a region of the longest target (2 000 residues) for every wave slot, 3 907 GCUPS; 64: targets beyond 1 101 residues go to the packed kernel, 3 559; grouped layout at 64: 2 079")
+ap.add_argument("--workspace-gib", type=float, default=64, help="shared layout: the regions of 3 072 wave slots, each sized by the tile it starts on, take 41 GB on this database; grouped layout at 64: 2 079 GCUPS")
 ap.add_argument("--layout", choices=("shared", "grouped"), default="shared")
 ap.add_argument("--check", type=int, default=200)
 ap.add_argument("--score-only", action="store_true", help="MGL_SW_FLAG_SCORE_ONLY: the database-search pre-filter mode")
@@ -54,7 +54,7 @@ a = sw.MicrosoftSmithWaterman(0)
 a.set_workspace(int(args.workspace_gib * (1 << 30)))
 shared = args.layout == "shared" and not os.environ.get("MGL_PROTEIN_INT32")
 if shared:
-    ds = protein.DatabaseSearch(db, db_off, queries, dev, args.stride, workspace_bytes=int(args.workspace_gib * (1 << 30)))
+    ds = protein.DatabaseSearch(db, db_off, queries, dev, args.stride)
     run_pass = lambda: ds.run(a, code, mat, 11, 1, score_only=args.score_only)
     batches = ds.batches()
     where = ds.where

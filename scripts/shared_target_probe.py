@@ -27,7 +27,7 @@ for k in range(0, Q, 5):
         frag[mut] = protein.random_proteins(rng, 1, int(mut.sum()))[0]
         queries[k] = frag
 dev = torch.device("cuda", 0)
-ds = protein.DatabaseSearch(db, db_off, queries, dev, workspace_bytes=int(WS * (1 << 30)))
+ds = protein.DatabaseSearch(db, db_off, queries, dev)
 print(f'shared-target tiles up to {ds.shared_max_tl} residues; longer targets: {0 if ds.long is None else ds.long.n} pairs through the packed kernel', flush=True)
 a = sw.MicrosoftSmithWaterman(0)
 a.set_workspace(int(WS * (1 << 30)))
