@@ -38,7 +38,7 @@ P="python3 scripts/pairhmm_bench.py --no-cpu --steps 1"
 run pairhmm_trace --kernel-trace --stats $PM -d $O/pairhmm_trace -- $P
 run pairhmm_sq --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES $PM -d $O/pairhmm_sq -- $P
 run pairhmm_lds --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS $PM -d $O/pairhmm_lds -- $P
-# ---- protein (configs[4] shape): one pass of 2 M alignments, sw_dp16_matrix_kernel + sw_traceback_kernel (the review's item 5: counters of the shipped kernel)
+# ---- protein (configs[4] shape): one pass of 2 M alignments in the shared-target layout: sw_dp16_lane_matrix_kernel (1.92 M pairs) + sw_dp16_matrix_kernel + sw_traceback_kernel (80 000)
 Q="python3 scripts/protein_bench.py --steps 1 --check 0"
 run prot_trace --kernel-trace --stats $PM -d $O/prot_trace -- $Q
 run prot_sq --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES $PM -d $O/prot_sq -- $Q
