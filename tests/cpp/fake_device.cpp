@@ -145,6 +145,7 @@ hipError_t launch_dp16_lane(const DpArgs &a, const TbArgs &w, int, hipStream_t)
 bool lane16_matrix_params_ok(int, int, int, int) { return false; }
 int lane16_matrix_lds_bytes(int) { return 0; }
 hipError_t launch_dp16_lane_matrix(const DpArgs &, const TbArgs &, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t launch_tile_geometry(const SeqSet &, const SeqSet &, int64_t, int64_t, int32_t *, hipStream_t) { return hipErrorInvalidValue; }
 // ---- the persistent grid of sw_dp16_lane_ck.hip, protocol for protocol.  Device resident (no gate): done before the launch returns.
 // With a gate (the DIRECT form of the host entries: the grid is launched FIRST and its inputs arrive beside it) the grid is a THREAD
 // that goes through the waves' own loop -- wait at the gate for the tile's pairs and the next tile's, leave on a negative gate, give
