@@ -2335,7 +2335,16 @@ int mgl_sw_unregister_host_buffer(mgl_sw_ctx *ctx, void *ptr)
         if (ctx->registered[i].first == static_cast<const char *>(ptr)) {
             HIP_TRY(ctx, hipSetDevice(ctx->device));
             drain_streams(ctx, ctx->stream); // no copy of a finished call may still be in flight
-            (void)hipHostUnregister(ptr);
+            // (a registration the runtime does NOT let go of must not be forgotten here: it would outlive the caller's array, and whatever
+            // the allocator puts at that address next would look page-locked to the runtime -- round 5's intermittent fault, DESIGN.md 10,
+            // is of that kind as far as it is understood)
+            hipError_t e = hipHostUnregister(ptr);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipDeviceSynchronize();
+                e = hipHostUnregister(ptr);
+            }
+            if (e != hipSuccess) return fail(ctx, MGL_SW_ERR_DEVICE, std::string("hipHostUnregister: ") + hipGetErrorString(e));
             ctx->registered.erase(ctx->registered.begin() + (long)i);
             return MGL_SW_OK;
         }
