@@ -72,3 +72,41 @@ def test_bam_golden_suite_matches_fixture_inputs():
     assert [(g.t, g.q) for g in rows if g.suite == "bam"] == list(zip(ts, qs))
     ts, qs, _ = formats.bam_pairs(BAM, window=256)
     assert [(g.t, g.q) for g in rows if g.suite == "bamwin"] == list(zip(ts, qs))
+
+
+def test_database_search_layout_on_the_host():
+    """mgl_amd.protein.DatabaseSearch (no GPU: CPU tensors): the tiles of `shared` are aligned blocks of 128 pairs with ONE target and one
+    query length, longest database sequence first; `rest` holds the queries beyond whole tiles in blocks of eight of one geometry; `long`
+    the sequences beyond shared_max_tl; where() is a bijection onto the three batches' pairs and names the right (target, query)."""
+    import torch
+
+    from mgl_amd import protein
+
+    rng = np.random.default_rng(3)
+    lens = rng.integers(5, 900, 37)
+    db_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    db = protein.random_proteins(rng, 1, int(db_off[-1]))[0]
+    Q, QL = 272, 33                       # two whole tiles + 16 queries per database sequence
+    queries = protein.random_proteins(rng, Q, QL)
+    ds = protein.DatabaseSearch(db, db_off, queries, torch.device("cpu"), shared_max_tl=600)
+    n_long = int((lens > 600).sum())
+    assert ds.Qs == 256 and ds.Qr == 16 and ds.shared.n == (37 - n_long) * 256 and ds.rest.n == (37 - n_long) * 16 and ds.long.n == n_long * Q
+    t_off, t_len, q_len = ds.shared.t_off.numpy().reshape(-1, 128), ds.shared.t_len.numpy().reshape(-1, 128), ds.shared.q_len.numpy().reshape(-1, 128)
+    assert (t_off == t_off[:, :1]).all() and (t_len == t_len[:, :1]).all() and (q_len == QL).all()      # the promise of MGL_SW_FLAG_SHARED_TARGET
+    assert (np.diff(t_len[:, 0]) <= 0).all() and t_len.max() <= 600                                   # longest first, nothing beyond the bound
+    r_len = ds.rest.t_len.numpy().reshape(-1, 8)
+    assert (r_len == r_len[:, :1]).all()                                                                # blocks of eight of one geometry
+    seen = set()
+    for d in range(37):
+        for q in (0, 1, 127, 128, 255, 256, 271):
+            b, p = ds.where(d, q)
+            assert (id(b), p) not in seen
+            seen.add((id(b), p))
+            assert int(b.t_off[p]) == db_off[d] and int(b.t_len[p]) == lens[d] and int(b.q_off[p]) == q * QL and int(b.q_len[p]) == QL
+            assert (b is ds.long) == (lens[d] > 600) and (b is ds.rest) == (lens[d] <= 600 and q >= 256)
+    # by default nothing is sent to `long`; a workspace bound sends what would not get a region of its own length on every slot
+    assert protein.DatabaseSearch(db, db_off, queries, torch.device("cpu")).long is None
+    small = protein.DatabaseSearch(db, db_off, queries, torch.device("cpu"), workspace_bytes=protein.shared_target_region_bytes(320, QL) * 3072)
+    bound = protein.shared_target_region_bytes(320, QL)
+    assert protein.shared_target_region_bytes(small.shared_max_tl, QL) <= bound < protein.shared_target_region_bytes(small.shared_max_tl + 32, QL)
+    assert small.long.n == int((lens > small.shared_max_tl).sum()) * Q

@@ -220,6 +220,13 @@ def test_tiles_that_share_their_target_bit_exact(monkeypatch):
         torch.cuda.synchronize()
         assert a.fill_kernel_name(a.timing()) == "sw_dp16_lane_matrix_kernel"
         assert (b.scores.cpu().numpy() == sc).all() and int(b.offsets.abs().sum()) == 0 and int(b.cigar_len.abs().sum()) == 0 and int((b.status != 0).sum()) == 0
+        # MGL_SW_FLAG_BINARY_CIGAR: BAM-style uint32 elements, the same elements in the same order as the text
+        protein.run_matrix(b, a, code, mat, o, e, strategy, shared_target=True, binary_cigar=True)
+        torch.cuda.synchronize()
+        raw, ln = b.cigars.cpu().numpy(), b.cigar_len.cpu().numpy()
+        for k in range(0, len(cg), 37):
+            el = np.frombuffer(raw[k, : ln[k]].tobytes(), dtype="<u4")
+            assert "".join(f"{int(v) >> 4}{'MIDNS'[int(v) & 15]}" for v in el) == cg[k]
         a.check()
     # gap penalties under which an entry S + e + o is negative: the byte table cannot hold them, the batch takes the packed kernel
     ts, qs = _tiles(rng, shapes[3:9], 128)
