@@ -1563,6 +1563,11 @@ void mgl_sw_ctx_destroy(mgl_sw_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
+    // EVERY stream of the context is idle before it is destroyed (round 5): the copy streams have moved pageable arrays of the caller's,
+    // which the runtime page-locks for the time of the copy and lets go of when the queue is next found idle -- a queue that is
+    // destroyed first must not take such a pin with it (the intermittent fault, as far as it is understood)
+    for (hipStream_t st : {ctx->h2d, ctx->d2h, ctx->h2d_hi, ctx->d2h_hi, ctx->fill2})
+        if (st) (void)hipStreamSynchronize(st);
     // the caller's arrays this context page-locked (mgl_sw_register_host_buffer) and the caller never unregistered: every stream that may
     // still copy from or into them is drained first; left registered they would stay pinned, and a later context registering the same array
     // would be refused (hipErrorHostMemoryAlreadyRegistered)
@@ -2320,8 +2325,17 @@ int mgl_sw_register_host_buffer(mgl_sw_ctx *ctx, void *ptr, size_t bytes)
     if (!ctx || !ptr || bytes == 0) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (ctx->is_registered(ptr, bytes)) return MGL_SW_OK;
+    {   // already on this context's list: nothing to do.  (What the RUNTIME reports about the address is not asked here: it also knows
+        // pins of its own, taken for the time of somebody's pageable copy, and those do not last.)
+        const char *c = static_cast<const char *>(ptr);
+        for (const auto &r : ctx->registered)
+            if (c >= r.first && c + bytes <= r.first + r.second) return MGL_SW_OK;
+    }
     const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (e == hipErrorHostMemoryAlreadyRegistered) { // page-locked by the caller's own means: usable as it is, not this context's to undo
+        (void)hipGetLastError();
+        return MGL_SW_OK;
+    }
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? MGL_SW_ERR_NOMEM : MGL_SW_ERR_DEVICE, std::string("hipHostRegister: ") + hipGetErrorString(e));
     ctx->registered.emplace_back(static_cast<const char *>(ptr), bytes);
     return MGL_SW_OK;
