@@ -197,6 +197,9 @@ def secondary_workloads():
         # >= 30 s, with a roofline object and a CPU figure (the restatement's matrix extension: there is no reference path to time)
         "protein_blosum62 (configs[4] shape, 2 M alignments per pass, >= 30 s, no reference path: parity unpinned)": ["scripts/protein_bench.py", "--steps", "2", "--seconds", "30", "--check", "50", "--workspace-gib", "64",
                                                                                                              "--cpu-seconds", "10", "--json"],
+        # ... and its pre-filter mode (MGL_SW_FLAG_SCORE_ONLY: all six ScoreMax fields, no CIGAR), the same subset for >= 10 s
+        "protein_blosum62_score_only (the same 2 M alignments per pass, scores only, >= 10 s)": ["scripts/protein_bench.py", "--steps", "2", "--seconds", "10", "--check", "50", "--workspace-gib", "64",
+                                                                                                "--score-only", "--json"],
     }
     for name, cmd in runs.items():
         try:

@@ -170,6 +170,8 @@ if args.json:
                 "gathering out of a 2 KB table); nine waves per CU (12 B of LDS per query residue and group of two pairs); WRITE_SIZE 105 GB per pass = 0.87-1.06 TB/s.  "
                 "Neither pipe is full: the launches were -- 3 379 waves on 2 304 slots ran 1.47 rounds in the time of two; whole rounds per chunk and a 64 GiB "
                 "workspace: 1 684 -> 2 079 GCUPS")
+    if args.score_only:
+        note = "MGL_SW_FLAG_SCORE_ONLY: all six ScoreMax fields, no flags formed or stored, no regions, no walk (7 VALU instructions per two-cell step in the shared-target kernel).  " + note
     out = {"gcups": round(cells / dt / 1e9, 1), "pairs_per_pass": int(n), "alignments_per_s": round(n / dt, 1), "ms_per_pass": round(dt * 1e3, 3), "passes": steps,
            "seconds": round(total_s, 1), "kernel": kernels, "layout": args.layout if shared or args.layout == "grouped" else "grouped", "workspace_gib": args.workspace_gib,
            "kernel_ms": {"fill": round(tm.dp_ms, 3), "traceback": round(tm.tb_ms, 3), "launches": int(tm.dp_launches)},
