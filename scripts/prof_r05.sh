@@ -2,7 +2,7 @@
 # round 5 evidence on the SHIPPED build (run on the GPU box from the repo root): kernel trace + PMC passes of the headline kernel at
 # 256 x 150 and 1000 x 150, LDS-conflict and traffic passes of the long-read walk, the one-wave-per-pair kernel and PairHMM, and the
 # kernel + copy timeline of the packed host entry.  Counter passes never share a run with a trace domain.
-#   bash scripts/prof_r04.sh NAME
+#   bash scripts/prof_r05.sh NAME
 NAME=${1:-r05_prof}; R=$PWD; O=$R/gpurun_out/$NAME; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $R
 run() { # label, then the rocprofv3 arguments up to --, then the program
