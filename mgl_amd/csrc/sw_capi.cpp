@@ -2325,8 +2325,8 @@ int mgl_sw_register_host_buffer(mgl_sw_ctx *ctx, void *ptr, size_t bytes)
     if (!ctx || !ptr || bytes == 0) return MGL_SW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    {   // already on this context's list: nothing to do.  (What the RUNTIME reports about the address is not asked here: it also knows
-        // pins of its own, taken for the time of somebody's pageable copy, and those do not last.)
+    {   // already on this context's list: nothing to do.  (What the RUNTIME reports about the address is not asked here: registration is
+        // this context's own bookkeeping, and what it registers it unregisters.)
         const char *c = static_cast<const char *>(ptr);
         for (const auto &r : ctx->registered)
             if (c >= r.first && c + bytes <= r.first + r.second) return MGL_SW_OK;
